@@ -1,0 +1,192 @@
+"""Deterministic synthetic scenes for parity tests and the bench.
+
+Everything here is integer hashing plus IEEE add/mul (no libm, no BLAS, no torch RNG stream), so the
+build container, the GPU box and the golden-capture script all regenerate bit-identical weights and
+rays from a seed.  The scene statistics follow SURVEY.md section 8(d): low-frequency random fields so
+that rays actually terminate (default 0.1*randn init gives acc ~0.13, useless as a test).
+
+Shapes/keys follow the reference state_dict (models/EgoNeRF.py:102-122, models/tensorBase.py:54-66):
+  {density,app}_{plane,line}_{yin,yang}.{0,1,2}, basis_mat_{yin,yang}.weight, renderModule.mlp.{0,2,4}.{weight,bias}
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Dict, List, Sequence, Tuple
+
+import numpy as np
+
+_M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def _mix64(x: np.ndarray) -> np.ndarray:
+    """splitmix64 finaliser on a uint64 array (wrapping arithmetic)."""
+    x = x.astype(np.uint64, copy=True)
+    x ^= x >> np.uint64(30)
+    x *= np.uint64(0xBF58476D1CE4E5B9)
+    x ^= x >> np.uint64(27)
+    x *= np.uint64(0x94D049BB133111EB)
+    x ^= x >> np.uint64(31)
+    return x
+
+
+def hash_uniform(seed: int, stream: int, n: int) -> np.ndarray:
+    """n uniforms in [0,1) with 24-bit granularity (exact in fp32), float64 array."""
+    idx = np.arange(n, dtype=np.uint64)
+    key = np.uint64((seed * 0x9E3779B97F4A7C15 + stream * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF)
+    with np.errstate(over="ignore"):
+        x = _mix64(idx * np.uint64(0x2545F4914F6CDD1D) + key)
+    return (x >> np.uint64(40)).astype(np.float64) * (1.0 / 16777216.0)
+
+
+def hash_normal(seed: int, stream: int, n: int) -> np.ndarray:
+    """Approximate N(0,1): Irwin-Hall sum of 4 uniforms, rescaled (variance 4/12 -> 1). No libm."""
+    s = np.zeros(n, dtype=np.float64)
+    for k in range(4):
+        s += hash_uniform(seed, stream * 4 + k + 1000003, n)
+    return (s - 2.0) * 1.7320508075688772  # sqrt(3)
+
+
+def _lerp_axis(a: np.ndarray, n_out: int, axis: int) -> np.ndarray:
+    """Linear resize along one axis with align_corners=True semantics, explicit gathers only."""
+    n_in = a.shape[axis]
+    if n_in == n_out:
+        return a
+    if n_out == 1:
+        return np.take(a, [0], axis=axis)
+    pos = np.arange(n_out, dtype=np.float64) * ((n_in - 1) / (n_out - 1))
+    i0 = np.minimum(np.floor(pos).astype(np.int64), n_in - 2) if n_in > 1 else np.zeros(n_out, np.int64)
+    f = pos - i0
+    lo = np.take(a, i0, axis=axis)
+    hi = np.take(a, np.minimum(i0 + 1, n_in - 1), axis=axis)
+    shape = [1] * a.ndim
+    shape[axis] = n_out
+    f = f.reshape(shape)
+    return lo * (1.0 - f) + hi * f
+
+
+def smooth_field(seed: int, stream: int, C: int, H: int, W: int, lattice: int = 12) -> np.ndarray:
+    """(C,H,W) float64: min(lattice,H) x min(lattice,W) N(0,1) lattice, bilinearly up-sampled."""
+    lh, lw = min(lattice, H), min(lattice, W)
+    base = hash_normal(seed, stream, C * lh * lw).reshape(C, lh, lw)
+    return _lerp_axis(_lerp_axis(base, H, 1), W, 2)
+
+
+MAT_MODE = ((0, 1), (0, 2), (1, 2))  # models/EgoNeRF.py:30
+VEC_MODE = (2, 1, 0)  # models/EgoNeRF.py:31
+
+
+def n_to_reso(n_voxels: float) -> List[int]:
+    """Yin-yang grid resolution rule (models/coordinates.py:507-520); keeps Python's inexact pow(x,1/3)."""
+    n_r = int(pow(n_voxels, 1 / 3) / 2)
+    n_t = int(n_r * 2 * math.sqrt(3) / 3)
+    n_p = n_t * 3
+    up = lambda v: v + 1 if v % 2 else v
+    return [up(n_r), up(n_t), up(n_p)]
+
+
+@dataclass
+class SceneConfig:
+    """Resolved scene scalars; defaults = OmniBlender indoor / barbershop."""
+    n_voxel: float = 27_000_000
+    near: float = 0.01
+    far: float = 15.0
+    r0: float = 0.03
+    traj_radius: float = 0.5
+    density_shift: float = -8.0
+    distance_scale: float = 25.0
+    density_n_comp: Tuple[int, int, int] = (16, 16, 16)
+    app_n_comp: Tuple[int, int, int] = (48, 48, 48)
+    app_dim: int = 27
+    view_pe: int = 2
+    fea_pe: int = 2
+    featureC: int = 128
+    use_envmap: bool = False
+    envmap_res_H: int = 1000
+    grid: List[int] = field(default_factory=list)
+
+    def __post_init__(self):
+        if not self.grid:
+            self.grid = n_to_reso(self.n_voxel)
+
+    @property
+    def aabb(self) -> np.ndarray:
+        e = self.traj_radius + self.far  # dataLoader/dataset_omniblender.py:24-32
+        return np.array([[-e, -e, -e], [e, e, e]], dtype=np.float32)
+
+    @property
+    def in_mlpC(self) -> int:
+        return 2 * self.view_pe * 3 + 2 * self.fea_pe * self.app_dim + 3 + self.app_dim
+
+
+RICOH = dict(near=0.1, far=300.0, r0=0.05, density_shift=-10.0, use_envmap=True, envmap_res_H=1920)
+
+
+def table_shapes(cfg: SceneConfig, n_comp: Sequence[int]) -> Tuple[list, list]:
+    planes, lines = [], []
+    for i in range(3):
+        m0, m1 = MAT_MODE[i]
+        planes.append((1, n_comp[i], cfg.grid[m1], cfg.grid[m0]))
+        lines.append((1, n_comp[i], cfg.grid[VEC_MODE[i]], 1))
+    return planes, lines
+
+
+def make_weights(cfg: SceneConfig, seed: int = 1234, mlp_gain: float = 3.0) -> Dict[str, np.ndarray]:
+    """Reference-layout fp32 state dict with smooth-field tables and uniform-init linears."""
+    out: Dict[str, np.ndarray] = {}
+    stream = 0
+    for kind, n_comp, scale, white in (("density", cfg.density_n_comp, 0.9, 0.0), ("app", cfg.app_n_comp, 0.5, 0.1)):
+        planes, lines = table_shapes(cfg, n_comp)
+        for g in ("yin", "yang"):
+            for i in range(3):
+                for what, shp in (("plane", planes[i]), ("line", lines[i])):
+                    _, C, H, W = shp
+                    f = smooth_field(seed, stream, C, H, W) * scale
+                    if white:
+                        f = f + white * hash_normal(seed, stream + 5000, C * H * W).reshape(C, H, W)
+                    out[f"{kind}_{what}_{g}.{i}"] = f.reshape(shp).astype(np.float32)
+                    stream += 1
+
+    def linear(name: str, n_out: int, n_in: int, bias: bool, st: int, zero_bias: bool = False):
+        bound = 1.0 / math.sqrt(n_in)  # nn.Linear default init range
+        w = (hash_uniform(seed, st, n_out * n_in).reshape(n_out, n_in) * 2 - 1) * bound * mlp_gain
+        out[f"{name}.weight"] = w.astype(np.float32)
+        if bias:
+            b = np.zeros(n_out) if zero_bias else (hash_uniform(seed, st + 1, n_out) * 2 - 1) * bound
+            out[f"{name}.bias"] = b.astype(np.float32)
+
+    linear("basis_mat_yin", cfg.app_dim, sum(cfg.app_n_comp), False, 9000)
+    linear("basis_mat_yang", cfg.app_dim, sum(cfg.app_n_comp), False, 9010)
+    linear("renderModule.mlp.0", cfg.featureC, cfg.in_mlpC, True, 9020)
+    linear("renderModule.mlp.2", cfg.featureC, cfg.featureC, True, 9030)
+    linear("renderModule.mlp.4", 3, cfg.featureC, True, 9040, zero_bias=True)  # tensorBase.py:66
+    if cfg.use_envmap:
+        h = cfg.envmap_res_H
+        out["envmap.emission"] = (smooth_field(seed, 9100, 3, 2 * h, h, lattice=24) * 1.5).astype(np.float32)
+    return out
+
+
+def make_rays(n: int, seed: int = 1, origin_extent: float = 0.25) -> np.ndarray:
+    """[n,6] fp32: o ~ U(-e,e)^3, d = normalised approx-normal vector (sqrt is IEEE-exact)."""
+    o = (hash_uniform(seed, 1, n * 3).reshape(n, 3) * 2 - 1) * origin_extent
+    d = hash_normal(seed, 2, n * 3).reshape(n, 3)
+    nrm = np.sqrt((d * d).sum(-1, keepdims=True))
+    d = d / np.maximum(nrm, 1e-12)
+    return np.concatenate([o, d], -1).astype(np.float32)
+
+
+def erp_rays(H: int, W: int, row0: int = 0, row1: int | None = None, origin=(0.0, 0.0, 0.0)) -> np.ndarray:
+    """Equirectangular ray layout of dataLoader/ray_utils.py:24-40 (identity pose), rows [row0,row1).
+
+    Uses libm sin/cos (numpy float32, like the reference's torch float32), so these rays are
+    box-local inputs, not golden data.
+    """
+    row1 = H if row1 is None else row1
+    i = np.arange(W, dtype=np.float32)[None, :] + np.float32(0.5)
+    j = np.arange(row0, row1, dtype=np.float32)[:, None] + np.float32(0.5)
+    phi = (1 - 2 * i / W) * np.float32(np.pi)
+    theta = (1 - 2 * j / H) * np.float32(np.pi / 2)
+    d = np.stack(np.broadcast_arrays(-np.cos(theta) * np.sin(phi), np.sin(theta) * np.ones_like(phi),
+                                     -np.cos(theta) * np.cos(phi)), -1).reshape(-1, 3)
+    o = np.broadcast_to(np.asarray(origin, np.float32), d.shape)
+    return np.concatenate([o, d], -1).astype(np.float32)

@@ -1,0 +1,274 @@
+"""Golden-vector capture — runs ONLY in the build container (needs /root/reference, read-only).
+
+Imports the real reference with stub modules for its missing third-party imports,
+feeds it the deterministic synthetic scenes of egonerf_amd/synth.py and writes small .npz fixtures
+to tests/golden/.  Neither the reference nor any bytecode of it is copied anywhere; fixtures hold
+inputs (or seeds) and expected outputs only.
+
+    python oracle/capture_golden.py            # regenerate every fixture
+"""
+from __future__ import annotations
+
+import contextlib
+import io
+import os
+import sys
+import types
+
+sys.dont_write_bytecode = True
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+sys.path.insert(0, REPO)
+sys.path.insert(0, REF)
+
+import numpy as np
+import torch
+
+
+def _stub(name, **attrs):
+    m = types.ModuleType(name)
+    m.__dict__.update(attrs)
+    sys.modules[name] = m
+    return m
+
+
+_stub("kornia", create_meshgrid=lambda *a, **k: None)
+_stub("cv2", COLORMAP_JET=2)
+_tv = _stub("torchvision")
+_tv.transforms = _stub("torchvision.transforms")
+_stub("imageio")
+_stub("plyfile", PlyData=None, PlyElement=None)
+_sk = _stub("skimage")
+_sk.measure = _stub("skimage.measure")
+_stub("lpips")
+
+with contextlib.redirect_stdout(io.StringIO()):
+    from models.EgoNeRF import EgoNeRF, YinYangAlphaGridMask  # noqa: E402
+    from models.coordinates import YinYangSphericalCoords  # noqa: E402
+    from models.envmap import EnvironmentMap  # noqa: E402
+    from models.tensorBase import raw2alpha, positional_encoding  # noqa: E402
+    from dataLoader.ray_utils import sample_pdf  # noqa: E402
+    from renderer import volume_renderer  # noqa: E402
+    import sampler as ref_sampler  # noqa: E402
+
+from egonerf_amd import synth  # noqa: E402
+
+OUT = os.path.join(REPO, "tests", "golden")
+os.makedirs(OUT, exist_ok=True)
+
+
+def build_reference(cfg: synth.SceneConfig, weights):
+    aabb = torch.from_numpy(cfg.aabb)
+    with contextlib.redirect_stdout(io.StringIO()):
+        coords = YinYangSphericalCoords("cpu", aabb, exp_r=True, N_voxel=cfg.n_voxel, r0=cfg.r0, interval_th=True)
+        reso = coords.N_to_reso(cfg.n_voxel, aabb)
+        assert reso == cfg.grid, (reso, cfg.grid)
+        model = EgoNeRF(aabb, reso, "cpu", coords, density_n_comp=list(cfg.density_n_comp),
+                        appearance_n_comp=list(cfg.app_n_comp), app_dim=cfg.app_dim, near_far=[cfg.near, cfg.far],
+                        shadingMode="MLP_Fea", alphaMask_thres=1e-4, density_shift=cfg.density_shift,
+                        distance_scale=cfg.distance_scale, pos_pe=6, view_pe=cfg.view_pe, fea_pe=cfg.fea_pe,
+                        featureC=cfg.featureC, step_ratio=0.5, fea2denseAct="softplus", use_envmap=cfg.use_envmap,
+                        envmap_res_H=cfg.envmap_res_H, coarse_sigma_grid_update_rule="conv",
+                        coarse_sigma_grid_reso=None, interval_th=True)
+    sd = {k: torch.from_numpy(v) for k, v in weights.items() if k != "envmap.emission"}
+    model.load_state_dict(sd)
+    if cfg.use_envmap:
+        model.envmap.load_envmap(weights["envmap.emission"], device="cpu")
+    model.update_coarse_sigma_grid()
+    model.eval()
+    return model, coords
+
+
+class patched_rand:
+    """Make torch.rand_like / torch.rand return queued tensors (pins is_train noise)."""
+
+    def __init__(self, like_queue, rand_queue):
+        self.like_queue, self.rand_queue = list(like_queue), list(rand_queue)
+
+    def __enter__(self):
+        self._rl, self._r = torch.rand_like, torch.rand
+        torch.rand_like = lambda t, **k: self.like_queue.pop(0).to(t.dtype).reshape(t.shape)
+        torch.rand = lambda *a, **k: self.rand_queue.pop(0)
+        return self
+
+    def __exit__(self, *exc):
+        torch.rand_like, torch.rand = self._rl, self._r
+
+
+def run_forward(model, rays, **kw):
+    with contextlib.redirect_stdout(io.StringIO()):
+        return volume_renderer(rays, model, chunk=4096, exp_sampling=True, device="cpu", interval_th=True, **kw)
+
+
+def np_(t):
+    return None if t is None else t.detach().cpu().numpy()
+
+
+def capture_tiny():
+    """Tiny grid [10,10,30]: every intermediate of SURVEY 3.3, both resampling settings, train noise, envmap."""
+    cfg = synth.SceneConfig(n_voxel=20 ** 3)
+    weights = synth.make_weights(cfg, seed=1234)
+    model, coords = build_reference(cfg, weights)
+    rays = torch.from_numpy(synth.make_rays(64, seed=7))
+    fx = dict(seed_weights=1234, seed_rays=7, n_voxel=20 ** 3, grid=np.array(cfg.grid), rays=rays.numpy())
+
+    # --- stage vectors -------------------------------------------------------------------------
+    S = 24
+    xyz, z, _ = model.sample_ray_exp(rays[:, :3], rays[:, 3:6], is_train=False, N_samples=S)
+    c7 = coords.from_cartesian(xyz)
+    c7n = coords.normalize_coord(c7, downsample=2)
+    sf = model.compute_densityfeature(c7n)
+    sfc = model.compute_coarse_densityfeature(c7n)
+    sigma = model.feature2density(sf)
+    dists = torch.cat([z[:, 1:] - z[:, :-1], z[:, -1:] - z[:, -2:-1]], -1)
+    alpha, w, bgw = raw2alpha(sigma, dists * model.distance_scale)
+    af = model.compute_appfeature(c7n)
+    vd = rays[:, 3:6].view(-1, 1, 3).expand(xyz.shape)
+    rgb_s = model.renderModule(c7n, vd, af)
+    fx.update(st_xyz=np_(xyz), st_z=np_(z), st_c7=np_(c7), st_c7n=np_(c7n), st_sigma_feat=np_(sf),
+              st_sigma_feat_coarse=np_(sfc), st_sigma=np_(sigma), st_alpha=np_(alpha), st_weight=np_(w),
+              st_bg_weight=np_(bgw), st_app_feat=np_(af), st_rgb_samples=np_(rgb_s))
+
+    # random [M,7] incl. out-of-range coordinates (zero padding) for the lookup ops
+    M = 512
+    u = torch.from_numpy(synth.hash_uniform(99, 0, M * 7).reshape(M, 7).astype(np.float32))
+    q = u * 2.6 - 1.3
+    q[:, 6] = (u[:, 6] > 0.5).float()
+    fx.update(lk_coords=np_(q), lk_density=np_(model.compute_densityfeature(q)),
+              lk_density_coarse=np_(model.compute_coarse_densityfeature(q)), lk_app=np_(model.compute_appfeature(q)))
+
+    # --- end-to-end, eval ------------------------------------------------------------------------
+    o = run_forward(model, rays, n_coarse=24, n_fine=0, resampling=False)
+    fx.update(e2e_nr_rgb=np_(o[0]), e2e_nr_depth=np_(o[1]), e2e_nr_alpha=np_(o[4]))
+    o = run_forward(model, rays, n_coarse=16, n_fine=16, resampling=True, use_coarse_sample=True)
+    fx.update(e2e_rs_rgb=np_(o[0]), e2e_rs_depth=np_(o[1]), e2e_rs_alpha=np_(o[4]))
+    o = run_forward(model, rays, n_coarse=16, n_fine=16, resampling=True, use_coarse_sample=False)
+    fx.update(e2e_rsf_rgb=np_(o[0]), e2e_rsf_depth=np_(o[1]))
+
+    # --- end-to-end, train noise pinned ------------------------------------------------------------
+    jit = torch.from_numpy(synth.hash_uniform(5, 0, 64 * 16).reshape(64, 16).astype(np.float32))
+    uu = torch.from_numpy(synth.hash_uniform(5, 1, 64 * 16).reshape(64, 16).astype(np.float32))
+    with patched_rand([jit], [uu]):
+        o = run_forward(model, rays, n_coarse=16, n_fine=16, resampling=True, use_coarse_sample=True, is_train=True)
+    fx.update(tr_jitter=np_(jit), tr_u=np_(uu), tr_rgb=np_(o[0]), tr_depth=np_(o[1]))
+
+    # --- backward: MSE grads wrt every parameter (config 4 oracle) -----------------------------------
+    gt = torch.from_numpy(synth.hash_uniform(6, 0, 64 * 3).reshape(64, 3).astype(np.float32))
+    model.zero_grad()
+    with patched_rand([jit], [uu]):
+        o = run_forward(model, rays, n_coarse=16, n_fine=16, resampling=True, use_coarse_sample=True, is_train=True)
+    loss = torch.mean((o[0] - gt) ** 2)
+    loss.backward()
+    fx.update(bw_gt=np_(gt), bw_loss=np.float32(loss.item()))
+    for k, p in model.named_parameters():
+        fx["bw_grad/" + k] = np_(p.grad if p.grad is not None else torch.zeros_like(p))
+    np.savez_compressed(os.path.join(OUT, "tiny.npz"), **fx)
+
+    # --- envmap variant -----------------------------------------------------------------------------
+    cfg_e = synth.SceneConfig(n_voxel=20 ** 3, use_envmap=True, envmap_res_H=16)
+    w_e = synth.make_weights(cfg_e, seed=1234)
+    model_e, _ = build_reference(cfg_e, w_e)
+    o = run_forward(model_e, rays, n_coarse=24, n_fine=0, resampling=False)
+    rad = model_e.envmap.get_radiance(rays[:, 3:6])
+    np.savez_compressed(os.path.join(OUT, "tiny_envmap.npz"), rays=rays.numpy(), seed_weights=1234, envmap_res_H=16,
+                        rgb=np_(o[0]), depth=np_(o[1]), bg=np_(o[2]), env=np_(o[3]), alpha=np_(o[4]), radiance=np_(rad))
+
+
+def capture_stages():
+    """Scene-independent known answers: schedules, r normalisation, borders, sample_pdf, samplers."""
+    fx = {}
+    for name, (near, far, r0) in dict(indoor=(0.01, 15.0, 0.03), ricoh=(0.1, 300.0, 0.05), mid=(0.01, 50.0, 0.05)).items():
+        cfg = synth.SceneConfig(n_voxel=20 ** 3, near=near, far=far, r0=r0)
+        model, coords = build_reference(cfg, synth.make_weights(cfg, seed=3))
+        o = torch.zeros(1, 3)
+        d = torch.tensor([[0.0, 0.0, 1.0]])
+        for S in (32, 64, 128, 256, 512):
+            _, z, _ = model.sample_ray_exp(o, d, is_train=False, N_samples=S)
+            fx[f"sched/{name}/{S}"] = np_(z[0])
+    # r normalisation sweep on the full-resolution grid (N_r=150, far_r=26.85) and the tiny one
+    for name, nv in (("full", 27_000_000), ("tiny", 20 ** 3)):
+        cfg = synth.SceneConfig(n_voxel=nv)
+        aabb = torch.from_numpy(cfg.aabb)
+        with contextlib.redirect_stdout(io.StringIO()):
+            coords = YinYangSphericalCoords("cpu", aabb, exp_r=True, N_voxel=nv, r0=cfg.r0, interval_th=True)
+        r = torch.cat([torch.linspace(0, 0.2, 257), torch.linspace(0.2, 30.0, 1025),
+                       torch.from_numpy((synth.hash_uniform(11, 0, 512) * 27).astype(np.float32))])
+        fx[f"normr/{name}/r"] = np_(r)
+        fx[f"normr/{name}/out"] = np_(coords.normalize_r(r))
+        fx[f"normr/{name}/far_r"] = np_(coords.far[0])
+        # from_cartesian + normalize_coord at r=0, poles, region borders and random points
+        pts = [[0, 0, 0], [0, 0, 1], [0, 0, -1], [1, 0, 0], [-1, 0, 0], [0, 1, 0], [0, -1, 0], [1, 1, 0], [-1, 1e-3, 0],
+               [-1, -1e-3, 0], [1, 0, 1], [1, 0, -1], [-1, 1, 0], [-1, -1, 0], [0.3, -0.2, 5], [7, 8, -9], [20, 20, 20]]
+        rnd = (synth.hash_uniform(12, 0, 300).reshape(100, 3) * 2 - 1) * 16
+        P = torch.cat([torch.tensor(pts, dtype=torch.float32), torch.from_numpy(rnd.astype(np.float32))])
+        c7 = coords.from_cartesian(P)
+        fx[f"cart/{name}/xyz"] = np_(P)
+        fx[f"cart/{name}/c7"] = np_(c7)
+        fx[f"cart/{name}/c7n"] = np_(coords.normalize_coord(c7))
+    # sample_pdf eval + pinned-u train
+    bins = torch.sort(torch.from_numpy(synth.hash_uniform(13, 0, 8 * 31).reshape(8, 31).astype(np.float32)) * 10, -1)[0]
+    wts = torch.from_numpy((synth.hash_uniform(13, 1, 8 * 30).reshape(8, 30) ** 4).astype(np.float32))
+    wts[3] = 0
+    fx["pdf/bins"], fx["pdf/weights"] = np_(bins), np_(wts)
+    fx["pdf/eval32"] = np_(sample_pdf(bins, wts, 32, is_train=False))
+    uu = torch.from_numpy(synth.hash_uniform(13, 2, 8 * 20).reshape(8, 20).astype(np.float32))
+    with patched_rand([], [uu]):
+        fx["pdf/train20"] = np_(sample_pdf(bins, wts, 20, is_train=True))
+    fx["pdf/u"] = np_(uu)
+    # positional encoding
+    x = torch.from_numpy((synth.hash_uniform(14, 0, 5 * 4) * 2 - 1).reshape(5, 4).astype(np.float32))
+    fx["pe/x"], fx["pe/out"] = np_(x), np_(positional_encoding(x, 2))
+    # samplers (SURVEY 8c viii)
+    np.random.seed(20221028)
+    s = ref_sampler.SimpleSampler(10, 4)
+    fx["sampler/simple"] = np.stack([s.nextids().numpy() for _ in range(5)])
+    np.random.seed(20221028)
+    t = ref_sampler.ThetaImportanceSampler(5, 3, (8, 4), 6, [0, 1, 0, 1])
+    fx["sampler/theta_weight"] = t.weight
+    fx["sampler/theta_ids"] = np.asarray(t.nextids())
+    np.savez_compressed(os.path.join(OUT, "stages.npz"), **fx)
+
+
+def capture_full():
+    """Full barbershop grid [150,172,516]: seeds + outputs only (weights are regenerated by seed)."""
+    cfg = synth.SceneConfig()
+    weights = synth.make_weights(cfg, seed=1234)
+    model, _ = build_reference(cfg, weights)
+    rays = torch.from_numpy(synth.make_rays(256, seed=1))
+    fx = dict(seed_weights=1234, seed_rays=1, n_rays=256, grid=np.array(cfg.grid))
+    o = run_forward(model, rays, n_coarse=64, n_fine=0, resampling=False)
+    fx.update(nr64_rgb=np_(o[0]), nr64_depth=np_(o[1]), nr64_alpha=np_(o[4]))
+    o = run_forward(model, rays[:64], n_coarse=512, n_fine=0, resampling=False)
+    fx.update(nr512_rgb=np_(o[0]), nr512_depth=np_(o[1]))
+    o = run_forward(model, rays, n_coarse=32, n_fine=32, resampling=True, use_coarse_sample=True)
+    fx.update(rs32_rgb=np_(o[0]), rs32_depth=np_(o[1]))
+    o = run_forward(model, rays[:64], n_coarse=128, n_fine=128, resampling=True, use_coarse_sample=True)
+    fx.update(rs128_rgb=np_(o[0]), rs128_depth=np_(o[1]))
+    np.savez_compressed(os.path.join(OUT, "full.npz"), **fx)
+
+
+def capture_alpha_mask():
+    """Occupancy semantics: updateAlphaMask + sample_alpha on the tiny grid."""
+    import warnings
+    cfg = synth.SceneConfig(n_voxel=20 ** 3)
+    model, coords = build_reference(cfg, synth.make_weights(cfg, seed=1234))
+    with contextlib.redirect_stdout(io.StringIO()), warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        model.updateAlphaMask(tuple(cfg.grid))
+    am = model.alphaMask
+    M = 400
+    u = torch.from_numpy(synth.hash_uniform(21, 0, M * 7).reshape(M, 7).astype(np.float32))
+    q = u * 2.4 - 1.2
+    q[:, 6] = (u[:, 6] > 0.5).float()
+    np.savez_compressed(os.path.join(OUT, "alpha_mask.npz"), seed_weights=1234,
+                        step_size=np_(model.stepSize), vol_yin=np_(am.alpha_volume_yin).astype(np.uint8),
+                        vol_yang=np_(am.alpha_volume_yang).astype(np.uint8), coords=np_(q), sampled=np_(am.sample_alpha(q)))
+
+
+if __name__ == "__main__":
+    torch.manual_seed(0)
+    which = sys.argv[1:] or ["tiny", "stages", "full", "alpha_mask"]
+    for name in which:
+        globals()["capture_" + name]()
+        print("captured", name)
+    assert not os.path.exists(os.path.join(REF, "models", "__pycache__")), "bytecode leaked into the reference mount"

@@ -1,0 +1,332 @@
+"""ORACLE — TEST INFRASTRUCTURE ONLY.  CPU restatement of EgoNeRF's volume-rendering hot path.
+
+Only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may import this module.
+The product package (`egonerf_amd/`) never does: its hot path is the HIP library and it raises if
+that library is missing.
+
+Parity status: PINNED.  `oracle/capture_golden.py` imports the real reference (read-only, this
+container only) and writes `tests/golden/*.npz`; `tests/test_oracle_golden.py` checks every stage of
+this file against those vectors (per-stage intermediates on a tiny grid, outputs on the full grid).
+
+It deliberately keeps the reference's ATen op sequence (F.grid_sample on (1,C,H,W) tables, boolean
+mask gather/scatter per yin/yang grid, cat -> Linear, cumprod, searchsorted, sort), because it doubles
+as the "reference PyTorch CPU path" timed by bench.py (`cpu_baseline.kind == "port"`).
+`dtype=torch.float64` evaluates the same maths in double (LUTs stay float32-quantised like the
+reference's) and is used by tests to decide which of two fp32 answers is closer to the truth.
+
+Each function cites the reference lines it restates (paths relative to /root/reference).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+MAT_MODE = ((0, 1), (0, 2), (1, 2))  # models/EgoNeRF.py:30-33 (same for yin and yang)
+VEC_MODE = (2, 1, 0)
+GRIDS = ("yin", "yang")
+
+
+def linearised_exp_grid(r0: float, ratio, n: int) -> torch.Tensor:
+    """r[0]=0, r[i]=r0*ratio^(i-1) in float32, then every shell thinner than r0 is replaced by an
+    arithmetic run of step r0 and the tail shifted to stay continuous.
+
+    extra/test_exp_r.py:10-15 (index2r, hard float32) + models/EgoNeRF.py:71-76 (ratio = Python
+    float) / models/coordinates.py:118-124 (ratio = 0-dim float32 tensor).
+    """
+    idx = torch.arange(n)
+    r = torch.zeros(n, dtype=torch.float32)
+    if isinstance(ratio, torch.Tensor):
+        r[1:] = r0 * ratio ** (idx[1:] - 1)
+    else:
+        r[1:] = r0 * ratio ** (idx[1:].float() - 1)
+    step = r[1:] - r[:-1]
+    csum = torch.cumsum(step, 0)
+    n_lin = (step <= r0).sum()  # stays a 0-dim int64 tensor: r0 * n_lin must round in float32
+    r[: n_lin + 1] = torch.arange(n_lin + 1) * r0
+    r[n_lin + 1:] = r[n_lin + 1:] + r0 * n_lin - csum[n_lin - 1]
+    return r
+
+
+class OracleScene:
+    """Holds reference-layout weights + resolved scalars and evaluates the path on CPU."""
+
+    def __init__(self, cfg, weights: Dict[str, np.ndarray], dtype=torch.float32):
+        self.cfg = cfg
+        self.dtype = dtype
+        self.w = {k: torch.as_tensor(np.asarray(v)).to(dtype) for k, v in weights.items()}
+        self.grid = list(cfg.grid)
+        self.aabb = torch.as_tensor(cfg.aabb)
+        self.center = self.aabb.sum(0).div(2)  # coordinates.py:76
+        # coordinates.py:187-204 (_get_max_r) and :500-505 (update_aabb), float32 like the reference
+        lo, hi = self.aabb.tolist()
+        corners = torch.tensor([[lo[b] if (i >> b) & 1 else hi[b] for b in range(3)] for i in range(8)])
+        self.far_r = (corners - self.center).pow(2).sum(1).sqrt().amax()
+        pi = math.pi
+        self.ang_near = torch.tensor([pi / 4, -3 * pi / 4])
+        ang_far = torch.tensor([3 * pi / 4, 3 * pi / 4])
+        self.ang_inv = 1.0 / (ang_far - self.ang_near)
+        n_r = self.grid[0]
+        ratio = pow(self.far_r / cfg.r0, 1 / (n_r - 1))  # coordinates.py:117 (tensor pow)
+        self.r_lut = linearised_exp_grid(cfg.r0, ratio, n_r + 1)  # coordinates.py:118-124
+        self.coarse = None
+        self.update_coarse_sigma_grid()
+
+    # ---- parameters -------------------------------------------------------------------------
+    def table(self, kind: str, what: str, g: str, i: int) -> torch.Tensor:
+        return self.w[f"{kind}_{what}_{g}.{i}"]
+
+    def update_coarse_sigma_grid(self):
+        """2x average-pooled density tables (EgoNeRF.py:124-131)."""
+        self.coarse = {}
+        for g in GRIDS:
+            for i in range(3):
+                self.coarse[f"plane_{g}.{i}"] = F.avg_pool2d(self.table("density", "plane", g, i), 2, 2)
+                self.coarse[f"line_{g}.{i}"] = F.avg_pool1d(self.table("density", "line", g, i).squeeze(-1), 2, 2).unsqueeze(-1)
+
+    # ---- row A: sample schedule -------------------------------------------------------------
+    def sample_schedule(self, S: int) -> torch.Tensor:
+        """Radial offsets r[S] (float32) of EgoNeRF.sample_ray_exp, interval_th branch (EgoNeRF.py:69-76)."""
+        c = self.cfg
+        ratio = math.exp(math.log((c.far - c.near) / c.r0) / (S - 1))
+        return linearised_exp_grid(c.r0, ratio, S)
+
+    def sample_ray_exp(self, rays_o, rays_d, S: int, jitter: Optional[torch.Tensor] = None):
+        """EgoNeRF.py:56-87.  `jitter` [N,S] in [0,1) replaces torch.rand_like for is_train."""
+        r = self.sample_schedule(S).repeat(rays_d.shape[-2], 1)
+        if jitter is not None:
+            step = r[:, 1:] - r[:, :-1]
+            step = torch.cat([step, step[:, -1:]], -1)
+            r = r + step * jitter
+        z = (self.cfg.near + r).to(self.dtype)
+        xyz = rays_o[..., None, :] + rays_d[..., None, :] * z[..., None]
+        return xyz, z
+
+    # ---- row B: Cartesian -> yin-yang 7-vector ----------------------------------------------
+    def from_cartesian(self, xyz: torch.Tensor) -> torch.Tensor:
+        """coordinates.py:468-498: [r,th,ph,0,0,0,0] (yin) or [0,0,0,r,th_e,ph_e,1] (yang)."""
+        pi = math.pi
+        d = xyz - self.center.to(xyz.dtype)
+        r = d.pow(2).sum(-1).sqrt()
+        th_n = torch.acos(d[..., 2] / r).nan_to_num_()
+        ph_n = torch.atan2(d[..., 1], d[..., 0])
+        yin = (pi / 4 <= th_n) & (th_n <= 3 * pi / 4) & (-3 * pi / 4 <= ph_n) & (ph_n <= 3 * pi / 4)
+        th_e = torch.acos(d[..., 1] / r).nan_to_num_()
+        ph_e = torch.atan2(d[..., 2], -d[..., 0])
+        zero = torch.zeros_like(r)
+        as_yin = torch.stack([r, th_n, ph_n, zero, zero, zero, zero], -1)
+        as_yang = torch.stack([zero, zero, zero, r, th_e, ph_e, torch.ones_like(r)], -1)
+        return torch.where(yin[..., None], as_yin, as_yang)
+
+    # ---- row C: normalisation ----------------------------------------------------------------
+    def normalize_r(self, r: torch.Tensor) -> torch.Tensor:
+        """coordinates.py:110-131,156 (interval_th branch; `downsample` is ignored there)."""
+        G = self.r_lut.to(r.dtype)
+        n_r = self.grid[0]
+        k_out = torch.clamp(torch.searchsorted(G, r.contiguous(), side="right"), 1, G.shape[0] - 1)
+        k_in = k_out - 1
+        frac = (r - G[k_in]) / (G[k_out] - G[k_in])
+        return (k_in + frac) / n_r
+
+    def normalize_coord(self, c7: torch.Tensor) -> torch.Tensor:
+        """coordinates.py:442-466 (exp_r branch)."""
+        near = self.ang_near.to(c7.dtype)
+        inv = self.ang_inv.to(c7.dtype)
+        parts = []
+        for base in (0, 3):
+            parts.append((self.normalize_r(c7[..., base]) * 2 - 1).unsqueeze(-1))
+            parts.append((c7[..., base + 1: base + 3] - near) * inv * 2 - 1)
+        parts.append(c7[..., 6:7])
+        return torch.cat(parts, -1)
+
+    # ---- rows D, D', F: VM lookups -----------------------------------------------------------
+    @staticmethod
+    def _vm_taps(planes, lines, p3: torch.Tensor):
+        """Per plane/line pair: bilinear plane sample [C,M] and linear line sample [C,M]
+        (F.grid_sample, align_corners=True, zero padding; EgoNeRF.py:301-346)."""
+        outs = []
+        for i in range(3):
+            m0, m1 = MAT_MODE[i]
+            gp = torch.stack([p3[:, m0], p3[:, m1]], -1).view(1, -1, 1, 2)
+            gl = torch.stack([torch.zeros_like(p3[:, 0]), p3[:, VEC_MODE[i]]], -1).view(1, -1, 1, 2)
+            P = F.grid_sample(planes[i], gp, align_corners=True).view(planes[i].shape[1], -1)
+            L = F.grid_sample(lines[i], gl, align_corners=True).view(lines[i].shape[1], -1)
+            outs.append((P, L))
+        return outs
+
+    def density_feature(self, c7n: torch.Tensor, coarse: bool = False) -> torch.Tensor:
+        """EgoNeRF.py:291-347 (full-res) / :232-289 (pooled tables): sum_i relu(sum_c P_ic L_ic)."""
+        flat = c7n.reshape(-1, 7)
+        out = torch.zeros(flat.shape[0], dtype=flat.dtype)
+        is_yin = flat[:, -1] == 0
+        for g, sel, base in (("yin", is_yin, 0), ("yang", ~is_yin, 3)):
+            if not bool(sel.any()):
+                continue
+            p3 = flat[sel][:, base: base + 3]
+            if coarse:
+                planes = [self.coarse[f"plane_{g}.{i}"] for i in range(3)]
+                lines = [self.coarse[f"line_{g}.{i}"] for i in range(3)]
+            else:
+                planes = [self.table("density", "plane", g, i) for i in range(3)]
+                lines = [self.table("density", "line", g, i) for i in range(3)]
+            acc = torch.zeros(p3.shape[0], dtype=flat.dtype)
+            for P, L in self._vm_taps(planes, lines, p3):
+                acc = acc + F.relu((P * L).sum(0))
+            out[sel] = acc
+        return out.view(c7n.shape[:-1])
+
+    def app_feature(self, c7n: torch.Tensor) -> torch.Tensor:
+        """EgoNeRF.py:349-413: concat of 3x48 products -> per-grid Linear(144->27, no bias)."""
+        flat = c7n.reshape(-1, 7)
+        out = torch.zeros(flat.shape[0], self.cfg.app_dim, dtype=flat.dtype)
+        is_yin = flat[:, -1] == 0
+        for g, sel, base in (("yin", is_yin, 0), ("yang", ~is_yin, 3)):
+            if not bool(sel.any()):
+                continue
+            p3 = flat[sel][:, base: base + 3]
+            planes = [self.table("app", "plane", g, i) for i in range(3)]
+            lines = [self.table("app", "line", g, i) for i in range(3)]
+            taps = self._vm_taps(planes, lines, p3)
+            Pc = torch.cat([t[0] for t in taps])
+            Lc = torch.cat([t[1] for t in taps])
+            out[sel] = F.linear((Pc * Lc).T, self.w[f"basis_mat_{g}.weight"])
+        return out.view(*c7n.shape[:-1], self.cfg.app_dim)
+
+    # ---- row E ---------------------------------------------------------------------------------
+    def feature2density(self, f: torch.Tensor) -> torch.Tensor:
+        """tensorBase.py:415-419 (softplus, torch threshold 20)."""
+        return F.softplus(f + self.cfg.density_shift)
+
+    @staticmethod
+    def raw2alpha(sigma: torch.Tensor, dist: torch.Tensor):
+        """tensorBase.py:22-27."""
+        alpha = 1.0 - torch.exp(-sigma * dist)
+        T = torch.cumprod(torch.cat([torch.ones_like(alpha[:, :1]), 1.0 - alpha + 1e-10], -1), -1)
+        return alpha, alpha * T[:, :-1], T[:, -1:]
+
+    # ---- row G ---------------------------------------------------------------------------------
+    @staticmethod
+    def positional_encoding(x: torch.Tensor, n_freq: int) -> torch.Tensor:
+        """tensorBase.py:14-19: element-major / frequency-minor, all sines then all cosines."""
+        bands = (2 ** torch.arange(n_freq).float()).to(x.dtype)
+        p = (x[..., None] * bands).reshape(x.shape[:-1] + (n_freq * x.shape[-1],))
+        return torch.cat([torch.sin(p), torch.cos(p)], -1)
+
+    def mlp_fea(self, viewdirs: torch.Tensor, feat: torch.Tensor) -> torch.Tensor:
+        """MLPRender_Fea.forward (tensorBase.py:68-78); 150 -> 128 -> 128 -> 3, sigmoid."""
+        c = self.cfg
+        x = torch.cat([feat, viewdirs, self.positional_encoding(feat, c.fea_pe),
+                       self.positional_encoding(viewdirs, c.view_pe)], -1)
+        h = F.relu(F.linear(x, self.w["renderModule.mlp.0.weight"], self.w["renderModule.mlp.0.bias"]))
+        h = F.relu(F.linear(h, self.w["renderModule.mlp.2.weight"], self.w["renderModule.mlp.2.bias"]))
+        return torch.sigmoid(F.linear(h, self.w["renderModule.mlp.4.weight"], self.w["renderModule.mlp.4.bias"]))
+
+    # ---- row I ---------------------------------------------------------------------------------
+    @staticmethod
+    def sample_pdf(bins: torch.Tensor, weights: torch.Tensor, n: int, u: Optional[torch.Tensor] = None):
+        """dataLoader/ray_utils.py:156-187.  `u` [N,n] replaces torch.rand for is_train."""
+        w = weights + 1e-5
+        pdf = w / w.sum(-1, keepdim=True)
+        cdf = torch.cat([torch.zeros_like(pdf[..., :1]), torch.cumsum(pdf, -1)], -1)
+        if u is None:
+            u = torch.linspace(0.0, 1.0, steps=n, dtype=cdf.dtype).expand(list(cdf.shape[:-1]) + [n])
+        u = u.contiguous()
+        idx = torch.searchsorted(cdf.detach(), u, right=True)
+        lo = (idx - 1).clamp(min=0)
+        hi = idx.clamp(max=cdf.shape[-1] - 1)
+        c_lo, c_hi = torch.gather(cdf, -1, lo), torch.gather(cdf, -1, hi)
+        b_lo, b_hi = torch.gather(bins, -1, lo), torch.gather(bins, -1, hi)
+        den = c_hi - c_lo
+        den = torch.where(den < 1e-5, torch.ones_like(den), den)
+        return b_lo + (u - c_lo) / den * (b_hi - b_lo)
+
+    # ---- row J ---------------------------------------------------------------------------------
+    def envmap_radiance(self, dirs: torch.Tensor) -> torch.Tensor:
+        """models/envmap.py:6-14,26-34: u=(d_z+1)/2 on the h-wide axis, v=(atan2(d_y,d_x)+pi)/2pi."""
+        d = F.normalize(dirs, dim=-1)
+        u = (d[:, 2] + 1) * 0.5
+        v = (torch.atan2(d[:, 1], d[:, 0]) + math.pi) / (2 * math.pi)
+        uv = torch.stack([u, v], 1) * 2 - 1
+        em = self.w["envmap.emission"]
+        s = F.grid_sample(em[None], uv[None, :, None, :], align_corners=True)
+        return torch.sigmoid(s.permute(0, 2, 3, 1).reshape(-1, 3))
+
+    # ---- rows A..J assembled: EgoNeRF.forward ----------------------------------------------------
+    def forward(self, rays: torch.Tensor, n_coarse: int, n_fine: int = 0, resampling: bool = False,
+                use_coarse_sample: bool = True, is_train: bool = False,
+                jitter: Optional[torch.Tensor] = None, u: Optional[torch.Tensor] = None,
+                keep: bool = False):
+        """EgoNeRF.forward (EgoNeRF.py:491-602), exp_sampling + interval_th path.
+
+        Returns (rgb[N,3], depth[N], bg|None, env|None, alpha[N,S(+1)]) and, if keep, a dict of
+        intermediates.
+        """
+        rays = rays.to(self.dtype)
+        c = self.cfg
+        o, viewdirs = rays[:, :3], rays[:, 3:6]
+        if is_train and jitter is None:
+            jitter = torch.rand(rays.shape[0], n_coarse)
+        xyz, z = self.sample_ray_exp(o, viewdirs, n_coarse, jitter if is_train else None)
+        if not is_train:
+            z = z[0].repeat(xyz.shape[0], 1)  # EgoNeRF.py:515-516
+        dists = z[..., 1:] - z[..., :-1]
+        dists = torch.cat([dists, dists[..., -1:]], -1)
+        c7 = self.from_cartesian(xyz)
+        c7n = self.normalize_coord(c7)
+        inter = dict(z_coarse=z, c7=c7, c7n=c7n) if keep else None
+
+        if resampling:
+            sf = self.density_feature(c7n, coarse=True)
+            _, cw, _ = self.raw2alpha(self.feature2density(sf), dists * c.distance_scale)
+            z_mid = 0.5 * (z[..., 1:] + z[..., :-1])
+            if is_train and u is None:
+                u = torch.rand(rays.shape[0], n_fine)
+            z_new = self.sample_pdf(z_mid, cw[..., 1:-1], n_fine, u if is_train else None).detach()
+            if use_coarse_sample:
+                z, _ = torch.sort(torch.cat([z, z_new], -1), -1)
+            else:
+                z, _ = torch.sort(z_new, -1)
+            dists = z[..., 1:] - z[..., :-1]
+            dists = torch.cat([dists, dists[..., -1:]], -1)
+            xyz = o[:, None, :] + viewdirs[:, None, :] * z[..., None]
+            c7n = self.normalize_coord(self.from_cartesian(xyz))
+            if keep:
+                inter.update(coarse_sigma_feat=sf, coarse_weight=cw, z_new=z_new, z_fine=z)
+
+        sf = self.density_feature(c7n)
+        sigma = self.feature2density(sf)
+        alpha, weight, bg_w = self.raw2alpha(sigma, dists * c.distance_scale)
+        af = self.app_feature(c7n)
+        vd = viewdirs.view(-1, 1, 3).expand(xyz.shape)
+        rgb = self.mlp_fea(vd.reshape(-1, 3), af.reshape(-1, c.app_dim)).view(*xyz.shape[:2], 3)
+
+        acc = weight.sum(-1)
+        rgb_map = (weight[..., None] * rgb).sum(-2)
+        bg_map = env_map = None
+        if c.use_envmap:
+            alpha = torch.cat([alpha, torch.ones_like(alpha[..., :1])], -1)
+            env_map = self.envmap_radiance(viewdirs)
+            bg_map = bg_w * env_map
+            rgb_map = rgb_map + bg_map
+        rgb_map = rgb_map.clamp(0, 1)
+        depth = (weight * z).sum(-1) + (1.0 - acc) * rays[..., -1]  # EgoNeRF.py:598 (d_z quirk)
+        if keep:
+            inter.update(sigma_feat=sf, sigma=sigma, weight=weight, bg_weight=bg_w, app_feat=af,
+                         rgb_samples=rgb, z=z, acc=acc)
+            return (rgb_map, depth, bg_map, env_map, alpha), inter
+        return rgb_map, depth, bg_map, env_map, alpha
+
+
+def volume_render(scene: OracleScene, rays: torch.Tensor, chunk: int = 4096, **kw):
+    """Chunk loop of renderer.py:11-79 (torch outputs, no D2H variant)."""
+    outs = [scene.forward(rays[i:i + chunk], **kw) for i in range(0, rays.shape[0], chunk)]
+    cat = lambda j: None if outs[0][j] is None else torch.cat([o[j] for o in outs])
+    return cat(0), cat(1), cat(2), cat(3), cat(4)
+
+
+def psnr(img: torch.Tensor, gt: torch.Tensor) -> float:
+    """renderer.py:156-157."""
+    return float(-10.0 * np.log(torch.mean((img - gt) ** 2).item()) / np.log(10.0))
