@@ -1,0 +1,112 @@
+"""ctypes binding of include/egonerf_hip.h (the C ABI of libegonerf_hip.so).
+
+This is the only place the product touches native code.  There is no fallback: if the library is
+missing or a call fails, a RuntimeError is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import re
+from typing import List
+
+from .build import LIB
+
+c_float_p = C.POINTER(C.c_float)
+
+
+class VmField(C.Structure):
+    _fields_ = [("plane", (C.c_void_p * 3) * 2), ("line", (C.c_void_p * 3) * 2), ("n_comp", C.c_int32),
+                ("res", C.c_int32 * 3)]
+
+
+class Scene(C.Structure):
+    _fields_ = [
+        ("center", C.c_float * 3), ("ang_near", C.c_float * 2), ("ang_inv", C.c_float * 2),
+        ("r_lut", C.c_void_p), ("n_r_lut", C.c_int32), ("n_r", C.c_int32),
+        ("act_softplus", C.c_int32), ("density_shift", C.c_float), ("distance_scale", C.c_float),
+        ("density", VmField), ("density_coarse", VmField), ("app", VmField),
+        ("basis", C.c_void_p * 2), ("app_dim", C.c_int32),
+        ("mlp_w", C.c_void_p * 3), ("mlp_b", C.c_void_p * 3),
+        ("mlp_in", C.c_int32), ("mlp_hidden", C.c_int32), ("view_pe", C.c_int32), ("fea_pe", C.c_int32),
+        ("packed", C.c_void_p), ("envmap", C.c_void_p), ("envmap_h", C.c_int32), ("reserved", C.c_int32),
+    ]
+
+
+class RenderArgs(C.Structure):
+    _fields_ = [("n_coarse", C.c_int32), ("n_fine", C.c_int32), ("resampling", C.c_int32),
+                ("use_coarse_sample", C.c_int32), ("r_sched", C.c_void_p), ("jitter", C.c_void_p),
+                ("u", C.c_void_p), ("near_", C.c_float), ("reserved", C.c_int32)]
+
+
+P, I32, I64, F32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+SP = C.POINTER(Scene)
+
+# name -> (restype, argtypes); mirrors include/egonerf_hip.h one to one
+PROTOTYPES = {
+    "ego_abi_version": (C.c_int, []),
+    "ego_last_error": (C.c_char_p, []),
+    "ego_sizeof": (I64, [I32]),
+    "ego_packed_floats": (I64, []),
+    "ego_sample_ray_exp": (C.c_int, [P, P, P, F32, I64, I32, P, P, P]),
+    "ego_from_cartesian": (C.c_int, [SP, P, I64, P, P]),
+    "ego_normalize_coord": (C.c_int, [SP, P, I64, P, P]),
+    "ego_density_feature": (C.c_int, [SP, P, I64, I32, P, P]),
+    "ego_app_feature": (C.c_int, [SP, P, I64, P, P]),
+    "ego_feature2density": (C.c_int, [SP, P, I64, P, P]),
+    "ego_raw2alpha": (C.c_int, [P, P, I64, I32, P, P, P, P]),
+    "ego_mlp_fea": (C.c_int, [SP, P, P, I64, P, P]),
+    "ego_sample_pdf_merge": (C.c_int, [P, P, P, I64, I32, I32, I32, P, P, P]),
+    "ego_envmap_radiance": (C.c_int, [SP, P, I64, P, P]),
+    "ego_avgpool_table": (C.c_int, [P, I32, I32, I32, P, P]),
+    "ego_pack_mlp": (C.c_int, [SP, P, P]),
+    "ego_march_density": (C.c_int, [SP, P, I64, I32, P, P, P, F32, I32, P, P, I32, P, P, P]),
+    "ego_shade": (C.c_int, [SP, P, P, I64, I32, P, P]),
+    "ego_composite": (C.c_int, [SP, P, P, P, P, P, I64, I32, P, P, P, P, P]),
+    "ego_render_workspace_bytes": (I64, [I64, C.POINTER(RenderArgs)]),
+    "ego_render_forward": (C.c_int, [SP, C.POINTER(RenderArgs), P, I64, P, P, P, P, P, P, P]),
+}
+
+_lib = None
+
+
+def header_symbols() -> List[str]:
+    """Every function declared in include/egonerf_hip.h (used by the symbol-export test)."""
+    hdr = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "egonerf_hip.h")
+    text = re.sub(r"/\*.*?\*/", "", open(hdr).read(), flags=re.S)
+    return sorted(set(re.findall(r"\b(ego_[a-z0-9_]+)\s*\(", text)))
+
+
+def load() -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB):
+        raise RuntimeError(f"{LIB} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(the EgoNeRF hot path has no CPU fallback)")
+    lib = C.CDLL(LIB)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = res, args
+    for which, struct in ((0, Scene), (1, RenderArgs), (2, VmField)):
+        if lib.ego_sizeof(which) != C.sizeof(struct):
+            raise RuntimeError(f"ABI mismatch: struct {struct.__name__} is {C.sizeof(struct)} B here, "
+                               f"{lib.ego_sizeof(which)} B in {LIB}")
+    _lib = lib
+    return lib
+
+
+def check(code: int, what: str) -> None:
+    if code != 0:
+        msg = load().ego_last_error().decode(errors="replace")
+        raise RuntimeError(f"{what} failed (code {code}): {msg}")
+
+
+def ptr(t) -> int:
+    """Device pointer of a torch tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def stream_handle() -> int:
+    import torch
+    return torch.cuda.current_stream().cuda_stream

@@ -1,0 +1,147 @@
+"""Yin-yang spherical coordinates: host-side mirror of models/coordinates.py (YinYangSphericalCoords
+over GenericSphericalCoords) for the configuration every shipped EgoNeRF config uses
+(`coordinates = yinyang`, `exp_r`, `interval_th`; configs/EgoNeRF/common.txt:2,15).
+
+The host only builds the small float32 constants (centre, angular ranges, max radius, the
+linearised-exponential radius LUT and the sample schedule) with the same torch float32 operations the
+reference uses, so they are bit-identical; the per-point work (from_cartesian, normalize_coord) runs in
+libegonerf_hip.so.
+"""
+from __future__ import annotations
+
+from math import exp, log, pi, sqrt
+
+import torch
+
+from . import _lib
+
+
+def linearised_exp_grid(r0: float, ratio, n: int) -> torch.Tensor:
+    """Shell radii r[0]=0, r[i]=r0*ratio**(i-1), with every shell thinner than r0 replaced by an
+    arithmetic run of step r0 (tail shifted to stay continuous); float32 on the CPU.
+
+    Restates extra/test_exp_r.py:10-15 + models/EgoNeRF.py:71-76 (Python-float ratio) and
+    models/coordinates.py:117-124 (0-dim float32 tensor ratio).  The float32 roundings matter
+    (see tests/golden/stages.npz `sched/*`, `normr/*`), so dtype promotion is kept as in the reference:
+    r0 * n_lin is a float32 tensor product, not a Python double.
+    """
+    idx = torch.arange(n)
+    r = torch.zeros(n, dtype=torch.float32)
+    expo = (idx[1:] - 1) if isinstance(ratio, torch.Tensor) else (idx[1:].float() - 1)
+    r[1:] = r0 * ratio ** expo
+    step = r[1:] - r[:-1]
+    run = torch.cumsum(step, 0)
+    n_lin = (step <= r0).sum()  # 0-dim int64 tensor on purpose (float32 product below)
+    r[n_lin + 1:] = r[n_lin + 1:] + r0 * n_lin - run[n_lin - 1]
+    r[: n_lin + 1] = torch.arange(n_lin + 1) * r0
+    return r
+
+
+class YinYangSphericalCoords:
+    """[r_n, theta_n, phi_n, r_e, theta_e, phi_e, Y]: Y=0 yin grid, Y=1 yang grid (coordinates.py:432-438)."""
+
+    def __init__(self, device, aabb, exp_r=True, N_voxel=None, r0=None, interval_th=False):
+        self.device = device
+        aabb = torch.as_tensor(aabb, dtype=torch.float32).cpu()
+        self.aabb = aabb
+        self.center = aabb.sum(0).div(2)  # coordinates.py:76
+        self.exp_r = exp_r
+        self.interval_th = interval_th
+        self.update_aabb(aabb)
+        self.set_resolution(self.N_to_reso(N_voxel, aabb), r0=r0)
+
+    # -- constants ---------------------------------------------------------------------------------
+    def _get_max_r(self, aabb) -> torch.Tensor:
+        """Distance centre -> farthest aabb corner, float32 (coordinates.py:187-204)."""
+        lo, hi = torch.as_tensor(aabb).tolist()
+        corners = torch.tensor([[lo[b] if (i >> b) & 1 else hi[b] for b in range(3)] for i in range(8)])
+        return (corners - self.center).pow(2).sum(1).sqrt().amax()
+
+    def update_aabb(self, new_aabb):
+        """coordinates.py:500-505."""
+        max_r = self._get_max_r(new_aabb)
+        self.near = torch.tensor([0, pi / 4, -3 * pi / 4, 0, pi / 4, -3 * pi / 4])
+        self.far = torch.stack([max_r, torch.tensor(3 * pi / 4), torch.tensor(3 * pi / 4)] * 2)
+        self.inv_diff = 1.0 / (self.far - self.near)
+        self._lut_dev = None
+
+    def N_to_reso(self, n_voxels, bbox=None):
+        """coordinates.py:507-520 (keeps Python's inexact pow(x, 1/3): 27e6 -> N_r starts from 149)."""
+        n_r = int(pow(n_voxels, 1 / 3) / 2)
+        n_t = int(n_r * 2 * sqrt(3) / 3)
+        n_p = n_t * 3
+        even = lambda v: v + 1 if v % 2 else v
+        return [even(n_r), even(n_t), even(n_p)]
+
+    def set_resolution(self, resolution, r0=None):
+        """coordinates.py:206-215."""
+        self.N_r, self.N_theta, self.N_phi = resolution
+        self.resolution = list(resolution)
+        if self.exp_r:
+            self.r0 = r0 if r0 is not None else 0.05
+            self.ratio = pow(self.far[0] / self.r0, 1 / (self.N_r - 1))
+        self._lut_dev = None
+
+    def reference_r_grid(self) -> torch.Tensor:
+        """The [N_r+1] radius LUT the reference rebuilds on every normalize_r call (coordinates.py:116-124)."""
+        ratio = pow(self.far[0] / self.r0, 1 / (self.N_r - 1))
+        return linearised_exp_grid(self.r0, ratio, self.N_r + 1)
+
+    def sample_schedule(self, near: float, far: float, n_samples: int) -> torch.Tensor:
+        """Radial sample offsets r[S] of EgoNeRF.sample_ray_exp, interval_th branch (EgoNeRF.py:69-76)."""
+        ratio = exp(log((far - near) / self.r0) / (n_samples - 1))
+        return linearised_exp_grid(self.r0, ratio, n_samples)
+
+    def _require_supported(self):
+        if not (self.exp_r and self.interval_th):
+            raise NotImplementedError("the HIP path covers exp_r + interval_th coordinates (every shipped EgoNeRF config); "
+                                      "plain-exponential / uniform r grids are out of scope")
+
+    def lut_device(self, device) -> torch.Tensor:
+        if self._lut_dev is None or self._lut_dev.device != torch.device(device):
+            self._lut_dev = self.reference_r_grid().to(device)
+        return self._lut_dev
+
+    def fill_scene(self, sc: "_lib.Scene", device) -> None:
+        """Writes the coordinate block of the C-ABI scene struct."""
+        self._require_supported()
+        lut = self.lut_device(device)
+        sc.center[:] = self.center.tolist()
+        sc.ang_near[:] = self.near[1:3].tolist()
+        sc.ang_inv[:] = self.inv_diff[1:3].tolist()
+        sc.r_lut = lut.data_ptr()
+        sc.n_r_lut = lut.numel()
+        sc.n_r = self.N_r
+
+    def _scene(self, device):
+        sc = _lib.Scene()
+        self.fill_scene(sc, device)
+        return sc
+
+    # -- per-point ops (HIP) ---------------------------------------------------------------------------
+    def from_cartesian(self, xyz_points: torch.Tensor) -> torch.Tensor:
+        """[...,3] -> [...,7] (coordinates.py:468-498)."""
+        _require_cuda(xyz_points, "from_cartesian")
+        x = xyz_points.contiguous().float()
+        out = torch.empty(*x.shape[:-1], 7, device=x.device, dtype=torch.float32)
+        sc = self._scene(x.device)
+        _lib.check(_lib.load().ego_from_cartesian(sc, x.data_ptr(), x.numel() // 3, out.data_ptr(), _lib.stream_handle()),
+                   "ego_from_cartesian")
+        return out
+
+    def normalize_coord(self, unnormalized_coords: torch.Tensor, downsample=None) -> torch.Tensor:
+        """[...,7] -> [...,7] in [-1,1] (+flag) (coordinates.py:442-466).  `downsample` is accepted and
+        ignored, exactly like the reference's interval_th branch (coordinates.py:112-117)."""
+        _require_cuda(unnormalized_coords, "normalize_coord")
+        x = unnormalized_coords.contiguous().float()
+        out = torch.empty_like(x)
+        sc = self._scene(x.device)
+        _lib.check(_lib.load().ego_normalize_coord(sc, x.data_ptr(), x.numel() // 7, out.data_ptr(), _lib.stream_handle()),
+                   "ego_normalize_coord")
+        return out
+
+
+def _require_cuda(t: torch.Tensor, what: str) -> None:
+    if not t.is_cuda:
+        raise RuntimeError(f"{what}: tensor is on {t.device}; the EgoNeRF hot path runs only on the HIP device "
+                           "(there is no CPU fallback)")

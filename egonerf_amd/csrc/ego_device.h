@@ -1,0 +1,192 @@
+// Device helpers shared by every kernel of libegonerf_hip.so (gfx950 only, wave64).
+// Arithmetic follows the reference's ATen op sequence rounding-by-rounding where that is cheap
+// (explicit __f*_rn so the compiler does not contract into FMAs the CPU path does not use).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/egonerf_hip.h"
+
+#define EGO_WAVE 64
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ---------------------------------------------------------------------------------------------
+// POD copies of the scene that travel in kernel arguments (SGPR-resident, no pointer chasing).
+// ---------------------------------------------------------------------------------------------
+struct DevField {
+  const float* plane[2][3];
+  const float* line[2][3];
+  int32_t res[3];  // N_r, N_theta, N_phi
+};
+
+struct DevCoords {
+  float cx, cy, cz;
+  float th_near, ph_near, th_inv, ph_inv;
+  const float* r_lut;
+  int32_t n_lut;  // N_r + 1
+  int32_t n_r;
+};
+
+__host__ inline DevField make_field(const ego_vm_field& f) {
+  DevField d;
+  for (int g = 0; g < 2; ++g)
+    for (int i = 0; i < 3; ++i) {
+      d.plane[g][i] = f.plane[g][i];
+      d.line[g][i] = f.line[g][i];
+    }
+  for (int i = 0; i < 3; ++i) d.res[i] = f.res[i];
+  return d;
+}
+
+__host__ inline DevCoords make_coords(const ego_scene& s) {
+  DevCoords c;
+  c.cx = s.center[0]; c.cy = s.center[1]; c.cz = s.center[2];
+  c.th_near = s.ang_near[0]; c.ph_near = s.ang_near[1];
+  c.th_inv = s.ang_inv[0]; c.ph_inv = s.ang_inv[1];
+  c.r_lut = s.r_lut; c.n_lut = s.n_r_lut; c.n_r = s.n_r;
+  return c;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Row B: Cartesian -> (r, theta, phi, is_yang)   models/coordinates.py:468-498
+// ---------------------------------------------------------------------------------------------
+struct YinYang {
+  float r, th, ph;
+  int yang;
+};
+
+#define EGO_PI_4 0.78539816339744830962f       // float32(pi/4): thresholds compare in float32
+#define EGO_3PI_4 2.35619449019234492885f
+
+__device__ __forceinline__ float nan_to_zero(float v) { return (v != v) ? 0.0f : v; }
+
+__device__ __forceinline__ YinYang yinyang_from_xyz(float x, float y, float z, const DevCoords& c) {
+  const float dx = __fsub_rn(x, c.cx), dy = __fsub_rn(y, c.cy), dz = __fsub_rn(z, c.cz);
+  const float r = __fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz)));
+  const float th_n = nan_to_zero(acosf(__fdiv_rn(dz, r)));
+  const float ph_n = atan2f(dy, dx);
+  const bool yin = (EGO_PI_4 <= th_n) && (th_n <= EGO_3PI_4) && (-EGO_3PI_4 <= ph_n) && (ph_n <= EGO_3PI_4);
+  YinYang o;
+  o.r = r;
+  if (yin) {
+    o.th = th_n; o.ph = ph_n; o.yang = 0;
+  } else {
+    o.th = nan_to_zero(acosf(__fdiv_rn(dy, r)));
+    o.ph = atan2f(dz, -dx);
+    o.yang = 1;
+  }
+  return o;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Row C: normalisation   models/coordinates.py:442-466, :110-131, :156
+// `lut` may point to LDS or global memory.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float normalize_r(float r, const float* lut, int n_lut, int n_r) {
+  // searchsorted(side='right'): first index with lut[i] > r; NaN sorts last like torch.
+  int lo = 0, hi = n_lut;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (!(lut[mid] > r)) lo = mid + 1; else hi = mid;
+  }
+  int k_out = lo < 1 ? 1 : (lo > n_lut - 1 ? n_lut - 1 : lo);
+  const int k_in = k_out - 1;
+  const float g0 = lut[k_in], g1 = lut[k_out];
+  const float frac = __fdiv_rn(__fsub_rn(r, g0), __fsub_rn(g1, g0));
+  const float v = __fdiv_rn(__fadd_rn((float)k_in, frac), (float)n_r);
+  return __fsub_rn(__fmul_rn(v, 2.0f), 1.0f);
+}
+
+__device__ __forceinline__ float normalize_ang(float a, float near_, float inv) {
+  return __fsub_rn(__fmul_rn(__fmul_rn(__fsub_rn(a, near_), inv), 2.0f), 1.0f);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Bilinear / linear tap set-up with align_corners=True, zero padding (F.grid_sample semantics,
+// ATen GridSamplerKernel: ix = (x+1)*((W-1)/2); west weight = 1-fx).
+// ---------------------------------------------------------------------------------------------
+struct Lin1 {
+  int i0, i1;    // clamped indices (always addressable)
+  float w0, w1;  // weights with the out-of-range taps zeroed
+};
+
+__device__ __forceinline__ Lin1 lin_setup(float xhat, int n) {
+  Lin1 t;
+  const float ix = __fmul_rn(__fadd_rn(xhat, 1.0f), 0.5f * (float)(n - 1));
+  const float fl = floorf(ix);
+  const float f = __fsub_rn(ix, fl);
+  // ix may be NaN/huge for degenerate points: keep the int conversion defined and the taps masked
+  const float flc = fminf(fmaxf(fl, -2.0f), (float)n);
+  const int i0 = (int)flc, i1 = i0 + 1;
+  const bool ok = (ix == ix);
+  t.w0 = (ok && i0 >= 0 && i0 < n) ? __fsub_rn(1.0f, f) : 0.0f;
+  t.w1 = (ok && i1 >= 0 && i1 < n) ? f : 0.0f;
+  t.i0 = min(max(i0, 0), n - 1);
+  t.i1 = min(max(i1, 0), n - 1);
+  return t;
+}
+
+// The three (plane, line) lookups of one grid address these axes (matMode / vecMode, EgoNeRF.py:30-33):
+//   i=0: plane x=r (W=N_r), y=theta (H=N_theta); line = phi
+//   i=1: plane x=r,         y=phi   (H=N_phi);   line = theta
+//   i=2: plane x=theta (W=N_theta), y=phi;       line = r
+struct VMTaps {
+  Lin1 ax[3];  // per axis: 0 r, 1 theta, 2 phi
+};
+
+__device__ __forceinline__ VMTaps vm_setup(float a_r, float a_th, float a_ph, const int32_t res[3]) {
+  VMTaps t;
+  t.ax[0] = lin_setup(a_r, res[0]);
+  t.ax[1] = lin_setup(a_th, res[1]);
+  t.ax[2] = lin_setup(a_ph, res[2]);
+  return t;
+}
+
+__device__ __forceinline__ constexpr int vm_plane_x(int i) { return i == 2 ? 1 : 0; }
+__device__ __forceinline__ constexpr int vm_plane_y(int i) { return i == 0 ? 1 : 2; }
+__device__ __forceinline__ constexpr int vm_line_ax(int i) { return 2 - i; }
+
+// ---------------------------------------------------------------------------------------------
+// Row E scalars
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float softplus_shift(float f, float shift) {
+  const float x = __fadd_rn(f, shift);
+  return x > 20.0f ? x : log1pf(expf(x));  // torch softplus, threshold 20
+}
+
+__device__ __forceinline__ float sigmoidf(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// sin and cos of one argument: Cody-Waite reduction by pi/2 (two FMAs) + Cephes minimax polynomials on
+// [-pi/4, pi/4].  ~1 ulp for |x| < 1e4, branch-free (the libm versions drag a Payne-Hanek slow path
+// into every call site, which matters when 68 of them are inlined between MFMAs).
+__device__ __forceinline__ void sincos_f32(float x, float& s_out, float& c_out) {
+  const float k = rintf(x * 0.63661977236758134308f);
+  float r = fmaf(k, -1.57079637050628662109375f, x);      // float32(pi/2)
+  r = fmaf(k, 4.37113900018624283e-8f, r);                // pi/2 - float32(pi/2) = -4.371139e-8
+  const float r2 = r * r;
+  const float ps = fmaf(fmaf(fmaf(-1.9515295891e-4f, r2, 8.3321608736e-3f), r2, -1.6666654611e-1f), r2 * r, r);
+  const float pc = fmaf(fmaf(fmaf(2.443315711809948e-5f, r2, -1.388731625493765e-3f), r2, 4.166664568298827e-2f),
+                        r2 * r2, fmaf(-0.5f, r2, 1.0f));
+  const int q = (int)k;
+  const float s = (q & 1) ? pc : ps;
+  const float c = (q & 1) ? ps : pc;
+  s_out = (q & 2) ? -s : s;
+  c_out = ((q + 1) & 2) ? -c : c;
+}
+
+// wave64 inclusive multiplicative scan (Kogge-Stone over __shfl_up)
+__device__ __forceinline__ float wave_scan_mul(float v, int lane) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const float o = __shfl_up(v, d, 64);
+    if (lane >= d) v *= o;
+  }
+  return v;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+  return v;
+}

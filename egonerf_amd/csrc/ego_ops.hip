@@ -1,0 +1,510 @@
+// libegonerf_hip.so, part 1: the separately callable stages (rows A-E, I, J of SURVEY 8a) and the
+// fused marching / compositing kernels.  gfx950 only.
+#include "ego_device.h"
+#include "ego_host.h"
+
+// =============================================================================================
+// Row A  — sample schedule -> points      models/EgoNeRF.py:56-87
+// =============================================================================================
+__device__ __forceinline__ float sched_z(const float* __restrict__ r_sched, const float* __restrict__ jitter,
+                                         int64_t ray, int s, int S, float near_) {
+  float r = r_sched[s];
+  if (jitter) {
+    const float step = (s < S - 1) ? __fsub_rn(r_sched[s + 1], r) : __fsub_rn(r, r_sched[S - 2]);
+    r = __fadd_rn(r, __fmul_rn(step, jitter[ray * S + s]));
+  }
+  return __fadd_rn(near_, r);
+}
+
+__global__ void k_sample_ray_exp(const float* __restrict__ rays, const float* __restrict__ r_sched,
+                                 const float* __restrict__ jitter, float near_, int64_t N, int S,
+                                 float* __restrict__ xyz, float* __restrict__ z_out) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= N * S) return;
+  const int64_t ray = idx / S;
+  const int s = (int)(idx - ray * S);
+  const float z = sched_z(r_sched, jitter, ray, s, S, near_);
+  if (z_out) z_out[idx] = z;
+  if (xyz) {
+    const float* R = rays + ray * 6;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) xyz[idx * 3 + k] = __fadd_rn(R[k], __fmul_rn(R[3 + k], z));
+  }
+}
+
+// =============================================================================================
+// Rows B, C
+// =============================================================================================
+__global__ void k_from_cartesian(DevCoords c, const float* __restrict__ xyz, int64_t M, float* __restrict__ c7) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= M) return;
+  const YinYang y = yinyang_from_xyz(xyz[i * 3], xyz[i * 3 + 1], xyz[i * 3 + 2], c);
+  float* o = c7 + i * 7;
+  const int b = y.yang ? 3 : 0, nb = y.yang ? 0 : 3;
+  o[b] = y.r; o[b + 1] = y.th; o[b + 2] = y.ph;
+  o[nb] = 0.f; o[nb + 1] = 0.f; o[nb + 2] = 0.f;
+  o[6] = y.yang ? 1.f : 0.f;
+}
+
+__global__ void k_normalize_coord(DevCoords c, const float* __restrict__ c7, int64_t M, float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= M) return;
+  const float* p = c7 + i * 7;
+  float* o = out + i * 7;
+#pragma unroll
+  for (int b = 0; b < 6; b += 3) {
+    o[b] = normalize_r(p[b], c.r_lut, c.n_lut, c.n_r);
+    o[b + 1] = normalize_ang(p[b + 1], c.th_near, c.th_inv);
+    o[b + 2] = normalize_ang(p[b + 2], c.ph_near, c.ph_inv);
+  }
+  o[6] = p[6];
+}
+
+// =============================================================================================
+// Row D / D' — density feature: sum_i relu(sum_c P_ic * L_ic)      models/EgoNeRF.py:291-347, 232-289
+// lane = sample; one bilinear tap = C contiguous floats (C/4 x 16-byte loads).
+// =============================================================================================
+template <int C>
+__device__ __forceinline__ float density_lookup(const DevField& F, int g, float a_r, float a_th, float a_ph) {
+  const VMTaps t = vm_setup(a_r, a_th, a_ph, F.res);
+  float feat = 0.f;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const Lin1 X = t.ax[vm_plane_x(i)], Y = t.ax[vm_plane_y(i)], Ln = t.ax[vm_line_ax(i)];
+    const int W = F.res[vm_plane_x(i)];
+    const float* P = g ? F.plane[1][i] : F.plane[0][i];
+    const float* L = g ? F.line[1][i] : F.line[0][i];
+    const f32x4* p00 = (const f32x4*)(P + ((int64_t)Y.i0 * W + X.i0) * C);
+    const f32x4* p01 = (const f32x4*)(P + ((int64_t)Y.i0 * W + X.i1) * C);
+    const f32x4* p10 = (const f32x4*)(P + ((int64_t)Y.i1 * W + X.i0) * C);
+    const f32x4* p11 = (const f32x4*)(P + ((int64_t)Y.i1 * W + X.i1) * C);
+    const f32x4* l0 = (const f32x4*)(L + (int64_t)Ln.i0 * C);
+    const f32x4* l1 = (const f32x4*)(L + (int64_t)Ln.i1 * C);
+    const float w00 = __fmul_rn(Y.w0, X.w0), w01 = __fmul_rn(Y.w0, X.w1);
+    const float w10 = __fmul_rn(Y.w1, X.w0), w11 = __fmul_rn(Y.w1, X.w1);
+    float dot = 0.f;
+#pragma unroll
+    for (int q = 0; q < C / 4; ++q) {
+      const f32x4 pv = p00[q] * w00 + p01[q] * w01 + p10[q] * w10 + p11[q] * w11;
+      const f32x4 lv = l0[q] * Ln.w0 + l1[q] * Ln.w1;
+      const f32x4 m = pv * lv;
+      dot += (m.x + m.y) + (m.z + m.w);
+    }
+    feat += fmaxf(dot, 0.f);
+  }
+  return feat;
+}
+
+template <int C>
+__global__ void k_density_feature(DevField F, const float* __restrict__ c7n, int64_t M, float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= M) return;
+  const float* p = c7n + i * 7;
+  const int g = (p[6] == 0.f) ? 0 : 1;
+  const int b = g ? 3 : 0;
+  out[i] = density_lookup<C>(F, g, p[b], p[b + 1], p[b + 2]);
+}
+
+// =============================================================================================
+// Row E
+// =============================================================================================
+__global__ void k_feature2density(const float* __restrict__ f, int64_t M, int softplus, float shift,
+                                  float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= M) return;
+  out[i] = softplus ? softplus_shift(f[i], shift) : fmaxf(f[i], 0.f);
+}
+
+// one wave per ray; transmittance = exclusive product of (1 - alpha + 1e-10)   tensorBase.py:22-27
+__global__ void k_raw2alpha(const float* __restrict__ sigma, const float* __restrict__ dist, int64_t N, int S,
+                            float* __restrict__ alpha, float* __restrict__ weight, float* __restrict__ bg) {
+  const int lane = threadIdx.x & 63;
+  const int64_t ray = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (ray >= N) return;
+  float carry = 1.f;
+  for (int s0 = 0; s0 < S; s0 += 64) {
+    const int s = s0 + lane;
+    const bool ok = s < S;
+    const float a = ok ? __fsub_rn(1.f, expf(-sigma[ray * S + s] * dist[ray * S + s])) : 0.f;
+    const float t = ok ? __fadd_rn(__fsub_rn(1.f, a), 1e-10f) : 1.f;
+    const float inc = wave_scan_mul(t, lane);
+    float exc = __shfl_up(inc, 1, 64);
+    if (lane == 0) exc = 1.f;
+    const float T = carry * exc;
+    if (ok) {
+      if (alpha) alpha[ray * S + s] = a;
+      if (weight) weight[ray * S + s] = a * T;
+    }
+    carry *= __shfl(inc, 63, 64);
+  }
+  if (bg && lane == 0) bg[ray] = carry;
+}
+
+// =============================================================================================
+// Fused: rows A+B+C+D+E for one ray per wave.  models/EgoNeRF.py:507-529 (coarse) / 544-553 (fine)
+// =============================================================================================
+template <int C>
+__global__ __launch_bounds__(256) void k_march_density(DevCoords c, DevField F, const float* __restrict__ rays,
+                                                       int64_t N, int S, const float* __restrict__ z_in,
+                                                       const float* __restrict__ r_sched,
+                                                       const float* __restrict__ jitter, float near_,
+                                                       int softplus, float shift, float dscale,
+                                                       float* __restrict__ z_out, float* __restrict__ alpha,
+                                                       int alpha_stride, float* __restrict__ weight,
+                                                       float* __restrict__ bg) {
+  __shared__ float lut[1024];
+  for (int i = threadIdx.x; i < c.n_lut; i += blockDim.x) lut[i] = c.r_lut[i];
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int64_t ray = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (ray >= N) return;
+  const float* R = rays + ray * 6;
+  const float ox = R[0], oy = R[1], oz = R[2], dx = R[3], dy = R[4], dz = R[5];
+  float carry = 1.f;
+  for (int s0 = 0; s0 < S; s0 += 64) {
+    const int s = min(s0 + lane, S - 1);
+    const bool ok = (s0 + lane) < S;
+    // z[s] and its right neighbour (left neighbour for the last sample: dists repeat the last interval)
+    const int sn = (s < S - 1) ? s + 1 : s - 1;
+    float z, zn;
+    if (z_in) {
+      z = z_in[ray * S + s];
+      zn = z_in[ray * S + sn];
+    } else {
+      z = sched_z(r_sched, jitter, ray, s, S, near_);
+      zn = sched_z(r_sched, jitter, ray, sn, S, near_);
+    }
+    const float dist = (s < S - 1) ? __fsub_rn(zn, z) : __fsub_rn(z, zn);
+    const float px = __fadd_rn(ox, __fmul_rn(dx, z)), py = __fadd_rn(oy, __fmul_rn(dy, z)),
+                pz = __fadd_rn(oz, __fmul_rn(dz, z));
+    const YinYang y = yinyang_from_xyz(px, py, pz, c);
+    const float a_r = normalize_r(y.r, lut, c.n_lut, c.n_r);
+    const float a_th = normalize_ang(y.th, c.th_near, c.th_inv);
+    const float a_ph = normalize_ang(y.ph, c.ph_near, c.ph_inv);
+    const float f = density_lookup<C>(F, y.yang, a_r, a_th, a_ph);
+    const float sg = softplus ? softplus_shift(f, shift) : fmaxf(f, 0.f);
+    const float a = ok ? __fsub_rn(1.f, expf(-sg * __fmul_rn(dist, dscale))) : 0.f;
+    const float t = ok ? __fadd_rn(__fsub_rn(1.f, a), 1e-10f) : 1.f;
+    const float inc = wave_scan_mul(t, lane);
+    float exc = __shfl_up(inc, 1, 64);
+    if (lane == 0) exc = 1.f;
+    const float T = carry * exc;
+    if (ok) {
+      const int64_t o = ray * S + s;
+      if (z_out) z_out[o] = z;
+      if (alpha) alpha[ray * alpha_stride + s] = a;
+      if (weight) weight[o] = a * T;
+    }
+    carry *= __shfl(inc, 63, 64);
+  }
+  // with an environment map the reference appends a column of ones to alpha (EgoNeRF.py:587)
+  if (alpha && lane < alpha_stride - S) alpha[ray * alpha_stride + S + lane] = 1.f;
+  if (bg && lane == 0) bg[ray] = carry;
+}
+
+// =============================================================================================
+// Row J — environment map     models/envmap.py:6-14, 26-34
+// =============================================================================================
+__device__ __forceinline__ void envmap_lookup(const float* __restrict__ em, int h, float dx, float dy, float dz,
+                                              float out[3]) {
+  const float nrm = fmaxf(__fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz))), 1e-12f);
+  const float nx = __fdiv_rn(dx, nrm), ny = __fdiv_rn(dy, nrm), nz = __fdiv_rn(dz, nrm);
+  const float u = __fmul_rn(__fadd_rn(nz, 1.f), 0.5f);
+  const float v = __fdiv_rn(__fadd_rn(atan2f(ny, nx), 3.14159265358979323846f), 6.28318530717958647692f);
+  const Lin1 X = lin_setup(__fsub_rn(__fmul_rn(u, 2.f), 1.f), h);       // u indexes the h-wide axis
+  const Lin1 Y = lin_setup(__fsub_rn(__fmul_rn(v, 2.f), 1.f), 2 * h);   // v indexes the 2h axis
+  const float w00 = __fmul_rn(Y.w0, X.w0), w01 = __fmul_rn(Y.w0, X.w1), w10 = __fmul_rn(Y.w1, X.w0),
+              w11 = __fmul_rn(Y.w1, X.w1);
+#pragma unroll
+  for (int ch = 0; ch < 3; ++ch) {
+    const float* E = em + (int64_t)ch * 2 * h * h;
+    const float s = E[(int64_t)Y.i0 * h + X.i0] * w00 + E[(int64_t)Y.i0 * h + X.i1] * w01 +
+                    E[(int64_t)Y.i1 * h + X.i0] * w10 + E[(int64_t)Y.i1 * h + X.i1] * w11;
+    out[ch] = sigmoidf(s);
+  }
+}
+
+__global__ void k_envmap(const float* __restrict__ em, int h, const float* __restrict__ dirs, int64_t N,
+                         float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  float o[3];
+  envmap_lookup(em, h, dirs[i * 3], dirs[i * 3 + 1], dirs[i * 3 + 2], o);
+  out[i * 3] = o[0]; out[i * 3 + 1] = o[1]; out[i * 3 + 2] = o[2];
+}
+
+// =============================================================================================
+// Row H — compositing, one wave per ray      models/EgoNeRF.py:579-598
+// =============================================================================================
+__global__ void k_composite(const float* __restrict__ em, int em_h, const float* __restrict__ rays,
+                            const float* __restrict__ z, const float* __restrict__ weight,
+                            const float* __restrict__ bgw, const float* __restrict__ rgb, int64_t N, int S,
+                            float* __restrict__ rgb_map, float* __restrict__ depth, float* __restrict__ bg_map,
+                            float* __restrict__ env_map) {
+  const int lane = threadIdx.x & 63;
+  const int64_t ray = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (ray >= N) return;
+  float acc = 0.f, cr = 0.f, cg = 0.f, cb = 0.f, dp = 0.f;
+  for (int s = lane; s < S; s += 64) {
+    const int64_t o = ray * S + s;
+    const float w = weight[o];
+    acc += w;
+    cr += w * rgb[o * 3];
+    cg += w * rgb[o * 3 + 1];
+    cb += w * rgb[o * 3 + 2];
+    dp += w * z[o];
+  }
+  acc = wave_sum(acc); cr = wave_sum(cr); cg = wave_sum(cg); cb = wave_sum(cb); dp = wave_sum(dp);
+  if (lane != 0) return;
+  const float* R = rays + ray * 6;
+  if (em) {
+    float e[3];
+    envmap_lookup(em, em_h, R[3], R[4], R[5], e);
+    const float b = bgw[ray];
+    const float bx = b * e[0], by = b * e[1], bz = b * e[2];
+    cr += bx; cg += by; cb += bz;
+    if (bg_map) { bg_map[ray * 3] = bx; bg_map[ray * 3 + 1] = by; bg_map[ray * 3 + 2] = bz; }
+    if (env_map) { env_map[ray * 3] = e[0]; env_map[ray * 3 + 1] = e[1]; env_map[ray * 3 + 2] = e[2]; }
+  }
+  rgb_map[ray * 3] = fminf(fmaxf(cr, 0.f), 1.f);
+  rgb_map[ray * 3 + 1] = fminf(fmaxf(cg, 0.f), 1.f);
+  rgb_map[ray * 3 + 2] = fminf(fmaxf(cb, 0.f), 1.f);
+  if (depth) depth[ray] = dp + (1.f - acc) * R[5];  // (1-acc) * d_z: reference quirk, EgoNeRF.py:598
+}
+
+// =============================================================================================
+// Row I — inverse-CDF resampling + sort, one workgroup (256 threads) per ray
+// dataLoader/ray_utils.py:156-187 and models/EgoNeRF.py:532-542
+// =============================================================================================
+#define PDF_MAX 2048
+__global__ __launch_bounds__(256) void k_sample_pdf_merge(const float* __restrict__ z, const float* __restrict__ weight,
+                                                          const float* __restrict__ u_in, int Sc, int n_fine,
+                                                          int use_coarse, float* __restrict__ z_out,
+                                                          float* __restrict__ z_new_out) {
+  __shared__ float cdf[PDF_MAX];   // [Sc-1] entries: 0, cumsum(pdf)
+  __shared__ float keys[PDF_MAX];  // sort buffer
+  __shared__ float red[256];
+  const int64_t ray = blockIdx.x;
+  const int tid = threadIdx.x;
+  const float* zr = z + ray * Sc;
+  const float* wr = weight + ray * Sc;
+  const int nb = Sc - 1;  // bins = midpoints z_mid[0..Sc-2]
+  const int nw = Sc - 2;  // pdf entries = weight[1..Sc-2]
+  // sum(w + 1e-5)
+  float part = 0.f;
+  for (int i = tid; i < nw; i += 256) part += __fadd_rn(wr[1 + i], 1e-5f);
+  red[tid] = part;
+  __syncthreads();
+  for (int d = 128; d > 0; d >>= 1) {
+    if (tid < d) red[tid] += red[tid + d];
+    __syncthreads();
+  }
+  const float total = red[0];
+  // pdf -> cdf by a sequential-order blocked scan (one wave does the scan; nw <= 2046)
+  for (int i = tid; i < nw; i += 256) keys[i] = __fdiv_rn(__fadd_rn(wr[1 + i], 1e-5f), total);
+  __syncthreads();
+  if (tid < 64) {
+    float carry = 0.f;
+    for (int s0 = 0; s0 < nw; s0 += 64) {
+      const int i = s0 + tid;
+      float v = (i < nw) ? keys[i] : 0.f;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const float o = __shfl_up(v, d, 64);
+        if (tid >= d) v += o;
+      }
+      if (i < nw) cdf[i + 1] = carry + v;
+      carry += __shfl(v, 63, 64);
+    }
+    if (tid == 0) cdf[0] = 0.f;
+  }
+  __syncthreads();
+  // inverse CDF
+  const int n_out = use_coarse ? Sc + n_fine : n_fine;
+  for (int j = tid; j < n_fine; j += 256) {
+    float u;
+    if (u_in) u = u_in[ray * n_fine + j];
+    else {  // torch.linspace(0, 1, n) in float32: symmetric evaluation from both ends
+      const float step = __fdiv_rn(1.f, (float)(n_fine - 1));
+      u = (n_fine == 1) ? 0.f : (j < n_fine / 2 ? __fmul_rn(step, (float)j) : __fsub_rn(1.f, __fmul_rn(step, (float)(n_fine - 1 - j))));
+    }
+    int lo = 0, hi = nb;  // searchsorted right over cdf[0..nb-1]
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (!(cdf[mid] > u)) lo = mid + 1; else hi = mid;
+    }
+    const int below = max(lo - 1, 0), above = min(lo, nb - 1);
+    const float c0 = cdf[below], c1 = cdf[above];
+    const float b0 = 0.5f * __fadd_rn(zr[below + 1], zr[below]);
+    const float b1 = 0.5f * __fadd_rn(zr[above + 1], zr[above]);
+    float den = __fsub_rn(c1, c0);
+    if (den < 1e-5f) den = 1.f;
+    const float t = __fdiv_rn(__fsub_rn(u, c0), den);
+    const float zs = __fadd_rn(b0, __fmul_rn(t, __fsub_rn(b1, b0)));
+    keys[(use_coarse ? Sc : 0) + j] = zs;
+    if (z_new_out) z_new_out[ray * n_fine + j] = zs;
+  }
+  if (use_coarse)
+    for (int i = tid; i < Sc; i += 256) keys[i] = zr[i];
+  // bitonic sort of n_out keys padded to a power of two with +inf
+  int P = 1;
+  while (P < n_out) P <<= 1;
+  for (int i = n_out + tid; i < P; i += 256) keys[i] = __int_as_float(0x7f800000);
+  __syncthreads();
+  for (int k = 2; k <= P; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = tid; i < P; i += 256) {
+        const int l = i ^ j;
+        if (l > i) {
+          const float a = keys[i], b = keys[l];
+          const bool up = (i & k) == 0;
+          if ((a > b) == up) { keys[i] = b; keys[l] = a; }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  for (int i = tid; i < n_out; i += 256) z_out[ray * n_out + i] = keys[i];
+}
+
+// =============================================================================================
+// update_coarse_sigma_grid — 2x average pooling of a channel-last table    models/EgoNeRF.py:124-131
+// =============================================================================================
+__global__ void k_avgpool(const float* __restrict__ src, int H, int W, int C, float* __restrict__ dst) {
+  const int Ho = H / 2, Wo = (W == 1) ? 1 : W / 2;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)Ho * Wo * C) return;
+  const int ch = (int)(idx % C);
+  const int x = (int)((idx / C) % Wo);
+  const int y = (int)(idx / ((int64_t)C * Wo));
+  if (W == 1) {
+    dst[idx] = (src[((int64_t)2 * y) * C + ch] + src[((int64_t)2 * y + 1) * C + ch]) * 0.5f;
+  } else {
+    const float* r0 = src + ((int64_t)(2 * y) * W + 2 * x) * C + ch;
+    const float* r1 = src + ((int64_t)(2 * y + 1) * W + 2 * x) * C + ch;
+    dst[idx] = (((r0[0] + r0[C]) + r1[0]) + r1[C]) * 0.25f;
+  }
+}
+
+// =============================================================================================
+// C ABI
+// =============================================================================================
+static inline unsigned nblk(int64_t n, int b) { return (unsigned)((n + b - 1) / b); }
+
+extern "C" {
+
+int ego_abi_version(void) { return EGO_ABI_VERSION; }
+const char* ego_last_error(void) { return ego_err_buf(); }
+
+int ego_sample_ray_exp(const float* rays, const float* r_sched, const float* jitter, float near_, int64_t N, int32_t S,
+                       float* xyz, float* z, void* stream) {
+  EGO_REQUIRE(rays && r_sched && N >= 0 && S >= 2, "sample_ray_exp: null input or S < 2");
+  if (N == 0) return EGO_OK;
+  k_sample_ray_exp<<<nblk(N * S, 256), 256, 0, (hipStream_t)stream>>>(rays, r_sched, jitter, near_, N, S, xyz, z);
+  return ego_launch_status("k_sample_ray_exp");
+}
+
+int ego_from_cartesian(const ego_scene* sc, const float* xyz, int64_t M, float* c7, void* stream) {
+  EGO_REQUIRE(sc && xyz && c7 && M >= 0, "from_cartesian: null argument");
+  if (M == 0) return EGO_OK;
+  k_from_cartesian<<<nblk(M, 256), 256, 0, (hipStream_t)stream>>>(make_coords(*sc), xyz, M, c7);
+  return ego_launch_status("k_from_cartesian");
+}
+
+int ego_normalize_coord(const ego_scene* sc, const float* c7, int64_t M, float* c7n, void* stream) {
+  EGO_REQUIRE(sc && c7 && c7n && sc->r_lut && M >= 0, "normalize_coord: null argument");
+  if (M == 0) return EGO_OK;
+  k_normalize_coord<<<nblk(M, 256), 256, 0, (hipStream_t)stream>>>(make_coords(*sc), c7, M, c7n);
+  return ego_launch_status("k_normalize_coord");
+}
+
+static int check_field(const ego_vm_field& f, const char* what) {
+  for (int g = 0; g < 2; ++g)
+    for (int i = 0; i < 3; ++i)
+      if (!f.plane[g][i] || !f.line[g][i]) return ego_fail(EGO_E_BADARG, "%s: null table pointer", what);
+  if (f.res[0] < 2 || f.res[1] < 2 || f.res[2] < 2) return ego_fail(EGO_E_BADARG, "%s: resolution < 2", what);
+  return EGO_OK;
+}
+
+int ego_density_feature(const ego_scene* sc, const float* c7n, int64_t M, int32_t coarse, float* out, void* stream) {
+  EGO_REQUIRE(sc && c7n && out && M >= 0, "density_feature: null argument");
+  const ego_vm_field& f = coarse ? sc->density_coarse : sc->density;
+  if (int e = check_field(f, "density_feature")) return e;
+  if (M == 0) return EGO_OK;
+  if (f.n_comp == 16)
+    k_density_feature<16><<<nblk(M, 256), 256, 0, (hipStream_t)stream>>>(make_field(f), c7n, M, out);
+  else if (f.n_comp == 8)
+    k_density_feature<8><<<nblk(M, 256), 256, 0, (hipStream_t)stream>>>(make_field(f), c7n, M, out);
+  else
+    return ego_fail(EGO_E_UNSUPPORTED, "density_feature: n_comp %d (supported: 8, 16)", f.n_comp);
+  return ego_launch_status("k_density_feature");
+}
+
+int ego_feature2density(const ego_scene* sc, const float* feat, int64_t M, float* sigma, void* stream) {
+  EGO_REQUIRE(sc && feat && sigma && M >= 0, "feature2density: null argument");
+  if (M == 0) return EGO_OK;
+  k_feature2density<<<nblk(M, 256), 256, 0, (hipStream_t)stream>>>(feat, M, sc->act_softplus, sc->density_shift, sigma);
+  return ego_launch_status("k_feature2density");
+}
+
+int ego_raw2alpha(const float* sigma, const float* dist, int64_t N, int32_t S, float* alpha, float* weight,
+                  float* bg_weight, void* stream) {
+  EGO_REQUIRE(sigma && dist && N >= 0 && S >= 1, "raw2alpha: null argument");
+  if (N == 0) return EGO_OK;
+  k_raw2alpha<<<nblk(N, 4), 256, 0, (hipStream_t)stream>>>(sigma, dist, N, S, alpha, weight, bg_weight);
+  return ego_launch_status("k_raw2alpha");
+}
+
+int ego_sample_pdf_merge(const float* z, const float* weight, const float* u, int64_t N, int32_t Sc, int32_t n_fine,
+                         int32_t use_coarse, float* z_out, float* z_new_out, void* stream) {
+  EGO_REQUIRE(z && weight && z_out && N >= 0, "sample_pdf_merge: null argument");
+  EGO_REQUIRE(Sc >= 3 && n_fine >= 1 && Sc + n_fine <= PDF_MAX, "sample_pdf_merge: need 3 <= Sc, Sc + n_fine <= 2048");
+  if (N == 0) return EGO_OK;
+  k_sample_pdf_merge<<<(unsigned)N, 256, 0, (hipStream_t)stream>>>(z, weight, u, Sc, n_fine, use_coarse, z_out, z_new_out);
+  return ego_launch_status("k_sample_pdf_merge");
+}
+
+int ego_envmap_radiance(const ego_scene* sc, const float* dirs, int64_t N, float* out, void* stream) {
+  EGO_REQUIRE(sc && dirs && out && sc->envmap && sc->envmap_h >= 2 && N >= 0, "envmap_radiance: no envmap / null argument");
+  if (N == 0) return EGO_OK;
+  k_envmap<<<nblk(N, 256), 256, 0, (hipStream_t)stream>>>(sc->envmap, sc->envmap_h, dirs, N, out);
+  return ego_launch_status("k_envmap");
+}
+
+int ego_avgpool_table(const float* src, int32_t H, int32_t W, int32_t C, float* dst, void* stream) {
+  EGO_REQUIRE(src && dst && H >= 2 && W >= 1 && C >= 1, "avgpool_table: bad argument");
+  const int64_t n = (int64_t)(H / 2) * (W == 1 ? 1 : W / 2) * C;
+  k_avgpool<<<nblk(n, 256), 256, 0, (hipStream_t)stream>>>(src, H, W, C, dst);
+  return ego_launch_status("k_avgpool");
+}
+
+int ego_march_density(const ego_scene* sc, const float* rays, int64_t N, int32_t S, const float* z_in,
+                      const float* r_sched, const float* jitter, float near_, int32_t coarse, float* z_out,
+                      float* alpha, int32_t alpha_stride, float* weight, float* bg_weight, void* stream) {
+  EGO_REQUIRE(sc && rays && N >= 0 && S >= 2, "march_density: null argument or S < 2");
+  if (alpha_stride == 0) alpha_stride = S;
+  EGO_REQUIRE(alpha_stride >= S && alpha_stride <= S + 64, "march_density: alpha_stride must be in [S, S+64]");
+  EGO_REQUIRE(z_in || r_sched, "march_density: need z_in or r_sched");
+  EGO_REQUIRE(sc->r_lut && sc->n_r_lut >= 2 && sc->n_r_lut <= 1024, "march_density: r_lut missing or > 1024 entries");
+  const ego_vm_field& f = coarse ? sc->density_coarse : sc->density;
+  if (int e = check_field(f, "march_density")) return e;
+  if (N == 0) return EGO_OK;
+  if (f.n_comp != 16) return ego_fail(EGO_E_UNSUPPORTED, "march_density: n_comp %d (supported: 16)", f.n_comp);
+  k_march_density<16><<<nblk(N, 4), 256, 0, (hipStream_t)stream>>>(
+      make_coords(*sc), make_field(f), rays, N, S, z_in, r_sched, jitter, near_, sc->act_softplus, sc->density_shift,
+      sc->distance_scale, z_out, alpha, alpha_stride, weight, bg_weight);
+  return ego_launch_status("k_march_density");
+}
+
+int ego_composite(const ego_scene* sc, const float* rays, const float* z, const float* weight, const float* bg_weight,
+                  const float* rgb, int64_t N, int32_t S, float* rgb_map, float* depth, float* bg_map, float* env_map,
+                  void* stream) {
+  EGO_REQUIRE(sc && rays && z && weight && rgb && rgb_map && N >= 0 && S >= 1, "composite: null argument");
+  EGO_REQUIRE(!sc->envmap || bg_weight, "composite: envmap needs bg_weight");
+  if (N == 0) return EGO_OK;
+  k_composite<<<nblk(N, 4), 256, 0, (hipStream_t)stream>>>(sc->envmap, sc->envmap_h, rays, z, weight, bg_weight, rgb, N, S,
+                                                          rgb_map, depth, bg_map, env_map);
+  return ego_launch_status("k_composite");
+}
+
+}  // extern "C"

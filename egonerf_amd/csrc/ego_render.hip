@@ -1,0 +1,71 @@
+// libegonerf_hip.so, part 3: EgoNeRF.forward as one call (models/EgoNeRF.py:491-602) — a fixed
+// sequence of launches on the caller's stream, no host synchronisation, no allocation.
+#include "ego_host.h"
+
+namespace {
+struct Plan {
+  int64_t zc, wc, zf, w, bg, rgb, total;  // float offsets
+  int32_t S_out;
+};
+
+inline int64_t align64(int64_t v) { return (v + 63) & ~int64_t(63); }
+
+Plan make_plan(int64_t N, const ego_render_args* a) {
+  Plan p{};
+  const int64_t Sc = a->n_coarse;
+  p.S_out = a->resampling ? (a->use_coarse_sample ? a->n_coarse + a->n_fine : a->n_fine) : a->n_coarse;
+  int64_t o = 0;
+  p.zc = o; o = align64(o + N * Sc);
+  p.wc = o; o = align64(o + (a->resampling ? N * Sc : 0));
+  p.zf = o; o = align64(o + (a->resampling ? N * (int64_t)p.S_out : 0));
+  p.w = o; o = align64(o + N * (int64_t)p.S_out);
+  p.bg = o; o = align64(o + N);
+  p.rgb = o; o = align64(o + N * (int64_t)p.S_out * 3);
+  p.total = o;
+  return p;
+}
+}  // namespace
+
+extern "C" {
+
+/* lets a binding verify its struct mirrors: which = 0 ego_scene, 1 ego_render_args, 2 ego_vm_field */
+int64_t ego_sizeof(int32_t which) {
+  return which == 0 ? (int64_t)sizeof(ego_scene) : which == 1 ? (int64_t)sizeof(ego_render_args) : which == 2 ? (int64_t)sizeof(ego_vm_field) : -1;
+}
+
+int64_t ego_render_workspace_bytes(int64_t N, const ego_render_args* args) {
+  if (!args || N < 0 || args->n_coarse < 2) return -1;
+  return make_plan(N, args).total * (int64_t)sizeof(float);
+}
+
+int ego_render_forward(const ego_scene* sc, const ego_render_args* a, const float* rays, int64_t N, void* workspace,
+                       float* rgb_map, float* depth, float* alpha, float* bg_map, float* env_map, void* stream) {
+  EGO_REQUIRE(sc && a && rays && workspace && rgb_map && N >= 0, "render_forward: null argument");
+  EGO_REQUIRE(a->r_sched && a->n_coarse >= 2, "render_forward: r_sched missing or n_coarse < 2");
+  EGO_REQUIRE(!a->resampling || a->n_fine >= 1, "render_forward: resampling needs n_fine >= 1");
+  if (N == 0) return EGO_OK;
+  const Plan p = make_plan(N, a);
+  float* ws = (float*)workspace;
+  const int32_t S = p.S_out;
+  const int32_t astride = sc->envmap ? S + 1 : S;
+  int e;
+  const float* z;
+  if (a->resampling) {
+    // coarse pass on the pooled tables -> weights -> inverse-CDF samples merged into the coarse schedule
+    if ((e = ego_march_density(sc, rays, N, a->n_coarse, nullptr, a->r_sched, a->jitter, a->near_, 1, ws + p.zc, nullptr, 0,
+                               ws + p.wc, nullptr, stream))) return e;
+    if ((e = ego_sample_pdf_merge(ws + p.zc, ws + p.wc, a->u, N, a->n_coarse, a->n_fine, a->use_coarse_sample, ws + p.zf,
+                                  nullptr, stream))) return e;
+    if ((e = ego_march_density(sc, rays, N, S, ws + p.zf, nullptr, nullptr, a->near_, 0, nullptr, alpha, astride, ws + p.w,
+                               ws + p.bg, stream))) return e;
+    z = ws + p.zf;
+  } else {
+    if ((e = ego_march_density(sc, rays, N, S, nullptr, a->r_sched, a->jitter, a->near_, 0, ws + p.zc, alpha, astride,
+                               ws + p.w, ws + p.bg, stream))) return e;
+    z = ws + p.zc;
+  }
+  if ((e = ego_shade(sc, rays, z, N, S, ws + p.rgb, stream))) return e;
+  return ego_composite(sc, rays, z, ws + p.w, ws + p.bg, ws + p.rgb, N, S, rgb_map, depth, bg_map, env_map, stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,435 @@
+// libegonerf_hip.so, part 2: appearance lookup -> basis -> positional encoding -> MLP_Fea, on the
+// fp32 matrix cores (v_mfma_f32_32x32x2_f32: exact fp32 FMA chains, so parity with the reference's
+// fp32 Linear layers is rounding-order only).
+//
+// Work mapping (wave64): a wave owns a tile of 32 consecutive samples; lane l serves sample
+// j = l & 31 and "half" h = l >> 5.  In D = A*B (32x32x2): A[i][k] comes from lane (i, k) = (l&31, l>>5),
+// B[k][j] from lane (j, k) = (l&31, l>>5), and D[i][j] lands in lane j + 32*((i>>2)&1), register
+// r = (i&3) + 4*(i>>3).  So with samples on the N axis a lane only ever supplies / receives values of
+// ITS OWN sample: the gathered products feed the basis MFMAs straight from registers, the basis
+// output feeds layer 1, layer 1 feeds layer 2 — no cross-lane traffic, no LDS round trip for
+// activations.  The price is a fixed K-order per lane half, which ego_pack_mlp bakes into the weights:
+//   * lane half h gathers appearance channels [24h, 24h+24) of each of the 3 planes  (72 k-steps)
+//   * basis rows are permuted so half h receives features f = 2r + h in register r   (14 slots)
+//   * layer-1 k-steps: 14 slots x (f, sin f, sin 2f, cos f, cos 2f) + 8 view slots + 2 zero pads = 80
+//     (slot-major, so each encoding is produced right before the MFMAs that consume it)
+//   * layer-2 k-step m*16 + r consumes hidden unit m*32 + (r&3) + 8*(r>>2) + 4h
+// Layer 3 (128 -> 3) runs on the VALU from the layer-2 accumulators + one xor-32 exchange.
+//
+// W1/W2/W3/biases (150.5 KB packed) live in LDS for the whole persistent workgroup (8 waves = 2 per
+// SIMD, so one wave's gather overlaps the other's MFMA chain); the basis fragments stream from L2.
+#include "ego_device.h"
+#include "ego_host.h"
+
+namespace {
+
+constexpr int APP_C = 48;      // appearance components per plane
+constexpr int APP_HALF = 24;   // channels gathered by one lane half
+constexpr int APP_DIM = 27;
+constexpr int HID = 128;
+constexpr int NSLOT = 14;      // feature slots per lane half
+constexpr int KS_BASIS = 72;
+constexpr int KS1 = 80;
+constexpr int KS2 = 64;
+constexpr int MLP_IN = 150;
+
+constexpr int OFF_W1 = 0;                           // [KS1/4][4 m][64 lanes][4]
+constexpr int OFF_W2 = OFF_W1 + KS1 * 4 * 64;       // [KS2/4][4 m][64][4]
+constexpr int OFF_B1 = OFF_W2 + KS2 * 4 * 64;       // [4 m][2 h][16 r]
+constexpr int OFF_B2 = OFF_B1 + 128;
+constexpr int OFF_W3 = OFF_B2 + 128;                // [4 m][2 h][16 r][4 (c0,c1,c2,0)]
+constexpr int OFF_B3 = OFF_W3 + 512;                // [4]
+constexpr int LDS_W_FLOATS = OFF_B3 + 4;            // 37636 floats = 150544 B
+constexpr int OFF_BASIS = LDS_W_FLOATS;             // [2 g][KS_BASIS/4][64][4]
+constexpr int PACKED_FLOATS = OFF_BASIS + 2 * (KS_BASIS / 4) * 64 * 4;
+constexpr int LUT_MAX = 1024;
+
+__host__ __device__ constexpr int slot_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// reference MLP input column held by X register kk of lane half h (-1: zero weight)
+__device__ int x_channel(int kk, int h) {
+  if (kk < 5 * NSLOT) {
+    const int kind = kk % 5, r = kk / 5, f = 2 * r + h;
+    if (f >= APP_DIM) return -1;
+    const int pe0 = APP_DIM + 3;               // 30: sin block of the feature PE
+    const int pe1 = pe0 + 2 * APP_DIM;         // 84: cos block
+    switch (kind) {
+      case 0: return f;
+      case 1: return pe0 + 2 * f;
+      case 2: return pe0 + 2 * f + 1;
+      case 3: return pe1 + 2 * f;
+      default: return pe1 + 2 * f + 1;
+    }
+  }
+  if (kk < 5 * NSLOT + 8) {
+    const int t = (kk - 5 * NSLOT) + 8 * h;
+    // d0 d1 d2 | sin d0, sin 2d0, sin d1, sin 2d1, sin d2, sin 2d2 | cos ... | pad
+    return t < 3 ? APP_DIM + t : (t < 15 ? 138 + (t - 3) : -1);
+  }
+  return -1;
+}
+
+__global__ void k_pack_mlp(const float* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ w2,
+                           const float* __restrict__ b2, const float* __restrict__ w3, const float* __restrict__ b3,
+                           const float* __restrict__ basis_yin, const float* __restrict__ basis_yang,
+                           float* __restrict__ out) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= PACKED_FLOATS) return;
+  float v = 0.f;
+  if (idx < OFF_W2) {  // W1 fragments
+    const int j = idx & 3, lane = (idx >> 2) & 63, m = (idx >> 8) & 3, kk4 = idx >> 10;
+    const int ch = x_channel(kk4 * 4 + j, lane >> 5);
+    if (ch >= 0) v = w1[(m * 32 + (lane & 31)) * MLP_IN + ch];
+  } else if (idx < OFF_B1) {  // W2 fragments
+    const int e = idx - OFF_W2;
+    const int j = e & 3, lane = (e >> 2) & 63, m2 = (e >> 8) & 3, kk4 = e >> 10;
+    const int kk = kk4 * 4 + j;
+    v = w2[(m2 * 32 + (lane & 31)) * HID + (kk >> 4) * 32 + slot_row(kk & 15, lane >> 5)];
+  } else if (idx < OFF_W3) {  // biases of layers 1, 2 in accumulator layout
+    const int e = (idx - OFF_B1) & 127;
+    const float* b = (idx < OFF_B2) ? b1 : b2;
+    v = b[(e >> 5) * 32 + slot_row(e & 15, (e >> 4) & 1)];
+  } else if (idx < OFF_B3) {  // W3 in accumulator layout
+    const int e = idx - OFF_W3;
+    const int c = e & 3, r = (e >> 2) & 15, h = (e >> 6) & 1, m = e >> 7;
+    if (c < 3) v = w3[c * HID + m * 32 + slot_row(r, h)];
+  } else if (idx < OFF_BASIS) {
+    const int c = idx - OFF_B3;
+    if (c < 3) v = b3[c];
+  } else {  // basis fragments
+    const int e = idx - OFF_BASIS;
+    const int j = e & 3, lane = (e >> 2) & 63, kk4 = (e >> 8) % (KS_BASIS / 4), g = e / (KS_BASIS / 4 * 256);
+    const int i = lane & 31, h = lane >> 5, kk = kk4 * 4 + j;
+    const int rh = (i >> 2) & 1, r = (i & 3) + 4 * (i >> 3), f = 2 * r + rh;  // feature delivered to tile row i
+    if (r < NSLOT && f < APP_DIM) {
+      const int col = (kk / APP_HALF) * APP_C + APP_HALF * h + (kk % APP_HALF);
+      v = (g ? basis_yang : basis_yin)[f * (3 * APP_C) + col];
+    }
+  }
+  out[idx] = v;
+}
+
+enum { MODE_SHADE = 0, MODE_APP = 1, MODE_MLP = 2 };
+
+struct ShadeArgs {
+  DevCoords c;
+  DevField F;
+  const float* packed;
+  const float* rays;  // MODE_SHADE: [N][6]
+  const float* z;     // MODE_SHADE: [N][S]
+  const float* c7n;   // MODE_APP: [M][7]
+  const float* feat;  // MODE_MLP: [M][27]
+  const float* dirs;  // MODE_MLP: [M][3]
+  float* out;         // rgb [M][3] or feat [M][27]
+  int64_t M;
+  int32_t S;
+};
+
+#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+
+// gather this lane's 24-channel half of the three (plane x line) products: v[72]
+__device__ __forceinline__ void gather_app(const DevField& F, int g, int h, float a_r, float a_th, float a_ph,
+                                           float v[KS_BASIS]) {
+  const VMTaps t = vm_setup(a_r, a_th, a_ph, F.res);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const Lin1 X = t.ax[vm_plane_x(i)], Y = t.ax[vm_plane_y(i)], Ln = t.ax[vm_line_ax(i)];
+    const int W = F.res[vm_plane_x(i)];
+    const float* P = (g ? F.plane[1][i] : F.plane[0][i]) + APP_HALF * h;
+    const float* L = (g ? F.line[1][i] : F.line[0][i]) + APP_HALF * h;
+    const f32x4* p00 = (const f32x4*)(P + (Y.i0 * W + X.i0) * APP_C);
+    const f32x4* p01 = (const f32x4*)(P + (Y.i0 * W + X.i1) * APP_C);
+    const f32x4* p10 = (const f32x4*)(P + (Y.i1 * W + X.i0) * APP_C);
+    const f32x4* p11 = (const f32x4*)(P + (Y.i1 * W + X.i1) * APP_C);
+    const f32x4* l0 = (const f32x4*)(L + Ln.i0 * APP_C);
+    const f32x4* l1 = (const f32x4*)(L + Ln.i1 * APP_C);
+    const float w00 = __fmul_rn(Y.w0, X.w0), w01 = __fmul_rn(Y.w0, X.w1);
+    const float w10 = __fmul_rn(Y.w1, X.w0), w11 = __fmul_rn(Y.w1, X.w1);
+#pragma unroll
+    for (int q = 0; q < APP_HALF / 4; ++q) {
+      const f32x4 pv = p00[q] * w00 + p01[q] * w01 + p10[q] * w10 + p11[q] * w11;
+      const f32x4 lv = l0[q] * Ln.w0 + l1[q] * Ln.w1;
+      const f32x4 m = pv * lv;
+      v[i * APP_HALF + q * 4 + 0] = m.x;
+      v[i * APP_HALF + q * 4 + 1] = m.y;
+      v[i * APP_HALF + q * 4 + 2] = m.z;
+      v[i * APP_HALF + q * 4 + 3] = m.w;
+    }
+  }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(512) void k_shade(ShadeArgs A) {
+  __shared__ __attribute__((aligned(16))) float lds[(MODE == MODE_APP ? 0 : LDS_W_FLOATS) + (MODE == MODE_MLP ? 4 : LUT_MAX)];
+  float* lut = lds + (MODE == MODE_APP ? 0 : LDS_W_FLOATS);
+  if (MODE != MODE_APP) {
+    const f32x4* src = (const f32x4*)A.packed;
+    f32x4* dst = (f32x4*)lds;
+    for (int i = threadIdx.x; i < LDS_W_FLOATS / 4; i += 512) dst[i] = src[i];
+  }
+  if (MODE == MODE_SHADE)
+    for (int i = threadIdx.x; i < A.c.n_lut; i += 512) lut[i] = A.c.r_lut[i];
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 31, h = lane >> 5;
+  const int64_t n_tiles = (A.M + 31) >> 5;
+  const f32x4* W1 = (const f32x4*)(lds + OFF_W1);
+  const f32x4* W2 = (const f32x4*)(lds + OFF_W2);
+  const f32x4* B1 = (const f32x4*)(lds + OFF_B1);
+  const f32x4* B2 = (const f32x4*)(lds + OFF_B2);
+  const f32x4* W3 = (const f32x4*)(lds + OFF_W3);
+  const f32x4* BAS = (const f32x4*)(A.packed + OFF_BASIS);
+
+  for (int64_t tile = (int64_t)blockIdx.x * 8 + wave; tile < n_tiles; tile += (int64_t)gridDim.x * 8) {
+    // LDS weights are loop-invariant: without an opaque per-iteration index LICM hoists all 240
+    // ds_read_b128 out of the tile loop and spills them to scratch
+    int lw = lane;
+    asm volatile("" : "+v"(lw));
+    const int hw = lw >> 5;
+    const int64_t m_raw = tile * 32 + j;
+    const bool valid = m_raw < A.M;
+    const int64_t m = valid ? m_raw : A.M - 1;
+
+    f32x16 fe;  // basis output: register r holds feature 2r + h
+    float vd0 = 0.f, vd1 = 0.f, vd2 = 0.f;
+    if (MODE == MODE_MLP) {
+      const float* fp = A.feat + m * APP_DIM;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) fe[r] = (r < NSLOT && 2 * r + h < APP_DIM) ? fp[min(2 * r + h, APP_DIM - 1)] : 0.f;
+      vd0 = A.dirs[m * 3]; vd1 = A.dirs[m * 3 + 1]; vd2 = A.dirs[m * 3 + 2];
+    } else {
+      float a_r, a_th, a_ph;
+      int g;
+      if (MODE == MODE_APP) {
+        const float* p = A.c7n + m * 7;
+        g = (p[6] == 0.f) ? 0 : 1;
+        const int b = g ? 3 : 0;
+        a_r = p[b]; a_th = p[b + 1]; a_ph = p[b + 2];
+      } else {
+        const uint32_t ray = (uint32_t)m / (uint32_t)A.S;
+        const float* R = A.rays + (int64_t)ray * 6;
+        const float zz = A.z[m];
+        vd0 = R[3]; vd1 = R[4]; vd2 = R[5];
+        const float px = __fadd_rn(R[0], __fmul_rn(vd0, zz)), py = __fadd_rn(R[1], __fmul_rn(vd1, zz)),
+                    pz = __fadd_rn(R[2], __fmul_rn(vd2, zz));
+        const YinYang y = yinyang_from_xyz(px, py, pz, A.c);
+        g = y.yang;
+        a_r = normalize_r(y.r, lut, A.c.n_lut, A.c.n_r);
+        a_th = normalize_ang(y.th, A.c.th_near, A.c.th_inv);
+        a_ph = normalize_ang(y.ph, A.c.ph_near, A.c.ph_inv);
+      }
+      float v[KS_BASIS];
+      gather_app(A.F, g, h, a_r, a_th, a_ph, v);
+      // basis: a wave that straddles the yin/yang border runs both weight sets with the other grid's
+      // samples zeroed on the B side (a lane only feeds its own output column)
+      const bool any_yin = __ballot(g == 0) != 0ull, any_yang = __ballot(g != 0) != 0ull;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) fe[r] = 0.f;
+      if (any_yin) {
+#pragma unroll
+        for (int k4 = 0; k4 < KS_BASIS / 4; ++k4) {
+          const f32x4 a = BAS[k4 * 64 + lane];
+          fe = MFMA(a.x, g ? 0.f : v[k4 * 4 + 0], fe);
+          fe = MFMA(a.y, g ? 0.f : v[k4 * 4 + 1], fe);
+          fe = MFMA(a.z, g ? 0.f : v[k4 * 4 + 2], fe);
+          fe = MFMA(a.w, g ? 0.f : v[k4 * 4 + 3], fe);
+        }
+      }
+      if (any_yang) {
+#pragma unroll
+        for (int k4 = 0; k4 < KS_BASIS / 4; ++k4) {
+          const f32x4 a = BAS[(KS_BASIS / 4 + k4) * 64 + lane];
+          fe = MFMA(a.x, g ? v[k4 * 4 + 0] : 0.f, fe);
+          fe = MFMA(a.y, g ? v[k4 * 4 + 1] : 0.f, fe);
+          fe = MFMA(a.z, g ? v[k4 * 4 + 2] : 0.f, fe);
+          fe = MFMA(a.w, g ? v[k4 * 4 + 3] : 0.f, fe);
+        }
+      }
+    }
+
+    if (MODE == MODE_APP) {
+      if (valid) {
+        float* o = A.out + m * APP_DIM;
+#pragma unroll
+        for (int r = 0; r < NSLOT; ++r)
+          if (2 * r + h < APP_DIM) o[2 * r + h] = fe[r];
+      }
+      continue;
+    }
+
+    // ---- view-direction slots (3 raw + 12 encodings, 8 per lane half) -------------------------------
+    float vw[8];
+    {
+      const float d[3] = {vd0, vd1, vd2};
+      float vl[16];
+#pragma unroll
+      for (int e = 0; e < 3; ++e) {
+        vl[e] = d[e];
+        sincos_f32(d[e], vl[3 + 2 * e], vl[9 + 2 * e]);
+        sincos_f32(__fmul_rn(d[e], 2.f), vl[4 + 2 * e], vl[10 + 2 * e]);
+      }
+      vl[15] = 0.f;
+#pragma unroll
+      for (int t = 0; t < 8; ++t) vw[t] = h ? vl[8 + t] : vl[t];
+    }
+
+    // ---- layer 1: 150 -> 128.  K-outer: four accumulators (one per 32-unit M-tile) stay live, the
+    // B operand of k-step kk is produced right before it is consumed -------------------------------
+    f32x16 H[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 b = B1[(mt * 2 + hw) * 4 + q];
+        H[mt][q * 4 + 0] = b.x; H[mt][q * 4 + 1] = b.y; H[mt][q * 4 + 2] = b.z; H[mt][q * 4 + 3] = b.w;
+      }
+    {
+      f32x4 a[4];
+      float s1 = 0.f, c1 = 0.f, s2 = 0.f, c2 = 0.f;
+#pragma unroll
+      for (int kk = 0; kk < KS1; ++kk) {
+        if ((kk & 3) == 0) {
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt) a[mt] = W1[((kk >> 2) * 4 + mt) * 64 + lw];
+        }
+        float x;
+        if (kk < 5 * NSLOT) {
+          const int r = kk / 5, kind = kk % 5;
+          if (kind == 0) {
+            sincos_f32(fe[r], s1, c1);
+            sincos_f32(__fmul_rn(fe[r], 2.f), s2, c2);
+          }
+          x = kind == 0 ? fe[r] : (kind == 1 ? s1 : (kind == 2 ? s2 : (kind == 3 ? c1 : c2)));
+        } else if (kk < 5 * NSLOT + 8) {
+          x = vw[kk - 5 * NSLOT];
+        } else {
+          x = 0.f;
+        }
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) H[mt] = MFMA(a[mt][kk & 3], x, H[mt]);
+      }
+    }
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) H[mt][r] = fmaxf(H[mt][r], 0.f);
+
+    // ---- layer 2: 128 -> 128 (K-outer again), then layer 3: 128 -> 3 on the VALU -----------------------
+    f32x16 G[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 b = B2[(mt * 2 + hw) * 4 + q];
+        G[mt][q * 4 + 0] = b.x; G[mt][q * 4 + 1] = b.y; G[mt][q * 4 + 2] = b.z; G[mt][q * 4 + 3] = b.w;
+      }
+    {
+      f32x4 a[4];
+#pragma unroll
+      for (int kk = 0; kk < KS2; ++kk) {
+        if ((kk & 3) == 0) {
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt) a[mt] = W2[((kk >> 2) * 4 + mt) * 64 + lw];
+        }
+        const float x = H[kk >> 4][kk & 15];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) G[mt] = MFMA(a[mt][kk & 3], x, G[mt]);
+      }
+    }
+    float o0 = 0.f, o1 = 0.f, o2 = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const f32x4 w = W3[(mt * 2 + hw) * 16 + r];
+        const float hv = fmaxf(G[mt][r], 0.f);
+        o0 += hv * w.x; o1 += hv * w.y; o2 += hv * w.z;
+      }
+    o0 += __shfl_xor(o0, 32, 64);
+    o1 += __shfl_xor(o1, 32, 64);
+    o2 += __shfl_xor(o2, 32, 64);
+    if (valid && h == 0) {
+      const float* b3 = lds + OFF_B3;
+      float* o = A.out + m * 3;
+      o[0] = sigmoidf(o0 + b3[0]);
+      o[1] = sigmoidf(o1 + b3[1]);
+      o[2] = sigmoidf(o2 + b3[2]);
+    }
+  }
+}
+
+int check_shade_config(const ego_scene* sc, const char* who, bool need_tables, bool need_mlp) {
+  if (!sc) return ego_fail(EGO_E_BADARG, "%s: null scene", who);
+  if (!sc->packed) return ego_fail(EGO_E_BADARG, "%s: scene.packed is null (call ego_pack_mlp first)", who);
+  if (sc->app_dim != APP_DIM) return ego_fail(EGO_E_UNSUPPORTED, "%s: app_dim %d (supported: 27)", who, sc->app_dim);
+  if (need_tables) {
+    if (sc->app.n_comp != APP_C) return ego_fail(EGO_E_UNSUPPORTED, "%s: appearance n_comp %d (supported: 48)", who, sc->app.n_comp);
+    for (int g = 0; g < 2; ++g)
+      for (int i = 0; i < 3; ++i)
+        if (!sc->app.plane[g][i] || !sc->app.line[g][i]) return ego_fail(EGO_E_BADARG, "%s: null appearance table", who);
+  }
+  if (need_mlp && (sc->mlp_in != MLP_IN || sc->mlp_hidden != HID || sc->view_pe != 2 || sc->fea_pe != 2))
+    return ego_fail(EGO_E_UNSUPPORTED, "%s: MLP_Fea config in=%d hidden=%d view_pe=%d fea_pe=%d (supported: 150/128/2/2)", who,
+                    sc->mlp_in, sc->mlp_hidden, sc->view_pe, sc->fea_pe);
+  return EGO_OK;
+}
+
+unsigned shade_grid(int64_t M) {
+  const int64_t tiles = (M + 31) >> 5;
+  const int64_t wgs = (tiles + 7) / 8;
+  return (unsigned)(wgs < 256 ? wgs : 256);  // persistent: one 8-wave workgroup per CU
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t ego_packed_floats(void) { return PACKED_FLOATS; }
+
+int ego_pack_mlp(const ego_scene* sc, float* packed_out, void* stream) {
+  EGO_REQUIRE(sc && packed_out, "pack_mlp: null argument");
+  for (int i = 0; i < 3; ++i) EGO_REQUIRE(sc->mlp_w[i] && sc->mlp_b[i], "pack_mlp: null MLP weight");
+  EGO_REQUIRE(sc->basis[0] && sc->basis[1], "pack_mlp: null basis matrix");
+  if (sc->app_dim != APP_DIM || sc->app.n_comp != APP_C || sc->mlp_in != MLP_IN || sc->mlp_hidden != HID ||
+      sc->view_pe != 2 || sc->fea_pe != 2)
+    return ego_fail(EGO_E_UNSUPPORTED, "pack_mlp: only app_dim=27, n_comp=48, MLP_Fea 150/128 with view_pe=fea_pe=2 is supported");
+  k_pack_mlp<<<(PACKED_FLOATS + 255) / 256, 256, 0, (hipStream_t)stream>>>(sc->mlp_w[0], sc->mlp_b[0], sc->mlp_w[1], sc->mlp_b[1],
+                                                                          sc->mlp_w[2], sc->mlp_b[2], sc->basis[0], sc->basis[1],
+                                                                          packed_out);
+  return ego_launch_status("k_pack_mlp");
+}
+
+int ego_app_feature(const ego_scene* sc, const float* c7n, int64_t M, float* out, void* stream) {
+  EGO_REQUIRE(c7n && out && M >= 0 && M < (1ll << 31), "app_feature: null argument or M >= 2^31");
+  if (int e = check_shade_config(sc, "app_feature", true, false)) return e;
+  if (M == 0) return EGO_OK;
+  ShadeArgs a{};
+  a.c = make_coords(*sc); a.F = make_field(sc->app); a.packed = sc->packed; a.c7n = c7n; a.out = out; a.M = M; a.S = 1;
+  k_shade<MODE_APP><<<shade_grid(M), 512, 0, (hipStream_t)stream>>>(a);
+  return ego_launch_status("k_shade<APP>");
+}
+
+int ego_mlp_fea(const ego_scene* sc, const float* viewdirs, const float* feat, int64_t M, float* rgb, void* stream) {
+  EGO_REQUIRE(viewdirs && feat && rgb && M >= 0 && M < (1ll << 31), "mlp_fea: null argument or M >= 2^31");
+  if (int e = check_shade_config(sc, "mlp_fea", false, true)) return e;
+  if (M == 0) return EGO_OK;
+  ShadeArgs a{};
+  a.c = make_coords(*sc); a.packed = sc->packed; a.feat = feat; a.dirs = viewdirs; a.out = rgb; a.M = M; a.S = 1;
+  k_shade<MODE_MLP><<<shade_grid(M), 512, 0, (hipStream_t)stream>>>(a);
+  return ego_launch_status("k_shade<MLP>");
+}
+
+int ego_shade(const ego_scene* sc, const float* rays, const float* z, int64_t N, int32_t S, float* rgb, void* stream) {
+  EGO_REQUIRE(rays && z && rgb && N >= 0 && S >= 1 && N * (int64_t)S < (1ll << 31), "shade: null argument or N*S >= 2^31");
+  if (int e = check_shade_config(sc, "shade", true, true)) return e;
+  EGO_REQUIRE(sc->r_lut && sc->n_r_lut >= 2 && sc->n_r_lut <= LUT_MAX, "shade: r_lut missing or > 1024 entries");
+  if (N == 0) return EGO_OK;
+  ShadeArgs a{};
+  a.c = make_coords(*sc); a.F = make_field(sc->app); a.packed = sc->packed; a.rays = rays; a.z = z; a.out = rgb;
+  a.M = N * (int64_t)S; a.S = S;
+  k_shade<MODE_SHADE><<<shade_grid(a.M), 512, 0, (hipStream_t)stream>>>(a);
+  return ego_launch_status("k_shade<SHADE>");
+}
+
+}  // extern "C"

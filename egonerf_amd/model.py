@@ -1,0 +1,464 @@
+"""Host-side mirror of the reference model surface for the volume-rendering path:
+
+    models/tensorBase.py : raw2alpha, MLPRender_Fea, TensorBase (ctor kwargs, feature2density, save/load)
+    models/EgoNeRF.py    : EgoNeRF (forward, compute_densityfeature, compute_coarse_densityfeature,
+                           compute_appfeature, sample_ray_exp, update_coarse_sigma_grid,
+                           get_optparam_groups, save, load)
+    models/envmap.py     : EnvironmentMap
+
+Same names, argument meaning, state-dict keys and return tuples, so the parity tests read like calls into
+the reference.  All per-sample arithmetic runs in libegonerf_hip.so through the C ABI (egonerf_amd/_lib.py);
+PyTorch only owns device memory, streams and parameters.  There is no CPU fallback: calling the path with
+CPU tensors raises.
+
+Parameters keep the reference's shapes ((1,C,H,W) planes, (1,C,L,1) lines) but are allocated channel-last
+([H][W][C] in memory), which is the layout the kernels gather from; `state_dict()` keys and shapes are the
+reference's, so checkpoints interchange.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional
+
+import numpy as np
+import torch
+import torch.nn
+
+from . import _lib
+from .coordinates import YinYangSphericalCoords, _require_cuda
+
+MAT_MODE = [[0, 1], [0, 2], [1, 2]]  # models/EgoNeRF.py:30-33
+VEC_MODE = [2, 1, 0]
+
+
+def _call(name: str, *args) -> None:
+    _lib.check(getattr(_lib.load(), name)(*args), name)
+
+
+def _f32c(t: torch.Tensor) -> torch.Tensor:
+    return t.contiguous().float()
+
+
+def _channel_last_param(C_: int, H: int, W: int, scale: float, device) -> torch.nn.Parameter:
+    """Reference-shaped (1,C,H,W) parameter whose memory is [H][W][C]."""
+    mem = torch.empty(1, H, W, C_, device=device, dtype=torch.float32)
+    mem.copy_(scale * torch.randn(1, C_, H, W).permute(0, 2, 3, 1))
+    return torch.nn.Parameter(mem.permute(0, 3, 1, 2))
+
+
+def _table_ptr(t: torch.Tensor) -> int:
+    """Device pointer of a (1,C,H,W) tensor after checking its memory really is [H][W][C]."""
+    if not t.permute(0, 2, 3, 1).is_contiguous():
+        raise RuntimeError(f"table of shape {tuple(t.shape)} / strides {t.stride()} is not channel-last; "
+                           "assign parameters with param.data.copy_(...) so the layout is kept")
+    return t.data_ptr()
+
+
+# ---------------------------------------------------------------------------------------------------
+# models/tensorBase.py
+# ---------------------------------------------------------------------------------------------------
+def raw2alpha(sigma: torch.Tensor, dist: torch.Tensor):
+    """alpha, weights, bg_weight of tensorBase.py:22-27 (sigma, dist: [N_rays, N_samples])."""
+    _require_cuda(sigma, "raw2alpha")
+    sigma, dist = _f32c(sigma), _f32c(dist)
+    N, S = sigma.shape
+    alpha, weight = torch.empty_like(sigma), torch.empty_like(sigma)
+    bg = torch.empty(N, 1, device=sigma.device)
+    _call("ego_raw2alpha", sigma.data_ptr(), dist.data_ptr(), N, S, alpha.data_ptr(), weight.data_ptr(), bg.data_ptr(),
+          _lib.stream_handle())
+    return alpha, weight, bg
+
+
+class EnvironmentMap:
+    """models/envmap.py:17-37: plain requires_grad tensor `emission` [3, 2h, h] (not an nn.Parameter)."""
+
+    def __init__(self, h=1000, init_strategy="random", device="cuda"):
+        if init_strategy == "random":
+            self.emission = torch.rand((3, 2 * h, h), requires_grad=True, device=device)
+        elif init_strategy == "zero":
+            self.emission = torch.zeros((3, 2 * h, h), requires_grad=True, device=device)
+        else:
+            raise ValueError("Unknown environment map initialization: {}".format(init_strategy))
+
+    def get_radiance(self, direction: torch.Tensor) -> torch.Tensor:
+        _require_cuda(direction, "EnvironmentMap.get_radiance")
+        d = _f32c(direction)
+        out = torch.empty(d.shape[0], 3, device=d.device)
+        sc = _lib.Scene()
+        em = self.emission.detach().contiguous()
+        sc.envmap, sc.envmap_h = em.data_ptr(), em.shape[2]
+        _call("ego_envmap_radiance", sc, d.data_ptr(), d.shape[0], out.data_ptr(), _lib.stream_handle())
+        return out
+
+    def load_envmap(self, emission, device):
+        self.emission = torch.tensor(np.asarray(emission.detach().cpu() if torch.is_tensor(emission) else emission),
+                                     requires_grad=True, device=device, dtype=torch.float32)
+
+
+class MLPRender_Fea(torch.nn.Module):
+    """tensorBase.py:54-78.  The Linear layers only hold the weights (state-dict keys `mlp.{0,2,4}.*`);
+    forward runs the fused PE + 150->128->128->3 + sigmoid MFMA kernel."""
+
+    def __init__(self, inChannel, viewpe=6, feape=6, featureC=128):
+        super().__init__()
+        self.in_mlpC = 2 * viewpe * 3 + 2 * feape * inChannel + 3 + inChannel
+        self.viewpe, self.feape = viewpe, feape
+        self.mlp = torch.nn.Sequential(torch.nn.Linear(self.in_mlpC, featureC), torch.nn.ReLU(inplace=True),
+                                       torch.nn.Linear(featureC, featureC), torch.nn.ReLU(inplace=True),
+                                       torch.nn.Linear(featureC, 3))
+        torch.nn.init.constant_(self.mlp[-1].bias, 0)
+        self._owner = None  # set by the model: provides the packed weights
+
+    def forward(self, pts, viewdirs, features):
+        _require_cuda(features, "MLPRender_Fea")
+        if self._owner is None:
+            raise RuntimeError("MLPRender_Fea must belong to an EgoNeRF model (it owns the packed MFMA weights)")
+        model = self._owner()
+        v = _f32c(viewdirs.reshape(-1, 3))
+        f = _f32c(features.reshape(-1, features.shape[-1]))
+        out = torch.empty(f.shape[0], 3, device=f.device)
+        _call("ego_mlp_fea", model.scene(), v.data_ptr(), f.data_ptr(), f.shape[0], out.data_ptr(), _lib.stream_handle())
+        return out.view(*features.shape[:-1], 3)
+
+
+class TensorBase(torch.nn.Module):
+    """Constructor surface and shared helpers of tensorBase.py:132-186, 206-217, 241-295, 415-419."""
+
+    def __init__(self, aabb, gridSize, device, coordinates, density_n_comp=8, appearance_n_comp=24, app_dim=27,
+                 shadingMode="MLP_PE", alphaMask=None, near_far=[2.0, 6.0], density_shift=-10, alphaMask_thres=0.001,
+                 distance_scale=25, rayMarch_weight_thres=0.0001, pos_pe=6, view_pe=6, fea_pe=6, featureC=128,
+                 step_ratio=2.0, fea2denseAct="softplus", use_envmap=False, envmap_res_H=1000, envmap=None,
+                 coarse_sigma_grid_update_rule=None, coarse_sigma_grid_reso=None, interval_th=False):
+        super().__init__()
+        as_list = lambda n: list(n) if isinstance(n, (list, tuple)) else [n] * 3
+        self.density_n_comp, self.app_n_comp, self.app_dim = as_list(density_n_comp), as_list(appearance_n_comp), app_dim
+        self.aabb = torch.as_tensor(aabb, dtype=torch.float32)
+        self.alphaMask = alphaMask
+        self.device = device
+        self.density_shift, self.alphaMask_thres, self.distance_scale = density_shift, alphaMask_thres, distance_scale
+        self.rayMarch_weight_thres, self.fea2denseAct = rayMarch_weight_thres, fea2denseAct
+        self.near_far, self.step_ratio = list(near_far), step_ratio
+        self.update_stepSize(gridSize)
+        self.envmap = None
+        if use_envmap:
+            if envmap is None:
+                self.init_envmap(envmap_res_H, init_strategy="random", device=device)
+            else:
+                self.envmap = EnvironmentMap(h=envmap.emission.shape[2], init_strategy="zero", device=device)
+                self.envmap.load_envmap(envmap.emission, device=device)
+        self.shadingMode, self.pos_pe, self.view_pe, self.fea_pe, self.featureC = shadingMode, pos_pe, view_pe, fea_pe, featureC
+        if shadingMode != "MLP_Fea":
+            raise NotImplementedError(f"shadingMode {shadingMode!r}: the HIP path implements MLP_Fea (every shipped config, "
+                                      "configs/EgoNeRF/common.txt:34)")
+        self.renderModule = MLPRender_Fea(self.app_dim, view_pe, fea_pe, featureC).to(device)
+        self.coordinates = coordinates
+        self.coarse_sigma_grid_update_rule = coarse_sigma_grid_update_rule
+
+    def init_envmap(self, envmap_res_H, init_strategy="zero", device="cuda"):
+        self.envmap = EnvironmentMap(h=envmap_res_H, init_strategy=init_strategy, device=device)
+
+    def update_stepSize(self, gridSize):
+        """tensorBase.py:206-217 (values unused by EgoNeRF.forward, kept for get_kwargs/alpha-mask parity)."""
+        self.aabbSize = self.aabb[1] - self.aabb[0]
+        self.invaabbSize = 2.0 / self.aabbSize
+        self.gridSize = torch.LongTensor(list(gridSize))
+        self.units = self.aabbSize / (self.gridSize - 1)
+        self.stepSize = torch.mean(self.units) * self.step_ratio
+        self.aabbHalfDiag = torch.sqrt(torch.sum(torch.square(self.aabbSize))) / 2.0
+        self.nSamples = int((self.aabbHalfDiag / self.stepSize).item()) + 1
+
+    def get_kwargs(self):
+        return {"aabb": self.aabb, "gridSize": self.gridSize.tolist(), "density_n_comp": self.density_n_comp,
+                "appearance_n_comp": self.app_n_comp, "app_dim": self.app_dim, "density_shift": self.density_shift,
+                "alphaMask_thres": self.alphaMask_thres, "distance_scale": self.distance_scale,
+                "rayMarch_weight_thres": self.rayMarch_weight_thres, "fea2denseAct": self.fea2denseAct,
+                "near_far": self.near_far, "step_ratio": self.step_ratio, "shadingMode": self.shadingMode,
+                "pos_pe": self.pos_pe, "view_pe": self.view_pe, "fea_pe": self.fea_pe, "featureC": self.featureC,
+                "coordinates": self.coordinates, "use_envmap": self.envmap is not None, "envmap": self.envmap,
+                "coarse_sigma_grid_update_rule": self.coarse_sigma_grid_update_rule}
+
+    def feature2density(self, density_features: torch.Tensor) -> torch.Tensor:
+        """tensorBase.py:415-419."""
+        _require_cuda(density_features, "feature2density")
+        f = _f32c(density_features)
+        out = torch.empty_like(f)
+        sc = _lib.Scene()
+        sc.act_softplus, sc.density_shift = int(self.fea2denseAct == "softplus"), float(self.density_shift)
+        _call("ego_feature2density", sc, f.data_ptr(), f.numel(), out.data_ptr(), _lib.stream_handle())
+        return out
+
+
+# ---------------------------------------------------------------------------------------------------
+# models/EgoNeRF.py
+# ---------------------------------------------------------------------------------------------------
+class EgoNeRF(TensorBase):
+    def __init__(self, aabb, gridSize, device, coordinates, **kargs):
+        super().__init__(aabb, gridSize, device, coordinates, **kargs)
+        assert isinstance(coordinates, YinYangSphericalCoords), "EgoNeRF needs YinYangSphericalCoords (EgoNeRF.py:522)"
+        self.matMode_yin = self.matMode_yang = MAT_MODE
+        self.vecMode_yin = self.vecMode_yang = VEC_MODE
+        self.init_svd_volume(gridSize[0], device)
+        self.renderModule._owner = _WeakOwner(self)
+        self._scene_cache = None
+        self._packed = None
+        self._packed_versions = None
+        self._sched_cache = {}
+        self.coarse_sigma_plane_yin, self.coarse_sigma_line_yin = [None] * 3, [None] * 3
+        self.coarse_sigma_plane_yang, self.coarse_sigma_line_yang = [None] * 3, [None] * 3
+        if self.coarse_sigma_grid_update_rule is not None:
+            if self.coarse_sigma_grid_update_rule != "conv":
+                raise NotImplementedError  # EgoNeRF.py:92-94
+            if torch.device(device).type == "cuda":
+                self.update_coarse_sigma_grid()
+
+    # -- parameters -------------------------------------------------------------------------------------
+    def init_one_svd(self, n_component, gridSize, scale, device):
+        """EgoNeRF.py:102-122, channel-last memory."""
+        out = []
+        for _grid in ("yin", "yang"):
+            planes, lines = [], []
+            for i in range(3):
+                m0, m1 = MAT_MODE[i]
+                planes.append(_channel_last_param(n_component[i], gridSize[m1], gridSize[m0], scale, device))
+                lines.append(_channel_last_param(n_component[i], gridSize[VEC_MODE[i]], 1, scale, device))
+            out += [torch.nn.ParameterList(planes), torch.nn.ParameterList(lines)]
+        return out
+
+    def init_svd_volume(self, res, device):
+        g = self.gridSize.tolist()
+        (self.density_plane_yin, self.density_line_yin, self.density_plane_yang,
+         self.density_line_yang) = self.init_one_svd(self.density_n_comp, g, 0.1, device)
+        (self.app_plane_yin, self.app_line_yin, self.app_plane_yang,
+         self.app_line_yang) = self.init_one_svd(self.app_n_comp, g, 0.1, device)
+        self.basis_mat_yin = torch.nn.Linear(sum(self.app_n_comp), self.app_dim, bias=False).to(device)
+        self.basis_mat_yang = torch.nn.Linear(sum(self.app_n_comp), self.app_dim, bias=False).to(device)
+
+    def get_optparam_groups(self, lr_init_spatialxyz=0.02, lr_init_network=0.001, lr_init_envmap=0.1):
+        """EgoNeRF.py:139-156."""
+        gv = []
+        for g in ("yin", "yang"):
+            gv += [{"params": getattr(self, f"density_line_{g}"), "lr": lr_init_spatialxyz},
+                   {"params": getattr(self, f"density_plane_{g}"), "lr": lr_init_spatialxyz},
+                   {"params": getattr(self, f"app_line_{g}"), "lr": lr_init_spatialxyz},
+                   {"params": getattr(self, f"app_plane_{g}"), "lr": lr_init_spatialxyz},
+                   {"params": getattr(self, f"basis_mat_{g}").parameters(), "lr": lr_init_network}]
+        gv += [{"params": self.renderModule.parameters(), "lr": lr_init_network}]
+        if self.envmap is not None:
+            gv += [{"params": self.envmap.emission, "lr": lr_init_envmap}]
+        return gv
+
+    @torch.no_grad()
+    def update_coarse_sigma_grid(self):
+        """2x average-pooled density tables (EgoNeRF.py:124-133), kept channel-last."""
+        if self.coarse_sigma_grid_update_rule != "conv":
+            raise NotImplementedError
+        st = _lib.stream_handle()
+        for g in ("yin", "yang"):
+            for i in range(3):
+                for what in ("plane", "line"):
+                    src = getattr(self, f"density_{what}_{g}")[i]
+                    _require_cuda(src, "update_coarse_sigma_grid")
+                    _, C_, H, W = src.shape
+                    dst = torch.empty(1, H // 2, 1 if W == 1 else W // 2, C_, device=src.device)
+                    _call("ego_avgpool_table", _table_ptr(src), H, W, C_, dst.data_ptr(), st)
+                    getattr(self, f"coarse_sigma_{what}_{g}")[i] = dst.permute(0, 3, 1, 2)
+        self._scene_cache = None
+
+    # -- C-ABI scene ----------------------------------------------------------------------------------------
+    def _mlp_tensors(self) -> List[torch.Tensor]:
+        m = self.renderModule.mlp
+        return [m[0].weight, m[0].bias, m[2].weight, m[2].bias, m[4].weight, m[4].bias, self.basis_mat_yin.weight,
+                self.basis_mat_yang.weight]
+
+    def _fill_field(self, f: "_lib.VmField", prefix: str, n_comp, res, coarse=False):
+        if len(set(n_comp)) != 1:
+            raise NotImplementedError("per-plane component counts must be equal (true for every shipped config)")
+        f.n_comp = n_comp[0]
+        f.res[:] = res
+        for gi, g in enumerate(("yin", "yang")):
+            planes = getattr(self, f"coarse_sigma_plane_{g}" if coarse else f"{prefix}_plane_{g}")
+            lines = getattr(self, f"coarse_sigma_line_{g}" if coarse else f"{prefix}_line_{g}")
+            for i in range(3):
+                if planes[i] is None:
+                    raise RuntimeError("coarse density tables missing: call update_coarse_sigma_grid()")
+                f.plane[gi][i] = _table_ptr(planes[i])
+                f.line[gi][i] = _table_ptr(lines[i])
+
+    def scene(self) -> "_lib.Scene":
+        """The ego_scene struct for the current parameters (re-packs the MFMA weights when they changed)."""
+        dev = self.density_plane_yin[0].device
+        if dev.type != "cuda":
+            raise RuntimeError(f"model parameters are on {dev}; the EgoNeRF hot path runs only on the HIP device")
+        mlp = self._mlp_tensors()
+        versions = tuple((t.data_ptr(), t._version) for t in mlp)
+        keys = tuple(p.data_ptr() for p in self.parameters()) + (None if self.envmap is None else self.envmap.emission.data_ptr(),)
+        if self._scene_cache is not None and self._scene_cache[0] == keys and self._packed_versions == versions:
+            return self._scene_cache[1]
+        lib = _lib.load()
+        sc = _lib.Scene()
+        self.coordinates.fill_scene(sc, dev)
+        sc.act_softplus = int(self.fea2denseAct == "softplus")
+        sc.density_shift, sc.distance_scale = float(self.density_shift), float(self.distance_scale)
+        g = self.gridSize.tolist()
+        self._fill_field(sc.density, "density", self.density_n_comp, g)
+        self._fill_field(sc.app, "app", self.app_n_comp, g)
+        if self.coarse_sigma_plane_yin[0] is not None:
+            self._fill_field(sc.density_coarse, "density", self.density_n_comp, [v // 2 for v in g], coarse=True)
+        holds = [t.detach().contiguous() for t in mlp]
+        sc.mlp_w[:] = [holds[0].data_ptr(), holds[2].data_ptr(), holds[4].data_ptr()]
+        sc.mlp_b[:] = [holds[1].data_ptr(), holds[3].data_ptr(), holds[5].data_ptr()]
+        sc.basis[:] = [holds[6].data_ptr(), holds[7].data_ptr()]
+        sc.app_dim = self.app_dim
+        sc.mlp_in, sc.mlp_hidden = self.renderModule.in_mlpC, self.featureC
+        sc.view_pe, sc.fea_pe = self.view_pe, self.fea_pe
+        if self._packed is None or self._packed.device != dev:
+            self._packed = torch.empty(lib.ego_packed_floats(), device=dev)
+        _call("ego_pack_mlp", sc, self._packed.data_ptr(), _lib.stream_handle())
+        sc.packed = self._packed.data_ptr()
+        if self.envmap is not None:
+            em = self.envmap.emission.detach()
+            if not em.is_contiguous():
+                raise RuntimeError("envmap.emission must be contiguous [3][2h][h]")
+            sc.envmap, sc.envmap_h = em.data_ptr(), em.shape[2]
+        self._scene_cache = (keys, sc, holds)
+        self._packed_versions = versions
+        return sc
+
+    # -- stage methods (reference public API) ----------------------------------------------------------------
+    def _sched(self, n_samples: int, device) -> torch.Tensor:
+        key = (n_samples, str(device))
+        if key not in self._sched_cache:
+            near, far = self.near_far
+            self._sched_cache[key] = self.coordinates.sample_schedule(near, far, n_samples).to(device)
+        return self._sched_cache[key]
+
+    def sample_ray_exp(self, rays_o, rays_d, is_train=True, N_samples=-1, jitter: Optional[torch.Tensor] = None):
+        """EgoNeRF.py:56-87 -> (rays_pts [N,S,3], interpx [N,S], ~mask_outbbox [N,S]).  `jitter` [N,S] pins the
+        training noise (the reference draws it with torch.rand_like on the CPU generator)."""
+        _require_cuda(rays_o, "sample_ray_exp")
+        self.coordinates._require_supported()
+        N, S = rays_d.shape[-2], N_samples
+        rays = torch.cat([_f32c(rays_o), _f32c(rays_d)], -1).contiguous()
+        if is_train and jitter is None:
+            jitter = torch.rand(N, S).to(rays.device)
+        jit = _f32c(jitter) if is_train else None
+        xyz = torch.empty(N, S, 3, device=rays.device)
+        z = torch.empty(N, S, device=rays.device)
+        _call("ego_sample_ray_exp", rays.data_ptr(), self._sched(S, rays.device).data_ptr(), _lib.ptr(jit),
+              float(self.near_far[0]), N, S, xyz.data_ptr(), z.data_ptr(), _lib.stream_handle())
+        aabb = self.aabb.to(rays.device)
+        mask_outbbox = ((aabb[0] > xyz) | (xyz > aabb[1])).any(dim=-1)
+        return xyz, z, ~mask_outbbox
+
+    def _density(self, coords_sampled, coarse: int):
+        _require_cuda(coords_sampled, "compute_densityfeature")
+        c = _f32c(coords_sampled)
+        out = torch.empty(c.shape[:-1], device=c.device)
+        _call("ego_density_feature", self.scene(), c.data_ptr(), c.numel() // 7, coarse, out.data_ptr(), _lib.stream_handle())
+        return out
+
+    def compute_densityfeature(self, coords_sampled):
+        """EgoNeRF.py:291-347: [...,7] normalised coords -> [...]."""
+        return self._density(coords_sampled, 0)
+
+    def compute_coarse_densityfeature(self, coords_sampled, coarse_sigma_grid_update_rule="conv"):
+        """EgoNeRF.py:232-289."""
+        return self._density(coords_sampled, 1)
+
+    def compute_appfeature(self, coords_sampled):
+        """EgoNeRF.py:349-413: [...,7] -> [..., app_dim]."""
+        _require_cuda(coords_sampled, "compute_appfeature")
+        c = _f32c(coords_sampled)
+        out = torch.empty(*c.shape[:-1], self.app_dim, device=c.device)
+        _call("ego_app_feature", self.scene(), c.data_ptr(), c.numel() // 7, out.data_ptr(), _lib.stream_handle())
+        return out
+
+    # -- the hot path -------------------------------------------------------------------------------------------
+    def forward(self, rays_chunk, white_bg=True, is_train=False, ndc_ray=False, n_coarse=-1, n_fine=0, exp_sampling=False,
+                pretrain_envmap=False, pivotal_sample_th=0.0, resampling=False, use_coarse_sample=True, interval_th=False,
+                jitter: Optional[torch.Tensor] = None, u: Optional[torch.Tensor] = None):
+        """EgoNeRF.forward (EgoNeRF.py:491-602) -> (rgb_map [N,3], depth_map [N], bg_map|None, env_map|None,
+        alpha [N, S(+1)]).  `white_bg`, `pivotal_sample_th`, `interval_th` are accepted and unused, as in the
+        reference.  `jitter` [N,n_coarse] / `u` [N,n_fine] pin the is_train noise."""
+        _require_cuda(rays_chunk, "EgoNeRF.forward")
+        if pretrain_envmap:
+            return self.envmap.get_radiance(rays_chunk[:, 3:6])
+        if ndc_ray:
+            raise NotImplementedError  # EgoNeRF.py:503-504
+        if not exp_sampling:
+            raise NotImplementedError("exp_sampling=False (uniform aabb-clipped steps) is outside the HIP path; every "
+                                      "shipped config sets exp_sampling (configs/EgoNeRF/common.txt:4)")
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()) and is_train:
+            raise NotImplementedError("the HIP backward (config 4) is not wired into autograd yet; wrap calls in torch.no_grad()")
+        rays = _f32c(rays_chunk[:, :6])
+        N, dev = rays.shape[0], rays.device
+        sc = self.scene()
+        args = _lib.RenderArgs()
+        args.n_coarse, args.n_fine = int(n_coarse), int(n_fine)
+        args.resampling, args.use_coarse_sample = int(bool(resampling)), int(bool(use_coarse_sample))
+        args.r_sched = self._sched(n_coarse, dev).data_ptr()
+        args.near_ = float(self.near_far[0])
+        if is_train:
+            if jitter is None:
+                jitter = torch.rand(N, n_coarse).to(dev)  # CPU generator like EgoNeRF.py:81
+            if resampling and u is None:
+                u = torch.rand(N, n_fine, device=dev)  # device generator like ray_utils.py:169
+            jitter = _f32c(jitter)
+            args.jitter = jitter.data_ptr()
+            if resampling:
+                u = _f32c(u)
+                args.u = u.data_ptr()
+        S = (n_coarse + n_fine if use_coarse_sample else n_fine) if resampling else n_coarse
+        lib = _lib.load()
+        ws_bytes = lib.ego_render_workspace_bytes(N, C.byref(args))
+        if ws_bytes < 0:
+            raise RuntimeError("ego_render_workspace_bytes rejected the arguments (n_coarse < 2?)")
+        ws = torch.empty(max(ws_bytes, 4) // 4, device=dev)
+        has_env = self.envmap is not None
+        rgb_map = torch.empty(N, 3, device=dev)
+        depth = torch.empty(N, device=dev)
+        alpha = torch.empty(N, S + int(has_env), device=dev)
+        bg_map = torch.empty(N, 3, device=dev) if has_env else None
+        env_map = torch.empty(N, 3, device=dev) if has_env else None
+        _call("ego_render_forward", sc, C.byref(args), rays.data_ptr(), N, ws.data_ptr(), rgb_map.data_ptr(), depth.data_ptr(),
+              alpha.data_ptr(), _lib.ptr(bg_map), _lib.ptr(env_map), _lib.stream_handle())
+        return rgb_map, depth, bg_map, env_map, alpha
+
+    # -- checkpoints (EgoNeRF.py:158-187) -----------------------------------------------------------------------------
+    def save(self, path, global_step):
+        ckpt = {"kwargs": self.get_kwargs(), "state_dict": {k: v.contiguous() for k, v in self.state_dict().items()},
+                "global_step": global_step}
+        if self.envmap is not None:
+            ckpt.update({"envmap.emission": self.envmap.emission.detach().cpu().numpy(),
+                         "envmap_res_H": self.envmap.emission.shape[2]})
+        torch.save(ckpt, path)
+
+    def load(self, ckpt):
+        if self.envmap is not None and "envmap.emission" in ckpt:
+            self.envmap = EnvironmentMap(h=ckpt["envmap_res_H"], init_strategy="zero", device=self.device)
+            self.envmap.load_envmap(emission=ckpt["envmap.emission"], device=self.device)
+        self.load_state_dict(ckpt["state_dict"])
+        self._scene_cache = None
+        if self.coarse_sigma_grid_update_rule == "conv":
+            self.update_coarse_sigma_grid()
+        return ckpt["global_step"]
+
+    def load_state_dict(self, state_dict, strict=True):
+        """Values are copied into the existing channel-last parameters (shapes/keys are the reference's)."""
+        r = super().load_state_dict(state_dict, strict=strict)
+        self._scene_cache = None
+        return r
+
+
+class _WeakOwner:
+    """Weak back-reference (keeps MLPRender_Fea out of the module graph cycle / state_dict)."""
+
+    def __init__(self, obj):
+        import weakref
+        self._r = weakref.ref(obj)
+
+    def __call__(self):
+        o = self._r()
+        if o is None:
+            raise RuntimeError("owning EgoNeRF model was freed")
+        return o

@@ -1,0 +1,101 @@
+"""Render driver: mirror of renderer.py:11-79 (volume_renderer) and the PSNR part of
+renderer.py:82-196 (evaluation), plus the multi-GPU sharding of SURVEY 8(e).
+
+Rays are independent, so N GPUs = N processes each rendering a contiguous block of rays with a
+replicated (read-only) model; the only exchange is the 2-float [sum of squared error, pixel count]
+all-reduce per image for PSNR and an optional gather of the tiles (torch.distributed: RCCL on GPUs,
+gloo in the CPU tests).
+"""
+from __future__ import annotations
+
+import time
+from typing import Callable, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+
+def volume_renderer(rays, model, chunk=4096, n_coarse=-1, n_fine=0, ndc_ray=False, white_bg=True, is_train=False,
+                    exp_sampling=False, device="cuda", empty_gpu_cache=False, pretrain_envmap=False, pivotal_sample_th=0.0,
+                    resampling=False, use_coarse_sample=True, interval_th=False, jitter=None, u=None):
+    """renderer.py:11-79.  Returns (rgb [N,3], depth [N], bg|None, env|None, alpha [N,S(+1)]); numpy arrays
+    when `empty_gpu_cache` (per-chunk D2H like the reference), torch tensors otherwise."""
+    if pretrain_envmap:
+        return model(rays_chunk=rays.to(device), pretrain_envmap=True)
+    outs: List[Tuple] = []
+    n_all = rays.shape[0]
+    for lo in range(0, n_all, chunk):
+        rays_chunk = rays[lo:lo + chunk].to(device)
+        o = model(rays_chunk, is_train=is_train, white_bg=white_bg, ndc_ray=ndc_ray, n_coarse=n_coarse, n_fine=n_fine,
+                  exp_sampling=exp_sampling, pivotal_sample_th=pivotal_sample_th, resampling=resampling,
+                  use_coarse_sample=use_coarse_sample, interval_th=interval_th,
+                  jitter=None if jitter is None else jitter[lo:lo + chunk], u=None if u is None else u[lo:lo + chunk])
+        if empty_gpu_cache:
+            o = tuple(None if t is None else t.cpu().numpy() for t in o)
+        outs.append(o)
+    cat = (lambda xs: np.concatenate(xs)) if empty_gpu_cache else (lambda xs: torch.cat(xs))
+    col = lambda j: None if outs[0][j] is None else cat([o[j] for o in outs])
+    return col(0), col(1), col(2), col(3), col(4)
+
+
+# ---------------------------------------------------------------------------------------------------
+# ray sharding + PSNR reduction (one process per GPU)
+# ---------------------------------------------------------------------------------------------------
+def shard_bounds(n: int, world_size: int, rank: int) -> Tuple[int, int]:
+    """Contiguous, balanced block [lo, hi) of n rays for `rank` (first n % world ranks get one extra)."""
+    base, extra = divmod(n, world_size)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def psnr_from_sse(sse: float, count: float) -> float:
+    """renderer.py:156-157: -10 log10(mean squared error)."""
+    return float(-10.0 * np.log(sse / count) / np.log(10.0))
+
+
+def sharded_render(render_fn: Callable[[torch.Tensor], torch.Tensor], rays: torch.Tensor, gt: Optional[torch.Tensor] = None,
+                   gather_image: bool = False, group=None):
+    """Each rank renders its block of `rays` with `render_fn(rays_block) -> rgb [n,3]`.
+
+    Returns dict(rgb_local, lo, hi, psnr (if gt given; identical on every rank), image (rank 0, if gather_image)).
+    No data-path collective: only the [sse, count] all-reduce and the optional tile gather.
+    """
+    import torch.distributed as dist
+
+    distributed = dist.is_available() and dist.is_initialized()
+    world = dist.get_world_size(group) if distributed else 1
+    rank = dist.get_rank(group) if distributed else 0
+    lo, hi = shard_bounds(rays.shape[0], world, rank)
+    rgb = render_fn(rays[lo:hi])
+    out = dict(rgb_local=rgb, lo=lo, hi=hi)
+    if gt is not None:
+        diff = rgb.double().clamp(0.0, 1.0) - gt[lo:hi].to(rgb.device).double()
+        stat = torch.stack([(diff * diff).sum(), torch.tensor(float(diff.numel()), device=rgb.device, dtype=torch.float64)])
+        if distributed:
+            dist.all_reduce(stat, op=dist.ReduceOp.SUM, group=group)
+        out["psnr"] = psnr_from_sse(stat[0].item(), stat[1].item())
+    if gather_image:
+        if distributed:
+            sizes = [shard_bounds(rays.shape[0], world, r) for r in range(world)]
+            pad = max(h - l for l, h in sizes)
+            buf = torch.zeros(pad, 3, device=rgb.device, dtype=rgb.dtype)
+            buf[: hi - lo] = rgb
+            tiles = [torch.empty_like(buf) for _ in range(world)] if rank == 0 else None
+            dist.gather(buf, tiles, dst=0, group=group)
+            if rank == 0:
+                out["image"] = torch.cat([t[: h - l] for t, (l, h) in zip(tiles, sizes)])
+        else:
+            out["image"] = rgb
+    return out
+
+
+@torch.no_grad()
+def evaluation_psnr(images_rays: Sequence[torch.Tensor], images_gt: Sequence[torch.Tensor], model, chunk=4096, device="cuda",
+                    **render_kw) -> List[float]:
+    """Per-image PSNR list with renderer.py:125-157 semantics (render -> clamp -> MSE -> dB), rays sharded over
+    the ranks of the default process group when one is initialised."""
+    psnrs = []
+    for rays, gt in zip(images_rays, images_gt):
+        fn = lambda block: volume_renderer(block, model, chunk=chunk, device=device, **render_kw)[0]
+        psnrs.append(sharded_render(fn, rays.view(-1, rays.shape[-1]), gt.view(-1, 3))["psnr"])
+    return psnrs

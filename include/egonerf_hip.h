@@ -1,0 +1,177 @@
+/*
+ * egonerf_hip.h — C ABI of libegonerf_hip.so: EgoNeRF's volume-rendering hot path on MI355X (gfx950).
+ *
+ * Plain pointers and sizes only (no torch types).  Every pointer marked "dev" is device memory owned
+ * by the caller; the library allocates nothing, keeps no global mutable state and launches every
+ * kernel on the hipStream_t handed in (`stream`, may be NULL = default stream).  All entry points
+ * return 0 on success or a negative EGO_E_* / positive hipError_t code; ego_last_error() returns a
+ * thread-local message.  The reference signals errors with Python exceptions / assert
+ * (models/EgoNeRF.py:504,522); the Python host layer turns non-zero codes into RuntimeError.
+ *
+ * Reference interface replaced by each entry point (paths relative to the reference repo):
+ *   ego_sample_ray_exp      EgoNeRF.sample_ray_exp                models/EgoNeRF.py:56-87
+ *   ego_from_cartesian      YinYangSphericalCoords.from_cartesian  models/coordinates.py:468-498
+ *   ego_normalize_coord     YinYangSphericalCoords.normalize_coord models/coordinates.py:442-466 (+ :110-131)
+ *   ego_density_feature     EgoNeRF.compute_densityfeature         models/EgoNeRF.py:291-347
+ *                           EgoNeRF.compute_coarse_densityfeature  models/EgoNeRF.py:232-289 (coarse=1)
+ *   ego_app_feature         EgoNeRF.compute_appfeature             models/EgoNeRF.py:349-413
+ *   ego_feature2density     TensorBase.feature2density             models/tensorBase.py:415-419
+ *   ego_raw2alpha           raw2alpha                              models/tensorBase.py:22-27
+ *   ego_mlp_fea             MLPRender_Fea.forward                  models/tensorBase.py:54-78
+ *   ego_sample_pdf_merge    sample_pdf + sort(cat(z, z_fine))      dataLoader/ray_utils.py:156-187, models/EgoNeRF.py:532-542
+ *   ego_envmap_radiance     EnvironmentMap.get_radiance            models/envmap.py:6-14,26-34
+ *   ego_avgpool_tables      EgoNeRF.update_coarse_sigma_grid       models/EgoNeRF.py:124-133
+ *   ego_pack_mlp            (new) weight re-layout for the MFMA kernels; no reference counterpart
+ *   ego_march_density       EgoNeRF.forward lines 507-529 / 544-553 (sampling -> sigma -> alpha,w)   models/EgoNeRF.py
+ *   ego_shade               EgoNeRF.forward lines 555-556 / 571-572 (app feature -> renderModule)   models/EgoNeRF.py
+ *   ego_composite           EgoNeRF.forward lines 579-598 (acc, rgb_map, envmap, clamp, depth)       models/EgoNeRF.py
+ *   ego_render_forward      EgoNeRF.forward (whole call)                                          models/EgoNeRF.py:491-602
+ *
+ * Table layout in HBM ("channel-last"): a reference plane parameter (1,C,H,W) is stored as [H][W][C]
+ * and a line parameter (1,C,L,1) as [L][C], fp32, so one bilinear tap is one contiguous C*4-byte read
+ * (64 B for the 16 density components, 192 B for the 48 appearance components).  torch's
+ * channels_last memory format of the reference-shaped tensor is exactly this layout.
+ */
+#ifndef EGONERF_HIP_H
+#define EGONERF_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EGO_ABI_VERSION 1
+
+enum {
+  EGO_OK = 0,
+  EGO_E_BADARG = -1,   /* null pointer / bad size / unsupported configuration */
+  EGO_E_UNSUPPORTED = -2,
+};
+
+/* One VM-decomposed field of both grids.  grid index 0 = yin, 1 = yang; i = 0..2 follow the
+ * reference's matMode [[0,1],[0,2],[1,2]] / vecMode [2,1,0] over axes (r, theta, phi):
+ *   plane[g][0]: [N_theta][N_r][C]   line[g][0]: [N_phi][C]
+ *   plane[g][1]: [N_phi][N_r][C]     line[g][1]: [N_theta][C]
+ *   plane[g][2]: [N_phi][N_theta][C] line[g][2]: [N_r][C]                                      */
+typedef struct ego_vm_field {
+  const float* plane[2][3]; /* dev */
+  const float* line[2][3];  /* dev */
+  int32_t n_comp;           /* C: 16 (density) or 48 (appearance) in every shipped config */
+  int32_t res[3];           /* (N_r, N_theta, N_phi) of THIS field (coarse field = full / 2) */
+} ego_vm_field;
+
+typedef struct ego_scene {
+  /* coordinates (models/coordinates.py:76,500-505): all float32 values computed by the host exactly
+   * as the reference computes them */
+  float center[3];
+  float ang_near[2]; /* theta, phi lower bounds: pi/4, -3pi/4 */
+  float ang_inv[2];  /* 1/(far-near) per angle */
+  const float* r_lut; /* dev [n_r_lut] = reference_r_grid, n_r_lut = N_r + 1 */
+  int32_t n_r_lut;
+  int32_t n_r;        /* N_r used in the final division (coordinates.py:156) */
+  /* density activation (tensorBase.py:415-419) and compositing scale (opt.py:144) */
+  int32_t act_softplus; /* 1 softplus, 0 relu */
+  float density_shift;
+  float distance_scale;
+  /* tables */
+  ego_vm_field density;
+  ego_vm_field density_coarse;
+  ego_vm_field app;
+  const float* basis[2]; /* dev [app_dim][3*C_app] row-major = nn.Linear.weight, per grid */
+  int32_t app_dim;       /* 27 */
+  /* MLP_Fea (tensorBase.py:54-78): reference-layout weights (row-major [out][in]) ... */
+  const float* mlp_w[3]; /* dev [128][150], [128][128], [3][128] */
+  const float* mlp_b[3]; /* dev */
+  int32_t mlp_in, mlp_hidden, view_pe, fea_pe;
+  /* ... and the MFMA re-layout of the same weights produced by ego_pack_mlp (dev, EGO_PACKED_FLOATS) */
+  const float* packed;
+  /* environment map (models/envmap.py): emission [3][2h][h] or NULL */
+  const float* envmap;
+  int32_t envmap_h;
+  int32_t reserved;
+} ego_scene;
+
+/* number of floats ego_pack_mlp writes (packed weight blob used by ego_shade / ego_mlp_fea / ego_app_feature) */
+int64_t ego_packed_floats(void);
+
+int ego_abi_version(void);
+const char* ego_last_error(void);
+/* sizeof the ABI structs as compiled (0 ego_scene, 1 ego_render_args, 2 ego_vm_field): lets a foreign-
+ * language binding verify its struct mirrors at load time */
+int64_t ego_sizeof(int32_t which);
+
+/* ---- separately callable stages (back the reference's public methods; parity-tested one by one) ---- */
+
+/* rays [N][6] (o,d); r_sched [S] = radial offsets (host-built, float32); jitter [N][S] in [0,1) or NULL.
+ * z = near + r (+ step*jitter); xyz = o + d*z.  Outputs xyz [N][S][3], z [N][S] (either may be NULL). */
+int ego_sample_ray_exp(const float* rays, const float* r_sched, const float* jitter, float near_, int64_t N, int32_t S,
+                       float* xyz, float* z, void* stream);
+
+int ego_from_cartesian(const ego_scene* sc, const float* xyz, int64_t M, float* c7, void* stream);
+int ego_normalize_coord(const ego_scene* sc, const float* c7, int64_t M, float* c7n, void* stream);
+
+/* c7n [M][7] normalised yin-yang coordinates; out [M].  coarse != 0 uses sc->density_coarse. */
+int ego_density_feature(const ego_scene* sc, const float* c7n, int64_t M, int32_t coarse, float* out, void* stream);
+/* out [M][app_dim] */
+int ego_app_feature(const ego_scene* sc, const float* c7n, int64_t M, float* out, void* stream);
+int ego_feature2density(const ego_scene* sc, const float* feat, int64_t M, float* sigma, void* stream);
+/* sigma, dist [N][S] (dist already multiplied by distance_scale, like the reference call site);
+ * alpha, weight [N][S]; bg_weight [N] */
+int ego_raw2alpha(const float* sigma, const float* dist, int64_t N, int32_t S, float* alpha, float* weight,
+                  float* bg_weight, void* stream);
+/* viewdirs [M][3], feat [M][app_dim] -> rgb [M][3] */
+int ego_mlp_fea(const ego_scene* sc, const float* viewdirs, const float* feat, int64_t M, float* rgb, void* stream);
+/* z [N][Sc] coarse distances, weight [N][Sc] coarse weights (bins = midpoints of z, pdf = weight[1:-1]),
+ * u [N][n_fine] or NULL (= linspace(0,1,n_fine), eval mode).  use_coarse != 0: z_out [N][Sc+n_fine] =
+ * sort(cat(z, z_new)); else z_out [N][n_fine] = sort(z_new).  z_new_out [N][n_fine] optional (unsorted). */
+int ego_sample_pdf_merge(const float* z, const float* weight, const float* u, int64_t N, int32_t Sc, int32_t n_fine,
+                         int32_t use_coarse, float* z_out, float* z_new_out, void* stream);
+int ego_envmap_radiance(const ego_scene* sc, const float* dirs, int64_t N, float* out, void* stream);
+/* 2x average pooling of one channel-last plane [H][W][C] -> [H/2][W/2][C] (W==1: line [H][C] -> [H/2][C]) */
+int ego_avgpool_table(const float* src, int32_t H, int32_t W, int32_t C, float* dst, void* stream);
+/* reference-layout basis/MLP weights in `sc` -> packed blob (dev, ego_packed_floats() floats) */
+int ego_pack_mlp(const ego_scene* sc, float* packed_out, void* stream);
+
+/* ---- the fused hot path ------------------------------------------------------------------------ */
+
+/* Sampling -> yin-yang coords -> density lookup -> sigma -> alpha, transmittance scan.
+ * z_in [N][S] explicit sample distances, or NULL: z = near + r_sched[s] (+ jitter).  coarse selects the
+ * pooled tables.  Outputs (any may be NULL): z_out [N][S], alpha [N][alpha_stride] (alpha_stride 0 = S;
+ * columns S.. are filled with 1, the reference's trailing ones column when an envmap is present,
+ * EgoNeRF.py:587), weight [N][S], bg_weight [N]. */
+int ego_march_density(const ego_scene* sc, const float* rays, int64_t N, int32_t S, const float* z_in,
+                      const float* r_sched, const float* jitter, float near_, int32_t coarse, float* z_out,
+                      float* alpha, int32_t alpha_stride, float* weight, float* bg_weight, void* stream);
+
+/* Appearance lookup -> basis -> positional encoding -> MLP for every sample: rgb [N][S][3].
+ * z [N][S] sample distances (from ego_march_density). */
+int ego_shade(const ego_scene* sc, const float* rays, const float* z, int64_t N, int32_t S, float* rgb, void* stream);
+
+/* acc, rgb_map (+ envmap background), clamp, depth (+ (1-acc)*d_z quirk, EgoNeRF.py:598).
+ * Outputs rgb_map [N][3], depth [N]; bg_map/env_map [N][3] written only when sc->envmap != NULL (may be NULL). */
+int ego_composite(const ego_scene* sc, const float* rays, const float* z, const float* weight, const float* bg_weight,
+                  const float* rgb, int64_t N, int32_t S, float* rgb_map, float* depth, float* bg_map, float* env_map,
+                  void* stream);
+
+typedef struct ego_render_args {
+  int32_t n_coarse, n_fine;
+  int32_t resampling, use_coarse_sample;
+  const float* r_sched; /* dev [n_coarse] */
+  const float* jitter;  /* dev [N][n_coarse] or NULL (eval) */
+  const float* u;       /* dev [N][n_fine] or NULL (eval: linspace) */
+  float near_;
+  int32_t reserved;
+} ego_render_args;
+
+/* Whole EgoNeRF.forward for N rays.  S_out = n_coarse (no resampling) | n_coarse+n_fine | n_fine.
+ * workspace: dev scratch of ego_render_workspace_bytes(N, args) bytes.
+ * Outputs: rgb_map [N][3], depth [N], alpha [N][S_out (+1 with envmap)], bg_map/env_map [N][3] (envmap only). */
+int64_t ego_render_workspace_bytes(int64_t N, const ego_render_args* args);
+int ego_render_forward(const ego_scene* sc, const ego_render_args* args, const float* rays, int64_t N, void* workspace,
+                       float* rgb_map, float* depth, float* alpha, float* bg_map, float* env_map, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EGONERF_HIP_H */

@@ -1,0 +1,143 @@
+"""Test infrastructure: numpy model of (a) the packed-weight layout ego_pack_mlp produces and (b) the
+wave64 dataflow of k_shade (v_mfma_f32_32x32x2_f32 operand/accumulator lane maps from the CDNA4 ISA:
+A[i][k] <- lane (i + 32k), B[k][j] <- lane (j + 32k), D[i][j] -> lane j + 32*((i>>2)&1), reg (i&3) + 4*(i>>3)).
+Lets the CPU test-suite check the K-permutation bookkeeping without a GPU, and gives the GPU test a
+bit-exact expectation for the device-side packer."""
+import numpy as np
+
+APP_C, APP_HALF, APP_DIM, HID, NSLOT = 48, 24, 27, 128, 14
+KS_BASIS, KS1, KS2, MLP_IN = 72, 80, 64, 150
+OFF_W1 = 0
+OFF_W2 = OFF_W1 + KS1 * 4 * 64
+OFF_B1 = OFF_W2 + KS2 * 4 * 64
+OFF_B2 = OFF_B1 + 128
+OFF_W3 = OFF_B2 + 128
+OFF_B3 = OFF_W3 + 512
+OFF_BASIS = OFF_B3 + 4
+PACKED_FLOATS = OFF_BASIS + 2 * (KS_BASIS // 4) * 64 * 4
+
+
+def slot_row(r, h):
+    return (r & 3) + 8 * (r >> 2) + 4 * h
+
+
+def x_channel(kk, h):
+    if kk < 5 * NSLOT:
+        kind, r = kk % 5, kk // 5
+        f = 2 * r + h
+        if f >= APP_DIM:
+            return -1
+        pe0, pe1 = APP_DIM + 3, APP_DIM + 3 + 2 * APP_DIM
+        return [f, pe0 + 2 * f, pe0 + 2 * f + 1, pe1 + 2 * f, pe1 + 2 * f + 1][kind]
+    if kk < 5 * NSLOT + 8:
+        t = kk - 5 * NSLOT + 8 * h
+        return APP_DIM + t if t < 3 else (138 + (t - 3) if t < 15 else -1)
+    return -1
+
+
+def pack_mlp(w):
+    """w: reference-layout dict (synth.make_weights keys) -> packed float32 blob."""
+    w1, b1 = w["renderModule.mlp.0.weight"], w["renderModule.mlp.0.bias"]
+    w2, b2 = w["renderModule.mlp.2.weight"], w["renderModule.mlp.2.bias"]
+    w3, b3 = w["renderModule.mlp.4.weight"], w["renderModule.mlp.4.bias"]
+    out = np.zeros(PACKED_FLOATS, np.float32)
+    W1 = out[OFF_W1:OFF_W2].reshape(KS1 // 4, 4, 64, 4)
+    W2 = out[OFF_W2:OFF_B1].reshape(KS2 // 4, 4, 64, 4)
+    for lane in range(64):
+        i, h = lane & 31, lane >> 5
+        for m in range(4):
+            for kk in range(KS1):
+                ch = x_channel(kk, h)
+                if ch >= 0:
+                    W1[kk // 4, m, lane, kk % 4] = w1[m * 32 + i, ch]
+            for kk in range(KS2):
+                W2[kk // 4, m, lane, kk % 4] = w2[m * 32 + i, (kk >> 4) * 32 + slot_row(kk & 15, h)]
+    B1 = out[OFF_B1:OFF_B2].reshape(4, 2, 16)
+    B2 = out[OFF_B2:OFF_W3].reshape(4, 2, 16)
+    W3 = out[OFF_W3:OFF_B3].reshape(4, 2, 16, 4)
+    for m in range(4):
+        for h in range(2):
+            for r in range(16):
+                u = m * 32 + slot_row(r, h)
+                B1[m, h, r], B2[m, h, r] = b1[u], b2[u]
+                W3[m, h, r, :3] = w3[:, u]
+    out[OFF_B3:OFF_B3 + 3] = b3
+    BAS = out[OFF_BASIS:].reshape(2, KS_BASIS // 4, 64, 4)
+    for g, key in enumerate(("basis_mat_yin.weight", "basis_mat_yang.weight")):
+        bm = w[key]
+        for lane in range(64):
+            i, h = lane & 31, lane >> 5
+            rh, r = (i >> 2) & 1, (i & 3) + 4 * (i >> 3)
+            f = 2 * r + rh
+            if r < NSLOT and f < APP_DIM:
+                for kk in range(KS_BASIS):
+                    col = (kk // APP_HALF) * APP_C + APP_HALF * h + kk % APP_HALF
+                    BAS[g, kk // 4, lane, kk % 4] = bm[f, col]
+    return out
+
+
+def mfma_32x32x2(a, b, acc):
+    """a, b: [64] per-lane operands; acc: [64,16] per-lane accumulators.  Returns the updated acc."""
+    A = np.stack([a[:32], a[32:]], 1).astype(np.float64)   # A[i][k]
+    B = np.stack([b[:32], b[32:]], 0).astype(np.float64)   # B[k][j]
+    D = A @ B                                                # [32 i][32 j]
+    out = acc.astype(np.float64).copy()
+    for i in range(32):
+        h, r = (i >> 2) & 1, (i & 3) + 4 * (i >> 3)
+        out[h * 32 + np.arange(32), r] += D[i]
+    return out
+
+
+def emulate_tile(packed, v, grid_flag, viewdirs):
+    """One wave: v [32 samples][144] products (reference channel order), grid_flag [32] (0 yin / 1 yang),
+    viewdirs [32][3] -> (feat [32][27], rgb [32][3]) following k_shade's register dataflow."""
+    lane = np.arange(64)
+    j, h = lane & 31, lane >> 5
+    # lane's B operands for the basis: its half of each plane's channels
+    vl = np.zeros((64, KS_BASIS))
+    for kk in range(KS_BASIS):
+        col = (kk // APP_HALF) * APP_C + APP_HALF * h + kk % APP_HALF
+        vl[:, kk] = v[j, col]
+    g = grid_flag[j]
+    BAS = packed[OFF_BASIS:].reshape(2, KS_BASIS // 4, 64, 4)
+    fe = np.zeros((64, 16))
+    for gi in range(2):
+        for kk in range(KS_BASIS):
+            fe = mfma_32x32x2(BAS[gi, kk // 4, :, kk % 4], np.where(g == gi, vl[:, kk], 0.0), fe)
+    feat = np.zeros((32, APP_DIM))
+    for r in range(NSLOT):
+        for hh in range(2):
+            if 2 * r + hh < APP_DIM:
+                feat[:, 2 * r + hh] = fe[hh * 32 + np.arange(32), r]
+    # layer-1 operands
+    d = viewdirs[j]
+    vlist = np.concatenate([d, np.stack([np.sin(d[:, 0]), np.sin(2 * d[:, 0]), np.sin(d[:, 1]), np.sin(2 * d[:, 1]),
+                                         np.sin(d[:, 2]), np.sin(2 * d[:, 2]), np.cos(d[:, 0]), np.cos(2 * d[:, 0]),
+                                         np.cos(d[:, 1]), np.cos(2 * d[:, 1]), np.cos(d[:, 2]), np.cos(2 * d[:, 2])], 1),
+                            np.zeros((64, 1))], 1)
+    X = np.zeros((64, KS1))
+    for r in range(NSLOT):
+        f = fe[:, r]
+        X[:, 5 * r:5 * r + 5] = np.stack([f, np.sin(f), np.sin(2 * f), np.cos(f), np.cos(2 * f)], 1)
+    for t in range(8):
+        X[:, 5 * NSLOT + t] = np.where(h == 1, vlist[:, 8 + t], vlist[:, t])
+    W1 = packed[OFF_W1:OFF_W2].reshape(KS1 // 4, 4, 64, 4)
+    W2 = packed[OFF_W2:OFF_B1].reshape(KS2 // 4, 4, 64, 4)
+    B1 = packed[OFF_B1:OFF_B2].reshape(4, 2, 16)
+    B2 = packed[OFF_B2:OFF_W3].reshape(4, 2, 16)
+    W3 = packed[OFF_W3:OFF_B3].reshape(4, 2, 16, 4)
+    H = [B1[m][h].astype(np.float64) for m in range(4)]
+    for kk in range(KS1):
+        for m in range(4):
+            H[m] = mfma_32x32x2(W1[kk // 4, m, :, kk % 4], X[:, kk], H[m])
+    H = [np.maximum(x, 0) for x in H]
+    G = [B2[m][h].astype(np.float64) for m in range(4)]
+    for kk in range(KS2):
+        for m in range(4):
+            G[m] = mfma_32x32x2(W2[kk // 4, m, :, kk % 4], H[kk >> 4][:, kk & 15], G[m])
+    o = np.zeros((64, 3))
+    for m in range(4):
+        o += np.einsum("lr,lrc->lc", np.maximum(G[m], 0), W3[m][h][:, :, :3])
+    o = o[:32] + o[32:]
+    rgb = 1.0 / (1.0 + np.exp(-(o + packed[OFF_B3:OFF_B3 + 3])))
+    return feat, rgb
