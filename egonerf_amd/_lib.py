@@ -10,6 +10,10 @@ import os
 import re
 from typing import List
 
+# torch first: it bundles its own libamdhip64.so.7; loading ours before torch would bind the process to a
+# second HIP runtime copy (/opt/rocm) and torch would then see no device
+import torch  # noqa: F401
+
 from .build import LIB
 
 c_float_p = C.POINTER(C.c_float)

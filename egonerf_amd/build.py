@@ -31,7 +31,7 @@ def is_stale() -> bool:
 def build_library(force: bool = False, verbose: bool = False) -> str:
     if not force and not is_stale():
         return LIB
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-shared", "-fPIC",
            *[os.path.join(CSRC, f) for f in SOURCES], "-o", LIB + ".tmp"]
     if verbose:
         print(" ".join(cmd))

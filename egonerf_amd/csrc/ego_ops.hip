@@ -66,6 +66,7 @@ __global__ void k_normalize_coord(DevCoords c, const float* __restrict__ c7, int
 // =============================================================================================
 template <int C>
 __device__ __forceinline__ float density_lookup(const DevField& F, int g, float a_r, float a_th, float a_ph) {
+#pragma clang fp contract(fast)  // the library is built with -ffp-contract=off; interpolation may use FMAs
   const VMTaps t = vm_setup(a_r, a_th, a_ph, F.res);
   float feat = 0.f;
 #pragma unroll
@@ -283,37 +284,38 @@ __global__ __launch_bounds__(256) void k_sample_pdf_merge(const float* __restric
                                                           float* __restrict__ z_new_out) {
   __shared__ float cdf[PDF_MAX];   // [Sc-1] entries: 0, cumsum(pdf)
   __shared__ float keys[PDF_MAX];  // sort buffer
-  __shared__ float red[256];
+  __shared__ double red[256];
   const int64_t ray = blockIdx.x;
   const int tid = threadIdx.x;
   const float* zr = z + ray * Sc;
   const float* wr = weight + ray * Sc;
   const int nb = Sc - 1;  // bins = midpoints z_mid[0..Sc-2]
   const int nw = Sc - 2;  // pdf entries = weight[1..Sc-2]
-  // sum(w + 1e-5)
-  float part = 0.f;
-  for (int i = tid; i < nw; i += 256) part += __fadd_rn(wr[1 + i], 1e-5f);
+  // sum(w + 1e-5) and the cdf are accumulated in double and rounded to float per element, like ATen's CPU
+  // sum/cumsum (acc_type<float> = double): the inverse CDF is discontinuous at u == 1 when the last bin is
+  // thinner than 1e-5, so the rounding of cdf[-1] is observable
+  double part = 0.0;
+  for (int i = tid; i < nw; i += 256) part += (double)__fadd_rn(wr[1 + i], 1e-5f);
   red[tid] = part;
   __syncthreads();
   for (int d = 128; d > 0; d >>= 1) {
     if (tid < d) red[tid] += red[tid + d];
     __syncthreads();
   }
-  const float total = red[0];
-  // pdf -> cdf by a sequential-order blocked scan (one wave does the scan; nw <= 2046)
+  const float total = (float)red[0];
   for (int i = tid; i < nw; i += 256) keys[i] = __fdiv_rn(__fadd_rn(wr[1 + i], 1e-5f), total);
   __syncthreads();
   if (tid < 64) {
-    float carry = 0.f;
+    double carry = 0.0;
     for (int s0 = 0; s0 < nw; s0 += 64) {
       const int i = s0 + tid;
-      float v = (i < nw) ? keys[i] : 0.f;
+      double v = (i < nw) ? (double)keys[i] : 0.0;
 #pragma unroll
       for (int d = 1; d < 64; d <<= 1) {
-        const float o = __shfl_up(v, d, 64);
+        const double o = __shfl_up(v, d, 64);
         if (tid >= d) v += o;
       }
-      if (i < nw) cdf[i + 1] = carry + v;
+      if (i < nw) cdf[i + 1] = (float)(carry + v);
       carry += __shfl(v, 63, 64);
     }
     if (tid == 0) cdf[0] = 0.f;
@@ -405,15 +407,17 @@ int ego_sample_ray_exp(const float* rays, const float* r_sched, const float* jit
 }
 
 int ego_from_cartesian(const ego_scene* sc, const float* xyz, int64_t M, float* c7, void* stream) {
-  EGO_REQUIRE(sc && xyz && c7 && M >= 0, "from_cartesian: null argument");
+  EGO_REQUIRE(M >= 0, "from_cartesian: M < 0");
   if (M == 0) return EGO_OK;
+  EGO_REQUIRE(sc && xyz && c7, "from_cartesian: null argument");
   k_from_cartesian<<<nblk(M, 256), 256, 0, (hipStream_t)stream>>>(make_coords(*sc), xyz, M, c7);
   return ego_launch_status("k_from_cartesian");
 }
 
 int ego_normalize_coord(const ego_scene* sc, const float* c7, int64_t M, float* c7n, void* stream) {
-  EGO_REQUIRE(sc && c7 && c7n && sc->r_lut && M >= 0, "normalize_coord: null argument");
+  EGO_REQUIRE(M >= 0, "normalize_coord: M < 0");
   if (M == 0) return EGO_OK;
+  EGO_REQUIRE(sc && c7 && c7n && sc->r_lut, "normalize_coord: null argument");
   k_normalize_coord<<<nblk(M, 256), 256, 0, (hipStream_t)stream>>>(make_coords(*sc), c7, M, c7n);
   return ego_launch_status("k_normalize_coord");
 }
@@ -427,10 +431,11 @@ static int check_field(const ego_vm_field& f, const char* what) {
 }
 
 int ego_density_feature(const ego_scene* sc, const float* c7n, int64_t M, int32_t coarse, float* out, void* stream) {
-  EGO_REQUIRE(sc && c7n && out && M >= 0, "density_feature: null argument");
+  EGO_REQUIRE(M >= 0, "density_feature: M < 0");
+  if (M == 0) return EGO_OK;
+  EGO_REQUIRE(sc && c7n && out, "density_feature: null argument");
   const ego_vm_field& f = coarse ? sc->density_coarse : sc->density;
   if (int e = check_field(f, "density_feature")) return e;
-  if (M == 0) return EGO_OK;
   if (f.n_comp == 16)
     k_density_feature<16><<<nblk(M, 256), 256, 0, (hipStream_t)stream>>>(make_field(f), c7n, M, out);
   else if (f.n_comp == 8)
@@ -441,16 +446,18 @@ int ego_density_feature(const ego_scene* sc, const float* c7n, int64_t M, int32_
 }
 
 int ego_feature2density(const ego_scene* sc, const float* feat, int64_t M, float* sigma, void* stream) {
-  EGO_REQUIRE(sc && feat && sigma && M >= 0, "feature2density: null argument");
+  EGO_REQUIRE(M >= 0, "feature2density: M < 0");
   if (M == 0) return EGO_OK;
+  EGO_REQUIRE(sc && feat && sigma, "feature2density: null argument");
   k_feature2density<<<nblk(M, 256), 256, 0, (hipStream_t)stream>>>(feat, M, sc->act_softplus, sc->density_shift, sigma);
   return ego_launch_status("k_feature2density");
 }
 
 int ego_raw2alpha(const float* sigma, const float* dist, int64_t N, int32_t S, float* alpha, float* weight,
                   float* bg_weight, void* stream) {
-  EGO_REQUIRE(sigma && dist && N >= 0 && S >= 1, "raw2alpha: null argument");
+  EGO_REQUIRE(N >= 0 && S >= 1, "raw2alpha: bad size");
   if (N == 0) return EGO_OK;
+  EGO_REQUIRE(sigma && dist, "raw2alpha: null argument");
   k_raw2alpha<<<nblk(N, 4), 256, 0, (hipStream_t)stream>>>(sigma, dist, N, S, alpha, weight, bg_weight);
   return ego_launch_status("k_raw2alpha");
 }
@@ -465,8 +472,9 @@ int ego_sample_pdf_merge(const float* z, const float* weight, const float* u, in
 }
 
 int ego_envmap_radiance(const ego_scene* sc, const float* dirs, int64_t N, float* out, void* stream) {
-  EGO_REQUIRE(sc && dirs && out && sc->envmap && sc->envmap_h >= 2 && N >= 0, "envmap_radiance: no envmap / null argument");
+  EGO_REQUIRE(N >= 0, "envmap_radiance: N < 0");
   if (N == 0) return EGO_OK;
+  EGO_REQUIRE(sc && dirs && out && sc->envmap && sc->envmap_h >= 2, "envmap_radiance: no envmap / null argument");
   k_envmap<<<nblk(N, 256), 256, 0, (hipStream_t)stream>>>(sc->envmap, sc->envmap_h, dirs, N, out);
   return ego_launch_status("k_envmap");
 }

@@ -130,6 +130,7 @@ struct ShadeArgs {
 // gather this lane's 24-channel half of the three (plane x line) products: v[72]
 __device__ __forceinline__ void gather_app(const DevField& F, int g, int h, float a_r, float a_th, float a_ph,
                                            float v[KS_BASIS]) {
+#pragma clang fp contract(fast)  // built with -ffp-contract=off; interpolation may use FMAs
   const VMTaps t = vm_setup(a_r, a_th, a_ph, F.res);
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
@@ -344,7 +345,7 @@ __global__ __launch_bounds__(512) void k_shade(ShadeArgs A) {
       for (int r = 0; r < 16; ++r) {
         const f32x4 w = W3[(mt * 2 + hw) * 16 + r];
         const float hv = fmaxf(G[mt][r], 0.f);
-        o0 += hv * w.x; o1 += hv * w.y; o2 += hv * w.z;
+        o0 = fmaf(hv, w.x, o0); o1 = fmaf(hv, w.y, o1); o2 = fmaf(hv, w.z, o2);
       }
     o0 += __shfl_xor(o0, 32, 64);
     o1 += __shfl_xor(o1, 32, 64);
@@ -401,9 +402,10 @@ int ego_pack_mlp(const ego_scene* sc, float* packed_out, void* stream) {
 }
 
 int ego_app_feature(const ego_scene* sc, const float* c7n, int64_t M, float* out, void* stream) {
-  EGO_REQUIRE(c7n && out && M >= 0 && M < (1ll << 31), "app_feature: null argument or M >= 2^31");
-  if (int e = check_shade_config(sc, "app_feature", true, false)) return e;
+  EGO_REQUIRE(M >= 0 && M < (1ll << 31), "app_feature: M out of range [0, 2^31)");
   if (M == 0) return EGO_OK;
+  EGO_REQUIRE(c7n && out, "app_feature: null argument");
+  if (int e = check_shade_config(sc, "app_feature", true, false)) return e;
   ShadeArgs a{};
   a.c = make_coords(*sc); a.F = make_field(sc->app); a.packed = sc->packed; a.c7n = c7n; a.out = out; a.M = M; a.S = 1;
   k_shade<MODE_APP><<<shade_grid(M), 512, 0, (hipStream_t)stream>>>(a);
@@ -411,9 +413,10 @@ int ego_app_feature(const ego_scene* sc, const float* c7n, int64_t M, float* out
 }
 
 int ego_mlp_fea(const ego_scene* sc, const float* viewdirs, const float* feat, int64_t M, float* rgb, void* stream) {
-  EGO_REQUIRE(viewdirs && feat && rgb && M >= 0 && M < (1ll << 31), "mlp_fea: null argument or M >= 2^31");
-  if (int e = check_shade_config(sc, "mlp_fea", false, true)) return e;
+  EGO_REQUIRE(M >= 0 && M < (1ll << 31), "mlp_fea: M out of range [0, 2^31)");
   if (M == 0) return EGO_OK;
+  EGO_REQUIRE(viewdirs && feat && rgb, "mlp_fea: null argument");
+  if (int e = check_shade_config(sc, "mlp_fea", false, true)) return e;
   ShadeArgs a{};
   a.c = make_coords(*sc); a.packed = sc->packed; a.feat = feat; a.dirs = viewdirs; a.out = rgb; a.M = M; a.S = 1;
   k_shade<MODE_MLP><<<shade_grid(M), 512, 0, (hipStream_t)stream>>>(a);
