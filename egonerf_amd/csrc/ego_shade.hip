@@ -127,36 +127,60 @@ struct ShadeArgs {
 
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
-// gather this lane's 24-channel half of the three (plane x line) products: v[72]
-__device__ __forceinline__ void gather_app(const DevField& F, int g, int h, float a_r, float a_th, float a_ph,
-                                           float v[KS_BASIS]) {
+// The gather/basis phase runs in 6 stages (plane ST>>1, channel quads 3*(ST&1)..+2 of this lane's 24-channel half):
+// 18 x 16-byte loads in flight per lane per stage, 12 products, 12 basis k-steps.
+constexpr int STQ = 3;                 // float4 quads per stage
+constexpr int STV = STQ * 4;           // products per stage
+
+template <int ST>
+__device__ __forceinline__ void gather_stage(const DevField& F, const VMTaps& t, int g, int h, float v[STV]) {
 #pragma clang fp contract(fast)  // built with -ffp-contract=off; interpolation may use FMAs
-  const VMTaps t = vm_setup(a_r, a_th, a_ph, F.res);
+  constexpr int I = ST >> 1, Q0 = STQ * (ST & 1);
+  const Lin1 X = t.ax[vm_plane_x(I)], Y = t.ax[vm_plane_y(I)], Ln = t.ax[vm_line_ax(I)];
+  const int W = F.res[vm_plane_x(I)];
+  const float* P = (g ? F.plane[1][I] : F.plane[0][I]) + APP_HALF * h + 4 * Q0;
+  const float* L = (g ? F.line[1][I] : F.line[0][I]) + APP_HALF * h + 4 * Q0;
+  const f32x4* p00 = (const f32x4*)(P + (Y.i0 * W + X.i0) * APP_C);
+  const f32x4* p01 = (const f32x4*)(P + (Y.i0 * W + X.i1) * APP_C);
+  const f32x4* p10 = (const f32x4*)(P + (Y.i1 * W + X.i0) * APP_C);
+  const f32x4* p11 = (const f32x4*)(P + (Y.i1 * W + X.i1) * APP_C);
+  const f32x4* l0 = (const f32x4*)(L + Ln.i0 * APP_C);
+  const f32x4* l1 = (const f32x4*)(L + Ln.i1 * APP_C);
+  const float w00 = __fmul_rn(Y.w0, X.w0), w01 = __fmul_rn(Y.w0, X.w1);
+  const float w10 = __fmul_rn(Y.w1, X.w0), w11 = __fmul_rn(Y.w1, X.w1);
 #pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    const Lin1 X = t.ax[vm_plane_x(i)], Y = t.ax[vm_plane_y(i)], Ln = t.ax[vm_line_ax(i)];
-    const int W = F.res[vm_plane_x(i)];
-    const float* P = (g ? F.plane[1][i] : F.plane[0][i]) + APP_HALF * h;
-    const float* L = (g ? F.line[1][i] : F.line[0][i]) + APP_HALF * h;
-    const f32x4* p00 = (const f32x4*)(P + (Y.i0 * W + X.i0) * APP_C);
-    const f32x4* p01 = (const f32x4*)(P + (Y.i0 * W + X.i1) * APP_C);
-    const f32x4* p10 = (const f32x4*)(P + (Y.i1 * W + X.i0) * APP_C);
-    const f32x4* p11 = (const f32x4*)(P + (Y.i1 * W + X.i1) * APP_C);
-    const f32x4* l0 = (const f32x4*)(L + Ln.i0 * APP_C);
-    const f32x4* l1 = (const f32x4*)(L + Ln.i1 * APP_C);
-    const float w00 = __fmul_rn(Y.w0, X.w0), w01 = __fmul_rn(Y.w0, X.w1);
-    const float w10 = __fmul_rn(Y.w1, X.w0), w11 = __fmul_rn(Y.w1, X.w1);
-#pragma unroll
-    for (int q = 0; q < APP_HALF / 4; ++q) {
-      const f32x4 pv = p00[q] * w00 + p01[q] * w01 + p10[q] * w10 + p11[q] * w11;
-      const f32x4 lv = l0[q] * Ln.w0 + l1[q] * Ln.w1;
-      const f32x4 m = pv * lv;
-      v[i * APP_HALF + q * 4 + 0] = m.x;
-      v[i * APP_HALF + q * 4 + 1] = m.y;
-      v[i * APP_HALF + q * 4 + 2] = m.z;
-      v[i * APP_HALF + q * 4 + 3] = m.w;
-    }
+  for (int q = 0; q < STQ; ++q) {
+    const f32x4 pv = p00[q] * w00 + p01[q] * w01 + p10[q] * w10 + p11[q] * w11;
+    const f32x4 lv = l0[q] * Ln.w0 + l1[q] * Ln.w1;
+    const f32x4 m = pv * lv;
+    v[q * 4 + 0] = m.x; v[q * 4 + 1] = m.y; v[q * 4 + 2] = m.z; v[q * 4 + 3] = m.w;
   }
+}
+
+// basis A fragments of stage ST for grid gsel (streamed from L2, fetched one stage ahead of their MFMAs)
+template <int ST>
+__device__ __forceinline__ void basis_load(const f32x4* __restrict__ BAS, int lane, int gsel, f32x4 a[STQ]) {
+#pragma unroll
+  for (int q = 0; q < STQ; ++q) a[q] = BAS[(gsel * (KS_BASIS / 4) + ST * STQ + q) * 64 + lane];
+}
+
+__device__ __forceinline__ void basis_mfma(const f32x4 a[STQ], const float v[STV], bool keep, f32x16& fe) {
+#pragma unroll
+  for (int q = 0; q < STQ; ++q) {
+    fe = MFMA(a[q].x, keep ? v[q * 4 + 0] : 0.f, fe);
+    fe = MFMA(a[q].y, keep ? v[q * 4 + 1] : 0.f, fe);
+    fe = MFMA(a[q].z, keep ? v[q * 4 + 2] : 0.f, fe);
+    fe = MFMA(a[q].w, keep ? v[q * 4 + 3] : 0.f, fe);
+  }
+}
+
+// a wave that straddles the yin/yang border (rare: ~0.8 crossings per 512-sample ray) runs the second weight set
+// with the first grid's samples zeroed on the B side (a lane only feeds its own output column)
+template <int ST>
+__device__ __forceinline__ void basis_mixed(const f32x4* __restrict__ BAS, int lane, int g, const float v[STV], f32x16& fe) {
+  f32x4 a[STQ];
+  basis_load<ST>(BAS, lane, 1, a);
+  basis_mfma(a, v, g != 0, fe);
 }
 
 template <int MODE>
@@ -174,6 +198,9 @@ __global__ __launch_bounds__(512) void k_shade(ShadeArgs A) {
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 31, h = lane >> 5;
+  // waves w and w+4 share a SIMD and would otherwise run their gather and MFMA phases in lockstep (equal sharing
+  // of the matrix pipe keeps them synchronised); a static priority for one of them staggers the phases
+  if (wave >= 4) __builtin_amdgcn_s_setprio(1);
   const int64_t n_tiles = (A.M + 31) >> 5;
   const f32x4* W1 = (const f32x4*)(lds + OFF_W1);
   const f32x4* W2 = (const f32x4*)(lds + OFF_W2);
@@ -220,32 +247,34 @@ __global__ __launch_bounds__(512) void k_shade(ShadeArgs A) {
         a_th = normalize_ang(y.th, A.c.th_near, A.c.th_inv);
         a_ph = normalize_ang(y.ph, A.c.ph_near, A.c.ph_inv);
       }
-      float v[KS_BASIS];
-      gather_app(A.F, g, h, a_r, a_th, a_ph, v);
-      // basis: a wave that straddles the yin/yang border runs both weight sets with the other grid's
-      // samples zeroed on the B side (a lane only feeds its own output column)
       const bool any_yin = __ballot(g == 0) != 0ull, any_yang = __ballot(g != 0) != 0ull;
+      const VMTaps taps = vm_setup(a_r, a_th, a_ph, A.F.res);
 #pragma unroll
       for (int r = 0; r < 16; ++r) fe[r] = 0.f;
-      if (any_yin) {
-#pragma unroll
-        for (int k4 = 0; k4 < KS_BASIS / 4; ++k4) {
-          const f32x4 a = BAS[k4 * 64 + lane];
-          fe = MFMA(a.x, g ? 0.f : v[k4 * 4 + 0], fe);
-          fe = MFMA(a.y, g ? 0.f : v[k4 * 4 + 1], fe);
-          fe = MFMA(a.z, g ? 0.f : v[k4 * 4 + 2], fe);
-          fe = MFMA(a.w, g ? 0.f : v[k4 * 4 + 3], fe);
-        }
-      }
-      if (any_yang) {
-#pragma unroll
-        for (int k4 = 0; k4 < KS_BASIS / 4; ++k4) {
-          const f32x4 a = BAS[(KS_BASIS / 4 + k4) * 64 + lane];
-          fe = MFMA(a.x, g ? v[k4 * 4 + 0] : 0.f, fe);
-          fe = MFMA(a.y, g ? v[k4 * 4 + 1] : 0.f, fe);
-          fe = MFMA(a.z, g ? v[k4 * 4 + 2] : 0.f, fe);
-          fe = MFMA(a.w, g ? v[k4 * 4 + 3] : 0.f, fe);
-        }
+      // software pipeline over the 6 stages; sched_barriers keep the scheduler from hoisting every load to the top
+      {
+        const bool mixed = any_yin && any_yang;
+        const int gu = any_yin ? 0 : 1;              // weight set of the first pass
+        const bool keep = !mixed || g == 0;          // first pass keeps yin lanes only when the wave is mixed
+        float vA[STV], vB[STV];
+        f32x4 aA[STQ], aB[STQ];
+        basis_load<0>(BAS, lane, gu, aA);
+        gather_stage<0>(A.F, taps, g, h, vA);
+        __builtin_amdgcn_sched_barrier(0);
+#define EGO_STAGE(ST, vN, aN, vP, aP)                         \
+        basis_load<ST>(BAS, lane, gu, aN);                    \
+        gather_stage<ST>(A.F, taps, g, h, vN);                \
+        basis_mfma(aP, vP, keep, fe);                         \
+        if (mixed) basis_mixed<ST - 1>(BAS, lane, g, vP, fe); \
+        __builtin_amdgcn_sched_barrier(0);
+        EGO_STAGE(1, vB, aB, vA, aA)
+        EGO_STAGE(2, vA, aA, vB, aB)
+        EGO_STAGE(3, vB, aB, vA, aA)
+        EGO_STAGE(4, vA, aA, vB, aB)
+        EGO_STAGE(5, vB, aB, vA, aA)
+#undef EGO_STAGE
+        basis_mfma(aB, vB, keep, fe);
+        if (mixed) basis_mixed<5>(BAS, lane, g, vB, fe);
       }
     }
 
@@ -262,17 +291,13 @@ __global__ __launch_bounds__(512) void k_shade(ShadeArgs A) {
     // ---- view-direction slots (3 raw + 12 encodings, 8 per lane half) -------------------------------
     float vw[8];
     {
-      const float d[3] = {vd0, vd1, vd2};
-      float vl[16];
-#pragma unroll
-      for (int e = 0; e < 3; ++e) {
-        vl[e] = d[e];
-        sincos_f32(d[e], vl[3 + 2 * e], vl[9 + 2 * e]);
-        sincos_f32(__fmul_rn(d[e], 2.f), vl[4 + 2 * e], vl[10 + 2 * e]);
-      }
-      vl[15] = 0.f;
-#pragma unroll
-      for (int t = 0; t < 8; ++t) vw[t] = h ? vl[8 + t] : vl[t];
+      float sa0, ca0, sb0, cb0, sa1, ca1, sb1, cb1, sa2, ca2, sb2, cb2;
+      sincos_f32(vd0, sa0, ca0); sincos_f32(__fmul_rn(vd0, 2.f), sb0, cb0);
+      sincos_f32(vd1, sa1, ca1); sincos_f32(__fmul_rn(vd1, 2.f), sb1, cb1);
+      sincos_f32(vd2, sa2, ca2); sincos_f32(__fmul_rn(vd2, 2.f), sb2, cb2);
+      // half 0: d0 d1 d2 sin(d0) sin(2d0) sin(d1) sin(2d1) sin(d2) | half 1: sin(2d2) cos(d0) cos(2d0) ... cos(2d2) 0
+      vw[0] = h ? sb2 : vd0; vw[1] = h ? ca0 : vd1; vw[2] = h ? cb0 : vd2; vw[3] = h ? ca1 : sa0;
+      vw[4] = h ? cb1 : sb0; vw[5] = h ? ca2 : sa1; vw[6] = h ? cb2 : sb1; vw[7] = h ? 0.f : sa2;
     }
 
     // ---- layer 1: 150 -> 128.  K-outer: four accumulators (one per 32-unit M-tile) stay live, the
