@@ -33,7 +33,7 @@ class Scene(C.Structure):
         ("basis", C.c_void_p * 2), ("app_dim", C.c_int32),
         ("mlp_w", C.c_void_p * 3), ("mlp_b", C.c_void_p * 3),
         ("mlp_in", C.c_int32), ("mlp_hidden", C.c_int32), ("view_pe", C.c_int32), ("fea_pe", C.c_int32),
-        ("packed", C.c_void_p), ("envmap", C.c_void_p), ("envmap_h", C.c_int32), ("reserved", C.c_int32),
+        ("packed", C.c_void_p), ("envmap", C.c_void_p), ("envmap_h", C.c_int32), ("mlp_precision", C.c_int32),
     ]
 
 

@@ -109,6 +109,62 @@ __global__ void k_pack_mlp(const float* __restrict__ w1, const float* __restrict
   out[idx] = v;
 }
 
+// ---- fp16-split ("f16x3") weight layout ------------------------------------------------------------------
+// Same regions/offsets as the fp32 blob, but the three matrix regions hold fp16 pairs: w = hi + lo with
+// hi = fp16(w), lo = fp16(w - hi) (22 significant bits).  Fragment order [k-step][m-tile][term hi|lo][lane][8 k]:
+// one ds_read_b128 / global_load_dwordx4 per (step, tile, term) per lane, conflict-free.  A lane's 8 k of a step
+// are its values 8*step .. 8*step+7 in the same per-half K order as the fp32 layout.
+constexpr int KH1 = KS1 / 8, KH2 = KS2 / 8, KHB = KS_BASIS / 8;
+
+__device__ inline void split_weight(float w, _Float16& hi, _Float16& lo) {
+  hi = (_Float16)w;
+  lo = (_Float16)(w - (float)hi);
+}
+
+__global__ void k_pack_mlp_h(const float* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ w2,
+                             const float* __restrict__ b2, const float* __restrict__ w3, const float* __restrict__ b3,
+                             const float* __restrict__ basis_yin, const float* __restrict__ basis_yang,
+                             const float* __restrict__ f32_blob, float* __restrict__ out) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;  // one 32-bit slot = two fp16
+  if (idx >= PACKED_FLOATS) return;
+  if (idx >= OFF_B1 && idx < OFF_BASIS) { out[idx] = f32_blob[idx]; return; }  // biases, W3, b3 stay fp32
+  _Float16 pr[2];
+  for (int p = 0; p < 2; ++p) {
+    float w = 0.f;
+    int term;
+    if (idx < OFF_W2) {
+      const int hidx = (idx - OFF_W1) * 2 + p;
+      const int e = hidx & 7, lane = (hidx >> 3) & 63, step = hidx >> 12, mt = (hidx >> 10) & 3;
+      term = (hidx >> 9) & 1;
+      const int ch = x_channel(step * 8 + e, lane >> 5);
+      if (ch >= 0) w = w1[(mt * 32 + (lane & 31)) * MLP_IN + ch];
+    } else if (idx < OFF_B1) {
+      const int hidx = (idx - OFF_W2) * 2 + p;
+      const int e = hidx & 7, lane = (hidx >> 3) & 63, step = hidx >> 12, mt = (hidx >> 10) & 3;
+      term = (hidx >> 9) & 1;
+      const int kk = step * 8 + e;
+      w = w2[(mt * 32 + (lane & 31)) * HID + (kk >> 4) * 32 + slot_row(kk & 15, lane >> 5)];
+    } else {
+      const int hidx = (idx - OFF_BASIS) * 2 + p;
+      const int e = hidx & 7, lane = (hidx >> 3) & 63, sg = hidx >> 10;  // sg = g * KHB + step
+      term = (hidx >> 9) & 1;
+      const int g = sg / KHB, kk = (sg % KHB) * 8 + e;
+      const int i = lane & 31, h = lane >> 5;
+      const int rh = (i >> 2) & 1, r = (i & 3) + 4 * (i >> 3), f = 2 * r + rh;
+      if (r < NSLOT && f < APP_DIM) {
+        const int col = (kk / APP_HALF) * APP_C + APP_HALF * h + (kk % APP_HALF);
+        w = (g ? basis_yang : basis_yin)[f * (3 * APP_C) + col];
+      }
+    }
+    _Float16 hi, lo;
+    split_weight(w, hi, lo);
+    pr[p] = term ? lo : hi;
+  }
+  typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+  h2v v = {pr[0], pr[1]};
+  out[idx] = __builtin_bit_cast(float, v);
+}
+
 enum { MODE_SHADE = 0, MODE_APP = 1, MODE_MLP = 2 };
 
 struct ShadeArgs {
@@ -385,6 +441,318 @@ __global__ __launch_bounds__(512) void k_shade(ShadeArgs A) {
   }
 }
 
+
+// =================================================================================================================
+// f16x3 variant of k_shade: same dataflow, but every matrix product runs as three v_mfma_f32_32x32x16_f16
+// (w_hi*x_hi + w_lo*x_hi + w_hi*x_lo, fp32 accumulate; the dropped lo*lo term and the 22-bit operands leave ~2^-21
+// relative error, i.e. fp32-grade: 2.4e-7 max |dRGB| vs 1.4e-7 for the fp32 MFMA path on the oracle's inputs).
+// fp16 subnormals are honoured by the instruction on gfx950 (tools/mfma_probe.hip), which the small x_lo terms need.
+// 6 matrix-pipe cycles per K instead of 32.
+// =================================================================================================================
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+#define MFMAH(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
+
+struct HL {
+  h8 hi, lo;
+};
+
+__device__ __forceinline__ void split_pair(float a, float b, bool keep, uint32_t& hi, uint32_t& lo) {
+  a = keep ? a : 0.f;
+  b = keep ? b : 0.f;
+  const auto hp = __builtin_amdgcn_cvt_pkrtz(a, b);
+  hi = __builtin_bit_cast(uint32_t, hp);
+  lo = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(a - (float)hp[0], b - (float)hp[1]));  // residuals are exact
+}
+
+__device__ __forceinline__ HL split8(const float x[8], bool keep) {
+  u32x4 hi, lo;
+  uint32_t a, b;
+  split_pair(x[0], x[1], keep, a, b); hi.x = a; lo.x = b;
+  split_pair(x[2], x[3], keep, a, b); hi.y = a; lo.y = b;
+  split_pair(x[4], x[5], keep, a, b); hi.z = a; lo.z = b;
+  split_pair(x[6], x[7], keep, a, b); hi.w = a; lo.w = b;
+  HL o;
+  o.hi = __builtin_bit_cast(h8, hi);
+  o.lo = __builtin_bit_cast(h8, lo);
+  return o;
+}
+
+// 3 quads (12 channels) of plane I starting at quad Q0 of this lane's 24-channel half
+template <int I, int Q0>
+__device__ __forceinline__ void gather_quads3(const DevField& F, const VMTaps& t, int g, int h, float* v) {
+#pragma clang fp contract(fast)
+  const Lin1 X = t.ax[vm_plane_x(I)], Y = t.ax[vm_plane_y(I)], Ln = t.ax[vm_line_ax(I)];
+  const int W = F.res[vm_plane_x(I)];
+  const float* P = (g ? F.plane[1][I] : F.plane[0][I]) + APP_HALF * h + 4 * Q0;
+  const float* L = (g ? F.line[1][I] : F.line[0][I]) + APP_HALF * h + 4 * Q0;
+  const f32x4* p00 = (const f32x4*)(P + (Y.i0 * W + X.i0) * APP_C);
+  const f32x4* p01 = (const f32x4*)(P + (Y.i0 * W + X.i1) * APP_C);
+  const f32x4* p10 = (const f32x4*)(P + (Y.i1 * W + X.i0) * APP_C);
+  const f32x4* p11 = (const f32x4*)(P + (Y.i1 * W + X.i1) * APP_C);
+  const f32x4* l0 = (const f32x4*)(L + Ln.i0 * APP_C);
+  const f32x4* l1 = (const f32x4*)(L + Ln.i1 * APP_C);
+  const float w00 = __fmul_rn(Y.w0, X.w0), w01 = __fmul_rn(Y.w0, X.w1);
+  const float w10 = __fmul_rn(Y.w1, X.w0), w11 = __fmul_rn(Y.w1, X.w1);
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    const f32x4 pv = p00[q] * w00 + p01[q] * w01 + p10[q] * w10 + p11[q] * w11;
+    const f32x4 lv = l0[q] * Ln.w0 + l1[q] * Ln.w1;
+    const f32x4 m = pv * lv;
+    v[q * 4 + 0] = m.x; v[q * 4 + 1] = m.y; v[q * 4 + 2] = m.z; v[q * 4 + 3] = m.w;
+  }
+}
+
+struct BasisFrag {
+  h8 hi, lo;
+};
+
+template <int STEP>
+__device__ __forceinline__ BasisFrag basis_frag(const u32x4* __restrict__ BASH, int lane, int gsel) {
+  BasisFrag f;
+  f.hi = __builtin_bit_cast(h8, BASH[((gsel * KHB + STEP) * 2 + 0) * 64 + lane]);
+  f.lo = __builtin_bit_cast(h8, BASH[((gsel * KHB + STEP) * 2 + 1) * 64 + lane]);
+  return f;
+}
+
+__device__ __forceinline__ void basis_step(const BasisFrag& a, const float x[8], bool keep, f32x16& fe) {
+  const HL b = split8(x, keep);
+  fe = MFMAH(a.hi, b.hi, fe);
+  fe = MFMAH(a.lo, b.hi, fe);
+  fe = MFMAH(a.hi, b.lo, fe);
+}
+
+template <int STEP>
+__device__ __forceinline__ void basis_step_mixed(const u32x4* __restrict__ BASH, int lane, int g, const float x[8], f32x16& fe) {
+  const BasisFrag a = basis_frag<STEP>(BASH, lane, 1);
+  basis_step(a, x, g != 0, fe);
+}
+
+template <int MODE>
+__global__ __launch_bounds__(512) void k_shade_h(ShadeArgs A) {
+  __shared__ __attribute__((aligned(16))) float lds[(MODE == MODE_APP ? 0 : LDS_W_FLOATS) + (MODE == MODE_MLP ? 4 : LUT_MAX)];
+  float* lut = lds + (MODE == MODE_APP ? 0 : LDS_W_FLOATS);
+  const float* blob = A.packed + PACKED_FLOATS;  // the f16x3 half of the packed blob
+  if (MODE != MODE_APP) {
+    const f32x4* src = (const f32x4*)blob;
+    f32x4* dst = (f32x4*)lds;
+    for (int i = threadIdx.x; i < LDS_W_FLOATS / 4; i += 512) dst[i] = src[i];
+  }
+  if (MODE == MODE_SHADE)
+    for (int i = threadIdx.x; i < A.c.n_lut; i += 512) lut[i] = A.c.r_lut[i];
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 31, h = lane >> 5;
+  if (wave >= 4) __builtin_amdgcn_s_setprio(1);  // de-phase the two waves of a SIMD (see k_shade)
+  const int64_t n_tiles = (A.M + 31) >> 5;
+  const u32x4* W1 = (const u32x4*)(lds + OFF_W1);
+  const u32x4* W2 = (const u32x4*)(lds + OFF_W2);
+  const f32x4* B1 = (const f32x4*)(lds + OFF_B1);
+  const f32x4* B2 = (const f32x4*)(lds + OFF_B2);
+  const f32x4* W3 = (const f32x4*)(lds + OFF_W3);
+  const u32x4* BASH = (const u32x4*)(blob + OFF_BASIS);
+
+  for (int64_t tile = (int64_t)blockIdx.x * 8 + wave; tile < n_tiles; tile += (int64_t)gridDim.x * 8) {
+    int lw = lane;
+    asm volatile("" : "+v"(lw));  // keeps the LDS weight reads inside the loop (see k_shade)
+    const int hw = lw >> 5;
+    const int64_t m_raw = tile * 32 + j;
+    const bool valid = m_raw < A.M;
+    const int64_t m = valid ? m_raw : A.M - 1;
+
+    f32x16 fe;
+    float vd0 = 0.f, vd1 = 0.f, vd2 = 0.f;
+    if (MODE == MODE_MLP) {
+      const float* fp = A.feat + m * APP_DIM;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) fe[r] = (r < NSLOT && 2 * r + h < APP_DIM) ? fp[min(2 * r + h, APP_DIM - 1)] : 0.f;
+      vd0 = A.dirs[m * 3]; vd1 = A.dirs[m * 3 + 1]; vd2 = A.dirs[m * 3 + 2];
+    } else {
+      float a_r, a_th, a_ph;
+      int g;
+      if (MODE == MODE_APP) {
+        const float* p = A.c7n + m * 7;
+        g = (p[6] == 0.f) ? 0 : 1;
+        const int b = g ? 3 : 0;
+        a_r = p[b]; a_th = p[b + 1]; a_ph = p[b + 2];
+      } else {
+        const uint32_t ray = (uint32_t)m / (uint32_t)A.S;
+        const float* R = A.rays + (int64_t)ray * 6;
+        const float zz = A.z[m];
+        vd0 = R[3]; vd1 = R[4]; vd2 = R[5];
+        const float px = __fadd_rn(R[0], __fmul_rn(vd0, zz)), py = __fadd_rn(R[1], __fmul_rn(vd1, zz)),
+                    pz = __fadd_rn(R[2], __fmul_rn(vd2, zz));
+        const YinYang y = yinyang_from_xyz(px, py, pz, A.c);
+        g = y.yang;
+        a_r = normalize_r(y.r, lut, A.c.n_lut, A.c.n_r);
+        a_th = normalize_ang(y.th, A.c.th_near, A.c.th_inv);
+        a_ph = normalize_ang(y.ph, A.c.ph_near, A.c.ph_inv);
+      }
+      const bool any_yin = __ballot(g == 0) != 0ull, any_yang = __ballot(g != 0) != 0ull;
+      const bool mixed = any_yin && any_yang;
+      const int gu = any_yin ? 0 : 1;
+      const bool keep = !mixed || g == 0;
+      const VMTaps taps = vm_setup(a_r, a_th, a_ph, A.F.res);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) fe[r] = 0.f;
+      // per plane: two half-stages of 18 loads (12 products each); 3 basis k-steps of 8 products.  Loads of the
+      // next half-stage are issued before the MFMAs of the previous one; sched_barriers bound the hoisting.
+      float v0[24], v1[24], v2[24];
+      BasisFrag f0, f1, f2;
+      gather_quads3<0, 0>(A.F, taps, g, h, v0);
+      f0 = basis_frag<0>(BASH, lane, gu);
+      __builtin_amdgcn_sched_barrier(0);
+      gather_quads3<0, 3>(A.F, taps, g, h, v0 + 12);
+      f1 = basis_frag<1>(BASH, lane, gu); f2 = basis_frag<2>(BASH, lane, gu);
+      basis_step(f0, v0, keep, fe);
+      if (mixed) basis_step_mixed<0>(BASH, lane, g, v0, fe);
+      __builtin_amdgcn_sched_barrier(0);
+      gather_quads3<1, 0>(A.F, taps, g, h, v1);
+      f0 = basis_frag<3>(BASH, lane, gu);
+      basis_step(f1, v0 + 8, keep, fe); basis_step(f2, v0 + 16, keep, fe);
+      if (mixed) { basis_step_mixed<1>(BASH, lane, g, v0 + 8, fe); basis_step_mixed<2>(BASH, lane, g, v0 + 16, fe); }
+      __builtin_amdgcn_sched_barrier(0);
+      gather_quads3<1, 3>(A.F, taps, g, h, v1 + 12);
+      f1 = basis_frag<4>(BASH, lane, gu); f2 = basis_frag<5>(BASH, lane, gu);
+      basis_step(f0, v1, keep, fe);
+      if (mixed) basis_step_mixed<3>(BASH, lane, g, v1, fe);
+      __builtin_amdgcn_sched_barrier(0);
+      gather_quads3<2, 0>(A.F, taps, g, h, v2);
+      f0 = basis_frag<6>(BASH, lane, gu);
+      basis_step(f1, v1 + 8, keep, fe); basis_step(f2, v1 + 16, keep, fe);
+      if (mixed) { basis_step_mixed<4>(BASH, lane, g, v1 + 8, fe); basis_step_mixed<5>(BASH, lane, g, v1 + 16, fe); }
+      __builtin_amdgcn_sched_barrier(0);
+      gather_quads3<2, 3>(A.F, taps, g, h, v2 + 12);
+      f1 = basis_frag<7>(BASH, lane, gu); f2 = basis_frag<8>(BASH, lane, gu);
+      basis_step(f0, v2, keep, fe);
+      if (mixed) basis_step_mixed<6>(BASH, lane, g, v2, fe);
+      __builtin_amdgcn_sched_barrier(0);
+      basis_step(f1, v2 + 8, keep, fe); basis_step(f2, v2 + 16, keep, fe);
+      if (mixed) { basis_step_mixed<7>(BASH, lane, g, v2 + 8, fe); basis_step_mixed<8>(BASH, lane, g, v2 + 16, fe); }
+    }
+
+    if (MODE == MODE_APP) {
+      if (valid) {
+        float* o = A.out + m * APP_DIM;
+#pragma unroll
+        for (int r = 0; r < NSLOT; ++r)
+          if (2 * r + h < APP_DIM) o[2 * r + h] = fe[r];
+      }
+      continue;
+    }
+
+    float vw[8];
+    {
+      float sa0, ca0, sb0, cb0, sa1, ca1, sb1, cb1, sa2, ca2, sb2, cb2;
+      sincos_f32(vd0, sa0, ca0); sincos_f32(__fmul_rn(vd0, 2.f), sb0, cb0);
+      sincos_f32(vd1, sa1, ca1); sincos_f32(__fmul_rn(vd1, 2.f), sb1, cb1);
+      sincos_f32(vd2, sa2, ca2); sincos_f32(__fmul_rn(vd2, 2.f), sb2, cb2);
+      vw[0] = h ? sb2 : vd0; vw[1] = h ? ca0 : vd1; vw[2] = h ? cb0 : vd2; vw[3] = h ? ca1 : sa0;
+      vw[4] = h ? cb1 : sb0; vw[5] = h ? ca2 : sa1; vw[6] = h ? cb2 : sb1; vw[7] = h ? 0.f : sa2;
+    }
+
+    // ---- layer 1 (K-outer, 10 steps of 8 values per lane half) ----------------------------------------------
+    f32x16 H[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 b = B1[(mt * 2 + hw) * 4 + q];
+        H[mt][q * 4 + 0] = b.x; H[mt][q * 4 + 1] = b.y; H[mt][q * 4 + 2] = b.z; H[mt][q * 4 + 3] = b.w;
+      }
+    {
+      float s1 = 0.f, c1 = 0.f, s2 = 0.f, c2 = 0.f;
+      float xs[8];
+#pragma unroll
+      for (int kk = 0; kk < KS1; ++kk) {
+        float x;
+        if (kk < 5 * NSLOT) {
+          const int r = kk / 5, kind = kk % 5;
+          if (kind == 0) {
+            sincos_f32(fe[r], s1, c1);
+            sincos_f32(__fmul_rn(fe[r], 2.f), s2, c2);
+          }
+          x = kind == 0 ? fe[r] : (kind == 1 ? s1 : (kind == 2 ? s2 : (kind == 3 ? c1 : c2)));
+        } else if (kk < 5 * NSLOT + 8) {
+          x = vw[kk - 5 * NSLOT];
+        } else {
+          x = 0.f;
+        }
+        xs[kk & 7] = x;
+        if ((kk & 7) == 7) {
+          const int step = kk >> 3;
+          const HL b = split8(xs, true);
+          h8 ah[4], al[4];
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt) {
+            ah[mt] = __builtin_bit_cast(h8, W1[((step * 4 + mt) * 2 + 0) * 64 + lw]);
+            al[mt] = __builtin_bit_cast(h8, W1[((step * 4 + mt) * 2 + 1) * 64 + lw]);
+          }
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt) H[mt] = MFMAH(ah[mt], b.hi, H[mt]);
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt) H[mt] = MFMAH(al[mt], b.hi, H[mt]);
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt) H[mt] = MFMAH(ah[mt], b.lo, H[mt]);
+        }
+      }
+    }
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) H[mt][r] = fmaxf(H[mt][r], 0.f);
+
+    // ---- layer 2 (8 steps), layer 3 on the VALU ----------------------------------------------------------------
+    f32x16 G[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 b = B2[(mt * 2 + hw) * 4 + q];
+        G[mt][q * 4 + 0] = b.x; G[mt][q * 4 + 1] = b.y; G[mt][q * 4 + 2] = b.z; G[mt][q * 4 + 3] = b.w;
+      }
+#pragma unroll
+    for (int step = 0; step < KH2; ++step) {
+      float xs[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) xs[e] = H[(step * 8 + e) >> 4][(step * 8 + e) & 15];
+      const HL b = split8(xs, true);
+      h8 ah[4], al[4];
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        ah[mt] = __builtin_bit_cast(h8, W2[((step * 4 + mt) * 2 + 0) * 64 + lw]);
+        al[mt] = __builtin_bit_cast(h8, W2[((step * 4 + mt) * 2 + 1) * 64 + lw]);
+      }
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) G[mt] = MFMAH(ah[mt], b.hi, G[mt]);
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) G[mt] = MFMAH(al[mt], b.hi, G[mt]);
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) G[mt] = MFMAH(ah[mt], b.lo, G[mt]);
+    }
+    float o0 = 0.f, o1 = 0.f, o2 = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const f32x4 w = W3[(mt * 2 + hw) * 16 + r];
+        const float hv = fmaxf(G[mt][r], 0.f);
+        o0 = fmaf(hv, w.x, o0); o1 = fmaf(hv, w.y, o1); o2 = fmaf(hv, w.z, o2);
+      }
+    o0 += __shfl_xor(o0, 32, 64);
+    o1 += __shfl_xor(o1, 32, 64);
+    o2 += __shfl_xor(o2, 32, 64);
+    if (valid && h == 0) {
+      const float* b3 = lds + OFF_B3;
+      float* o = A.out + m * 3;
+      o[0] = sigmoidf(o0 + b3[0]);
+      o[1] = sigmoidf(o1 + b3[1]);
+      o[2] = sigmoidf(o2 + b3[2]);
+    }
+  }
+}
+
 int check_shade_config(const ego_scene* sc, const char* who, bool need_tables, bool need_mlp) {
   if (!sc) return ego_fail(EGO_E_BADARG, "%s: null scene", who);
   if (!sc->packed) return ego_fail(EGO_E_BADARG, "%s: scene.packed is null (call ego_pack_mlp first)", who);
@@ -411,7 +779,7 @@ unsigned shade_grid(int64_t M) {
 
 extern "C" {
 
-int64_t ego_packed_floats(void) { return PACKED_FLOATS; }
+int64_t ego_packed_floats(void) { return 2 * (int64_t)PACKED_FLOATS; }
 
 int ego_pack_mlp(const ego_scene* sc, float* packed_out, void* stream) {
   EGO_REQUIRE(sc && packed_out, "pack_mlp: null argument");
@@ -423,7 +791,11 @@ int ego_pack_mlp(const ego_scene* sc, float* packed_out, void* stream) {
   k_pack_mlp<<<(PACKED_FLOATS + 255) / 256, 256, 0, (hipStream_t)stream>>>(sc->mlp_w[0], sc->mlp_b[0], sc->mlp_w[1], sc->mlp_b[1],
                                                                           sc->mlp_w[2], sc->mlp_b[2], sc->basis[0], sc->basis[1],
                                                                           packed_out);
-  return ego_launch_status("k_pack_mlp");
+  if (int e = ego_launch_status("k_pack_mlp")) return e;
+  k_pack_mlp_h<<<(PACKED_FLOATS + 255) / 256, 256, 0, (hipStream_t)stream>>>(sc->mlp_w[0], sc->mlp_b[0], sc->mlp_w[1], sc->mlp_b[1],
+                                                                            sc->mlp_w[2], sc->mlp_b[2], sc->basis[0], sc->basis[1],
+                                                                            packed_out, packed_out + PACKED_FLOATS);
+  return ego_launch_status("k_pack_mlp_h");
 }
 
 int ego_app_feature(const ego_scene* sc, const float* c7n, int64_t M, float* out, void* stream) {
@@ -433,7 +805,8 @@ int ego_app_feature(const ego_scene* sc, const float* c7n, int64_t M, float* out
   if (int e = check_shade_config(sc, "app_feature", true, false)) return e;
   ShadeArgs a{};
   a.c = make_coords(*sc); a.F = make_field(sc->app); a.packed = sc->packed; a.c7n = c7n; a.out = out; a.M = M; a.S = 1;
-  k_shade<MODE_APP><<<shade_grid(M), 512, 0, (hipStream_t)stream>>>(a);
+  if (sc->mlp_precision == EGO_PREC_F32) k_shade<MODE_APP><<<shade_grid(M), 512, 0, (hipStream_t)stream>>>(a);
+  else k_shade_h<MODE_APP><<<shade_grid(M), 512, 0, (hipStream_t)stream>>>(a);
   return ego_launch_status("k_shade<APP>");
 }
 
@@ -444,7 +817,8 @@ int ego_mlp_fea(const ego_scene* sc, const float* viewdirs, const float* feat, i
   if (int e = check_shade_config(sc, "mlp_fea", false, true)) return e;
   ShadeArgs a{};
   a.c = make_coords(*sc); a.packed = sc->packed; a.feat = feat; a.dirs = viewdirs; a.out = rgb; a.M = M; a.S = 1;
-  k_shade<MODE_MLP><<<shade_grid(M), 512, 0, (hipStream_t)stream>>>(a);
+  if (sc->mlp_precision == EGO_PREC_F32) k_shade<MODE_MLP><<<shade_grid(M), 512, 0, (hipStream_t)stream>>>(a);
+  else k_shade_h<MODE_MLP><<<shade_grid(M), 512, 0, (hipStream_t)stream>>>(a);
   return ego_launch_status("k_shade<MLP>");
 }
 
@@ -456,7 +830,8 @@ int ego_shade(const ego_scene* sc, const float* rays, const float* z, int64_t N,
   ShadeArgs a{};
   a.c = make_coords(*sc); a.F = make_field(sc->app); a.packed = sc->packed; a.rays = rays; a.z = z; a.out = rgb;
   a.M = N * (int64_t)S; a.S = S;
-  k_shade<MODE_SHADE><<<shade_grid(a.M), 512, 0, (hipStream_t)stream>>>(a);
+  if (sc->mlp_precision == EGO_PREC_F32) k_shade<MODE_SHADE><<<shade_grid(a.M), 512, 0, (hipStream_t)stream>>>(a);
+  else k_shade_h<MODE_SHADE><<<shade_grid(a.M), 512, 0, (hipStream_t)stream>>>(a);
   return ego_launch_status("k_shade<SHADE>");
 }
 

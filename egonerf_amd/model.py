@@ -203,6 +203,7 @@ class EgoNeRF(TensorBase):
         self._packed = None
         self._packed_versions = None
         self._sched_cache = {}
+        self._mlp_precision = "f16x3"
         self.coarse_sigma_plane_yin, self.coarse_sigma_line_yin = [None] * 3, [None] * 3
         self.coarse_sigma_plane_yang, self.coarse_sigma_line_yang = [None] * 3, [None] * 3
         if self.coarse_sigma_grid_update_rule is not None:
@@ -264,6 +265,19 @@ class EgoNeRF(TensorBase):
                     getattr(self, f"coarse_sigma_{what}_{g}")[i] = dst.permute(0, 3, 1, 2)
         self._scene_cache = None
 
+    @property
+    def mlp_precision(self) -> str:
+        """Arithmetic of the basis/MLP products: "f16x3" (three fp16 MFMAs per product, fp32-grade, default) or
+        "f32" (fp32-input MFMA; bit-for-bit fp32 FMA chains)."""
+        return self._mlp_precision
+
+    @mlp_precision.setter
+    def mlp_precision(self, value: str):
+        if value not in ("f16x3", "f32"):
+            raise ValueError("mlp_precision must be 'f16x3' or 'f32'")
+        self._mlp_precision = value
+        self._scene_cache = None
+
     # -- C-ABI scene ----------------------------------------------------------------------------------------
     def _mlp_tensors(self) -> List[torch.Tensor]:
         m = self.renderModule.mlp
@@ -311,6 +325,7 @@ class EgoNeRF(TensorBase):
         sc.app_dim = self.app_dim
         sc.mlp_in, sc.mlp_hidden = self.renderModule.in_mlpC, self.featureC
         sc.view_pe, sc.fea_pe = self.view_pe, self.fea_pe
+        sc.mlp_precision = 1 if self._mlp_precision == "f32" else 0
         if self._packed is None or self._packed.device != dev:
             self._packed = torch.empty(lib.ego_packed_floats(), device=dev)
         _call("ego_pack_mlp", sc, self._packed.data_ptr(), _lib.stream_handle())

@@ -43,6 +43,8 @@ extern "C" {
 
 #define EGO_ABI_VERSION 1
 
+enum { EGO_PREC_F16X3 = 0, EGO_PREC_F32 = 1 };
+
 enum {
   EGO_OK = 0,
   EGO_E_BADARG = -1,   /* null pointer / bad size / unsupported configuration */
@@ -89,10 +91,13 @@ typedef struct ego_scene {
   /* environment map (models/envmap.py): emission [3][2h][h] or NULL */
   const float* envmap;
   int32_t envmap_h;
-  int32_t reserved;
+  /* arithmetic of the basis/MLP matrix products: EGO_PREC_F16X3 (default, 0) = three fp16 MFMAs per product
+   * (hi*hi + lo*hi + hi*lo, fp32 accumulate, ~2^-21 relative: fp32-grade), EGO_PREC_F32 = fp32-input MFMA */
+  int32_t mlp_precision;
 } ego_scene;
 
-/* number of floats ego_pack_mlp writes (packed weight blob used by ego_shade / ego_mlp_fea / ego_app_feature) */
+/* number of floats ego_pack_mlp writes: the packed weight blob used by ego_shade / ego_mlp_fea / ego_app_feature
+ * (fp32 fragment layout followed by the fp16-split layout) */
 int64_t ego_packed_floats(void);
 
 int ego_abi_version(void);

@@ -141,3 +141,33 @@ def emulate_tile(packed, v, grid_flag, viewdirs):
     o = o[:32] + o[32:]
     rgb = 1.0 / (1.0 + np.exp(-(o + packed[OFF_B3:OFF_B3 + 3])))
     return feat, rgb
+
+
+def pack_mlp_f16(w):
+    """fp16-split blob (second half of what ego_pack_mlp writes): same offsets, matrix regions hold
+    [k-step][m-tile][term hi|lo][lane][8 k] fp16 with hi = fp16(w), lo = fp16(w - hi)."""
+    f32 = pack_mlp(w)
+    out = f32.copy()
+
+    def split(x):
+        hi = x.astype(np.float16)
+        lo = (x - hi.astype(np.float32)).astype(np.float16)
+        return hi, lo
+
+    def region(src_f32_frag, steps, tiles):
+        # src: [k4][m][lane][4] fp32 fragments -> per-lane K list [m][lane][kk]
+        kk = src_f32_frag.reshape(steps * 2, tiles, 64, 4).transpose(1, 2, 0, 3).reshape(tiles, 64, steps * 8)
+        hi, lo = split(kk)
+        dst = np.zeros((steps, tiles, 2, 64, 8), np.float16)
+        for st in range(steps):
+            dst[st, :, 0] = hi[:, :, st * 8:st * 8 + 8]
+            dst[st, :, 1] = lo[:, :, st * 8:st * 8 + 8]
+        return dst.reshape(-1).view(np.float32)
+
+    out[OFF_W1:OFF_W2] = region(f32[OFF_W1:OFF_W2], KS1 // 8, 4)
+    out[OFF_W2:OFF_B1] = region(f32[OFF_W2:OFF_B1], KS2 // 8, 4)
+    bas = f32[OFF_BASIS:].reshape(2, KS_BASIS // 4, 64, 4)
+    for g in range(2):
+        n = (KS_BASIS // 8) * 2 * 64 * 8 // 2
+        out[OFF_BASIS + g * n: OFF_BASIS + (g + 1) * n] = region(bas[g].reshape(KS_BASIS // 4, 1, 64, 4), KS_BASIS // 8, 1)
+    return out

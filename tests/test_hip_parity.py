@@ -36,6 +36,14 @@ def full(golden):
     return fx, cfg, w, make_model(cfg, w, DEV)
 
 
+@pytest.fixture(params=["f16x3", "f32"], autouse=True)
+def precision(request, tiny, full):
+    """Every test runs with both matrix-product arithmetics (default fp16-split MFMA, and fp32 MFMA)."""
+    tiny[3].mlp_precision = request.param
+    full[3].mlp_precision = request.param
+    return request.param
+
+
 def test_native_library_is_the_path(tiny):
     from egonerf_amd import _lib
     assert _lib.load().ego_abi_version() == 1
@@ -47,7 +55,9 @@ def test_device_packer_is_bit_exact(tiny):
     _, _, w, model = tiny
     model.scene()
     torch.cuda.synchronize()
-    assert np.array_equal(model._packed.cpu().numpy(), em.pack_mlp(w))
+    blob = model._packed.cpu().numpy()
+    assert np.array_equal(blob[:em.PACKED_FLOATS], em.pack_mlp(w))
+    assert np.array_equal(blob[em.PACKED_FLOATS:].view(np.uint32), em.pack_mlp_f16(w).view(np.uint32))
 
 
 def test_stage_sample_and_coords(tiny):
@@ -182,11 +192,12 @@ def test_e2e_tiny_train_noise_pinned(tiny):
     assert maxerr(depth, fx["tr_depth"]) <= 1e-3 * 15.0
 
 
-def test_e2e_tiny_envmap(golden):
+def test_e2e_tiny_envmap(golden, precision):
     fx = golden("tiny_envmap")
     cfg = synth.SceneConfig(n_voxel=20 ** 3, use_envmap=True, envmap_res_H=int(fx["envmap_res_H"]))
     w = synth.make_weights(cfg, seed=int(fx["seed_weights"]))
     model = make_model(cfg, w, DEV)
+    model.mlp_precision = precision
     rays = T(fx["rays"])
     with torch.no_grad():
         rgb, depth, bg, env, alpha = model(rays, n_coarse=24, exp_sampling=True)
