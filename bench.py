@@ -121,6 +121,7 @@ def main():
         alpha, w = torch.empty_like(z), torch.empty_like(z)
         bg = torch.empty(N_RAYS, device=dev)
         rgb = torch.empty(N_RAYS, N_SAMPLES, 3, device=dev)
+        crd = torch.empty(N_RAYS, N_SAMPLES, 4, device=dev)
         rgb_map, depth = torch.empty(N_RAYS, 3, device=dev), torch.empty(N_RAYS, device=dev)
         reps = max(a.steps, 5)
         ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(reps)]
@@ -128,9 +129,9 @@ def main():
             e = ev[max(i - 2, 0)]
             e[0].record()
             _lib.check(lib.ego_march_density(sc, rays.data_ptr(), N_RAYS, N_SAMPLES, None, sched.data_ptr(), None, cfg.near, 0,
-                                             z.data_ptr(), alpha.data_ptr(), 0, w.data_ptr(), bg.data_ptr(), st), "march")
+                                             z.data_ptr(), alpha.data_ptr(), 0, w.data_ptr(), bg.data_ptr(), crd.data_ptr(), st), "march")
             e[1].record()
-            _lib.check(lib.ego_shade(sc, rays.data_ptr(), z.data_ptr(), N_RAYS, N_SAMPLES, rgb.data_ptr(), st), "shade")
+            _lib.check(lib.ego_shade(sc, rays.data_ptr(), z.data_ptr(), crd.data_ptr(), N_RAYS, N_SAMPLES, rgb.data_ptr(), st), "shade")
             e[2].record()
             _lib.check(lib.ego_composite(sc, rays.data_ptr(), z.data_ptr(), w.data_ptr(), bg.data_ptr(), rgb.data_ptr(), N_RAYS,
                                          N_SAMPLES, rgb_map.data_ptr(), depth.data_ptr(), None, None, st), "composite")

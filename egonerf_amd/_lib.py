@@ -64,8 +64,8 @@ PROTOTYPES = {
     "ego_envmap_radiance": (C.c_int, [SP, P, I64, P, P]),
     "ego_avgpool_table": (C.c_int, [P, I32, I32, I32, P, P]),
     "ego_pack_mlp": (C.c_int, [SP, P, P]),
-    "ego_march_density": (C.c_int, [SP, P, I64, I32, P, P, P, F32, I32, P, P, I32, P, P, P]),
-    "ego_shade": (C.c_int, [SP, P, P, I64, I32, P, P]),
+    "ego_march_density": (C.c_int, [SP, P, I64, I32, P, P, P, F32, I32, P, P, I32, P, P, P, P]),
+    "ego_shade": (C.c_int, [SP, P, P, P, I64, I32, P, P]),
     "ego_composite": (C.c_int, [SP, P, P, P, P, P, I64, I32, P, P, P, P, P]),
     "ego_render_workspace_bytes": (I64, [I64, C.POINTER(RenderArgs)]),
     "ego_render_forward": (C.c_int, [SP, C.POINTER(RenderArgs), P, I64, P, P, P, P, P, P, P]),

@@ -175,6 +175,15 @@ __device__ __forceinline__ void sincos_f32(float x, float& s_out, float& c_out) 
   c_out = ((q + 1) & 2) ? -c : c;
 }
 
+// sin/cos of x and 2x (the two positional-encoding frequencies): one reduction + double-angle identities.
+// sin 2x = 2 s c, cos 2x = 1 - 2 s^2: adds <= 2 ulp to the ~1 ulp of sincos_f32.
+__device__ __forceinline__ void sincos_x_2x(float x, float& s1, float& c1, float& s2, float& c2) {
+  sincos_f32(x, s1, c1);
+  const float t = s1 + s1;
+  s2 = t * c1;
+  c2 = fmaf(-t, s1, 1.0f);
+}
+
 // wave64 inclusive multiplicative scan (Kogge-Stone over __shfl_up)
 __device__ __forceinline__ float wave_scan_mul(float v, int lane) {
 #pragma unroll

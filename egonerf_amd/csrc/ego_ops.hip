@@ -152,7 +152,7 @@ __global__ __launch_bounds__(256) void k_march_density(DevCoords c, DevField F, 
                                                        int softplus, float shift, float dscale,
                                                        float* __restrict__ z_out, float* __restrict__ alpha,
                                                        int alpha_stride, float* __restrict__ weight,
-                                                       float* __restrict__ bg) {
+                                                       float* __restrict__ bg, float* __restrict__ coords_out) {
   __shared__ float lut[1024];
   for (int i = threadIdx.x; i < c.n_lut; i += blockDim.x) lut[i] = c.r_lut[i];
   __syncthreads();
@@ -193,6 +193,7 @@ __global__ __launch_bounds__(256) void k_march_density(DevCoords c, DevField F, 
     if (ok) {
       const int64_t o = ray * S + s;
       if (z_out) z_out[o] = z;
+      if (coords_out) ((f32x4*)coords_out)[o] = f32x4{a_r, a_th, a_ph, y.yang ? 1.f : 0.f};
       if (alpha) alpha[ray * alpha_stride + s] = a;
       if (weight) weight[o] = a * T;
     }
@@ -488,7 +489,7 @@ int ego_avgpool_table(const float* src, int32_t H, int32_t W, int32_t C, float* 
 
 int ego_march_density(const ego_scene* sc, const float* rays, int64_t N, int32_t S, const float* z_in,
                       const float* r_sched, const float* jitter, float near_, int32_t coarse, float* z_out,
-                      float* alpha, int32_t alpha_stride, float* weight, float* bg_weight, void* stream) {
+                      float* alpha, int32_t alpha_stride, float* weight, float* bg_weight, float* coords_out, void* stream) {
   EGO_REQUIRE(sc && rays && N >= 0 && S >= 2, "march_density: null argument or S < 2");
   if (alpha_stride == 0) alpha_stride = S;
   EGO_REQUIRE(alpha_stride >= S && alpha_stride <= S + 64, "march_density: alpha_stride must be in [S, S+64]");
@@ -500,7 +501,7 @@ int ego_march_density(const ego_scene* sc, const float* rays, int64_t N, int32_t
   if (f.n_comp != 16) return ego_fail(EGO_E_UNSUPPORTED, "march_density: n_comp %d (supported: 16)", f.n_comp);
   k_march_density<16><<<nblk(N, 4), 256, 0, (hipStream_t)stream>>>(
       make_coords(*sc), make_field(f), rays, N, S, z_in, r_sched, jitter, near_, sc->act_softplus, sc->density_shift,
-      sc->distance_scale, z_out, alpha, alpha_stride, weight, bg_weight);
+      sc->distance_scale, z_out, alpha, alpha_stride, weight, bg_weight, coords_out);
   return ego_launch_status("k_march_density");
 }
 

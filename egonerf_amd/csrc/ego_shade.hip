@@ -46,6 +46,13 @@ constexpr int LUT_MAX = 1024;
 
 __host__ __device__ constexpr int slot_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
+// appearance channel (0..143, plane-major) gathered by lane half h as its kk-th product: the halves interleave at
+// 16-byte granularity (half h owns float4 quads 2i+h of a texel), so the two lanes of a sample always read the
+// same 64-byte line in a given load instruction -> half as many L1 tag lookups as a [0,24) / [24,48) split.
+__host__ __device__ constexpr int app_channel(int kk, int h) {
+  return (kk / APP_HALF) * APP_C + ((kk % APP_HALF) / 4) * 8 + 4 * h + (kk % 4);
+}
+
 // reference MLP input column held by X register kk of lane half h (-1: zero weight)
 __device__ int x_channel(int kk, int h) {
   if (kk < 5 * NSLOT) {
@@ -102,7 +109,7 @@ __global__ void k_pack_mlp(const float* __restrict__ w1, const float* __restrict
     const int i = lane & 31, h = lane >> 5, kk = kk4 * 4 + j;
     const int rh = (i >> 2) & 1, r = (i & 3) + 4 * (i >> 3), f = 2 * r + rh;  // feature delivered to tile row i
     if (r < NSLOT && f < APP_DIM) {
-      const int col = (kk / APP_HALF) * APP_C + APP_HALF * h + (kk % APP_HALF);
+      const int col = app_channel(kk, h);
       v = (g ? basis_yang : basis_yin)[f * (3 * APP_C) + col];
     }
   }
@@ -152,7 +159,7 @@ __global__ void k_pack_mlp_h(const float* __restrict__ w1, const float* __restri
       const int i = lane & 31, h = lane >> 5;
       const int rh = (i >> 2) & 1, r = (i & 3) + 4 * (i >> 3), f = 2 * r + rh;
       if (r < NSLOT && f < APP_DIM) {
-        const int col = (kk / APP_HALF) * APP_C + APP_HALF * h + (kk % APP_HALF);
+        const int col = app_channel(kk, h);
         w = (g ? basis_yang : basis_yin)[f * (3 * APP_C) + col];
       }
     }
@@ -173,6 +180,7 @@ struct ShadeArgs {
   const float* packed;
   const float* rays;  // MODE_SHADE: [N][6]
   const float* z;     // MODE_SHADE: [N][S]
+  const float* coords;  // MODE_SHADE, optional: [N][S][4] = (r^, theta^, phi^, is_yang) from ego_march_density
   const float* c7n;   // MODE_APP: [M][7]
   const float* feat;  // MODE_MLP: [M][27]
   const float* dirs;  // MODE_MLP: [M][3]
@@ -194,8 +202,8 @@ __device__ __forceinline__ void gather_stage(const DevField& F, const VMTaps& t,
   constexpr int I = ST >> 1, Q0 = STQ * (ST & 1);
   const Lin1 X = t.ax[vm_plane_x(I)], Y = t.ax[vm_plane_y(I)], Ln = t.ax[vm_line_ax(I)];
   const int W = F.res[vm_plane_x(I)];
-  const float* P = (g ? F.plane[1][I] : F.plane[0][I]) + APP_HALF * h + 4 * Q0;
-  const float* L = (g ? F.line[1][I] : F.line[0][I]) + APP_HALF * h + 4 * Q0;
+  const float* P = (g ? F.plane[1][I] : F.plane[0][I]) + 4 * h + 8 * Q0;
+  const float* L = (g ? F.line[1][I] : F.line[0][I]) + 4 * h + 8 * Q0;
   const f32x4* p00 = (const f32x4*)(P + (Y.i0 * W + X.i0) * APP_C);
   const f32x4* p01 = (const f32x4*)(P + (Y.i0 * W + X.i1) * APP_C);
   const f32x4* p10 = (const f32x4*)(P + (Y.i1 * W + X.i0) * APP_C);
@@ -206,8 +214,8 @@ __device__ __forceinline__ void gather_stage(const DevField& F, const VMTaps& t,
   const float w10 = __fmul_rn(Y.w1, X.w0), w11 = __fmul_rn(Y.w1, X.w1);
 #pragma unroll
   for (int q = 0; q < STQ; ++q) {
-    const f32x4 pv = p00[q] * w00 + p01[q] * w01 + p10[q] * w10 + p11[q] * w11;
-    const f32x4 lv = l0[q] * Ln.w0 + l1[q] * Ln.w1;
+    const f32x4 pv = p00[2 * q] * w00 + p01[2 * q] * w01 + p10[2 * q] * w10 + p11[2 * q] * w11;
+    const f32x4 lv = l0[2 * q] * Ln.w0 + l1[2 * q] * Ln.w1;
     const f32x4 m = pv * lv;
     v[q * 4 + 0] = m.x; v[q * 4 + 1] = m.y; v[q * 4 + 2] = m.z; v[q * 4 + 3] = m.w;
   }
@@ -484,8 +492,8 @@ __device__ __forceinline__ void gather_quads3(const DevField& F, const VMTaps& t
 #pragma clang fp contract(fast)
   const Lin1 X = t.ax[vm_plane_x(I)], Y = t.ax[vm_plane_y(I)], Ln = t.ax[vm_line_ax(I)];
   const int W = F.res[vm_plane_x(I)];
-  const float* P = (g ? F.plane[1][I] : F.plane[0][I]) + APP_HALF * h + 4 * Q0;
-  const float* L = (g ? F.line[1][I] : F.line[0][I]) + APP_HALF * h + 4 * Q0;
+  const float* P = (g ? F.plane[1][I] : F.plane[0][I]) + 4 * h + 8 * Q0;
+  const float* L = (g ? F.line[1][I] : F.line[0][I]) + 4 * h + 8 * Q0;
   const f32x4* p00 = (const f32x4*)(P + (Y.i0 * W + X.i0) * APP_C);
   const f32x4* p01 = (const f32x4*)(P + (Y.i0 * W + X.i1) * APP_C);
   const f32x4* p10 = (const f32x4*)(P + (Y.i1 * W + X.i0) * APP_C);
@@ -496,8 +504,8 @@ __device__ __forceinline__ void gather_quads3(const DevField& F, const VMTaps& t
   const float w10 = __fmul_rn(Y.w1, X.w0), w11 = __fmul_rn(Y.w1, X.w1);
 #pragma unroll
   for (int q = 0; q < 3; ++q) {
-    const f32x4 pv = p00[q] * w00 + p01[q] * w01 + p10[q] * w10 + p11[q] * w11;
-    const f32x4 lv = l0[q] * Ln.w0 + l1[q] * Ln.w1;
+    const f32x4 pv = p00[2 * q] * w00 + p01[2 * q] * w01 + p10[2 * q] * w10 + p11[2 * q] * w11;
+    const f32x4 lv = l0[2 * q] * Ln.w0 + l1[2 * q] * Ln.w1;
     const f32x4 m = pv * lv;
     v[q * 4 + 0] = m.x; v[q * 4 + 1] = m.y; v[q * 4 + 2] = m.z; v[q * 4 + 3] = m.w;
   }
@@ -522,24 +530,49 @@ __device__ __forceinline__ void basis_step(const BasisFrag& a, const float x[8],
   fe = MFMAH(a.hi, b.lo, fe);
 }
 
-template <int STEP>
-__device__ __forceinline__ void basis_step_mixed(const u32x4* __restrict__ BASH, int lane, int g, const float x[8], f32x16& fe) {
-  const BasisFrag a = basis_frag<STEP>(BASH, lane, 1);
-  basis_step(a, x, g != 0, fe);
+// One pass over the 9 basis k-steps with weight set `gsel`.  MASKED: lanes with keep == false contribute zeros
+// (a lane only feeds its own output column), used twice for the rare waves that straddle the yin/yang border.
+template <bool MASKED>
+__device__ __forceinline__ void gather_basis(const DevField& F, const VMTaps& taps, const u32x4* __restrict__ BASH, int lane, int g,
+                                             int h, int gsel, bool keep_in, f32x16& fe) {
+  const bool keep = !MASKED || keep_in;  // compile-time true on the uniform path: the selects fold away
+  float v0[24], v1[24], v2[24];
+  BasisFrag f0, f1, f2;
+  gather_quads3<0, 0>(F, taps, g, h, v0);
+  f0 = basis_frag<0>(BASH, lane, gsel);
+  __builtin_amdgcn_sched_barrier(0);
+  gather_quads3<0, 3>(F, taps, g, h, v0 + 12);
+  f1 = basis_frag<1>(BASH, lane, gsel); f2 = basis_frag<2>(BASH, lane, gsel);
+  basis_step(f0, v0, keep, fe);
+  __builtin_amdgcn_sched_barrier(0);
+  gather_quads3<1, 0>(F, taps, g, h, v1);
+  f0 = basis_frag<3>(BASH, lane, gsel);
+  basis_step(f1, v0 + 8, keep, fe); basis_step(f2, v0 + 16, keep, fe);
+  __builtin_amdgcn_sched_barrier(0);
+  gather_quads3<1, 3>(F, taps, g, h, v1 + 12);
+  f1 = basis_frag<4>(BASH, lane, gsel); f2 = basis_frag<5>(BASH, lane, gsel);
+  basis_step(f0, v1, keep, fe);
+  __builtin_amdgcn_sched_barrier(0);
+  gather_quads3<2, 0>(F, taps, g, h, v2);
+  f0 = basis_frag<6>(BASH, lane, gsel);
+  basis_step(f1, v1 + 8, keep, fe); basis_step(f2, v1 + 16, keep, fe);
+  __builtin_amdgcn_sched_barrier(0);
+  gather_quads3<2, 3>(F, taps, g, h, v2 + 12);
+  f1 = basis_frag<7>(BASH, lane, gsel); f2 = basis_frag<8>(BASH, lane, gsel);
+  basis_step(f0, v2, keep, fe);
+  __builtin_amdgcn_sched_barrier(0);
+  basis_step(f1, v2 + 8, keep, fe); basis_step(f2, v2 + 16, keep, fe);
 }
 
 template <int MODE>
 __global__ __launch_bounds__(512) void k_shade_h(ShadeArgs A) {
-  __shared__ __attribute__((aligned(16))) float lds[(MODE == MODE_APP ? 0 : LDS_W_FLOATS) + (MODE == MODE_MLP ? 4 : LUT_MAX)];
-  float* lut = lds + (MODE == MODE_APP ? 0 : LDS_W_FLOATS);
+  __shared__ __attribute__((aligned(16))) float lds[(MODE == MODE_APP ? 0 : LDS_W_FLOATS) + 4];
   const float* blob = A.packed + PACKED_FLOATS;  // the f16x3 half of the packed blob
   if (MODE != MODE_APP) {
     const f32x4* src = (const f32x4*)blob;
     f32x4* dst = (f32x4*)lds;
     for (int i = threadIdx.x; i < LDS_W_FLOATS / 4; i += 512) dst[i] = src[i];
   }
-  if (MODE == MODE_SHADE)
-    for (int i = threadIdx.x; i < A.c.n_lut; i += 512) lut[i] = A.c.r_lut[i];
   __syncthreads();
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -579,57 +612,28 @@ __global__ __launch_bounds__(512) void k_shade_h(ShadeArgs A) {
       } else {
         const uint32_t ray = (uint32_t)m / (uint32_t)A.S;
         const float* R = A.rays + (int64_t)ray * 6;
-        const float zz = A.z[m];
         vd0 = R[3]; vd1 = R[4]; vd2 = R[5];
-        const float px = __fadd_rn(R[0], __fmul_rn(vd0, zz)), py = __fadd_rn(R[1], __fmul_rn(vd1, zz)),
-                    pz = __fadd_rn(R[2], __fmul_rn(vd2, zz));
-        const YinYang y = yinyang_from_xyz(px, py, pz, A.c);
-        g = y.yang;
-        a_r = normalize_r(y.r, lut, A.c.n_lut, A.c.n_r);
-        a_th = normalize_ang(y.th, A.c.th_near, A.c.th_inv);
-        a_ph = normalize_ang(y.ph, A.c.ph_near, A.c.ph_inv);
+        // normalised coordinates come from ego_march_density (no acos/atan2/LUT search here)
+        const f32x4 cc = ((const f32x4*)A.coords)[m];
+        a_r = cc.x; a_th = cc.y; a_ph = cc.z; g = cc.w != 0.f;
       }
       const bool any_yin = __ballot(g == 0) != 0ull, any_yang = __ballot(g != 0) != 0ull;
       const bool mixed = any_yin && any_yang;
       const int gu = any_yin ? 0 : 1;
-      const bool keep = !mixed || g == 0;
       const VMTaps taps = vm_setup(a_r, a_th, a_ph, A.F.res);
 #pragma unroll
       for (int r = 0; r < 16; ++r) fe[r] = 0.f;
       // per plane: two half-stages of 18 loads (12 products each); 3 basis k-steps of 8 products.  Loads of the
       // next half-stage are issued before the MFMAs of the previous one; sched_barriers bound the hoisting.
-      float v0[24], v1[24], v2[24];
-      BasisFrag f0, f1, f2;
-      gather_quads3<0, 0>(A.F, taps, g, h, v0);
-      f0 = basis_frag<0>(BASH, lane, gu);
-      __builtin_amdgcn_sched_barrier(0);
-      gather_quads3<0, 3>(A.F, taps, g, h, v0 + 12);
-      f1 = basis_frag<1>(BASH, lane, gu); f2 = basis_frag<2>(BASH, lane, gu);
-      basis_step(f0, v0, keep, fe);
-      if (mixed) basis_step_mixed<0>(BASH, lane, g, v0, fe);
-      __builtin_amdgcn_sched_barrier(0);
-      gather_quads3<1, 0>(A.F, taps, g, h, v1);
-      f0 = basis_frag<3>(BASH, lane, gu);
-      basis_step(f1, v0 + 8, keep, fe); basis_step(f2, v0 + 16, keep, fe);
-      if (mixed) { basis_step_mixed<1>(BASH, lane, g, v0 + 8, fe); basis_step_mixed<2>(BASH, lane, g, v0 + 16, fe); }
-      __builtin_amdgcn_sched_barrier(0);
-      gather_quads3<1, 3>(A.F, taps, g, h, v1 + 12);
-      f1 = basis_frag<4>(BASH, lane, gu); f2 = basis_frag<5>(BASH, lane, gu);
-      basis_step(f0, v1, keep, fe);
-      if (mixed) basis_step_mixed<3>(BASH, lane, g, v1, fe);
-      __builtin_amdgcn_sched_barrier(0);
-      gather_quads3<2, 0>(A.F, taps, g, h, v2);
-      f0 = basis_frag<6>(BASH, lane, gu);
-      basis_step(f1, v1 + 8, keep, fe); basis_step(f2, v1 + 16, keep, fe);
-      if (mixed) { basis_step_mixed<4>(BASH, lane, g, v1 + 8, fe); basis_step_mixed<5>(BASH, lane, g, v1 + 16, fe); }
-      __builtin_amdgcn_sched_barrier(0);
-      gather_quads3<2, 3>(A.F, taps, g, h, v2 + 12);
-      f1 = basis_frag<7>(BASH, lane, gu); f2 = basis_frag<8>(BASH, lane, gu);
-      basis_step(f0, v2, keep, fe);
-      if (mixed) basis_step_mixed<6>(BASH, lane, g, v2, fe);
-      __builtin_amdgcn_sched_barrier(0);
-      basis_step(f1, v2 + 8, keep, fe); basis_step(f2, v2 + 16, keep, fe);
-      if (mixed) { basis_step_mixed<7>(BASH, lane, g, v2 + 8, fe); basis_step_mixed<8>(BASH, lane, g, v2 + 16, fe); }
+      // Waves whose 32 samples all lie in one grid (the common case) take the path without per-value masking.
+      if (!mixed) {
+        // lw / hw (opaque copies of lane / lane half) keep the per-table base pointers from being hoisted out of
+        // the tile loop, where 24 64-bit loop invariants would spill
+        gather_basis<false>(A.F, taps, BASH, lw, g, hw, gu, true, fe);
+      } else {
+        gather_basis<true>(A.F, taps, BASH, lw, g, hw, 0, g == 0, fe);
+        gather_basis<true>(A.F, taps, BASH, lw, g, hw, 1, g != 0, fe);
+      }
     }
 
     if (MODE == MODE_APP) {
@@ -645,9 +649,9 @@ __global__ __launch_bounds__(512) void k_shade_h(ShadeArgs A) {
     float vw[8];
     {
       float sa0, ca0, sb0, cb0, sa1, ca1, sb1, cb1, sa2, ca2, sb2, cb2;
-      sincos_f32(vd0, sa0, ca0); sincos_f32(__fmul_rn(vd0, 2.f), sb0, cb0);
-      sincos_f32(vd1, sa1, ca1); sincos_f32(__fmul_rn(vd1, 2.f), sb1, cb1);
-      sincos_f32(vd2, sa2, ca2); sincos_f32(__fmul_rn(vd2, 2.f), sb2, cb2);
+      sincos_x_2x(vd0, sa0, ca0, sb0, cb0);
+      sincos_x_2x(vd1, sa1, ca1, sb1, cb1);
+      sincos_x_2x(vd2, sa2, ca2, sb2, cb2);
       vw[0] = h ? sb2 : vd0; vw[1] = h ? ca0 : vd1; vw[2] = h ? cb0 : vd2; vw[3] = h ? ca1 : sa0;
       vw[4] = h ? cb1 : sb0; vw[5] = h ? ca2 : sa1; vw[6] = h ? cb2 : sb1; vw[7] = h ? 0.f : sa2;
     }
@@ -664,15 +668,18 @@ __global__ __launch_bounds__(512) void k_shade_h(ShadeArgs A) {
     {
       float s1 = 0.f, c1 = 0.f, s2 = 0.f, c2 = 0.f;
       float xs[8];
+      h8 ah[4], al[4], nh[4], nl[4];  // A fragments of the current / next k-step (LDS reads issued one step ahead)
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        nh[mt] = __builtin_bit_cast(h8, W1[(mt * 2 + 0) * 64 + lw]);
+        nl[mt] = __builtin_bit_cast(h8, W1[(mt * 2 + 1) * 64 + lw]);
+      }
 #pragma unroll
       for (int kk = 0; kk < KS1; ++kk) {
         float x;
         if (kk < 5 * NSLOT) {
           const int r = kk / 5, kind = kk % 5;
-          if (kind == 0) {
-            sincos_f32(fe[r], s1, c1);
-            sincos_f32(__fmul_rn(fe[r], 2.f), s2, c2);
-          }
+          if (kind == 0) sincos_x_2x(fe[r], s1, c1, s2, c2);
           x = kind == 0 ? fe[r] : (kind == 1 ? s1 : (kind == 2 ? s2 : (kind == 3 ? c1 : c2)));
         } else if (kk < 5 * NSLOT + 8) {
           x = vw[kk - 5 * NSLOT];
@@ -683,11 +690,14 @@ __global__ __launch_bounds__(512) void k_shade_h(ShadeArgs A) {
         if ((kk & 7) == 7) {
           const int step = kk >> 3;
           const HL b = split8(xs, true);
-          h8 ah[4], al[4];
 #pragma unroll
-          for (int mt = 0; mt < 4; ++mt) {
-            ah[mt] = __builtin_bit_cast(h8, W1[((step * 4 + mt) * 2 + 0) * 64 + lw]);
-            al[mt] = __builtin_bit_cast(h8, W1[((step * 4 + mt) * 2 + 1) * 64 + lw]);
+          for (int mt = 0; mt < 4; ++mt) { ah[mt] = nh[mt]; al[mt] = nl[mt]; }
+          if (step + 1 < KH1) {
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+              nh[mt] = __builtin_bit_cast(h8, W1[(((step + 1) * 4 + mt) * 2 + 0) * 64 + lw]);
+              nl[mt] = __builtin_bit_cast(h8, W1[(((step + 1) * 4 + mt) * 2 + 1) * 64 + lw]);
+            }
           }
 #pragma unroll
           for (int mt = 0; mt < 4; ++mt) H[mt] = MFMAH(ah[mt], b.hi, H[mt]);
@@ -712,34 +722,49 @@ __global__ __launch_bounds__(512) void k_shade_h(ShadeArgs A) {
         const f32x4 b = B2[(mt * 2 + hw) * 4 + q];
         G[mt][q * 4 + 0] = b.x; G[mt][q * 4 + 1] = b.y; G[mt][q * 4 + 2] = b.z; G[mt][q * 4 + 3] = b.w;
       }
-#pragma unroll
-    for (int step = 0; step < KH2; ++step) {
-      float xs[8];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) xs[e] = H[(step * 8 + e) >> 4][(step * 8 + e) & 15];
-      const HL b = split8(xs, true);
-      h8 ah[4], al[4];
+    {
+      h8 ah[4], al[4], nh[4], nl[4];
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt) {
-        ah[mt] = __builtin_bit_cast(h8, W2[((step * 4 + mt) * 2 + 0) * 64 + lw]);
-        al[mt] = __builtin_bit_cast(h8, W2[((step * 4 + mt) * 2 + 1) * 64 + lw]);
+        nh[mt] = __builtin_bit_cast(h8, W2[(mt * 2 + 0) * 64 + lw]);
+        nl[mt] = __builtin_bit_cast(h8, W2[(mt * 2 + 1) * 64 + lw]);
       }
 #pragma unroll
-      for (int mt = 0; mt < 4; ++mt) G[mt] = MFMAH(ah[mt], b.hi, G[mt]);
+      for (int step = 0; step < KH2; ++step) {
+        float xs[8];
 #pragma unroll
-      for (int mt = 0; mt < 4; ++mt) G[mt] = MFMAH(al[mt], b.hi, G[mt]);
+        for (int e = 0; e < 8; ++e) xs[e] = H[(step * 8 + e) >> 4][(step * 8 + e) & 15];
+        const HL b = split8(xs, true);
 #pragma unroll
-      for (int mt = 0; mt < 4; ++mt) G[mt] = MFMAH(ah[mt], b.lo, G[mt]);
+        for (int mt = 0; mt < 4; ++mt) { ah[mt] = nh[mt]; al[mt] = nl[mt]; }
+        if (step + 1 < KH2) {
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt) {
+            nh[mt] = __builtin_bit_cast(h8, W2[(((step + 1) * 4 + mt) * 2 + 0) * 64 + lw]);
+            nl[mt] = __builtin_bit_cast(h8, W2[(((step + 1) * 4 + mt) * 2 + 1) * 64 + lw]);
+          }
+        }
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) G[mt] = MFMAH(ah[mt], b.hi, G[mt]);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) G[mt] = MFMAH(al[mt], b.hi, G[mt]);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) G[mt] = MFMAH(ah[mt], b.lo, G[mt]);
+      }
     }
     float o0 = 0.f, o1 = 0.f, o2 = 0.f;
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
+    for (int mt = 0; mt < 4; ++mt) {
+      f32x4 w3[16];  // all 16 rows of this tile first: one LDS latency instead of 16 exposed round trips
+#pragma unroll
+      for (int r = 0; r < 16; ++r) w3[r] = W3[(mt * 2 + hw) * 16 + r];
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const f32x4 w = W3[(mt * 2 + hw) * 16 + r];
         const float hv = fmaxf(G[mt][r], 0.f);
-        o0 = fmaf(hv, w.x, o0); o1 = fmaf(hv, w.y, o1); o2 = fmaf(hv, w.z, o2);
+        o0 = fmaf(hv, w3[r].x, o0); o1 = fmaf(hv, w3[r].y, o1); o2 = fmaf(hv, w3[r].z, o2);
       }
+    }
     o0 += __shfl_xor(o0, 32, 64);
     o1 += __shfl_xor(o1, 32, 64);
     o2 += __shfl_xor(o2, 32, 64);
@@ -822,13 +847,15 @@ int ego_mlp_fea(const ego_scene* sc, const float* viewdirs, const float* feat, i
   return ego_launch_status("k_shade<MLP>");
 }
 
-int ego_shade(const ego_scene* sc, const float* rays, const float* z, int64_t N, int32_t S, float* rgb, void* stream) {
+int ego_shade(const ego_scene* sc, const float* rays, const float* z, const float* coords, int64_t N, int32_t S, float* rgb,
+              void* stream) {
   EGO_REQUIRE(rays && z && rgb && N >= 0 && S >= 1 && N * (int64_t)S < (1ll << 31), "shade: null argument or N*S >= 2^31");
   if (int e = check_shade_config(sc, "shade", true, true)) return e;
   EGO_REQUIRE(sc->r_lut && sc->n_r_lut >= 2 && sc->n_r_lut <= LUT_MAX, "shade: r_lut missing or > 1024 entries");
+  EGO_REQUIRE(coords || sc->mlp_precision == EGO_PREC_F32, "shade: coords (from ego_march_density) is required unless mlp_precision = EGO_PREC_F32");
   if (N == 0) return EGO_OK;
   ShadeArgs a{};
-  a.c = make_coords(*sc); a.F = make_field(sc->app); a.packed = sc->packed; a.rays = rays; a.z = z; a.out = rgb;
+  a.c = make_coords(*sc); a.F = make_field(sc->app); a.packed = sc->packed; a.rays = rays; a.z = z; a.coords = coords; a.out = rgb;
   a.M = N * (int64_t)S; a.S = S;
   if (sc->mlp_precision == EGO_PREC_F32) k_shade<MODE_SHADE><<<shade_grid(a.M), 512, 0, (hipStream_t)stream>>>(a);
   else k_shade_h<MODE_SHADE><<<shade_grid(a.M), 512, 0, (hipStream_t)stream>>>(a);

@@ -144,14 +144,17 @@ int ego_pack_mlp(const ego_scene* sc, float* packed_out, void* stream);
  * z_in [N][S] explicit sample distances, or NULL: z = near + r_sched[s] (+ jitter).  coarse selects the
  * pooled tables.  Outputs (any may be NULL): z_out [N][S], alpha [N][alpha_stride] (alpha_stride 0 = S;
  * columns S.. are filled with 1, the reference's trailing ones column when an envmap is present,
- * EgoNeRF.py:587), weight [N][S], bg_weight [N]. */
+ * EgoNeRF.py:587), weight [N][S], bg_weight [N], coords_out [N][S][4] = normalised (r, theta, phi) of the sample's
+ * grid + is_yang flag (what ego_shade needs; saves it the acos/atan2/LUT search). */
 int ego_march_density(const ego_scene* sc, const float* rays, int64_t N, int32_t S, const float* z_in,
                       const float* r_sched, const float* jitter, float near_, int32_t coarse, float* z_out,
-                      float* alpha, int32_t alpha_stride, float* weight, float* bg_weight, void* stream);
+                      float* alpha, int32_t alpha_stride, float* weight, float* bg_weight, float* coords_out, void* stream);
 
 /* Appearance lookup -> basis -> positional encoding -> MLP for every sample: rgb [N][S][3].
- * z [N][S] sample distances (from ego_march_density). */
-int ego_shade(const ego_scene* sc, const float* rays, const float* z, int64_t N, int32_t S, float* rgb, void* stream);
+ * z [N][S] sample distances (from ego_march_density); coords [N][S][4] optional (ego_march_density's coords_out),
+ * NULL = recompute the yin-yang coordinates from rays and z. */
+int ego_shade(const ego_scene* sc, const float* rays, const float* z, const float* coords, int64_t N, int32_t S, float* rgb,
+              void* stream);
 
 /* acc, rgb_map (+ envmap background), clamp, depth (+ (1-acc)*d_z quirk, EgoNeRF.py:598).
  * Outputs rgb_map [N][3], depth [N]; bg_map/env_map [N][3] written only when sc->envmap != NULL (may be NULL). */

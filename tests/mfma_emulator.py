@@ -21,6 +21,11 @@ def slot_row(r, h):
     return (r & 3) + 8 * (r >> 2) + 4 * h
 
 
+def app_channel(kk, h):
+    """Appearance channel gathered by lane half h as its kk-th product (halves interleave per float4 quad)."""
+    return (kk // APP_HALF) * APP_C + ((kk % APP_HALF) // 4) * 8 + 4 * h + kk % 4
+
+
 def x_channel(kk, h):
     if kk < 5 * NSLOT:
         kind, r = kk % 5, kk // 5
@@ -71,8 +76,7 @@ def pack_mlp(w):
             f = 2 * r + rh
             if r < NSLOT and f < APP_DIM:
                 for kk in range(KS_BASIS):
-                    col = (kk // APP_HALF) * APP_C + APP_HALF * h + kk % APP_HALF
-                    BAS[g, kk // 4, lane, kk % 4] = bm[f, col]
+                    BAS[g, kk // 4, lane, kk % 4] = bm[f, app_channel(kk, h)]
     return out
 
 
@@ -96,8 +100,7 @@ def emulate_tile(packed, v, grid_flag, viewdirs):
     # lane's B operands for the basis: its half of each plane's channels
     vl = np.zeros((64, KS_BASIS))
     for kk in range(KS_BASIS):
-        col = (kk // APP_HALF) * APP_C + APP_HALF * h + kk % APP_HALF
-        vl[:, kk] = v[j, col]
+        vl[:, kk] = v[j, app_channel(kk, h)]
     g = grid_flag[j]
     BAS = packed[OFF_BASIS:].reshape(2, KS_BASIS // 4, 64, 4)
     fe = np.zeros((64, 16))
