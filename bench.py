@@ -28,6 +28,7 @@ from egonerf_amd import synth  # noqa: E402
 N_RAYS, N_SAMPLES = 4096, 512
 HBM_PEAK_GBPS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3  # fp32-input MFMA dense peak
+MFMA_F16_PEAK_TFLOPS = 2500.0  # dense fp16/bf16 MFMA peak
 # algorithmic bytes / flops per sample: density 3*(4+2) taps * 16 ch * 4 B, appearance ... * 48 ch
 B_DENSITY, B_APP = 1152, 3456
 FLOP_SAMPLE_SHADE = 2 * (150 * 128 + 128 * 128 + 128 * 3) + 2 * 144 * 27  # MLP + basis
@@ -139,17 +140,34 @@ def main():
         torch.cuda.synchronize()
         ms = np.array([[e[k].elapsed_time(e[k + 1]) for k in range(3)] for e in ev]).mean(0)
         t_march, t_shade, t_comp = (float(x) * 1e-3 for x in ms)
-        shade_bytes = (B_APP + 4 + 12) * M          # gathered taps + z read + rgb write
+        shade_bytes = (B_APP + 16 + 12) * M         # gathered taps + 16 B coords read + 12 B rgb write, per sample
         shade_gbps = shade_bytes / t_shade / 1e9
         shade_tflops = FLOP_SAMPLE_SHADE * M / t_shade / 1e12
-        roofline = dict(bound="hbm", kernel="k_shade<SHADE>", achieved=shade_gbps, peak=HBM_PEAK_GBPS, unit="GB/s",
-                        frac=shade_gbps / HBM_PEAK_GBPS, traffic=None, ms=t_shade * 1e3,
+        prec = model.mlp_precision
+        kname = "k_shade_h<SHADE>" if prec == "f16x3" else "k_shade<SHADE>"
+        # HBM bytes per launch from the committed PMC passes of this build (bench.py cannot collect PMC counters live)
+        traffic, traffic_src = None, None
+        try:
+            pmc = json.load(open(os.path.join(REPO, "profiles", "r01", "pmc_traffic.json")))
+            if kname in pmc:
+                traffic, traffic_src = pmc[kname]["traffic_bytes"], "profiles/r01/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE)"
+        except OSError:
+            pass
+        # matrix-pipe view: f16x3 executes 3 fp16 MFMA flops per algorithmic flop (dense fp16 peak ~2.5 PF)
+        mfma = (dict(mode="f16x3", achieved_algorithmic=shade_tflops, executed=3 * shade_tflops, peak=MFMA_F16_PEAK_TFLOPS,
+                     unit="TFLOP/s", frac=3 * shade_tflops / MFMA_F16_PEAK_TFLOPS) if prec == "f16x3" else
+                dict(mode="f32", achieved=shade_tflops, peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s", frac=shade_tflops / MFMA_F32_PEAK_TFLOPS))
+        l1_peak = 256 * 64 * 2.4  # GB/s: 64 B/clk/CU vector-L1 return path x 256 CUs x 2.4 GHz
+        roofline = dict(bound="hbm", kernel=kname, achieved=shade_gbps, peak=HBM_PEAK_GBPS, unit="GB/s",
+                        frac=shade_gbps / HBM_PEAK_GBPS, traffic=traffic, traffic_source=traffic_src, ms=t_shade * 1e3,
                         algorithmic_bytes_per_launch=shade_bytes,
-                        mfma_f32=dict(achieved=shade_tflops, peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s",
-                                      frac=shade_tflops / MFMA_F32_PEAK_TFLOPS),
+                        note="the 94 MB table set is L2/Infinity-Cache resident, so algorithmic bytes/s exceeds the HBM peak; "
+                             "the binding resource is the vector-L1 return path (l1) and VALU issue",
+                        l1=dict(achieved=shade_gbps, peak=l1_peak, unit="GB/s", frac=shade_gbps / l1_peak),
+                        mfma=mfma,
                         other_kernels_ms=dict(k_march_density=t_march * 1e3, k_composite=t_comp * 1e3),
-                        march_density=dict(achieved=(B_DENSITY + 12) * M / t_march / 1e9, unit="GB/s",
-                                           frac=(B_DENSITY + 12) * M / t_march / 1e9 / HBM_PEAK_GBPS),
+                        march_density=dict(achieved=(B_DENSITY + 28) * M / t_march / 1e9, unit="GB/s",
+                                           frac=(B_DENSITY + 28) * M / t_march / 1e9 / HBM_PEAK_GBPS),
                         path_algorithmic_GBps=(B_DENSITY + B_APP) * M / (t_march + t_shade + t_comp) / 1e9)
 
         cpu = None
@@ -166,7 +184,9 @@ def main():
         rays_per_s = world * N_RAYS * a.steps / dt
         line = dict(metric="rays/sec at 4096-ray batch, 512 samples (EgoNeRF volume-rendering forward)", value=rays_per_s,
                     unit="rays/s", samples_per_s=rays_per_s * N_SAMPLES, n_gpus=world, steps=a.steps, warmup=a.warmup,
-                    ms_per_step=dt / a.steps * 1e3, higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32",
+                    ms_per_step=dt / a.steps * 1e3, higher_is_better=True, scaling="weak", vs_baseline=None,
+                    dtype="f32 (tables, interpolation, compositing; matrix products as 3x fp16 MFMA with fp32 accumulate)"
+                    if model.mlp_precision == "f16x3" else "f32",
                     data="synthetic",
                     config=dict(workload="OmniBlender barbershop shape: grid [150,172,516], 16x3/48x3 comps, MLP_Fea; "
                                          "4096 rays x 512 samples, eval, no resampling (BASELINE configs[1])",
