@@ -43,6 +43,14 @@ class RenderArgs(C.Structure):
                 ("u", C.c_void_p), ("near_", C.c_float), ("reserved", C.c_int32)]
 
 
+class VmGrad(C.Structure):
+    _fields_ = [("plane", (C.c_void_p * 3) * 2), ("line", (C.c_void_p * 3) * 2)]
+
+
+class ShadeDump(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("h1", C.c_void_p), ("h2", C.c_void_p), ("v", C.c_void_p)]
+
+
 P, I32, I64, F32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 SP = C.POINTER(Scene)
 
@@ -64,9 +72,14 @@ PROTOTYPES = {
     "ego_envmap_radiance": (C.c_int, [SP, P, I64, P, P]),
     "ego_avgpool_table": (C.c_int, [P, I32, I32, I32, P, P]),
     "ego_pack_mlp": (C.c_int, [SP, P, P]),
-    "ego_march_density": (C.c_int, [SP, P, I64, I32, P, P, P, F32, I32, P, P, I32, P, P, P, P]),
-    "ego_shade": (C.c_int, [SP, P, P, P, I64, I32, P, P]),
-    "ego_composite": (C.c_int, [SP, P, P, P, P, P, I64, I32, P, P, P, P, P]),
+    "ego_march_density": (C.c_int, [SP, P, I64, I32, P, P, P, F32, I32, P, P, I32, P, P, P, P, P]),
+    "ego_shade": (C.c_int, [SP, P, P, P, I64, I32, P, P, P]),
+    "ego_composite": (C.c_int, [SP, P, P, P, P, P, I64, I32, P, P, P, P, P, P]),
+    "ego_train_packed_floats": (I64, []),
+    "ego_pack_train": (C.c_int, [SP, P, P]),
+    "ego_train_layout": (C.c_int, [I32, C.POINTER(C.c_int32), I32]),
+    "ego_march_backward": (C.c_int, [SP, C.POINTER(VmGrad), P, P, P, P, P, P, P, P, P, P, I64, I32, P, P]),
+    "ego_shade_backward": (C.c_int, [SP, P, C.POINTER(VmGrad), P, P, P, C.POINTER(ShadeDump), P, P, P, I64, I32, P]),
     "ego_render_workspace_bytes": (I64, [I64, C.POINTER(RenderArgs)]),
     "ego_render_forward": (C.c_int, [SP, C.POINTER(RenderArgs), P, I64, P, P, P, P, P, P, P]),
 }

@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libegonerf_hip.so")
 SOURCES = ["ego_ops.hip", "ego_shade.hip", "ego_render.hip"]
-HEADERS = ["ego_device.h", "ego_host.h", os.path.join("..", "..", "include", "egonerf_hip.h")]
+HEADERS = ["ego_device.h", "ego_host.h", "ego_train.inc", os.path.join("..", "..", "include", "egonerf_hip.h")]
 
 
 def _hipcc() -> str:
@@ -31,7 +31,7 @@ def is_stale() -> bool:
 def build_library(force: bool = False, verbose: bool = False) -> str:
     if not force and not is_stale():
         return LIB
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-shared", "-fPIC",
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-munsafe-fp-atomics", "-shared", "-fPIC",
            *[os.path.join(CSRC, f) for f in SOURCES], "-o", LIB + ".tmp"]
     if verbose:
         print(" ".join(cmd))

@@ -152,7 +152,8 @@ __global__ __launch_bounds__(256) void k_march_density(DevCoords c, DevField F, 
                                                        int softplus, float shift, float dscale,
                                                        float* __restrict__ z_out, float* __restrict__ alpha,
                                                        int alpha_stride, float* __restrict__ weight,
-                                                       float* __restrict__ bg, float* __restrict__ coords_out) {
+                                                       float* __restrict__ bg, float* __restrict__ coords_out,
+                                                       float* __restrict__ sigma_out) {
   __shared__ float lut[1024];
   for (int i = threadIdx.x; i < c.n_lut; i += blockDim.x) lut[i] = c.r_lut[i];
   __syncthreads();
@@ -194,6 +195,7 @@ __global__ __launch_bounds__(256) void k_march_density(DevCoords c, DevField F, 
       const int64_t o = ray * S + s;
       if (z_out) z_out[o] = z;
       if (coords_out) ((f32x4*)coords_out)[o] = f32x4{a_r, a_th, a_ph, y.yang ? 1.f : 0.f};
+      if (sigma_out) sigma_out[o] = sg;
       if (alpha) alpha[ray * alpha_stride + s] = a;
       if (weight) weight[o] = a * T;
     }
@@ -242,7 +244,7 @@ __global__ void k_composite(const float* __restrict__ em, int em_h, const float*
                             const float* __restrict__ z, const float* __restrict__ weight,
                             const float* __restrict__ bgw, const float* __restrict__ rgb, int64_t N, int S,
                             float* __restrict__ rgb_map, float* __restrict__ depth, float* __restrict__ bg_map,
-                            float* __restrict__ env_map) {
+                            float* __restrict__ env_map, float* __restrict__ rgb_raw) {
   const int lane = threadIdx.x & 63;
   const int64_t ray = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (ray >= N) return;
@@ -268,6 +270,7 @@ __global__ void k_composite(const float* __restrict__ em, int em_h, const float*
     if (bg_map) { bg_map[ray * 3] = bx; bg_map[ray * 3 + 1] = by; bg_map[ray * 3 + 2] = bz; }
     if (env_map) { env_map[ray * 3] = e[0]; env_map[ray * 3 + 1] = e[1]; env_map[ray * 3 + 2] = e[2]; }
   }
+  if (rgb_raw) { rgb_raw[ray * 3] = cr; rgb_raw[ray * 3 + 1] = cg; rgb_raw[ray * 3 + 2] = cb; }
   rgb_map[ray * 3] = fminf(fmaxf(cr, 0.f), 1.f);
   rgb_map[ray * 3 + 1] = fminf(fmaxf(cg, 0.f), 1.f);
   rgb_map[ray * 3 + 2] = fminf(fmaxf(cb, 0.f), 1.f);
@@ -489,7 +492,8 @@ int ego_avgpool_table(const float* src, int32_t H, int32_t W, int32_t C, float* 
 
 int ego_march_density(const ego_scene* sc, const float* rays, int64_t N, int32_t S, const float* z_in,
                       const float* r_sched, const float* jitter, float near_, int32_t coarse, float* z_out,
-                      float* alpha, int32_t alpha_stride, float* weight, float* bg_weight, float* coords_out, void* stream) {
+                      float* alpha, int32_t alpha_stride, float* weight, float* bg_weight, float* coords_out, float* sigma_out,
+                      void* stream) {
   EGO_REQUIRE(sc && rays && N >= 0 && S >= 2, "march_density: null argument or S < 2");
   if (alpha_stride == 0) alpha_stride = S;
   EGO_REQUIRE(alpha_stride >= S && alpha_stride <= S + 64, "march_density: alpha_stride must be in [S, S+64]");
@@ -501,18 +505,18 @@ int ego_march_density(const ego_scene* sc, const float* rays, int64_t N, int32_t
   if (f.n_comp != 16) return ego_fail(EGO_E_UNSUPPORTED, "march_density: n_comp %d (supported: 16)", f.n_comp);
   k_march_density<16><<<nblk(N, 4), 256, 0, (hipStream_t)stream>>>(
       make_coords(*sc), make_field(f), rays, N, S, z_in, r_sched, jitter, near_, sc->act_softplus, sc->density_shift,
-      sc->distance_scale, z_out, alpha, alpha_stride, weight, bg_weight, coords_out);
+      sc->distance_scale, z_out, alpha, alpha_stride, weight, bg_weight, coords_out, sigma_out);
   return ego_launch_status("k_march_density");
 }
 
 int ego_composite(const ego_scene* sc, const float* rays, const float* z, const float* weight, const float* bg_weight,
                   const float* rgb, int64_t N, int32_t S, float* rgb_map, float* depth, float* bg_map, float* env_map,
-                  void* stream) {
+                  float* rgb_raw, void* stream) {
   EGO_REQUIRE(sc && rays && z && weight && rgb && rgb_map && N >= 0 && S >= 1, "composite: null argument");
   EGO_REQUIRE(!sc->envmap || bg_weight, "composite: envmap needs bg_weight");
   if (N == 0) return EGO_OK;
   k_composite<<<nblk(N, 4), 256, 0, (hipStream_t)stream>>>(sc->envmap, sc->envmap_h, rays, z, weight, bg_weight, rgb, N, S,
-                                                          rgb_map, depth, bg_map, env_map);
+                                                          rgb_map, depth, bg_map, env_map, rgb_raw);
   return ego_launch_status("k_composite");
 }
 

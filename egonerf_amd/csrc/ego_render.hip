@@ -54,19 +54,19 @@ int ego_render_forward(const ego_scene* sc, const ego_render_args* a, const floa
   if (a->resampling) {
     // coarse pass on the pooled tables -> weights -> inverse-CDF samples merged into the coarse schedule
     if ((e = ego_march_density(sc, rays, N, a->n_coarse, nullptr, a->r_sched, a->jitter, a->near_, 1, ws + p.zc, nullptr, 0,
-                               ws + p.wc, nullptr, nullptr, stream))) return e;
+                               ws + p.wc, nullptr, nullptr, nullptr, stream))) return e;
     if ((e = ego_sample_pdf_merge(ws + p.zc, ws + p.wc, a->u, N, a->n_coarse, a->n_fine, a->use_coarse_sample, ws + p.zf,
                                   nullptr, stream))) return e;
     if ((e = ego_march_density(sc, rays, N, S, ws + p.zf, nullptr, nullptr, a->near_, 0, nullptr, alpha, astride, ws + p.w,
-                               ws + p.bg, ws + p.crd, stream))) return e;
+                               ws + p.bg, ws + p.crd, nullptr, stream))) return e;
     z = ws + p.zf;
   } else {
     if ((e = ego_march_density(sc, rays, N, S, nullptr, a->r_sched, a->jitter, a->near_, 0, ws + p.zc, alpha, astride,
-                               ws + p.w, ws + p.bg, ws + p.crd, stream))) return e;
+                               ws + p.w, ws + p.bg, ws + p.crd, nullptr, stream))) return e;
     z = ws + p.zc;
   }
-  if ((e = ego_shade(sc, rays, z, ws + p.crd, N, S, ws + p.rgb, stream))) return e;
-  return ego_composite(sc, rays, z, ws + p.w, ws + p.bg, ws + p.rgb, N, S, rgb_map, depth, bg_map, env_map, stream);
+  if ((e = ego_shade(sc, rays, z, ws + p.crd, N, S, ws + p.rgb, nullptr, stream))) return e;
+  return ego_composite(sc, rays, z, ws + p.w, ws + p.bg, ws + p.rgb, N, S, rgb_map, depth, bg_map, env_map, nullptr, stream);
 }
 
 }  // extern "C"

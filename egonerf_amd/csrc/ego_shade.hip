@@ -185,6 +185,10 @@ struct ShadeArgs {
   const float* feat;  // MODE_MLP: [M][27]
   const float* dirs;  // MODE_MLP: [M][3]
   float* out;         // rgb [M][3] or feat [M][27]
+  float* dump_x;      // training forward (MODE_SHADE, f16x3): activations kept for the backward pass, lane-contiguous
+  float* dump_h1;     //   [M][160] X, [M][128] relu(H1), [M][128] relu(H2), [M][144] v   (see include/egonerf_hip.h)
+  float* dump_h2;
+  float* dump_v;
   int64_t M;
   int32_t S;
 };
@@ -532,39 +536,52 @@ __device__ __forceinline__ void basis_step(const BasisFrag& a, const float x[8],
 
 // One pass over the 9 basis k-steps with weight set `gsel`.  MASKED: lanes with keep == false contribute zeros
 // (a lane only feeds its own output column), used twice for the rare waves that straddle the yin/yang border.
+__device__ __forceinline__ void dump12(float* dst, const float* v) {
+  if (dst) {
+    f32x4* d = (f32x4*)dst;
+    d[0] = f32x4{v[0], v[1], v[2], v[3]}; d[1] = f32x4{v[4], v[5], v[6], v[7]}; d[2] = f32x4{v[8], v[9], v[10], v[11]};
+  }
+}
+
 template <bool MASKED>
 __device__ __forceinline__ void gather_basis(const DevField& F, const VMTaps& taps, const u32x4* __restrict__ BASH, int lane, int g,
-                                             int h, int gsel, bool keep_in, f32x16& fe) {
+                                             int h, int gsel, bool keep_in, f32x16& fe, float* vdump = nullptr) {
   const bool keep = !MASKED || keep_in;  // compile-time true on the uniform path: the selects fold away
   float v0[24], v1[24], v2[24];
   BasisFrag f0, f1, f2;
   gather_quads3<0, 0>(F, taps, g, h, v0);
+  dump12(vdump ? vdump + 0 : nullptr, v0);
   f0 = basis_frag<0>(BASH, lane, gsel);
   __builtin_amdgcn_sched_barrier(0);
   gather_quads3<0, 3>(F, taps, g, h, v0 + 12);
+  dump12(vdump ? vdump + 12 : nullptr, v0 + 12);
   f1 = basis_frag<1>(BASH, lane, gsel); f2 = basis_frag<2>(BASH, lane, gsel);
   basis_step(f0, v0, keep, fe);
   __builtin_amdgcn_sched_barrier(0);
   gather_quads3<1, 0>(F, taps, g, h, v1);
+  dump12(vdump ? vdump + 24 : nullptr, v1);
   f0 = basis_frag<3>(BASH, lane, gsel);
   basis_step(f1, v0 + 8, keep, fe); basis_step(f2, v0 + 16, keep, fe);
   __builtin_amdgcn_sched_barrier(0);
   gather_quads3<1, 3>(F, taps, g, h, v1 + 12);
+  dump12(vdump ? vdump + 36 : nullptr, v1 + 12);
   f1 = basis_frag<4>(BASH, lane, gsel); f2 = basis_frag<5>(BASH, lane, gsel);
   basis_step(f0, v1, keep, fe);
   __builtin_amdgcn_sched_barrier(0);
   gather_quads3<2, 0>(F, taps, g, h, v2);
+  dump12(vdump ? vdump + 48 : nullptr, v2);
   f0 = basis_frag<6>(BASH, lane, gsel);
   basis_step(f1, v1 + 8, keep, fe); basis_step(f2, v1 + 16, keep, fe);
   __builtin_amdgcn_sched_barrier(0);
   gather_quads3<2, 3>(F, taps, g, h, v2 + 12);
+  dump12(vdump ? vdump + 60 : nullptr, v2 + 12);
   f1 = basis_frag<7>(BASH, lane, gsel); f2 = basis_frag<8>(BASH, lane, gsel);
   basis_step(f0, v2, keep, fe);
   __builtin_amdgcn_sched_barrier(0);
   basis_step(f1, v2 + 8, keep, fe); basis_step(f2, v2 + 16, keep, fe);
 }
 
-template <int MODE>
+template <int MODE, bool DUMP = false>
 __global__ __launch_bounds__(512) void k_shade_h(ShadeArgs A) {
   __shared__ __attribute__((aligned(16))) float lds[(MODE == MODE_APP ? 0 : LDS_W_FLOATS) + 4];
   const float* blob = A.packed + PACKED_FLOATS;  // the f16x3 half of the packed blob
@@ -629,9 +646,9 @@ __global__ __launch_bounds__(512) void k_shade_h(ShadeArgs A) {
       if (!mixed) {
         // lw / hw (opaque copies of lane / lane half) keep the per-table base pointers from being hoisted out of
         // the tile loop, where 24 64-bit loop invariants would spill
-        gather_basis<false>(A.F, taps, BASH, lw, g, hw, gu, true, fe);
+        gather_basis<false>(A.F, taps, BASH, lw, g, hw, gu, true, fe, (DUMP && valid) ? A.dump_v + m * 144 + hw * 72 : nullptr);
       } else {
-        gather_basis<true>(A.F, taps, BASH, lw, g, hw, 0, g == 0, fe);
+        gather_basis<true>(A.F, taps, BASH, lw, g, hw, 0, g == 0, fe, (DUMP && valid) ? A.dump_v + m * 144 + hw * 72 : nullptr);
         gather_basis<true>(A.F, taps, BASH, lw, g, hw, 1, g != 0, fe);
       }
     }
@@ -690,6 +707,10 @@ __global__ __launch_bounds__(512) void k_shade_h(ShadeArgs A) {
         if ((kk & 7) == 7) {
           const int step = kk >> 3;
           const HL b = split8(xs, true);
+          if (DUMP && valid) {
+            f32x4* d = (f32x4*)(A.dump_x + m * 160 + hw * 80 + step * 8);
+            d[0] = f32x4{xs[0], xs[1], xs[2], xs[3]}; d[1] = f32x4{xs[4], xs[5], xs[6], xs[7]};
+          }
 #pragma unroll
           for (int mt = 0; mt < 4; ++mt) { ah[mt] = nh[mt]; al[mt] = nl[mt]; }
           if (step + 1 < KH1) {
@@ -712,6 +733,13 @@ __global__ __launch_bounds__(512) void k_shade_h(ShadeArgs A) {
     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) H[mt][r] = fmaxf(H[mt][r], 0.f);
+    if (DUMP && valid) {
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          ((f32x4*)(A.dump_h1 + m * 128 + hw * 64 + mt * 16))[q] = f32x4{H[mt][4 * q], H[mt][4 * q + 1], H[mt][4 * q + 2], H[mt][4 * q + 3]};
+    }
 
     // ---- layer 2 (8 steps), layer 3 on the VALU ----------------------------------------------------------------
     f32x16 G[4];
@@ -752,6 +780,14 @@ __global__ __launch_bounds__(512) void k_shade_h(ShadeArgs A) {
         for (int mt = 0; mt < 4; ++mt) G[mt] = MFMAH(ah[mt], b.lo, G[mt]);
       }
     }
+    if (DUMP && valid) {
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          ((f32x4*)(A.dump_h2 + m * 128 + hw * 64 + mt * 16))[q] =
+              f32x4{fmaxf(G[mt][4 * q], 0.f), fmaxf(G[mt][4 * q + 1], 0.f), fmaxf(G[mt][4 * q + 2], 0.f), fmaxf(G[mt][4 * q + 3], 0.f)};
+    }
     float o0 = 0.f, o1 = 0.f, o2 = 0.f;
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
@@ -777,6 +813,8 @@ __global__ __launch_bounds__(512) void k_shade_h(ShadeArgs A) {
     }
   }
 }
+
+#include "ego_train.inc"
 
 int check_shade_config(const ego_scene* sc, const char* who, bool need_tables, bool need_mlp) {
   if (!sc) return ego_fail(EGO_E_BADARG, "%s: null scene", who);
@@ -848,7 +886,7 @@ int ego_mlp_fea(const ego_scene* sc, const float* viewdirs, const float* feat, i
 }
 
 int ego_shade(const ego_scene* sc, const float* rays, const float* z, const float* coords, int64_t N, int32_t S, float* rgb,
-              void* stream) {
+              const ego_shade_dump* dump, void* stream) {
   EGO_REQUIRE(rays && z && rgb && N >= 0 && S >= 1 && N * (int64_t)S < (1ll << 31), "shade: null argument or N*S >= 2^31");
   if (int e = check_shade_config(sc, "shade", true, true)) return e;
   EGO_REQUIRE(sc->r_lut && sc->n_r_lut >= 2 && sc->n_r_lut <= LUT_MAX, "shade: r_lut missing or > 1024 entries");
@@ -857,9 +895,109 @@ int ego_shade(const ego_scene* sc, const float* rays, const float* z, const floa
   ShadeArgs a{};
   a.c = make_coords(*sc); a.F = make_field(sc->app); a.packed = sc->packed; a.rays = rays; a.z = z; a.coords = coords; a.out = rgb;
   a.M = N * (int64_t)S; a.S = S;
-  if (sc->mlp_precision == EGO_PREC_F32) k_shade<MODE_SHADE><<<shade_grid(a.M), 512, 0, (hipStream_t)stream>>>(a);
+  if (dump) {
+    EGO_REQUIRE(sc->mlp_precision == EGO_PREC_F16X3 && dump->x && dump->h1 && dump->h2 && dump->v,
+                "shade: activation dumps need mlp_precision = EGO_PREC_F16X3 and four non-null buffers");
+    a.dump_x = dump->x; a.dump_h1 = dump->h1; a.dump_h2 = dump->h2; a.dump_v = dump->v;
+    k_shade_h<MODE_SHADE, true><<<shade_grid(a.M), 512, 0, (hipStream_t)stream>>>(a);
+  } else if (sc->mlp_precision == EGO_PREC_F32) k_shade<MODE_SHADE><<<shade_grid(a.M), 512, 0, (hipStream_t)stream>>>(a);
   else k_shade_h<MODE_SHADE><<<shade_grid(a.M), 512, 0, (hipStream_t)stream>>>(a);
   return ego_launch_status("k_shade<SHADE>");
+}
+
+// ---- training step (backward) --------------------------------------------------------------------------------------
+int64_t ego_train_packed_floats(void) { return TRAIN_FLOATS; }
+
+int ego_pack_train(const ego_scene* sc, float* out, void* stream) {
+  EGO_REQUIRE(sc && out, "pack_train: null argument");
+  if (int e = check_shade_config(sc, "pack_train", true, true)) return e;
+  EGO_REQUIRE(sc->mlp_w[0] && sc->mlp_w[1] && sc->mlp_w[2] && sc->basis[0] && sc->basis[1], "pack_train: null weight");
+  k_pack_train<<<(TRAIN_FLOATS + 255) / 256, 256, 0, (hipStream_t)stream>>>(sc->mlp_w[0], sc->mlp_w[1], sc->mlp_w[2], sc->basis[0],
+                                                                            sc->basis[1], out);
+  return ego_launch_status("k_pack_train");
+}
+
+int ego_train_layout(int32_t which, int32_t* out, int32_t n) {
+  EGO_REQUIRE(out, "train_layout: null output");
+  if (which == 0) {  // x dump column -> reference MLP input column (-1: padding)
+    EGO_REQUIRE(n == 2 * KS1, "train_layout(0): n must be 160");
+    for (int h = 0; h < 2; ++h)
+      for (int kk = 0; kk < KS1; ++kk) {
+        int ch = -1;
+        if (kk < 5 * NSLOT) {
+          const int kind = kk % 5, r = kk / 5, f = 2 * r + h;
+          if (f < APP_DIM) ch = kind == 0 ? f : (kind == 1 ? 30 + 2 * f : (kind == 2 ? 31 + 2 * f : (kind == 3 ? 84 + 2 * f : 85 + 2 * f)));
+        } else if (kk < 5 * NSLOT + 8) {
+          const int t = kk - 5 * NSLOT + 8 * h;
+          ch = t < 3 ? APP_DIM + t : (t < 15 ? 138 + (t - 3) : -1);
+        }
+        out[h * KS1 + kk] = ch;
+      }
+  } else if (which == 1) {  // h1 / h2 / dh1 / dh2 dump column -> hidden unit
+    EGO_REQUIRE(n == HID, "train_layout(1): n must be 128");
+    for (int h = 0; h < 2; ++h)
+      for (int mt = 0; mt < 4; ++mt)
+        for (int r = 0; r < 16; ++r) out[h * 64 + mt * 16 + r] = mt * 32 + slot_row(r, h);
+  } else if (which == 2) {  // dfe column (within one grid's 32) -> feature (-1: padding)
+    EGO_REQUIRE(n == 32, "train_layout(2): n must be 32");
+    for (int h = 0; h < 2; ++h)
+      for (int r = 0; r < 16; ++r) out[h * 16 + r] = (r < NSLOT && 2 * r + h < APP_DIM) ? 2 * r + h : -1;
+  } else if (which == 3) {  // v dump column -> basis input column (0..143)
+    EGO_REQUIRE(n == 2 * KS_BASIS, "train_layout(3): n must be 144");
+    for (int h = 0; h < 2; ++h)
+      for (int kk = 0; kk < KS_BASIS; ++kk) out[h * KS_BASIS + kk] = app_channel(kk, h);
+  } else {
+    return ego_fail(EGO_E_BADARG, "train_layout: which must be 0..3");
+  }
+  return EGO_OK;
+}
+
+static GradField make_grad(const ego_vm_grad& g) {
+  GradField o;
+  for (int a = 0; a < 2; ++a)
+    for (int i = 0; i < 3; ++i) { o.plane[a][i] = g.plane[a][i]; o.line[a][i] = g.line[a][i]; }
+  return o;
+}
+
+static int check_grad(const ego_vm_grad* g, const char* who) {
+  if (!g) return ego_fail(EGO_E_BADARG, "%s: null gradient tables", who);
+  for (int a = 0; a < 2; ++a)
+    for (int i = 0; i < 3; ++i)
+      if (!g->plane[a][i] || !g->line[a][i]) return ego_fail(EGO_E_BADARG, "%s: null gradient table pointer", who);
+  return EGO_OK;
+}
+
+int ego_march_backward(const ego_scene* sc, const ego_vm_grad* gdensity, const float* coords, const float* z, const float* alpha,
+                       const float* weight, const float* sigma, const float* bg_weight, const float* rgb, const float* g_rgb,
+                       const float* rgb_raw, const float* env_map, int64_t N, int32_t S, float* dc, void* stream) {
+  EGO_REQUIRE(N >= 0 && S >= 2, "march_backward: bad size");
+  if (N == 0) return EGO_OK;
+  EGO_REQUIRE(sc && coords && z && alpha && weight && sigma && bg_weight && rgb && g_rgb && rgb_raw && dc, "march_backward: null argument");
+  if (int e = check_grad(gdensity, "march_backward")) return e;
+  if (sc->density.n_comp != 16) return ego_fail(EGO_E_UNSUPPORTED, "march_backward: n_comp %d (supported: 16)", sc->density.n_comp);
+  if (!sc->act_softplus) return ego_fail(EGO_E_UNSUPPORTED, "march_backward: only the softplus density activation is supported");
+  MarchBwdArgs a{};
+  a.F = make_field(sc->density); a.G = make_grad(*gdensity);
+  a.coords = coords; a.z = z; a.alpha = alpha; a.weight = weight; a.sigma = sigma; a.bg = bg_weight; a.rgb = rgb; a.g_rgb = g_rgb;
+  a.rgb_raw = rgb_raw; a.env = env_map; a.dc = dc; a.N = N; a.S = S; a.dscale = sc->distance_scale;
+  k_march_bwd<16><<<(unsigned)((N + 3) / 4), 256, 0, (hipStream_t)stream>>>(a);
+  return ego_launch_status("k_march_bwd");
+}
+
+int ego_shade_backward(const ego_scene* sc, const float* train_packed, const ego_vm_grad* gapp, const float* coords, float* dc,
+                       const float* rgb, const ego_shade_dump* fwd, float* dh2, float* dh1, float* dfe, int64_t N, int32_t S,
+                       void* stream) {
+  EGO_REQUIRE(N >= 0 && S >= 1 && N * (int64_t)S < (1ll << 31), "shade_backward: bad size");
+  if (N == 0) return EGO_OK;
+  EGO_REQUIRE(sc && train_packed && coords && dc && rgb && fwd && fwd->x && fwd->h1 && fwd->h2 && dh2 && dh1 && dfe,
+              "shade_backward: null argument");
+  if (int e = check_grad(gapp, "shade_backward")) return e;
+  if (int e = check_shade_config(sc, "shade_backward", true, true)) return e;
+  ShadeBwdArgs a{};
+  a.F = make_field(sc->app); a.G = make_grad(*gapp); a.tpacked = train_packed; a.coords = coords; a.dc = dc; a.rgb = rgb;
+  a.x = fwd->x; a.h1 = fwd->h1; a.h2 = fwd->h2; a.dh2 = dh2; a.dh1 = dh1; a.dfe = dfe; a.M = N * (int64_t)S;
+  k_shade_bwd<<<shade_grid(a.M), 512, 0, (hipStream_t)stream>>>(a);
+  return ego_launch_status("k_shade_bwd");
 }
 
 }  // extern "C"

@@ -403,26 +403,30 @@ class EgoNeRF(TensorBase):
         if not exp_sampling:
             raise NotImplementedError("exp_sampling=False (uniform aabb-clipped steps) is outside the HIP path; every "
                                       "shipped config sets exp_sampling (configs/EgoNeRF/common.txt:4)")
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()) and is_train:
-            raise NotImplementedError("the HIP backward (config 4) is not wired into autograd yet; wrap calls in torch.no_grad()")
         rays = _f32c(rays_chunk[:, :6])
         N, dev = rays.shape[0], rays.device
-        sc = self.scene()
-        args = _lib.RenderArgs()
-        args.n_coarse, args.n_fine = int(n_coarse), int(n_fine)
-        args.resampling, args.use_coarse_sample = int(bool(resampling)), int(bool(use_coarse_sample))
-        args.r_sched = self._sched(n_coarse, dev).data_ptr()
-        args.near_ = float(self.near_far[0])
         if is_train:
             if jitter is None:
                 jitter = torch.rand(N, n_coarse).to(dev)  # CPU generator like EgoNeRF.py:81
             if resampling and u is None:
                 u = torch.rand(N, n_fine, device=dev)  # device generator like ray_utils.py:169
             jitter = _f32c(jitter)
+            u = _f32c(u) if resampling else None
+        else:
+            jitter = u = None
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            from .train import render_train  # differentiable path: keeps activations, backward in HIP (egonerf_amd/train.py)
+            return render_train(self, rays, n_coarse, n_fine, resampling, use_coarse_sample, jitter, u)
+        sc = self.scene()
+        args = _lib.RenderArgs()
+        args.n_coarse, args.n_fine = int(n_coarse), int(n_fine)
+        args.resampling, args.use_coarse_sample = int(bool(resampling)), int(bool(use_coarse_sample))
+        args.r_sched = self._sched(n_coarse, dev).data_ptr()
+        args.near_ = float(self.near_far[0])
+        if jitter is not None:
             args.jitter = jitter.data_ptr()
-            if resampling:
-                u = _f32c(u)
-                args.u = u.data_ptr()
+        if u is not None:
+            args.u = u.data_ptr()
         S = (n_coarse + n_fine if use_coarse_sample else n_fine) if resampling else n_coarse
         lib = _lib.load()
         ws_bytes = lib.ego_render_workspace_bytes(N, C.byref(args))

@@ -1,0 +1,181 @@
+"""Training step of the render path: forward with kept activations + backward (the autograd of
+EgoNeRF.forward that train.py:312-314 runs in the reference).
+
+The differentiable call is a `torch.autograd.Function` whose forward is the same kernel sequence as inference
+(coarse march on the pooled tables -> inverse-CDF resampling -> fine march -> shade -> composite; the fine
+sample positions are detached like EgoNeRF.py:534) and whose backward runs `ego_march_backward`
+(compositing + density, scatter-add into the density tables) and `ego_shade_backward` (MLP / basis data
+gradients on the fp16-split MFMA path, scatter-add into the appearance tables).  The basis / MLP weight
+gradients are plain library GEMMs (rocBLAS through torch.matmul) over the per-sample buffers the kernels
+leave behind, un-permuted with the column maps of `ego_train_layout`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+
+_LAYOUT_CACHE = {}
+
+
+def _layout(which: int, n: int, device) -> torch.Tensor:
+    key = (which, str(device))
+    if key not in _LAYOUT_CACHE:
+        buf = (C.c_int32 * n)()
+        _lib.check(_lib.load().ego_train_layout(which, buf, n), "ego_train_layout")
+        _LAYOUT_CACHE[key] = torch.from_numpy(np.frombuffer(buf, dtype=np.int32).astype(np.int64).copy()).to(device)
+    return _LAYOUT_CACHE[key]
+
+
+def _grad_struct(tensors: List[torch.Tensor]) -> "_lib.VmGrad":
+    """tensors: [plane_yin x3, line_yin x3, plane_yang x3, line_yang x3] gradient tables (channel-last memory)."""
+    g = _lib.VmGrad()
+    for gi in range(2):
+        for i in range(3):
+            g.plane[gi][i] = tensors[gi * 6 + i].data_ptr()
+            g.line[gi][i] = tensors[gi * 6 + 3 + i].data_ptr()
+    return g
+
+
+def table_params(model, kind: str) -> List[torch.nn.Parameter]:
+    out = []
+    for g in ("yin", "yang"):
+        out += list(getattr(model, f"{kind}_plane_{g}")) + list(getattr(model, f"{kind}_line_{g}"))
+    return out
+
+
+def differentiable_params(model) -> List[torch.nn.Parameter]:
+    """Fixed order: 12 density tables, 12 appearance tables, basis yin/yang, mlp (w0,b0,w1,b1,w2,b2)."""
+    m = model.renderModule.mlp
+    return (table_params(model, "density") + table_params(model, "app") +
+            [model.basis_mat_yin.weight, model.basis_mat_yang.weight, m[0].weight, m[0].bias, m[2].weight, m[2].bias,
+             m[4].weight, m[4].bias])
+
+
+class RenderFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model, rays, opts, *params):
+        lib, st = _lib.load(), _lib.stream_handle()
+        dev = rays.device
+        sc = model.scene()
+        if sc.mlp_precision != 0:
+            raise NotImplementedError("training uses the f16x3 matrix path (model.mlp_precision = 'f16x3')")
+        N = rays.shape[0]
+        n_coarse, n_fine = opts["n_coarse"], opts["n_fine"]
+        resampling, use_coarse = opts["resampling"], opts["use_coarse_sample"]
+        jitter, u = opts["jitter"], opts["u"]
+        near = float(model.near_far[0])
+        sched = model._sched(n_coarse, dev)
+        S = (n_coarse + n_fine if use_coarse else n_fine) if resampling else n_coarse
+        f = lambda *shape: torch.empty(*shape, device=dev, dtype=torch.float32)
+        z, alpha, weight, sigma, bg = f(N, S), f(N, S + int(model.envmap is not None)), f(N, S), f(N, S), f(N)
+        coords = f(N, S, 4)
+        astride = alpha.shape[1]
+        if resampling:
+            zc, wc = f(N, n_coarse), f(N, n_coarse)
+            _lib.check(lib.ego_march_density(sc, rays.data_ptr(), N, n_coarse, None, sched.data_ptr(), _lib.ptr(jitter), near, 1,
+                                             zc.data_ptr(), None, 0, wc.data_ptr(), None, None, None, st), "ego_march_density")
+            _lib.check(lib.ego_sample_pdf_merge(zc.data_ptr(), wc.data_ptr(), _lib.ptr(u), N, n_coarse, n_fine, int(use_coarse),
+                                                z.data_ptr(), None, st), "ego_sample_pdf_merge")
+            _lib.check(lib.ego_march_density(sc, rays.data_ptr(), N, S, z.data_ptr(), None, None, near, 0, None, alpha.data_ptr(),
+                                             astride, weight.data_ptr(), bg.data_ptr(), coords.data_ptr(), sigma.data_ptr(), st),
+                       "ego_march_density")
+        else:
+            _lib.check(lib.ego_march_density(sc, rays.data_ptr(), N, S, None, sched.data_ptr(), _lib.ptr(jitter), near, 0,
+                                             z.data_ptr(), alpha.data_ptr(), astride, weight.data_ptr(), bg.data_ptr(),
+                                             coords.data_ptr(), sigma.data_ptr(), st), "ego_march_density")
+        M = N * S
+        rgb = f(N, S, 3)
+        dump = dict(x=f(M, 160), h1=f(M, 128), h2=f(M, 128), v=f(M, 144))
+        ds = _lib.ShadeDump(dump["x"].data_ptr(), dump["h1"].data_ptr(), dump["h2"].data_ptr(), dump["v"].data_ptr())
+        _lib.check(lib.ego_shade(sc, rays.data_ptr(), z.data_ptr(), coords.data_ptr(), N, S, rgb.data_ptr(), C.byref(ds), st), "ego_shade")
+        rgb_map, depth, raw = f(N, 3), f(N), f(N, 3)
+        has_env = model.envmap is not None
+        bg_map = f(N, 3) if has_env else None
+        env_map = f(N, 3) if has_env else None
+        _lib.check(lib.ego_composite(sc, rays.data_ptr(), z.data_ptr(), weight.data_ptr(), bg.data_ptr(), rgb.data_ptr(), N, S,
+                                     rgb_map.data_ptr(), depth.data_ptr(), _lib.ptr(bg_map), _lib.ptr(env_map), raw.data_ptr(), st),
+                   "ego_composite")
+        ctx.model, ctx.N, ctx.S = model, N, S
+        ctx.saved = dict(z=z, alpha=alpha, weight=weight, sigma=sigma, bg=bg, coords=coords, rgb=rgb, raw=raw, env=env_map, **dump)
+        ctx.mark_non_differentiable(depth, alpha)
+        if has_env:
+            ctx.mark_non_differentiable(bg_map, env_map)
+            return rgb_map, depth, alpha, bg_map, env_map
+        return rgb_map, depth, alpha
+
+    @staticmethod
+    def backward(ctx, g_rgb, *_unused):
+        lib, st = _lib.load(), _lib.stream_handle()
+        model, N, S, sv = ctx.model, ctx.N, ctx.S, ctx.saved
+        dev = g_rgb.device
+        M = N * S
+        sc = model.scene()
+        g_rgb = g_rgb.contiguous().float()
+        dens, app = table_params(model, "density"), table_params(model, "app")
+        g_dens = [torch.zeros_like(p) for p in dens]  # zeros_like keeps the channel-last strides of the parameter
+        g_app = [torch.zeros_like(p) for p in app]
+        for p, g in zip(dens + app, g_dens + g_app):
+            assert g.stride() == p.stride()
+        f = lambda *shape: torch.empty(*shape, device=dev, dtype=torch.float32)
+        dc = f(N, S, 3)
+        gd = _grad_struct(g_dens)
+        _lib.check(lib.ego_march_backward(sc, C.byref(gd), sv["coords"].data_ptr(), sv["z"].data_ptr(), sv["alpha"].data_ptr()
+                                          if sv["alpha"].shape[1] == S else sv["alpha"][:, :S].contiguous().data_ptr(),
+                                          sv["weight"].data_ptr(), sv["sigma"].data_ptr(), sv["bg"].data_ptr(), sv["rgb"].data_ptr(),
+                                          g_rgb.data_ptr(), sv["raw"].data_ptr(), _lib.ptr(sv["env"]), N, S, dc.data_ptr(), st),
+                   "ego_march_backward")
+        tp = f(lib.ego_train_packed_floats())
+        _lib.check(lib.ego_pack_train(sc, tp.data_ptr(), st), "ego_pack_train")
+        dh2, dh1, dfe = f(M, 128), f(M, 128), f(M, 64)
+        ga = _grad_struct(g_app)
+        ds = _lib.ShadeDump(sv["x"].data_ptr(), sv["h1"].data_ptr(), sv["h2"].data_ptr(), sv["v"].data_ptr())
+        _lib.check(lib.ego_shade_backward(sc, tp.data_ptr(), C.byref(ga), sv["coords"].data_ptr(), dc.data_ptr(), sv["rgb"].data_ptr(),
+                                          C.byref(ds), dh2.data_ptr(), dh1.data_ptr(), dfe.data_ptr(), N, S, st), "ego_shade_backward")
+        # ---- weight gradients: library GEMMs with K = all samples, then un-permute the lane-order columns ----
+        do = dc.view(M, 3)  # now d(pre-sigmoid)
+        hid = _layout(1, 128, dev)
+        xmap = _layout(0, 160, dev)
+        fmap = _layout(2, 32, dev)
+        vmap = _layout(3, 144, dev)
+        mlp = model.renderModule.mlp
+        gw3 = torch.zeros_like(mlp[4].weight)
+        gw3[:, hid] = do.t() @ sv["h2"]
+        gb3 = do.sum(0)
+        gw2 = torch.zeros_like(mlp[2].weight)
+        gw2[hid[:, None], hid[None, :]] = dh2.t() @ sv["h1"]
+        gb2 = torch.zeros_like(mlp[2].bias)
+        gb2[hid] = dh2.sum(0)
+        gw1 = torch.zeros_like(mlp[0].weight)
+        G1 = dh1.t() @ sv["x"]
+        xv = xmap >= 0
+        gw1[hid[:, None], xmap[xv][None, :]] = G1[:, xv]
+        gb1 = torch.zeros_like(mlp[0].bias)
+        gb1[hid] = dh1.sum(0)
+        gbasis = []
+        fv = fmap >= 0
+        for g in range(2):
+            Gb = dfe[:, 32 * g: 32 * g + 32].t() @ sv["v"]
+            gb = torch.zeros(model.app_dim, 144, device=dev)
+            gb[fmap[fv][:, None], vmap[None, :]] = Gb[fv]
+            gbasis.append(gb)
+        grads = g_dens + g_app + gbasis + [gw1, gb1, gw2, gb2, gw3, gb3]
+        ctx.saved = None
+        return (None, None, None, *grads)
+
+
+def render_train(model, rays, n_coarse, n_fine=0, resampling=False, use_coarse_sample=True, jitter: Optional[torch.Tensor] = None,
+                 u: Optional[torch.Tensor] = None):
+    """Differentiable EgoNeRF.forward (is_train semantics) -> (rgb_map, depth, bg_map|None, env_map|None, alpha)."""
+    opts = dict(n_coarse=int(n_coarse), n_fine=int(n_fine), resampling=bool(resampling), use_coarse_sample=bool(use_coarse_sample),
+                jitter=jitter, u=u)
+    out = RenderFunction.apply(model, rays, opts, *differentiable_params(model))
+    if model.envmap is not None:
+        rgb_map, depth, alpha, bg_map, env_map = out
+        return rgb_map, depth, bg_map, env_map, alpha
+    rgb_map, depth, alpha = out
+    return rgb_map, depth, None, None, alpha

@@ -145,22 +145,63 @@ int ego_pack_mlp(const ego_scene* sc, float* packed_out, void* stream);
  * pooled tables.  Outputs (any may be NULL): z_out [N][S], alpha [N][alpha_stride] (alpha_stride 0 = S;
  * columns S.. are filled with 1, the reference's trailing ones column when an envmap is present,
  * EgoNeRF.py:587), weight [N][S], bg_weight [N], coords_out [N][S][4] = normalised (r, theta, phi) of the sample's
- * grid + is_yang flag (what ego_shade needs; saves it the acos/atan2/LUT search). */
+ * grid + is_yang flag (what ego_shade needs; saves it the acos/atan2/LUT search), sigma_out [N][S] (kept for the
+ * backward pass). */
 int ego_march_density(const ego_scene* sc, const float* rays, int64_t N, int32_t S, const float* z_in,
                       const float* r_sched, const float* jitter, float near_, int32_t coarse, float* z_out,
-                      float* alpha, int32_t alpha_stride, float* weight, float* bg_weight, float* coords_out, void* stream);
+                      float* alpha, int32_t alpha_stride, float* weight, float* bg_weight, float* coords_out, float* sigma_out,
+                      void* stream);
+
+/* Per-sample activations the training forward keeps for the backward pass (all dev, "lane order": the two lanes
+ * (halves h = 0, 1) that serve a sample each own a contiguous run):
+ *   x  [M][160]: layer-1 inputs, half h at [h*80 .. h*80+80) in the kernel's K order (ego_train_layout() maps them)
+ *   h1 [M][128], h2 [M][128]: post-ReLU hidden activations, half h at [h*64 ..), index m-tile*16 + reg
+ *   v  [M][144]: plane x line products, half h at [h*72 ..) */
+typedef struct ego_shade_dump {
+  float* x;
+  float* h1;
+  float* h2;
+  float* v;
+} ego_shade_dump;
 
 /* Appearance lookup -> basis -> positional encoding -> MLP for every sample: rgb [N][S][3].
  * z [N][S] sample distances (from ego_march_density); coords [N][S][4] optional (ego_march_density's coords_out),
  * NULL = recompute the yin-yang coordinates from rays and z. */
 int ego_shade(const ego_scene* sc, const float* rays, const float* z, const float* coords, int64_t N, int32_t S, float* rgb,
-              void* stream);
+              const ego_shade_dump* dump /* NULL for inference */, void* stream);
 
 /* acc, rgb_map (+ envmap background), clamp, depth (+ (1-acc)*d_z quirk, EgoNeRF.py:598).
- * Outputs rgb_map [N][3], depth [N]; bg_map/env_map [N][3] written only when sc->envmap != NULL (may be NULL). */
+ * Outputs rgb_map [N][3], depth [N]; bg_map/env_map [N][3] written only when sc->envmap != NULL (may be NULL);
+ * rgb_raw [N][3] optional = rgb_map before the clamp (the backward pass needs the clamp mask). */
 int ego_composite(const ego_scene* sc, const float* rays, const float* z, const float* weight, const float* bg_weight,
                   const float* rgb, int64_t N, int32_t S, float* rgb_map, float* depth, float* bg_map, float* env_map,
-                  void* stream);
+                  float* rgb_raw, void* stream);
+
+/* ---- training step: backward of the path (autograd of EgoNeRF.forward, train.py:312-314) ---------
+ * Table gradients are accumulated with float atomics straight into channel-last gradient tables (same layout as the
+ * parameters; the caller zeroes them).  Weight gradients of the basis / MLP are left to the caller as plain GEMMs over
+ * the per-sample buffers these kernels write (lane order; ego_train_layout gives the column maps). */
+typedef struct ego_vm_grad {
+  float* plane[2][3]; /* dev, [H][W][C] like the parameter */
+  float* line[2][3];
+} ego_vm_grad;
+
+int64_t ego_train_packed_floats(void);
+/* transposed fp16-split fragments of W2, W1, the basis matrices and W3 for the data-gradient chain */
+int ego_pack_train(const ego_scene* sc, float* out, void* stream);
+/* which = 0: x column [160] -> MLP input column | 1: hidden column [128] -> unit | 2: dfe column [32] -> feature |
+ * 3: v column [144] -> basis input column; -1 marks padding.  Host memory. */
+int ego_train_layout(int32_t which, int32_t* out, int32_t n);
+/* compositing + density backward.  g_rgb [N][3] = dL/d rgb_map, rgb_raw = rgb_map before the clamp, env_map [N][3] or
+ * NULL.  Writes dc [N][S][3] = dL/d rgb_sample and scatters d(density tables). */
+int ego_march_backward(const ego_scene* sc, const ego_vm_grad* gdensity, const float* coords, const float* z, const float* alpha,
+                       const float* weight, const float* sigma, const float* bg_weight, const float* rgb, const float* g_rgb,
+                       const float* rgb_raw, const float* env_map, int64_t N, int32_t S, float* dc, void* stream);
+/* shade backward: dc [N][S][3] in = dL/d rgb_sample, out = dL/d(pre-sigmoid).  Writes dh2, dh1 [M][128], dfe [M][64]
+ * (grid g at [32g..)) and scatters d(appearance tables). */
+int ego_shade_backward(const ego_scene* sc, const float* train_packed, const ego_vm_grad* gapp, const float* coords, float* dc,
+                       const float* rgb, const ego_shade_dump* fwd, float* dh2, float* dh1, float* dfe, int64_t N, int32_t S,
+                       void* stream);
 
 typedef struct ego_render_args {
   int32_t n_coarse, n_fine;

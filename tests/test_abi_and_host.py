@@ -33,7 +33,7 @@ def test_argument_validation_needs_no_gpu():
     assert lib.ego_sample_ray_exp(None, None, None, 0.0, 4, 8, None, None, None) == -1
     assert b"sample_ray_exp" in lib.ego_last_error()
     sc = _lib.Scene()
-    assert lib.ego_shade(sc, None, None, None, 1, 1, None, None) == -1
+    assert lib.ego_shade(sc, None, None, None, 1, 1, None, None, None) == -1
     assert lib.ego_render_workspace_bytes(4096, None) == -1
     a = _lib.RenderArgs()
     a.n_coarse, a.n_fine, a.resampling, a.use_coarse_sample = 128, 128, 1, 1

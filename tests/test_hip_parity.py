@@ -251,7 +251,7 @@ def test_abi_rejects_bad_arguments(tiny):
     lib = _lib.load()
     model = tiny[3]
     sc = model.scene()
-    assert lib.ego_shade(sc, None, None, None, 4, 8, None, None) == -1 and b"null" in lib.ego_last_error()
+    assert lib.ego_shade(sc, None, None, None, 4, 8, None, None, None) == -1 and b"null" in lib.ego_last_error()
     bad = _lib.Scene.from_buffer_copy(sc)
     bad.app_dim = 9
     x = torch.zeros(8, 7, device=DEV)
