@@ -31,6 +31,22 @@ def _layout(which: int, n: int, device) -> torch.Tensor:
     return _LAYOUT_CACHE[key]
 
 
+def _tgemm(a: torch.Tensor, b: torch.Tensor, chunk: int = 8192) -> torch.Tensor:
+    """a.T @ b for tall-skinny a [M,p], b [M,q] (M = all samples of the step): a plain sgemm with K = M gets one
+    poorly parallelised rocBLAS kernel, so the K axis is cut into a batch (bmm) and the partial products are summed."""
+    M = a.shape[0]
+    nb = M // chunk
+    out = None
+    if nb > 0:
+        av = a[: nb * chunk].view(nb, chunk, a.shape[1]).transpose(1, 2)
+        bv = b[: nb * chunk].view(nb, chunk, b.shape[1])
+        out = torch.bmm(av, bv).sum(0)
+    if nb * chunk < M:
+        tail = a[nb * chunk:].t() @ b[nb * chunk:]
+        out = tail if out is None else out + tail
+    return out
+
+
 def _grad_struct(tensors: List[torch.Tensor]) -> "_lib.VmGrad":
     """tensors: [plane_yin x3, line_yin x3, plane_yang x3, line_yang x3] gradient tables (channel-last memory)."""
     g = _lib.VmGrad()
@@ -144,14 +160,14 @@ class RenderFunction(torch.autograd.Function):
         vmap = _layout(3, 144, dev)
         mlp = model.renderModule.mlp
         gw3 = torch.zeros_like(mlp[4].weight)
-        gw3[:, hid] = do.t() @ sv["h2"]
+        gw3[:, hid] = _tgemm(do, sv["h2"])
         gb3 = do.sum(0)
         gw2 = torch.zeros_like(mlp[2].weight)
-        gw2[hid[:, None], hid[None, :]] = dh2.t() @ sv["h1"]
+        gw2[hid[:, None], hid[None, :]] = _tgemm(dh2, sv["h1"])
         gb2 = torch.zeros_like(mlp[2].bias)
         gb2[hid] = dh2.sum(0)
         gw1 = torch.zeros_like(mlp[0].weight)
-        G1 = dh1.t() @ sv["x"]
+        G1 = _tgemm(dh1, sv["x"])
         xv = xmap >= 0
         gw1[hid[:, None], xmap[xv][None, :]] = G1[:, xv]
         gb1 = torch.zeros_like(mlp[0].bias)
@@ -159,7 +175,7 @@ class RenderFunction(torch.autograd.Function):
         gbasis = []
         fv = fmap >= 0
         for g in range(2):
-            Gb = dfe[:, 32 * g: 32 * g + 32].t() @ sv["v"]
+            Gb = _tgemm(dfe[:, 32 * g: 32 * g + 32].contiguous(), sv["v"])
             gb = torch.zeros(model.app_dim, 144, device=dev)
             gb[fmap[fv][:, None], vmap[None, :]] = Gb[fv]
             gbasis.append(gb)
