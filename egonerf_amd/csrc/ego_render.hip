@@ -41,10 +41,11 @@ int64_t ego_render_workspace_bytes(int64_t N, const ego_render_args* args) {
 
 int ego_render_forward(const ego_scene* sc, const ego_render_args* a, const float* rays, int64_t N, void* workspace,
                        float* rgb_map, float* depth, float* alpha, float* bg_map, float* env_map, void* stream) {
-  EGO_REQUIRE(sc && a && rays && workspace && rgb_map && N >= 0, "render_forward: null argument");
+  EGO_REQUIRE(N >= 0, "render_forward: N < 0");
+  if (N == 0) return EGO_OK;
+  EGO_REQUIRE(sc && a && rays && workspace && rgb_map, "render_forward: null argument");
   EGO_REQUIRE(a->r_sched && a->n_coarse >= 2, "render_forward: r_sched missing or n_coarse < 2");
   EGO_REQUIRE(!a->resampling || a->n_fine >= 1, "render_forward: resampling needs n_fine >= 1");
-  if (N == 0) return EGO_OK;
   const Plan p = make_plan(N, a);
   float* ws = (float*)workspace;
   const int32_t S = p.S_out;

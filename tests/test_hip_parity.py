@@ -258,3 +258,29 @@ def test_abi_rejects_bad_arguments(tiny):
     out = torch.zeros(8, 27, device=DEV)
     assert lib.ego_app_feature(bad, x.data_ptr(), 8, out.data_ptr(), None) == -2  # EGO_E_UNSUPPORTED
     assert b"app_dim" in lib.ego_last_error()
+
+
+@pytest.mark.parametrize("n_rays,kw", [
+    (37, dict(n_coarse=70)),                                            # S not a multiple of 32/64, N not of 4
+    (5, dict(n_coarse=33, n_fine=17, resampling=True)),                  # odd coarse/fine counts
+    (1, dict(n_coarse=3, n_fine=2, resampling=True, use_coarse_sample=False)),  # minimum sizes the sampler allows
+    (130, dict(n_coarse=2)),                                             # two samples per ray
+])
+def test_ragged_sizes_vs_oracle(tiny, n_rays, kw):
+    _, cfg, w, model = tiny
+    oracle = make_oracle(cfg, w)
+    rays = torch.from_numpy(synth.make_rays(n_rays, seed=21))
+    with torch.no_grad():
+        rgb, depth, _, _, alpha = model(rays.to(DEV), exp_sampling=True, **kw)
+    ref = oracle.forward(rays, **kw)
+    assert rgb.shape == (n_rays, 3) and alpha.shape == ref[4].shape
+    assert maxerr(rgb, ref[0]) <= RGB_TOL and maxerr(depth, ref[1]) <= 1e-3 * 15.0
+    if not kw.get("resampling"):
+        assert maxerr(alpha, ref[4]) <= 1e-5
+
+
+def test_empty_batch(tiny):
+    model = tiny[3]
+    with torch.no_grad():
+        rgb, depth, _, _, alpha = model(torch.zeros(0, 6, device=DEV), n_coarse=16, exp_sampling=True)
+    assert rgb.shape == (0, 3) and depth.shape == (0,) and alpha.shape == (0, 16)

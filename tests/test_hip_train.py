@@ -134,3 +134,26 @@ def test_one_adam_step_matches_oracle_step():
         assert float(d.max()) <= 2 * lr + 1e-7, (k, float(d.max()))
         if bool(big.any()):
             assert float(d[big].max()) <= 2e-3 * lr + 1e-7, (k, float(d[big].max()))
+
+
+def test_gradients_ragged_sizes_vs_oracle():
+    """N, S not multiples of the wave / tile sizes, no resampling: every parameter gradient vs the oracle's autograd."""
+    cfg = synth.SceneConfig(n_voxel=20 ** 3)
+    w = synth.make_weights(cfg, seed=11)
+    model = make_model(cfg, w, DEV)
+    N, S = 37, 45
+    rays = torch.from_numpy(synth.make_rays(N, seed=5))
+    jit = torch.from_numpy(synth.hash_uniform(12, 0, N * S).reshape(N, S).astype(np.float32))
+    gt = torch.from_numpy(synth.hash_uniform(12, 1, N * 3).reshape(N, 3).astype(np.float32))
+    rgb, *_ = model(rays.to(DEV), is_train=True, n_coarse=S, exp_sampling=True, jitter=jit.to(DEV))
+    torch.mean((rgb - gt.to(DEV)) ** 2).backward()
+    oracle = make_oracle(cfg, w)
+    for v in oracle.w.values():
+        v.requires_grad_(True)
+    ref, *_ = oracle.forward(rays, n_coarse=S, is_train=True, jitter=jit)
+    torch.mean((ref - gt) ** 2).backward()
+    for k, p in model.named_parameters():
+        r = oracle.w[k].grad
+        r = torch.zeros_like(oracle.w[k]) if r is None else r
+        scale = max(float(r.abs().max()), 1e-12)
+        assert float((p.grad.detach().cpu() - r).abs().max()) / scale <= 3e-4, k
