@@ -34,6 +34,7 @@ class Scene(C.Structure):
         ("mlp_w", C.c_void_p * 3), ("mlp_b", C.c_void_p * 3),
         ("mlp_in", C.c_int32), ("mlp_hidden", C.c_int32), ("view_pe", C.c_int32), ("fea_pe", C.c_int32),
         ("packed", C.c_void_p), ("envmap", C.c_void_p), ("envmap_h", C.c_int32), ("mlp_precision", C.c_int32),
+        ("occ", C.c_void_p), ("occ_res", C.c_int32 * 3), ("term_eps", C.c_float),
     ]
 
 
@@ -72,8 +73,9 @@ PROTOTYPES = {
     "ego_envmap_radiance": (C.c_int, [SP, P, I64, P, P]),
     "ego_avgpool_table": (C.c_int, [P, I32, I32, I32, P, P]),
     "ego_pack_mlp": (C.c_int, [SP, P, P]),
-    "ego_march_density": (C.c_int, [SP, P, I64, I32, P, P, P, F32, I32, P, P, I32, P, P, P, P, P]),
-    "ego_shade": (C.c_int, [SP, P, P, P, I64, I32, P, P, P]),
+    "ego_march_density": (C.c_int, [SP, P, I64, I32, P, P, P, F32, I32, P, P, I32, P, P, P, P, P, P]),
+    "ego_shade": (C.c_int, [SP, P, P, P, I64, I32, P, P, P, P]),
+    "ego_alpha_mask_sample": (C.c_int, [SP, P, I64, P, P]),
     "ego_composite": (C.c_int, [SP, P, P, P, P, P, I64, I32, P, P, P, P, P, P]),
     "ego_train_packed_floats": (I64, []),
     "ego_pack_train": (C.c_int, [SP, P, P]),

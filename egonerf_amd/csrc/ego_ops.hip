@@ -142,6 +142,37 @@ __global__ void k_raw2alpha(const float* __restrict__ sigma, const float* __rest
 }
 
 // =============================================================================================
+// Row M — occupancy lookup: trilinear F.grid_sample (align_corners, zeros) on a {0,1} volume [N_phi][N_theta][N_r]
+// models/EgoNeRF.py:11-24
+// =============================================================================================
+struct DevOcc {
+  const uint8_t* vol;  // [2][res2][res1][res0] or null
+  int32_t res[3];
+};
+
+__device__ __forceinline__ float occ_sample(const DevOcc& O, int g, float a_r, float a_th, float a_ph) {
+  const Lin1 X = lin_setup(a_r, O.res[0]), Y = lin_setup(a_th, O.res[1]), Z = lin_setup(a_ph, O.res[2]);
+  const uint8_t* V = O.vol + (int64_t)g * O.res[0] * O.res[1] * O.res[2];
+  float v = 0.f;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int ix = (k & 1) ? X.i1 : X.i0, iy = (k & 2) ? Y.i1 : Y.i0, iz = (k & 4) ? Z.i1 : Z.i0;
+    const float w = ((k & 1) ? X.w1 : X.w0) * ((k & 2) ? Y.w1 : Y.w0) * ((k & 4) ? Z.w1 : Z.w0);
+    v += w * (float)V[((int64_t)iz * O.res[1] + iy) * O.res[0] + ix];
+  }
+  return v;
+}
+
+__global__ void k_alpha_mask_sample(DevOcc O, const float* __restrict__ c7n, int64_t M, float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= M) return;
+  const float* p = c7n + i * 7;
+  const int g = (p[6] == 0.f) ? 0 : 1;
+  const int b = g ? 3 : 0;
+  out[i] = occ_sample(O, g, p[b], p[b + 1], p[b + 2]);
+}
+
+// =============================================================================================
 // Fused: rows A+B+C+D+E for one ray per wave.  models/EgoNeRF.py:507-529 (coarse) / 544-553 (fine)
 // =============================================================================================
 template <int C>
@@ -153,7 +184,8 @@ __global__ __launch_bounds__(256) void k_march_density(DevCoords c, DevField F, 
                                                        float* __restrict__ z_out, float* __restrict__ alpha,
                                                        int alpha_stride, float* __restrict__ weight,
                                                        float* __restrict__ bg, float* __restrict__ coords_out,
-                                                       float* __restrict__ sigma_out) {
+                                                       float* __restrict__ sigma_out, DevOcc occ, float term_eps,
+                                                       uint8_t* __restrict__ tile_active) {
   __shared__ float lut[1024];
   for (int i = threadIdx.x; i < c.n_lut; i += blockDim.x) lut[i] = c.r_lut[i];
   __syncthreads();
@@ -183,21 +215,33 @@ __global__ __launch_bounds__(256) void k_march_density(DevCoords c, DevField F, 
     const float a_r = normalize_r(y.r, lut, c.n_lut, c.n_r);
     const float a_th = normalize_ang(y.th, c.th_near, c.th_inv);
     const float a_ph = normalize_ang(y.ph, c.ph_near, c.ph_inv);
-    const float f = density_lookup<C>(F, y.yang, a_r, a_th, a_ph);
-    const float sg = softplus ? softplus_shift(f, shift) : fmaxf(f, 0.f);
+    // occupancy mask (opt-in): unoccupied samples keep sigma = 0 and skip the 18-tap gather
+    const bool occupied = !occ.vol || occ_sample(occ, y.yang, a_r, a_th, a_ph) > 0.f;
+    float sg = 0.f;
+    if (occupied) {
+      const float f = density_lookup<C>(F, y.yang, a_r, a_th, a_ph);
+      sg = softplus ? softplus_shift(f, shift) : fmaxf(f, 0.f);
+    }
     const float a = ok ? __fsub_rn(1.f, expf(-sg * __fmul_rn(dist, dscale))) : 0.f;
     const float t = ok ? __fadd_rn(__fsub_rn(1.f, a), 1e-10f) : 1.f;
     const float inc = wave_scan_mul(t, lane);
     float exc = __shfl_up(inc, 1, 64);
     if (lane == 0) exc = 1.f;
     const float T = carry * exc;
+    const float wgt = (term_eps > 0.f && T < term_eps) ? 0.f : a * T;  // early termination (opt-in)
+    if (tile_active) {
+      // 32-sample shade tiles are cut from the flat [N*S] order: lanes 0-31 / 32-63 of this pass are (parts of) tiles
+      const unsigned long long nz = __ballot(ok && wgt != 0.f);
+      const int64_t o = ray * S + s;
+      if (ok && (nz >> (lane & 32) & 0xffffffffull) != 0ull && ((lane & 31) == 0 || (o & 31) == 0)) tile_active[o >> 5] = 1;
+    }
     if (ok) {
       const int64_t o = ray * S + s;
       if (z_out) z_out[o] = z;
       if (coords_out) ((f32x4*)coords_out)[o] = f32x4{a_r, a_th, a_ph, y.yang ? 1.f : 0.f};
       if (sigma_out) sigma_out[o] = sg;
       if (alpha) alpha[ray * alpha_stride + s] = a;
-      if (weight) weight[o] = a * T;
+      if (weight) weight[o] = wgt;
     }
     carry *= __shfl(inc, 63, 64);
   }
@@ -252,11 +296,13 @@ __global__ void k_composite(const float* __restrict__ em, int em_h, const float*
   for (int s = lane; s < S; s += 64) {
     const int64_t o = ray * S + s;
     const float w = weight[o];
-    acc += w;
-    cr += w * rgb[o * 3];
-    cg += w * rgb[o * 3 + 1];
-    cb += w * rgb[o * 3 + 2];
-    dp += w * z[o];
+    if (w != 0.f) {  // tiles skipped by ego_shade (mask / early termination) never wrote their rgb
+      acc += w;
+      cr += w * rgb[o * 3];
+      cg += w * rgb[o * 3 + 1];
+      cb += w * rgb[o * 3 + 2];
+      dp += w * z[o];
+    }
   }
   acc = wave_sum(acc); cr = wave_sum(cr); cg = wave_sum(cg); cb = wave_sum(cb); dp = wave_sum(dp);
   if (lane != 0) return;
@@ -426,6 +472,13 @@ int ego_normalize_coord(const ego_scene* sc, const float* c7, int64_t M, float* 
   return ego_launch_status("k_normalize_coord");
 }
 
+static DevOcc make_occ(const ego_scene& sc, int coarse) {
+  DevOcc o;
+  o.vol = coarse ? nullptr : sc.occ;  // the coarse (proposal) pass always sees the full field
+  o.res[0] = sc.occ_res[0]; o.res[1] = sc.occ_res[1]; o.res[2] = sc.occ_res[2];
+  return o;
+}
+
 static int check_field(const ego_vm_field& f, const char* what) {
   for (int g = 0; g < 2; ++g)
     for (int i = 0; i < 3; ++i)
@@ -483,6 +536,15 @@ int ego_envmap_radiance(const ego_scene* sc, const float* dirs, int64_t N, float
   return ego_launch_status("k_envmap");
 }
 
+int ego_alpha_mask_sample(const ego_scene* sc, const float* c7n, int64_t M, float* out, void* stream) {
+  EGO_REQUIRE(M >= 0, "alpha_mask_sample: M < 0");
+  if (M == 0) return EGO_OK;
+  EGO_REQUIRE(sc && c7n && out && sc->occ && sc->occ_res[0] >= 2 && sc->occ_res[1] >= 2 && sc->occ_res[2] >= 2,
+              "alpha_mask_sample: no occupancy volume / null argument");
+  k_alpha_mask_sample<<<nblk(M, 256), 256, 0, (hipStream_t)stream>>>(make_occ(*sc, 0), c7n, M, out);
+  return ego_launch_status("k_alpha_mask_sample");
+}
+
 int ego_avgpool_table(const float* src, int32_t H, int32_t W, int32_t C, float* dst, void* stream) {
   EGO_REQUIRE(src && dst && H >= 2 && W >= 1 && C >= 1, "avgpool_table: bad argument");
   const int64_t n = (int64_t)(H / 2) * (W == 1 ? 1 : W / 2) * C;
@@ -493,7 +555,7 @@ int ego_avgpool_table(const float* src, int32_t H, int32_t W, int32_t C, float* 
 int ego_march_density(const ego_scene* sc, const float* rays, int64_t N, int32_t S, const float* z_in,
                       const float* r_sched, const float* jitter, float near_, int32_t coarse, float* z_out,
                       float* alpha, int32_t alpha_stride, float* weight, float* bg_weight, float* coords_out, float* sigma_out,
-                      void* stream) {
+                      uint8_t* tile_active, void* stream) {
   EGO_REQUIRE(sc && rays && N >= 0 && S >= 2, "march_density: null argument or S < 2");
   if (alpha_stride == 0) alpha_stride = S;
   EGO_REQUIRE(alpha_stride >= S && alpha_stride <= S + 64, "march_density: alpha_stride must be in [S, S+64]");
@@ -505,7 +567,8 @@ int ego_march_density(const ego_scene* sc, const float* rays, int64_t N, int32_t
   if (f.n_comp != 16) return ego_fail(EGO_E_UNSUPPORTED, "march_density: n_comp %d (supported: 16)", f.n_comp);
   k_march_density<16><<<nblk(N, 4), 256, 0, (hipStream_t)stream>>>(
       make_coords(*sc), make_field(f), rays, N, S, z_in, r_sched, jitter, near_, sc->act_softplus, sc->density_shift,
-      sc->distance_scale, z_out, alpha, alpha_stride, weight, bg_weight, coords_out, sigma_out);
+      sc->distance_scale, z_out, alpha, alpha_stride, weight, bg_weight, coords_out, sigma_out, make_occ(*sc, coarse), sc->term_eps,
+      tile_active);
   return ego_launch_status("k_march_density");
 }
 

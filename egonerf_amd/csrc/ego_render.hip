@@ -4,7 +4,7 @@
 
 namespace {
 struct Plan {
-  int64_t zc, wc, zf, w, bg, rgb, crd, total;  // float offsets
+  int64_t zc, wc, zf, w, bg, rgb, crd, act, total;  // float offsets
   int32_t S_out;
 };
 
@@ -22,6 +22,7 @@ Plan make_plan(int64_t N, const ego_render_args* a) {
   p.bg = o; o = align64(o + N);
   p.rgb = o; o = align64(o + N * (int64_t)p.S_out * 3);
   p.crd = o; o = align64(o + N * (int64_t)p.S_out * 4);
+  p.act = o; o = align64(o + (N * (int64_t)p.S_out / 32 + 1 + 3) / 4);  // tile flags (bytes)
   p.total = o;
   return p;
 }
@@ -52,21 +53,27 @@ int ego_render_forward(const ego_scene* sc, const ego_render_args* a, const floa
   const int32_t astride = sc->envmap ? S + 1 : S;
   int e;
   const float* z;
+  // tile-level skipping only when a mask or early termination is switched on (otherwise no weight is exactly zero)
+  uint8_t* act = (sc->occ || sc->term_eps > 0.f) ? (uint8_t*)(ws + p.act) : nullptr;
+  if (act) {
+    const hipError_t me = hipMemsetAsync(act, 0, (size_t)(N * (int64_t)S / 32 + 1), (hipStream_t)stream);
+    if (me != hipSuccess) return ego_fail((int)me, "render_forward: hipMemsetAsync failed: %s", hipGetErrorString(me));
+  }
   if (a->resampling) {
     // coarse pass on the pooled tables -> weights -> inverse-CDF samples merged into the coarse schedule
     if ((e = ego_march_density(sc, rays, N, a->n_coarse, nullptr, a->r_sched, a->jitter, a->near_, 1, ws + p.zc, nullptr, 0,
-                               ws + p.wc, nullptr, nullptr, nullptr, stream))) return e;
+                               ws + p.wc, nullptr, nullptr, nullptr, nullptr, stream))) return e;
     if ((e = ego_sample_pdf_merge(ws + p.zc, ws + p.wc, a->u, N, a->n_coarse, a->n_fine, a->use_coarse_sample, ws + p.zf,
                                   nullptr, stream))) return e;
     if ((e = ego_march_density(sc, rays, N, S, ws + p.zf, nullptr, nullptr, a->near_, 0, nullptr, alpha, astride, ws + p.w,
-                               ws + p.bg, ws + p.crd, nullptr, stream))) return e;
+                               ws + p.bg, ws + p.crd, nullptr, act, stream))) return e;
     z = ws + p.zf;
   } else {
     if ((e = ego_march_density(sc, rays, N, S, nullptr, a->r_sched, a->jitter, a->near_, 0, ws + p.zc, alpha, astride,
-                               ws + p.w, ws + p.bg, ws + p.crd, nullptr, stream))) return e;
+                               ws + p.w, ws + p.bg, ws + p.crd, nullptr, act, stream))) return e;
     z = ws + p.zc;
   }
-  if ((e = ego_shade(sc, rays, z, ws + p.crd, N, S, ws + p.rgb, nullptr, stream))) return e;
+  if ((e = ego_shade(sc, rays, z, ws + p.crd, N, S, ws + p.rgb, nullptr, act, stream))) return e;
   return ego_composite(sc, rays, z, ws + p.w, ws + p.bg, ws + p.rgb, N, S, rgb_map, depth, bg_map, env_map, nullptr, stream);
 }
 

@@ -189,6 +189,7 @@ struct ShadeArgs {
   float* dump_h1;     //   [M][160] X, [M][128] relu(H1), [M][128] relu(H2), [M][144] v   (see include/egonerf_hip.h)
   float* dump_h2;
   float* dump_v;
+  const uint8_t* tile_active;  // optional [n_tiles]: 0 = every weight of the tile is zero, skip it
   int64_t M;
   int32_t S;
 };
@@ -278,6 +279,7 @@ __global__ __launch_bounds__(512) void k_shade(ShadeArgs A) {
   const f32x4* BAS = (const f32x4*)(A.packed + OFF_BASIS);
 
   for (int64_t tile = (int64_t)blockIdx.x * 8 + wave; tile < n_tiles; tile += (int64_t)gridDim.x * 8) {
+    if (MODE == MODE_SHADE && A.tile_active && !A.tile_active[tile]) continue;
     // LDS weights are loop-invariant: without an opaque per-iteration index LICM hoists all 240
     // ds_read_b128 out of the tile loop and spills them to scratch
     int lw = lane;
@@ -604,6 +606,7 @@ __global__ __launch_bounds__(512) void k_shade_h(ShadeArgs A) {
   const u32x4* BASH = (const u32x4*)(blob + OFF_BASIS);
 
   for (int64_t tile = (int64_t)blockIdx.x * 8 + wave; tile < n_tiles; tile += (int64_t)gridDim.x * 8) {
+    if (MODE == MODE_SHADE && A.tile_active && !A.tile_active[tile]) continue;
     int lw = lane;
     asm volatile("" : "+v"(lw));  // keeps the LDS weight reads inside the loop (see k_shade)
     const int hw = lw >> 5;
@@ -886,14 +889,14 @@ int ego_mlp_fea(const ego_scene* sc, const float* viewdirs, const float* feat, i
 }
 
 int ego_shade(const ego_scene* sc, const float* rays, const float* z, const float* coords, int64_t N, int32_t S, float* rgb,
-              const ego_shade_dump* dump, void* stream) {
+              const ego_shade_dump* dump, const uint8_t* tile_active, void* stream) {
   EGO_REQUIRE(rays && z && rgb && N >= 0 && S >= 1 && N * (int64_t)S < (1ll << 31), "shade: null argument or N*S >= 2^31");
   if (int e = check_shade_config(sc, "shade", true, true)) return e;
   EGO_REQUIRE(sc->r_lut && sc->n_r_lut >= 2 && sc->n_r_lut <= LUT_MAX, "shade: r_lut missing or > 1024 entries");
   EGO_REQUIRE(coords || sc->mlp_precision == EGO_PREC_F32, "shade: coords (from ego_march_density) is required unless mlp_precision = EGO_PREC_F32");
   if (N == 0) return EGO_OK;
   ShadeArgs a{};
-  a.c = make_coords(*sc); a.F = make_field(sc->app); a.packed = sc->packed; a.rays = rays; a.z = z; a.coords = coords; a.out = rgb;
+  a.c = make_coords(*sc); a.F = make_field(sc->app); a.packed = sc->packed; a.rays = rays; a.z = z; a.coords = coords; a.out = rgb; a.tile_active = tile_active;
   a.M = N * (int64_t)S; a.S = S;
   if (dump) {
     EGO_REQUIRE(sc->mlp_precision == EGO_PREC_F16X3 && dump->x && dump->h1 && dump->h2 && dump->v,

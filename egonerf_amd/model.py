@@ -191,6 +191,37 @@ class TensorBase(torch.nn.Module):
 # ---------------------------------------------------------------------------------------------------
 # models/EgoNeRF.py
 # ---------------------------------------------------------------------------------------------------
+class YinYangAlphaGridMask(torch.nn.Module):
+    """models/EgoNeRF.py:11-24: two {0,1} volumes shaped (1,1,N_phi,N_theta,N_r); sample_alpha = trilinear lookup."""
+
+    def __init__(self, device, alpha_volume_yin, alpha_volume_yang):
+        super().__init__()
+        self.device = device
+        self.alpha_volume_yin = alpha_volume_yin.view(1, 1, *alpha_volume_yin.shape[-3:])
+        self.alpha_volume_yang = alpha_volume_yang.view(1, 1, *alpha_volume_yang.shape[-3:])
+        self._bytes = None
+
+    def packed(self) -> torch.Tensor:
+        """[2][N_phi][N_theta][N_r] uint8 (what the kernels read)."""
+        if self._bytes is None:
+            self._bytes = torch.stack([self.alpha_volume_yin[0, 0], self.alpha_volume_yang[0, 0]]).gt(0).to(torch.uint8).contiguous()
+        return self._bytes
+
+    def fill_scene(self, sc):
+        vol = self.packed()
+        sc.occ = vol.data_ptr()
+        sc.occ_res[:] = [vol.shape[3], vol.shape[2], vol.shape[1]]
+
+    def sample_alpha(self, norm_samples):
+        _require_cuda(norm_samples, "sample_alpha")
+        c = _f32c(norm_samples)
+        out = torch.empty(c.shape[:-1], device=c.device)
+        sc = _lib.Scene()
+        self.fill_scene(sc)
+        _call("ego_alpha_mask_sample", sc, c.data_ptr(), c.numel() // 7, out.data_ptr(), _lib.stream_handle())
+        return out
+
+
 class EgoNeRF(TensorBase):
     def __init__(self, aabb, gridSize, device, coordinates, **kargs):
         super().__init__(aabb, gridSize, device, coordinates, **kargs)
@@ -204,6 +235,9 @@ class EgoNeRF(TensorBase):
         self._packed_versions = None
         self._sched_cache = {}
         self._mlp_precision = "f16x3"
+        # opt-in skipping (EgoNeRF.forward itself evaluates every sample; see include/egonerf_hip.h):
+        self.use_alpha_mask = False          # apply self.alphaMask with TensorBase.forward's semantics (sigma = 0 where empty)
+        self.early_termination_eps = 0.0     # > 0: zero the weight of samples behind transmittance < eps
         self.coarse_sigma_plane_yin, self.coarse_sigma_line_yin = [None] * 3, [None] * 3
         self.coarse_sigma_plane_yang, self.coarse_sigma_line_yang = [None] * 3, [None] * 3
         if self.coarse_sigma_grid_update_rule is not None:
@@ -305,7 +339,8 @@ class EgoNeRF(TensorBase):
             raise RuntimeError(f"model parameters are on {dev}; the EgoNeRF hot path runs only on the HIP device")
         mlp = self._mlp_tensors()
         versions = tuple((t.data_ptr(), t._version) for t in mlp)
-        keys = tuple(p.data_ptr() for p in self.parameters()) + (None if self.envmap is None else self.envmap.emission.data_ptr(),)
+        keys = tuple(p.data_ptr() for p in self.parameters()) + (None if self.envmap is None else self.envmap.emission.data_ptr(),
+                                                                  self.use_alpha_mask, id(self.alphaMask), float(self.early_termination_eps))
         if self._scene_cache is not None and self._scene_cache[0] == keys and self._packed_versions == versions:
             return self._scene_cache[1]
         lib = _lib.load()
@@ -330,6 +365,9 @@ class EgoNeRF(TensorBase):
             self._packed = torch.empty(lib.ego_packed_floats(), device=dev)
         _call("ego_pack_mlp", sc, self._packed.data_ptr(), _lib.stream_handle())
         sc.packed = self._packed.data_ptr()
+        if self.use_alpha_mask and self.alphaMask is not None:
+            self.alphaMask.fill_scene(sc)
+        sc.term_eps = float(self.early_termination_eps)
         if self.envmap is not None:
             em = self.envmap.emission.detach()
             if not em.is_contiguous():
@@ -387,6 +425,46 @@ class EgoNeRF(TensorBase):
         out = torch.empty(*c.shape[:-1], self.app_dim, device=c.device)
         _call("ego_app_feature", self.scene(), c.data_ptr(), c.numel() // 7, out.data_ptr(), _lib.stream_handle())
         return out
+
+    # -- occupancy ------------------------------------------------------------------------------
+    @torch.no_grad()
+    def compute_alpha(self, norm_locs, length=1):
+        """tensorBase.py:421-436: alpha on arbitrary normalised locations, skipping what an existing mask marks empty."""
+        sigma = torch.zeros(norm_locs.shape[:-1], device=norm_locs.device)
+        if self.alphaMask is not None:
+            keep = self.alphaMask.sample_alpha(norm_locs) > 0
+        else:
+            keep = torch.ones_like(sigma, dtype=torch.bool)
+        if bool(keep.any()):
+            sigma[keep] = self.feature2density(self.compute_densityfeature(norm_locs[keep]))
+        return 1 - torch.exp(-sigma * length)
+
+    @torch.no_grad()
+    def getDenseAlpha(self, gridSize=None):
+        """EgoNeRF.py:437-465: alpha on the grid lattice of both grids, step length = stepSize (no distance_scale)."""
+        g = self.gridSize.tolist() if gridSize is None else list(gridSize)
+        dev = self.density_plane_yin[0].device
+        lin = [torch.linspace(0, 1, n) for n in g]
+        norm = (torch.stack(torch.meshgrid(*lin, indexing="ij"), -1) * 2 - 1).to(dev)
+        zeros3, flag = torch.zeros_like(norm), torch.zeros_like(norm[..., :1])
+        yin = torch.cat([norm, zeros3, flag], -1).view(-1, 7)
+        yang = torch.cat([zeros3, norm, flag + 1], -1).view(-1, 7)
+        step = float(self.stepSize)
+        return self.compute_alpha(yin, step).view(g), self.compute_alpha(yang, step).view(g)
+
+    @torch.no_grad()
+    def updateAlphaMask(self, gridSize=None):
+        """EgoNeRF.py:467-489: clamp, 3x3x3 max-pool, threshold at alphaMask_thres -> YinYangAlphaGridMask.  Building the
+        mask does not switch it on: set `use_alpha_mask = True` to apply it."""
+        g = self.gridSize.tolist() if gridSize is None else list(gridSize)
+        vols = []
+        for a in self.getDenseAlpha(g):
+            a = a.clamp(0, 1).transpose(0, 2).contiguous()[None, None]
+            a = torch.nn.functional.max_pool3d(a, kernel_size=3, padding=1, stride=1).view(g[::-1])
+            vols.append((a >= self.alphaMask_thres).float())
+        self.alphaMask = YinYangAlphaGridMask(self.device, vols[0], vols[1])
+        self._scene_cache = None
+        return float((vols[0].sum() + vols[1].sum()) / (2 * g[0] * g[1] * g[2]))
 
     # -- the hot path -------------------------------------------------------------------------------------------
     def forward(self, rays_chunk, white_bg=True, is_train=False, ndc_ray=False, n_coarse=-1, n_fine=0, exp_sampling=False,

@@ -94,21 +94,21 @@ class RenderFunction(torch.autograd.Function):
         if resampling:
             zc, wc = f(N, n_coarse), f(N, n_coarse)
             _lib.check(lib.ego_march_density(sc, rays.data_ptr(), N, n_coarse, None, sched.data_ptr(), _lib.ptr(jitter), near, 1,
-                                             zc.data_ptr(), None, 0, wc.data_ptr(), None, None, None, st), "ego_march_density")
+                                             zc.data_ptr(), None, 0, wc.data_ptr(), None, None, None, None, st), "ego_march_density")
             _lib.check(lib.ego_sample_pdf_merge(zc.data_ptr(), wc.data_ptr(), _lib.ptr(u), N, n_coarse, n_fine, int(use_coarse),
                                                 z.data_ptr(), None, st), "ego_sample_pdf_merge")
             _lib.check(lib.ego_march_density(sc, rays.data_ptr(), N, S, z.data_ptr(), None, None, near, 0, None, alpha.data_ptr(),
-                                             astride, weight.data_ptr(), bg.data_ptr(), coords.data_ptr(), sigma.data_ptr(), st),
+                                             astride, weight.data_ptr(), bg.data_ptr(), coords.data_ptr(), sigma.data_ptr(), None, st),
                        "ego_march_density")
         else:
             _lib.check(lib.ego_march_density(sc, rays.data_ptr(), N, S, None, sched.data_ptr(), _lib.ptr(jitter), near, 0,
                                              z.data_ptr(), alpha.data_ptr(), astride, weight.data_ptr(), bg.data_ptr(),
-                                             coords.data_ptr(), sigma.data_ptr(), st), "ego_march_density")
+                                             coords.data_ptr(), sigma.data_ptr(), None, st), "ego_march_density")
         M = N * S
         rgb = f(N, S, 3)
         dump = dict(x=f(M, 160), h1=f(M, 128), h2=f(M, 128), v=f(M, 144))
         ds = _lib.ShadeDump(dump["x"].data_ptr(), dump["h1"].data_ptr(), dump["h2"].data_ptr(), dump["v"].data_ptr())
-        _lib.check(lib.ego_shade(sc, rays.data_ptr(), z.data_ptr(), coords.data_ptr(), N, S, rgb.data_ptr(), C.byref(ds), st), "ego_shade")
+        _lib.check(lib.ego_shade(sc, rays.data_ptr(), z.data_ptr(), coords.data_ptr(), N, S, rgb.data_ptr(), C.byref(ds), None, st), "ego_shade")
         rgb_map, depth, raw = f(N, 3), f(N), f(N, 3)
         has_env = model.envmap is not None
         bg_map = f(N, 3) if has_env else None

@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define EGO_ABI_VERSION 1
+#define EGO_ABI_VERSION 2
 
 enum { EGO_PREC_F16X3 = 0, EGO_PREC_F32 = 1 };
 
@@ -94,6 +94,14 @@ typedef struct ego_scene {
   /* arithmetic of the basis/MLP matrix products: EGO_PREC_F16X3 (default, 0) = three fp16 MFMAs per product
    * (hi*hi + lo*hi + hi*lo, fp32 accumulate, ~2^-21 relative: fp32-grade), EGO_PREC_F32 = fp32-input MFMA */
   int32_t mlp_precision;
+  /* Opt-in skipping (EgoNeRF.forward itself evaluates every sample; these follow TensorBase.forward's mask semantics,
+   * models/tensorBase.py:464-478, and YinYangAlphaGridMask, models/EgoNeRF.py:11-24):
+   * occ: two {0,1} byte volumes [grid][N_phi][N_theta][N_r] (occ_res = N_r, N_theta, N_phi) or NULL.  A sample whose
+   * trilinear mask value (align_corners, zero padding) is <= 0 gets sigma = 0.
+   * term_eps > 0: samples whose incoming transmittance T is below term_eps get weight 0 (|d rgb| <= term_eps). */
+  const uint8_t* occ;
+  int32_t occ_res[3];
+  float term_eps;
 } ego_scene;
 
 /* number of floats ego_pack_mlp writes: the packed weight blob used by ego_shade / ego_mlp_fea / ego_app_feature
@@ -135,6 +143,9 @@ int ego_sample_pdf_merge(const float* z, const float* weight, const float* u, in
 int ego_envmap_radiance(const ego_scene* sc, const float* dirs, int64_t N, float* out, void* stream);
 /* 2x average pooling of one channel-last plane [H][W][C] -> [H/2][W/2][C] (W==1: line [H][C] -> [H/2][C]) */
 int ego_avgpool_table(const float* src, int32_t H, int32_t W, int32_t C, float* dst, void* stream);
+/* 8-tap occupancy lookup of YinYangAlphaGridMask.sample_alpha (models/EgoNeRF.py:19-24): c7n [M][7] -> out [M] (the
+ * trilinear mask value; > 0 means occupied). */
+int ego_alpha_mask_sample(const ego_scene* sc, const float* c7n, int64_t M, float* out, void* stream);
 /* reference-layout basis/MLP weights in `sc` -> packed blob (dev, ego_packed_floats() floats) */
 int ego_pack_mlp(const ego_scene* sc, float* packed_out, void* stream);
 
@@ -146,11 +157,12 @@ int ego_pack_mlp(const ego_scene* sc, float* packed_out, void* stream);
  * columns S.. are filled with 1, the reference's trailing ones column when an envmap is present,
  * EgoNeRF.py:587), weight [N][S], bg_weight [N], coords_out [N][S][4] = normalised (r, theta, phi) of the sample's
  * grid + is_yang flag (what ego_shade needs; saves it the acos/atan2/LUT search), sigma_out [N][S] (kept for the
- * backward pass). */
+ * backward pass), tile_active [ceil(N*S/32)] bytes, pre-zeroed by the caller: set to 1 for every 32-sample tile that
+ * holds a non-zero weight (lets ego_shade skip tiles that are fully masked / terminated). */
 int ego_march_density(const ego_scene* sc, const float* rays, int64_t N, int32_t S, const float* z_in,
                       const float* r_sched, const float* jitter, float near_, int32_t coarse, float* z_out,
                       float* alpha, int32_t alpha_stride, float* weight, float* bg_weight, float* coords_out, float* sigma_out,
-                      void* stream);
+                      uint8_t* tile_active, void* stream);
 
 /* Per-sample activations the training forward keeps for the backward pass (all dev, "lane order": the two lanes
  * (halves h = 0, 1) that serve a sample each own a contiguous run):
@@ -168,7 +180,8 @@ typedef struct ego_shade_dump {
  * z [N][S] sample distances (from ego_march_density); coords [N][S][4] optional (ego_march_density's coords_out),
  * NULL = recompute the yin-yang coordinates from rays and z. */
 int ego_shade(const ego_scene* sc, const float* rays, const float* z, const float* coords, int64_t N, int32_t S, float* rgb,
-              const ego_shade_dump* dump /* NULL for inference */, void* stream);
+              const ego_shade_dump* dump /* NULL for inference */, const uint8_t* tile_active /* NULL = shade every tile */,
+              void* stream);
 
 /* acc, rgb_map (+ envmap background), clamp, depth (+ (1-acc)*d_z quirk, EgoNeRF.py:598).
  * Outputs rgb_map [N][3], depth [N]; bg_map/env_map [N][3] written only when sc->envmap != NULL (may be NULL);

@@ -74,6 +74,9 @@ class OracleScene:
         self.r_lut = linearised_exp_grid(cfg.r0, ratio, n_r + 1)  # coordinates.py:118-124
         self.coarse = None
         self.update_coarse_sigma_grid()
+        # opt-in skipping, mirrored from the product for parity tests (the reference's EgoNeRF.forward has neither):
+        self.alpha_mask = None   # (vol_yin, vol_yang) float {0,1} volumes (1,1,N_phi,N_theta,N_r), TensorBase.forward semantics
+        self.term_eps = 0.0      # early termination: weight := 0 where the incoming transmittance < term_eps
 
     # ---- parameters -------------------------------------------------------------------------
     def table(self, kind: str, what: str, g: str, i: int) -> torch.Tensor:
@@ -243,6 +246,32 @@ class OracleScene:
         den = torch.where(den < 1e-5, torch.ones_like(den), den)
         return b_lo + (u - c_lo) / den * (b_hi - b_lo)
 
+    # ---- row M ---------------------------------------------------------------------------------
+    def sample_alpha(self, c7n: torch.Tensor) -> torch.Tensor:
+        """YinYangAlphaGridMask.sample_alpha (EgoNeRF.py:19-24): trilinear grid_sample of the {0,1} volumes."""
+        flat = c7n.reshape(-1, 7)
+        out = torch.empty(flat.shape[0], dtype=flat.dtype)
+        is_yin = flat[:, -1] == 0
+        for vol, sel, base in ((self.alpha_mask[0], is_yin, 0), (self.alpha_mask[1], ~is_yin, 3)):
+            if bool(sel.any()):
+                out[sel] = F.grid_sample(vol.to(flat.dtype), flat[sel][:, base:base + 3].view(1, -1, 1, 1, 3), align_corners=True).view(-1)
+        return out.view(c7n.shape[:-1])
+
+    def build_alpha_mask(self, step_size: float, thres: float = 1e-4):
+        """EgoNeRF.getDenseAlpha + updateAlphaMask (EgoNeRF.py:437-489)."""
+        g = self.grid
+        lin = [torch.linspace(0, 1, n) for n in g]
+        norm = torch.stack(torch.meshgrid(*lin, indexing="ij"), -1) * 2 - 1
+        zeros3, flag = torch.zeros_like(norm), torch.zeros_like(norm[..., :1])
+        vols = []
+        for c7 in (torch.cat([norm, zeros3, flag], -1), torch.cat([zeros3, norm, flag + 1], -1)):
+            a = 1 - torch.exp(-self.feature2density(self.density_feature(c7.view(-1, 7))) * step_size)
+            a = a.view(g).clamp(0, 1).transpose(0, 2).contiguous()[None, None]
+            a = F.max_pool3d(a, kernel_size=3, padding=1, stride=1).view(g[::-1])
+            vols.append((a >= thres).float()[None, None])
+        self.alpha_mask = (vols[0], vols[1])
+        return self.alpha_mask
+
     # ---- row J ---------------------------------------------------------------------------------
     def envmap_radiance(self, dirs: torch.Tensor) -> torch.Tensor:
         """models/envmap.py:6-14,26-34: u=(d_z+1)/2 on the h-wide axis, v=(atan2(d_y,d_x)+pi)/2pi."""
@@ -298,7 +327,12 @@ class OracleScene:
 
         sf = self.density_feature(c7n)
         sigma = self.feature2density(sf)
+        if self.alpha_mask is not None:  # tensorBase.py:464-478: masked samples keep sigma = 0
+            sigma = torch.where(self.sample_alpha(c7n) > 0, sigma, torch.zeros_like(sigma))
         alpha, weight, bg_w = self.raw2alpha(sigma, dists * c.distance_scale)
+        if self.term_eps > 0:
+            T = torch.cumprod(torch.cat([torch.ones_like(alpha[:, :1]), 1.0 - alpha + 1e-10], -1), -1)[:, :-1]
+            weight = torch.where(T < self.term_eps, torch.zeros_like(weight), weight)
         af = self.app_feature(c7n)
         vd = viewdirs.view(-1, 1, 3).expand(xyz.shape)
         rgb = self.mlp_fea(vd.reshape(-1, 3), af.reshape(-1, c.app_dim)).view(*xyz.shape[:2], 3)

@@ -22,7 +22,7 @@ def test_library_exports_every_header_symbol():
     for n in names:
         assert hasattr(lib, n), n
     assert set(names) == set(_lib.PROTOTYPES)  # the binding covers the whole header, nothing extra
-    assert lib.ego_abi_version() == 1
+    assert lib.ego_abi_version() == 2
     assert [lib.ego_sizeof(i) for i in range(3)] == [ctypes.sizeof(_lib.Scene), ctypes.sizeof(_lib.RenderArgs),
                                                      ctypes.sizeof(_lib.VmField)]
     assert lib.ego_packed_floats() == 2 * 46852  # fp32 fragment layout + fp16-split layout
@@ -33,7 +33,7 @@ def test_argument_validation_needs_no_gpu():
     assert lib.ego_sample_ray_exp(None, None, None, 0.0, 4, 8, None, None, None) == -1
     assert b"sample_ray_exp" in lib.ego_last_error()
     sc = _lib.Scene()
-    assert lib.ego_shade(sc, None, None, None, 1, 1, None, None, None) == -1
+    assert lib.ego_shade(sc, None, None, None, 1, 1, None, None, None, None) == -1
     assert lib.ego_render_workspace_bytes(4096, None) == -1
     a = _lib.RenderArgs()
     a.n_coarse, a.n_fine, a.resampling, a.use_coarse_sample = 128, 128, 1, 1

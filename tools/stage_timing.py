@@ -19,7 +19,7 @@ z = torch.empty(N, S, device=dev); w = torch.empty_like(z); alpha = torch.empty_
 crd = torch.empty(N, S, 4, device=dev); rgb = torch.empty(N, S, 3, device=dev)
 sched = model._sched(S, dev)
 _lib.check(lib.ego_march_density(sc, rays.data_ptr(), N, S, None, sched.data_ptr(), None, cfg.near, 0, z.data_ptr(), alpha.data_ptr(), 0,
-                                 w.data_ptr(), bg.data_ptr(), crd.data_ptr(), None, st), "march")
+                                 w.data_ptr(), bg.data_ptr(), crd.data_ptr(), None, None, st), "march")
 c7 = torch.zeros(M, 7, device=dev)
 flat = crd.view(M, 4)
 yang = flat[:, 3] != 0
@@ -39,9 +39,9 @@ def timeit(fn, reps=10):
 res = dict(precision=prec)
 res["app_only_ms"] = timeit(lambda: _lib.check(lib.ego_app_feature(sc, c7.data_ptr(), M, feat.data_ptr(), st), "app"))
 res["mlp_only_ms"] = timeit(lambda: _lib.check(lib.ego_mlp_fea(sc, vd.data_ptr(), feat.data_ptr(), M, rgb.data_ptr(), st), "mlp"))
-res["shade_ms"] = timeit(lambda: _lib.check(lib.ego_shade(sc, rays.data_ptr(), z.data_ptr(), crd.data_ptr(), N, S, rgb.data_ptr(), None, st), "shade"))
+res["shade_ms"] = timeit(lambda: _lib.check(lib.ego_shade(sc, rays.data_ptr(), z.data_ptr(), crd.data_ptr(), N, S, rgb.data_ptr(), None, None, st), "shade"))
 res["march_ms"] = timeit(lambda: _lib.check(lib.ego_march_density(sc, rays.data_ptr(), N, S, None, sched.data_ptr(), None, cfg.near, 0, z.data_ptr(),
-                                                                   alpha.data_ptr(), 0, w.data_ptr(), bg.data_ptr(), crd.data_ptr(), None, st), "march"))
+                                                                   alpha.data_ptr(), 0, w.data_ptr(), bg.data_ptr(), crd.data_ptr(), None, None, st), "march"))
 # same-texel variant: every sample at the same coordinates (all gathers hit one texel set -> pure L1 hits)
 c7s = c7[:1].expand(M, 7).contiguous()
 res["app_only_same_texel_ms"] = timeit(lambda: _lib.check(lib.ego_app_feature(sc, c7s.data_ptr(), M, feat.data_ptr(), st), "app"))
