@@ -62,6 +62,7 @@ PROTOTYPES = {
     "ego_sizeof": (I64, [I32]),
     "ego_packed_floats": (I64, []),
     "ego_sample_ray_exp": (C.c_int, [P, P, P, F32, I64, I32, P, P, P]),
+    "ego_erp_rays": (C.c_int, [I32, I32, I32, I32, C.POINTER(C.c_float), P, P]),
     "ego_from_cartesian": (C.c_int, [SP, P, I64, P, P]),
     "ego_normalize_coord": (C.c_int, [SP, P, I64, P, P]),
     "ego_density_feature": (C.c_int, [SP, P, I64, I32, P, P]),

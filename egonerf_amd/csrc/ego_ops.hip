@@ -439,6 +439,25 @@ __global__ void k_avgpool(const float* __restrict__ src, int H, int W, int C, fl
 }
 
 // =============================================================================================
+// Equirectangular camera rays on the device   dataLoader/ray_utils.py:24-40 (directions), :85-113 (pose)
+// =============================================================================================
+struct Pose34 { float m[12]; };
+
+__global__ void k_erp_rays(int H, int W, int row0, int n_rows, Pose34 c2w, float* __restrict__ rays) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)n_rows * W) return;
+  const int col = (int)(idx % W), row = row0 + (int)(idx / W);
+  const float i = (float)col + 0.5f, j = (float)row + 0.5f;
+  const float phi = __fmul_rn(__fsub_rn(1.f, __fdiv_rn(__fmul_rn(2.f, i), (float)W)), 3.14159265358979323846f);
+  const float theta = __fdiv_rn(__fmul_rn(__fsub_rn(1.f, __fdiv_rn(__fmul_rn(2.f, j), (float)H)), 3.14159265358979323846f), 2.f);
+  const float ct = cosf(theta), d0 = -ct * sinf(phi), d1 = sinf(theta), d2 = -ct * cosf(phi);
+  float* o = rays + idx * 6;
+  o[0] = c2w.m[3]; o[1] = c2w.m[7]; o[2] = c2w.m[11];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) o[3 + r] = (d0 * c2w.m[4 * r] + d1 * c2w.m[4 * r + 1]) + d2 * c2w.m[4 * r + 2];
+}
+
+// =============================================================================================
 // C ABI
 // =============================================================================================
 static inline unsigned nblk(int64_t n, int b) { return (unsigned)((n + b - 1) / b); }
@@ -454,6 +473,16 @@ int ego_sample_ray_exp(const float* rays, const float* r_sched, const float* jit
   if (N == 0) return EGO_OK;
   k_sample_ray_exp<<<nblk(N * S, 256), 256, 0, (hipStream_t)stream>>>(rays, r_sched, jitter, near_, N, S, xyz, z);
   return ego_launch_status("k_sample_ray_exp");
+}
+
+int ego_erp_rays(int32_t H, int32_t W, int32_t row0, int32_t n_rows, const float* c2w, float* rays, void* stream) {
+  EGO_REQUIRE(H >= 1 && W >= 1 && row0 >= 0 && n_rows >= 0 && row0 + n_rows <= H, "erp_rays: bad image window");
+  if (n_rows == 0) return EGO_OK;
+  EGO_REQUIRE(c2w && rays, "erp_rays: null argument");
+  Pose34 p;
+  for (int i = 0; i < 12; ++i) p.m[i] = c2w[i];
+  k_erp_rays<<<nblk((int64_t)n_rows * W, 256), 256, 0, (hipStream_t)stream>>>(H, W, row0, n_rows, p, rays);
+  return ego_launch_status("k_erp_rays");
 }
 
 int ego_from_cartesian(const ego_scene* sc, const float* xyz, int64_t M, float* c7, void* stream) {

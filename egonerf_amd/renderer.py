@@ -38,6 +38,19 @@ def volume_renderer(rays, model, chunk=4096, n_coarse=-1, n_fine=0, ndc_ray=Fals
     return col(0), col(1), col(2), col(3), col(4)
 
 
+def erp_rays(H: int, W: int, c2w, device, row0: int = 0, n_rows: Optional[int] = None) -> torch.Tensor:
+    """[n_rows*W, 6] rays of an equirectangular camera, generated on the device (no [H*W,6] host transfer):
+    dataLoader/ray_utils.py:24-40 (get_ray_directions_360) + :85-113 (get_rays)."""
+    import ctypes
+    from . import _lib
+    n_rows = H - row0 if n_rows is None else n_rows
+    pose = (ctypes.c_float * 12)(*[float(v) for v in np.asarray(c2w, dtype=np.float32).reshape(-1)[:12]])
+    rays = torch.empty(n_rows * W, 6, device=device, dtype=torch.float32)
+    with torch.cuda.device(rays.device):
+        _lib.check(_lib.load().ego_erp_rays(H, W, row0, n_rows, pose, rays.data_ptr(), _lib.stream_handle()), "ego_erp_rays")
+    return rays
+
+
 # ---------------------------------------------------------------------------------------------------
 # ray sharding + PSNR reduction (one process per GPU)
 # ---------------------------------------------------------------------------------------------------

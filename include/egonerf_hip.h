@@ -9,6 +9,7 @@
  * (models/EgoNeRF.py:504,522); the Python host layer turns non-zero codes into RuntimeError.
  *
  * Reference interface replaced by each entry point (paths relative to the reference repo):
+ *   ego_erp_rays            get_ray_directions_360 + get_rays      dataLoader/ray_utils.py:24-40, :85-113
  *   ego_sample_ray_exp      EgoNeRF.sample_ray_exp                models/EgoNeRF.py:56-87
  *   ego_from_cartesian      YinYangSphericalCoords.from_cartesian  models/coordinates.py:468-498
  *   ego_normalize_coord     YinYangSphericalCoords.normalize_coord models/coordinates.py:442-466 (+ :110-131)
@@ -120,6 +121,10 @@ int64_t ego_sizeof(int32_t which);
  * z = near + r (+ step*jitter); xyz = o + d*z.  Outputs xyz [N][S][3], z [N][S] (either may be NULL). */
 int ego_sample_ray_exp(const float* rays, const float* r_sched, const float* jitter, float near_, int64_t N, int32_t S,
                        float* xyz, float* z, void* stream);
+
+/* Equirectangular rays of rows [row0, row0+n_rows) of an H x W panorama for the camera-to-world pose c2w (HOST pointer,
+ * 3x4 row-major): get_ray_directions_360 + get_rays (dataLoader/ray_utils.py:24-40, :85-113).  rays [n_rows*W][6] dev. */
+int ego_erp_rays(int32_t H, int32_t W, int32_t row0, int32_t n_rows, const float* c2w, float* rays, void* stream);
 
 int ego_from_cartesian(const ego_scene* sc, const float* xyz, int64_t M, float* c7, void* stream);
 int ego_normalize_coord(const ego_scene* sc, const float* c7, int64_t M, float* c7n, void* stream);

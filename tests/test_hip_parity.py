@@ -339,3 +339,19 @@ def test_masked_and_terminated_render_vs_oracle(full):
         model.early_termination_eps = 0.0
         model.alphaMask = None
         model._scene_cache = None
+
+
+def test_erp_rays_on_device():
+    """ego_erp_rays vs the numpy restatement of get_ray_directions_360/get_rays (egonerf_amd.synth.erp_rays)."""
+    from egonerf_amd.renderer import erp_rays
+    H, W = 16, 32
+    eye = np.concatenate([np.eye(3), np.zeros((3, 1))], 1).astype(np.float32)
+    got = erp_rays(H, W, eye, DEV).cpu().numpy()
+    assert np.abs(got - synth.erp_rays(H, W)).max() <= 3e-7
+    # rotated / translated pose, a window of rows
+    c, s_ = np.cos(0.3), np.sin(0.3)
+    pose = np.array([[c, 0, s_, 0.1], [0, 1, 0, -0.2], [-s_, 0, c, 0.05]], np.float32)
+    win = erp_rays(H, W, pose, DEV, row0=4, n_rows=5).cpu().numpy()
+    ref = synth.erp_rays(H, W, 4, 9)
+    ref = np.concatenate([np.broadcast_to(pose[:, 3], (ref.shape[0], 3)), ref[:, 3:] @ pose[:, :3].T], 1)
+    assert np.abs(win - ref).max() <= 5e-7
