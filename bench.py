@@ -79,11 +79,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}"
+    # EGO_BENCH_TEST_SHARED_GPU=1: dry-run of the multi-rank path on a box with one GPU (all ranks on cuda:0, gloo)
+    shared = os.environ.get("EGO_BENCH_TEST_SHARED_GPU") == "1"
+    if shared:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)  # RCCL on ROCm
+        if shared:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)  # RCCL on ROCm
 
     from tests.helpers import make_model
     cfg = synth.SceneConfig()
@@ -106,9 +113,9 @@ def main():
             out = model(rays, **kw)
         barrier()
         dt = time.perf_counter() - t0
-    t = torch.tensor([dt], device=dev, dtype=torch.float64)
+    t = torch.tensor([dt], device="cpu" if shared else dev, dtype=torch.float64)
     if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)  # MAX over ranks of the barrier-bracketed wall time
     dt = float(t.item())
 
     if rank == 0:
@@ -172,7 +179,7 @@ def main():
 
         cpu = None
         parity = None
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and world == 1:  # the CPU baseline is timed at N=1 only
             cpu, ref, cpu_rays = cpu_baseline(cfg, weights, a.cpu_rays)
             with torch.no_grad():
                 got = model(cpu_rays.to(dev), **kw)
