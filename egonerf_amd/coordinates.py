@@ -50,6 +50,21 @@ class YinYangSphericalCoords:
         self.update_aabb(aabb)
         self.set_resolution(self.N_to_reso(N_voxel, aabb), r0=r0)
 
+    def __setstate__(self, state):
+        """Also accepts the attribute set of a pickled reference object (models.coordinates.YinYangSphericalCoords inside
+        a `.th` checkpoint's kwargs, tensorBase.py:264): device, center, near, far, inv_diff, exp_r, interval_th, N_*, r0,
+        ratio, resolution."""
+        self.__dict__.update(state)
+        self.__dict__.setdefault("aabb", None)
+        self._lut_dev = None
+        for k in ("center", "near", "far", "inv_diff"):
+            if torch.is_tensor(self.__dict__.get(k)):
+                self.__dict__[k] = self.__dict__[k].detach().cpu().float()
+        if torch.is_tensor(self.__dict__.get("ratio")):
+            self.ratio = self.ratio.detach().cpu()
+        if not hasattr(self, "resolution"):
+            self.resolution = [self.N_r, self.N_theta, self.N_phi]
+
     # -- constants ---------------------------------------------------------------------------------
     def _get_max_r(self, aabb) -> torch.Tensor:
         """Distance centre -> farthest aabb corner, float32 (coordinates.py:187-204)."""

@@ -525,19 +525,30 @@ class EgoNeRF(TensorBase):
     def save(self, path, global_step):
         ckpt = {"kwargs": self.get_kwargs(), "state_dict": {k: v.contiguous() for k, v in self.state_dict().items()},
                 "global_step": global_step}
+        if self.alphaMask is not None:  # packed bit volumes, EgoNeRF.py:161-167
+            for g in ("yin", "yang"):
+                vol = getattr(self.alphaMask, f"alpha_volume_{g}").bool().cpu().numpy()
+                ckpt.update({f"alphaMask_{g}.shape": vol.shape, f"alphaMask_{g}.mask": np.packbits(vol.reshape(-1))})
         if self.envmap is not None:
             ckpt.update({"envmap.emission": self.envmap.emission.detach().cpu().numpy(),
                          "envmap_res_H": self.envmap.emission.shape[2]})
         torch.save(ckpt, path)
 
     def load(self, ckpt):
+        if "alphaMask_yin.shape" in ckpt:  # EgoNeRF.py:175-180
+            vols = []
+            for g in ("yin", "yang"):
+                shape = tuple(ckpt[f"alphaMask_{g}.shape"])
+                bits = np.unpackbits(ckpt[f"alphaMask_{g}.mask"])[: int(np.prod(shape))].reshape(shape)
+                vols.append(torch.from_numpy(bits).float().to(self.device))
+            self.alphaMask = YinYangAlphaGridMask(self.device, vols[0], vols[1])
         if self.envmap is not None and "envmap.emission" in ckpt:
             self.envmap = EnvironmentMap(h=ckpt["envmap_res_H"], init_strategy="zero", device=self.device)
             self.envmap.load_envmap(emission=ckpt["envmap.emission"], device=self.device)
         self.load_state_dict(ckpt["state_dict"])
         self._scene_cache = None
-        if self.coarse_sigma_grid_update_rule == "conv":
-            self.update_coarse_sigma_grid()
+        if self.coarse_sigma_grid_update_rule == "conv" and self.density_plane_yin[0].is_cuda:
+            self.update_coarse_sigma_grid()  # EgoNeRF.py:185-186 (a CPU-resident model only holds weights)
         return ckpt["global_step"]
 
     def load_state_dict(self, state_dict, strict=True):

@@ -265,9 +265,27 @@ def capture_alpha_mask():
                         vol_yang=np_(am.alpha_volume_yang).astype(np.uint8), coords=np_(q), sampled=np_(am.sample_alpha(q)))
 
 
+def capture_checkpoint():
+    """A `.th` checkpoint written by the reference's own EgoNeRF.save (EgoNeRF.py:158-172): tiny grid, envmap and a
+    packed alpha mask, so loading exercises every key of the format (state_dict, kwargs with the pickled coordinates /
+    envmap objects, alphaMask_{yin,yang}.{shape,mask}, envmap.emission, global_step).  Plus the reference's render of it."""
+    import warnings
+    cfg = synth.SceneConfig(n_voxel=20 ** 3, use_envmap=True, envmap_res_H=16)
+    model, _ = build_reference(cfg, synth.make_weights(cfg, seed=77))
+    with contextlib.redirect_stdout(io.StringIO()), warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        model.updateAlphaMask(tuple(cfg.grid))
+    path = os.path.join(OUT, "reference_ckpt.th")
+    model.save(path, global_step=4321)
+    rays = torch.from_numpy(synth.make_rays(48, seed=17))
+    o = run_forward(model, rays, n_coarse=16, n_fine=16, resampling=True, use_coarse_sample=True)
+    np.savez_compressed(os.path.join(OUT, "reference_ckpt_render.npz"), rays=rays.numpy(), rgb=np_(o[0]), depth=np_(o[1]),
+                        bg=np_(o[2]), env=np_(o[3]), alpha=np_(o[4]))
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
-    which = sys.argv[1:] or ["tiny", "stages", "full", "alpha_mask"]
+    which = sys.argv[1:] or ["tiny", "stages", "full", "alpha_mask", "checkpoint"]
     for name in which:
         globals()["capture_" + name]()
         print("captured", name)

@@ -134,3 +134,24 @@ def test_shard_bounds_partition():
         assert all(blocks[i][1] == blocks[i + 1][0] for i in range(w - 1))
         assert max(h - l for l, h in blocks) - min(h - l for l, h in blocks) <= 1
     assert abs(psnr_from_sse(0.01 * 300, 300) - 20.0) < 1e-12
+
+
+def test_reference_checkpoint_loads_on_cpu(golden):
+    """A `.th` file written by the reference's own EgoNeRF.save (tests/golden/reference_ckpt.th) unpickles through the
+    module shims and rebuilds the model: kwargs objects, state_dict, packed alpha mask, envmap, global_step."""
+    import sys
+    from egonerf_amd.compat import load_reference_checkpoint
+    from egonerf_amd.coordinates import YinYangSphericalCoords
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_ckpt.th")
+    model, step = load_reference_checkpoint(path, device="cpu")
+    assert step == 4321 and "models.coordinates" not in sys.modules  # shims are removed after the load
+    cfg = synth.SceneConfig(n_voxel=20 ** 3, use_envmap=True, envmap_res_H=16)
+    w = synth.make_weights(cfg, seed=77)
+    for k, v in model.state_dict().items():
+        assert np.array_equal(v.numpy(), w[k]), k
+    assert isinstance(model.coordinates, YinYangSphericalCoords) and model.coordinates.resolution == [10, 10, 30]
+    assert np.array_equal(model.coordinates.reference_r_grid().numpy(),
+                          make_model(cfg, w, "cpu").coordinates.reference_r_grid().numpy())
+    assert np.array_equal(model.envmap.emission.detach().numpy(), w["envmap.emission"])
+    assert model.alphaMask is not None and tuple(model.alphaMask.alpha_volume_yin.shape) == (1, 1, 30, 10, 10)
+    assert model.near_far == [0.01, 15.0] and model.density_shift == -8 and model.fea2denseAct == "softplus"

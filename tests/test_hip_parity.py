@@ -355,3 +355,21 @@ def test_erp_rays_on_device():
     ref = synth.erp_rays(H, W, 4, 9)
     ref = np.concatenate([np.broadcast_to(pose[:, 3], (ref.shape[0], 3)), ref[:, 3:] @ pose[:, :3].T], 1)
     assert np.abs(win - ref).max() <= 5e-7
+
+
+def test_reference_checkpoint_renders_like_the_reference(golden):
+    """Load the reference-written `.th` (shim module paths), save it again in the same format, reload, render."""
+    import os, tempfile
+    from egonerf_amd.compat import load_reference_checkpoint
+    fx = golden("reference_ckpt_render")
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_ckpt.th")
+    model, step = load_reference_checkpoint(path, device=DEV)
+    assert step == 4321
+    with tempfile.TemporaryDirectory() as d:
+        model.save(os.path.join(d, "again.th"), 99)
+        model, step = load_reference_checkpoint(os.path.join(d, "again.th"), device=DEV)
+    assert step == 99
+    with torch.no_grad():
+        rgb, depth, bg, env, alpha = model(T(fx["rays"]), n_coarse=16, n_fine=16, exp_sampling=True, resampling=True)
+    assert maxerr(rgb, fx["rgb"]) <= RGB_TOL and maxerr(depth, fx["depth"]) <= 1e-3 * 15.0
+    assert maxerr(bg, fx["bg"]) <= RGB_TOL and maxerr(env, fx["env"]) <= 1e-5 and alpha.shape == fx["alpha"].shape
