@@ -184,6 +184,18 @@ __device__ __forceinline__ void sincos_x_2x(float x, float& s1, float& c1, float
   c2 = fmaf(-t, s1, 1.0f);
 }
 
+// Same outputs through the hardware transcendentals (v_sin_f32 / v_cos_f32 take revolutions): 6 VALU issues instead
+// of 27.  Measured on gfx950 (tools/sincos_probe.hip): max |err| 1.4e-7 for |x| < 2 (the feature range), 8e-7 at |x| = 12
+// (the x / 2pi product rounds at |x| * 6e-8); the double angle doubles it.  Used by the f16x3 shade kernel only.
+__device__ __forceinline__ void sincos_x_2x_hw(float x, float& s1, float& c1, float& s2, float& c2) {
+  const float t = x * 0.15915494309189533577f;
+  s1 = __builtin_amdgcn_sinf(t);
+  c1 = __builtin_amdgcn_cosf(t);
+  const float d = s1 + s1;
+  s2 = d * c1;
+  c2 = fmaf(-d, s1, 1.0f);
+}
+
 // wave64 inclusive multiplicative scan (Kogge-Stone over __shfl_up)
 __device__ __forceinline__ float wave_scan_mul(float v, int lane) {
 #pragma unroll

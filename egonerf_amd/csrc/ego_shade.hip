@@ -172,6 +172,32 @@ __global__ void k_pack_mlp_h(const float* __restrict__ w1, const float* __restri
   out[idx] = __builtin_bit_cast(float, v);
 }
 
+// basis fragments for the fp16-table gather: same [g][step][term][lane][8] order, columns follow app_channel_f16
+__host__ __device__ constexpr int app_channel_f16_fwd(int kk, int h) {
+  return (kk / APP_HALF) * APP_C + ((kk % APP_HALF) / 8) * 16 + 8 * h + (kk % 8);
+}
+
+__global__ void k_pack_basis16(const float* __restrict__ basis_yin, const float* __restrict__ basis_yang, float* __restrict__ out) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= 2 * KHB * 2 * 64 * 4) return;
+  _Float16 pr[2];
+  for (int p = 0; p < 2; ++p) {
+    const int hidx = idx * 2 + p;
+    const int e = hidx & 7, lane = (hidx >> 3) & 63, term = (hidx >> 9) & 1, sg = hidx >> 10;
+    const int g = sg / KHB, kk = (sg % KHB) * 8 + e;
+    const int i = lane & 31, h = lane >> 5;
+    const int rh = (i >> 2) & 1, r = (i & 3) + 4 * (i >> 3), f = 2 * r + rh;
+    float w = 0.f;
+    if (r < NSLOT && f < APP_DIM) w = (g ? basis_yang : basis_yin)[f * (3 * APP_C) + app_channel_f16_fwd(kk, h)];
+    _Float16 hi, lo;
+    split_weight(w, hi, lo);
+    pr[p] = term ? lo : hi;
+  }
+  typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+  h2v v = {pr[0], pr[1]};
+  out[idx] = __builtin_bit_cast(float, v);
+}
+
 enum { MODE_SHADE = 0, MODE_APP = 1, MODE_MLP = 2 };
 
 struct ShadeArgs {
@@ -583,7 +609,64 @@ __device__ __forceinline__ void gather_basis(const DevField& F, const VMTaps& ta
   basis_step(f1, v2 + 8, keep, fe); basis_step(f2, v2 + 16, keep, fe);
 }
 
-template <int MODE, bool DUMP = false>
+// ---- half-precision appearance tables (ego_scene.app_f16) --------------------------------------------------------
+// Same [H][W][48] channel-last layout with IEEE half elements (96 B per texel).  Lane half h owns the 16-byte chunks
+// 2i+h (8 channels each), so one plane is 18 loads per lane and yields 24 products: one plane per pipeline stage, three
+// stages per tile instead of six — the gather is bound by bytes in flight per VGPR, and a VGPR now carries two values.
+// Interpolation and everything downstream stay fp32.
+__host__ __device__ constexpr int app_channel_f16(int kk, int h) {
+  return (kk / APP_HALF) * APP_C + ((kk % APP_HALF) / 8) * 16 + 8 * h + (kk % 8);
+}
+
+template <int I>
+__device__ __forceinline__ void gather_plane_f16(const DevField& F, const VMTaps& t, int g, int h, float v[APP_HALF]) {
+#pragma clang fp contract(fast)
+  const Lin1 X = t.ax[vm_plane_x(I)], Y = t.ax[vm_plane_y(I)], Ln = t.ax[vm_line_ax(I)];
+  const int W = F.res[vm_plane_x(I)];
+  // element offsets are in halves; the DevField pointers are nominally float*
+  const _Float16* P = (const _Float16*)(g ? F.plane[1][I] : F.plane[0][I]) + 8 * h;
+  const _Float16* L = (const _Float16*)(g ? F.line[1][I] : F.line[0][I]) + 8 * h;
+  const h8* p00 = (const h8*)(P + (Y.i0 * W + X.i0) * APP_C);
+  const h8* p01 = (const h8*)(P + (Y.i0 * W + X.i1) * APP_C);
+  const h8* p10 = (const h8*)(P + (Y.i1 * W + X.i0) * APP_C);
+  const h8* p11 = (const h8*)(P + (Y.i1 * W + X.i1) * APP_C);
+  const h8* l0 = (const h8*)(L + Ln.i0 * APP_C);
+  const h8* l1 = (const h8*)(L + Ln.i1 * APP_C);
+  const float w00 = __fmul_rn(Y.w0, X.w0), w01 = __fmul_rn(Y.w0, X.w1);
+  const float w10 = __fmul_rn(Y.w1, X.w0), w11 = __fmul_rn(Y.w1, X.w1);
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {  // chunk 2c+h: h8 index 2c
+    const h8 a00 = p00[2 * c], a01 = p01[2 * c], a10 = p10[2 * c], a11 = p11[2 * c], b0 = l0[2 * c], b1 = l1[2 * c];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float pv = (float)a00[e] * w00 + (float)a01[e] * w01 + (float)a10[e] * w10 + (float)a11[e] * w11;
+      const float lv = (float)b0[e] * Ln.w0 + (float)b1[e] * Ln.w1;
+      v[c * 8 + e] = pv * lv;
+    }
+  }
+}
+
+template <bool MASKED>
+__device__ __forceinline__ void gather_basis_f16(const DevField& F, const VMTaps& taps, const u32x4* __restrict__ BASH, int lane,
+                                                 int g, int h, int gsel, bool keep_in, f32x16& fe) {
+  const bool keep = !MASKED || keep_in;
+  float v0[APP_HALF], v1[APP_HALF], v2[APP_HALF];
+  BasisFrag f0, f1, f2;
+  gather_plane_f16<0>(F, taps, g, h, v0);
+  f0 = basis_frag<0>(BASH, lane, gsel); f1 = basis_frag<1>(BASH, lane, gsel); f2 = basis_frag<2>(BASH, lane, gsel);
+  __builtin_amdgcn_sched_barrier(0);
+  gather_plane_f16<1>(F, taps, g, h, v1);
+  basis_step(f0, v0, keep, fe); basis_step(f1, v0 + 8, keep, fe); basis_step(f2, v0 + 16, keep, fe);
+  f0 = basis_frag<3>(BASH, lane, gsel); f1 = basis_frag<4>(BASH, lane, gsel); f2 = basis_frag<5>(BASH, lane, gsel);
+  __builtin_amdgcn_sched_barrier(0);
+  gather_plane_f16<2>(F, taps, g, h, v2);
+  basis_step(f0, v1, keep, fe); basis_step(f1, v1 + 8, keep, fe); basis_step(f2, v1 + 16, keep, fe);
+  f0 = basis_frag<6>(BASH, lane, gsel); f1 = basis_frag<7>(BASH, lane, gsel); f2 = basis_frag<8>(BASH, lane, gsel);
+  __builtin_amdgcn_sched_barrier(0);
+  basis_step(f0, v2, keep, fe); basis_step(f1, v2 + 8, keep, fe); basis_step(f2, v2 + 16, keep, fe);
+}
+
+template <int MODE, bool DUMP = false, bool TAB16 = false>
 __global__ __launch_bounds__(512) void k_shade_h(ShadeArgs A) {
   __shared__ __attribute__((aligned(16))) float lds[(MODE == MODE_APP ? 0 : LDS_W_FLOATS) + 4];
   const float* blob = A.packed + PACKED_FLOATS;  // the f16x3 half of the packed blob
@@ -603,7 +686,8 @@ __global__ __launch_bounds__(512) void k_shade_h(ShadeArgs A) {
   const f32x4* B1 = (const f32x4*)(lds + OFF_B1);
   const f32x4* B2 = (const f32x4*)(lds + OFF_B2);
   const f32x4* W3 = (const f32x4*)(lds + OFF_W3);
-  const u32x4* BASH = (const u32x4*)(blob + OFF_BASIS);
+  // basis fragments: K order of the fp32-table gather, or of the fp16-table gather (third region of the blob)
+  const u32x4* BASH = TAB16 ? (const u32x4*)(A.packed + 2 * PACKED_FLOATS) : (const u32x4*)(blob + OFF_BASIS);
 
   for (int64_t tile = (int64_t)blockIdx.x * 8 + wave; tile < n_tiles; tile += (int64_t)gridDim.x * 8) {
     if (MODE == MODE_SHADE && A.tile_active && !A.tile_active[tile]) continue;
@@ -649,7 +733,11 @@ __global__ __launch_bounds__(512) void k_shade_h(ShadeArgs A) {
       if (!mixed) {
         // lw / hw (opaque copies of lane / lane half) keep the per-table base pointers from being hoisted out of
         // the tile loop, where 24 64-bit loop invariants would spill
-        gather_basis<false>(A.F, taps, BASH, lw, g, hw, gu, true, fe, (DUMP && valid) ? A.dump_v + m * 144 + hw * 72 : nullptr);
+        if (TAB16) gather_basis_f16<false>(A.F, taps, BASH, lw, g, hw, gu, true, fe);
+        else gather_basis<false>(A.F, taps, BASH, lw, g, hw, gu, true, fe, (DUMP && valid) ? A.dump_v + m * 144 + hw * 72 : nullptr);
+      } else if (TAB16) {
+        gather_basis_f16<true>(A.F, taps, BASH, lw, g, hw, 0, g == 0, fe);
+        gather_basis_f16<true>(A.F, taps, BASH, lw, g, hw, 1, g != 0, fe);
       } else {
         gather_basis<true>(A.F, taps, BASH, lw, g, hw, 0, g == 0, fe, (DUMP && valid) ? A.dump_v + m * 144 + hw * 72 : nullptr);
         gather_basis<true>(A.F, taps, BASH, lw, g, hw, 1, g != 0, fe);
@@ -669,9 +757,9 @@ __global__ __launch_bounds__(512) void k_shade_h(ShadeArgs A) {
     float vw[8];
     {
       float sa0, ca0, sb0, cb0, sa1, ca1, sb1, cb1, sa2, ca2, sb2, cb2;
-      sincos_x_2x(vd0, sa0, ca0, sb0, cb0);
-      sincos_x_2x(vd1, sa1, ca1, sb1, cb1);
-      sincos_x_2x(vd2, sa2, ca2, sb2, cb2);
+      sincos_x_2x_hw(vd0, sa0, ca0, sb0, cb0);
+      sincos_x_2x_hw(vd1, sa1, ca1, sb1, cb1);
+      sincos_x_2x_hw(vd2, sa2, ca2, sb2, cb2);
       vw[0] = h ? sb2 : vd0; vw[1] = h ? ca0 : vd1; vw[2] = h ? cb0 : vd2; vw[3] = h ? ca1 : sa0;
       vw[4] = h ? cb1 : sb0; vw[5] = h ? ca2 : sa1; vw[6] = h ? cb2 : sb1; vw[7] = h ? 0.f : sa2;
     }
@@ -699,7 +787,7 @@ __global__ __launch_bounds__(512) void k_shade_h(ShadeArgs A) {
         float x;
         if (kk < 5 * NSLOT) {
           const int r = kk / 5, kind = kk % 5;
-          if (kind == 0) sincos_x_2x(fe[r], s1, c1, s2, c2);
+          if (kind == 0) sincos_x_2x_hw(fe[r], s1, c1, s2, c2);
           x = kind == 0 ? fe[r] : (kind == 1 ? s1 : (kind == 2 ? s2 : (kind == 3 ? c1 : c2)));
         } else if (kk < 5 * NSLOT + 8) {
           x = vw[kk - 5 * NSLOT];
@@ -835,6 +923,14 @@ int check_shade_config(const ego_scene* sc, const char* who, bool need_tables, b
   return EGO_OK;
 }
 
+int check_app16(const ego_scene* sc, const char* who) {
+  if (sc->app16.n_comp != APP_C) return ego_fail(EGO_E_BADARG, "%s: app_f16 is set but app16.n_comp is %d", who, sc->app16.n_comp);
+  for (int g = 0; g < 2; ++g)
+    for (int i = 0; i < 3; ++i)
+      if (!sc->app16.plane[g][i] || !sc->app16.line[g][i]) return ego_fail(EGO_E_BADARG, "%s: app_f16 is set but an app16 table is null", who);
+  return EGO_OK;
+}
+
 unsigned shade_grid(int64_t M) {
   const int64_t tiles = (M + 31) >> 5;
   const int64_t wgs = (tiles + 7) / 8;
@@ -845,7 +941,9 @@ unsigned shade_grid(int64_t M) {
 
 extern "C" {
 
-int64_t ego_packed_floats(void) { return 2 * (int64_t)PACKED_FLOATS; }
+constexpr int BASIS16_FLOATS = 2 * KHB * 2 * 64 * 4;  // [2 g][9 steps][2 terms][64 lanes][8 halves]
+
+int64_t ego_packed_floats(void) { return 2 * (int64_t)PACKED_FLOATS + BASIS16_FLOATS; }
 
 int ego_pack_mlp(const ego_scene* sc, float* packed_out, void* stream) {
   EGO_REQUIRE(sc && packed_out, "pack_mlp: null argument");
@@ -861,7 +959,9 @@ int ego_pack_mlp(const ego_scene* sc, float* packed_out, void* stream) {
   k_pack_mlp_h<<<(PACKED_FLOATS + 255) / 256, 256, 0, (hipStream_t)stream>>>(sc->mlp_w[0], sc->mlp_b[0], sc->mlp_w[1], sc->mlp_b[1],
                                                                             sc->mlp_w[2], sc->mlp_b[2], sc->basis[0], sc->basis[1],
                                                                             packed_out, packed_out + PACKED_FLOATS);
-  return ego_launch_status("k_pack_mlp_h");
+  if (int e = ego_launch_status("k_pack_mlp_h")) return e;
+  k_pack_basis16<<<(BASIS16_FLOATS + 255) / 256, 256, 0, (hipStream_t)stream>>>(sc->basis[0], sc->basis[1], packed_out + 2 * PACKED_FLOATS);
+  return ego_launch_status("k_pack_basis16");
 }
 
 int ego_app_feature(const ego_scene* sc, const float* c7n, int64_t M, float* out, void* stream) {
@@ -872,7 +972,11 @@ int ego_app_feature(const ego_scene* sc, const float* c7n, int64_t M, float* out
   ShadeArgs a{};
   a.c = make_coords(*sc); a.F = make_field(sc->app); a.packed = sc->packed; a.c7n = c7n; a.out = out; a.M = M; a.S = 1;
   if (sc->mlp_precision == EGO_PREC_F32) k_shade<MODE_APP><<<shade_grid(M), 512, 0, (hipStream_t)stream>>>(a);
-  else k_shade_h<MODE_APP><<<shade_grid(M), 512, 0, (hipStream_t)stream>>>(a);
+  else if (sc->app_f16) {
+    if (int e = check_app16(sc, "app_feature")) return e;
+    a.F = make_field(sc->app16);
+    k_shade_h<MODE_APP, false, true><<<shade_grid(M), 512, 0, (hipStream_t)stream>>>(a);
+  } else k_shade_h<MODE_APP><<<shade_grid(M), 512, 0, (hipStream_t)stream>>>(a);
   return ego_launch_status("k_shade<APP>");
 }
 
@@ -904,7 +1008,11 @@ int ego_shade(const ego_scene* sc, const float* rays, const float* z, const floa
     a.dump_x = dump->x; a.dump_h1 = dump->h1; a.dump_h2 = dump->h2; a.dump_v = dump->v;
     k_shade_h<MODE_SHADE, true><<<shade_grid(a.M), 512, 0, (hipStream_t)stream>>>(a);
   } else if (sc->mlp_precision == EGO_PREC_F32) k_shade<MODE_SHADE><<<shade_grid(a.M), 512, 0, (hipStream_t)stream>>>(a);
-  else k_shade_h<MODE_SHADE><<<shade_grid(a.M), 512, 0, (hipStream_t)stream>>>(a);
+  else if (sc->app_f16) {
+    if (int e = check_app16(sc, "shade")) return e;
+    a.F = make_field(sc->app16);
+    k_shade_h<MODE_SHADE, false, true><<<shade_grid(a.M), 512, 0, (hipStream_t)stream>>>(a);
+  } else k_shade_h<MODE_SHADE><<<shade_grid(a.M), 512, 0, (hipStream_t)stream>>>(a);
   return ego_launch_status("k_shade<SHADE>");
 }
 

@@ -235,6 +235,8 @@ class EgoNeRF(TensorBase):
         self._packed_versions = None
         self._sched_cache = {}
         self._mlp_precision = "f16x3"
+        self._app_table_dtype = "f32"   # "f16": inference gathers appearance taps from a half-precision copy of the tables
+        self._app16 = None              # (versions, [12 half tensors])
         # opt-in skipping (EgoNeRF.forward itself evaluates every sample; see include/egonerf_hip.h):
         self.use_alpha_mask = False          # apply self.alphaMask with TensorBase.forward's semantics (sigma = 0 where empty)
         self.early_termination_eps = 0.0     # > 0: zero the weight of samples behind transmittance < eps
@@ -312,6 +314,41 @@ class EgoNeRF(TensorBase):
         self._mlp_precision = value
         self._scene_cache = None
 
+    @property
+    def app_table_dtype(self) -> str:
+        """Storage of the appearance tables the inference gather reads: "f32" (the parameters themselves) or "f16" (a
+        half-precision shadow copy, refreshed when the parameters change; interpolation stays fp32).  Training always
+        uses the fp32 tables."""
+        return self._app_table_dtype
+
+    @app_table_dtype.setter
+    def app_table_dtype(self, value: str):
+        if value not in ("f32", "f16"):
+            raise ValueError("app_table_dtype must be 'f32' or 'f16'")
+        self._app_table_dtype = value
+        self._scene_cache = None
+
+    def _app_tables(self) -> List[torch.Tensor]:
+        out = []
+        for g in ("yin", "yang"):
+            out += list(getattr(self, f"app_plane_{g}")) + list(getattr(self, f"app_line_{g}"))
+        return out
+
+    def _fill_app16(self, sc):
+        tabs = self._app_tables()
+        ver = tuple((t.data_ptr(), t._version) for t in tabs)
+        if self._app16 is None or self._app16[0] != ver:
+            # [1,H,W,C] channel-last memory of the (1,C,H,W) parameter, converted to half (a cast, done when weights change)
+            self._app16 = (ver, [t.detach().permute(0, 2, 3, 1).contiguous().half() for t in tabs])
+        halves = self._app16[1]
+        sc.app16.n_comp = self.app_n_comp[0]
+        sc.app16.res[:] = self.gridSize.tolist()
+        for gi in range(2):
+            for i in range(3):
+                sc.app16.plane[gi][i] = halves[gi * 6 + i].data_ptr()
+                sc.app16.line[gi][i] = halves[gi * 6 + 3 + i].data_ptr()
+        sc.app_f16 = 1
+
     # -- C-ABI scene ----------------------------------------------------------------------------------------
     def _mlp_tensors(self) -> List[torch.Tensor]:
         m = self.renderModule.mlp
@@ -339,6 +376,8 @@ class EgoNeRF(TensorBase):
             raise RuntimeError(f"model parameters are on {dev}; the EgoNeRF hot path runs only on the HIP device")
         mlp = self._mlp_tensors()
         versions = tuple((t.data_ptr(), t._version) for t in mlp)
+        if self._app_table_dtype == "f16":  # the half copy follows the appearance tables' versions
+            versions += tuple((t.data_ptr(), t._version) for t in self._app_tables())
         keys = tuple(p.data_ptr() for p in self.parameters()) + (None if self.envmap is None else self.envmap.emission.data_ptr(),
                                                                   self.use_alpha_mask, id(self.alphaMask), float(self.early_termination_eps))
         if self._scene_cache is not None and self._scene_cache[0] == keys and self._packed_versions == versions:
@@ -365,6 +404,8 @@ class EgoNeRF(TensorBase):
             self._packed = torch.empty(lib.ego_packed_floats(), device=dev)
         _call("ego_pack_mlp", sc, self._packed.data_ptr(), _lib.stream_handle())
         sc.packed = self._packed.data_ptr()
+        if self._app_table_dtype == "f16":
+            self._fill_app16(sc)
         if self.use_alpha_mask and self.alphaMask is not None:
             self.alphaMask.fill_scene(sc)
         sc.term_eps = float(self.early_termination_eps)

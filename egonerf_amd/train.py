@@ -78,6 +78,9 @@ class RenderFunction(torch.autograd.Function):
         lib, st = _lib.load(), _lib.stream_handle()
         dev = rays.device
         sc = model.scene()
+        if sc.app_f16:  # training gathers from the fp32 parameters (the backward re-gathers from them)
+            sc = _lib.Scene.from_buffer_copy(sc)
+            sc.app_f16 = 0
         if sc.mlp_precision != 0:
             raise NotImplementedError("training uses the f16x3 matrix path (model.mlp_precision = 'f16x3')")
         N = rays.shape[0]

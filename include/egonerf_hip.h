@@ -103,10 +103,17 @@ typedef struct ego_scene {
   const uint8_t* occ;
   int32_t occ_res[3];
   float term_eps;
+  /* Optional half-precision copy of the appearance tables (inference only): same shapes/layout as `app`, elements are
+   * IEEE binary16 (the pointer type is nominal).  app_f16 != 0 makes ego_shade / ego_app_feature gather from it
+   * (halves the bytes through the vector L1; interpolation and everything after stay fp32).  Measured effect on RGB in
+   * DESIGN.md. */
+  ego_vm_field app16;
+  int32_t app_f16;
+  int32_t reserved2;
 } ego_scene;
 
 /* number of floats ego_pack_mlp writes: the packed weight blob used by ego_shade / ego_mlp_fea / ego_app_feature
- * (fp32 fragment layout followed by the fp16-split layout) */
+ * (fp32 fragment layout, the fp16-split layout, then the basis fragments in the K order of the fp16-table gather) */
 int64_t ego_packed_floats(void);
 
 int ego_abi_version(void);

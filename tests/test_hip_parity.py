@@ -57,7 +57,8 @@ def test_device_packer_is_bit_exact(tiny):
     torch.cuda.synchronize()
     blob = model._packed.cpu().numpy()
     assert np.array_equal(blob[:em.PACKED_FLOATS], em.pack_mlp(w))
-    assert np.array_equal(blob[em.PACKED_FLOATS:].view(np.uint32), em.pack_mlp_f16(w).view(np.uint32))
+    assert np.array_equal(blob[em.PACKED_FLOATS:2 * em.PACKED_FLOATS].view(np.uint32), em.pack_mlp_f16(w).view(np.uint32))
+    assert blob.shape[0] == 2 * em.PACKED_FLOATS + 9216  # + basis fragments in the fp16-table K order
 
 
 def test_stage_sample_and_coords(tiny):
@@ -373,3 +374,26 @@ def test_reference_checkpoint_renders_like_the_reference(golden):
         rgb, depth, bg, env, alpha = model(T(fx["rays"]), n_coarse=16, n_fine=16, exp_sampling=True, resampling=True)
     assert maxerr(rgb, fx["rgb"]) <= RGB_TOL and maxerr(depth, fx["depth"]) <= 1e-3 * 15.0
     assert maxerr(bg, fx["bg"]) <= RGB_TOL and maxerr(env, fx["env"]) <= 1e-5 and alpha.shape == fx["alpha"].shape
+
+
+def test_fp16_appearance_tables(full):
+    """Optional half-precision shadow of the appearance tables (inference): parity against the oracle on the fp32 tables
+    (tolerance 1e-4 like every other path), and against the fp32-table render to bound what the storage format costs."""
+    _, cfg, w, model = full
+    if model.mlp_precision != "f16x3":
+        pytest.skip("the fp16-table gather exists in the f16x3 kernel")
+    rays = torch.from_numpy(synth.make_rays(256, seed=4))
+    oracle = make_oracle(cfg, w)
+    try:
+        with torch.no_grad():
+            base = model(rays.to(DEV), n_coarse=128, exp_sampling=True)
+            model.app_table_dtype = "f16"
+            got = model(rays.to(DEV), n_coarse=128, exp_sampling=True)
+            feat16 = model.compute_appfeature(T(np.concatenate([np.random.RandomState(0).uniform(-1, 1, (512, 6)), np.zeros((512, 1))], 1).astype(np.float32)))
+        ref = oracle.forward(rays, n_coarse=128)
+        assert maxerr(got[0], ref[0]) <= RGB_TOL and maxerr(got[1], ref[1]) <= 1e-3 * 23.3
+        assert maxerr(got[0], base[0]) <= 8e-5          # fp16 storage (2^-11 per entry) costs ~5e-5 here: opt-in, not default
+        assert torch.equal(got[4], base[4])             # density path untouched
+        assert bool(torch.isfinite(feat16).all())
+    finally:
+        model.app_table_dtype = "f32"

@@ -11,6 +11,8 @@ cfg = synth.SceneConfig()
 model = make_model(cfg, synth.make_weights(cfg, seed=1234), dev)
 prec = sys.argv[1] if len(sys.argv) > 1 else "f16x3"
 model.mlp_precision = prec
+if len(sys.argv) > 2:
+    model.app_table_dtype = sys.argv[2]  # "f16": half-precision shadow of the appearance tables
 N, S = 4096, 512
 M = N * S
 rays = torch.from_numpy(synth.make_rays(N, seed=1)).to(dev)
