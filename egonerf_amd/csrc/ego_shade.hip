@@ -49,6 +49,15 @@ __host__ __device__ constexpr int slot_row(int r, int h) { return (r & 3) + 8 * 
 // appearance channel (0..143, plane-major) gathered by lane half h as its kk-th product: the halves interleave at
 // 16-byte granularity (half h owns float4 quads 2i+h of a texel), so the two lanes of a sample always read the
 // same 64-byte line in a given load instruction -> half as many L1 tag lookups as a [0,24) / [24,48) split.
+// K order of the f16x3 kernel's gather (gather_team4 below): samples are gathered by 4-lane teams (part p reads quad
+// 4i+p of line i, so a team reads whole 64-byte lines) and transposed into the 2-lanes-per-sample MFMA layout with
+// v_permlane16_swap + v_permlane32_swap.  Lane half h ends up with the parts p = h (first 12 products of a plane) and
+// p = h + 2 (next 12): product kk = plane*24 + half*12 + i*4 + c is channel plane*48 + 16i + 4(h + 2 half) + c.
+__host__ __device__ constexpr int app_channel_g(int kk, int h) {
+  return (kk / APP_HALF) * APP_C + (((kk % APP_HALF) % 12) / 4) * 16 + 4 * (h + 2 * ((kk % APP_HALF) / 12)) + (kk % 4);
+}
+
+// (fp32-MFMA kernel k_shade: lane half h owns float4 quads 2i+h)
 __host__ __device__ constexpr int app_channel(int kk, int h) {
   return (kk / APP_HALF) * APP_C + ((kk % APP_HALF) / 4) * 8 + 4 * h + (kk % 4);
 }
@@ -159,7 +168,7 @@ __global__ void k_pack_mlp_h(const float* __restrict__ w1, const float* __restri
       const int i = lane & 31, h = lane >> 5;
       const int rh = (i >> 2) & 1, r = (i & 3) + 4 * (i >> 3), f = 2 * r + rh;
       if (r < NSLOT && f < APP_DIM) {
-        const int col = app_channel(kk, h);
+        const int col = app_channel_g(kk, h);
         w = (g ? basis_yang : basis_yin)[f * (3 * APP_C) + col];
       }
     }
@@ -609,6 +618,124 @@ __device__ __forceinline__ void gather_basis(const DevField& F, const VMTaps& ta
   basis_step(f1, v2 + 8, keep, fe); basis_step(f2, v2 + 16, keep, fe);
 }
 
+// ---- 4-lane-team gather (fp32 tables, f16x3 kernel) ------------------------------------------------------------------
+// The vector L1 looks up one distinct 64-byte line per cycle, and with two lanes per sample a load instruction touches
+// ~26 distinct lines (PMC: 3270 tag lookups per tile), which - not bytes - bounds the gather.  Here the wave gathers as 16
+// teams of 4 lanes (lane = 16*p + s): part p reads quad 4i+p of line i, so a team reads a whole line per instruction and
+// an instruction touches <= 16 lines.  Two rounds cover the tile's 32 samples (round rd: team s serves sample 16*rd + s);
+// v_permlane16_swap + v_permlane32_swap then move the products into the MFMA layout (lane = 32*h + j): lane half h
+// receives parts p = h and p = h + 2 of its sample, which fixes the K order app_channel_g.
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+struct TeamSample {  // normalised coordinates of the sample this lane's team serves in one round
+  float a_r, a_th, a_ph;
+  int g;
+};
+
+template <int I>
+__device__ __forceinline__ void team_load(const DevField& F, const VMTaps& t, int g, int p, f32x4 raw[18]) {
+  const Lin1 X = t.ax[vm_plane_x(I)], Y = t.ax[vm_plane_y(I)], Ln = t.ax[vm_line_ax(I)];
+  const int W = F.res[vm_plane_x(I)];
+  const float* P = (g ? F.plane[1][I] : F.plane[0][I]) + 4 * p;
+  const float* L = (g ? F.line[1][I] : F.line[0][I]) + 4 * p;
+  const f32x4* p00 = (const f32x4*)(P + (Y.i0 * W + X.i0) * APP_C);
+  const f32x4* p01 = (const f32x4*)(P + (Y.i0 * W + X.i1) * APP_C);
+  const f32x4* p10 = (const f32x4*)(P + (Y.i1 * W + X.i0) * APP_C);
+  const f32x4* p11 = (const f32x4*)(P + (Y.i1 * W + X.i1) * APP_C);
+  const f32x4* l0 = (const f32x4*)(L + Ln.i0 * APP_C);
+  const f32x4* l1 = (const f32x4*)(L + Ln.i1 * APP_C);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {  // quad 4i + p: f32x4 index 4i from the p-shifted base
+    raw[i] = p00[4 * i]; raw[3 + i] = p01[4 * i]; raw[6 + i] = p10[4 * i]; raw[9 + i] = p11[4 * i];
+    raw[12 + i] = l0[4 * i]; raw[15 + i] = l1[4 * i];
+  }
+}
+
+template <int I>
+__device__ __forceinline__ void team_finish(const VMTaps& t, const f32x4 raw[18], float out[12]) {
+#pragma clang fp contract(fast)
+  const Lin1 X = t.ax[vm_plane_x(I)], Y = t.ax[vm_plane_y(I)], Ln = t.ax[vm_line_ax(I)];
+  const float w00 = __fmul_rn(Y.w0, X.w0), w01 = __fmul_rn(Y.w0, X.w1);
+  const float w10 = __fmul_rn(Y.w1, X.w0), w11 = __fmul_rn(Y.w1, X.w1);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const f32x4 pv = raw[i] * w00 + raw[3 + i] * w01 + raw[6 + i] * w10 + raw[9 + i] * w11;
+    const f32x4 lv = raw[12 + i] * Ln.w0 + raw[15 + i] * Ln.w1;
+    const f32x4 m = pv * lv;
+    out[4 * i + 0] = m.x; out[4 * i + 1] = m.y; out[4 * i + 2] = m.z; out[4 * i + 3] = m.w;
+  }
+}
+
+// rows of 16 lanes: (ga rows a0..a3, gb rows b0..b3) -> v[idx] rows [a0 b0 a1 b1], v[12+idx] rows [a2 b2 a3 b3]
+__device__ __forceinline__ void team_to_halves(const float ga[12], const float gb[12], float* v) {
+#pragma unroll
+  for (int idx = 0; idx < 12; ++idx) {
+    const u32x2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(ga[idx]), __float_as_uint(gb[idx]), false, false);
+    const u32x2 q = __builtin_amdgcn_permlane32_swap(r.x, r.y, false, false);
+    v[idx] = __uint_as_float(q.x);
+    v[12 + idx] = __uint_as_float(q.y);
+  }
+}
+
+__device__ __forceinline__ void dump24(float* dst, const float* v) {
+  if (dst) {
+#pragma unroll
+    for (int q = 0; q < 6; ++q) ((f32x4*)dst)[q] = f32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+  }
+}
+
+// whole gather + basis for one tile; ts[rd] = the sample this lane's team serves in round rd.  All 64 lanes must call
+// (cross-lane swaps).
+__device__ __forceinline__ void basis3(const u32x4* __restrict__ BASH, int lane, int step0, int gsel, bool keep, const float* v,
+                                       f32x16& fe) {
+  BasisFrag f0, f1, f2;
+  if (step0 == 0) { f0 = basis_frag<0>(BASH, lane, gsel); f1 = basis_frag<1>(BASH, lane, gsel); f2 = basis_frag<2>(BASH, lane, gsel); }
+  else if (step0 == 3) { f0 = basis_frag<3>(BASH, lane, gsel); f1 = basis_frag<4>(BASH, lane, gsel); f2 = basis_frag<5>(BASH, lane, gsel); }
+  else { f0 = basis_frag<6>(BASH, lane, gsel); f1 = basis_frag<7>(BASH, lane, gsel); f2 = basis_frag<8>(BASH, lane, gsel); }
+  basis_step(f0, v, keep, fe); basis_step(f1, v + 8, keep, fe); basis_step(f2, v + 16, keep, fe);
+}
+
+__device__ __forceinline__ void gather_basis_team(const DevField& F, const TeamSample ts[2], const u32x4* __restrict__ BASH, int lane,
+                                                  int g, bool mixed, int gu, f32x16& fe, float* vdump) {
+  const int p = lane >> 4;
+  const int g0 = mixed ? 0 : gu;            // weight set of the first pass
+  const bool keep0 = !mixed || g == 0;      // a mixed wave keeps only its yin lanes in the first pass
+  const VMTaps tA = vm_setup(ts[0].a_r, ts[0].a_th, ts[0].a_ph, F.res), tB = vm_setup(ts[1].a_r, ts[1].a_th, ts[1].a_ph, F.res);
+  // one 18-load buffer in flight (72 VGPRs); the next plane's first round is issued right before the MFMAs of the
+  // previous plane so that they overlap; the co-resident wave and the MLP phase hide the rest
+  f32x4 raw[18];
+  float ga[12], gb[12], v[24];
+  team_load<0>(F, tA, ts[0].g, p, raw);
+  team_finish<0>(tA, raw, ga);
+  __builtin_amdgcn_sched_barrier(0);
+  team_load<0>(F, tB, ts[1].g, p, raw);
+  team_finish<0>(tB, raw, gb);
+  team_to_halves(ga, gb, v);
+  dump24(vdump, v);
+  __builtin_amdgcn_sched_barrier(0);
+  team_load<1>(F, tA, ts[0].g, p, raw);
+  basis3(BASH, lane, 0, g0, keep0, v, fe);
+  if (mixed) basis3(BASH, lane, 0, 1, g != 0, v, fe);
+  team_finish<1>(tA, raw, ga);
+  __builtin_amdgcn_sched_barrier(0);
+  team_load<1>(F, tB, ts[1].g, p, raw);
+  team_finish<1>(tB, raw, gb);
+  team_to_halves(ga, gb, v);
+  dump24(vdump ? vdump + 24 : nullptr, v);
+  __builtin_amdgcn_sched_barrier(0);
+  team_load<2>(F, tA, ts[0].g, p, raw);
+  basis3(BASH, lane, 3, g0, keep0, v, fe);
+  if (mixed) basis3(BASH, lane, 3, 1, g != 0, v, fe);
+  team_finish<2>(tA, raw, ga);
+  __builtin_amdgcn_sched_barrier(0);
+  team_load<2>(F, tB, ts[1].g, p, raw);
+  team_finish<2>(tB, raw, gb);
+  team_to_halves(ga, gb, v);
+  dump24(vdump ? vdump + 48 : nullptr, v);
+  basis3(BASH, lane, 6, g0, keep0, v, fe);
+  if (mixed) basis3(BASH, lane, 6, 1, g != 0, v, fe);
+}
+
 // ---- half-precision appearance tables (ego_scene.app_f16) --------------------------------------------------------
 // Same [H][W][48] channel-last layout with IEEE half elements (96 B per texel).  Lane half h owns the 16-byte chunks
 // 2i+h (8 channels each), so one plane is 18 loads per lane and yields 24 products: one plane per pipeline stage, three
@@ -730,17 +857,37 @@ __global__ __launch_bounds__(512) void k_shade_h(ShadeArgs A) {
       // per plane: two half-stages of 18 loads (12 products each); 3 basis k-steps of 8 products.  Loads of the
       // next half-stage are issued before the MFMAs of the previous one; sched_barriers bound the hoisting.
       // Waves whose 32 samples all lie in one grid (the common case) take the path without per-value masking.
-      if (!mixed) {
-        // lw / hw (opaque copies of lane / lane half) keep the per-table base pointers from being hoisted out of
-        // the tile loop, where 24 64-bit loop invariants would spill
-        if (TAB16) gather_basis_f16<false>(A.F, taps, BASH, lw, g, hw, gu, true, fe);
-        else gather_basis<false>(A.F, taps, BASH, lw, g, hw, gu, true, fe, (DUMP && valid) ? A.dump_v + m * 144 + hw * 72 : nullptr);
-      } else if (TAB16) {
-        gather_basis_f16<true>(A.F, taps, BASH, lw, g, hw, 0, g == 0, fe);
-        gather_basis_f16<true>(A.F, taps, BASH, lw, g, hw, 1, g != 0, fe);
+      // lw / hw (opaque copies of lane / lane half) keep the per-table base pointers from being hoisted out of the tile
+      // loop, where 24 64-bit loop invariants would spill.  Waves whose 32 samples all lie in one grid (the common case)
+      // take the path without per-value masking; border-straddling waves run both weight sets masked.
+      if (TAB16) {
+        if (!mixed) {
+          gather_basis_f16<false>(A.F, taps, BASH, lw, g, hw, gu, true, fe);
+        } else {
+          gather_basis_f16<true>(A.F, taps, BASH, lw, g, hw, 0, g == 0, fe);
+          gather_basis_f16<true>(A.F, taps, BASH, lw, g, hw, 1, g != 0, fe);
+        }
       } else {
-        gather_basis<true>(A.F, taps, BASH, lw, g, hw, 0, g == 0, fe, (DUMP && valid) ? A.dump_v + m * 144 + hw * 72 : nullptr);
-        gather_basis<true>(A.F, taps, BASH, lw, g, hw, 1, g != 0, fe);
+        // team gather: in round rd this lane's 4-lane team serves sample 16*rd + (lane & 15) of the tile
+        TeamSample ts[2];
+#pragma unroll
+        for (int rd = 0; rd < 2; ++rd) {
+          const int64_t mt_raw = tile * 32 + 16 * rd + (lw & 15);
+          const int64_t mt = mt_raw < A.M ? mt_raw : A.M - 1;
+          if (MODE == MODE_APP) {
+            const float* p = A.c7n + mt * 7;
+            ts[rd].g = (p[6] == 0.f) ? 0 : 1;
+            const int b = ts[rd].g ? 3 : 0;
+            ts[rd].a_r = p[b]; ts[rd].a_th = p[b + 1]; ts[rd].a_ph = p[b + 2];
+          } else {
+            const f32x4 c4 = ((const f32x4*)A.coords)[mt];
+            ts[rd].a_r = c4.x; ts[rd].a_th = c4.y; ts[rd].a_ph = c4.z; ts[rd].g = c4.w != 0.f;
+          }
+        }
+        float* vd = (DUMP && valid) ? A.dump_v + m * 144 + hw * 72 : nullptr;
+        // one gather per tile; a border-straddling wave runs the basis steps of each plane twice (yin weights with the
+        // yang lanes zeroed, then the reverse) inside gather_basis_team
+        gather_basis_team(A.F, ts, BASH, lw, g, mixed, gu, fe, vd);
       }
     }
 
@@ -1056,7 +1203,7 @@ int ego_train_layout(int32_t which, int32_t* out, int32_t n) {
   } else if (which == 3) {  // v dump column -> basis input column (0..143)
     EGO_REQUIRE(n == 2 * KS_BASIS, "train_layout(3): n must be 144");
     for (int h = 0; h < 2; ++h)
-      for (int kk = 0; kk < KS_BASIS; ++kk) out[h * KS_BASIS + kk] = app_channel(kk, h);
+      for (int kk = 0; kk < KS_BASIS; ++kk) out[h * KS_BASIS + kk] = app_channel_g(kk, h);
   } else {
     return ego_fail(EGO_E_BADARG, "train_layout: which must be 0..3");
   }

@@ -169,8 +169,24 @@ def pack_mlp_f16(w):
 
     out[OFF_W1:OFF_W2] = region(f32[OFF_W1:OFF_W2], KS1 // 8, 4)
     out[OFF_W2:OFF_B1] = region(f32[OFF_W2:OFF_B1], KS2 // 8, 4)
-    bas = f32[OFF_BASIS:].reshape(2, KS_BASIS // 4, 64, 4)
+    # basis fragments of the f16x3 kernel follow the team-gather K order (app_channel_g), not the fp32 kernel's
+    bas = np.zeros((2, KS_BASIS // 4, 64, 4), np.float32)
+    for g, key in enumerate(("basis_mat_yin.weight", "basis_mat_yang.weight")):
+        for lane in range(64):
+            i, h = lane & 31, lane >> 5
+            rh, r = (i >> 2) & 1, (i & 3) + 4 * (i >> 3)
+            f = 2 * r + rh
+            if r < NSLOT and f < APP_DIM:
+                for kk in range(KS_BASIS):
+                    bas[g, kk // 4, lane, kk % 4] = w[key][f, app_channel_g(kk, h)]
     for g in range(2):
         n = (KS_BASIS // 8) * 2 * 64 * 8 // 2
         out[OFF_BASIS + g * n: OFF_BASIS + (g + 1) * n] = region(bas[g].reshape(KS_BASIS // 4, 1, 64, 4), KS_BASIS // 8, 1)
     return out
+
+
+def app_channel_g(kk, h):
+    """K order of the f16x3 kernel's 4-lane-team gather: product kk = plane*24 + half*12 + i*4 + c of lane half h is
+    channel plane*48 + 16 i + 4 (h + 2 half) + c."""
+    within = kk % APP_HALF
+    return (kk // APP_HALF) * APP_C + ((within % 12) // 4) * 16 + 4 * (h + 2 * (within // 12)) + kk % 4
