@@ -49,6 +49,11 @@ class VmGrad(C.Structure):
     _fields_ = [("plane", (C.c_void_p * 3) * 2), ("line", (C.c_void_p * 3) * 2)]
 
 
+class AdamTensor(C.Structure):
+    _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p), ("n", C.c_int64),
+                ("lr", C.c_float), ("reserved", C.c_int32)]
+
+
 class ShadeDump(C.Structure):
     _fields_ = [("x", C.c_void_p), ("h1", C.c_void_p), ("h2", C.c_void_p), ("v", C.c_void_p)]
 
@@ -82,8 +87,15 @@ PROTOTYPES = {
     "ego_train_packed_floats": (I64, []),
     "ego_pack_train": (C.c_int, [SP, P, P]),
     "ego_train_layout": (C.c_int, [I32, C.POINTER(C.c_int32), I32]),
-    "ego_march_backward": (C.c_int, [SP, C.POINTER(VmGrad), P, P, P, P, P, P, P, P, P, P, I64, I32, P, P]),
+    "ego_march_backward": (C.c_int, [SP, C.POINTER(VmGrad), P, P, P, I32, P, P, P, P, P, P, P, P, I64, I32, P, P]),
+    "ego_envmap_backward": (C.c_int, [SP, P, I32, P, P, P, P, I64, P, P]),
     "ego_shade_backward": (C.c_int, [SP, P, C.POINTER(VmGrad), P, P, P, C.POINTER(ShadeDump), P, P, P, I64, I32, P]),
+    "ego_tv_plane": (C.c_int, [P, I32, I32, I32, F32, P, P, P]),
+    "ego_l1_table": (C.c_int, [P, I64, F32, P, P, P]),
+    "ego_line_ortho": (C.c_int, [P, I32, I32, F32, P, P, P]),
+    "ego_ray_entropy": (C.c_int, [P, I64, I32, I32, P, P, P]),
+    "ego_resample_table": (C.c_int, [P, I32, I32, I32, P, P, I32, I32, P, P]),
+    "ego_adam_step": (C.c_int, [C.POINTER(AdamTensor), I32, F32, F32, F32, I32, P]),
     "ego_render_workspace_bytes": (I64, [I64, C.POINTER(RenderArgs)]),
     "ego_render_forward": (C.c_int, [SP, C.POINTER(RenderArgs), P, I64, P, P, P, P, P, P, P]),
 }
@@ -109,7 +121,7 @@ def load() -> C.CDLL:
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)
         fn.restype, fn.argtypes = res, args
-    for which, struct in ((0, Scene), (1, RenderArgs), (2, VmField)):
+    for which, struct in ((0, Scene), (1, RenderArgs), (2, VmField), (3, AdamTensor)):
         if lib.ego_sizeof(which) != C.sizeof(struct):
             raise RuntimeError(f"ABI mismatch: struct {struct.__name__} is {C.sizeof(struct)} B here, "
                                f"{lib.ego_sizeof(which)} B in {LIB}")

@@ -107,6 +107,40 @@ class YinYangSphericalCoords:
         ratio = exp(log((far - near) / self.r0) / (n_samples - 1))
         return linearised_exp_grid(self.r0, ratio, n_samples)
 
+    def upsample_axis_positions(self, res_target, axis: int) -> torch.Tensor:
+        """Normalised [-1, 1] positions, on the CURRENT grid, of the samples of a `res_target` grid along `axis`
+        (coordinates.py:226-266 for r: the new shell radii located in the old LUT; :27-39 for the angles: linspace)."""
+        n = int(res_target[axis])
+        if axis != 0:
+            return torch.linspace(-1, 1, n)
+        self._require_supported()
+        ratio = pow(self.far[0] / self.r0, 1 / (n - 1))  # coordinates.py:238 (0-dim tensor pow)
+        new = linearised_exp_grid(self.r0, ratio, n)
+        G = self.reference_r_grid()
+        k_out = torch.clamp(torch.searchsorted(G, new, right=True), 1, G.shape[0] - 1)
+        k_in = k_out - 1
+        r01 = (k_in + (new - G[k_in]) / (G[k_out] - G[k_in])) / self.N_r  # normalize_r, coordinates.py:125-131
+        return r01 * 2 - 1
+
+    def up_sampling_VM(self, weights: torch.Tensor, res_target, ids):
+        """coordinates.py:226-266: `weights` (1, C, H, W) channel-last table; ids = [axis of H, axis of W] (plane) or
+        [axis] (line) -> resampled channel-last nn.Parameter."""
+        from . import _lib
+        assert len(ids) in (1, 2), "ids should be 1 or 2!"
+        if not weights.is_cuda:
+            raise RuntimeError("up_sampling_VM: needs a HIP device tensor (the EgoNeRF path has no CPU fallback)")
+        _, C_, H, W = weights.shape
+        src = weights.detach()
+        if not src.permute(0, 2, 3, 1).is_contiguous():
+            src = src.contiguous(memory_format=torch.channels_last)
+        dev = weights.device
+        ys = self.upsample_axis_positions(res_target, ids[0]).to(dev, torch.float32).contiguous()
+        xs = (self.upsample_axis_positions(res_target, ids[1]) if len(ids) == 2 else -torch.ones(1)).to(dev, torch.float32).contiguous()
+        dst = torch.empty(1, ys.numel(), xs.numel(), C_, device=dev)
+        _lib.check(_lib.load().ego_resample_table(src.data_ptr(), C_, H, W, xs.data_ptr(), ys.data_ptr(), ys.numel(), xs.numel(),
+                                                  dst.data_ptr(), _lib.stream_handle()), "ego_resample_table")
+        return torch.nn.Parameter(dst.permute(0, 3, 1, 2))
+
     def _require_supported(self):
         if not (self.exp_r and self.interval_th):
             raise NotImplementedError("the HIP path covers exp_r + interval_th coordinates (every shipped EgoNeRF config); "

@@ -281,6 +281,35 @@ __global__ void k_envmap(const float* __restrict__ em, int h, const float* __res
   out[i * 3] = o[0]; out[i * 3 + 1] = o[1]; out[i * 3 + 2] = o[2];
 }
 
+// backward of bg_weight * sigmoid(bilinear(emission)) into d(emission); thread per ray, 12 float atomics
+__global__ void k_envmap_bwd(int h, const float* __restrict__ dirs, int dstride, const float* __restrict__ g_rgb,
+                             const float* __restrict__ rgb_raw, const float* __restrict__ bgw,
+                             const float* __restrict__ env_map, int64_t N, float* __restrict__ g_em) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const float dx = dirs[i * dstride], dy = dirs[i * dstride + 1], dz = dirs[i * dstride + 2];
+  const float nrm = fmaxf(__fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz))), 1e-12f);
+  const float nx = __fdiv_rn(dx, nrm), ny = __fdiv_rn(dy, nrm), nz = __fdiv_rn(dz, nrm);
+  const float u = __fmul_rn(__fadd_rn(nz, 1.f), 0.5f);
+  const float v = __fdiv_rn(__fadd_rn(atan2f(ny, nx), 3.14159265358979323846f), 6.28318530717958647692f);
+  const Lin1 X = lin_setup(__fsub_rn(__fmul_rn(u, 2.f), 1.f), h);
+  const Lin1 Y = lin_setup(__fsub_rn(__fmul_rn(v, 2.f), 1.f), 2 * h);
+  const float b = bgw[i];
+#pragma unroll
+  for (int ch = 0; ch < 3; ++ch) {
+    const float raw = rgb_raw[i * 3 + ch];
+    const float g = (raw >= 0.f && raw <= 1.f) ? g_rgb[i * 3 + ch] : 0.f;  // clamp(0,1) backward
+    const float e = env_map[i * 3 + ch];
+    const float ge = g * b * e * (1.f - e);
+    if (ge == 0.f) continue;
+    float* E = g_em + (int64_t)ch * 2 * h * h;
+    unsafeAtomicAdd(E + (int64_t)Y.i0 * h + X.i0, ge * Y.w0 * X.w0);
+    unsafeAtomicAdd(E + (int64_t)Y.i0 * h + X.i1, ge * Y.w0 * X.w1);
+    unsafeAtomicAdd(E + (int64_t)Y.i1 * h + X.i0, ge * Y.w1 * X.w0);
+    unsafeAtomicAdd(E + (int64_t)Y.i1 * h + X.i1, ge * Y.w1 * X.w1);
+  }
+}
+
 // =============================================================================================
 // Row H — compositing, one wave per ray      models/EgoNeRF.py:579-598
 // =============================================================================================
@@ -563,6 +592,16 @@ int ego_envmap_radiance(const ego_scene* sc, const float* dirs, int64_t N, float
   EGO_REQUIRE(sc && dirs && out && sc->envmap && sc->envmap_h >= 2, "envmap_radiance: no envmap / null argument");
   k_envmap<<<nblk(N, 256), 256, 0, (hipStream_t)stream>>>(sc->envmap, sc->envmap_h, dirs, N, out);
   return ego_launch_status("k_envmap");
+}
+
+int ego_envmap_backward(const ego_scene* sc, const float* dirs, int32_t dir_stride, const float* g_rgb, const float* rgb_raw, const float* bg_weight,
+                        const float* env_map, int64_t N, float* g_emission, void* stream) {
+  EGO_REQUIRE(N >= 0, "envmap_backward: N < 0");
+  if (N == 0) return EGO_OK;
+  EGO_REQUIRE(sc && dirs && dir_stride >= 3 && g_rgb && rgb_raw && bg_weight && env_map && g_emission && sc->envmap_h >= 2,
+              "envmap_backward: no envmap / null argument");
+  k_envmap_bwd<<<nblk(N, 256), 256, 0, (hipStream_t)stream>>>(sc->envmap_h, dirs, dir_stride, g_rgb, rgb_raw, bg_weight, env_map, N, g_emission);
+  return ego_launch_status("k_envmap_bwd");
 }
 
 int ego_alpha_mask_sample(const ego_scene* sc, const float* c7n, int64_t M, float* out, void* stream) {

@@ -1226,9 +1226,10 @@ static int check_grad(const ego_vm_grad* g, const char* who) {
 }
 
 int ego_march_backward(const ego_scene* sc, const ego_vm_grad* gdensity, const float* coords, const float* z, const float* alpha,
-                       const float* weight, const float* sigma, const float* bg_weight, const float* rgb, const float* g_rgb,
-                       const float* rgb_raw, const float* env_map, int64_t N, int32_t S, float* dc, void* stream) {
-  EGO_REQUIRE(N >= 0 && S >= 2, "march_backward: bad size");
+                       int32_t alpha_stride, const float* weight, const float* sigma, const float* bg_weight, const float* rgb,
+                       const float* g_rgb, const float* g_alpha, const float* rgb_raw, const float* env_map, int64_t N, int32_t S,
+                       float* dc, void* stream) {
+  EGO_REQUIRE(N >= 0 && S >= 2 && alpha_stride >= S, "march_backward: bad size");
   if (N == 0) return EGO_OK;
   EGO_REQUIRE(sc && coords && z && alpha && weight && sigma && bg_weight && rgb && g_rgb && rgb_raw && dc, "march_backward: null argument");
   if (int e = check_grad(gdensity, "march_backward")) return e;
@@ -1236,7 +1237,8 @@ int ego_march_backward(const ego_scene* sc, const ego_vm_grad* gdensity, const f
   if (!sc->act_softplus) return ego_fail(EGO_E_UNSUPPORTED, "march_backward: only the softplus density activation is supported");
   MarchBwdArgs a{};
   a.F = make_field(sc->density); a.G = make_grad(*gdensity);
-  a.coords = coords; a.z = z; a.alpha = alpha; a.weight = weight; a.sigma = sigma; a.bg = bg_weight; a.rgb = rgb; a.g_rgb = g_rgb;
+  a.coords = coords; a.z = z; a.alpha = alpha; a.g_alpha = g_alpha; a.astride = alpha_stride; a.weight = weight; a.sigma = sigma;
+  a.bg = bg_weight; a.rgb = rgb; a.g_rgb = g_rgb;
   a.rgb_raw = rgb_raw; a.env = env_map; a.dc = dc; a.N = N; a.S = S; a.dscale = sc->distance_scale;
   k_march_bwd<16><<<(unsigned)((N + 3) / 4), 256, 0, (hipStream_t)stream>>>(a);
   return ego_launch_status("k_march_bwd");

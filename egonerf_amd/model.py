@@ -83,6 +83,9 @@ class EnvironmentMap:
     def get_radiance(self, direction: torch.Tensor) -> torch.Tensor:
         _require_cuda(direction, "EnvironmentMap.get_radiance")
         d = _f32c(direction)
+        if torch.is_grad_enabled() and self.emission.requires_grad:  # envmap pre-training (train.py:218-236)
+            from .train import EnvRadianceFunction
+            return EnvRadianceFunction.apply(self.emission, d)
         out = torch.empty(d.shape[0], 3, device=d.device)
         sc = _lib.Scene()
         em = self.emission.detach().contiguous()
@@ -284,6 +287,61 @@ class EgoNeRF(TensorBase):
             gv += [{"params": self.envmap.emission, "lr": lr_init_envmap}]
         return gv
 
+    # -- regularisers (train.py:289-304) ----------------------------------------------------------------------
+    def vectorDiffs(self, vector_comps):
+        """EgoNeRF.py:189-196: sum over line tables of mean |off-diagonal of the component Gram matrix|."""
+        from .losses import table_regulariser
+        return table_regulariser("ortho", list(vector_comps), [1.0] * len(vector_comps))
+
+    def vector_comp_diffs(self):
+        """EgoNeRF.py:198-199."""
+        from .losses import table_regulariser
+        lines = (list(self.density_line_yin) + list(self.app_line_yin) + list(self.density_line_yang) + list(self.app_line_yang))
+        return table_regulariser("ortho", lines, [1.0] * len(lines))
+
+    def density_L1(self):
+        """EgoNeRF.py:206-212."""
+        from .losses import table_regulariser
+        t = []
+        for i in range(len(self.density_plane_yin)):
+            t += [self.density_plane_yin[i], self.density_line_yin[i], self.density_plane_yang[i], self.density_line_yang[i]]
+        return table_regulariser("l1", t, [1.0] * len(t))
+
+    def _tv(self, reg, planes):
+        from .losses import table_regulariser
+        w = float(getattr(reg, "TVLoss_weight", 1.0))
+        return table_regulariser("tv", planes, [1e-2 * w] * len(planes))
+
+    def TV_loss_density(self, reg):
+        """EgoNeRF.py:214-220: planes only, 1e-2 each; `reg` is a TVLoss (its weight is honoured, its forward is fused here)."""
+        return self._tv(reg, [p for i in range(3) for p in (self.density_plane_yin[i], self.density_plane_yang[i])])
+
+    def TV_loss_app(self, reg):
+        """EgoNeRF.py:222-228."""
+        return self._tv(reg, [p for i in range(3) for p in (self.app_plane_yin[i], self.app_plane_yang[i])])
+
+    # -- coarse-to-fine upsampling (train.py:371-385) -------------------------------------------------------------
+    @torch.no_grad()
+    def up_sampling_VM(self, plane_coef, line_coef, res_target):
+        """EgoNeRF.py:415-426."""
+        for i in range(3):
+            m0, m1 = MAT_MODE[i]
+            plane_coef[i] = self.coordinates.up_sampling_VM(plane_coef[i].data, res_target=res_target, ids=[m1, m0])
+            line_coef[i] = self.coordinates.up_sampling_VM(line_coef[i].data, res_target=res_target, ids=[VEC_MODE[i]])
+        return plane_coef, line_coef
+
+    @torch.no_grad()
+    def upsample_volume_grid(self, res_target):
+        """EgoNeRF.py:428-435.  The caller then calls coordinates.set_resolution(res_target) (train.py:376-377; note that
+        call resets r0 to 0.05 unless r0 is passed) and rebuilds the optimiser."""
+        self.app_plane_yin, self.app_line_yin = self.up_sampling_VM(self.app_plane_yin, self.app_line_yin, res_target)
+        self.density_plane_yin, self.density_line_yin = self.up_sampling_VM(self.density_plane_yin, self.density_line_yin, res_target)
+        self.app_plane_yang, self.app_line_yang = self.up_sampling_VM(self.app_plane_yang, self.app_line_yang, res_target)
+        self.density_plane_yang, self.density_line_yang = self.up_sampling_VM(self.density_plane_yang, self.density_line_yang, res_target)
+        self.update_stepSize(res_target)
+        self._scene_cache = None
+        print(f"upsamping to {res_target}")
+
     @torch.no_grad()
     def update_coarse_sigma_grid(self):
         """2x average-pooled density tables (EgoNeRF.py:124-133), kept channel-last."""
@@ -379,7 +437,8 @@ class EgoNeRF(TensorBase):
         if self._app_table_dtype == "f16":  # the half copy follows the appearance tables' versions
             versions += tuple((t.data_ptr(), t._version) for t in self._app_tables())
         keys = tuple(p.data_ptr() for p in self.parameters()) + (None if self.envmap is None else self.envmap.emission.data_ptr(),
-                                                                  self.use_alpha_mask, id(self.alphaMask), float(self.early_termination_eps))
+                                                                  self.use_alpha_mask, id(self.alphaMask), float(self.early_termination_eps),
+                                                                  self.coordinates.N_r, float(self.coordinates.r0))
         if self._scene_cache is not None and self._scene_cache[0] == keys and self._packed_versions == versions:
             return self._scene_cache[1]
         lib = _lib.load()
@@ -420,7 +479,7 @@ class EgoNeRF(TensorBase):
 
     # -- stage methods (reference public API) ----------------------------------------------------------------
     def _sched(self, n_samples: int, device) -> torch.Tensor:
-        key = (n_samples, str(device))
+        key = (n_samples, str(device), float(self.coordinates.r0))  # set_resolution() may move r0 (coordinates.py:214)
         if key not in self._sched_cache:
             near, far = self.near_far
             self._sched_cache[key] = self.coordinates.sample_schedule(near, far, n_samples).to(device)

@@ -1,0 +1,54 @@
+"""Multi-tensor Adam over `ego_adam_step` — a drop-in for the reference's `torch.optim.Adam(grad_vars, betas=(0.9, 0.99))`
+(train.py:182,186): same parameter groups (model.get_optparam_groups), same update rule, and `param_groups[i]["lr"]` stays
+writable so train.py:328-329's per-step exponential decay reads unchanged.  One launch updates all 33 tensors."""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+
+class FusedAdam(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        if not 0.0 <= betas[0] < 1.0 or not 0.0 <= betas[1] < 1.0 or eps <= 0:
+            raise ValueError("FusedAdam: bad betas / eps")
+        super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps))
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        lib, st = _lib.load(), _lib.stream_handle()
+        batches = {}  # (beta1, beta2, eps, step) -> [AdamTensor]
+        keep = []
+        for group in self.param_groups:
+            b1, b2 = group["betas"]
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                if not p.is_cuda:
+                    raise RuntimeError("FusedAdam: needs HIP device parameters (the EgoNeRF path has no CPU fallback)")
+                state = self.state[p]
+                if not state:
+                    state["step"] = 0
+                    state["exp_avg"] = torch.zeros_like(p)      # zeros_like keeps the parameter's (channel-last) strides
+                    state["exp_avg_sq"] = torch.zeros_like(p)
+                state["step"] += 1
+                g = p.grad
+                if g.stride() != p.stride() or g.dtype != torch.float32:
+                    g = torch.empty_like(p).copy_(g)
+                    keep.append(g)
+                if p.dtype != torch.float32 or not p.permute(*sorted(range(p.dim()), key=lambda d: -p.stride(d))).is_contiguous():
+                    raise RuntimeError("FusedAdam: parameters must be dense float32")
+                t = _lib.AdamTensor(p.data_ptr(), g.data_ptr(), state["exp_avg"].data_ptr(), state["exp_avg_sq"].data_ptr(), p.numel(),
+                                    float(group["lr"]), 0)
+                batches.setdefault((float(b1), float(b2), float(group["eps"]), state["step"]), []).append(t)
+                torch.autograd.graph.increment_version(p)  # written through a raw pointer: keep autograd / caches honest
+        for (b1, b2, eps, step), ts in batches.items():
+            arr = (_lib.AdamTensor * len(ts))(*ts)
+            _lib.check(lib.ego_adam_step(arr, len(ts), b1, b2, eps, step, st), "ego_adam_step")
+        return loss

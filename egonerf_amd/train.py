@@ -75,7 +75,9 @@ def differentiable_params(model) -> List[torch.nn.Parameter]:
 class RenderFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, rays, opts, *params):
+        """params = differentiable_params(model) (+ envmap.emission last when the model has an envmap)."""
         lib, st = _lib.load(), _lib.stream_handle()
+        ctx.set_materialize_grads(False)
         dev = rays.device
         sc = model.scene()
         if sc.app_f16:  # training gathers from the fp32 parameters (the backward re-gathers from them)
@@ -120,21 +122,26 @@ class RenderFunction(torch.autograd.Function):
                                      rgb_map.data_ptr(), depth.data_ptr(), _lib.ptr(bg_map), _lib.ptr(env_map), raw.data_ptr(), st),
                    "ego_composite")
         ctx.model, ctx.N, ctx.S = model, N, S
-        ctx.saved = dict(z=z, alpha=alpha, weight=weight, sigma=sigma, bg=bg, coords=coords, rgb=rgb, raw=raw, env=env_map, **dump)
-        ctx.mark_non_differentiable(depth, alpha)
+        ctx.saved = dict(z=z, alpha=alpha, weight=weight, sigma=sigma, bg=bg, coords=coords, rgb=rgb, raw=raw, env=env_map, rays=rays,
+                         **dump)
+        ctx.mark_non_differentiable(depth)  # computed under no_grad in the reference (EgoNeRF.py:595-598)
         if has_env:
             ctx.mark_non_differentiable(bg_map, env_map)
             return rgb_map, depth, alpha, bg_map, env_map
         return rgb_map, depth, alpha
 
     @staticmethod
-    def backward(ctx, g_rgb, *_unused):
+    def backward(ctx, g_rgb, _g_depth=None, g_alpha=None, *_unused):
         lib, st = _lib.load(), _lib.stream_handle()
         model, N, S, sv = ctx.model, ctx.N, ctx.S, ctx.saved
-        dev = g_rgb.device
+        dev = sv["z"].device
         M = N * S
         sc = model.scene()
-        g_rgb = g_rgb.contiguous().float()
+        g_rgb = torch.zeros(N, 3, device=dev) if g_rgb is None else g_rgb.contiguous().float()
+        astride = sv["alpha"].shape[1]
+        if g_alpha is not None:  # ray_entropy_loss (train.py:306-309); the envmap's ones column takes no gradient
+            g_alpha = g_alpha.contiguous().float()
+            assert g_alpha.shape == sv["alpha"].shape
         dens, app = table_params(model, "density"), table_params(model, "app")
         g_dens = [torch.zeros_like(p) for p in dens]  # zeros_like keeps the channel-last strides of the parameter
         g_app = [torch.zeros_like(p) for p in app]
@@ -143,11 +150,10 @@ class RenderFunction(torch.autograd.Function):
         f = lambda *shape: torch.empty(*shape, device=dev, dtype=torch.float32)
         dc = f(N, S, 3)
         gd = _grad_struct(g_dens)
-        _lib.check(lib.ego_march_backward(sc, C.byref(gd), sv["coords"].data_ptr(), sv["z"].data_ptr(), sv["alpha"].data_ptr()
-                                          if sv["alpha"].shape[1] == S else sv["alpha"][:, :S].contiguous().data_ptr(),
+        _lib.check(lib.ego_march_backward(sc, C.byref(gd), sv["coords"].data_ptr(), sv["z"].data_ptr(), sv["alpha"].data_ptr(), astride,
                                           sv["weight"].data_ptr(), sv["sigma"].data_ptr(), sv["bg"].data_ptr(), sv["rgb"].data_ptr(),
-                                          g_rgb.data_ptr(), sv["raw"].data_ptr(), _lib.ptr(sv["env"]), N, S, dc.data_ptr(), st),
-                   "ego_march_backward")
+                                          g_rgb.data_ptr(), _lib.ptr(g_alpha), sv["raw"].data_ptr(), _lib.ptr(sv["env"]), N, S,
+                                          dc.data_ptr(), st), "ego_march_backward")
         tp = f(lib.ego_train_packed_floats())
         _lib.check(lib.ego_pack_train(sc, tp.data_ptr(), st), "ego_pack_train")
         dh2, dh1, dfe = f(M, 128), f(M, 128), f(M, 64)
@@ -183,8 +189,42 @@ class RenderFunction(torch.autograd.Function):
             gb[fmap[fv][:, None], vmap[None, :]] = Gb[fv]
             gbasis.append(gb)
         grads = g_dens + g_app + gbasis + [gw1, gb1, gw2, gb2, gw3, gb3]
+        if sv["env"] is not None:
+            g_em = torch.zeros_like(model.envmap.emission)
+            rays = sv["rays"]
+            _lib.check(lib.ego_envmap_backward(sc, rays.data_ptr() + 12, 6, g_rgb.data_ptr(), sv["raw"].data_ptr(), sv["bg"].data_ptr(),
+                                               sv["env"].data_ptr(), N, g_em.data_ptr(), st), "ego_envmap_backward")
+            grads.append(g_em)
         ctx.saved = None
         return (None, None, None, *grads)
+
+
+class EnvRadianceFunction(torch.autograd.Function):
+    """EnvironmentMap.get_radiance with a gradient to `emission` (the reference's envmap pre-training, train.py:218-236)."""
+
+    @staticmethod
+    def forward(ctx, emission, dirs):
+        lib, st = _lib.load(), _lib.stream_handle()
+        sc = _lib.Scene()
+        sc.envmap, sc.envmap_h = emission.data_ptr(), emission.shape[2]
+        out = torch.empty(dirs.shape[0], 3, device=dirs.device)
+        _lib.check(lib.ego_envmap_radiance(sc, dirs.data_ptr(), dirs.shape[0], out.data_ptr(), st), "ego_envmap_radiance")
+        ctx.save_for_backward(dirs, out)
+        ctx.shape = emission.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib, st = _lib.load(), _lib.stream_handle()
+        dirs, out = ctx.saved_tensors
+        N = dirs.shape[0]
+        sc = _lib.Scene()
+        sc.envmap_h = ctx.shape[2]
+        g_em = torch.zeros(ctx.shape, device=dirs.device)
+        ones, inside = torch.ones(N, device=dirs.device), torch.zeros(N, 3, device=dirs.device)
+        _lib.check(lib.ego_envmap_backward(sc, dirs.data_ptr(), 3, g.contiguous().float().data_ptr(), inside.data_ptr(), ones.data_ptr(),
+                                           out.data_ptr(), N, g_em.data_ptr(), st), "ego_envmap_backward")
+        return g_em, None
 
 
 def render_train(model, rays, n_coarse, n_fine=0, resampling=False, use_coarse_sample=True, jitter: Optional[torch.Tensor] = None,
@@ -192,7 +232,10 @@ def render_train(model, rays, n_coarse, n_fine=0, resampling=False, use_coarse_s
     """Differentiable EgoNeRF.forward (is_train semantics) -> (rgb_map, depth, bg_map|None, env_map|None, alpha)."""
     opts = dict(n_coarse=int(n_coarse), n_fine=int(n_fine), resampling=bool(resampling), use_coarse_sample=bool(use_coarse_sample),
                 jitter=jitter, u=u)
-    out = RenderFunction.apply(model, rays, opts, *differentiable_params(model))
+    params = differentiable_params(model)
+    if model.envmap is not None:
+        params = params + [model.envmap.emission]
+    out = RenderFunction.apply(model, rays, opts, *params)
     if model.envmap is not None:
         rgb_map, depth, alpha, bg_map, env_map = out
         return rgb_map, depth, bg_map, env_map, alpha

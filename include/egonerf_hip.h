@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define EGO_ABI_VERSION 2
+#define EGO_ABI_VERSION 3
 
 enum { EGO_PREC_F16X3 = 0, EGO_PREC_F32 = 1 };
 
@@ -118,7 +118,7 @@ int64_t ego_packed_floats(void);
 
 int ego_abi_version(void);
 const char* ego_last_error(void);
-/* sizeof the ABI structs as compiled (0 ego_scene, 1 ego_render_args, 2 ego_vm_field): lets a foreign-
+/* sizeof the ABI structs as compiled (0 ego_scene, 1 ego_render_args, 2 ego_vm_field, 3 ego_adam_tensor): lets a foreign-
  * language binding verify its struct mirrors at load time */
 int64_t ego_sizeof(int32_t which);
 
@@ -217,16 +217,55 @@ int ego_pack_train(const ego_scene* sc, float* out, void* stream);
 /* which = 0: x column [160] -> MLP input column | 1: hidden column [128] -> unit | 2: dfe column [32] -> feature |
  * 3: v column [144] -> basis input column; -1 marks padding.  Host memory. */
 int ego_train_layout(int32_t which, int32_t* out, int32_t n);
-/* compositing + density backward.  g_rgb [N][3] = dL/d rgb_map, rgb_raw = rgb_map before the clamp, env_map [N][3] or
- * NULL.  Writes dc [N][S][3] = dL/d rgb_sample and scatters d(density tables). */
+/* compositing + density backward (autograd of EgoNeRF.py:579-593 back to the density tables, EgoNeRF.py:291-347).
+ * g_rgb [N][3] = dL/d rgb_map, rgb_raw = rgb_map before the clamp, env_map [N][3] or NULL.  alpha has row stride
+ * alpha_stride (S, or S+1 when the envmap's ones column is appended); g_alpha = dL/d alpha with the same stride or NULL
+ * (train.py:306-309 ray_entropy_loss).  depth_map carries no gradient in the reference (computed under no_grad,
+ * EgoNeRF.py:595-598).  Writes dc [N][S][3] = dL/d rgb_sample and scatters d(density tables). */
 int ego_march_backward(const ego_scene* sc, const ego_vm_grad* gdensity, const float* coords, const float* z, const float* alpha,
-                       const float* weight, const float* sigma, const float* bg_weight, const float* rgb, const float* g_rgb,
-                       const float* rgb_raw, const float* env_map, int64_t N, int32_t S, float* dc, void* stream);
+                       int32_t alpha_stride, const float* weight, const float* sigma, const float* bg_weight, const float* rgb,
+                       const float* g_rgb, const float* g_alpha, const float* rgb_raw, const float* env_map, int64_t N, int32_t S,
+                       float* dc, void* stream);
+/* d(envmap.emission) [3][2h][h] += backward of bg_weight * sigmoid(bilinear(emission, dir)) (envmap.py:26-34,
+ * EgoNeRF.py:588-590).  dirs = N directions dir_stride floats apart (rays + 3 with stride 6, or a packed [N][3]);
+ * env_map = the forward's radiance [N][3]; the clamp mask is taken from rgb_raw (pass values in [0,1] for none). */
+int ego_envmap_backward(const ego_scene* sc, const float* dirs, int32_t dir_stride, const float* g_rgb, const float* rgb_raw, const float* bg_weight,
+                        const float* env_map, int64_t N, float* g_emission, void* stream);
 /* shade backward: dc [N][S][3] in = dL/d rgb_sample, out = dL/d(pre-sigmoid).  Writes dh2, dh1 [M][128], dfe [M][64]
  * (grid g at [32g..)) and scatters d(appearance tables). */
 int ego_shade_backward(const ego_scene* sc, const float* train_packed, const ego_vm_grad* gapp, const float* coords, float* dc,
                        const float* rgb, const ego_shade_dump* fwd, float* dh2, float* dh1, float* dfe, int64_t N, int32_t S,
                        void* stream);
+
+/* ---- training-step table ops (train.py:245-330).  Tables are channel-last [H][W][C].  `value` (device double, may be
+ * NULL) and `grad` (device, same layout as the table, may be NULL) are ACCUMULATED into, so one buffer collects a whole
+ * regulariser and gradients add onto the render's. ---- */
+/* utils.py:155-171 TVLoss on one plane: value += scale * 2 (sum dH^2 / (C (H-1) W) + sum dW^2 / (C H (W-1)));
+ * EgoNeRF.py:214-228 call it with scale = 1e-2 per plane. */
+int ego_tv_plane(const float* table, int32_t C, int32_t H, int32_t W, float scale, double* value, float* grad, void* stream);
+/* EgoNeRF.py:206-212 density_L1 term of one table: value += scale * mean |x|. */
+int ego_l1_table(const float* table, int64_t n, float scale, double* value, float* grad, void* stream);
+/* EgoNeRF.py:189-201 vectorDiffs term of one line table [n][C]: value += scale * mean |off-diagonal of L^T L|. */
+int ego_line_ortho(const float* line, int32_t C, int32_t n, float scale, double* value, float* grad, void* stream);
+/* utils.py:175-183 ray_entropy_loss over alpha [N][S] (row stride `stride`): value += mean_ray H(alpha / (sum alpha + 1e-10)),
+ * g_alpha (same stride, WRITTEN) = d value / d alpha. */
+int ego_ray_entropy(const float* alpha, int64_t N, int32_t S, int32_t stride, double* value, float* g_alpha, void* stream);
+/* coordinates.py:27-39 and :226-266 (up_sampling_VM): bilinear, align_corners=True, zero-padded resample of a table at
+ * per-axis normalised positions xs [W2], ys [H2] (device) -> dst [H2][W2][C]. */
+int ego_resample_table(const float* src, int32_t C, int32_t H, int32_t W, const float* xs, const float* ys, int32_t H2, int32_t W2,
+                       float* dst, void* stream);
+/* torch.optim.Adam step (train.py:182,311-313; no weight decay / amsgrad) over `count` tensors (host array of device
+ * pointers), each with its own lr (train.py:328-329 decays lr per group); `step` counts from 1. */
+typedef struct ego_adam_tensor {
+  float* param;
+  const float* grad;
+  float* exp_avg;
+  float* exp_avg_sq;
+  int64_t n;
+  float lr;
+  int32_t reserved;
+} ego_adam_tensor;
+int ego_adam_step(const ego_adam_tensor* tensors, int32_t count, float beta1, float beta2, float eps, int32_t step, void* stream);
 
 typedef struct ego_render_args {
   int32_t n_coarse, n_fine;

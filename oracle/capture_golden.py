@@ -283,9 +283,84 @@ def capture_checkpoint():
                         bg=np_(o[2]), env=np_(o[3]), alpha=np_(o[4]))
 
 
+def capture_train_extras():
+    """Training-step pieces beyond the MSE gradient (train.py:245-330): ray-entropy gradient through `alpha` with the envmap's
+    ones column, envmap-emission gradient, envmap pre-training (train.py:218-236), the TV / L1 / ortho regularisers
+    (EgoNeRF.py:191-230, utils.py:155-171) with their gradients, and upsample_volume_grid (EgoNeRF.py:415-435)."""
+    from utils import TVLoss, ray_entropy_loss
+    cfg = synth.SceneConfig(n_voxel=20 ** 3, use_envmap=True, envmap_res_H=16)
+    w = synth.make_weights(cfg, seed=4321)
+    model, coords = build_reference(cfg, w)
+    rays = torch.from_numpy(synth.make_rays(64, seed=11))
+    jit = torch.from_numpy(synth.hash_uniform(8, 0, 64 * 16).reshape(64, 16).astype(np.float32))
+    uu = torch.from_numpy(synth.hash_uniform(8, 1, 64 * 16).reshape(64, 16).astype(np.float32))
+    gt = torch.from_numpy(synth.hash_uniform(8, 2, 64 * 3).reshape(64, 3).astype(np.float32))
+    fx = dict(seed_weights=4321, seed_rays=11, envmap_res_H=16, rays=rays.numpy(), jitter=np_(jit), u=np_(uu), gt=np_(gt),
+              entropy_weight=np.float32(0.05))
+
+    def grads(prefix):
+        for k, p in model.named_parameters():
+            fx[f"{prefix}/{k}"] = np_(p.grad if p.grad is not None else torch.zeros_like(p))
+        em = model.envmap.emission
+        fx[f"{prefix}/envmap.emission"] = np_(em.grad if em.grad is not None else torch.zeros_like(em))
+
+    def zero():
+        model.zero_grad()
+        model.envmap.emission.grad = None
+
+    # (1) MSE + entropy, train noise pinned, envmap on
+    zero()
+    with patched_rand([jit], [uu]):
+        o = run_forward(model, rays, n_coarse=16, n_fine=16, resampling=True, use_coarse_sample=True, is_train=True)
+    mse = torch.mean((o[0] - gt) ** 2)
+    ent = ray_entropy_loss(o[4])
+    (mse + 0.05 * ent).backward()
+    fx.update(ent_rgb=np_(o[0]), ent_alpha=np_(o[4]), ent_mse=np.float32(mse.item()), ent_entropy=np.float32(ent.item()))
+    grads("ent_grad")
+    # entropy alone (isolates the alpha path)
+    zero()
+    with patched_rand([jit], [uu]):
+        o = run_forward(model, rays, n_coarse=16, n_fine=16, resampling=True, use_coarse_sample=True, is_train=True)
+    ray_entropy_loss(o[4]).backward()
+    grads("entonly_grad")
+
+    # (2) envmap pre-training
+    zero()
+    env = model(rays_chunk=rays, pretrain_envmap=True)
+    lp = torch.mean((env - gt) ** 2)
+    lp.backward()
+    fx.update(pre_env=np_(env), pre_loss=np.float32(lp.item()), pre_grad=np_(model.envmap.emission.grad))
+
+    # (3) regularisers
+    tv = TVLoss()
+    for name, fn in (("tv_density", lambda: model.TV_loss_density(tv)), ("tv_app", lambda: model.TV_loss_app(tv)),
+                     ("l1", model.density_L1), ("ortho", model.vector_comp_diffs)):
+        zero()
+        v = fn()
+        v.backward()
+        fx[f"reg/{name}/value"] = np.float32(v.item())
+        for k, p in model.named_parameters():
+            if p.grad is not None:
+                fx[f"reg/{name}/grad/{k}"] = np_(p.grad)
+
+    # (4) coarse-to-fine upsampling, then a render on the finer grid
+    target = [20, 22, 64]
+    with contextlib.redirect_stdout(io.StringIO()), torch.no_grad():
+        model.upsample_volume_grid(list(target))
+        coords.set_resolution(list(target))
+        model.update_coarse_sigma_grid()
+    fx["up_target"] = np.array(target)
+    for k, p in model.named_parameters():
+        if "plane" in k or "line" in k:
+            fx[f"up/{k}"] = np_(p)
+    o = run_forward(model, rays, n_coarse=16, n_fine=16, resampling=True, use_coarse_sample=True)
+    fx.update(up_rgb=np_(o[0]), up_depth=np_(o[1]))
+    np.savez_compressed(os.path.join(OUT, "train_extras.npz"), **fx)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
-    which = sys.argv[1:] or ["tiny", "stages", "full", "alpha_mask", "checkpoint"]
+    which = sys.argv[1:] or ["tiny", "stages", "full", "alpha_mask", "checkpoint", "train_extras"]
     for name in which:
         globals()["capture_" + name]()
         print("captured", name)

@@ -69,14 +69,20 @@ class OracleScene:
         self.ang_near = torch.tensor([pi / 4, -3 * pi / 4])
         ang_far = torch.tensor([3 * pi / 4, 3 * pi / 4])
         self.ang_inv = 1.0 / (ang_far - self.ang_near)
-        n_r = self.grid[0]
-        ratio = pow(self.far_r / cfg.r0, 1 / (n_r - 1))  # coordinates.py:117 (tensor pow)
-        self.r_lut = linearised_exp_grid(cfg.r0, ratio, n_r + 1)  # coordinates.py:118-124
+        self.set_resolution(self.grid, r0=cfg.r0)
         self.coarse = None
         self.update_coarse_sigma_grid()
         # opt-in skipping, mirrored from the product for parity tests (the reference's EgoNeRF.forward has neither):
         self.alpha_mask = None   # (vol_yin, vol_yang) float {0,1} volumes (1,1,N_phi,N_theta,N_r), TensorBase.forward semantics
         self.term_eps = 0.0      # early termination: weight := 0 where the incoming transmittance < term_eps
+
+    def set_resolution(self, resolution, r0=None):
+        """coordinates.py:206-215.  Quirk kept: without an explicit r0 (as train.py:377 calls it after an upsample) the
+        radial knee resets to 0.05 whatever the scene's config said."""
+        self.grid = [int(v) for v in resolution]
+        self.r0 = r0 if r0 is not None else 0.05
+        ratio = pow(self.far_r / self.r0, 1 / (self.grid[0] - 1))  # coordinates.py:117 (tensor pow)
+        self.r_lut = linearised_exp_grid(self.r0, ratio, self.grid[0] + 1)  # coordinates.py:118-124
 
     # ---- parameters -------------------------------------------------------------------------
     def table(self, kind: str, what: str, g: str, i: int) -> torch.Tensor:
@@ -94,8 +100,8 @@ class OracleScene:
     def sample_schedule(self, S: int) -> torch.Tensor:
         """Radial offsets r[S] (float32) of EgoNeRF.sample_ray_exp, interval_th branch (EgoNeRF.py:69-76)."""
         c = self.cfg
-        ratio = math.exp(math.log((c.far - c.near) / c.r0) / (S - 1))
-        return linearised_exp_grid(c.r0, ratio, S)
+        ratio = math.exp(math.log((c.far - c.near) / self.r0) / (S - 1))
+        return linearised_exp_grid(self.r0, ratio, S)
 
     def sample_ray_exp(self, rays_o, rays_d, S: int, jitter: Optional[torch.Tensor] = None):
         """EgoNeRF.py:56-87.  `jitter` [N,S] in [0,1) replaces torch.rand_like for is_train."""
@@ -346,12 +352,80 @@ class OracleScene:
             bg_map = bg_w * env_map
             rgb_map = rgb_map + bg_map
         rgb_map = rgb_map.clamp(0, 1)
-        depth = (weight * z).sum(-1) + (1.0 - acc) * rays[..., -1]  # EgoNeRF.py:598 (d_z quirk)
+        depth = ((weight * z).sum(-1) + (1.0 - acc) * rays[..., -1]).detach()  # EgoNeRF.py:595-598 (no_grad; d_z quirk)
         if keep:
             inter.update(sigma_feat=sf, sigma=sigma, weight=weight, bg_weight=bg_w, app_feat=af,
                          rgb_samples=rgb, z=z, acc=acc)
             return (rgb_map, depth, bg_map, env_map, alpha), inter
         return rgb_map, depth, bg_map, env_map, alpha
+
+
+    # ---- training-step extras (train.py:245-330) ---------------------------------------------------
+    @staticmethod
+    def tv_loss(x: torch.Tensor) -> torch.Tensor:
+        """utils.py:155-171 (TVLoss, weight 1): 2 * (sum dH^2 / count_h + sum dW^2 / count_w) / batch."""
+        _, C, H, W = x.shape
+        h_tv = (x[:, :, 1:, :] - x[:, :, :-1, :]).pow(2).sum()
+        w_tv = (x[:, :, :, 1:] - x[:, :, :, :-1]).pow(2).sum()
+        return 2 * (h_tv / (C * (H - 1) * W) + w_tv / (C * H * (W - 1))) / x.shape[0]
+
+    def TV_loss(self, kind: str) -> torch.Tensor:
+        """EgoNeRF.py:214-228: planes only, 1e-2 each, yin and yang."""
+        total = 0
+        for i in range(3):
+            for g in GRIDS:
+                total = total + self.tv_loss(self.table(kind, "plane", g, i)) * 1e-2
+        return total
+
+    def density_L1(self) -> torch.Tensor:
+        """EgoNeRF.py:206-212."""
+        total = 0
+        for i in range(3):
+            for g in GRIDS:
+                total = total + self.table("density", "plane", g, i).abs().mean() + self.table("density", "line", g, i).abs().mean()
+        return total
+
+    def vector_comp_diffs(self) -> torch.Tensor:
+        """EgoNeRF.py:189-201: mean |off-diagonal| of the line Gram matrices, density + app, yin + yang."""
+        total = 0
+        for kind in ("density", "app"):
+            for g in GRIDS:
+                for i in range(3):
+                    v = self.table(kind, "line", g, i)
+                    v = v.reshape(v.shape[1], v.shape[2])
+                    gram = v @ v.T
+                    off = gram[~torch.eye(gram.shape[0], dtype=torch.bool)]
+                    total = total + off.abs().mean()
+        return total
+
+    def upsample_volume_grid(self, res_target):
+        """EgoNeRF.py:415-435 + coordinates.py:226-266 (exp_r, interval_th) + :27-39: bilinear (align_corners) resample of
+        every table; angular axes at linspace(-1,1), the radial axis at the *new* shell radii located in the *old* grid.
+        The caller then calls set_resolution (train.py:376-377)."""
+        c = self.cfg
+        n_new = int(res_target[0])
+        ratio = pow(self.far_r / self.r0, 1 / (n_new - 1))  # coordinates.py:238: far tensor -> 0-dim tensor ratio
+        r_samples = self.normalize_r(linearised_exp_grid(self.r0, ratio, n_new)) * 2 - 1  # positions on the old grid
+        axis = lambda a: r_samples if a == 0 else torch.linspace(-1, 1, int(res_target[a]))
+        for kind in ("density", "app"):
+            for g in GRIDS:
+                for i in range(3):
+                    ax, ay = MAT_MODE[i]  # plane (1,C,size[ay],size[ax]) sampled at (x = ax, y = ay)
+                    xs, ys = axis(ax).to(self.dtype), axis(ay).to(self.dtype)
+                    grid = torch.stack(torch.meshgrid(ys, xs, indexing="ij")[::-1], -1)[None]
+                    key = f"{kind}_plane_{g}.{i}"
+                    self.w[key] = F.grid_sample(self.w[key].detach(), grid, align_corners=True)
+                    ls = axis(VEC_MODE[i]).to(self.dtype)
+                    grid = torch.stack([-torch.ones_like(ls), ls], -1)[None, :, None, :]
+                    key = f"{kind}_line_{g}.{i}"
+                    self.w[key] = F.grid_sample(self.w[key].detach(), grid, align_corners=True)
+        self.update_coarse_sigma_grid()
+
+
+def ray_entropy_loss(alpha: torch.Tensor) -> torch.Tensor:
+    """utils.py:175-183."""
+    p = alpha / (alpha.sum(-1, keepdim=True) + 1e-10)
+    return (-(p * torch.log2(p + 1e-10)).sum(-1)).mean()
 
 
 def volume_render(scene: OracleScene, rays: torch.Tensor, chunk: int = 4096, **kw):

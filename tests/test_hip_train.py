@@ -23,7 +23,7 @@ def test_gradients_match_reference_autograd(golden):
     rays = T(fx["rays"])
     rgb, depth, _, _, alpha = model(rays, is_train=True, n_coarse=16, n_fine=16, exp_sampling=True, resampling=True,
                                     use_coarse_sample=True, jitter=T(fx["tr_jitter"]), u=T(fx["tr_u"]))
-    assert rgb.requires_grad and not depth.requires_grad and not alpha.requires_grad
+    assert rgb.requires_grad and not depth.requires_grad and alpha.requires_grad  # alpha feeds ray_entropy_loss (train.py:306)
     assert float((rgb.detach().cpu() - torch.from_numpy(fx["tr_rgb"])).abs().max()) <= 1e-4
     loss = torch.mean((rgb - T(fx["bw_gt"])) ** 2)
     assert abs(loss.item() - float(fx["bw_loss"])) <= 1e-6

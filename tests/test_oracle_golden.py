@@ -119,6 +119,7 @@ def test_schedules_all_scenes(golden):
     for name, (near, far, r0) in dict(indoor=(0.01, 15.0, 0.03), ricoh=(0.1, 300.0, 0.05), mid=(0.01, 50.0, 0.05)).items():
         sc = OracleScene.__new__(OracleScene)
         sc.cfg = synth.SceneConfig(n_voxel=20 ** 3, near=near, far=far, r0=r0)
+        sc.r0 = r0
         for S in (32, 64, 128, 256, 512):
             z = sc.cfg.near + sc.sample_schedule(S)
             assert np.array_equal(z.numpy(), fx[f"sched/{name}/{S}"]), (name, S)
@@ -163,3 +164,85 @@ def test_full_grid_outputs(golden):
     close(rgb, fx["rs32_rgb"], 5e-6), close(depth, fx["rs32_depth"], 2e-4)
     rgb, depth, *_ = sc.forward(rays[:64], n_coarse=512)
     close(rgb, fx["nr512_rgb"], 5e-6), close(depth, fx["nr512_depth"], 2e-4)
+
+
+# ---- training-step extras (tests/golden/train_extras.npz, captured from the reference by oracle/capture_golden.py) -------
+@pytest.fixture(scope="module")
+def extras(golden):
+    fx = golden("train_extras")
+    cfg = synth.SceneConfig(n_voxel=20 ** 3, use_envmap=True, envmap_res_H=int(fx["envmap_res_H"]))
+    return fx, cfg
+
+
+def _grad_scene(fx, cfg):
+    sc = OracleScene(cfg, synth.make_weights(cfg, seed=int(fx["seed_weights"])))
+    for v in sc.w.values():
+        v.requires_grad_(True)
+    sc.update_coarse_sigma_grid()
+    return sc
+
+
+def _check_grads(sc, fx, prefix, rel=2e-5):
+    for k, v in sc.w.items():
+        ref = fx[f"{prefix}/{k}"]
+        g = np.zeros_like(ref) if v.grad is None else v.grad.numpy()
+        scale = max(float(np.abs(ref).max()), 1e-8)
+        assert float(np.abs(g - ref).max()) <= rel * scale + 1e-9, (prefix, k)
+
+
+def test_entropy_and_envmap_gradients(extras):
+    from oracle.egonerf_oracle import ray_entropy_loss
+    fx, cfg = extras
+    kw = dict(n_coarse=16, n_fine=16, resampling=True, is_train=True, jitter=T(fx["jitter"]), u=T(fx["u"]))
+    sc = _grad_scene(fx, cfg)
+    rgb, _, _, _, alpha = sc.forward(T(fx["rays"]), **kw)
+    close(rgb, fx["ent_rgb"], 1e-6), close(alpha, fx["ent_alpha"], 1e-6)
+    mse, ent = torch.mean((rgb - T(fx["gt"])) ** 2), ray_entropy_loss(alpha)
+    assert abs(mse.item() - float(fx["ent_mse"])) < 1e-6 and abs(ent.item() - float(fx["ent_entropy"])) < 1e-5
+    (mse + float(fx["entropy_weight"]) * ent).backward()
+    _check_grads(sc, fx, "ent_grad")
+    assert np.abs(fx["ent_grad/envmap.emission"]).max() > 0
+    sc = _grad_scene(fx, cfg)
+    ray_entropy_loss(sc.forward(T(fx["rays"]), **kw)[4]).backward()
+    _check_grads(sc, fx, "entonly_grad")
+
+
+def test_envmap_pretraining_gradient(extras):
+    fx, cfg = extras
+    sc = _grad_scene(fx, cfg)
+    env = sc.envmap_radiance(T(fx["rays"])[:, 3:6])
+    close(env, fx["pre_env"], 1e-6)
+    loss = torch.mean((env - T(fx["gt"])) ** 2)
+    assert abs(loss.item() - float(fx["pre_loss"])) < 1e-6
+    loss.backward()
+    close(sc.w["envmap.emission"].grad, fx["pre_grad"], 1e-8)
+
+
+@pytest.mark.parametrize("name", ["tv_density", "tv_app", "l1", "ortho"])
+def test_regularisers(extras, name):
+    fx, cfg = extras
+    sc = _grad_scene(fx, cfg)
+    v = dict(tv_density=lambda: sc.TV_loss("density"), tv_app=lambda: sc.TV_loss("app"), l1=sc.density_L1,
+             ortho=sc.vector_comp_diffs)[name]()
+    ref = float(fx[f"reg/{name}/value"])
+    assert abs(v.item() - ref) <= 2e-6 * max(abs(ref), 1.0)
+    v.backward()
+    keys = [k[len(f"reg/{name}/grad/"):] for k in fx.files if k.startswith(f"reg/{name}/grad/")]
+    assert keys
+    for k in keys:
+        g, r = sc.w[k].grad.numpy(), fx[f"reg/{name}/grad/{k}"]
+        assert float(np.abs(g - r).max()) <= 2e-5 * max(float(np.abs(r).max()), 1e-8), (name, k)
+    assert all(v.grad is None for k, v in sc.w.items() if k not in keys)
+
+
+def test_upsample_volume_grid(extras):
+    fx, cfg = extras
+    sc = OracleScene(cfg, synth.make_weights(cfg, seed=int(fx["seed_weights"])))
+    sc.upsample_volume_grid(fx["up_target"].tolist())
+    sc.set_resolution(fx["up_target"].tolist())  # train.py:376-377: no r0 argument -> the knee resets to 0.05
+    assert sc.r0 == 0.05
+    for k in [k[3:] for k in fx.files if k.startswith("up/")]:
+        assert tuple(sc.w[k].shape) == fx["up/" + k].shape, k
+        close(sc.w[k], fx["up/" + k], 5e-6)  # angular axes: linspace + grid_sample vs F.interpolate rounding
+    rgb, depth, *_ = sc.forward(T(fx["rays"]), n_coarse=16, n_fine=16, resampling=True)
+    close(rgb, fx["up_rgb"], 2e-6), close(depth, fx["up_depth"], 4e-5)
