@@ -124,10 +124,11 @@ class RenderFunction(torch.autograd.Function):
         ctx.model, ctx.N, ctx.S = model, N, S
         ctx.saved = dict(z=z, alpha=alpha, weight=weight, sigma=sigma, bg=bg, coords=coords, rgb=rgb, raw=raw, env=env_map, rays=rays,
                          **dump)
-        ctx.mark_non_differentiable(depth)  # computed under no_grad in the reference (EgoNeRF.py:595-598)
+        # depth is computed under no_grad in the reference (EgoNeRF.py:595-598); one call: a second would replace the first
         if has_env:
-            ctx.mark_non_differentiable(bg_map, env_map)
+            ctx.mark_non_differentiable(depth, bg_map, env_map)
             return rgb_map, depth, alpha, bg_map, env_map
+        ctx.mark_non_differentiable(depth)
         return rgb_map, depth, alpha
 
     @staticmethod
