@@ -112,3 +112,34 @@ def evaluation_psnr(images_rays: Sequence[torch.Tensor], images_gt: Sequence[tor
         fn = lambda block: volume_renderer(block, model, chunk=chunk, device=device, **render_kw)[0]
         psnrs.append(sharded_render(fn, rays.view(-1, rays.shape[-1]), gt.view(-1, 3))["psnr"])
     return psnrs
+
+
+@torch.no_grad()
+def evaluation(images_rays: Sequence[torch.Tensor], images_gt: Sequence[torch.Tensor], img_wh: Tuple[int, int], model, chunk=4096,
+               device="cuda", compute_extra_metrics=True, **render_kw):
+    """renderer.py:82-196 without the file output: per image render -> clamp -> PSNR (:156-157) and, with
+    compute_extra_metrics, rgb_ssim (:160; LPIPS omitted).  Rays are sharded over the ranks of the default process group; the
+    image is gathered to rank 0 for the windowed SSIM, whose value is then broadcast.  Returns (PSNRs, ssims)."""
+    import torch.distributed as dist
+    from .metrics import rgb_ssim
+    W, H = img_wh
+    distributed = dist.is_available() and dist.is_initialized()
+    rank = dist.get_rank() if distributed else 0
+    was_training = model.training
+    model.eval()
+    psnrs, ssims = [], []
+    for rays, gt in zip(images_rays, images_gt):
+        fn = lambda block: volume_renderer(block, model, chunk=chunk, device=device, **render_kw)[0]
+        out = sharded_render(fn, rays.view(-1, rays.shape[-1]), gt.view(-1, 3), gather_image=compute_extra_metrics)
+        psnrs.append(out["psnr"])
+        if compute_extra_metrics:
+            val = torch.zeros(1, dtype=torch.float64, device=out["rgb_local"].device)
+            if rank == 0:
+                img = out["image"].clamp(0.0, 1.0).reshape(H, W, 3)
+                val[0] = rgb_ssim(img, gt.view(H, W, 3).to(img.device), 1)
+            if distributed:
+                dist.broadcast(val, src=0)
+            ssims.append(float(val.item()))
+    model.train(was_training)
+    return psnrs, ssims
+

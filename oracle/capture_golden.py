@@ -358,9 +358,30 @@ def capture_train_extras():
     np.savez_compressed(os.path.join(OUT, "train_extras.npz"), **fx)
 
 
+def capture_metrics():
+    """utils.py:104-152 rgb_ssim as renderer.py:160 calls it (torch float32 images, max_val 1) + the PSNR line (:156-157)."""
+    from utils import rgb_ssim
+    H, W = 40, 56
+    yy, xx = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+    base = np.stack([0.5 + 0.4 * np.sin(xx / 5.0 + c) * np.cos(yy / 7.0 - c) for c in range(3)], -1)
+    noise = synth.hash_uniform(31, 0, H * W * 3).reshape(H, W, 3)
+    img0 = torch.from_numpy(np.clip(base, 0, 1).astype(np.float32))
+    img1 = torch.from_numpy(np.clip(base + 0.15 * (noise - 0.5), 0, 1).astype(np.float32))
+    flat = torch.full((H, W, 3), 0.25)
+    fx = dict(img0=img0.numpy(), img1=img1.numpy())
+    fx["ssim"] = np.float64(rgb_ssim(img0, img1, 1))
+    fx["ssim_map"] = np.asarray(rgb_ssim(img0, img1, 1, return_map=True))
+    fx["ssim_same"] = np.float64(rgb_ssim(img0, img0, 1))
+    fx["ssim_flat"] = np.float64(rgb_ssim(flat, img1, 1))
+    fx["ssim_fs7"] = np.float64(rgb_ssim(img0, img1, 1, filter_size=7, filter_sigma=1.0))
+    loss = torch.mean((img1 - img0) ** 2)
+    fx["psnr"] = np.float64(-10.0 * np.log(loss.item()) / np.log(10.0))
+    np.savez_compressed(os.path.join(OUT, "metrics.npz"), **fx)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
-    which = sys.argv[1:] or ["tiny", "stages", "full", "alpha_mask", "checkpoint", "train_extras"]
+    which = sys.argv[1:] or ["tiny", "stages", "full", "alpha_mask", "checkpoint", "train_extras", "metrics"]
     for name in which:
         globals()["capture_" + name]()
         print("captured", name)

@@ -438,3 +438,29 @@ def volume_render(scene: OracleScene, rays: torch.Tensor, chunk: int = 4096, **k
 def psnr(img: torch.Tensor, gt: torch.Tensor) -> float:
     """renderer.py:156-157."""
     return float(-10.0 * np.log(torch.mean((img - gt) ** 2).item()) / np.log(10.0))
+
+
+def rgb_ssim(img0, img1, max_val, filter_size=11, filter_sigma=1.5, k1=0.01, k2=0.03, return_map=False):
+    """utils.py:104-152: per-channel 'valid' separable Gaussian statistics in float64 over float32 images (squares and
+    products are taken in float32 first, as the reference does with torch tensors), clipped variances, mean of the map."""
+    a, b = np.asarray(img0, np.float32), np.asarray(img1, np.float32)
+    hw = filter_size // 2
+    shift = (2 * hw - filter_size + 1) / 2
+    filt = np.exp(-0.5 * ((np.arange(filter_size) - hw + shift) / filter_sigma) ** 2)
+    filt /= filt.sum()
+
+    def blur(z):
+        z = z.astype(np.float64)
+        v = sum(filt[k] * z[k: z.shape[0] - filter_size + 1 + k] for k in range(filter_size))
+        return sum(filt[k] * v[:, k: v.shape[1] - filter_size + 1 + k] for k in range(filter_size))
+
+    mu0, mu1 = blur(a), blur(b)
+    mu00, mu11, mu01 = mu0 * mu0, mu1 * mu1, mu0 * mu1
+    s00 = np.maximum(0.0, blur(a * a) - mu00)
+    s11 = np.maximum(0.0, blur(b * b) - mu11)
+    s01 = blur(a * b) - mu01
+    s01 = np.sign(s01) * np.minimum(np.sqrt(s00 * s11), np.abs(s01))
+    c1, c2 = (k1 * max_val) ** 2, (k2 * max_val) ** 2
+    ssim_map = ((2 * mu01 + c1) * (2 * s01 + c2)) / ((mu00 + mu11 + c1) * (s00 + s11 + c2))
+    return ssim_map if return_map else float(np.mean(ssim_map))
+

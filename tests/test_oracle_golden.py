@@ -246,3 +246,15 @@ def test_upsample_volume_grid(extras):
         close(sc.w[k], fx["up/" + k], 5e-6)  # angular axes: linspace + grid_sample vs F.interpolate rounding
     rgb, depth, *_ = sc.forward(T(fx["rays"]), n_coarse=16, n_fine=16, resampling=True)
     close(rgb, fx["up_rgb"], 2e-6), close(depth, fx["up_depth"], 4e-5)
+
+
+def test_rgb_ssim_restatement(golden):
+    from oracle.egonerf_oracle import rgb_ssim, psnr
+    fx = golden("metrics")
+    a, b = fx["img0"], fx["img1"]
+    assert abs(rgb_ssim(a, b, 1) - float(fx["ssim"])) < 1e-12
+    assert float(np.abs(rgb_ssim(a, b, 1, return_map=True) - fx["ssim_map"]).max()) < 1e-11
+    assert abs(rgb_ssim(a, a, 1) - 1.0) < 1e-12 and abs(float(fx["ssim_same"]) - 1.0) < 1e-12
+    assert abs(rgb_ssim(np.full_like(a, 0.25), b, 1) - float(fx["ssim_flat"])) < 1e-12
+    assert abs(rgb_ssim(a, b, 1, filter_size=7, filter_sigma=1.0) - float(fx["ssim_fs7"])) < 1e-12
+    assert abs(psnr(torch.from_numpy(b), torch.from_numpy(a)) - float(fx["psnr"])) < 1e-9
