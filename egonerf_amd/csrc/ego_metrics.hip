@@ -75,9 +75,9 @@ __global__ __launch_bounds__(256) void k_rgb_ssim(SsimArgs A) {
 
 extern "C" {
 
-int ego_rgb_ssim(const float* img0, const float* img1, int32_t H, int32_t W, float max_val, int32_t filter_size, float filter_sigma,
-                 float k1, float k2, double* sum, float* ssim_map, void* stream) {
-  EGO_REQUIRE(filter_size >= 1 && filter_size <= SSIM_MAX_FS && H >= filter_size && W >= filter_size && filter_sigma > 0.f,
+int ego_rgb_ssim(const float* img0, const float* img1, int32_t H, int32_t W, double max_val, int32_t filter_size, double filter_sigma,
+                 double k1, double k2, double* sum, float* ssim_map, void* stream) {
+  EGO_REQUIRE(filter_size >= 1 && filter_size <= SSIM_MAX_FS && H >= filter_size && W >= filter_size && filter_sigma > 0.0,
               "rgb_ssim: bad size (image must cover the filter, filter_size <= 15)");
   EGO_REQUIRE(img0 && img1 && (sum || ssim_map), "rgb_ssim: null argument");
   SsimArgs a{};
@@ -87,13 +87,13 @@ int ego_rgb_ssim(const float* img0, const float* img1, int32_t H, int32_t W, flo
   const double shift = (2 * hw - filter_size + 1) / 2.0;
   double tot = 0.0;
   for (int i = 0; i < filter_size; ++i) {
-    const double f = ((double)(i - hw) + shift) / (double)filter_sigma;
+    const double f = ((double)(i - hw) + shift) / filter_sigma;
     a.filt[i] = exp(-0.5 * f * f);
     tot += a.filt[i];
   }
   for (int i = 0; i < filter_size; ++i) a.filt[i] /= tot;
-  a.c1 = ((double)k1 * (double)max_val) * ((double)k1 * (double)max_val);
-  a.c2 = ((double)k2 * (double)max_val) * ((double)k2 * (double)max_val);
+  a.c1 = (k1 * max_val) * (k1 * max_val);
+  a.c2 = (k2 * max_val) * (k2 * max_val);
   const int Ho = H - filter_size + 1, Wo = W - filter_size + 1;
   dim3 grid((Wo + SSIM_TILE - 1) / SSIM_TILE, (Ho + SSIM_TILE - 1) / SSIM_TILE);
   k_rgb_ssim<<<grid, 256, 0, (hipStream_t)stream>>>(a);

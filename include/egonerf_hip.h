@@ -270,8 +270,8 @@ int ego_adam_step(const ego_adam_tensor* tensors, int32_t count, float beta1, fl
 /* utils.py:104-152 rgb_ssim (renderer.py:160) on device images [H][W][3]: 'valid' separable Gaussian window in float64 over
  * float32 inputs.  sum (device double, may be NULL) accumulates the sum of the SSIM map — the caller divides by
  * (H-fs+1)(W-fs+1)3; ssim_map [(H-fs+1)][(W-fs+1)][3] may be NULL. */
-int ego_rgb_ssim(const float* img0, const float* img1, int32_t H, int32_t W, float max_val, int32_t filter_size, float filter_sigma,
-                 float k1, float k2, double* sum, float* ssim_map, void* stream);
+int ego_rgb_ssim(const float* img0, const float* img1, int32_t H, int32_t W, double max_val, int32_t filter_size, double filter_sigma,
+                 double k1, double k2, double* sum, float* ssim_map, void* stream);
 
 typedef struct ego_render_args {
   int32_t n_coarse, n_fine;
