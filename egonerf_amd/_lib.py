@@ -87,9 +87,11 @@ PROTOTYPES = {
     "ego_train_packed_floats": (I64, []),
     "ego_pack_train": (C.c_int, [SP, P, P]),
     "ego_train_layout": (C.c_int, [I32, C.POINTER(C.c_int32), I32]),
-    "ego_march_backward": (C.c_int, [SP, C.POINTER(VmGrad), P, P, P, I32, P, P, P, P, P, P, P, P, I64, I32, P, P]),
+    "ego_march_backward": (C.c_int, [SP, P, P, I32, P, P, P, P, P, P, P, P, I64, I32, P, P, P]),
+    "ego_scatter_density": (C.c_int, [SP, C.POINTER(VmGrad), P, P, I64, I32, P]),
+    "ego_scatter_app": (C.c_int, [SP, C.POINTER(VmGrad), P, P, I64, I32, P]),
     "ego_envmap_backward": (C.c_int, [SP, P, I32, P, P, P, P, I64, P, P]),
-    "ego_shade_backward": (C.c_int, [SP, P, C.POINTER(VmGrad), P, P, P, C.POINTER(ShadeDump), P, P, P, I64, I32, P]),
+    "ego_shade_backward": (C.c_int, [SP, P, P, P, P, C.POINTER(ShadeDump), P, P, P, P, I64, I32, P]),
     "ego_tv_plane": (C.c_int, [P, I32, I32, I32, F32, P, P, P]),
     "ego_l1_table": (C.c_int, [P, I64, F32, P, P, P]),
     "ego_line_ortho": (C.c_int, [P, I32, I32, F32, P, P, P]),

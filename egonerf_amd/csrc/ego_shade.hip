@@ -1225,39 +1225,72 @@ static int check_grad(const ego_vm_grad* g, const char* who) {
   return EGO_OK;
 }
 
-int ego_march_backward(const ego_scene* sc, const ego_vm_grad* gdensity, const float* coords, const float* z, const float* alpha,
-                       int32_t alpha_stride, const float* weight, const float* sigma, const float* bg_weight, const float* rgb,
-                       const float* g_rgb, const float* g_alpha, const float* rgb_raw, const float* env_map, int64_t N, int32_t S,
-                       float* dc, void* stream) {
+int ego_march_backward(const ego_scene* sc, const float* z, const float* alpha, int32_t alpha_stride, const float* weight,
+                       const float* sigma, const float* bg_weight, const float* rgb, const float* g_rgb, const float* g_alpha,
+                       const float* rgb_raw, const float* env_map, int64_t N, int32_t S, float* dc, float* dfeat, void* stream) {
   EGO_REQUIRE(N >= 0 && S >= 2 && alpha_stride >= S, "march_backward: bad size");
   if (N == 0) return EGO_OK;
-  EGO_REQUIRE(sc && coords && z && alpha && weight && sigma && bg_weight && rgb && g_rgb && rgb_raw && dc, "march_backward: null argument");
-  if (int e = check_grad(gdensity, "march_backward")) return e;
-  if (sc->density.n_comp != 16) return ego_fail(EGO_E_UNSUPPORTED, "march_backward: n_comp %d (supported: 16)", sc->density.n_comp);
+  EGO_REQUIRE(sc && z && alpha && weight && sigma && bg_weight && rgb && g_rgb && rgb_raw && dc && dfeat, "march_backward: null argument");
   if (!sc->act_softplus) return ego_fail(EGO_E_UNSUPPORTED, "march_backward: only the softplus density activation is supported");
   MarchBwdArgs a{};
-  a.F = make_field(sc->density); a.G = make_grad(*gdensity);
-  a.coords = coords; a.z = z; a.alpha = alpha; a.g_alpha = g_alpha; a.astride = alpha_stride; a.weight = weight; a.sigma = sigma;
+  a.z = z; a.alpha = alpha; a.g_alpha = g_alpha; a.astride = alpha_stride; a.weight = weight; a.sigma = sigma;
   a.bg = bg_weight; a.rgb = rgb; a.g_rgb = g_rgb;
-  a.rgb_raw = rgb_raw; a.env = env_map; a.dc = dc; a.N = N; a.S = S; a.dscale = sc->distance_scale;
-  k_march_bwd<16><<<(unsigned)((N + 3) / 4), 256, 0, (hipStream_t)stream>>>(a);
+  a.rgb_raw = rgb_raw; a.env = env_map; a.dc = dc; a.dfeat = dfeat; a.N = N; a.S = S; a.dscale = sc->distance_scale;
+  k_march_bwd<<<(unsigned)((N + 3) / 4), 256, 0, (hipStream_t)stream>>>(a);
   return ego_launch_status("k_march_bwd");
 }
 
-int ego_shade_backward(const ego_scene* sc, const float* train_packed, const ego_vm_grad* gapp, const float* coords, float* dc,
-                       const float* rgb, const ego_shade_dump* fwd, float* dh2, float* dh1, float* dfe, int64_t N, int32_t S,
-                       void* stream) {
+int ego_shade_backward(const ego_scene* sc, const float* train_packed, const float* coords, float* dc, const float* rgb,
+                       const ego_shade_dump* fwd, float* dh2, float* dh1, float* dfe, float* dv, int64_t N, int32_t S, void* stream) {
   EGO_REQUIRE(N >= 0 && S >= 1 && N * (int64_t)S < (1ll << 31), "shade_backward: bad size");
   if (N == 0) return EGO_OK;
-  EGO_REQUIRE(sc && train_packed && coords && dc && rgb && fwd && fwd->x && fwd->h1 && fwd->h2 && dh2 && dh1 && dfe,
+  EGO_REQUIRE(sc && train_packed && coords && dc && rgb && fwd && fwd->x && fwd->h1 && fwd->h2 && dh2 && dh1 && dfe && dv,
               "shade_backward: null argument");
-  if (int e = check_grad(gapp, "shade_backward")) return e;
   if (int e = check_shade_config(sc, "shade_backward", true, true)) return e;
   ShadeBwdArgs a{};
-  a.F = make_field(sc->app); a.G = make_grad(*gapp); a.tpacked = train_packed; a.coords = coords; a.dc = dc; a.rgb = rgb;
-  a.x = fwd->x; a.h1 = fwd->h1; a.h2 = fwd->h2; a.dh2 = dh2; a.dh1 = dh1; a.dfe = dfe; a.M = N * (int64_t)S;
+  a.tpacked = train_packed; a.coords = coords; a.dc = dc; a.rgb = rgb;
+  a.x = fwd->x; a.h1 = fwd->h1; a.h2 = fwd->h2; a.dh2 = dh2; a.dh1 = dh1; a.dfe = dfe; a.dv = dv; a.M = N * (int64_t)S;
   k_shade_bwd<<<shade_grid(a.M), 512, 0, (hipStream_t)stream>>>(a);
   return ego_launch_status("k_shade_bwd");
+}
+
+static int scatter_common(const ego_vm_field& f, const ego_vm_grad* g, const float* coords, const float* d, int64_t N, int32_t S,
+                          ScatterArgs* a, const char* who) {
+  if (!(N >= 0 && S >= 1)) return ego_fail(EGO_E_BADARG, "%s: bad size", who);
+  if (N == 0) return EGO_OK;
+  if (!coords || !d) return ego_fail(EGO_E_BADARG, "%s: null argument", who);
+  if (int e = check_grad(g, who)) return e;
+  a->F = make_field(f); a->G = make_grad(*g); a->coords = coords; a->d = d; a->N = N; a->S = S;
+  a->seg = 64;
+  a->gpr = (S + a->seg - 1) / a->seg;
+  return EGO_OK;
+}
+
+static unsigned scatter_blocks(const ScatterArgs& a) {
+  const int64_t groups = a.N * a.gpr;
+  return (unsigned)((groups + 15) / 16);  // 4 groups per wave, 4 waves per workgroup
+}
+
+int ego_scatter_density(const ego_scene* sc, const ego_vm_grad* gdensity, const float* coords, const float* dfeat, int64_t N, int32_t S,
+                        void* stream) {
+  EGO_REQUIRE(sc, "scatter_density: null scene");
+  if (sc->density.n_comp != 16) return ego_fail(EGO_E_UNSUPPORTED, "scatter_density: n_comp %d (supported: 16)", sc->density.n_comp);
+  ScatterArgs a{};
+  if (int e = scatter_common(sc->density, gdensity, coords, dfeat, N, S, &a, "scatter_density")) return e;
+  if (N == 0) return EGO_OK;
+  k_vm_scatter<16, true><<<scatter_blocks(a), 256, 0, (hipStream_t)stream>>>(a);
+  return ego_launch_status("k_vm_scatter<16>");
+}
+
+int ego_scatter_app(const ego_scene* sc, const ego_vm_grad* gapp, const float* coords, const float* dv, int64_t N, int32_t S,
+                    void* stream) {
+  EGO_REQUIRE(sc, "scatter_app: null scene");
+  if (sc->app.n_comp != APP_C) return ego_fail(EGO_E_UNSUPPORTED, "scatter_app: n_comp %d (supported: 48)", sc->app.n_comp);
+  ScatterArgs a{};
+  if (int e = scatter_common(sc->app, gapp, coords, dv, N, S, &a, "scatter_app")) return e;
+  if (N == 0) return EGO_OK;
+  k_vm_scatter<APP_C, false><<<scatter_blocks(a), 256, 0, (hipStream_t)stream>>>(a);
+  return ego_launch_status("k_vm_scatter<48>");
 }
 
 }  // extern "C"

@@ -149,19 +149,22 @@ class RenderFunction(torch.autograd.Function):
         for p, g in zip(dens + app, g_dens + g_app):
             assert g.stride() == p.stride()
         f = lambda *shape: torch.empty(*shape, device=dev, dtype=torch.float32)
-        dc = f(N, S, 3)
+        dc, dfeat = f(N, S, 3), f(N, S)
+        _lib.check(lib.ego_march_backward(sc, sv["z"].data_ptr(), sv["alpha"].data_ptr(), astride, sv["weight"].data_ptr(),
+                                          sv["sigma"].data_ptr(), sv["bg"].data_ptr(), sv["rgb"].data_ptr(), g_rgb.data_ptr(),
+                                          _lib.ptr(g_alpha), sv["raw"].data_ptr(), _lib.ptr(sv["env"]), N, S, dc.data_ptr(),
+                                          dfeat.data_ptr(), st), "ego_march_backward")
         gd = _grad_struct(g_dens)
-        _lib.check(lib.ego_march_backward(sc, C.byref(gd), sv["coords"].data_ptr(), sv["z"].data_ptr(), sv["alpha"].data_ptr(), astride,
-                                          sv["weight"].data_ptr(), sv["sigma"].data_ptr(), sv["bg"].data_ptr(), sv["rgb"].data_ptr(),
-                                          g_rgb.data_ptr(), _lib.ptr(g_alpha), sv["raw"].data_ptr(), _lib.ptr(sv["env"]), N, S,
-                                          dc.data_ptr(), st), "ego_march_backward")
+        _lib.check(lib.ego_scatter_density(sc, C.byref(gd), sv["coords"].data_ptr(), dfeat.data_ptr(), N, S, st), "ego_scatter_density")
         tp = f(lib.ego_train_packed_floats())
         _lib.check(lib.ego_pack_train(sc, tp.data_ptr(), st), "ego_pack_train")
-        dh2, dh1, dfe = f(M, 128), f(M, 128), f(M, 64)
-        ga = _grad_struct(g_app)
+        dh2, dh1, dfe, dv = f(M, 128), f(M, 128), f(M, 64), f(M, 144)
         ds = _lib.ShadeDump(sv["x"].data_ptr(), sv["h1"].data_ptr(), sv["h2"].data_ptr(), sv["v"].data_ptr())
-        _lib.check(lib.ego_shade_backward(sc, tp.data_ptr(), C.byref(ga), sv["coords"].data_ptr(), dc.data_ptr(), sv["rgb"].data_ptr(),
-                                          C.byref(ds), dh2.data_ptr(), dh1.data_ptr(), dfe.data_ptr(), N, S, st), "ego_shade_backward")
+        _lib.check(lib.ego_shade_backward(sc, tp.data_ptr(), sv["coords"].data_ptr(), dc.data_ptr(), sv["rgb"].data_ptr(), C.byref(ds),
+                                          dh2.data_ptr(), dh1.data_ptr(), dfe.data_ptr(), dv.data_ptr(), N, S, st), "ego_shade_backward")
+        ga = _grad_struct(g_app)
+        _lib.check(lib.ego_scatter_app(sc, C.byref(ga), sv["coords"].data_ptr(), dv.data_ptr(), N, S, st), "ego_scatter_app")
+        del dv
         # ---- weight gradients: library GEMMs with K = all samples, then un-permute the lane-order columns ----
         do = dc.view(M, 3)  # now d(pre-sigmoid)
         hid = _layout(1, 128, dev)

@@ -217,26 +217,30 @@ int ego_pack_train(const ego_scene* sc, float* out, void* stream);
 /* which = 0: x column [160] -> MLP input column | 1: hidden column [128] -> unit | 2: dfe column [32] -> feature |
  * 3: v column [144] -> basis input column; -1 marks padding.  Host memory. */
 int ego_train_layout(int32_t which, int32_t* out, int32_t n);
-/* compositing + density backward (autograd of EgoNeRF.py:579-593 back to the density tables, EgoNeRF.py:291-347).
+/* compositing backward (autograd of EgoNeRF.py:579-593 and tensorBase.py:22-27,415-419).
  * g_rgb [N][3] = dL/d rgb_map, rgb_raw = rgb_map before the clamp, env_map [N][3] or NULL.  alpha has row stride
  * alpha_stride (S, or S+1 when the envmap's ones column is appended); g_alpha = dL/d alpha with the same stride or NULL
  * (train.py:306-309 ray_entropy_loss).  depth_map carries no gradient in the reference (computed under no_grad,
- * EgoNeRF.py:595-598).  Writes dc [N][S][3] = dL/d rgb_sample and scatters d(density tables). */
-int ego_march_backward(const ego_scene* sc, const ego_vm_grad* gdensity, const float* coords, const float* z, const float* alpha,
-                       int32_t alpha_stride, const float* weight, const float* sigma, const float* bg_weight, const float* rgb,
-                       const float* g_rgb, const float* g_alpha, const float* rgb_raw, const float* env_map, int64_t N, int32_t S,
-                       float* dc, void* stream);
+ * EgoNeRF.py:595-598).  Writes dc [N][S][3] = dL/d rgb_sample and dfeat [N][S] = dL/d(density feature) (the per-plane relu
+ * mask of EgoNeRF.py:340,346 is applied by ego_scatter_density). */
+int ego_march_backward(const ego_scene* sc, const float* z, const float* alpha, int32_t alpha_stride, const float* weight,
+                       const float* sigma, const float* bg_weight, const float* rgb, const float* g_rgb, const float* g_alpha,
+                       const float* rgb_raw, const float* env_map, int64_t N, int32_t S, float* dc, float* dfeat, void* stream);
+/* shade backward: dc [N][S][3] in = dL/d rgb_sample, out = dL/d(pre-sigmoid).  Writes dh2, dh1 [M][128], dfe [M][64]
+ * (grid g at [32g..)) and dv [M][144] = dL/d(plane x line products) in the reference's channel order. */
+int ego_shade_backward(const ego_scene* sc, const float* train_packed, const float* coords, float* dc, const float* rgb,
+                       const ego_shade_dump* fwd, float* dh2, float* dh1, float* dfe, float* dv, int64_t N, int32_t S, void* stream);
+/* backward of the VM lookups (autograd of F.grid_sample in EgoNeRF.py:291-347 / :349-413): accumulates into the gradient
+ * tables (same channel-last layout as the parameters).  coords [N][S][4] = the forward's normalised (r, theta, phi, grid). */
+int ego_scatter_density(const ego_scene* sc, const ego_vm_grad* gdensity, const float* coords, const float* dfeat, int64_t N, int32_t S,
+                        void* stream);
+int ego_scatter_app(const ego_scene* sc, const ego_vm_grad* gapp, const float* coords, const float* dv, int64_t N, int32_t S,
+                    void* stream);
 /* d(envmap.emission) [3][2h][h] += backward of bg_weight * sigmoid(bilinear(emission, dir)) (envmap.py:26-34,
  * EgoNeRF.py:588-590).  dirs = N directions dir_stride floats apart (rays + 3 with stride 6, or a packed [N][3]);
  * env_map = the forward's radiance [N][3]; the clamp mask is taken from rgb_raw (pass values in [0,1] for none). */
 int ego_envmap_backward(const ego_scene* sc, const float* dirs, int32_t dir_stride, const float* g_rgb, const float* rgb_raw, const float* bg_weight,
                         const float* env_map, int64_t N, float* g_emission, void* stream);
-/* shade backward: dc [N][S][3] in = dL/d rgb_sample, out = dL/d(pre-sigmoid).  Writes dh2, dh1 [M][128], dfe [M][64]
- * (grid g at [32g..)) and scatters d(appearance tables). */
-int ego_shade_backward(const ego_scene* sc, const float* train_packed, const ego_vm_grad* gapp, const float* coords, float* dc,
-                       const float* rgb, const ego_shade_dump* fwd, float* dh2, float* dh1, float* dfe, int64_t N, int32_t S,
-                       void* stream);
-
 /* ---- training-step table ops (train.py:245-330).  Tables are channel-last [H][W][C].  `value` (device double, may be
  * NULL) and `grad` (device, same layout as the table, may be NULL) are ACCUMULATED into, so one buffer collects a whole
  * regulariser and gradients add onto the render's. ---- */

@@ -163,7 +163,7 @@ def test_upsample_volume_grid(extras):
     rgb, depth, *_ = model(T(fx["rays"]), n_coarse=16, n_fine=16, exp_sampling=True, resampling=True)
     assert float((rgb.detach().cpu() - torch.from_numpy(fx["up_rgb"])).abs().max()) <= 1e-4
     assert float((depth.detach().cpu() - torch.from_numpy(fx["up_depth"])).abs().max()) <= 1e-3
-    assert float((rgb - before).abs().max()) > 1e-3  # the scene cache noticed the new tables / LUT / schedule
+    assert float((rgb.detach() - before.detach()).abs().max()) > 1e-3  # the scene cache noticed the new tables / LUT / schedule
 
 
 def test_fused_adam_matches_torch_adam():
