@@ -1266,9 +1266,9 @@ static int scatter_common(const ego_vm_field& f, const ego_vm_grad* g, const flo
   return EGO_OK;
 }
 
-static unsigned scatter_blocks(const ScatterArgs& a) {
+static dim3 scatter_blocks(const ScatterArgs& a) {
   const int64_t groups = a.N * a.gpr;
-  return (unsigned)((groups + 15) / 16);  // 4 groups per wave, 4 waves per workgroup
+  return dim3((unsigned)((groups + 15) / 16), 3);  // 4 groups per wave, 4 waves per workgroup; y = plane
 }
 
 int ego_scatter_density(const ego_scene* sc, const ego_vm_grad* gdensity, const float* coords, const float* dfeat, int64_t N, int32_t S,

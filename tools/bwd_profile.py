@@ -22,5 +22,7 @@ for it in range(3):
             loss.backward(); torch.cuda.synchronize()
     else:
         loss.backward()
-rows = sorted(prof.key_averages(), key=lambda e: -e.device_time_total)[:14]
-print({r.key[:40]: round(r.device_time_total / 1000, 2) for r in rows})
+rows = sorted(prof.key_averages(), key=lambda e: -e.device_time_total)[:20]
+for r in rows:
+    print(f"{r.device_time_total / 1000:8.3f} ms  x{r.count:<3d} {r.key[:110]}")
+print("total device ms:", round(sum(r.device_time_total for r in prof.key_averages()) / 1000, 2))
