@@ -53,6 +53,11 @@ __host__ __device__ constexpr int slot_row(int r, int h) { return (r & 3) + 8 * 
 // 4i+p of line i, so a team reads whole 64-byte lines) and transposed into the 2-lanes-per-sample MFMA layout with
 // v_permlane16_swap + v_permlane32_swap.  Lane half h ends up with the parts p = h (first 12 products of a plane) and
 // p = h + 2 (next 12): product kk = plane*24 + half*12 + i*4 + c is channel plane*48 + 16i + 4(h + 2 half) + c.
+// Activation dumps of the training forward ([M][2 K] rows: x 160, h1/h2 128, v 144): element kk of lane half h sits at
+// dump_col(kk, h), i.e. the float4 quads of the two halves interleave, so the two lanes of a sample write 32 contiguous
+// bytes per store instruction (half as many lines per instruction as half-major rows; the stores are TA-bound).
+__host__ __device__ constexpr int dump_col(int kk, int h) { return (kk >> 2) * 8 + h * 4 + (kk & 3); }
+
 __host__ __device__ constexpr int app_channel_g(int kk, int h) {
   return (kk / APP_HALF) * APP_C + (((kk % APP_HALF) % 12) / 4) * 16 + 4 * (h + 2 * ((kk % APP_HALF) / 12)) + (kk % 4);
 }
@@ -680,7 +685,7 @@ __device__ __forceinline__ void team_to_halves(const float ga[12], const float g
 __device__ __forceinline__ void dump24(float* dst, const float* v) {
   if (dst) {
 #pragma unroll
-    for (int q = 0; q < 6; ++q) ((f32x4*)dst)[q] = f32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+    for (int q = 0; q < 6; ++q) ((f32x4*)dst)[2 * q] = f32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};  // dump_col order
   }
 }
 
@@ -721,7 +726,7 @@ __device__ __forceinline__ void gather_basis_team(const DevField& F, const TeamS
   team_load<1>(F, tB, ts[1].g, p, raw);
   team_finish<1>(tB, raw, gb);
   team_to_halves(ga, gb, v);
-  dump24(vdump ? vdump + 24 : nullptr, v);
+  dump24(vdump ? vdump + 48 : nullptr, v);
   __builtin_amdgcn_sched_barrier(0);
   team_load<2>(F, tA, ts[0].g, p, raw);
   basis3(BASH, lane, 3, g0, keep0, v, fe);
@@ -731,7 +736,7 @@ __device__ __forceinline__ void gather_basis_team(const DevField& F, const TeamS
   team_load<2>(F, tB, ts[1].g, p, raw);
   team_finish<2>(tB, raw, gb);
   team_to_halves(ga, gb, v);
-  dump24(vdump ? vdump + 48 : nullptr, v);
+  dump24(vdump ? vdump + 96 : nullptr, v);
   basis3(BASH, lane, 6, g0, keep0, v, fe);
   if (mixed) basis3(BASH, lane, 6, 1, g != 0, v, fe);
 }
@@ -884,7 +889,7 @@ __global__ __launch_bounds__(512) void k_shade_h(ShadeArgs A) {
             ts[rd].a_r = c4.x; ts[rd].a_th = c4.y; ts[rd].a_ph = c4.z; ts[rd].g = c4.w != 0.f;
           }
         }
-        float* vd = (DUMP && valid) ? A.dump_v + m * 144 + hw * 72 : nullptr;
+        float* vd = (DUMP && valid) ? A.dump_v + m * 144 + hw * 4 : nullptr;
         // one gather per tile; a border-straddling wave runs the basis steps of each plane twice (yin weights with the
         // yang lanes zeroed, then the reverse) inside gather_basis_team
         gather_basis_team(A.F, ts, BASH, lw, g, mixed, gu, fe, vd);
@@ -946,8 +951,8 @@ __global__ __launch_bounds__(512) void k_shade_h(ShadeArgs A) {
           const int step = kk >> 3;
           const HL b = split8(xs, true);
           if (DUMP && valid) {
-            f32x4* d = (f32x4*)(A.dump_x + m * 160 + hw * 80 + step * 8);
-            d[0] = f32x4{xs[0], xs[1], xs[2], xs[3]}; d[1] = f32x4{xs[4], xs[5], xs[6], xs[7]};
+            f32x4* d = (f32x4*)(A.dump_x + m * 160 + dump_col(step * 8, hw));  // quads of the two halves interleaved
+            d[0] = f32x4{xs[0], xs[1], xs[2], xs[3]}; d[2] = f32x4{xs[4], xs[5], xs[6], xs[7]};
           }
 #pragma unroll
           for (int mt = 0; mt < 4; ++mt) { ah[mt] = nh[mt]; al[mt] = nl[mt]; }
@@ -976,7 +981,7 @@ __global__ __launch_bounds__(512) void k_shade_h(ShadeArgs A) {
       for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-          ((f32x4*)(A.dump_h1 + m * 128 + hw * 64 + mt * 16))[q] = f32x4{H[mt][4 * q], H[mt][4 * q + 1], H[mt][4 * q + 2], H[mt][4 * q + 3]};
+          *(f32x4*)(A.dump_h1 + m * 128 + dump_col(mt * 16 + q * 4, hw)) = f32x4{H[mt][4 * q], H[mt][4 * q + 1], H[mt][4 * q + 2], H[mt][4 * q + 3]};
     }
 
     // ---- layer 2 (8 steps), layer 3 on the VALU ----------------------------------------------------------------
@@ -1023,7 +1028,7 @@ __global__ __launch_bounds__(512) void k_shade_h(ShadeArgs A) {
       for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-          ((f32x4*)(A.dump_h2 + m * 128 + hw * 64 + mt * 16))[q] =
+          *(f32x4*)(A.dump_h2 + m * 128 + dump_col(mt * 16 + q * 4, hw)) =
               f32x4{fmaxf(G[mt][4 * q], 0.f), fmaxf(G[mt][4 * q + 1], 0.f), fmaxf(G[mt][4 * q + 2], 0.f), fmaxf(G[mt][4 * q + 3], 0.f)};
     }
     float o0 = 0.f, o1 = 0.f, o2 = 0.f;
@@ -1189,13 +1194,13 @@ int ego_train_layout(int32_t which, int32_t* out, int32_t n) {
           const int t = kk - 5 * NSLOT + 8 * h;
           ch = t < 3 ? APP_DIM + t : (t < 15 ? 138 + (t - 3) : -1);
         }
-        out[h * KS1 + kk] = ch;
+        out[dump_col(kk, h)] = ch;
       }
   } else if (which == 1) {  // h1 / h2 / dh1 / dh2 dump column -> hidden unit
     EGO_REQUIRE(n == HID, "train_layout(1): n must be 128");
     for (int h = 0; h < 2; ++h)
       for (int mt = 0; mt < 4; ++mt)
-        for (int r = 0; r < 16; ++r) out[h * 64 + mt * 16 + r] = mt * 32 + slot_row(r, h);
+        for (int r = 0; r < 16; ++r) out[dump_col(mt * 16 + r, h)] = mt * 32 + slot_row(r, h);
   } else if (which == 2) {  // dfe column (within one grid's 32) -> feature (-1: padding)
     EGO_REQUIRE(n == 32, "train_layout(2): n must be 32");
     for (int h = 0; h < 2; ++h)
@@ -1203,7 +1208,7 @@ int ego_train_layout(int32_t which, int32_t* out, int32_t n) {
   } else if (which == 3) {  // v dump column -> basis input column (0..143)
     EGO_REQUIRE(n == 2 * KS_BASIS, "train_layout(3): n must be 144");
     for (int h = 0; h < 2; ++h)
-      for (int kk = 0; kk < KS_BASIS; ++kk) out[h * KS_BASIS + kk] = app_channel_g(kk, h);
+      for (int kk = 0; kk < KS_BASIS; ++kk) out[dump_col(kk, h)] = app_channel_g(kk, h);
   } else {
     return ego_fail(EGO_E_BADARG, "train_layout: which must be 0..3");
   }

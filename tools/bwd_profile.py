@@ -14,7 +14,11 @@ kw = dict(is_train=True, n_coarse=128, n_fine=128, exp_sampling=True, resampling
 jit = torch.rand(N, 128, device=dev); u = torch.rand(N, 128, device=dev)
 from torch.profiler import profile, ProfilerActivity
 for it in range(3):
-    rgb, *_ = model(rays, jitter=jit, u=u, **kw)
+    if it == 2:
+        with profile(activities=[ProfilerActivity.CUDA]) as fprof:
+            rgb, *_ = model(rays, jitter=jit, u=u, **kw); torch.cuda.synchronize()
+    else:
+        rgb, *_ = model(rays, jitter=jit, u=u, **kw)
     loss = torch.mean((rgb - gt) ** 2)
     model.zero_grad(set_to_none=True)
     if it == 2:
@@ -22,6 +26,11 @@ for it in range(3):
             loss.backward(); torch.cuda.synchronize()
     else:
         loss.backward()
+print("---- forward")
+for r in sorted(fprof.key_averages(), key=lambda e: -e.device_time_total)[:8]:
+    print(f"{r.device_time_total / 1000:8.3f} ms  x{r.count:<3d} {r.key[:110]}")
+print("total device ms:", round(sum(r.device_time_total for r in fprof.key_averages()) / 1000, 2))
+print("---- backward")
 rows = sorted(prof.key_averages(), key=lambda e: -e.device_time_total)[:20]
 for r in rows:
     print(f"{r.device_time_total / 1000:8.3f} ms  x{r.count:<3d} {r.key[:110]}")
