@@ -37,8 +37,8 @@ FLOP_SAMPLE_SHADE = 2 * (150 * 128 + 128 * 128 + 128 * 3) + 2 * 144 * 27  # MLP 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)  # 0.7 ms each: amortises the barrier + synchronize bracket
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rays", type=int, default=1024, help="rays in the bounded CPU-baseline sample")
     return ap.parse_args()
@@ -92,7 +92,7 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev)  # RCCL on ROCm
 
-    from tests.helpers import make_model
+    from egonerf_amd.synth import build_model as make_model
     cfg = synth.SceneConfig()
     weights = synth.make_weights(cfg, seed=1234)
     model = make_model(cfg, weights, dev)

@@ -190,3 +190,32 @@ def erp_rays(H: int, W: int, row0: int = 0, row1: int | None = None, origin=(0.0
                                      -np.cos(theta) * np.cos(phi)), -1).reshape(-1, 3)
     o = np.broadcast_to(np.asarray(origin, np.float32), d.shape)
     return np.concatenate([o, d], -1).astype(np.float32)
+
+
+def build_coords(cfg: "SceneConfig", device):
+    """The scene's YinYangSphericalCoords exactly as train.py:118-130 constructs it."""
+    from .coordinates import YinYangSphericalCoords
+    return YinYangSphericalCoords(device, cfg.aabb, exp_r=True, N_voxel=cfg.n_voxel, r0=cfg.r0, interval_th=True)
+
+
+def build_model(cfg: "SceneConfig", weights, device="cuda"):
+    """egonerf_amd EgoNeRF for a synthetic scene, with the reference's ctor kwargs (train.py:163-171 resolved values) and
+    `weights` (reference state_dict layout, e.g. make_weights) loaded."""
+    import torch
+    from .model import EgoNeRF
+    coords = build_coords(cfg, device)
+    assert coords.resolution == cfg.grid
+    model = EgoNeRF(torch.from_numpy(cfg.aabb), cfg.grid, device, coords, density_n_comp=list(cfg.density_n_comp),
+                    appearance_n_comp=list(cfg.app_n_comp), app_dim=cfg.app_dim, near_far=[cfg.near, cfg.far],
+                    shadingMode="MLP_Fea", alphaMask_thres=1e-4, density_shift=cfg.density_shift,
+                    distance_scale=cfg.distance_scale, pos_pe=6, view_pe=cfg.view_pe, fea_pe=cfg.fea_pe, featureC=cfg.featureC,
+                    step_ratio=0.5, fea2denseAct="softplus", use_envmap=cfg.use_envmap, envmap_res_H=cfg.envmap_res_H,
+                    coarse_sigma_grid_update_rule="conv", coarse_sigma_grid_reso=None, interval_th=True)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in weights.items() if k != "envmap.emission"})
+    if cfg.use_envmap:
+        model.envmap.load_envmap(weights["envmap.emission"], device=device)
+    if torch.device(device).type == "cuda":
+        model.update_coarse_sigma_grid()
+    model.eval()
+    return model
+

@@ -22,7 +22,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from egonerf_amd import synth  # noqa: E402
 from egonerf_amd.renderer import erp_rays, psnr_from_sse, shard_bounds, volume_renderer  # noqa: E402
-from tests.helpers import make_model  # noqa: E402
+from egonerf_amd.synth import build_model as make_model  # noqa: E402
 
 
 def pose(k: int, K: int) -> np.ndarray:

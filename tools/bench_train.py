@@ -4,7 +4,7 @@ import sys, os, json, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from egonerf_amd import synth
-from tests.helpers import make_model
+from egonerf_amd.synth import build_model as make_model
 
 dev = torch.device("cuda", 0)
 cfg = synth.SceneConfig()

@@ -3,7 +3,7 @@ import sys, os, json
 import numpy as np, torch
 sys.path.insert(0, "/root/repo")
 from egonerf_amd import synth
-from tests.helpers import make_model
+from egonerf_amd.synth import build_model as make_model
 dev = torch.device("cuda", 0)
 cfg = synth.SceneConfig()
 model = make_model(cfg, synth.make_weights(cfg, seed=1234), dev); model.train()

@@ -2,7 +2,7 @@ import numpy as np, torch, sys, ctypes as C
 sys.path.insert(0,'/root/repo')
 from egonerf_amd import synth, _lib
 from egonerf_amd import train as T
-from tests.helpers import make_model
+from egonerf_amd.synth import build_model as make_model
 cfg=synth.SceneConfig()
 w=synth.make_weights(cfg, seed=1234)
 model=make_model(cfg, w, 'cuda')
