@@ -155,6 +155,11 @@ __device__ __forceinline__ float softplus_shift(float f, float shift) {
   return x > 20.0f ? x : log1pf(expf(x));  // torch softplus, threshold 20
 }
 
+// relu as an integer max: one v_max_i32 (fmaxf costs a canonicalising v_max_f32 first); -0.0 and negatives -> +0.0
+__device__ __forceinline__ float relu_f(float x) {
+  return __builtin_bit_cast(float, max(__builtin_bit_cast(int, x), 0));
+}
+
 __device__ __forceinline__ float sigmoidf(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 // sin and cos of one argument: Cody-Waite reduction by pi/2 (two FMAs) + Cephes minimax polynomials on

@@ -449,7 +449,7 @@ __global__ __launch_bounds__(512) void k_shade(ShadeArgs A) {
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) H[mt][r] = fmaxf(H[mt][r], 0.f);
+      for (int r = 0; r < 16; ++r) H[mt][r] = relu_f(H[mt][r]);
 
     // ---- layer 2: 128 -> 128 (K-outer again), then layer 3: 128 -> 3 on the VALU -----------------------
     f32x16 G[4];
@@ -479,7 +479,7 @@ __global__ __launch_bounds__(512) void k_shade(ShadeArgs A) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const f32x4 w = W3[(mt * 2 + hw) * 16 + r];
-        const float hv = fmaxf(G[mt][r], 0.f);
+        const float hv = relu_f(G[mt][r]);
         o0 = fmaf(hv, w.x, o0); o1 = fmaf(hv, w.y, o1); o2 = fmaf(hv, w.z, o2);
       }
     o0 += __shfl_xor(o0, 32, 64);
@@ -516,7 +516,12 @@ __device__ __forceinline__ void split_pair(float a, float b, bool keep, uint32_t
   b = keep ? b : 0.f;
   const auto hp = __builtin_amdgcn_cvt_pkrtz(a, b);
   hi = __builtin_bit_cast(uint32_t, hp);
-  lo = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(a - (float)hp[0], b - (float)hp[1]));  // residuals are exact
+  // residuals a - hi, b - hi are exact; each is ONE v_fma_mix_f32 (hi * -1 + a) reading the half straight from
+  // the packed register: no v_cvt_f32_f16 back-conversion (VALU and MFMA time add up on this SIMD, tools/coissue_probe.hip)
+  float ra, rb;
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(ra) : "v"(hi), "v"(a));
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(rb) : "v"(hi), "v"(b));
+  lo = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(ra, rb));
 }
 
 __device__ __forceinline__ HL split8(const float x[8], bool keep) {
@@ -975,7 +980,7 @@ __global__ __launch_bounds__(512) void k_shade_h(ShadeArgs A) {
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) H[mt][r] = fmaxf(H[mt][r], 0.f);
+      for (int r = 0; r < 16; ++r) H[mt][r] = relu_f(H[mt][r]);
     if (DUMP && valid) {
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt)
@@ -1029,7 +1034,7 @@ __global__ __launch_bounds__(512) void k_shade_h(ShadeArgs A) {
 #pragma unroll
         for (int q = 0; q < 4; ++q)
           *(f32x4*)(A.dump_h2 + m * 128 + dump_col(mt * 16 + q * 4, hw)) =
-              f32x4{fmaxf(G[mt][4 * q], 0.f), fmaxf(G[mt][4 * q + 1], 0.f), fmaxf(G[mt][4 * q + 2], 0.f), fmaxf(G[mt][4 * q + 3], 0.f)};
+              f32x4{relu_f(G[mt][4 * q]), relu_f(G[mt][4 * q + 1]), relu_f(G[mt][4 * q + 2]), relu_f(G[mt][4 * q + 3])};
     }
     float o0 = 0.f, o1 = 0.f, o2 = 0.f;
 #pragma unroll
@@ -1040,7 +1045,7 @@ __global__ __launch_bounds__(512) void k_shade_h(ShadeArgs A) {
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float hv = fmaxf(G[mt][r], 0.f);
+        const float hv = relu_f(G[mt][r]);
         o0 = fmaf(hv, w3[r].x, o0); o1 = fmaf(hv, w3[r].y, o1); o2 = fmaf(hv, w3[r].z, o2);
       }
     }
