@@ -96,6 +96,36 @@ __device__ __forceinline__ float density_lookup(const DevField& F, int g, float 
   return feat;
 }
 
+// Density feature by 4-lane teams (C == 16: one texel = one 64-B line = the team's four float4 parts): lane = 16 p + s serves
+// sample slot s with part p, so a load instruction touches 16 whole lines instead of 64 quarter-used ones.  Returns the
+// feature of the team's sample in all four of its lanes (relu per plane, EgoNeRF.py:340,346).
+__device__ __forceinline__ float density_team16(const DevField& F, int g, float a_r, float a_th, float a_ph, int p) {
+#pragma clang fp contract(fast)
+  constexpr int C = 16;
+  const VMTaps t = vm_setup(a_r, a_th, a_ph, F.res);
+  float feat = 0.f;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const Lin1 X = t.ax[vm_plane_x(i)], Y = t.ax[vm_plane_y(i)], Ln = t.ax[vm_line_ax(i)];
+    const int W = F.res[vm_plane_x(i)];
+    const float* P = (g ? F.plane[1][i] : F.plane[0][i]) + 4 * p;
+    const float* L = (g ? F.line[1][i] : F.line[0][i]) + 4 * p;
+    const f32x4 t00 = *(const f32x4*)(P + ((int64_t)Y.i0 * W + X.i0) * C), t01 = *(const f32x4*)(P + ((int64_t)Y.i0 * W + X.i1) * C);
+    const f32x4 t10 = *(const f32x4*)(P + ((int64_t)Y.i1 * W + X.i0) * C), t11 = *(const f32x4*)(P + ((int64_t)Y.i1 * W + X.i1) * C);
+    const f32x4 u0 = *(const f32x4*)(L + (int64_t)Ln.i0 * C), u1 = *(const f32x4*)(L + (int64_t)Ln.i1 * C);
+    const float w00 = __fmul_rn(Y.w0, X.w0), w01 = __fmul_rn(Y.w0, X.w1);
+    const float w10 = __fmul_rn(Y.w1, X.w0), w11 = __fmul_rn(Y.w1, X.w1);
+    const f32x4 pv = t00 * w00 + t01 * w01 + t10 * w10 + t11 * w11;
+    const f32x4 lv = u0 * Ln.w0 + u1 * Ln.w1;
+    const f32x4 m = pv * lv;
+    float dot = (m.x + m.y) + (m.z + m.w);
+    dot += __shfl_xor(dot, 16, 64);
+    dot += __shfl_xor(dot, 32, 64);
+    feat += fmaxf(dot, 0.f);
+  }
+  return feat;
+}
+
 template <int C>
 __global__ void k_density_feature(DevField F, const float* __restrict__ c7n, int64_t M, float* __restrict__ out) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -218,7 +248,22 @@ __global__ __launch_bounds__(256) void k_march_density(DevCoords c, DevField F, 
     // occupancy mask (opt-in): unoccupied samples keep sigma = 0 and skip the 18-tap gather
     const bool occupied = !occ.vol || occ_sample(occ, y.yang, a_r, a_th, a_ph) > 0.f;
     float sg = 0.f;
-    if (occupied) {
+    if (C == 16) {
+      // four rounds of 16 samples: round rd serves samples 16 rd .. 16 rd + 15 of this pass; lane 16 p + s keeps round p's result
+      float f = 0.f;
+      const int yg = y.yang ? 1 : 0;
+#pragma unroll
+      for (int rd = 0; rd < 4; ++rd) {
+        const int src = 16 * rd + (lane & 15);
+        const float tr = __shfl(a_r, src, 64), tt = __shfl(a_th, src, 64), tp = __shfl(a_ph, src, 64);
+        const int tg = __shfl(yg, src, 64);
+        const bool tocc = __shfl((int)occupied, src, 64) != 0;
+        float d = 0.f;
+        if (__ballot(tocc) != 0ull) d = density_team16(F, tg, tr, tt, tp, lane >> 4);
+        if ((lane >> 4) == rd) f = d;
+      }
+      if (occupied) sg = softplus ? softplus_shift(f, shift) : fmaxf(f, 0.f);
+    } else if (occupied) {
       const float f = density_lookup<C>(F, y.yang, a_r, a_th, a_ph);
       sg = softplus ? softplus_shift(f, shift) : fmaxf(f, 0.f);
     }
