@@ -648,12 +648,13 @@ __device__ __forceinline__ void team_load(const DevField& F, const VMTaps& t, in
   const int W = F.res[vm_plane_x(I)];
   const float* P = (g ? F.plane[1][I] : F.plane[0][I]) + 4 * p;
   const float* L = (g ? F.line[1][I] : F.line[0][I]) + 4 * p;
-  const f32x4* p00 = (const f32x4*)(P + (Y.i0 * W + X.i0) * APP_C);
-  const f32x4* p01 = (const f32x4*)(P + (Y.i0 * W + X.i1) * APP_C);
-  const f32x4* p10 = (const f32x4*)(P + (Y.i1 * W + X.i0) * APP_C);
-  const f32x4* p11 = (const f32x4*)(P + (Y.i1 * W + X.i1) * APP_C);
-  const f32x4* l0 = (const f32x4*)(L + Ln.i0 * APP_C);
-  const f32x4* l1 = (const f32x4*)(L + Ln.i1 * APP_C);
+  // unsigned element offsets: zero-extension into the 64-bit address is free, sign-extension is an extra VALU instruction
+  const f32x4* p00 = (const f32x4*)(P + (uint32_t)((Y.i0 * W + X.i0) * APP_C));
+  const f32x4* p01 = (const f32x4*)(P + (uint32_t)((Y.i0 * W + X.i1) * APP_C));
+  const f32x4* p10 = (const f32x4*)(P + (uint32_t)((Y.i1 * W + X.i0) * APP_C));
+  const f32x4* p11 = (const f32x4*)(P + (uint32_t)((Y.i1 * W + X.i1) * APP_C));
+  const f32x4* l0 = (const f32x4*)(L + (uint32_t)(Ln.i0 * APP_C));
+  const f32x4* l1 = (const f32x4*)(L + (uint32_t)(Ln.i1 * APP_C));
 #pragma unroll
   for (int i = 0; i < 3; ++i) {  // quad 4i + p: f32x4 index 4i from the p-shifted base
     raw[i] = p00[4 * i]; raw[3 + i] = p01[4 * i]; raw[6 + i] = p10[4 * i]; raw[9 + i] = p11[4 * i];
