@@ -678,13 +678,31 @@ __device__ __forceinline__ void team_finish(const VMTaps& t, const f32x4 raw[18]
 }
 
 // rows of 16 lanes: (ga rows a0..a3, gb rows b0..b3) -> v[idx] rows [a0 b0 a1 b1], v[12+idx] rows [a2 b2 a3 b3]
+// SWAPS: v_permlane16_swap + v_permlane32_swap (two VALU instructions per pair, no LDS).  The stand-alone appearance-feature
+// instantiation (MODE_APP) came out non-reproducible with them — one call in ~5 returned a 16-sample block a few percent
+// off, only in that instantiation (the fused kernel, its activation-dumping variant and MODE_APP + dump are bit-reproducible
+// over thousands of calls; s_nop padding around the swaps did not help; tools/determinism_check.py) — so that one, which is
+// not on the hot path, takes the ds_bpermute form (11 % slower in the fused kernel, irrelevant there).
+template <bool SWAPS>
 __device__ __forceinline__ void team_to_halves(const float ga[12], const float gb[12], float* v) {
+  if (SWAPS) {
 #pragma unroll
-  for (int idx = 0; idx < 12; ++idx) {
-    const u32x2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(ga[idx]), __float_as_uint(gb[idx]), false, false);
-    const u32x2 q = __builtin_amdgcn_permlane32_swap(r.x, r.y, false, false);
-    v[idx] = __uint_as_float(q.x);
-    v[12 + idx] = __uint_as_float(q.y);
+    for (int idx = 0; idx < 12; ++idx) {
+      const u32x2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(ga[idx]), __float_as_uint(gb[idx]), false, false);
+      const u32x2 q = __builtin_amdgcn_permlane32_swap(r.x, r.y, false, false);
+      v[idx] = __uint_as_float(q.x);
+      v[12 + idx] = __uint_as_float(q.y);
+    }
+  } else {
+    const int lane = threadIdx.x & 63, rho = lane >> 4;
+    const int src1 = 16 * (rho >> 1) + (lane & 15), src2 = 32 + src1;
+#pragma unroll
+    for (int idx = 0; idx < 12; ++idx) {
+      const float a1 = __shfl(ga[idx], src1, 64), b1 = __shfl(gb[idx], src1, 64);
+      const float a2 = __shfl(ga[idx], src2, 64), b2 = __shfl(gb[idx], src2, 64);
+      v[idx] = (rho & 1) ? b1 : a1;
+      v[12 + idx] = (rho & 1) ? b2 : a2;
+    }
   }
 }
 
@@ -706,6 +724,7 @@ __device__ __forceinline__ void basis3(const u32x4* __restrict__ BASH, int lane,
   basis_step(f0, v, keep, fe); basis_step(f1, v + 8, keep, fe); basis_step(f2, v + 16, keep, fe);
 }
 
+template <bool SWAPS>
 __device__ __forceinline__ void gather_basis_team(const DevField& F, const TeamSample ts[2], const u32x4* __restrict__ BASH, int lane,
                                                   int g, bool mixed, int gu, f32x16& fe, float* vdump) {
   const int p = lane >> 4;
@@ -721,7 +740,7 @@ __device__ __forceinline__ void gather_basis_team(const DevField& F, const TeamS
   __builtin_amdgcn_sched_barrier(0);
   team_load<0>(F, tB, ts[1].g, p, raw);
   team_finish<0>(tB, raw, gb);
-  team_to_halves(ga, gb, v);
+  team_to_halves<SWAPS>(ga, gb, v);
   dump24(vdump, v);
   __builtin_amdgcn_sched_barrier(0);
   team_load<1>(F, tA, ts[0].g, p, raw);
@@ -731,7 +750,7 @@ __device__ __forceinline__ void gather_basis_team(const DevField& F, const TeamS
   __builtin_amdgcn_sched_barrier(0);
   team_load<1>(F, tB, ts[1].g, p, raw);
   team_finish<1>(tB, raw, gb);
-  team_to_halves(ga, gb, v);
+  team_to_halves<SWAPS>(ga, gb, v);
   dump24(vdump ? vdump + 48 : nullptr, v);
   __builtin_amdgcn_sched_barrier(0);
   team_load<2>(F, tA, ts[0].g, p, raw);
@@ -741,7 +760,7 @@ __device__ __forceinline__ void gather_basis_team(const DevField& F, const TeamS
   __builtin_amdgcn_sched_barrier(0);
   team_load<2>(F, tB, ts[1].g, p, raw);
   team_finish<2>(tB, raw, gb);
-  team_to_halves(ga, gb, v);
+  team_to_halves<SWAPS>(ga, gb, v);
   dump24(vdump ? vdump + 96 : nullptr, v);
   basis3(BASH, lane, 6, g0, keep0, v, fe);
   if (mixed) basis3(BASH, lane, 6, 1, g != 0, v, fe);
@@ -898,7 +917,7 @@ __global__ __launch_bounds__(512) void k_shade_h(ShadeArgs A) {
         float* vd = (DUMP && valid) ? A.dump_v + m * 144 + hw * 4 : nullptr;
         // one gather per tile; a border-straddling wave runs the basis steps of each plane twice (yin weights with the
         // yang lanes zeroed, then the reverse) inside gather_basis_team
-        gather_basis_team(A.F, ts, BASH, lw, g, mixed, gu, fe, vd);
+        gather_basis_team<(MODE != MODE_APP || DUMP)>(A.F, ts, BASH, lw, g, mixed, gu, fe, vd);
       }
     }
 
