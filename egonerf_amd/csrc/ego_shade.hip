@@ -516,11 +516,13 @@ __device__ __forceinline__ void split_pair(float a, float b, bool keep, uint32_t
   b = keep ? b : 0.f;
   const auto hp = __builtin_amdgcn_cvt_pkrtz(a, b);
   hi = __builtin_bit_cast(uint32_t, hp);
-  // residuals a - hi, b - hi are exact; each is ONE v_fma_mix_f32 (hi * -1 + a) reading the half straight from
-  // the packed register: no v_cvt_f32_f16 back-conversion (VALU and MFMA time add up on this SIMD, tools/coissue_probe.hip)
-  float ra, rb;
-  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(ra) : "v"(hi), "v"(a));
-  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(rb) : "v"(hi), "v"(b));
+  // residuals a - hi, b - hi are exact; each is ONE v_fma_mix_f32 (hi * -1 + a) reading the half straight from the packed
+  // register: no v_cvt_f32_f16 back-conversion (VALU and MFMA time add up on this SIMD, tools/coissue_probe.hip).  The -1 is
+  // made opaque so that the fma survives to instruction selection (a literal -1 folds into convert + subtract); the
+  // instruction should come from the compiler rather than from inline asm, which its hazard recogniser cannot see into.
+  float neg1 = -1.0f;
+  asm("" : "+v"(neg1));
+  const float ra = __builtin_fmaf((float)hp[0], neg1, a), rb = __builtin_fmaf((float)hp[1], neg1, b);
   lo = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(ra, rb));
 }
 
@@ -728,8 +730,13 @@ template <bool SWAPS>
 __device__ __forceinline__ void gather_basis_team(const DevField& F, const TeamSample ts[2], const u32x4* __restrict__ BASH, int lane,
                                                   int g, bool mixed, int gu, f32x16& fe, float* vdump) {
   const int p = lane >> 4;
-  const int g0 = mixed ? 0 : gu;            // weight set of the first pass
-  const bool keep0 = !mixed || g == 0;      // a mixed wave keeps only its yin lanes in the first pass
+  // A lane's output column depends only on its own inputs, so a wave that straddles the yin/yang border (rare) runs the
+  // steps with both weight sets on the unmasked products, into two accumulators, and each lane keeps its grid's one at the
+  // end: no per-value masking anywhere, and nothing extra for the waves of one grid.
+  const int g0 = mixed ? 0 : gu;
+  f32x16 fe2;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) fe2[r] = 0.f;
   const VMTaps tA = vm_setup(ts[0].a_r, ts[0].a_th, ts[0].a_ph, F.res), tB = vm_setup(ts[1].a_r, ts[1].a_th, ts[1].a_ph, F.res);
   // one 18-load buffer in flight (72 VGPRs); the next plane's first round is issued right before the MFMAs of the
   // previous plane so that they overlap; the co-resident wave and the MLP phase hide the rest
@@ -744,8 +751,8 @@ __device__ __forceinline__ void gather_basis_team(const DevField& F, const TeamS
   dump24(vdump, v);
   __builtin_amdgcn_sched_barrier(0);
   team_load<1>(F, tA, ts[0].g, p, raw);
-  basis3(BASH, lane, 0, g0, keep0, v, fe);
-  if (mixed) basis3(BASH, lane, 0, 1, g != 0, v, fe);
+  basis3(BASH, lane, 0, g0, true, v, fe);
+  if (mixed) basis3(BASH, lane, 0, 1, true, v, fe2);
   team_finish<1>(tA, raw, ga);
   __builtin_amdgcn_sched_barrier(0);
   team_load<1>(F, tB, ts[1].g, p, raw);
@@ -754,16 +761,20 @@ __device__ __forceinline__ void gather_basis_team(const DevField& F, const TeamS
   dump24(vdump ? vdump + 48 : nullptr, v);
   __builtin_amdgcn_sched_barrier(0);
   team_load<2>(F, tA, ts[0].g, p, raw);
-  basis3(BASH, lane, 3, g0, keep0, v, fe);
-  if (mixed) basis3(BASH, lane, 3, 1, g != 0, v, fe);
+  basis3(BASH, lane, 3, g0, true, v, fe);
+  if (mixed) basis3(BASH, lane, 3, 1, true, v, fe2);
   team_finish<2>(tA, raw, ga);
   __builtin_amdgcn_sched_barrier(0);
   team_load<2>(F, tB, ts[1].g, p, raw);
   team_finish<2>(tB, raw, gb);
   team_to_halves<SWAPS>(ga, gb, v);
   dump24(vdump ? vdump + 96 : nullptr, v);
-  basis3(BASH, lane, 6, g0, keep0, v, fe);
-  if (mixed) basis3(BASH, lane, 6, 1, g != 0, v, fe);
+  basis3(BASH, lane, 6, g0, true, v, fe);
+  if (mixed) basis3(BASH, lane, 6, 1, true, v, fe2);
+  if (mixed) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) fe[r] = g ? fe2[r] : fe[r];
+  }
 }
 
 // ---- half-precision appearance tables (ego_scene.app_f16) --------------------------------------------------------
