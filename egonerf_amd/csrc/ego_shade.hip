@@ -539,31 +539,6 @@ __device__ __forceinline__ HL split8(const float x[8], bool keep) {
   return o;
 }
 
-// 3 quads (12 channels) of plane I starting at quad Q0 of this lane's 24-channel half
-template <int I, int Q0>
-__device__ __forceinline__ void gather_quads3(const DevField& F, const VMTaps& t, int g, int h, float* v) {
-#pragma clang fp contract(fast)
-  const Lin1 X = t.ax[vm_plane_x(I)], Y = t.ax[vm_plane_y(I)], Ln = t.ax[vm_line_ax(I)];
-  const int W = F.res[vm_plane_x(I)];
-  const float* P = (g ? F.plane[1][I] : F.plane[0][I]) + 4 * h + 8 * Q0;
-  const float* L = (g ? F.line[1][I] : F.line[0][I]) + 4 * h + 8 * Q0;
-  const f32x4* p00 = (const f32x4*)(P + (Y.i0 * W + X.i0) * APP_C);
-  const f32x4* p01 = (const f32x4*)(P + (Y.i0 * W + X.i1) * APP_C);
-  const f32x4* p10 = (const f32x4*)(P + (Y.i1 * W + X.i0) * APP_C);
-  const f32x4* p11 = (const f32x4*)(P + (Y.i1 * W + X.i1) * APP_C);
-  const f32x4* l0 = (const f32x4*)(L + Ln.i0 * APP_C);
-  const f32x4* l1 = (const f32x4*)(L + Ln.i1 * APP_C);
-  const float w00 = __fmul_rn(Y.w0, X.w0), w01 = __fmul_rn(Y.w0, X.w1);
-  const float w10 = __fmul_rn(Y.w1, X.w0), w11 = __fmul_rn(Y.w1, X.w1);
-#pragma unroll
-  for (int q = 0; q < 3; ++q) {
-    const f32x4 pv = p00[2 * q] * w00 + p01[2 * q] * w01 + p10[2 * q] * w10 + p11[2 * q] * w11;
-    const f32x4 lv = l0[2 * q] * Ln.w0 + l1[2 * q] * Ln.w1;
-    const f32x4 m = pv * lv;
-    v[q * 4 + 0] = m.x; v[q * 4 + 1] = m.y; v[q * 4 + 2] = m.z; v[q * 4 + 3] = m.w;
-  }
-}
-
 struct BasisFrag {
   h8 hi, lo;
 };
@@ -581,53 +556,6 @@ __device__ __forceinline__ void basis_step(const BasisFrag& a, const float x[8],
   fe = MFMAH(a.hi, b.hi, fe);
   fe = MFMAH(a.lo, b.hi, fe);
   fe = MFMAH(a.hi, b.lo, fe);
-}
-
-// One pass over the 9 basis k-steps with weight set `gsel`.  MASKED: lanes with keep == false contribute zeros
-// (a lane only feeds its own output column), used twice for the rare waves that straddle the yin/yang border.
-__device__ __forceinline__ void dump12(float* dst, const float* v) {
-  if (dst) {
-    f32x4* d = (f32x4*)dst;
-    d[0] = f32x4{v[0], v[1], v[2], v[3]}; d[1] = f32x4{v[4], v[5], v[6], v[7]}; d[2] = f32x4{v[8], v[9], v[10], v[11]};
-  }
-}
-
-template <bool MASKED>
-__device__ __forceinline__ void gather_basis(const DevField& F, const VMTaps& taps, const u32x4* __restrict__ BASH, int lane, int g,
-                                             int h, int gsel, bool keep_in, f32x16& fe, float* vdump = nullptr) {
-  const bool keep = !MASKED || keep_in;  // compile-time true on the uniform path: the selects fold away
-  float v0[24], v1[24], v2[24];
-  BasisFrag f0, f1, f2;
-  gather_quads3<0, 0>(F, taps, g, h, v0);
-  dump12(vdump ? vdump + 0 : nullptr, v0);
-  f0 = basis_frag<0>(BASH, lane, gsel);
-  __builtin_amdgcn_sched_barrier(0);
-  gather_quads3<0, 3>(F, taps, g, h, v0 + 12);
-  dump12(vdump ? vdump + 12 : nullptr, v0 + 12);
-  f1 = basis_frag<1>(BASH, lane, gsel); f2 = basis_frag<2>(BASH, lane, gsel);
-  basis_step(f0, v0, keep, fe);
-  __builtin_amdgcn_sched_barrier(0);
-  gather_quads3<1, 0>(F, taps, g, h, v1);
-  dump12(vdump ? vdump + 24 : nullptr, v1);
-  f0 = basis_frag<3>(BASH, lane, gsel);
-  basis_step(f1, v0 + 8, keep, fe); basis_step(f2, v0 + 16, keep, fe);
-  __builtin_amdgcn_sched_barrier(0);
-  gather_quads3<1, 3>(F, taps, g, h, v1 + 12);
-  dump12(vdump ? vdump + 36 : nullptr, v1 + 12);
-  f1 = basis_frag<4>(BASH, lane, gsel); f2 = basis_frag<5>(BASH, lane, gsel);
-  basis_step(f0, v1, keep, fe);
-  __builtin_amdgcn_sched_barrier(0);
-  gather_quads3<2, 0>(F, taps, g, h, v2);
-  dump12(vdump ? vdump + 48 : nullptr, v2);
-  f0 = basis_frag<6>(BASH, lane, gsel);
-  basis_step(f1, v1 + 8, keep, fe); basis_step(f2, v1 + 16, keep, fe);
-  __builtin_amdgcn_sched_barrier(0);
-  gather_quads3<2, 3>(F, taps, g, h, v2 + 12);
-  dump12(vdump ? vdump + 60 : nullptr, v2 + 12);
-  f1 = basis_frag<7>(BASH, lane, gsel); f2 = basis_frag<8>(BASH, lane, gsel);
-  basis_step(f0, v2, keep, fe);
-  __builtin_amdgcn_sched_barrier(0);
-  basis_step(f1, v2 + 8, keep, fe); basis_step(f2, v2 + 16, keep, fe);
 }
 
 // ---- 4-lane-team gather (fp32 tables, f16x3 kernel) ------------------------------------------------------------------
