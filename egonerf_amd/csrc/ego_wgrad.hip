@@ -1,0 +1,197 @@
+// Weight gradients of the shade backward: G[ca][cb] += sum over samples m of A[m][ca] * B[m][cb] for tall-skinny fp32
+// matrices (M = all samples of the batch, ca <= 128, cb <= 160) — d(W2) = dh2^T h1, d(W1) = dh1^T x, d(W3) = do^T h2,
+// d(basis_g) = dfe_g^T v (train.py's loss.backward() through nn.Linear).  The contraction index is the row index, so a
+// workgroup stages 32 rows at a time through LDS *transposed* ([column][32 samples]) — the layout the MFMA operands need —
+// split into bf16 hi + lo (bf16 keeps the fp32 exponent: gradients of 1e-8 need no scaling), and accumulates its share of
+// the rows in registers with three v_mfma_f32_32x32x16_bf16 per product (hi*hi + lo*hi + hi*lo: 16 significand bits, like
+// bf16x3; the sums run over 10^6 terms and are compared at 2e-4).  A designated column of B can be replaced by ones, which
+// puts the bias gradient (the column sums of A) into the same pass.  One pass over the dumps, HBM-bound.
+#include "ego_device.h"
+#include "ego_host.h"
+
+namespace {
+
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int WG_ROW = 72;  // bytes per LDS row: 32 bf16 samples (64 B) + 8 B padding (2-way instead of 16-way bank conflicts)
+
+struct WgradArgs {
+  const float* A;
+  const float* B;
+  float* G;
+  int64_t M;
+  int32_t lda, ca, ldb, cb, ones_col, ldg, steps_per_wg;
+};
+
+__device__ __forceinline__ void split_bf16_pair(float v0, float v1, uint32_t& hi, uint32_t& lo) {
+  const uint32_t b0 = __float_as_uint(v0), b1 = __float_as_uint(v1);
+  const uint32_t h0 = b0 & 0xffff0000u, h1 = b1 & 0xffff0000u;          // truncated bf16 (exactly representable)
+  const float r0 = __fsub_rn(v0, __uint_as_float(h0)), r1 = __fsub_rn(v1, __uint_as_float(h1));  // exact residuals
+  hi = (h0 >> 16) | h1;
+  lo = (__float_as_uint(r0) >> 16) | (__float_as_uint(r1) & 0xffff0000u);
+}
+
+// One matrix tile = rows [row0, row0 + 32) x columns [0, 32 NB), staged to LDS as [term][column][32 samples].  A thread owns
+// (column quad, sample pair) items: two float4 global loads (fetch, issued a whole step ahead of their use), then eight
+// packed bf16-pair stores (commit).
+template <int NB>
+struct Tile {
+  static constexpr int QUADS = NB * 8;                       // column quads per row
+  static constexpr int ITEMS = (16 * QUADS + 255) / 256;     // items per thread
+  f32x4 v0[ITEMS], v1[ITEMS];
+
+  __device__ __forceinline__ void fetch(const float* __restrict__ X, int ldx, int cx, int64_t row0, int64_t M) {
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+      const int idx = threadIdx.x + 256 * it;
+      const int cq = idx % QUADS, sp = idx / QUADS;
+      const int64_t r0 = row0 + 2 * sp;
+      const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
+      v0[it] = z; v1[it] = z;
+      if (idx < 16 * QUADS && 4 * cq < cx) {
+        if ((ldx & 3) == 0 && 4 * cq + 4 <= cx) {
+          if (r0 < M) v0[it] = *(const f32x4*)(X + r0 * ldx + 4 * cq);
+          if (r0 + 1 < M) v1[it] = *(const f32x4*)(X + (r0 + 1) * ldx + 4 * cq);
+        } else {  // ragged / unaligned rows (the 3-column d(output) matrix)
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (4 * cq + e < cx) {
+              if (r0 < M) v0[it][e] = X[r0 * ldx + 4 * cq + e];
+              if (r0 + 1 < M) v1[it][e] = X[(r0 + 1) * ldx + 4 * cq + e];
+            }
+        }
+      }
+    }
+  }
+
+  __device__ __forceinline__ void commit(int ones_col, int64_t row0, int64_t M, uint8_t* __restrict__ lds) const {
+    constexpr int COLS = NB * 32;
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+      const int idx = threadIdx.x + 256 * it;
+      if (idx >= 16 * QUADS) break;
+      const int cq = idx % QUADS, sp = idx / QUADS;
+      const int64_t r0 = row0 + 2 * sp;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int col = 4 * cq + e;
+        float a = v0[it][e], b = v1[it][e];
+        if (col == ones_col) { a = r0 < M ? 1.f : 0.f; b = r0 + 1 < M ? 1.f : 0.f; }
+        uint32_t hi, lo;
+        split_bf16_pair(a, b, hi, lo);
+        *(uint32_t*)(lds + col * WG_ROW + sp * 4) = hi;
+        *(uint32_t*)(lds + (COLS + col) * WG_ROW + sp * 4) = lo;
+      }
+    }
+  }
+};
+
+__device__ __forceinline__ bf8 frag(const uint8_t* row, int ks, int kb) {
+  const u32x2* p = (const u32x2*)(row + ks * 32 + kb * 16);
+  const u32x2 a = p[0], b = p[1];
+  return __builtin_bit_cast(bf8, u32x4{a.x, a.y, b.x, b.y});
+}
+
+template <int CAB, int CBB>
+__global__ __launch_bounds__(256) void k_wgrad(WgradArgs P) {
+  __shared__ __attribute__((aligned(16))) uint8_t lds[(CAB + CBB) * 32 * 2 * WG_ROW];
+  uint8_t* la = lds;
+  uint8_t* lb = lds + CAB * 32 * 2 * WG_ROW;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 31, kb = lane >> 5;
+  // the CAB x CBB output blocks (32 x 32 each) go to the four waves: a whole block row each when there are four rows (the
+  // A fragment is then shared by the wave's blocks), round-robin (b = wave + 4 k) otherwise
+  constexpr int NBLK = CAB * CBB, MAXB = (NBLK + 3) / 4;
+  f32x16 acc[MAXB];
+#pragma unroll
+  for (int k = 0; k < MAXB; ++k)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
+  const int64_t step0 = (int64_t)blockIdx.x * P.steps_per_wg;
+  Tile<CAB> ta;
+  Tile<CBB> tb;
+  ta.fetch(P.A, P.lda, P.ca, step0 * 32, P.M);
+  tb.fetch(P.B, P.ldb, P.cb, step0 * 32, P.M);
+  for (int st = 0; st < P.steps_per_wg; ++st) {
+    const int64_t row0 = (step0 + st) * 32;
+    if (row0 >= P.M) break;  // uniform over the workgroup
+    ta.commit(-1, row0, P.M, la);
+    tb.commit(P.ones_col, row0, P.M, lb);
+    __syncthreads();
+    if (st + 1 < P.steps_per_wg) {  // next step's rows travel while this step multiplies
+      ta.fetch(P.A, P.lda, P.ca, row0 + 32, P.M);
+      tb.fetch(P.B, P.ldb, P.cb, row0 + 32, P.M);
+    }
+#pragma unroll
+    for (int k = 0; k < MAXB; ++k) {
+      const int b = CAB == 4 ? wave * CBB + k : wave + 4 * k;
+      if (b < NBLK) {
+        const int mt = b / CBB, nt = b % CBB;
+        const uint8_t* ra = la + (32 * mt + i) * WG_ROW;
+        const uint8_t* rb = lb + (32 * nt + i) * WG_ROW;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const bf8 ah = frag(ra, ks, kb), al = frag(ra + CAB * 32 * WG_ROW, ks, kb);
+          const bf8 bh = frag(rb, ks, kb), bl = frag(rb + CBB * 32 * WG_ROW, ks, kb);
+          acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[k], 0, 0, 0);
+          acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[k], 0, 0, 0);
+          acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[k], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+  }
+  // D[row][col]: lane = col + 32 * ((row >> 2) & 1), register (row & 3) + 4 * (row >> 3)
+#pragma unroll
+  for (int k = 0; k < MAXB; ++k) {
+    const int b = CAB == 4 ? wave * CBB + k : wave + 4 * k;
+    if (b < NBLK) {
+      const int mt = b / CBB, nt = b % CBB;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * kb, col = 32 * nt + i;
+        const float v = acc[k][r];
+        if (v != 0.f) unsafeAtomicAdd(P.G + (int64_t)row * P.ldg + col, v);
+      }
+    }
+  }
+}
+
+template <int CAB, int CBB>
+int launch(const WgradArgs& a, hipStream_t st) {
+  WgradArgs p = a;
+  const int64_t steps = (a.M + 31) / 32;
+  const int64_t wgs = steps < 768 ? steps : 768;
+  p.steps_per_wg = (int32_t)((steps + wgs - 1) / wgs);
+  k_wgrad<CAB, CBB><<<(unsigned)((steps + p.steps_per_wg - 1) / p.steps_per_wg), 256, 0, st>>>(p);
+  return ego_launch_status("k_wgrad");
+}
+
+}  // namespace
+
+extern "C" {
+
+int ego_weight_grad(const float* A, int32_t lda, int32_t ca, const float* B, int32_t ldb, int32_t cb, int32_t ones_col, int64_t M,
+                    float* G, int32_t ldg, void* stream) {
+  EGO_REQUIRE(M >= 0 && ca >= 1 && ca <= 128 && cb >= 1 && cb <= 160 && lda >= ca && ldb >= cb && ones_col < 160,
+              "weight_grad: bad size (ca <= 128, cb <= 160)");
+  if (M == 0) return EGO_OK;
+  EGO_REQUIRE(A && B && G, "weight_grad: null argument");
+  const int cab = (ca + 31) / 32;
+  const int cbb = ((ones_col >= cb ? ones_col + 1 : cb) + 31) / 32;
+  EGO_REQUIRE(ldg >= 32 * cbb, "weight_grad: ldg must cover the padded column blocks");
+  WgradArgs a{A, B, G, M, lda, ca, ldb, cb, ones_col, ldg, 0};
+  const hipStream_t st = (hipStream_t)stream;
+  switch (cab * 8 + cbb) {
+    case 1 * 8 + 5: return launch<1, 5>(a, st);
+    case 2 * 8 + 5: return launch<2, 5>(a, st);
+    case 4 * 8 + 5: return launch<4, 5>(a, st);
+    case 4 * 8 + 4: return launch<4, 4>(a, st);
+    default: return ego_fail(EGO_E_UNSUPPORTED, "weight_grad: no instantiation for %d x %d column blocks", cab, cbb);
+  }
+}
+
+}  // extern "C"

@@ -174,32 +174,43 @@ class RenderFunction(torch.autograd.Function):
         ga = _grad_struct(g_app)
         _lib.check(lib.ego_scatter_app(sc, C.byref(ga), sv["coords"].data_ptr(), dv.data_ptr(), N, S, st), "ego_scatter_app")
         del dv
-        # ---- weight gradients: library GEMMs with K = all samples, then un-permute the lane-order columns ----
+        # ---- weight gradients: one pass of ego_weight_grad (bf16 hi/lo MFMA over transposed LDS tiles, bias gradients from a
+        # ones column) per layer over the dumped buffers, then un-permute the lane-order columns ----
         do = dc.view(M, 3)  # now d(pre-sigmoid)
         hid = _layout(1, 128, dev)
         xmap = _layout(0, 160, dev)
         fmap = _layout(2, 32, dev)
         vmap = _layout(3, 144, dev)
         mlp = model.renderModule.mlp
+
+        def wgrad(A, ca, B, cb, ones_col):
+            G = torch.zeros(32 * ((ca + 31) // 32), 160, device=dev)
+            _lib.check(lib.ego_weight_grad(A.data_ptr(), A.shape[1], ca, B.data_ptr(), B.shape[1], cb, ones_col, M, G.data_ptr(), 160, st),
+                       "ego_weight_grad")
+            return G
+
+        G3 = wgrad(do, 3, sv["h2"], 128, 128)
         gw3 = torch.zeros_like(mlp[4].weight)
-        gw3[:, hid] = _tgemm(do, sv["h2"])
-        gb3 = _colsum(do, N)
+        gw3[:, hid] = G3[:3, :128]
+        gb3 = G3[:3, 128].clone()
+        G2 = wgrad(dh2, 128, sv["h1"], 128, 128)
         gw2 = torch.zeros_like(mlp[2].weight)
-        gw2[hid[:, None], hid[None, :]] = _tgemm(dh2, sv["h1"])
+        gw2[hid[:, None], hid[None, :]] = G2[:, :128]
         gb2 = torch.zeros_like(mlp[2].bias)
-        gb2[hid] = _colsum(dh2, N)
-        gw1 = torch.zeros_like(mlp[0].weight)
-        G1 = _tgemm(dh1, sv["x"])
+        gb2[hid] = G2[:, 128]
+        pad = int((xmap < 0).nonzero()[0])  # a padding column of the x dump (holds zeros) doubles as the ones column
+        G1 = wgrad(dh1, 128, sv["x"], 160, pad)
         xv = xmap >= 0
+        gw1 = torch.zeros_like(mlp[0].weight)
         gw1[hid[:, None], xmap[xv][None, :]] = G1[:, xv]
         gb1 = torch.zeros_like(mlp[0].bias)
-        gb1[hid] = _colsum(dh1, N)
+        gb1[hid] = G1[:, pad]
+        Gb = wgrad(dfe, 64, sv["v"], 144, -1)
         gbasis = []
         fv = fmap >= 0
         for g in range(2):
-            Gb = _tgemm(dfe[:, 32 * g: 32 * g + 32].contiguous(), sv["v"])
             gb = torch.zeros(model.app_dim, 144, device=dev)
-            gb[fmap[fv][:, None], vmap[None, :]] = Gb[fv]
+            gb[fmap[fv][:, None], vmap[None, :]] = Gb[32 * g: 32 * g + 32, :144][fv]
             gbasis.append(gb)
         grads = g_dens + g_app + gbasis + [gw1, gb1, gw2, gb2, gw3, gb3]
         if sv["env"] is not None:
