@@ -3,8 +3,8 @@
 // d(basis_g) = dfe_g^T v (train.py's loss.backward() through nn.Linear).  The contraction index is the row index, so a
 // workgroup stages 32 rows at a time through LDS *transposed* ([column][32 samples]) — the layout the MFMA operands need —
 // split into bf16 hi + lo (bf16 keeps the fp32 exponent: gradients of 1e-8 need no scaling), and accumulates its share of
-// the rows in registers with three v_mfma_f32_32x32x16_bf16 per product (hi*hi + lo*hi + hi*lo: 16 significand bits, like
-// bf16x3; the sums run over 10^6 terms and are compared at 2e-4).  A designated column of B can be replaced by ones, which
+// the rows in registers with three v_mfma_f32_32x32x16_bf16 per product (hi*hi + lo*hi + hi*lo: ~17 significand bits per
+// operand, rounded to nearest so the error does not accumulate over the 10^6 terms; compared at 2e-4).  A designated column of B can be replaced by ones, which
 // puts the bias gradient (the column sums of A) into the same pass.  One pass over the dumps, HBM-bound.
 #include "ego_device.h"
 #include "ego_host.h"
@@ -26,12 +26,19 @@ struct WgradArgs {
   int32_t lda, ca, ldb, cb, ones_col, ldg, steps_per_wg;
 };
 
+// fp32 -> bf16 bits in the high half, round to nearest even (finite inputs)
+__device__ __forceinline__ uint32_t bf16_rn(float v) {
+  const uint32_t u = __float_as_uint(v);
+  return (u + 0x7fffu + ((u >> 16) & 1u)) & 0xffff0000u;
+}
+
+// v = hi + lo + O(2^-18 |v|): hi = bf16(v), lo = bf16(v - hi) (the residual is exact in fp32); rounding to nearest keeps the
+// error unbiased — truncation would lose up to 2^-15 |v|, always towards zero, which does not average out over the samples
 __device__ __forceinline__ void split_bf16_pair(float v0, float v1, uint32_t& hi, uint32_t& lo) {
-  const uint32_t b0 = __float_as_uint(v0), b1 = __float_as_uint(v1);
-  const uint32_t h0 = b0 & 0xffff0000u, h1 = b1 & 0xffff0000u;          // truncated bf16 (exactly representable)
-  const float r0 = __fsub_rn(v0, __uint_as_float(h0)), r1 = __fsub_rn(v1, __uint_as_float(h1));  // exact residuals
+  const uint32_t h0 = bf16_rn(v0), h1 = bf16_rn(v1);
+  const float r0 = __fsub_rn(v0, __uint_as_float(h0)), r1 = __fsub_rn(v1, __uint_as_float(h1));
   hi = (h0 >> 16) | h1;
-  lo = (__float_as_uint(r0) >> 16) | (__float_as_uint(r1) & 0xffff0000u);
+  lo = (bf16_rn(r0) >> 16) | bf16_rn(r1);
 }
 
 // One matrix tile = rows [row0, row0 + 32) x columns [0, 32 NB), staged to LDS as [term][column][32 samples].  A thread owns
