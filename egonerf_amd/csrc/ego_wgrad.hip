@@ -44,7 +44,7 @@ __device__ __forceinline__ void split_bf16_pair(float v0, float v1, uint32_t& hi
 // One matrix tile = rows [row0, row0 + 32) x columns [0, 32 NB), staged to LDS as [term][column][32 samples].  A thread owns
 // (column quad, sample pair) items: two float4 global loads (fetch, issued a whole step ahead of their use), then eight
 // packed bf16-pair stores (commit).
-template <int NB>
+template <int NB, bool VEC>
 struct Tile {
   static constexpr int QUADS = NB * 8;                       // column quads per row
   static constexpr int ITEMS = (16 * QUADS + 255) / 256;     // items per thread
@@ -59,10 +59,10 @@ struct Tile {
       const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
       v0[it] = z; v1[it] = z;
       if (idx < 16 * QUADS && 4 * cq < cx) {
-        if ((ldx & 3) == 0 && 4 * cq + 4 <= cx) {
+        if (VEC) {  // ldx and cx are multiples of 4 (checked on the host)
           if (r0 < M) v0[it] = *(const f32x4*)(X + r0 * ldx + 4 * cq);
           if (r0 + 1 < M) v1[it] = *(const f32x4*)(X + (r0 + 1) * ldx + 4 * cq);
-        } else {  // ragged / unaligned rows (the 3-column d(output) matrix)
+        } else {    // ragged / unaligned rows (the 3-column d(output) matrix)
 #pragma unroll
           for (int e = 0; e < 4; ++e)
             if (4 * cq + e < cx) {
@@ -102,8 +102,10 @@ __device__ __forceinline__ bf8 frag(const uint8_t* row, int ks, int kb) {
   return __builtin_bit_cast(bf8, u32x4{a.x, a.y, b.x, b.y});
 }
 
-template <int CAB, int CBB>
-__global__ __launch_bounds__(256) void k_wgrad(WgradArgs P) {
+// 2-3 workgroups per CU hide the row fetches of one behind the multiplies of the others: cap the registers (left alone the
+// compiler takes 272 for the 4 x 5 shape, i.e. one workgroup per CU)
+template <int CAB, int CBB, bool AVEC>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CAB * CBB >= 20 ? 2 : 3, CAB * CBB >= 20 ? 2 : 3))) void k_wgrad(WgradArgs P) {
   __shared__ __attribute__((aligned(16))) uint8_t lds[(CAB + CBB) * 32 * 2 * WG_ROW];
   uint8_t* la = lds;
   uint8_t* lb = lds + CAB * 32 * 2 * WG_ROW;
@@ -118,8 +120,8 @@ __global__ __launch_bounds__(256) void k_wgrad(WgradArgs P) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
   const int64_t step0 = (int64_t)blockIdx.x * P.steps_per_wg;
-  Tile<CAB> ta;
-  Tile<CBB> tb;
+  Tile<CAB, AVEC> ta;
+  Tile<CBB, true> tb;
   ta.fetch(P.A, P.lda, P.ca, step0 * 32, P.M);
   tb.fetch(P.B, P.ldb, P.cb, step0 * 32, P.M);
   for (int st = 0; st < P.steps_per_wg; ++st) {
@@ -167,13 +169,13 @@ __global__ __launch_bounds__(256) void k_wgrad(WgradArgs P) {
   }
 }
 
-template <int CAB, int CBB>
+template <int CAB, int CBB, bool AVEC>
 int launch(const WgradArgs& a, hipStream_t st) {
   WgradArgs p = a;
   const int64_t steps = (a.M + 31) / 32;
   const int64_t wgs = steps < 768 ? steps : 768;
   p.steps_per_wg = (int32_t)((steps + wgs - 1) / wgs);
-  k_wgrad<CAB, CBB><<<(unsigned)((steps + p.steps_per_wg - 1) / p.steps_per_wg), 256, 0, st>>>(p);
+  k_wgrad<CAB, CBB, AVEC><<<(unsigned)((steps + p.steps_per_wg - 1) / p.steps_per_wg), 256, 0, st>>>(p);
   return ego_launch_status("k_wgrad");
 }
 
@@ -190,15 +192,19 @@ int ego_weight_grad(const float* A, int32_t lda, int32_t ca, const float* B, int
   const int cab = (ca + 31) / 32;
   const int cbb = ((ones_col >= cb ? ones_col + 1 : cb) + 31) / 32;
   EGO_REQUIRE(ldg >= 32 * cbb, "weight_grad: ldg must cover the padded column blocks");
+  EGO_REQUIRE((ldb & 3) == 0 && (cb & 3) == 0 && ((uintptr_t)B & 15) == 0, "weight_grad: B rows must be 16-byte aligned, cb a multiple of 4");
+  const bool avec = (lda & 3) == 0 && (ca & 3) == 0 && ((uintptr_t)A & 15) == 0;
   WgradArgs a{A, B, G, M, lda, ca, ldb, cb, ones_col, ldg, 0};
   const hipStream_t st = (hipStream_t)stream;
   switch (cab * 8 + cbb) {
-    case 1 * 8 + 5: return launch<1, 5>(a, st);
-    case 2 * 8 + 5: return launch<2, 5>(a, st);
-    case 4 * 8 + 5: return launch<4, 5>(a, st);
-    case 4 * 8 + 4: return launch<4, 4>(a, st);
-    default: return ego_fail(EGO_E_UNSUPPORTED, "weight_grad: no instantiation for %d x %d column blocks", cab, cbb);
+    case 1 * 8 + 5: return avec ? launch<1, 5, true>(a, st) : launch<1, 5, false>(a, st);
+    case 2 * 8 + 5: if (avec) return launch<2, 5, true>(a, st); break;
+    case 4 * 8 + 5: if (avec) return launch<4, 5, true>(a, st); break;
+    case 4 * 8 + 4: if (avec) return launch<4, 4, true>(a, st); break;
+    default: break;
   }
+  return ego_fail(EGO_E_UNSUPPORTED, "weight_grad: no instantiation for %d x %d column blocks%s", cab, cbb,
+                  avec ? "" : " with unaligned A rows");
 }
 
 }  // extern "C"
