@@ -35,7 +35,8 @@ class Scene(C.Structure):
         ("mlp_in", C.c_int32), ("mlp_hidden", C.c_int32), ("view_pe", C.c_int32), ("fea_pe", C.c_int32),
         ("packed", C.c_void_p), ("envmap", C.c_void_p), ("envmap_h", C.c_int32), ("mlp_precision", C.c_int32),
         ("occ", C.c_void_p), ("occ_res", C.c_int32 * 3), ("term_eps", C.c_float),
-        ("app16", VmField), ("app_f16", C.c_int32), ("reserved2", C.c_int32),
+        ("app16", VmField), ("app_f16", C.c_int32), ("n_r_lut_fine", C.c_int32), ("r_lut_fine", C.c_void_p), ("n_r_fine", C.c_int32),
+        ("reserved2", C.c_int32),
     ]
 
 

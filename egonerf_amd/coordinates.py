@@ -97,13 +97,29 @@ class YinYangSphericalCoords:
             self.ratio = pow(self.far[0] / self.r0, 1 / (self.N_r - 1))
         self._lut_dev = None
 
-    def reference_r_grid(self) -> torch.Tensor:
-        """The [N_r+1] radius LUT the reference rebuilds on every normalize_r call (coordinates.py:116-124)."""
-        ratio = pow(self.far[0] / self.r0, 1 / (self.N_r - 1))
-        return linearised_exp_grid(self.r0, ratio, self.N_r + 1)
+    def reference_r_grid(self, downsample=None) -> torch.Tensor:
+        """Knots of the piecewise-linear radius normalisation, r -> (cell + fraction) / (len - 1).
+        interval_th: the [N_r+1] LUT the reference rebuilds on every normalize_r call (coordinates.py:116-124; `downsample` is
+        ignored there).  Plain exponential grid (coordinates.py:132-155): [0, r0, r0 ratio, ..., r0 ratio^(N-1)] with
+        N = N_r // downsample and ratio = (far / r0)^(1 / (N - 1)); the reference finds the cell with a truncated logarithm,
+        which is the same piecewise-linear map."""
+        if self.interval_th:
+            ratio = pow(self.far[0] / self.r0, 1 / (self.N_r - 1))
+            return linearised_exp_grid(self.r0, ratio, self.N_r + 1)
+        n = self.N_r if downsample is None else self.N_r // downsample
+        ratio = self.ratio if downsample is None else pow(self.far[0] / self.r0, 1 / (n - 1))
+        ratio = torch.as_tensor(ratio, dtype=torch.float32).cpu()
+        knots = self.r0 * torch.pow(ratio, torch.arange(n))
+        return torch.cat([torch.zeros(1), knots]).float()
 
     def sample_schedule(self, near: float, far: float, n_samples: int) -> torch.Tensor:
-        """Radial sample offsets r[S] of EgoNeRF.sample_ray_exp, interval_th branch (EgoNeRF.py:69-76)."""
+        """Radial sample offsets r[S] of EgoNeRF.sample_ray_exp: interval_th branch (EgoNeRF.py:69-76) or the plain
+        exponential schedule (EgoNeRF.py:59-67)."""
+        if not self.interval_th:
+            ratio = 1 + (pi / 2.0) / n_samples
+            r0 = (far - near) * (ratio - 1) / (pow(ratio, n_samples) - 1)
+            rng = torch.arange(n_samples)[None].float()
+            return (torch.pow(ratio, rng) @ torch.tril(torch.ones(n_samples, n_samples), diagonal=-1).T * r0)[0]
         ratio = exp(log((far - near) / self.r0) / (n_samples - 1))
         return linearised_exp_grid(self.r0, ratio, n_samples)
 
@@ -114,6 +130,8 @@ class YinYangSphericalCoords:
         if axis != 0:
             return torch.linspace(-1, 1, n)
         self._require_supported()
+        if not self.interval_th:
+            raise NotImplementedError("up_sampling_VM of the plain exponential r grid (coordinates.py:260-262) is not built")
         ratio = pow(self.far[0] / self.r0, 1 / (n - 1))  # coordinates.py:238 (0-dim tensor pow)
         new = linearised_exp_grid(self.r0, ratio, n)
         G = self.reference_r_grid()
@@ -142,29 +160,37 @@ class YinYangSphericalCoords:
         return torch.nn.Parameter(dst.permute(0, 3, 1, 2))
 
     def _require_supported(self):
-        if not (self.exp_r and self.interval_th):
-            raise NotImplementedError("the HIP path covers exp_r + interval_th coordinates (every shipped EgoNeRF config); "
-                                      "plain-exponential / uniform r grids are out of scope")
+        if not self.exp_r:
+            raise NotImplementedError("the HIP path covers exponential r grids (exp_r; every shipped EgoNeRF config); "
+                                      "uniform r grids are out of scope")
 
-    def lut_device(self, device) -> torch.Tensor:
-        if self._lut_dev is None or self._lut_dev.device != torch.device(device):
-            self._lut_dev = self.reference_r_grid().to(device)
-        return self._lut_dev
+    def lut_device(self, device, downsample=None) -> torch.Tensor:
+        if not isinstance(self._lut_dev, dict):
+            self._lut_dev = {}
+        key = (str(torch.device(device)), None if self.interval_th else downsample)
+        if key not in self._lut_dev:
+            self._lut_dev[key] = self.reference_r_grid(downsample).to(device)
+        return self._lut_dev[key]
 
-    def fill_scene(self, sc: "_lib.Scene", device) -> None:
-        """Writes the coordinate block of the C-ABI scene struct."""
+    def fill_scene(self, sc: "_lib.Scene", device, downsample=2) -> None:
+        """Writes the coordinate block of the C-ABI scene struct.  `downsample` = what the first (or only) pass of the render
+        normalises r with (EgoNeRF.py:524 passes 2; it only matters for the plain exponential grid, whose fine pass after
+        resampling then uses the full grid, EgoNeRF.py:546 -> r_lut_fine)."""
         self._require_supported()
-        lut = self.lut_device(device)
+        lut = self.lut_device(device, downsample)
         sc.center[:] = self.center.tolist()
         sc.ang_near[:] = self.near[1:3].tolist()
         sc.ang_inv[:] = self.inv_diff[1:3].tolist()
         sc.r_lut = lut.data_ptr()
         sc.n_r_lut = lut.numel()
-        sc.n_r = self.N_r
+        sc.n_r = lut.numel() - 1
+        if not self.interval_th and downsample is not None:
+            fine = self.lut_device(device, None)
+            sc.r_lut_fine, sc.n_r_lut_fine, sc.n_r_fine = fine.data_ptr(), fine.numel(), fine.numel() - 1
 
-    def _scene(self, device):
+    def _scene(self, device, downsample=2):
         sc = _lib.Scene()
-        self.fill_scene(sc, device)
+        self.fill_scene(sc, device, downsample)
         return sc
 
     # -- per-point ops (HIP) ---------------------------------------------------------------------------
@@ -179,12 +205,12 @@ class YinYangSphericalCoords:
         return out
 
     def normalize_coord(self, unnormalized_coords: torch.Tensor, downsample=None) -> torch.Tensor:
-        """[...,7] -> [...,7] in [-1,1] (+flag) (coordinates.py:442-466).  `downsample` is accepted and
-        ignored, exactly like the reference's interval_th branch (coordinates.py:112-117)."""
+        """[...,7] -> [...,7] in [-1,1] (+flag) (coordinates.py:442-466).  `downsample` is ignored by the interval_th grid
+        (coordinates.py:112-117) and coarsens the plain exponential one (coordinates.py:137-139)."""
         _require_cuda(unnormalized_coords, "normalize_coord")
         x = unnormalized_coords.contiguous().float()
         out = torch.empty_like(x)
-        sc = self._scene(x.device)
+        sc = self._scene(x.device, downsample)
         _lib.check(_lib.load().ego_normalize_coord(sc, x.data_ptr(), x.numel() // 7, out.data_ptr(), _lib.stream_handle()),
                    "ego_normalize_coord")
         return out

@@ -39,12 +39,13 @@ __host__ inline DevField make_field(const ego_vm_field& f) {
   return d;
 }
 
-__host__ inline DevCoords make_coords(const ego_scene& s) {
+__host__ inline DevCoords make_coords(const ego_scene& s, bool fine_pass = false) {
   DevCoords c;
   c.cx = s.center[0]; c.cy = s.center[1]; c.cz = s.center[2];
   c.th_near = s.ang_near[0]; c.ph_near = s.ang_near[1];
   c.th_inv = s.ang_inv[0]; c.ph_inv = s.ang_inv[1];
   c.r_lut = s.r_lut; c.n_lut = s.n_r_lut; c.n_r = s.n_r;
+  if (fine_pass && s.r_lut_fine) { c.r_lut = s.r_lut_fine; c.n_lut = s.n_r_lut_fine; c.n_r = s.n_r_fine; }
   return c;
 }
 

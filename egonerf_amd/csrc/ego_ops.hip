@@ -674,13 +674,13 @@ int ego_march_density(const ego_scene* sc, const float* rays, int64_t N, int32_t
   EGO_REQUIRE(alpha_stride >= S && alpha_stride <= S + 64, "march_density: alpha_stride must be in [S, S+64]");
   EGO_REQUIRE(z_in || r_sched, "march_density: need z_in or r_sched");
   EGO_REQUIRE(sc->r_lut && sc->n_r_lut >= 2 && sc->n_r_lut <= 1024, "march_density: r_lut missing or > 1024 entries");
-  const ego_vm_field& f = coarse ? sc->density_coarse : sc->density;
+  const ego_vm_field& f = (coarse & 1) ? sc->density_coarse : sc->density;
   if (int e = check_field(f, "march_density")) return e;
   if (N == 0) return EGO_OK;
   if (f.n_comp != 16) return ego_fail(EGO_E_UNSUPPORTED, "march_density: n_comp %d (supported: 16)", f.n_comp);
   k_march_density<16><<<nblk(N, 4), 256, 0, (hipStream_t)stream>>>(
-      make_coords(*sc), make_field(f), rays, N, S, z_in, r_sched, jitter, near_, sc->act_softplus, sc->density_shift,
-      sc->distance_scale, z_out, alpha, alpha_stride, weight, bg_weight, coords_out, sigma_out, make_occ(*sc, coarse), sc->term_eps,
+      make_coords(*sc, (coarse & 2) != 0), make_field(f), rays, N, S, z_in, r_sched, jitter, near_, sc->act_softplus, sc->density_shift,
+      sc->distance_scale, z_out, alpha, alpha_stride, weight, bg_weight, coords_out, sigma_out, make_occ(*sc, coarse & 1), sc->term_eps,
       tile_active);
   return ego_launch_status("k_march_density");
 }

@@ -66,7 +66,7 @@ int ego_render_forward(const ego_scene* sc, const ego_render_args* a, const floa
                                ws + p.wc, nullptr, nullptr, nullptr, nullptr, stream))) return e;
     if ((e = ego_sample_pdf_merge(ws + p.zc, ws + p.wc, a->u, N, a->n_coarse, a->n_fine, a->use_coarse_sample, ws + p.zf,
                                   nullptr, stream))) return e;
-    if ((e = ego_march_density(sc, rays, N, S, ws + p.zf, nullptr, nullptr, a->near_, 0, nullptr, alpha, astride, ws + p.w,
+    if ((e = ego_march_density(sc, rays, N, S, ws + p.zf, nullptr, nullptr, a->near_, 2 /* fine pass: full tables, fine LUT */, nullptr, alpha, astride, ws + p.w,
                                ws + p.bg, ws + p.crd, nullptr, act, stream))) return e;
     z = ws + p.zf;
   } else {

@@ -583,6 +583,9 @@ class EgoNeRF(TensorBase):
                                       "shipped config sets exp_sampling (configs/EgoNeRF/common.txt:4)")
         rays = _f32c(rays_chunk[:, :6])
         N, dev = rays.shape[0], rays.device
+        if is_train and not self.coordinates.interval_th:
+            raise NotImplementedError("is_train with the plain exponential sample schedule (EgoNeRF.py:59-67 jitters the exponent, "
+                                      "not the interval) is not built; every shipped config sets interval_th")
         if is_train:
             if jitter is None:
                 jitter = torch.rand(N, n_coarse).to(dev)  # CPU generator like EgoNeRF.py:81

@@ -103,6 +103,7 @@ class SceneConfig:
     featureC: int = 128
     use_envmap: bool = False
     envmap_res_H: int = 1000
+    interval_th: bool = True  # configs/EgoNeRF/common.txt:19; False = the plain exponential r grid / sample schedule
     grid: List[int] = field(default_factory=list)
 
     def __post_init__(self):
@@ -195,7 +196,7 @@ def erp_rays(H: int, W: int, row0: int = 0, row1: int | None = None, origin=(0.0
 def build_coords(cfg: "SceneConfig", device):
     """The scene's YinYangSphericalCoords exactly as train.py:118-130 constructs it."""
     from .coordinates import YinYangSphericalCoords
-    return YinYangSphericalCoords(device, cfg.aabb, exp_r=True, N_voxel=cfg.n_voxel, r0=cfg.r0, interval_th=True)
+    return YinYangSphericalCoords(device, cfg.aabb, exp_r=True, N_voxel=cfg.n_voxel, r0=cfg.r0, interval_th=cfg.interval_th)
 
 
 def build_model(cfg: "SceneConfig", weights, device="cuda"):
@@ -210,7 +211,7 @@ def build_model(cfg: "SceneConfig", weights, device="cuda"):
                     shadingMode="MLP_Fea", alphaMask_thres=1e-4, density_shift=cfg.density_shift,
                     distance_scale=cfg.distance_scale, pos_pe=6, view_pe=cfg.view_pe, fea_pe=cfg.fea_pe, featureC=cfg.featureC,
                     step_ratio=0.5, fea2denseAct="softplus", use_envmap=cfg.use_envmap, envmap_res_H=cfg.envmap_res_H,
-                    coarse_sigma_grid_update_rule="conv", coarse_sigma_grid_reso=None, interval_th=True)
+                    coarse_sigma_grid_update_rule="conv", coarse_sigma_grid_reso=None, interval_th=cfg.interval_th)
     model.load_state_dict({k: torch.from_numpy(v) for k, v in weights.items() if k != "envmap.emission"})
     if cfg.use_envmap:
         model.envmap.load_envmap(weights["envmap.emission"], device=device)

@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define EGO_ABI_VERSION 3
+#define EGO_ABI_VERSION 4
 
 enum { EGO_PREC_F16X3 = 0, EGO_PREC_F32 = 1 };
 
@@ -109,6 +109,12 @@ typedef struct ego_scene {
    * DESIGN.md. */
   ego_vm_field app16;
   int32_t app_f16;
+  /* Radius LUT of the fine pass after resampling, when it differs from r_lut: with the plain exponential grid
+   * (interval_th = False, coordinates.py:132-155) the first pass normalises r on the `downsample=2` grid (EgoNeRF.py:524) and
+   * the fine pass on the full one (EgoNeRF.py:546).  NULL / 0: the fine pass uses r_lut. */
+  int32_t n_r_lut_fine;
+  const float* r_lut_fine;
+  int32_t n_r_fine;
   int32_t reserved2;
 } ego_scene;
 
@@ -164,8 +170,8 @@ int ego_pack_mlp(const ego_scene* sc, float* packed_out, void* stream);
 /* ---- the fused hot path ------------------------------------------------------------------------ */
 
 /* Sampling -> yin-yang coords -> density lookup -> sigma -> alpha, transmittance scan.
- * z_in [N][S] explicit sample distances, or NULL: z = near + r_sched[s] (+ jitter).  coarse selects the
- * pooled tables.  Outputs (any may be NULL): z_out [N][S], alpha [N][alpha_stride] (alpha_stride 0 = S;
+ * z_in [N][S] explicit sample distances, or NULL: z = near + r_sched[s] (+ jitter).  coarse bit 0 selects the
+ * pooled tables, bit 1 the fine-pass radius LUT (ego_scene.r_lut_fine, if set).  Outputs (any may be NULL): z_out [N][S], alpha [N][alpha_stride] (alpha_stride 0 = S;
  * columns S.. are filled with 1, the reference's trailing ones column when an envmap is present,
  * EgoNeRF.py:587), weight [N][S], bg_weight [N], coords_out [N][S][4] = normalised (r, theta, phi) of the sample's
  * grid + is_yang flag (what ego_shade needs; saves it the acos/atan2/LUT search), sigma_out [N][S] (kept for the

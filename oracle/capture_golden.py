@@ -60,7 +60,7 @@ os.makedirs(OUT, exist_ok=True)
 def build_reference(cfg: synth.SceneConfig, weights):
     aabb = torch.from_numpy(cfg.aabb)
     with contextlib.redirect_stdout(io.StringIO()):
-        coords = YinYangSphericalCoords("cpu", aabb, exp_r=True, N_voxel=cfg.n_voxel, r0=cfg.r0, interval_th=True)
+        coords = YinYangSphericalCoords("cpu", aabb, exp_r=True, N_voxel=cfg.n_voxel, r0=cfg.r0, interval_th=cfg.interval_th)
         reso = coords.N_to_reso(cfg.n_voxel, aabb)
         assert reso == cfg.grid, (reso, cfg.grid)
         model = EgoNeRF(aabb, reso, "cpu", coords, density_n_comp=list(cfg.density_n_comp),
@@ -69,7 +69,7 @@ def build_reference(cfg: synth.SceneConfig, weights):
                         distance_scale=cfg.distance_scale, pos_pe=6, view_pe=cfg.view_pe, fea_pe=cfg.fea_pe,
                         featureC=cfg.featureC, step_ratio=0.5, fea2denseAct="softplus", use_envmap=cfg.use_envmap,
                         envmap_res_H=cfg.envmap_res_H, coarse_sigma_grid_update_rule="conv",
-                        coarse_sigma_grid_reso=None, interval_th=True)
+                        coarse_sigma_grid_reso=None, interval_th=cfg.interval_th)
     sd = {k: torch.from_numpy(v) for k, v in weights.items() if k != "envmap.emission"}
     model.load_state_dict(sd)
     if cfg.use_envmap:
@@ -379,9 +379,35 @@ def capture_metrics():
     np.savez_compressed(os.path.join(OUT, "metrics.npz"), **fx)
 
 
+def capture_plainexp():
+    """interval_th=False: the plain exponential r grid (coordinates.py:132-155, with the `downsample=2` the forward passes,
+    EgoNeRF.py:524) and the matching sample schedule (EgoNeRF.py:59-67).  Eval mode."""
+    cfg = synth.SceneConfig(n_voxel=20 ** 3, interval_th=False)
+    w = synth.make_weights(cfg, seed=1234)
+    model, coords = build_reference(cfg, w)
+    rays = torch.from_numpy(synth.make_rays(64, seed=7))
+    fx = dict(seed_weights=1234, seed_rays=7, rays=rays.numpy())
+    for S in (16, 24, 64):
+        _, z, _ = model.sample_ray_exp(rays[:1, :3], rays[:1, 3:6], is_train=False, N_samples=S)
+        fx[f"sched/{S}"] = np_(z[0])
+    r = torch.cat([torch.linspace(1e-4, 30.0, 4001), torch.tensor([0.03, 0.0300001, 26.8, 26.9])])
+    fx["normr/r"] = np_(r)
+    fx["normr/out"] = np_(coords.normalize_r(r))
+    fx["normr/out_ds2"] = np_(coords.normalize_r(r, downsample=2))
+    xyz, z, _ = model.sample_ray_exp(rays[:, :3], rays[:, 3:6], is_train=False, N_samples=24)
+    c7 = coords.from_cartesian(xyz)
+    fx["c7n_ds2"] = np_(coords.normalize_coord(c7, downsample=2))
+    fx["c7n"] = np_(coords.normalize_coord(c7))
+    o = run_forward(model, rays, n_coarse=24, n_fine=0, resampling=False)
+    fx.update(nr_rgb=np_(o[0]), nr_depth=np_(o[1]), nr_alpha=np_(o[4]))
+    o = run_forward(model, rays, n_coarse=16, n_fine=16, resampling=True, use_coarse_sample=True)
+    fx.update(rs_rgb=np_(o[0]), rs_depth=np_(o[1]))
+    np.savez_compressed(os.path.join(OUT, "tiny_plainexp.npz"), **fx)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
-    which = sys.argv[1:] or ["tiny", "stages", "full", "alpha_mask", "checkpoint", "train_extras", "metrics"]
+    which = sys.argv[1:] or ["tiny", "stages", "full", "alpha_mask", "checkpoint", "train_extras", "metrics", "plainexp"]
     for name in which:
         globals()["capture_" + name]()
         print("captured", name)

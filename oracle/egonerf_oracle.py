@@ -98,8 +98,14 @@ class OracleScene:
 
     # ---- row A: sample schedule -------------------------------------------------------------
     def sample_schedule(self, S: int) -> torch.Tensor:
-        """Radial offsets r[S] (float32) of EgoNeRF.sample_ray_exp, interval_th branch (EgoNeRF.py:69-76)."""
+        """Radial offsets r[S] (float32) of EgoNeRF.sample_ray_exp: interval_th branch (EgoNeRF.py:69-76) or the plain
+        exponential one (EgoNeRF.py:59-67: exclusive prefix sums of r0' ratio^k, ratio = 1 + (pi/2)/S)."""
         c = self.cfg
+        if not getattr(c, "interval_th", True):
+            ratio = 1 + (math.pi / 2.0) / S
+            r0 = (c.far - c.near) * (ratio - 1) / (pow(ratio, S) - 1)
+            rng = torch.arange(S)[None].float()
+            return (torch.pow(ratio, rng) @ torch.tril(torch.ones(S, S), diagonal=-1).T * r0)[0]
         ratio = math.exp(math.log((c.far - c.near) / self.r0) / (S - 1))
         return linearised_exp_grid(self.r0, ratio, S)
 
@@ -131,22 +137,36 @@ class OracleScene:
         return torch.where(yin[..., None], as_yin, as_yang)
 
     # ---- row C: normalisation ----------------------------------------------------------------
-    def normalize_r(self, r: torch.Tensor) -> torch.Tensor:
-        """coordinates.py:110-131,156 (interval_th branch; `downsample` is ignored there)."""
-        G = self.r_lut.to(r.dtype)
+    def normalize_r(self, r: torch.Tensor, downsample=None) -> torch.Tensor:
+        """coordinates.py:110-131,156 (interval_th branch; `downsample` is ignored there) or :132-156 (plain exponential grid:
+        cell index from a logarithm truncated through an int cast, `downsample` coarsens the grid)."""
         n_r = self.grid[0]
+        if not getattr(self.cfg, "interval_th", True):
+            r0 = self.r0
+            if downsample is None:
+                ratio = pow(self.far_r / r0, 1 / (n_r - 1))
+            else:
+                n_r = n_r // downsample
+                ratio = pow(self.far_r / r0, 1 / (n_r - 1))
+            k = (torch.log(r / r0) / torch.log(ratio.to(r.dtype))).to(torch.int32)
+            small = r < r0
+            r_in = torch.where(small, torch.zeros_like(r), r0 * torch.pow(ratio.to(r.dtype), k))
+            r_out = torch.where(small, torch.full_like(r, r0), r0 * torch.pow(ratio.to(r.dtype), k + 1))
+            lin = (r - r_in) / (r_out - r_in)
+            return torch.where(small, r / r0, 1 + k + lin) / n_r
+        G = self.r_lut.to(r.dtype)
         k_out = torch.clamp(torch.searchsorted(G, r.contiguous(), side="right"), 1, G.shape[0] - 1)
         k_in = k_out - 1
         frac = (r - G[k_in]) / (G[k_out] - G[k_in])
         return (k_in + frac) / n_r
 
-    def normalize_coord(self, c7: torch.Tensor) -> torch.Tensor:
-        """coordinates.py:442-466 (exp_r branch)."""
+    def normalize_coord(self, c7: torch.Tensor, downsample=2) -> torch.Tensor:
+        """coordinates.py:442-466 (exp_r branch); EgoNeRF.forward always passes downsample=2 (EgoNeRF.py:524)."""
         near = self.ang_near.to(c7.dtype)
         inv = self.ang_inv.to(c7.dtype)
         parts = []
         for base in (0, 3):
-            parts.append((self.normalize_r(c7[..., base]) * 2 - 1).unsqueeze(-1))
+            parts.append((self.normalize_r(c7[..., base], downsample) * 2 - 1).unsqueeze(-1))
             parts.append((c7[..., base + 1: base + 3] - near) * inv * 2 - 1)
         parts.append(c7[..., 6:7])
         return torch.cat(parts, -1)
@@ -327,7 +347,7 @@ class OracleScene:
             dists = z[..., 1:] - z[..., :-1]
             dists = torch.cat([dists, dists[..., -1:]], -1)
             xyz = o[:, None, :] + viewdirs[:, None, :] * z[..., None]
-            c7n = self.normalize_coord(self.from_cartesian(xyz))
+            c7n = self.normalize_coord(self.from_cartesian(xyz), downsample=None)  # the fine pass: full grid (EgoNeRF.py:546)
             if keep:
                 inter.update(coarse_sigma_feat=sf, coarse_weight=cw, z_new=z_new, z_fine=z)
 

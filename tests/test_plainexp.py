@@ -1,0 +1,71 @@
+"""interval_th = False (plain exponential r grid, coordinates.py:132-155, and sample schedule, EgoNeRF.py:59-67) against
+tests/golden/tiny_plainexp.npz captured from the reference: the oracle's restatement on CPU, the HIP path on the GPU."""
+import numpy as np
+import pytest
+import torch
+
+from egonerf_amd import synth
+from tests.helpers import make_coords, make_model, make_oracle
+
+T = torch.from_numpy
+
+
+def _cfg():
+    return synth.SceneConfig(n_voxel=20 ** 3, interval_th=False)
+
+
+def test_oracle_plain_exponential_grid(golden):
+    fx = golden("tiny_plainexp")
+    cfg = _cfg()
+    sc = make_oracle(cfg, synth.make_weights(cfg, seed=int(fx["seed_weights"])))
+    for S in (16, 24, 64):
+        assert np.array_equal((cfg.near + sc.sample_schedule(S)).numpy(), fx[f"sched/{S}"])
+    r = T(fx["normr/r"])
+    assert np.array_equal(sc.normalize_r(r).numpy(), fx["normr/out"])
+    assert np.array_equal(sc.normalize_r(r, 2).numpy(), fx["normr/out_ds2"])
+    rgb, depth, _, _, alpha = sc.forward(T(fx["rays"]), n_coarse=24)
+    assert float((rgb - T(fx["nr_rgb"])).abs().max()) <= 1e-6 and float((alpha - T(fx["nr_alpha"])).abs().max()) <= 1e-6
+    rgb, depth, *_ = sc.forward(T(fx["rays"]), n_coarse=16, n_fine=16, resampling=True)
+    assert float((rgb - T(fx["rs_rgb"])).abs().max()) <= 1e-6 and float((depth - T(fx["rs_depth"])).abs().max()) <= 2e-5
+
+
+def test_host_schedule_and_lut_reproduce_the_reference(golden):
+    """The product's host-built schedule is bit-exact; its LUT + searchsorted/lerp rule (numpy restatement of the kernel's
+    normalize_r) reproduces the reference's log-based cell search."""
+    fx = golden("tiny_plainexp")
+    cfg = _cfg()
+    c = make_coords(cfg, "cpu")
+    for S in (16, 24, 64):
+        assert np.array_equal((cfg.near + c.sample_schedule(cfg.near, cfg.far, S)).numpy(), fx[f"sched/{S}"])
+    r = fx["normr/r"]
+    for ds, key in ((None, "normr/out"), (2, "normr/out_ds2")):
+        G = c.reference_r_grid(ds).numpy()
+        k_out = np.clip(np.searchsorted(G, r, side="right"), 1, len(G) - 1)
+        k_in = k_out - 1
+        out = ((k_in.astype(np.float32) + (r - G[k_in]) / (G[k_out] - G[k_in])) / np.float32(len(G) - 1)).astype(np.float32)
+        inside = r <= G[-1]  # beyond the last shell the reference keeps exponential cells, the LUT extrapolates linearly
+        assert float(np.abs(out - fx[key])[inside].max()) <= 2e-6, ds
+
+
+@pytest.mark.gpu
+def test_hip_plain_exponential_grid(golden):
+    fx = golden("tiny_plainexp")
+    cfg = _cfg()
+    model = make_model(cfg, synth.make_weights(cfg, seed=int(fx["seed_weights"])), "cuda")
+    rays = T(fx["rays"]).cuda()
+    with torch.no_grad():
+        xyz, z, _ = model.sample_ray_exp(rays[:, :3], rays[:, 3:6], is_train=False, N_samples=24)
+        c7 = model.coordinates.from_cartesian(xyz)
+        for ds, key in ((2, "c7n_ds2"), (None, "c7n")):
+            c7n = model.coordinates.normalize_coord(c7, downsample=ds).cpu().numpy()
+            ok = np.isfinite(fx[key])
+            assert float(np.abs(c7n - fx[key])[ok].max()) <= 4e-6, ds
+        rgb, depth, _, _, alpha = model(rays, n_coarse=24, exp_sampling=True)
+        assert float((rgb.cpu() - T(fx["nr_rgb"])).abs().max()) <= 1e-4
+        assert float((alpha.cpu() - T(fx["nr_alpha"])).abs().max()) <= 1e-4
+        assert float((depth.cpu() - T(fx["nr_depth"])).abs().max()) <= 1e-3
+        rgb, depth, *_ = model(rays, n_coarse=16, n_fine=16, exp_sampling=True, resampling=True)
+        assert float((rgb.cpu() - T(fx["rs_rgb"])).abs().max()) <= 1e-4
+        assert float((depth.cpu() - T(fx["rs_depth"])).abs().max()) <= 1e-3
+    with pytest.raises(NotImplementedError):
+        model(rays, is_train=True, n_coarse=24, exp_sampling=True)
