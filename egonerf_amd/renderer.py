@@ -17,9 +17,10 @@ import torch
 
 def volume_renderer(rays, model, chunk=4096, n_coarse=-1, n_fine=0, ndc_ray=False, white_bg=True, is_train=False,
                     exp_sampling=False, device="cuda", empty_gpu_cache=False, pretrain_envmap=False, pivotal_sample_th=0.0,
-                    resampling=False, use_coarse_sample=True, interval_th=False, jitter=None, u=None):
+                    resampling=False, use_coarse_sample=True, interval_th=False, jitter=None, u=None, keep_alpha=True):
     """renderer.py:11-79.  Returns (rgb [N,3], depth [N], bg|None, env|None, alpha [N,S(+1)]); numpy arrays
-    when `empty_gpu_cache` (per-chunk D2H like the reference), torch tensors otherwise."""
+    when `empty_gpu_cache` (per-chunk D2H like the reference), torch tensors otherwise.  keep_alpha=False drops the
+    per-sample alpha (2 GB for a 1024 x 2048 image at 256 samples; only the entropy loss reads it) and returns None there."""
     if pretrain_envmap:
         return model(rays_chunk=rays.to(device), pretrain_envmap=True)
     outs: List[Tuple] = []
@@ -30,6 +31,8 @@ def volume_renderer(rays, model, chunk=4096, n_coarse=-1, n_fine=0, ndc_ray=Fals
                   exp_sampling=exp_sampling, pivotal_sample_th=pivotal_sample_th, resampling=resampling,
                   use_coarse_sample=use_coarse_sample, interval_th=interval_th,
                   jitter=None if jitter is None else jitter[lo:lo + chunk], u=None if u is None else u[lo:lo + chunk])
+        if not keep_alpha:
+            o = o[:4] + (None,)
         if empty_gpu_cache:
             o = tuple(None if t is None else t.cpu().numpy() for t in o)
         outs.append(o)
@@ -109,7 +112,7 @@ def evaluation_psnr(images_rays: Sequence[torch.Tensor], images_gt: Sequence[tor
     the ranks of the default process group when one is initialised."""
     psnrs = []
     for rays, gt in zip(images_rays, images_gt):
-        fn = lambda block: volume_renderer(block, model, chunk=chunk, device=device, **render_kw)[0]
+        fn = lambda block: volume_renderer(block, model, chunk=chunk, device=device, keep_alpha=False, **render_kw)[0]
         psnrs.append(sharded_render(fn, rays.view(-1, rays.shape[-1]), gt.view(-1, 3))["psnr"])
     return psnrs
 
@@ -129,7 +132,7 @@ def evaluation(images_rays: Sequence[torch.Tensor], images_gt: Sequence[torch.Te
     model.eval()
     psnrs, ssims = [], []
     for rays, gt in zip(images_rays, images_gt):
-        fn = lambda block: volume_renderer(block, model, chunk=chunk, device=device, **render_kw)[0]
+        fn = lambda block: volume_renderer(block, model, chunk=chunk, device=device, keep_alpha=False, **render_kw)[0]
         out = sharded_render(fn, rays.view(-1, rays.shape[-1]), gt.view(-1, 3), gather_image=compute_extra_metrics)
         psnrs.append(out["psnr"])
         if compute_extra_metrics:

@@ -50,7 +50,8 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
     cfg = synth.SceneConfig(**synth.RICOH)
     model = make_model(cfg, synth.make_weights(cfg, seed=1234), dev)
-    kw = dict(chunk=a.chunk, n_coarse=128, n_fine=128, exp_sampling=True, resampling=True, use_coarse_sample=True, device=dev)
+    kw = dict(chunk=a.chunk, n_coarse=128, n_fine=128, exp_sampling=True, resampling=True, use_coarse_sample=True, device=dev,
+              keep_alpha=False)  # an image render reads rgb only (renderer.py:125-157)
     row0, row1 = shard_bounds(a.H, world, rank)  # contiguous block of rows per rank
 
     def render(k):
