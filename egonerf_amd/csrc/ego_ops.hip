@@ -355,6 +355,33 @@ __global__ void k_envmap_bwd(int h, const float* __restrict__ dirs, int dstride,
   }
 }
 
+// Row G alternative — SHRender (models/tensorBase.py:30-34 + models/sh.py:87-112, degree 2): rgb_c = relu(sum_k Y_k(d) f[9c+k] + 0.5)
+__global__ void k_sh_render(const float* __restrict__ dirs, const float* __restrict__ feat, int64_t M, float* __restrict__ rgb) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= M) return;
+  const float x = dirs[i * 3], y = dirs[i * 3 + 1], z = dirs[i * 3 + 2];
+  const float xx = __fmul_rn(x, x), yy = __fmul_rn(y, y), zz = __fmul_rn(z, z);
+  const float xy = __fmul_rn(x, y), yz = __fmul_rn(y, z), xz = __fmul_rn(x, z);
+  float Y[9];
+  Y[0] = 0.28209479177387814f;
+  Y[1] = __fmul_rn(-0.4886025119029199f, y);
+  Y[2] = __fmul_rn(0.4886025119029199f, z);
+  Y[3] = __fmul_rn(-0.4886025119029199f, x);
+  Y[4] = __fmul_rn(1.0925484305920792f, xy);
+  Y[5] = __fmul_rn(-1.0925484305920792f, yz);
+  Y[6] = __fmul_rn(0.31539156525252005f, __fsub_rn(__fsub_rn(__fmul_rn(2.0f, zz), xx), yy));
+  Y[7] = __fmul_rn(-1.0925484305920792f, xz);
+  Y[8] = __fmul_rn(0.5462742152960396f, __fsub_rn(xx, yy));
+  const float* f = feat + i * 27;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) s = __fadd_rn(s, __fmul_rn(Y[k], f[9 * c + k]));
+    rgb[i * 3 + c] = fmaxf(__fadd_rn(s, 0.5f), 0.f);
+  }
+}
+
 // =============================================================================================
 // Row H — compositing, one wave per ray      models/EgoNeRF.py:579-598
 // =============================================================================================
@@ -647,6 +674,14 @@ int ego_envmap_backward(const ego_scene* sc, const float* dirs, int32_t dir_stri
               "envmap_backward: no envmap / null argument");
   k_envmap_bwd<<<nblk(N, 256), 256, 0, (hipStream_t)stream>>>(sc->envmap_h, dirs, dir_stride, g_rgb, rgb_raw, bg_weight, env_map, N, g_emission);
   return ego_launch_status("k_envmap_bwd");
+}
+
+int ego_sh_render(const float* viewdirs, const float* features, int64_t M, float* rgb, void* stream) {
+  EGO_REQUIRE(M >= 0, "sh_render: M < 0");
+  if (M == 0) return EGO_OK;
+  EGO_REQUIRE(viewdirs && features && rgb, "sh_render: null argument");
+  k_sh_render<<<nblk(M, 256), 256, 0, (hipStream_t)stream>>>(viewdirs, features, M, rgb);
+  return ego_launch_status("k_sh_render");
 }
 
 int ego_alpha_mask_sample(const ego_scene* sc, const float* c7n, int64_t M, float* out, void* stream) {

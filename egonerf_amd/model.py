@@ -98,6 +98,20 @@ class EnvironmentMap:
                                      requires_grad=True, device=device, dtype=torch.float32)
 
 
+def SHRender(xyz_sampled, viewdirs: torch.Tensor, features: torch.Tensor) -> torch.Tensor:
+    """models/tensorBase.py:30-34: degree-2 SH colour head, viewdirs [M,3], features [M,27] -> rgb [M,3] = relu(SH . f + 0.5).
+    (`xyz_sampled` is unused, as in the reference.  The reference's EgoNeRF.forward cannot run with this head — it hands
+    SHRender [N,S,3] view directions against [N*S,3,9] features and the broadcast raises — so it is offered as the stage
+    function only.)"""
+    _require_cuda(viewdirs, "SHRender")
+    d, f = _f32c(viewdirs.reshape(-1, 3)), _f32c(features.reshape(-1, 27))
+    if d.shape[0] != f.shape[0]:
+        raise RuntimeError("SHRender: viewdirs and features disagree on the number of points")
+    out = torch.empty(d.shape[0], 3, device=d.device)
+    _call("ego_sh_render", d.data_ptr(), f.data_ptr(), d.shape[0], out.data_ptr(), _lib.stream_handle())
+    return out
+
+
 class MLPRender_Fea(torch.nn.Module):
     """tensorBase.py:54-78.  The Linear layers only hold the weights (state-dict keys `mlp.{0,2,4}.*`);
     forward runs the fused PE + 150->128->128->3 + sigmoid MFMA kernel."""

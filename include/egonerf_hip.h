@@ -153,6 +153,9 @@ int ego_raw2alpha(const float* sigma, const float* dist, int64_t N, int32_t S, f
                   float* bg_weight, void* stream);
 /* viewdirs [M][3], feat [M][app_dim] -> rgb [M][3] */
 int ego_mlp_fea(const ego_scene* sc, const float* viewdirs, const float* feat, int64_t M, float* rgb, void* stream);
+/* models/tensorBase.py:30-34 SHRender with models/sh.py:87-112 (degree-2 real spherical harmonics):
+ * rgb[m][c] = relu(sum_k Y_k(viewdirs[m]) * features[m][9c + k] + 0.5), features [M][27]. */
+int ego_sh_render(const float* viewdirs, const float* features, int64_t M, float* rgb, void* stream);
 /* z [N][Sc] coarse distances, weight [N][Sc] coarse weights (bins = midpoints of z, pdf = weight[1:-1]),
  * u [N][n_fine] or NULL (= linspace(0,1,n_fine), eval mode).  use_coarse != 0: z_out [N][Sc+n_fine] =
  * sort(cat(z, z_new)); else z_out [N][n_fine] = sort(z_new).  z_new_out [N][n_fine] optional (unsorted). */

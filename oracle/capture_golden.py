@@ -405,9 +405,17 @@ def capture_plainexp():
     np.savez_compressed(os.path.join(OUT, "tiny_plainexp.npz"), **fx)
 
 
+def capture_sh():
+    """models/tensorBase.py:30-34 SHRender on flat inputs (the only way the reference's function can be called)."""
+    from models.tensorBase import SHRender
+    d = torch.nn.functional.normalize(torch.from_numpy(synth.hash_uniform(41, 0, 300 * 3).reshape(300, 3).astype(np.float32) * 2 - 1), dim=-1)
+    f = torch.from_numpy(synth.hash_uniform(41, 1, 300 * 27).reshape(300, 27).astype(np.float32) * 4 - 2)
+    np.savez_compressed(os.path.join(OUT, "sh_render.npz"), dirs=d.numpy(), features=f.numpy(), rgb=np_(SHRender(None, d, f)))
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
-    which = sys.argv[1:] or ["tiny", "stages", "full", "alpha_mask", "checkpoint", "train_extras", "metrics", "plainexp"]
+    which = sys.argv[1:] or ["tiny", "stages", "full", "alpha_mask", "checkpoint", "train_extras", "metrics", "plainexp", "sh"]
     for name in which:
         globals()["capture_" + name]()
         print("captured", name)

@@ -484,3 +484,12 @@ def rgb_ssim(img0, img1, max_val, filter_size=11, filter_sigma=1.5, k1=0.01, k2=
     ssim_map = ((2 * mu01 + c1) * (2 * s01 + c2)) / ((mu00 + mu11 + c1) * (s00 + s11 + c2))
     return ssim_map if return_map else float(np.mean(ssim_map))
 
+
+
+def sh_render(viewdirs: torch.Tensor, features: torch.Tensor) -> torch.Tensor:
+    """models/tensorBase.py:30-34 with the degree-2 bases of models/sh.py:87-112."""
+    x, y, z = viewdirs.unbind(-1)
+    c1, c2 = 0.4886025119029199, (1.0925484305920792, -1.0925484305920792, 0.31539156525252005, -1.0925484305920792, 0.5462742152960396)
+    Y = torch.stack([torch.full_like(x, 0.28209479177387814), -c1 * y, c1 * z, -c1 * x, c2[0] * x * y, c2[1] * y * z,
+                     c2[2] * (2.0 * z * z - x * x - y * y), c2[3] * x * z, c2[4] * (x * x - y * y)], -1)
+    return torch.relu((Y[:, None] * features.view(-1, 3, 9)).sum(-1) + 0.5)
