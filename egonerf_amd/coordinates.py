@@ -197,6 +197,8 @@ class YinYangSphericalCoords:
     def from_cartesian(self, xyz_points: torch.Tensor) -> torch.Tensor:
         """[...,3] -> [...,7] (coordinates.py:468-498)."""
         _require_cuda(xyz_points, "from_cartesian")
+        if xyz_points.shape[-1] != 3:
+            raise IndexError(f"from_cartesian: expected [..., 3], got {tuple(xyz_points.shape)}")
         x = xyz_points.contiguous().float()
         out = torch.empty(*x.shape[:-1], 7, device=x.device, dtype=torch.float32)
         sc = self._scene(x.device)
@@ -208,6 +210,8 @@ class YinYangSphericalCoords:
         """[...,7] -> [...,7] in [-1,1] (+flag) (coordinates.py:442-466).  `downsample` is ignored by the interval_th grid
         (coordinates.py:112-117) and coarsens the plain exponential one (coordinates.py:137-139)."""
         _require_cuda(unnormalized_coords, "normalize_coord")
+        if unnormalized_coords.shape[-1] != 7:
+            raise IndexError(f"normalize_coord: expected [..., 7], got {tuple(unnormalized_coords.shape)}")
         x = unnormalized_coords.contiguous().float()
         out = torch.empty_like(x)
         sc = self._scene(x.device, downsample)

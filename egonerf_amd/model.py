@@ -35,6 +35,13 @@ def _call(name: str, *args) -> None:
     _lib.check(getattr(_lib.load(), name)(*args), name)
 
 
+def _last_dim(t: torch.Tensor, n: int, what: str) -> None:
+    """The reference indexes `[..., k]` and fails with an IndexError on a short last axis; a raw-pointer call would silently
+    reinterpret the memory instead."""
+    if t.dim() < 1 or t.shape[-1] != n:
+        raise IndexError(f"{what}: expected [..., {n}], got {tuple(t.shape)}")
+
+
 def _f32c(t: torch.Tensor) -> torch.Tensor:
     return t.contiguous().float()
 
@@ -231,6 +238,7 @@ class YinYangAlphaGridMask(torch.nn.Module):
 
     def sample_alpha(self, norm_samples):
         _require_cuda(norm_samples, "sample_alpha")
+        _last_dim(norm_samples, 7, "sample_alpha")
         c = _f32c(norm_samples)
         out = torch.empty(c.shape[:-1], device=c.device)
         sc = _lib.Scene()
@@ -519,6 +527,7 @@ class EgoNeRF(TensorBase):
 
     def _density(self, coords_sampled, coarse: int):
         _require_cuda(coords_sampled, "compute_densityfeature")
+        _last_dim(coords_sampled, 7, "compute_densityfeature")
         c = _f32c(coords_sampled)
         out = torch.empty(c.shape[:-1], device=c.device)
         _call("ego_density_feature", self.scene(), c.data_ptr(), c.numel() // 7, coarse, out.data_ptr(), _lib.stream_handle())
@@ -535,6 +544,7 @@ class EgoNeRF(TensorBase):
     def compute_appfeature(self, coords_sampled):
         """EgoNeRF.py:349-413: [...,7] -> [..., app_dim]."""
         _require_cuda(coords_sampled, "compute_appfeature")
+        _last_dim(coords_sampled, 7, "compute_appfeature")
         c = _f32c(coords_sampled)
         out = torch.empty(*c.shape[:-1], self.app_dim, device=c.device)
         _call("ego_app_feature", self.scene(), c.data_ptr(), c.numel() // 7, out.data_ptr(), _lib.stream_handle())
@@ -588,6 +598,8 @@ class EgoNeRF(TensorBase):
         alpha [N, S(+1)]).  `white_bg`, `pivotal_sample_th`, `interval_th` are accepted and unused, as in the
         reference.  `jitter` [N,n_coarse] / `u` [N,n_fine] pin the is_train noise."""
         _require_cuda(rays_chunk, "EgoNeRF.forward")
+        if rays_chunk.dim() != 2 or rays_chunk.shape[1] < 6:
+            raise IndexError(f"EgoNeRF.forward: rays_chunk must be [N, >=6] (origin, direction), got {tuple(rays_chunk.shape)}")
         if pretrain_envmap:
             return self.envmap.get_radiance(rays_chunk[:, 3:6])
         if ndc_ray:
