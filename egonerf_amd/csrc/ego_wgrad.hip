@@ -44,22 +44,34 @@ __device__ __forceinline__ void split_bf16_pair(float v0, float v1, uint32_t& hi
 // One matrix tile = rows [row0, row0 + 32) x columns [0, 32 NB), staged to LDS as [term][column][32 samples].  A thread owns
 // (column quad, sample pair) items: two float4 global loads (fetch, issued a whole step ahead of their use), then eight
 // packed bf16-pair stores (commit).
-template <int NB, bool VEC>
+template <int NB, bool VEC, bool BLK>
 struct Tile {
   static constexpr int QUADS = NB * 8;                       // column quads per row
   static constexpr int ITEMS = (16 * QUADS + 255) / 256;     // items per thread
   f32x4 v0[ITEMS], v1[ITEMS];
 
+  // item -> (column quad, sample pair).  Row-major source: consecutive lanes take consecutive quads of one row (coalesced
+  // rows); tile-blocked source (the shade kernels' dump layout, [tile][quad pair][32 h + j][4]): consecutive lanes take
+  // consecutive sample pairs of one quad (512 contiguous bytes per 16 lanes, and conflict-free LDS stores)
+  static __device__ __forceinline__ void item(int idx, int& cq, int& sp) {
+    if (BLK) { sp = idx & 15; cq = idx >> 4; } else { cq = idx % QUADS; sp = idx / QUADS; }
+  }
+
   __device__ __forceinline__ void fetch(const float* __restrict__ X, int ldx, int cx, int64_t row0, int64_t M) {
 #pragma unroll
     for (int it = 0; it < ITEMS; ++it) {
       const int idx = threadIdx.x + 256 * it;
-      const int cq = idx % QUADS, sp = idx / QUADS;
+      int cq, sp;
+      item(idx, cq, sp);
       const int64_t r0 = row0 + 2 * sp;
       const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
       v0[it] = z; v1[it] = z;
       if (idx < 16 * QUADS && 4 * cq < cx) {
-        if (VEC) {  // ldx and cx are multiples of 4 (checked on the host)
+        if (BLK) {  // row0 is a multiple of 32: tile = row0 / 32; logical column quad cq = 2 q + h
+          const float* p = X + row0 * ldx + (cq >> 1) * 256 + ((cq & 1) * 32 + 2 * sp) * 4;
+          if (r0 < M) v0[it] = *(const f32x4*)p;
+          if (r0 + 1 < M) v1[it] = *(const f32x4*)(p + 4);
+        } else if (VEC) {  // ldx and cx are multiples of 4 (checked on the host)
           if (r0 < M) v0[it] = *(const f32x4*)(X + r0 * ldx + 4 * cq);
           if (r0 + 1 < M) v1[it] = *(const f32x4*)(X + (r0 + 1) * ldx + 4 * cq);
         } else {    // ragged / unaligned rows (the 3-column d(output) matrix)
@@ -80,7 +92,8 @@ struct Tile {
     for (int it = 0; it < ITEMS; ++it) {
       const int idx = threadIdx.x + 256 * it;
       if (idx >= 16 * QUADS) break;
-      const int cq = idx % QUADS, sp = idx / QUADS;
+      int cq, sp;
+      item(idx, cq, sp);
       const int64_t r0 = row0 + 2 * sp;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -104,7 +117,7 @@ __device__ __forceinline__ bf8 frag(const uint8_t* row, int ks, int kb) {
 
 // 2-3 workgroups per CU hide the row fetches of one behind the multiplies of the others: cap the registers (left alone the
 // compiler takes 272 for the 4 x 5 shape, i.e. one workgroup per CU)
-template <int CAB, int CBB, bool AVEC>
+template <int CAB, int CBB, bool AVEC, bool ABLK, bool BBLK>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CAB * CBB >= 20 ? 2 : 3, CAB * CBB >= 20 ? 2 : 3))) void k_wgrad(WgradArgs P) {
   __shared__ __attribute__((aligned(16))) uint8_t lds[(CAB + CBB) * 32 * 2 * WG_ROW];
   uint8_t* la = lds;
@@ -120,8 +133,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CAB * CBB >
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
   const int64_t step0 = (int64_t)blockIdx.x * P.steps_per_wg;
-  Tile<CAB, AVEC> ta;
-  Tile<CBB, true> tb;
+  Tile<CAB, AVEC, ABLK> ta;
+  Tile<CBB, true, BBLK> tb;
   ta.fetch(P.A, P.lda, P.ca, step0 * 32, P.M);
   tb.fetch(P.B, P.ldb, P.cb, step0 * 32, P.M);
   for (int st = 0; st < P.steps_per_wg; ++st) {
@@ -169,13 +182,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CAB * CBB >
   }
 }
 
-template <int CAB, int CBB, bool AVEC>
+template <int CAB, int CBB, bool AVEC, bool ABLK, bool BBLK>
 int launch(const WgradArgs& a, hipStream_t st) {
   WgradArgs p = a;
   const int64_t steps = (a.M + 31) / 32;
   const int64_t wgs = steps < 768 ? steps : 768;
   p.steps_per_wg = (int32_t)((steps + wgs - 1) / wgs);
-  k_wgrad<CAB, CBB, AVEC><<<(unsigned)((steps + p.steps_per_wg - 1) / p.steps_per_wg), 256, 0, st>>>(p);
+  k_wgrad<CAB, CBB, AVEC, ABLK, BBLK><<<(unsigned)((steps + p.steps_per_wg - 1) / p.steps_per_wg), 256, 0, st>>>(p);
   return ego_launch_status("k_wgrad");
 }
 
@@ -183,8 +196,8 @@ int launch(const WgradArgs& a, hipStream_t st) {
 
 extern "C" {
 
-int ego_weight_grad(const float* A, int32_t lda, int32_t ca, const float* B, int32_t ldb, int32_t cb, int32_t ones_col, int64_t M,
-                    float* G, int32_t ldg, void* stream) {
+int ego_weight_grad(const float* A, int32_t lda, int32_t ca, int32_t a_blocked, const float* B, int32_t ldb, int32_t cb,
+                    int32_t b_blocked, int32_t ones_col, int64_t M, float* G, int32_t ldg, void* stream) {
   EGO_REQUIRE(M >= 0 && ca >= 1 && ca <= 128 && cb >= 1 && cb <= 160 && lda >= ca && ldb >= cb && ones_col < 160,
               "weight_grad: bad size (ca <= 128, cb <= 160)");
   if (M == 0) return EGO_OK;
@@ -196,15 +209,21 @@ int ego_weight_grad(const float* A, int32_t lda, int32_t ca, const float* B, int
   const bool avec = (lda & 3) == 0 && (ca & 3) == 0 && ((uintptr_t)A & 15) == 0;
   WgradArgs a{A, B, G, M, lda, ca, ldb, cb, ones_col, ldg, 0};
   const hipStream_t st = (hipStream_t)stream;
-  switch (cab * 8 + cbb) {
-    case 1 * 8 + 5: return avec ? launch<1, 5, true>(a, st) : launch<1, 5, false>(a, st);
-    case 2 * 8 + 5: if (avec) return launch<2, 5, true>(a, st); break;
-    case 4 * 8 + 5: if (avec) return launch<4, 5, true>(a, st); break;
-    case 4 * 8 + 4: if (avec) return launch<4, 4, true>(a, st); break;
+  // instantiations: the training step's four products (dh2^T h1, dh1^T x: both blocked; do^T h2: ragged row-major A, blocked
+  // B; dfe^T v: row-major A, blocked B) and the all-row-major forms of the same shapes
+  const int key = (cab * 8 + cbb) * 4 + (a_blocked ? 2 : 0) + (b_blocked ? 1 : 0);
+  switch (key) {
+    case (1 * 8 + 5) * 4 + 0: return avec ? launch<1, 5, true, false, false>(a, st) : launch<1, 5, false, false, false>(a, st);
+    case (1 * 8 + 5) * 4 + 1: return avec ? launch<1, 5, true, false, true>(a, st) : launch<1, 5, false, false, true>(a, st);
+    case (2 * 8 + 5) * 4 + 0: if (avec) return launch<2, 5, true, false, false>(a, st); break;
+    case (2 * 8 + 5) * 4 + 1: if (avec) return launch<2, 5, true, false, true>(a, st); break;
+    case (4 * 8 + 5) * 4 + 0: if (avec) return launch<4, 5, true, false, false>(a, st); break;
+    case (4 * 8 + 5) * 4 + 3: if (avec) return launch<4, 5, true, true, true>(a, st); break;
+    case (4 * 8 + 4) * 4 + 0: if (avec) return launch<4, 4, true, false, false>(a, st); break;
     default: break;
   }
-  return ego_fail(EGO_E_UNSUPPORTED, "weight_grad: no instantiation for %d x %d column blocks%s", cab, cbb,
-                  avec ? "" : " with unaligned A rows");
+  return ego_fail(EGO_E_UNSUPPORTED, "weight_grad: no instantiation for %d x %d column blocks%s (blocked A %d, B %d)", cab, cbb,
+                  avec ? "" : " with unaligned A rows", a_blocked, b_blocked);
 }
 
 }  // extern "C"

@@ -120,7 +120,8 @@ class RenderFunction(torch.autograd.Function):
                                              coords.data_ptr(), sigma.data_ptr(), None, st), "ego_march_density")
         M = N * S
         rgb = f(N, S, 3)
-        dump = dict(x=f(M, 160), h1=f(M, 128), h2=f(M, 128), v=f(M, 144))
+        Mp = (M + 31) // 32 * 32  # the dumps are tile-blocked ([tile][quad pair][lane][4], csrc/ego_shade.hip dump_off): whole tiles
+        dump = dict(x=f(Mp, 160), h1=f(Mp, 128), h2=f(Mp, 128), v=f(Mp, 144))
         ds = _lib.ShadeDump(dump["x"].data_ptr(), dump["h1"].data_ptr(), dump["h2"].data_ptr(), dump["v"].data_ptr())
         _lib.check(lib.ego_shade(sc, rays.data_ptr(), z.data_ptr(), coords.data_ptr(), N, S, rgb.data_ptr(), C.byref(ds), None, st), "ego_shade")
         rgb_map, depth, raw = f(N, 3), f(N), f(N, 3)
@@ -167,7 +168,8 @@ class RenderFunction(torch.autograd.Function):
         _lib.check(lib.ego_scatter_density(sc, C.byref(gd), sv["coords"].data_ptr(), dfeat.data_ptr(), N, S, st), "ego_scatter_density")
         tp = f(lib.ego_train_packed_floats())
         _lib.check(lib.ego_pack_train(sc, tp.data_ptr(), st), "ego_pack_train")
-        dh2, dh1, dfe, dv = f(M, 128), f(M, 128), f(M, 64), f(M, 144)
+        Mp = (M + 31) // 32 * 32
+        dh2, dh1, dfe, dv = f(Mp, 128), f(Mp, 128), f(M, 64), f(M, 144)  # dh2 / dh1: tile-blocked like the dumps
         ds = _lib.ShadeDump(sv["x"].data_ptr(), sv["h1"].data_ptr(), sv["h2"].data_ptr(), sv["v"].data_ptr())
         _lib.check(lib.ego_shade_backward(sc, tp.data_ptr(), sv["coords"].data_ptr(), dc.data_ptr(), sv["rgb"].data_ptr(), C.byref(ds),
                                           dh2.data_ptr(), dh1.data_ptr(), dfe.data_ptr(), dv.data_ptr(), N, S, st), "ego_shade_backward")
@@ -183,29 +185,29 @@ class RenderFunction(torch.autograd.Function):
         vmap = _layout(3, 144, dev)
         mlp = model.renderModule.mlp
 
-        def wgrad(A, ca, B, cb, ones_col):
+        def wgrad(A, ca, a_blocked, B, cb, ones_col):
             G = torch.zeros(32 * ((ca + 31) // 32), 160, device=dev)
-            _lib.check(lib.ego_weight_grad(A.data_ptr(), A.shape[1], ca, B.data_ptr(), B.shape[1], cb, ones_col, M, G.data_ptr(), 160, st),
-                       "ego_weight_grad")
+            _lib.check(lib.ego_weight_grad(A.data_ptr(), A.shape[1], ca, a_blocked, B.data_ptr(), B.shape[1], cb, 1, ones_col, M,
+                                           G.data_ptr(), 160, st), "ego_weight_grad")
             return G
 
-        G3 = wgrad(do, 3, sv["h2"], 128, 128)
+        G3 = wgrad(do, 3, 0, sv["h2"], 128, 128)
         gw3 = torch.zeros_like(mlp[4].weight)
         gw3[:, hid] = G3[:3, :128]
         gb3 = G3[:3, 128].clone()
-        G2 = wgrad(dh2, 128, sv["h1"], 128, 128)
+        G2 = wgrad(dh2, 128, 1, sv["h1"], 128, 128)
         gw2 = torch.zeros_like(mlp[2].weight)
         gw2[hid[:, None], hid[None, :]] = G2[:, :128]
         gb2 = torch.zeros_like(mlp[2].bias)
         gb2[hid] = G2[:, 128]
         pad = int((xmap < 0).nonzero()[0])  # a padding column of the x dump (holds zeros) doubles as the ones column
-        G1 = wgrad(dh1, 128, sv["x"], 160, pad)
+        G1 = wgrad(dh1, 128, 1, sv["x"], 160, pad)
         xv = xmap >= 0
         gw1 = torch.zeros_like(mlp[0].weight)
         gw1[hid[:, None], xmap[xv][None, :]] = G1[:, xv]
         gb1 = torch.zeros_like(mlp[0].bias)
         gb1[hid] = G1[:, pad]
-        Gb = wgrad(dfe, 64, sv["v"], 144, -1)
+        Gb = wgrad(dfe, 64, 0, sv["v"], 144, -1)
         gbasis = []
         fv = fmap >= 0
         for g in range(2):

@@ -250,12 +250,14 @@ int ego_scatter_app(const ego_scene* sc, const ego_vm_grad* gapp, const float* c
  * env_map = the forward's radiance [N][3]; the clamp mask is taken from rgb_raw (pass values in [0,1] for none). */
 int ego_envmap_backward(const ego_scene* sc, const float* dirs, int32_t dir_stride, const float* g_rgb, const float* rgb_raw, const float* bg_weight,
                         const float* env_map, int64_t N, float* g_emission, void* stream);
-/* Weight gradients of nn.Linear layers over all samples: G [32 ceil(ca/32)][ldg] += A^T B for row-major fp32 A [M][lda]
- * (ca <= 128 columns used) and B [M][ldb] (cb <= 160), G accumulated (zero it first).  ones_col >= 0 replaces that column of B
- * by ones (it may lie beyond cb, < 160), which yields the bias gradient = column sums of A in G[:, ones_col].  bf16 hi/lo
- * split MFMA, 16 significand bits per operand. */
-int ego_weight_grad(const float* A, int32_t lda, int32_t ca, const float* B, int32_t ldb, int32_t cb, int32_t ones_col, int64_t M,
-                    float* G, int32_t ldg, void* stream);
+/* Weight gradients of nn.Linear layers over all samples: G [32 ceil(ca/32)][ldg] += A^T B for fp32 A (M rows, ca <= 128
+ * columns used of lda) and B (M rows, cb <= 160 of ldb), G accumulated (zero it first).  a_blocked / b_blocked: the matrix is
+ * stored in the shade kernels' dump layout [tile = m / 32][quad pair q][lane = 32 h + m % 32][4] with logical column
+ * 8 q + 4 h + c (ceil(M / 32) * 32 rows allocated) instead of row-major.  ones_col >= 0 replaces that column of B by ones (it
+ * may lie beyond cb, < 160), which yields the bias gradient = column sums of A in G[:, ones_col].  bf16 hi/lo split MFMA,
+ * ~17 significand bits per operand. */
+int ego_weight_grad(const float* A, int32_t lda, int32_t ca, int32_t a_blocked, const float* B, int32_t ldb, int32_t cb,
+                    int32_t b_blocked, int32_t ones_col, int64_t M, float* G, int32_t ldg, void* stream);
 
 /* ---- training-step table ops (train.py:245-330).  Tables are channel-last [H][W][C].  `value` (device double, may be
  * NULL) and `grad` (device, same layout as the table, may be NULL) are ACCUMULATED into, so one buffer collects a whole

@@ -10,13 +10,22 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
-def _run(A, ca, B, cb, ones_col, G=None):
+def _blocked(X):
+    """Row-major [M, W] -> the shade kernels' dump layout [tile][quad pair q][lane = 32 h + j][4] (logical column 8 q + 4 h + c)."""
+    M, W = X.shape
+    Mp = (M + 31) // 32 * 32
+    P = torch.full((Mp, W), float("nan"))   # padding rows must never be read
+    P[:M] = X
+    return P.view(Mp // 32, 32, W // 8, 2, 4).permute(0, 2, 3, 1, 4).contiguous().view(Mp, W)
+
+
+def _run(A, ca, B, cb, ones_col, G=None, a_blocked=0, b_blocked=0, M=None):
     lib, st = _lib.load(), _lib.stream_handle()
-    M = A.shape[0]
+    M = A.shape[0] if M is None else M
     if G is None:
         G = torch.zeros(32 * ((ca + 31) // 32), 160, device=DEV)
-    _lib.check(lib.ego_weight_grad(A.data_ptr(), A.shape[1], ca, B.data_ptr(), B.shape[1], cb, ones_col, M, G.data_ptr(), 160, st),
-               "ego_weight_grad")
+    _lib.check(lib.ego_weight_grad(A.data_ptr(), A.shape[1], ca, a_blocked, B.data_ptr(), B.shape[1], cb, b_blocked, ones_col, M,
+                                   G.data_ptr(), 160, st), "ego_weight_grad")
     return G
 
 
@@ -37,6 +46,12 @@ def test_weight_grad_matches_float64(ca, lda, cb, ones_col, M):
         bias = A[:, :ca].double().sum(0)
         assert float((G[:ca, ones_col] - bias).abs().max()) <= 5e-5 * float(bias.abs().max())
     assert float(G[ca:].abs().max() if G.shape[0] > ca else 0.0) == 0.0  # padded rows stay zero
+    # the same product with the operands in the tile-blocked dump layout (the forms the training step uses)
+    if cb in (128, 160, 144):
+        ab = lda == 128
+        Gb = _run((_blocked(A) if ab else A).to(DEV), ca, _blocked(B).to(DEV), cb, ones_col, a_blocked=int(ab), b_blocked=1, M=M).cpu().double()
+        assert float((Gb[:ca, cols] - ref[:, cols]).abs().max()) <= 5e-5 * scale
+        assert torch.isfinite(Gb).all()
 
 
 def test_weight_grad_accumulates_and_validates():
@@ -45,6 +60,6 @@ def test_weight_grad_accumulates_and_validates():
     G = _run(A, 128, B, 128, -1, G)
     assert float(G[:128, :128].min()) == 80.0 and float(G[:128, :128].max()) == 80.0
     lib = _lib.load()
-    assert lib.ego_weight_grad(A.data_ptr(), 128, 129, B.data_ptr(), 128, 128, -1, 40, G.data_ptr(), 160, None) == -1
+    assert lib.ego_weight_grad(A.data_ptr(), 128, 129, 0, B.data_ptr(), 128, 128, 0, -1, 40, G.data_ptr(), 160, None) == -1
     assert b"weight_grad" in lib.ego_last_error()
-    assert lib.ego_weight_grad(A.data_ptr(), 128, 96, B.data_ptr(), 128, 128, -1, 40, G.data_ptr(), 160, None) != 0  # no 3 x 4 instance
+    assert lib.ego_weight_grad(A.data_ptr(), 128, 96, 0, B.data_ptr(), 128, 128, 0, -1, 40, G.data_ptr(), 160, None) != 0  # no 3 x 4 instance
