@@ -169,7 +169,7 @@ class RenderFunction(torch.autograd.Function):
         tp = f(lib.ego_train_packed_floats())
         _lib.check(lib.ego_pack_train(sc, tp.data_ptr(), st), "ego_pack_train")
         Mp = (M + 31) // 32 * 32
-        dh2, dh1, dfe, dv = f(Mp, 128), f(Mp, 128), f(M, 64), f(M, 144)  # dh2 / dh1: tile-blocked like the dumps
+        dh2, dh1, dfe, dv = f(Mp, 128), f(Mp, 128), f(M, 64), f(Mp, 144)  # dh2 / dh1 / dv: tile-blocked like the dumps
         ds = _lib.ShadeDump(sv["x"].data_ptr(), sv["h1"].data_ptr(), sv["h2"].data_ptr(), sv["v"].data_ptr())
         _lib.check(lib.ego_shade_backward(sc, tp.data_ptr(), sv["coords"].data_ptr(), dc.data_ptr(), sv["rgb"].data_ptr(), C.byref(ds),
                                           dh2.data_ptr(), dh1.data_ptr(), dfe.data_ptr(), dv.data_ptr(), N, S, st), "ego_shade_backward")

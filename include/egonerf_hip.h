@@ -185,11 +185,12 @@ int ego_march_density(const ego_scene* sc, const float* rays, int64_t N, int32_t
                       float* alpha, int32_t alpha_stride, float* weight, float* bg_weight, float* coords_out, float* sigma_out,
                       uint8_t* tile_active, void* stream);
 
-/* Per-sample activations the training forward keeps for the backward pass (all dev, "lane order": the two lanes
- * (halves h = 0, 1) that serve a sample each own a contiguous run):
- *   x  [M][160]: layer-1 inputs, half h at [h*80 .. h*80+80) in the kernel's K order (ego_train_layout() maps them)
- *   h1 [M][128], h2 [M][128]: post-ReLU hidden activations, half h at [h*64 ..), index m-tile*16 + reg
- *   v  [M][144]: plane x line products, half h at [h*72 ..) */
+/* Per-sample activations the training forward keeps for the backward pass (all dev).  Logical matrices x [M][160] (layer-1
+ * inputs), h1, h2 [M][128] (post-ReLU hidden activations), v [M][144] (plane x line products); element kk of lane half h
+ * is logical column 8 (kk / 4) + 4 h + kk % 4 (ego_train_layout() maps columns to the reference's inputs / units).  Storage
+ * is tile-blocked, lane-major: [tile = m / 32][quad pair q = column / 8][lane = 32 h + m % 32][4 floats], i.e. float offset
+ * tile * 32 * width + q * 256 + (32 h + m % 32) * 4 + c, so each buffer needs ceil(M / 32) * 32 rows.  ego_weight_grad reads
+ * this layout directly (a_blocked / b_blocked). */
 typedef struct ego_shade_dump {
   float* x;
   float* h1;
@@ -236,7 +237,9 @@ int ego_march_backward(const ego_scene* sc, const float* z, const float* alpha, 
                        const float* sigma, const float* bg_weight, const float* rgb, const float* g_rgb, const float* g_alpha,
                        const float* rgb_raw, const float* env_map, int64_t N, int32_t S, float* dc, float* dfeat, void* stream);
 /* shade backward: dc [N][S][3] in = dL/d rgb_sample, out = dL/d(pre-sigmoid).  Writes dh2, dh1 [M][128], dfe [M][64]
- * (grid g at [32g..)) and dv [M][144] = dL/d(plane x line products) in the reference's channel order. */
+ * (grid g at [32g..)) and dv = dL/d(plane x line products).  dh2, dh1 use the tile-blocked layout of the forward's dumps
+ * ([tile = m / 32][quad pair][lane = 32 h + m % 32][4]); dv is [tile][plane * 3 + line][sample][16 channels]; all three need
+ * ceil(M / 32) * 32 rows. */
 int ego_shade_backward(const ego_scene* sc, const float* train_packed, const float* coords, float* dc, const float* rgb,
                        const ego_shade_dump* fwd, float* dh2, float* dh1, float* dfe, float* dv, int64_t N, int32_t S, void* stream);
 /* backward of the VM lookups (autograd of F.grid_sample in EgoNeRF.py:291-347 / :349-413): accumulates into the gradient
@@ -244,7 +247,7 @@ int ego_shade_backward(const ego_scene* sc, const float* train_packed, const flo
 int ego_scatter_density(const ego_scene* sc, const ego_vm_grad* gdensity, const float* coords, const float* dfeat, int64_t N, int32_t S,
                         void* stream);
 int ego_scatter_app(const ego_scene* sc, const ego_vm_grad* gapp, const float* coords, const float* dv, int64_t N, int32_t S,
-                    void* stream);
+                    void* stream); /* dv: ego_shade_backward's blocked layout */
 /* d(envmap.emission) [3][2h][h] += backward of bg_weight * sigmoid(bilinear(emission, dir)) (envmap.py:26-34,
  * EgoNeRF.py:588-590).  dirs = N directions dir_stride floats apart (rays + 3 with stride 6, or a packed [N][3]);
  * env_map = the forward's radiance [N][3]; the clamp mask is taken from rgb_raw (pass values in [0,1] for none). */
