@@ -43,7 +43,7 @@ class Scene(C.Structure):
 class RenderArgs(C.Structure):
     _fields_ = [("n_coarse", C.c_int32), ("n_fine", C.c_int32), ("resampling", C.c_int32),
                 ("use_coarse_sample", C.c_int32), ("r_sched", C.c_void_p), ("jitter", C.c_void_p),
-                ("u", C.c_void_p), ("near_", C.c_float), ("reserved", C.c_int32)]
+                ("u", C.c_void_p), ("near_", C.c_float), ("reserved", C.c_int32), ("z_coarse", C.c_void_p)]
 
 
 class VmGrad(C.Structure):

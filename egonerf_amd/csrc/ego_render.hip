@@ -46,7 +46,7 @@ int ego_render_forward(const ego_scene* sc, const ego_render_args* a, const floa
   EGO_REQUIRE(N >= 0, "render_forward: N < 0");
   if (N == 0) return EGO_OK;
   EGO_REQUIRE(sc && a && rays && workspace && rgb_map, "render_forward: null argument");
-  EGO_REQUIRE(a->r_sched && a->n_coarse >= 2, "render_forward: r_sched missing or n_coarse < 2");
+  EGO_REQUIRE((a->r_sched || a->z_coarse) && a->n_coarse >= 2, "render_forward: r_sched / z_coarse missing or n_coarse < 2");
   EGO_REQUIRE(!a->resampling || a->n_fine >= 1, "render_forward: resampling needs n_fine >= 1");
   const Plan p = make_plan(N, a);
   float* ws = (float*)workspace;
@@ -60,19 +60,20 @@ int ego_render_forward(const ego_scene* sc, const ego_render_args* a, const floa
     const hipError_t me = hipMemsetAsync(act, 0, (size_t)(N * (int64_t)S / 32 + 1), (hipStream_t)stream);
     if (me != hipSuccess) return ego_fail((int)me, "render_forward: hipMemsetAsync failed: %s", hipGetErrorString(me));
   }
+  const float* zc_in = a->z_coarse;  // explicit first-pass distances (exp_sampling=False) or NULL (schedule + jitter)
   if (a->resampling) {
     // coarse pass on the pooled tables -> weights -> inverse-CDF samples merged into the coarse schedule
-    if ((e = ego_march_density(sc, rays, N, a->n_coarse, nullptr, a->r_sched, a->jitter, a->near_, 1, ws + p.zc, nullptr, 0,
-                               ws + p.wc, nullptr, nullptr, nullptr, nullptr, stream))) return e;
-    if ((e = ego_sample_pdf_merge(ws + p.zc, ws + p.wc, a->u, N, a->n_coarse, a->n_fine, a->use_coarse_sample, ws + p.zf,
+    if ((e = ego_march_density(sc, rays, N, a->n_coarse, zc_in, zc_in ? nullptr : a->r_sched, zc_in ? nullptr : a->jitter, a->near_, 1,
+                               zc_in ? nullptr : ws + p.zc, nullptr, 0, ws + p.wc, nullptr, nullptr, nullptr, nullptr, stream))) return e;
+    if ((e = ego_sample_pdf_merge(zc_in ? zc_in : ws + p.zc, ws + p.wc, a->u, N, a->n_coarse, a->n_fine, a->use_coarse_sample, ws + p.zf,
                                   nullptr, stream))) return e;
     if ((e = ego_march_density(sc, rays, N, S, ws + p.zf, nullptr, nullptr, a->near_, 2 /* fine pass: full tables, fine LUT */, nullptr, alpha, astride, ws + p.w,
                                ws + p.bg, ws + p.crd, nullptr, act, stream))) return e;
     z = ws + p.zf;
   } else {
-    if ((e = ego_march_density(sc, rays, N, S, nullptr, a->r_sched, a->jitter, a->near_, 0, ws + p.zc, alpha, astride,
-                               ws + p.w, ws + p.bg, ws + p.crd, nullptr, act, stream))) return e;
-    z = ws + p.zc;
+    if ((e = ego_march_density(sc, rays, N, S, zc_in, zc_in ? nullptr : a->r_sched, zc_in ? nullptr : a->jitter, a->near_, 0,
+                               zc_in ? nullptr : ws + p.zc, alpha, astride, ws + p.w, ws + p.bg, ws + p.crd, nullptr, act, stream))) return e;
+    z = zc_in ? zc_in : ws + p.zc;
   }
   if ((e = ego_shade(sc, rays, z, ws + p.crd, N, S, ws + p.rgb, nullptr, act, stream))) return e;
   return ego_composite(sc, rays, z, ws + p.w, ws + p.bg, ws + p.rgb, N, S, rgb_map, depth, bg_map, env_map, nullptr, stream);

@@ -507,6 +507,30 @@ class EgoNeRF(TensorBase):
             self._sched_cache[key] = self.coordinates.sample_schedule(near, far, n_samples).to(device)
         return self._sched_cache[key]
 
+    def sample_ray_z(self, rays: torch.Tensor, n_samples: int, jitter: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Distances of TensorBase.sample_ray (tensorBase.py:308-327): aabb entry clamped to [near, far] + stepSize * (k [+ U])."""
+        o, d = rays[:, :3], rays[:, 3:6]
+        near, far = self.near_far
+        aabb = self.aabb.to(rays.device, torch.float32)
+        vec = torch.where(d == 0, torch.full_like(d, 1e-6), d)
+        t_min = torch.minimum((aabb[1] - o) / vec, (aabb[0] - o) / vec).amax(-1).clamp(min=near, max=far)
+        rng = torch.arange(n_samples, device=rays.device)[None].float()
+        if jitter is not None:
+            rng = rng.repeat(rays.shape[0], 1) + jitter.to(rays.device, torch.float32)
+        step = self.stepSize.to(rays.device, torch.float32) if torch.is_tensor(self.stepSize) else float(self.stepSize)
+        z = t_min[:, None] + step * rng
+        return z.expand(rays.shape[0], n_samples).contiguous()
+
+    def sample_ray(self, rays_o, rays_d, is_train=True, N_samples=-1, jitter: Optional[torch.Tensor] = None):
+        """tensorBase.py:308-327 -> (rays_pts [N,S,3], interpx [N,S], inside-aabb mask [N,S])."""
+        N_samples = N_samples if N_samples > 0 else self.nSamples
+        if is_train and jitter is None:
+            jitter = torch.rand(rays_o.shape[0], N_samples)
+        z = self.sample_ray_z(torch.cat([rays_o, rays_d], -1).float(), N_samples, jitter if is_train else None)
+        pts = rays_o[..., None, :] + rays_d[..., None, :] * z[..., None]
+        aabb = self.aabb.to(pts.device)
+        return pts, z, ~((aabb[0] > pts) | (pts > aabb[1])).any(dim=-1)
+
     def sample_ray_exp(self, rays_o, rays_d, is_train=True, N_samples=-1, jitter: Optional[torch.Tensor] = None):
         """EgoNeRF.py:56-87 -> (rays_pts [N,S,3], interpx [N,S], ~mask_outbbox [N,S]).  `jitter` [N,S] pins the
         training noise (the reference draws it with torch.rand_like on the CPU generator)."""
@@ -604,12 +628,21 @@ class EgoNeRF(TensorBase):
             return self.envmap.get_radiance(rays_chunk[:, 3:6])
         if ndc_ray:
             raise NotImplementedError  # EgoNeRF.py:503-504
-        if not exp_sampling:
-            raise NotImplementedError("exp_sampling=False (uniform aabb-clipped steps) is outside the HIP path; every "
-                                      "shipped config sets exp_sampling (configs/EgoNeRF/common.txt:4)")
         rays = _f32c(rays_chunk[:, :6])
         N, dev = rays.shape[0], rays.device
-        if is_train and not self.coordinates.interval_th:
+        z_coarse = None
+        if not exp_sampling:
+            # TensorBase.sample_ray (tensorBase.py:308-327): the per-ray uniform schedule is computed here and handed over as
+            # explicit distances; the noise (`rng += rand`) is `jitter`
+            if is_train and jitter is None:
+                jitter = torch.rand(N, n_coarse)  # CPU generator like tensorBase.py:320
+            z_coarse = self.sample_ray_z(rays, n_coarse, jitter.to(dev) if is_train else None)
+            if not is_train:
+                if N and not bool((z_coarse[:, 0] == z_coarse[0, 0]).all()):
+                    raise NotImplementedError("exp_sampling=False in eval mode with rays that enter the aabb at different distances: "
+                                              "the reference then measures every ray with ray 0's distances (EgoNeRF.py:515-516)")
+            jitter = None
+        if is_train and exp_sampling and not self.coordinates.interval_th:
             raise NotImplementedError("is_train with the plain exponential sample schedule (EgoNeRF.py:59-67 jitters the exponent, "
                                       "not the interval) is not built; every shipped config sets interval_th")
         if is_train:
@@ -623,13 +656,15 @@ class EgoNeRF(TensorBase):
             jitter = u = None
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             from .train import render_train  # differentiable path: keeps activations, backward in HIP (egonerf_amd/train.py)
-            return render_train(self, rays, n_coarse, n_fine, resampling, use_coarse_sample, jitter, u)
+            return render_train(self, rays, n_coarse, n_fine, resampling, use_coarse_sample, jitter, u, z_coarse)
         sc = self.scene()
         args = _lib.RenderArgs()
         args.n_coarse, args.n_fine = int(n_coarse), int(n_fine)
         args.resampling, args.use_coarse_sample = int(bool(resampling)), int(bool(use_coarse_sample))
         args.r_sched = self._sched(n_coarse, dev).data_ptr()
         args.near_ = float(self.near_far[0])
+        if z_coarse is not None:
+            args.z_coarse = z_coarse.data_ptr()
         if jitter is not None:
             args.jitter = jitter.data_ptr()
         if u is not None:

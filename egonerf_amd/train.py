@@ -98,6 +98,7 @@ class RenderFunction(torch.autograd.Function):
         n_coarse, n_fine = opts["n_coarse"], opts["n_fine"]
         resampling, use_coarse = opts["resampling"], opts["use_coarse_sample"]
         jitter, u = opts["jitter"], opts["u"]
+        zc_in = opts.get("z_coarse")  # explicit first-pass distances (exp_sampling=False) instead of schedule + jitter
         near = float(model.near_far[0])
         sched = model._sched(n_coarse, dev)
         S = (n_coarse + n_fine if use_coarse else n_fine) if resampling else n_coarse
@@ -106,16 +107,19 @@ class RenderFunction(torch.autograd.Function):
         coords = f(N, S, 4)
         astride = alpha.shape[1]
         if resampling:
-            zc, wc = f(N, n_coarse), f(N, n_coarse)
-            _lib.check(lib.ego_march_density(sc, rays.data_ptr(), N, n_coarse, None, sched.data_ptr(), _lib.ptr(jitter), near, 1,
-                                             zc.data_ptr(), None, 0, wc.data_ptr(), None, None, None, None, st), "ego_march_density")
+            zc, wc = (f(N, n_coarse) if zc_in is None else zc_in), f(N, n_coarse)
+            _lib.check(lib.ego_march_density(sc, rays.data_ptr(), N, n_coarse, _lib.ptr(zc_in), None if zc_in is not None else sched.data_ptr(),
+                                             None if zc_in is not None else _lib.ptr(jitter), near, 1,
+                                             None if zc_in is not None else zc.data_ptr(), None, 0, wc.data_ptr(), None, None, None, None, st),
+                       "ego_march_density")
             _lib.check(lib.ego_sample_pdf_merge(zc.data_ptr(), wc.data_ptr(), _lib.ptr(u), N, n_coarse, n_fine, int(use_coarse),
                                                 z.data_ptr(), None, st), "ego_sample_pdf_merge")
             _lib.check(lib.ego_march_density(sc, rays.data_ptr(), N, S, z.data_ptr(), None, None, near, 0, None, alpha.data_ptr(),
                                              astride, weight.data_ptr(), bg.data_ptr(), coords.data_ptr(), sigma.data_ptr(), None, st),
                        "ego_march_density")
         else:
-            _lib.check(lib.ego_march_density(sc, rays.data_ptr(), N, S, None, sched.data_ptr(), _lib.ptr(jitter), near, 0,
+            _lib.check(lib.ego_march_density(sc, rays.data_ptr(), N, S, _lib.ptr(zc_in), None if zc_in is not None else sched.data_ptr(),
+                                             None if zc_in is not None else _lib.ptr(jitter), near, 0,
                                              z.data_ptr(), alpha.data_ptr(), astride, weight.data_ptr(), bg.data_ptr(),
                                              coords.data_ptr(), sigma.data_ptr(), None, st), "ego_march_density")
         M = N * S
@@ -254,10 +258,10 @@ class EnvRadianceFunction(torch.autograd.Function):
 
 
 def render_train(model, rays, n_coarse, n_fine=0, resampling=False, use_coarse_sample=True, jitter: Optional[torch.Tensor] = None,
-                 u: Optional[torch.Tensor] = None):
+                 u: Optional[torch.Tensor] = None, z_coarse: Optional[torch.Tensor] = None):
     """Differentiable EgoNeRF.forward (is_train semantics) -> (rgb_map, depth, bg_map|None, env_map|None, alpha)."""
     opts = dict(n_coarse=int(n_coarse), n_fine=int(n_fine), resampling=bool(resampling), use_coarse_sample=bool(use_coarse_sample),
-                jitter=jitter, u=u)
+                jitter=jitter, u=u, z_coarse=z_coarse)
     params = differentiable_params(model)
     if model.envmap is not None:
         params = params + [model.envmap.emission]

@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define EGO_ABI_VERSION 4
+#define EGO_ABI_VERSION 5
 
 enum { EGO_PREC_F16X3 = 0, EGO_PREC_F32 = 1 };
 
@@ -306,6 +306,9 @@ typedef struct ego_render_args {
   const float* u;       /* dev [N][n_fine] or NULL (eval: linspace) */
   float near_;
   int32_t reserved;
+  const float* z_coarse; /* dev [N][n_coarse] explicit distances of the first pass, or NULL.  Overrides r_sched / jitter: the
+                          * exp_sampling=False path, TensorBase.sample_ray (tensorBase.py:308-327), whose per-ray schedule the
+                          * host computes */
 } ego_render_args;
 
 /* Whole EgoNeRF.forward for N rays.  S_out = n_coarse (no resampling) | n_coarse+n_fine | n_fine.

@@ -413,9 +413,36 @@ def capture_sh():
     np.savez_compressed(os.path.join(OUT, "sh_render.npz"), dirs=d.numpy(), features=f.numpy(), rgb=np_(SHRender(None, d, f)))
 
 
+def capture_uniform():
+    """exp_sampling=False: TensorBase.sample_ray (tensorBase.py:308-327) feeding EgoNeRF.forward — per-ray aabb entry + uniform
+    steps of stepSize; eval (both resampling modes) and train with the noise pinned."""
+    cfg = synth.SceneConfig(n_voxel=20 ** 3)
+    w = synth.make_weights(cfg, seed=1234)
+    model, coords = build_reference(cfg, w)
+    rays = torch.from_numpy(synth.make_rays(64, seed=7))
+    fx = dict(seed_weights=1234, seed_rays=7, rays=rays.numpy(), step_size=np.float32(float(model.stepSize)))
+
+    def fwd(**kw):
+        with contextlib.redirect_stdout(io.StringIO()):
+            return volume_renderer(rays, model, chunk=4096, exp_sampling=False, device="cpu", interval_th=True, **kw)
+
+    xyz, z, _ = model.sample_ray(rays[:, :3], rays[:, 3:6], is_train=False, N_samples=24)
+    fx.update(z_eval=np_(z), xyz_eval=np_(xyz))
+    o = fwd(n_coarse=24, n_fine=0, resampling=False)
+    fx.update(nr_rgb=np_(o[0]), nr_depth=np_(o[1]), nr_alpha=np_(o[4]))
+    o = fwd(n_coarse=16, n_fine=16, resampling=True, use_coarse_sample=True)
+    fx.update(rs_rgb=np_(o[0]), rs_depth=np_(o[1]))
+    jit = torch.from_numpy(synth.hash_uniform(12, 0, 64 * 16).reshape(64, 16).astype(np.float32))
+    uu = torch.from_numpy(synth.hash_uniform(12, 1, 64 * 16).reshape(64, 16).astype(np.float32))
+    with patched_rand([jit], [uu]):
+        o = fwd(n_coarse=16, n_fine=16, resampling=True, use_coarse_sample=True, is_train=True)
+    fx.update(tr_jitter=np_(jit), tr_u=np_(uu), tr_rgb=np_(o[0]), tr_depth=np_(o[1]))
+    np.savez_compressed(os.path.join(OUT, "tiny_uniform.npz"), **fx)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
-    which = sys.argv[1:] or ["tiny", "stages", "full", "alpha_mask", "checkpoint", "train_extras", "metrics", "plainexp", "sh"]
+    which = sys.argv[1:] or ["tiny", "stages", "full", "alpha_mask", "checkpoint", "train_extras", "metrics", "plainexp", "sh", "uniform"]
     for name in which:
         globals()["capture_" + name]()
         print("captured", name)

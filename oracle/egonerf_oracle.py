@@ -109,6 +109,20 @@ class OracleScene:
         ratio = math.exp(math.log((c.far - c.near) / self.r0) / (S - 1))
         return linearised_exp_grid(self.r0, ratio, S)
 
+    def sample_ray(self, rays_o, rays_d, S: int, jitter: Optional[torch.Tensor] = None, step_ratio: float = 0.5):
+        """tensorBase.py:308-327 (exp_sampling=False): aabb entry distance clamped to [near, far], then uniform steps of
+        stepSize = mean(aabbSize / (gridSize - 1)) * step_ratio (tensorBase.py:206-217); train: + U[0,1) steps."""
+        c = self.cfg
+        aabb = self.aabb.to(rays_o.dtype)
+        step = ((aabb[1] - aabb[0]) / (torch.tensor(self.grid, dtype=torch.float32) - 1)).mean() * step_ratio
+        vec = torch.where(rays_d == 0, torch.full_like(rays_d, 1e-6), rays_d)
+        t_min = torch.minimum((aabb[1] - rays_o) / vec, (aabb[0] - rays_o) / vec).amax(-1).clamp(min=c.near, max=c.far)
+        rng = torch.arange(S)[None].float()
+        if jitter is not None:
+            rng = rng.repeat(rays_d.shape[-2], 1) + jitter
+        z = t_min[..., None] + step.to(rays_o.dtype) * rng.to(rays_o.dtype)
+        return rays_o[..., None, :] + rays_d[..., None, :] * z[..., None], z
+
     def sample_ray_exp(self, rays_o, rays_d, S: int, jitter: Optional[torch.Tensor] = None):
         """EgoNeRF.py:56-87.  `jitter` [N,S] in [0,1) replaces torch.rand_like for is_train."""
         r = self.sample_schedule(S).repeat(rays_d.shape[-2], 1)
@@ -313,7 +327,7 @@ class OracleScene:
     def forward(self, rays: torch.Tensor, n_coarse: int, n_fine: int = 0, resampling: bool = False,
                 use_coarse_sample: bool = True, is_train: bool = False,
                 jitter: Optional[torch.Tensor] = None, u: Optional[torch.Tensor] = None,
-                keep: bool = False):
+                keep: bool = False, exp_sampling: bool = True):
         """EgoNeRF.forward (EgoNeRF.py:491-602), exp_sampling + interval_th path.
 
         Returns (rgb[N,3], depth[N], bg|None, env|None, alpha[N,S(+1)]) and, if keep, a dict of
@@ -324,9 +338,10 @@ class OracleScene:
         o, viewdirs = rays[:, :3], rays[:, 3:6]
         if is_train and jitter is None:
             jitter = torch.rand(rays.shape[0], n_coarse)
-        xyz, z = self.sample_ray_exp(o, viewdirs, n_coarse, jitter if is_train else None)
+        sampler = self.sample_ray_exp if exp_sampling else self.sample_ray  # EgoNeRF.py:506-513
+        xyz, z = sampler(o, viewdirs, n_coarse, jitter if is_train else None)
         if not is_train:
-            z = z[0].repeat(xyz.shape[0], 1)  # EgoNeRF.py:515-516
+            z = z[0].repeat(xyz.shape[0], 1)  # EgoNeRF.py:515-516 (ray 0's distances for every ray, also with sample_ray)
         dists = z[..., 1:] - z[..., :-1]
         dists = torch.cat([dists, dists[..., -1:]], -1)
         c7 = self.from_cartesian(xyz)
