@@ -117,12 +117,12 @@ __device__ __forceinline__ Lin1 lin_setup(float xhat, int n) {
   const float ix = __fmul_rn(__fadd_rn(xhat, 1.0f), 0.5f * (float)(n - 1));
   const float fl = floorf(ix);
   const float f = __fsub_rn(ix, fl);
-  // ix may be NaN/huge for degenerate points: keep the int conversion defined and the taps masked
+  // ix may be NaN/huge for degenerate points: keep the int conversion defined and the taps masked (fmaxf(NaN, -2) = -2, so
+  // a NaN lands on i0 = -2, i1 = -1: both out of range).  One unsigned compare per tap: 0 <= i < n.
   const float flc = fminf(fmaxf(fl, -2.0f), (float)n);
   const int i0 = (int)flc, i1 = i0 + 1;
-  const bool ok = (ix == ix);
-  t.w0 = (ok && i0 >= 0 && i0 < n) ? __fsub_rn(1.0f, f) : 0.0f;
-  t.w1 = (ok && i1 >= 0 && i1 < n) ? f : 0.0f;
+  t.w0 = ((unsigned)i0 < (unsigned)n) ? __fsub_rn(1.0f, f) : 0.0f;
+  t.w1 = ((unsigned)i1 < (unsigned)n) ? f : 0.0f;
   t.i0 = min(max(i0, 0), n - 1);
   t.i1 = min(max(i1, 0), n - 1);
   return t;
