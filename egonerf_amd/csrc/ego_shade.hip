@@ -566,10 +566,20 @@ __device__ __forceinline__ void basis_step(const BasisFrag& a, const float x[8],
 // ---- 4-lane-team gather (fp32 tables, f16x3 kernel) ------------------------------------------------------------------
 // The vector L1 looks up one distinct 64-byte line per cycle, and with two lanes per sample a load instruction touches
 // ~26 distinct lines (PMC: 3270 tag lookups per tile), which - not bytes - bounds the gather.  Here the wave gathers as 16
-// teams of 4 lanes (lane = 16*p + s): part p reads quad 4i+p of line i, so a team reads a whole line per instruction and
-// an instruction touches <= 16 lines.  Two rounds cover the tile's 32 samples (round rd: team s serves sample 16*rd + s);
-// v_permlane16_swap + v_permlane32_swap then move the products into the MFMA layout (lane = 32*h + j): lane half h
-// receives parts p = h and p = h + 2 of its sample, which fixes the K order app_channel_g.
+// teams of 4 lanes, lane = 32*pa + 2*t + pb: team t = the lane pairs (2t, 2t+1) and (2t+32, 2t+33).  In round rd the team
+// serves the tile's sample 2t + rd and its lane reads quad pa + 2*(pb ^ rd) of each line, so a team reads a whole line per
+// instruction and an instruction touches <= 16 lines; two rounds cover the 32 samples.  The MFMA layout is lane = 32*h + j
+// (sample j, half h = pa holds quads h and h + 2, K order app_channel_g): a lane's own sample is 2t + pb, so it keeps the
+// round that served it (quad h) and gets quad h + 2 of its sample from the lane next to it: two selects and one neighbour
+// exchange per value.
+// The exchange is a ds_bpermute (LDS crossbar, no LDS memory).  The forms without an address operand - v_mov_b32_dpp quad_perm,
+// ds_swizzle SWAP 1, and before them v_permlane16_swap + v_permlane32_swap on a lane = 16*part + slot layout - are 7 % faster
+// and NOT reproducible in these kernels: some calls (0.3 % ... 100 % of them, depending on unrelated code changes) return one
+// round's products wrong in lanes 16-31 and 48-63 of a wave in slots 4-7 of its workgroup, i.e. the second wave of a SIMD.
+// Stand-alone probes of those instructions (tools/dpp_hazard_probe.hip, tools/vmem_war_probe.hip: producer -> cross-lane read,
+// overwritten sources, MFMAs in flight, high registers, two waves on the same registers) never fail, s_nop / s_waitcnt padding
+// makes it worse, wave priority does not matter; the bpermute form passed 100 000 calls.  Root cause not found - see DESIGN.md
+// section 5.1; tools/flaky_probe.py and tools/variant_test.sh reproduce it with -DEGO_TEAM_EXCHANGE=0 or 1.
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 struct TeamSample {  // normalised coordinates of the sample this lane's team serves in one round
@@ -578,11 +588,11 @@ struct TeamSample {  // normalised coordinates of the sample this lane's team se
 };
 
 template <int I>
-__device__ __forceinline__ void team_load(const DevField& F, const VMTaps& t, int g, int p, f32x4 raw[18]) {
+__device__ __forceinline__ void team_load(const DevField& F, const VMTaps& t, int g, int q, f32x4 raw[18]) {
   const Lin1 X = t.ax[vm_plane_x(I)], Y = t.ax[vm_plane_y(I)], Ln = t.ax[vm_line_ax(I)];
   const int W = F.res[vm_plane_x(I)];
-  const float* P = (g ? F.plane[1][I] : F.plane[0][I]) + 4 * p;
-  const float* L = (g ? F.line[1][I] : F.line[0][I]) + 4 * p;
+  const float* P = (g ? F.plane[1][I] : F.plane[0][I]) + 4 * q;
+  const float* L = (g ? F.line[1][I] : F.line[0][I]) + 4 * q;
   // unsigned element offsets: zero-extension into the 64-bit address is free, sign-extension is an extra VALU instruction
   const f32x4* p00 = (const f32x4*)(P + (uint32_t)((Y.i0 * W + X.i0) * APP_C));
   const f32x4* p01 = (const f32x4*)(P + (uint32_t)((Y.i0 * W + X.i1) * APP_C));
@@ -591,7 +601,7 @@ __device__ __forceinline__ void team_load(const DevField& F, const VMTaps& t, in
   const f32x4* l0 = (const f32x4*)(L + (uint32_t)(Ln.i0 * APP_C));
   const f32x4* l1 = (const f32x4*)(L + (uint32_t)(Ln.i1 * APP_C));
 #pragma unroll
-  for (int i = 0; i < 3; ++i) {  // quad 4i + p: f32x4 index 4i from the p-shifted base
+  for (int i = 0; i < 3; ++i) {  // quad 4i + q: f32x4 index 4i from the q-shifted base
     raw[i] = p00[4 * i]; raw[3 + i] = p01[4 * i]; raw[6 + i] = p10[4 * i]; raw[9 + i] = p11[4 * i];
     raw[12 + i] = l0[4 * i]; raw[15 + i] = l1[4 * i];
   }
@@ -612,32 +622,25 @@ __device__ __forceinline__ void team_finish(const VMTaps& t, const f32x4 raw[18]
   }
 }
 
-// rows of 16 lanes: (ga rows a0..a3, gb rows b0..b3) -> v[idx] rows [a0 b0 a1 b1], v[12+idx] rows [a2 b2 a3 b3]
-// SWAPS: v_permlane16_swap + v_permlane32_swap (two VALU instructions per pair, no LDS).  The stand-alone appearance-feature
-// instantiation (MODE_APP) came out non-reproducible with them — one call in ~5 returned a 16-sample block a few percent
-// off, only in that instantiation (the fused kernel, its activation-dumping variant and MODE_APP + dump are bit-reproducible
-// over thousands of calls; s_nop padding around the swaps did not help; tools/determinism_check.py) — so that one, which is
-// not on the hot path, takes the ds_bpermute form (11 % slower in the fused kernel, irrelevant there).
-template <bool SWAPS>
+// ga = this lane's quad of the sample served in round 0 (tile column 2t), gb = of round 1 (column 2t + 1).  Even lanes own
+// column 2t: they keep ga (quad h) and take the odd neighbour's ga (quad h + 2); odd lanes keep gb and take the even
+// neighbour's gb.  v[0..11] = quad h, v[12..23] = quad h + 2 of the lane's own sample.
+// EGO_TEAM_EXCHANGE: 2 = ds_bpermute (default, the only reproducible form), 1 = v_mov_b32_dpp, 0 = ds_swizzle.
+#ifndef EGO_TEAM_EXCHANGE
+#define EGO_TEAM_EXCHANGE 2
+#endif
 __device__ __forceinline__ void team_to_halves(const float ga[12], const float gb[12], float* v) {
-  if (SWAPS) {
+  const bool even = (threadIdx.x & 1) == 0;
 #pragma unroll
-    for (int idx = 0; idx < 12; ++idx) {
-      const u32x2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(ga[idx]), __float_as_uint(gb[idx]), false, false);
-      const u32x2 q = __builtin_amdgcn_permlane32_swap(r.x, r.y, false, false);
-      v[idx] = __uint_as_float(q.x);
-      v[12 + idx] = __uint_as_float(q.y);
-    }
-  } else {
-    const int lane = threadIdx.x & 63, rho = lane >> 4;
-    const int src1 = 16 * (rho >> 1) + (lane & 15), src2 = 32 + src1;
-#pragma unroll
-    for (int idx = 0; idx < 12; ++idx) {
-      const float a1 = __shfl(ga[idx], src1, 64), b1 = __shfl(gb[idx], src1, 64);
-      const float a2 = __shfl(ga[idx], src2, 64), b2 = __shfl(gb[idx], src2, 64);
-      v[idx] = (rho & 1) ? b1 : a1;
-      v[12 + idx] = (rho & 1) ? b2 : a2;
-    }
+  for (int idx = 0; idx < 12; ++idx) {
+    const float give = even ? gb[idx] : ga[idx];
+    v[idx] = even ? ga[idx] : gb[idx];
+    if (EGO_TEAM_EXCHANGE == 1)
+      v[12 + idx] = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(give), 0xB1 /* quad_perm [1,0,3,2] */, 0xf, 0xf, false));
+    else if (EGO_TEAM_EXCHANGE == 2)
+      v[12 + idx] = __shfl_xor(give, 1, 64);
+    else
+      v[12 + idx] = __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(give), 0x041F /* bit mode: lane ^ 1 */));
   }
 }
 
@@ -659,10 +662,9 @@ __device__ __forceinline__ void basis3(const u32x4* __restrict__ BASH, int lane,
   basis_step(f0, v, keep, fe); basis_step(f1, v + 8, keep, fe); basis_step(f2, v + 16, keep, fe);
 }
 
-template <bool SWAPS>
 __device__ __forceinline__ void gather_basis_team(const DevField& F, const TeamSample ts[2], const u32x4* __restrict__ BASH, int lane,
                                                   int g, bool mixed, int gu, f32x16& fe, float* vdump) {
-  const int p = lane >> 4;
+  const int qa = (lane >> 5) + 2 * (lane & 1), qb = (lane >> 5) + 2 * ((lane & 1) ^ 1);  // quad read in round 0 / round 1
   // A lane's output column depends only on its own inputs, so a wave that straddles the yin/yang border (rare) runs the
   // steps with both weight sets on the unmasked products, into two accumulators, and each lane keeps its grid's one at the
   // end: no per-value masking anywhere, and nothing extra for the waves of one grid.
@@ -675,32 +677,32 @@ __device__ __forceinline__ void gather_basis_team(const DevField& F, const TeamS
   // previous plane so that they overlap; the co-resident wave and the MLP phase hide the rest
   f32x4 raw[18];
   float ga[12], gb[12], v[24];
-  team_load<0>(F, tA, ts[0].g, p, raw);
+  team_load<0>(F, tA, ts[0].g, qa, raw);
   team_finish<0>(tA, raw, ga);
   __builtin_amdgcn_sched_barrier(0);
-  team_load<0>(F, tB, ts[1].g, p, raw);
+  team_load<0>(F, tB, ts[1].g, qb, raw);
   team_finish<0>(tB, raw, gb);
-  team_to_halves<SWAPS>(ga, gb, v);
+  team_to_halves(ga, gb, v);
   dump24(vdump, v);
   __builtin_amdgcn_sched_barrier(0);
-  team_load<1>(F, tA, ts[0].g, p, raw);
+  team_load<1>(F, tA, ts[0].g, qa, raw);
   basis3(BASH, lane, 0, g0, true, v, fe);
   if (mixed) basis3(BASH, lane, 0, 1, true, v, fe2);
   team_finish<1>(tA, raw, ga);
   __builtin_amdgcn_sched_barrier(0);
-  team_load<1>(F, tB, ts[1].g, p, raw);
+  team_load<1>(F, tB, ts[1].g, qb, raw);
   team_finish<1>(tB, raw, gb);
-  team_to_halves<SWAPS>(ga, gb, v);
+  team_to_halves(ga, gb, v);
   dump24(vdump ? vdump + 6 * 256 : nullptr, v);
   __builtin_amdgcn_sched_barrier(0);
-  team_load<2>(F, tA, ts[0].g, p, raw);
+  team_load<2>(F, tA, ts[0].g, qa, raw);
   basis3(BASH, lane, 3, g0, true, v, fe);
   if (mixed) basis3(BASH, lane, 3, 1, true, v, fe2);
   team_finish<2>(tA, raw, ga);
   __builtin_amdgcn_sched_barrier(0);
-  team_load<2>(F, tB, ts[1].g, p, raw);
+  team_load<2>(F, tB, ts[1].g, qb, raw);
   team_finish<2>(tB, raw, gb);
-  team_to_halves<SWAPS>(ga, gb, v);
+  team_to_halves(ga, gb, v);
   dump24(vdump ? vdump + 12 * 256 : nullptr, v);
   basis3(BASH, lane, 6, g0, true, v, fe);
   if (mixed) basis3(BASH, lane, 6, 1, true, v, fe2);
@@ -780,7 +782,11 @@ __global__ __launch_bounds__(512) void k_shade_h(ShadeArgs A) {
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 31, h = lane >> 5;
-  if (wave >= 4) __builtin_amdgcn_s_setprio(1);  // de-phase the two waves of a SIMD (see k_shade)
+#ifndef EGO_PRIO_VARIANT
+#define EGO_PRIO_VARIANT 0
+#endif
+  if (EGO_PRIO_VARIANT == 0 && wave >= 4) __builtin_amdgcn_s_setprio(1);  // de-phase the two waves of a SIMD (see k_shade)
+  if (EGO_PRIO_VARIANT == 2 && wave < 4) __builtin_amdgcn_s_setprio(1);
   const int64_t n_tiles = (A.M + 31) >> 5;
   const u32x4* W1 = (const u32x4*)(lds + OFF_W1);
   const u32x4* W2 = (const u32x4*)(lds + OFF_W2);
@@ -842,11 +848,11 @@ __global__ __launch_bounds__(512) void k_shade_h(ShadeArgs A) {
           gather_basis_f16<true>(A.F, taps, BASH, lw, g, hw, 1, g != 0, fe);
         }
       } else {
-        // team gather: in round rd this lane's 4-lane team serves sample 16*rd + (lane & 15) of the tile
+        // team gather: in round rd this lane's 4-lane team serves sample 2*((lane >> 1) & 15) + rd of the tile
         TeamSample ts[2];
 #pragma unroll
         for (int rd = 0; rd < 2; ++rd) {
-          const int64_t mt_raw = tile * 32 + 16 * rd + (lw & 15);
+          const int64_t mt_raw = tile * 32 + 2 * ((lw >> 1) & 15) + rd;
           const int64_t mt = mt_raw < A.M ? mt_raw : A.M - 1;
           if (MODE == MODE_APP) {
             const float* p = A.c7n + mt * 7;
@@ -861,7 +867,7 @@ __global__ __launch_bounds__(512) void k_shade_h(ShadeArgs A) {
         float* vd = (DUMP && valid) ? A.dump_v + dump_off(tile, 144, 0, hw, j) : nullptr;
         // one gather per tile; a border-straddling wave runs the basis steps of each plane twice (yin weights with the
         // yang lanes zeroed, then the reverse) inside gather_basis_team
-        gather_basis_team<(MODE != MODE_APP || DUMP)>(A.F, ts, BASH, lw, g, mixed, gu, fe, vd);
+        gather_basis_team(A.F, ts, BASH, lw, g, mixed, gu, fe, vd);
       }
     }
 

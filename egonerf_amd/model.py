@@ -20,6 +20,7 @@ from __future__ import annotations
 import ctypes as C
 from typing import List, Optional
 
+import math
 import numpy as np
 import torch
 import torch.nn
@@ -643,8 +644,17 @@ class EgoNeRF(TensorBase):
                                               "the reference then measures every ray with ray 0's distances (EgoNeRF.py:515-516)")
             jitter = None
         if is_train and exp_sampling and not self.coordinates.interval_th:
-            raise NotImplementedError("is_train with the plain exponential sample schedule (EgoNeRF.py:59-67 jitters the exponent, "
-                                      "not the interval) is not built; every shipped config sets interval_th")
+            # plain exponential schedule in training (EgoNeRF.py:59-67): the noise goes into the exponent and the distances are
+            # an exclusive prefix sum; computed here with the reference's own expression and handed over as explicit distances
+            if jitter is None:
+                jitter = torch.rand(N, n_coarse)
+            near, far = float(self.near_far[0]), float(self.near_far[1])
+            ratio = 1 + (math.pi / 2.0) / n_coarse
+            r0 = (far - near) * (ratio - 1) / (pow(ratio, n_coarse) - 1)
+            rng = torch.arange(n_coarse, device=dev)[None].float() + _f32c(jitter.to(dev))
+            tri = torch.tril(torch.ones(n_coarse, n_coarse, device=dev), diagonal=-1).T
+            z_coarse = (near + torch.pow(ratio, rng) @ tri * r0).contiguous()
+            jitter = None
         if is_train:
             if jitter is None:
                 jitter = torch.rand(N, n_coarse).to(dev)  # CPU generator like EgoNeRF.py:81

@@ -114,7 +114,8 @@ class RenderFunction(torch.autograd.Function):
                        "ego_march_density")
             _lib.check(lib.ego_sample_pdf_merge(zc.data_ptr(), wc.data_ptr(), _lib.ptr(u), N, n_coarse, n_fine, int(use_coarse),
                                                 z.data_ptr(), None, st), "ego_sample_pdf_merge")
-            _lib.check(lib.ego_march_density(sc, rays.data_ptr(), N, S, z.data_ptr(), None, None, near, 0, None, alpha.data_ptr(),
+            # fine pass: full tables and the full-resolution r grid (bit 1; EgoNeRF.py:546 normalises without `downsample`)
+            _lib.check(lib.ego_march_density(sc, rays.data_ptr(), N, S, z.data_ptr(), None, None, near, 2, None, alpha.data_ptr(),
                                              astride, weight.data_ptr(), bg.data_ptr(), coords.data_ptr(), sigma.data_ptr(), None, st),
                        "ego_march_density")
         else:

@@ -402,6 +402,14 @@ def capture_plainexp():
     fx.update(nr_rgb=np_(o[0]), nr_depth=np_(o[1]), nr_alpha=np_(o[4]))
     o = run_forward(model, rays, n_coarse=16, n_fine=16, resampling=True, use_coarse_sample=True)
     fx.update(rs_rgb=np_(o[0]), rs_depth=np_(o[1]))
+    # is_train: the noise is added to the exponent (EgoNeRF.py:64-67) and the distances are an exclusive prefix sum by matmul
+    jit = torch.from_numpy(synth.hash_uniform(13, 0, 64 * 16).reshape(64, 16).astype(np.float32))
+    uu = torch.from_numpy(synth.hash_uniform(13, 1, 64 * 16).reshape(64, 16).astype(np.float32))
+    with patched_rand([jit.clone()], []):
+        _, z, _ = model.sample_ray_exp(rays[:, :3], rays[:, 3:6], is_train=True, N_samples=16)
+    with patched_rand([jit.clone()], [uu]):
+        o = run_forward(model, rays, n_coarse=16, n_fine=16, resampling=True, use_coarse_sample=True, is_train=True)
+    fx.update(tr_jitter=np_(jit), tr_u=np_(uu), tr_z=np_(z), tr_rgb=np_(o[0]), tr_depth=np_(o[1]))
     np.savez_compressed(os.path.join(OUT, "tiny_plainexp.npz"), **fx)
 
 

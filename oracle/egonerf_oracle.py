@@ -125,6 +125,14 @@ class OracleScene:
 
     def sample_ray_exp(self, rays_o, rays_d, S: int, jitter: Optional[torch.Tensor] = None):
         """EgoNeRF.py:56-87.  `jitter` [N,S] in [0,1) replaces torch.rand_like for is_train."""
+        c = self.cfg
+        if jitter is not None and not getattr(c, "interval_th", True):
+            # plain exponential schedule in training: the noise goes into the exponent (EgoNeRF.py:63-67)
+            ratio = 1 + (math.pi / 2.0) / S
+            r0 = (c.far - c.near) * (ratio - 1) / (pow(ratio, S) - 1)
+            rng = torch.arange(S)[None].float().repeat(rays_d.shape[-2], 1) + jitter.float()
+            z = (c.near + torch.pow(ratio, rng) @ torch.tril(torch.ones(S, S), diagonal=-1).T * r0).to(self.dtype)
+            return rays_o[..., None, :] + rays_d[..., None, :] * z[..., None], z
         r = self.sample_schedule(S).repeat(rays_d.shape[-2], 1)
         if jitter is not None:
             step = r[:, 1:] - r[:, :-1]

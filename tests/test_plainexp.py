@@ -27,6 +27,12 @@ def test_oracle_plain_exponential_grid(golden):
     assert float((rgb - T(fx["nr_rgb"])).abs().max()) <= 1e-6 and float((alpha - T(fx["nr_alpha"])).abs().max()) <= 1e-6
     rgb, depth, *_ = sc.forward(T(fx["rays"]), n_coarse=16, n_fine=16, resampling=True)
     assert float((rgb - T(fx["rs_rgb"])).abs().max()) <= 1e-6 and float((depth - T(fx["rs_depth"])).abs().max()) <= 2e-5
+    # training: noise in the exponent, distances by the reference's prefix-sum matmul
+    _, z = sc.sample_ray_exp(T(fx["rays"])[:, :3], T(fx["rays"])[:, 3:6], 16, jitter=T(fx["tr_jitter"]))
+    assert float((z - T(fx["tr_z"])).abs().max()) <= 2e-6
+    rgb, depth, *_ = sc.forward(T(fx["rays"]), n_coarse=16, n_fine=16, resampling=True, is_train=True, jitter=T(fx["tr_jitter"]),
+                                u=T(fx["tr_u"]))
+    assert float((rgb - T(fx["tr_rgb"])).abs().max()) <= 2e-6 and float((depth - T(fx["tr_depth"])).abs().max()) <= 2e-5
 
 
 def test_host_schedule_and_lut_reproduce_the_reference(golden):
@@ -67,5 +73,25 @@ def test_hip_plain_exponential_grid(golden):
         rgb, depth, *_ = model(rays, n_coarse=16, n_fine=16, exp_sampling=True, resampling=True)
         assert float((rgb.cpu() - T(fx["rs_rgb"])).abs().max()) <= 1e-4
         assert float((depth.cpu() - T(fx["rs_depth"])).abs().max()) <= 1e-3
-    with pytest.raises(NotImplementedError):
-        model(rays, is_train=True, n_coarse=24, exp_sampling=True)
+        rgb, depth, *_ = model(rays, is_train=True, n_coarse=16, n_fine=16, exp_sampling=True, resampling=True,
+                               jitter=T(fx["tr_jitter"]).cuda(), u=T(fx["tr_u"]).cuda())
+        assert float((rgb.cpu() - T(fx["tr_rgb"])).abs().max()) <= 1e-4
+        assert float((depth.cpu() - T(fx["tr_depth"])).abs().max()) <= 1e-3
+    # the differentiable path (training proper) on the same noise: every parameter gradient against the oracle's autograd
+    model.train()
+    gt = T(synth.hash_uniform(22, 0, 64 * 3).reshape(64, 3).astype(np.float32))
+    rgb, *_ = model(rays, is_train=True, n_coarse=16, n_fine=16, exp_sampling=True, resampling=True,
+                    jitter=T(fx["tr_jitter"]).cuda(), u=T(fx["tr_u"]).cuda())
+    assert rgb.requires_grad and float((rgb.detach().cpu() - T(fx["tr_rgb"])).abs().max()) <= 1e-4
+    torch.mean((rgb - gt.cuda()) ** 2).backward()
+    w = synth.make_weights(cfg, seed=int(fx["seed_weights"]))
+    oracle = make_oracle(cfg, w)
+    for v in oracle.w.values():
+        v.requires_grad_(True)
+    ref, *_ = oracle.forward(T(fx["rays"]), n_coarse=16, n_fine=16, resampling=True, is_train=True, jitter=T(fx["tr_jitter"]),
+                             u=T(fx["tr_u"]))
+    torch.mean((ref - gt) ** 2).backward()
+    for k, p in model.named_parameters():
+        r = oracle.w[k].grad
+        r = torch.zeros_like(oracle.w[k]) if r is None else r
+        assert float((p.grad.detach().cpu() - r).abs().max()) / max(float(r.abs().max()), 1e-12) <= 3e-4, k

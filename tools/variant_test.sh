@@ -1,0 +1,16 @@
+#!/bin/bash
+# Build libegonerf_hip.so once per value of a -D macro and run a check script on each build inside ONE gpurun session.
+#   tools/variant_test.sh EGO_SWAP_VARIANT "0 4 7" tools/which_kernel.py
+set -e
+cd "$(dirname "$0")/.."
+MACRO=$1; VALUES=$2; SCRIPT=$3
+rm -f egonerf_amd/libvariant_*.so
+for v in $VALUES; do
+  (cd egonerf_amd/csrc && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -munsafe-fp-atomics -shared -fPIC \
+     -D$MACRO=$v ego_ops.hip ego_shade.hip ego_render.hip ego_reg.hip ego_metrics.hip ego_wgrad.hip -o ../libvariant_$v.so 2>&1 | grep -i "error" | head -3) &
+done
+wait
+for v in $VALUES; do test -f egonerf_amd/libvariant_$v.so || { echo "variant $v failed to build"; exit 1; }; done
+/usr/local/graft/bin/gpurun --timeout 900 -- "for v in $VALUES; do cp egonerf_amd/libvariant_\$v.so egonerf_amd/libegonerf_hip.so; echo \"== $MACRO=\$v\"; python $SCRIPT 2>&1 | tail -4; done" 2>&1 | tail -40
+rm -f egonerf_amd/libvariant_*.so
+python -c "import __graft_entry__ as g; g.build()" | tail -1

@@ -1,0 +1,55 @@
+import sys, os, ctypes as C
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from egonerf_amd import synth, _lib
+from egonerf_amd.synth import build_model
+dev = torch.device("cuda", 0)
+cfg = synth.SceneConfig(n_voxel=20 ** 3)
+model = build_model(cfg, synth.make_weights(cfg, seed=1234), dev)
+rays = torch.from_numpy(synth.make_rays(256, seed=7)).to(dev)
+lib = _lib.load(); st = _lib.stream_handle()
+N, S = 256, 24
+sc = model.scene()
+sched = model._sched(S, dev)
+near = float(model.near_far[0])
+f = lambda *s: torch.empty(*s, device=dev)
+def march():
+    z, alpha, w, bg, crd, sg = f(N, S), f(N, S), f(N, S), f(N), f(N, S, 4), f(N, S)
+    _lib.check(lib.ego_march_density(sc, rays.data_ptr(), N, S, None, sched.data_ptr(), None, near, 0, z.data_ptr(), alpha.data_ptr(), S,
+                                     w.data_ptr(), bg.data_ptr(), crd.data_ptr(), sg.data_ptr(), None, st), "march")
+    return z, alpha, w, bg, crd, sg
+ref = march()
+bad = [0] * 6
+for _ in range(100):
+    o = march()
+    for i in range(6):
+        bad[i] += int(not torch.equal(o[i], ref[i]))
+print("march mismatches (z, alpha, w, bg, coords, sigma):", bad)
+z, alpha, w, bg, crd, sg = ref
+def shade():
+    rgb = f(N, S, 3)
+    _lib.check(lib.ego_shade(sc, rays.data_ptr(), z.data_ptr(), crd.data_ptr(), N, S, rgb.data_ptr(), None, None, st), "shade")
+    return rgb
+r0 = shade(); b = 0; worst = 0
+for _ in range(100):
+    o = shade()
+    if not torch.equal(o, r0):
+        b += 1; worst = max(worst, float((o - r0).abs().max()))
+print("shade mismatches:", b, worst)
+with torch.no_grad():
+    a = model(rays, n_coarse=24, exp_sampling=True)
+    bb = model(rays, n_coarse=24, exp_sampling=True)
+    for i, (x, y) in enumerate(zip(a, bb)):
+        if x is not None:
+            print("forward output", i, "equal:", torch.equal(x, y), float((x - y).abs().max()))
+
+# structure of the differences between two shade calls
+r1 = shade().reshape(-1, 3); r2 = shade().reshape(-1, 3)
+bad_rows = ((r1 != r2).any(1)).nonzero().flatten().cpu().numpy()
+print("differing samples:", len(bad_rows), "of", r1.shape[0])
+if len(bad_rows):
+    tiles = np.unique(bad_rows // 32)
+    print("tiles:", len(tiles), tiles[:40], "... total tiles", r1.shape[0] // 32)
+    print("positions within tile (count per j):", np.bincount(bad_rows % 32, minlength=32))
+    print("tile % 8 (wave slot) histogram:", np.bincount(tiles % 8, minlength=8))
+    print("tile // 8 % 16 histogram:", np.bincount((tiles // 8) % 16, minlength=16))
