@@ -171,10 +171,10 @@ def main():
                         note="the 94 MB table set is L2/Infinity-Cache resident, so algorithmic bytes/s exceeds the HBM peak; "
                              "the binding resource is instruction issue: VALU and MFMA time add up on a CDNA4 SIMD "
                              "(tools/coissue_probe.hip), see `issue`",
-                        issue=dict(mfma_per_tile=243, mfma_cycles_per_tile=243 * 32, valu_per_tile=2100, valu_cycles_per_tile=2100 * 4,
+                        issue=dict(mfma_per_tile=243, mfma_cycles_per_tile=243 * 32, valu_per_tile=1800, valu_cycles_per_tile=1800 * 4,
                                    tiles_per_simd=M / 32 / 1024, clock_GHz=2.1,
-                                   additive_bound_ms=(243 * 32 + 2100 * 4) * (M / 32 / 1024) / 2.1e6,
-                                   frac=(243 * 32 + 2100 * 4) * (M / 32 / 1024) / 2.1e6 / (t_shade * 1e3)),
+                                   additive_bound_ms=(243 * 32 + 1800 * 4) * (M / 32 / 1024) / 2.1e6,
+                                   frac=(243 * 32 + 1800 * 4) * (M / 32 / 1024) / 2.1e6 / (t_shade * 1e3)),
                         l1=dict(achieved=shade_gbps, peak=l1_peak, unit="GB/s", frac=shade_gbps / l1_peak),
                         mfma=mfma,
                         other_kernels_ms=dict(k_march_density=t_march * 1e3, k_composite=t_comp * 1e3),
