@@ -1,5 +1,6 @@
-"""GPU: the forward path has no atomics, so every op must return the same bits call after call.  (A parity test sees an
-intermittent hazard / race once in a few runs; this one repeats each op 120 times — tools/determinism_check.py.)"""
+"""GPU: the forward path has no atomics, so every op must return the same bits call after call.  The team-gather kernels have
+a build-dependent, unexplained reproducibility fault (0.3 % ... 100 % of calls in the affected builds, none in
+100 000 calls of the shipped one), so every op is repeated 3000 times here — tools/determinism_check.py."""
 import os
 import sys
 
@@ -11,6 +12,6 @@ pytestmark = pytest.mark.gpu
 def test_forward_ops_are_bit_reproducible():
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
     import determinism_check
-    res = determinism_check.run(reps=120, full=False, verbose=False)
+    res = determinism_check.run(reps=3000, full=False, verbose=False)
     bad = {k: v for k, v in res.items() if v[0]}
     assert not bad, bad

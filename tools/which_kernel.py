@@ -53,3 +53,21 @@ if len(bad_rows):
     print("positions within tile (count per j):", np.bincount(bad_rows % 32, minlength=32))
     print("tile % 8 (wave slot) histogram:", np.bincount(tiles % 8, minlength=8))
     print("tile // 8 % 16 histogram:", np.bincount((tiles // 8) % 16, minlength=16))
+
+# the activation-dumping instantiation (training forward): rgb and all four dumps must repeat bit for bit
+import ctypes as C
+Mtot = N * S
+Mp = (Mtot + 31) // 32 * 32
+def shade_dump():
+    rgb = f(N, S, 3)
+    d = dict(x=torch.zeros(Mp, 160, device=dev), h1=torch.zeros(Mp, 128, device=dev), h2=torch.zeros(Mp, 128, device=dev), v=torch.zeros(Mp, 144, device=dev))
+    ds = _lib.ShadeDump(d["x"].data_ptr(), d["h1"].data_ptr(), d["h2"].data_ptr(), d["v"].data_ptr())
+    _lib.check(lib.ego_shade(sc, rays.data_ptr(), z.data_ptr(), crd.data_ptr(), N, S, rgb.data_ptr(), C.byref(ds), None, st), "shade")
+    return rgb, d["x"], d["h1"], d["h2"], d["v"]
+r0 = shade_dump(); bad = [0] * 5
+reps_d = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
+for _ in range(reps_d):
+    o = shade_dump()
+    for i in range(5):
+        bad[i] += int(not torch.equal(o[i], r0[i]))
+print("dumping forward mismatches (rgb, x, h1, h2, v) in", reps_d, "calls:", bad)
