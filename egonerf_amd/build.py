@@ -28,18 +28,44 @@ def is_stale() -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build_library(force: bool = False, verbose: bool = False) -> str:
-    if not force and not is_stale():
+# Per-source extra flags.  ego_shade.hip is built without the SLP vectoriser: of all the builds of its team-gather kernels tried
+#  the ones compiled this way have been bit-reproducible in every soak (> 300 000 calls); builds with SLP-formed
+# packed ops were reproducible only by accident of the rest of the code.  It costs no time (0.55 ms either way).
+EXTRA_FLAGS = {"ego_shade.hip": ["-fno-slp-vectorize"]}
+COMMON_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-munsafe-fp-atomics", "-fPIC"]
+
+
+def build_library(force: bool = False, verbose: bool = False, extra: list | None = None, out: str | None = None) -> str:
+    """`extra` (or the environment variable EGO_EXTRA_FLAGS) adds compiler flags to every source and `out` names another output
+    file: experiment builds (tools/variant_test.sh)."""
+    extra = list(extra or []) + os.environ.get("EGO_EXTRA_FLAGS", "").split()
+    out = out or os.environ.get("EGO_LIB_OUT") or LIB
+    if not force and not extra and out == LIB and not is_stale():
         return LIB
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-munsafe-fp-atomics", "-shared", "-fPIC",
-           *[os.path.join(CSRC, f) for f in SOURCES], "-o", LIB + ".tmp"]
+    objdir = os.path.join(HERE, "build" + ("_" + os.path.basename(out) if out != LIB else ""))
+    os.makedirs(objdir, exist_ok=True)
+    procs, objs = [], []
+    for f in SOURCES:  # one hipcc per source, in parallel: the sources have no device-side references to one another
+        obj = os.path.join(objdir, f.replace(".hip", ".o"))
+        objs.append(obj)
+        cmd = [_hipcc(), *COMMON_FLAGS, *EXTRA_FLAGS.get(f, []), *extra, "-c", os.path.join(CSRC, f), "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((f, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    for f, pr in procs:
+        out, _ = pr.communicate()
+        if pr.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {f}:\n" + out)
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", out + ".tmp"]
     if verbose:
         print(" ".join(cmd))
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
-        raise RuntimeError("hipcc failed:\n" + r.stdout + r.stderr)
-    os.replace(LIB + ".tmp", LIB)
-    return LIB
+        raise RuntimeError("hipcc (link) failed:\n" + r.stdout + r.stderr)
+    os.replace(out + ".tmp", out)
+    if out != LIB:
+        shutil.rmtree(objdir, ignore_errors=True)
+    return out
 
 
 if __name__ == "__main__":

@@ -572,14 +572,14 @@ __device__ __forceinline__ void basis_step(const BasisFrag& a, const float x[8],
 // (sample j, half h = pa holds quads h and h + 2, K order app_channel_g): a lane's own sample is 2t + pb, so it keeps the
 // round that served it (quad h) and gets quad h + 2 of its sample from the lane next to it: two selects and one neighbour
 // exchange per value.
-// The exchange is a ds_bpermute (LDS crossbar, no LDS memory).  The forms without an address operand - v_mov_b32_dpp quad_perm,
-// ds_swizzle SWAP 1, and before them v_permlane16_swap + v_permlane32_swap on a lane = 16*part + slot layout - are 7 % faster
-// and NOT reproducible in these kernels: some calls (0.3 % ... 100 % of them, depending on unrelated code changes) return one
-// round's products wrong in lanes 16-31 and 48-63 of a wave in slots 4-7 of its workgroup, i.e. the second wave of a SIMD.
-// Stand-alone probes of those instructions (tools/dpp_hazard_probe.hip, tools/vmem_war_probe.hip: producer -> cross-lane read,
-// overwritten sources, MFMAs in flight, high registers, two waves on the same registers) never fail, s_nop / s_waitcnt padding
-// makes it worse, wave priority does not matter; the bpermute form passed 100 000 calls.  Root cause not found - see DESIGN.md
-// section 5.1; tools/flaky_probe.py and tools/variant_test.sh reproduce it with -DEGO_TEAM_EXCHANGE=0 or 1.
+// The exchange is a v_mov_b32_dpp quad_perm (EGO_TEAM_EXCHANGE 1; 2 = __shfl_xor, 0 = ds_swizzle).
+// REPRODUCIBILITY: kernels of this family (fp32-table gather of the f16x3 kernel) have a build-dependent fault that is not
+// understood: in affected builds 0.3 % ... 100 % of the calls return one gather round's products wrong in lanes
+// 16-31 and 48-63 of a wave in slots 4-7 of its workgroup (the second wave of a SIMD).  It does not depend on the exchange (it also
+// hits EGO_GATHER_TEAMS 0, where no lane talks to another), needs two waves co-running on the SIMD, and none of the stand-alone
+// probes in tools/ reproduces it.  Builds of this file WITHOUT the SLP vectoriser (egonerf_amd/build.py) have been clean in every
+// soak (> 300 000 calls, all exchange forms tried); with it, only the __shfl_xor form happened to be.  tools/flaky_probe*.py,
+// tools/variant_test.sh and tests/test_hip_determinism.py are the guards: re-run them after ANY change to this file.
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 struct TeamSample {  // normalised coordinates of the sample this lane's team serves in one round
@@ -625,11 +625,18 @@ __device__ __forceinline__ void team_finish(const VMTaps& t, const f32x4 raw[18]
 // ga = this lane's quad of the sample served in round 0 (tile column 2t), gb = of round 1 (column 2t + 1).  Even lanes own
 // column 2t: they keep ga (quad h) and take the odd neighbour's ga (quad h + 2); odd lanes keep gb and take the even
 // neighbour's gb.  v[0..11] = quad h, v[12..23] = quad h + 2 of the lane's own sample.
-// EGO_TEAM_EXCHANGE: 2 = ds_bpermute (default, the only reproducible form), 1 = v_mov_b32_dpp, 0 = ds_swizzle.
 #ifndef EGO_TEAM_EXCHANGE
-#define EGO_TEAM_EXCHANGE 2
+#define EGO_TEAM_EXCHANGE 1
+#endif
+#ifndef EGO_GATHER_TEAMS
+#define EGO_GATHER_TEAMS 1
 #endif
 __device__ __forceinline__ void team_to_halves(const float ga[12], const float gb[12], float* v) {
+  if (!EGO_GATHER_TEAMS) {
+#pragma unroll
+    for (int idx = 0; idx < 12; ++idx) { v[idx] = ga[idx]; v[12 + idx] = gb[idx]; }
+    return;
+  }
   const bool even = (threadIdx.x & 1) == 0;
 #pragma unroll
   for (int idx = 0; idx < 12; ++idx) {
@@ -664,7 +671,10 @@ __device__ __forceinline__ void basis3(const u32x4* __restrict__ BASH, int lane,
 
 __device__ __forceinline__ void gather_basis_team(const DevField& F, const TeamSample ts[2], const u32x4* __restrict__ BASH, int lane,
                                                   int g, bool mixed, int gu, f32x16& fe, float* vdump) {
-  const int qa = (lane >> 5) + 2 * (lane & 1), qb = (lane >> 5) + 2 * ((lane & 1) ^ 1);  // quad read in round 0 / round 1
+  // EGO_GATHER_TEAMS 1: 4-lane teams (above).  0: no teams - both rounds serve the lane's OWN sample (ts[0] == ts[1]), round 0
+  // reads quad h and round 1 quad h + 2, nothing is exchanged between lanes; an instruction then touches 32 lines instead of 16.
+  const int qa = EGO_GATHER_TEAMS ? (lane >> 5) + 2 * (lane & 1) : (lane >> 5);
+  const int qb = EGO_GATHER_TEAMS ? (lane >> 5) + 2 * ((lane & 1) ^ 1) : (lane >> 5) + 2;
   // A lane's output column depends only on its own inputs, so a wave that straddles the yin/yang border (rare) runs the
   // steps with both weight sets on the unmasked products, into two accumulators, and each lane keeps its grid's one at the
   // end: no per-value masking anywhere, and nothing extra for the waves of one grid.
@@ -852,7 +862,7 @@ __global__ __launch_bounds__(512) void k_shade_h(ShadeArgs A) {
         TeamSample ts[2];
 #pragma unroll
         for (int rd = 0; rd < 2; ++rd) {
-          const int64_t mt_raw = tile * 32 + 2 * ((lw >> 1) & 15) + rd;
+          const int64_t mt_raw = EGO_GATHER_TEAMS ? tile * 32 + 2 * ((lw >> 1) & 15) + rd : tile * 32 + (lw & 31);
           const int64_t mt = mt_raw < A.M ? mt_raw : A.M - 1;
           if (MODE == MODE_APP) {
             const float* p = A.c7n + mt * 7;

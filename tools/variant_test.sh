@@ -6,8 +6,7 @@ cd "$(dirname "$0")/.."
 MACRO=$1; VALUES=$2; SCRIPT=$3
 rm -f egonerf_amd/libvariant_*.so
 for v in $VALUES; do
-  (cd egonerf_amd/csrc && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -munsafe-fp-atomics -shared -fPIC \
-     -D$MACRO=$v ego_ops.hip ego_shade.hip ego_render.hip ego_reg.hip ego_metrics.hip ego_wgrad.hip -o ../libvariant_$v.so 2>&1 | grep -i "error" | head -3) &
+  EGO_EXTRA_FLAGS="-D$MACRO=$v" EGO_LIB_OUT=$PWD/egonerf_amd/libvariant_$v.so python -c "from egonerf_amd.build import build_library as b; b(force=True)" &
 done
 wait
 for v in $VALUES; do test -f egonerf_amd/libvariant_$v.so || { echo "variant $v failed to build"; exit 1; }; done
