@@ -53,9 +53,9 @@ def build_library(force: bool = False, verbose: bool = False, extra: list | None
             print(" ".join(cmd))
         procs.append((f, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
     for f, pr in procs:
-        out, _ = pr.communicate()
+        log, _ = pr.communicate()
         if pr.returncode != 0:
-            raise RuntimeError(f"hipcc failed on {f}:\n" + out)
+            raise RuntimeError(f"hipcc failed on {f}:\n" + log)
     cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", out + ".tmp"]
     if verbose:
         print(" ".join(cmd))
