@@ -31,6 +31,22 @@ def _layout(which: int, n: int, device) -> torch.Tensor:
     return _LAYOUT_CACHE[key]
 
 
+_INDEX_CACHE = {}
+
+
+def _grad_indices(device):
+    """Index tensors that un-permute the lane-order columns of the weight-gradient products, derived once from the layouts
+    (boolean masks / nonzero() in the backward pass would cost a host synchronisation each, every step)."""
+    key = str(device)
+    if key not in _INDEX_CACHE:
+        hid, xmap, fmap, vmap = (_layout(w, n, "cpu") for w, n in ((1, 128), (0, 160), (2, 32), (3, 144)))
+        x_sel = (xmap >= 0).nonzero().flatten()
+        f_sel = (fmap >= 0).nonzero().flatten()
+        d = dict(hid=hid, x_sel=x_sel, x_cols=xmap[x_sel], pad=int((xmap < 0).nonzero()[0]), f_sel=f_sel, f_rows=fmap[f_sel], vmap=vmap)
+        _INDEX_CACHE[key] = {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in d.items()}
+    return _INDEX_CACHE[key]
+
+
 def _tgemm(a: torch.Tensor, b: torch.Tensor, chunk: int = 8192) -> torch.Tensor:
     """a.T @ b for tall-skinny a [M,p], b [M,q] (M = all samples of the step): a plain sgemm with K = M gets one
     poorly parallelised rocBLAS kernel, so the K axis is cut into a batch (bmm) and the partial products are summed."""
@@ -184,10 +200,8 @@ class RenderFunction(torch.autograd.Function):
         # ---- weight gradients: one pass of ego_weight_grad (bf16 hi/lo MFMA over transposed LDS tiles, bias gradients from a
         # ones column) per layer over the dumped buffers, then un-permute the lane-order columns ----
         do = dc.view(M, 3)  # now d(pre-sigmoid)
-        hid = _layout(1, 128, dev)
-        xmap = _layout(0, 160, dev)
-        fmap = _layout(2, 32, dev)
-        vmap = _layout(3, 144, dev)
+        ix = _grad_indices(dev)
+        hid, vmap = ix["hid"], ix["vmap"]
         mlp = model.renderModule.mlp
 
         def wgrad(A, ca, a_blocked, B, cb, ones_col):
@@ -205,19 +219,17 @@ class RenderFunction(torch.autograd.Function):
         gw2[hid[:, None], hid[None, :]] = G2[:, :128]
         gb2 = torch.zeros_like(mlp[2].bias)
         gb2[hid] = G2[:, 128]
-        pad = int((xmap < 0).nonzero()[0])  # a padding column of the x dump (holds zeros) doubles as the ones column
+        pad = ix["pad"]  # a padding column of the x dump (holds zeros) doubles as the ones column
         G1 = wgrad(dh1, 128, 1, sv["x"], 160, pad)
-        xv = xmap >= 0
         gw1 = torch.zeros_like(mlp[0].weight)
-        gw1[hid[:, None], xmap[xv][None, :]] = G1[:, xv]
+        gw1[hid[:, None], ix["x_cols"][None, :]] = G1[:, ix["x_sel"]]
         gb1 = torch.zeros_like(mlp[0].bias)
         gb1[hid] = G1[:, pad]
         Gb = wgrad(dfe, 64, 0, sv["v"], 144, -1)
         gbasis = []
-        fv = fmap >= 0
         for g in range(2):
             gb = torch.zeros(model.app_dim, 144, device=dev)
-            gb[fmap[fv][:, None], vmap[None, :]] = Gb[32 * g: 32 * g + 32, :144][fv]
+            gb[ix["f_rows"][:, None], vmap[None, :]] = Gb[32 * g: 32 * g + 32, :144][ix["f_sel"]]
             gbasis.append(gb)
         grads = g_dens + g_app + gbasis + [gw1, gb1, gw2, gb2, gw3, gb3]
         if sv["env"] is not None:
