@@ -47,6 +47,18 @@ def _grad_indices(device):
     return _INDEX_CACHE[key]
 
 
+def _zeros_like_many(tensors):
+    """One zero-filled flat buffer carved into tensors with the shapes AND strides of `tensors` (dense, e.g. channel-last
+    parameters): one fill kernel instead of one per gradient."""
+    total = sum(t.numel() for t in tensors)
+    flat = torch.zeros(total, device=tensors[0].device, dtype=tensors[0].dtype)
+    out, off = [], 0
+    for t in tensors:
+        out.append(torch.as_strided(flat, t.shape, t.stride(), off))
+        off += t.numel()
+    return out
+
+
 def _tgemm(a: torch.Tensor, b: torch.Tensor, chunk: int = 8192) -> torch.Tensor:
     """a.T @ b for tall-skinny a [M,p], b [M,q] (M = all samples of the step): a plain sgemm with K = M gets one
     poorly parallelised rocBLAS kernel, so the K axis is cut into a batch (bmm) and the partial products are summed."""
@@ -175,8 +187,8 @@ class RenderFunction(torch.autograd.Function):
             g_alpha = g_alpha.contiguous().float()
             assert g_alpha.shape == sv["alpha"].shape
         dens, app = table_params(model, "density"), table_params(model, "app")
-        g_dens = [torch.zeros_like(p) for p in dens]  # zeros_like keeps the channel-last strides of the parameter
-        g_app = [torch.zeros_like(p) for p in app]
+        g_all = _zeros_like_many(dens + app)  # keeps the channel-last strides of the parameters
+        g_dens, g_app = g_all[:len(dens)], g_all[len(dens):]
         for p, g in zip(dens + app, g_dens + g_app):
             assert g.stride() == p.stride()
         f = lambda *shape: torch.empty(*shape, device=dev, dtype=torch.float32)
