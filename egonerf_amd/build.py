@@ -28,9 +28,10 @@ def is_stale() -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-# Per-source extra flags.  ego_shade.hip is built without the SLP vectoriser: of all the builds of its team-gather kernels tried
-#  the ones compiled this way have been bit-reproducible in every soak (> 300 000 calls); builds with SLP-formed
-# packed ops were reproducible only by accident of the rest of the code.  It costs no time (0.55 ms either way).
+# Per-source extra flags.  ego_shade.hip is built without the SLP vectoriser: it forms {w00, w01}-style pairs of the interpolation
+# weights, and the packed fp32 instructions that then broadcast the high half of such a pair are what every non-reproducible build
+# of these kernels had in common.  The source also pins the weights to separate registers; either measure alone
+# was enough in every soak, neither costs time.
 EXTRA_FLAGS = {"ego_shade.hip": ["-fno-slp-vectorize"]}
 COMMON_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-munsafe-fp-atomics", "-fPIC"]
 
@@ -48,7 +49,8 @@ def build_library(force: bool = False, verbose: bool = False, extra: list | None
     for f in SOURCES:  # one hipcc per source, in parallel: the sources have no device-side references to one another
         obj = os.path.join(objdir, f.replace(".hip", ".o"))
         objs.append(obj)
-        cmd = [_hipcc(), *COMMON_FLAGS, *EXTRA_FLAGS.get(f, []), *extra, "-c", os.path.join(CSRC, f), "-o", obj]
+        per_file = [] if os.environ.get("EGO_NO_PER_FILE_FLAGS") else EXTRA_FLAGS.get(f, [])  # experiments only
+        cmd = [_hipcc(), *COMMON_FLAGS, *per_file, *extra, "-c", os.path.join(CSRC, f), "-o", obj]
         if verbose:
             print(" ".join(cmd))
         procs.append((f, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

@@ -611,12 +611,21 @@ template <int I>
 __device__ __forceinline__ void team_finish(const VMTaps& t, const f32x4 raw[18], float out[12]) {
 #pragma clang fp contract(fast)
   const Lin1 X = t.ax[vm_plane_x(I)], Y = t.ax[vm_plane_y(I)], Ln = t.ax[vm_line_ax(I)];
-  const float w00 = __fmul_rn(Y.w0, X.w0), w01 = __fmul_rn(Y.w0, X.w1);
-  const float w10 = __fmul_rn(Y.w1, X.w0), w11 = __fmul_rn(Y.w1, X.w1);
+  float w00 = __fmul_rn(Y.w0, X.w0), w01 = __fmul_rn(Y.w0, X.w1);
+  float w10 = __fmul_rn(Y.w1, X.w0), w11 = __fmul_rn(Y.w1, X.w1);
+  float l0 = Ln.w0, l1 = Ln.w1;
+#ifndef EGO_PAIRED_WEIGHTS
+  // Every weight in a register of its own: a packed multiply then broadcasts the LOW half of its pair operand
+  // (op_sel_hi:[1,0]).  If the compiler vectorises the four products above into {w00, w01} / {w10, w11} pairs, the packed ops
+  // that consume w01 / w11 broadcast the HIGH half (op_sel:[1,0,0]) - and every build of these kernels that contained such
+  // instructions was non-reproducible, every build without them clean.  tests/test_abi_and_host.py checks the ISA.
+  asm volatile("" : "+v"(w00)); asm volatile("" : "+v"(w01)); asm volatile("" : "+v"(w10)); asm volatile("" : "+v"(w11));
+  asm volatile("" : "+v"(l0)); asm volatile("" : "+v"(l1));
+#endif
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
     const f32x4 pv = raw[i] * w00 + raw[3 + i] * w01 + raw[6 + i] * w10 + raw[9 + i] * w11;
-    const f32x4 lv = raw[12 + i] * Ln.w0 + raw[15 + i] * Ln.w1;
+    const f32x4 lv = raw[12 + i] * l0 + raw[15 + i] * l1;
     const f32x4 m = pv * lv;
     out[4 * i + 0] = m.x; out[4 * i + 1] = m.y; out[4 * i + 2] = m.z; out[4 * i + 3] = m.w;
   }
