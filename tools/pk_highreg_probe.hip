@@ -10,7 +10,7 @@ __global__ __launch_bounds__(512) void k_probe(unsigned* errors, int reps) {
   unsigned err = 0;
   for (int it = 0; it < reps; ++it) {
     float a0 = (float)(lane + it % 13), a1 = (float)(lane * 2 + 1), b0 = (float)(lane % 5 + 1), b1 = (float)(lane % 3 + 2);
-    float c0 = (float)((it + lane) % 11), c1 = 3.f, w0 = 0.5f, w1 = 0.25f;
+    float c0 = (float)((it + lane) % 11), c1 = 3.f, w0 = 0.5f + wave, w1 = 0.25f + 2 * wave + (it & 3);  // wave-specific weights
     asm volatile("" : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1), "+v"(c0), "+v"(c1), "+v"(w0), "+v"(w1));
     float r0, r1;
     if (MODE == 0) {  // high registers
@@ -19,6 +19,15 @@ __global__ __launch_bounds__(512) void k_probe(unsigned* errors, int reps) {
                    "v_pk_mul_f32 v[228:229], v[220:221], v[226:227] op_sel_hi:[1,0]\n"     // a * w0
                    "v_pk_fma_f32 v[228:229], v[222:223], v[226:227], v[228:229] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n"  // + b * w1
                    "v_pk_mul_f32 v[230:231], v[228:229], v[224:225]\n"                    // * c
+                   "s_nop 1\n v_mov_b32 %0, v230\n v_mov_b32 %1, v231"
+                   : "=v"(r0), "=v"(r1) : "v"(a0), "v"(a1), "v"(b0), "v"(b1), "v"(c0), "v"(c1), "v"(w0), "v"(w1)
+                   : "v220", "v221", "v222", "v223", "v224", "v225", "v226", "v227", "v228", "v229", "v230", "v231");
+    } else if (MODE == 2) {  // the failing kernels' form: v_pk_fma_f32 D, W, X, D op_sel:[1,0,0] (both results use W's odd register)
+      asm volatile("v_mov_b32 v220, %2\n v_mov_b32 v221, %3\n v_mov_b32 v222, %4\n v_mov_b32 v223, %5\n v_mov_b32 v224, %6\n v_mov_b32 v225, %7\n"
+                   "v_mov_b32 v226, %8\n v_mov_b32 v227, %9\n s_nop 1\n"
+                   "v_pk_mul_f32 v[228:229], v[220:221], v[226:227] op_sel_hi:[1,0]\n"
+                   "v_pk_fma_f32 v[228:229], v[226:227], v[222:223], v[228:229] op_sel:[1,0,0]\n"
+                   "v_pk_mul_f32 v[230:231], v[228:229], v[224:225]\n"
                    "s_nop 1\n v_mov_b32 %0, v230\n v_mov_b32 %1, v231"
                    : "=v"(r0), "=v"(r1) : "v"(a0), "v"(a1), "v"(b0), "v"(b1), "v"(c0), "v"(c1), "v"(w0), "v"(w1)
                    : "v220", "v221", "v222", "v223", "v224", "v225", "v226", "v227", "v228", "v229", "v230", "v231");
@@ -52,5 +61,6 @@ int main() {
   (void)hipMalloc(&d_err, 32);
   run<0>(d_err, "packed fp32 math on v220..v231");
   run<1>(d_err, "packed fp32 math on v20..v31 (232-VGPR allocation)");
+  run<2>(d_err, "v_pk_fma_f32 D, W, X, D op_sel:[1,0,0] on v220..v231");
   return 0;
 }
