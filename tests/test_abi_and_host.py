@@ -157,18 +157,24 @@ def test_reference_checkpoint_loads_on_cpu(golden):
     assert model.near_far == [0.01, 15.0] and model.density_shift == -8 and model.fea2denseAct == "softplus"
 
 
-def test_shade_kernels_have_no_high_half_broadcast_packed_fp32_ops(tmp_path):
+def test_kernels_have_no_high_half_broadcast_packed_fp32_ops(tmp_path):
     """every build of ego_shade.hip whose kernels contained packed fp32 instructions broadcasting the HIGH dword of
     a register pair (`v_pk_fma_f32 ... op_sel:[1,0,0]` without op_sel_hi) returned wrong results in some calls on MI355X; builds
-    without them never did.  Compile the file to gfx950 assembly with the build's flags and check that none is there."""
+    without them never did.  Compile every source to gfx950 assembly with the build's flags and check that none is there."""
     import os, re, subprocess
     from egonerf_amd import build
-    src = os.path.join(build.CSRC, "ego_shade.hip")
-    out = str(tmp_path / "ego_shade.s")
-    cmd = [build._hipcc(), *[f for f in build.COMMON_FLAGS if f != "-fPIC"], *build.EXTRA_FLAGS.get("ego_shade.hip", []), "-S", "--cuda-device-only",
-           "-o", out, src]
-    r = subprocess.run(cmd, capture_output=True, text=True)
-    assert r.returncode == 0, r.stderr[-2000:]
-    bad = [l.strip() for l in open(out) if re.search(r"v_pk_(fma|mul|add)_f32", l) and "op_sel:" in l and "op_sel_hi" not in l]
-    assert not bad, bad[:5]
-    assert sum(1 for l in open(out) if "v_pk_fma_f32" in l) > 100  # the check looked at real code
+    procs = []
+    for f in build.SOURCES:
+        out = str(tmp_path / f.replace(".hip", ".s"))
+        cmd = [build._hipcc(), *[x for x in build.COMMON_FLAGS if x != "-fPIC"], *build.EXTRA_FLAGS.get(f, []), "-S", "--cuda-device-only",
+               "-o", out, os.path.join(build.CSRC, f)]
+        procs.append((f, out, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    n_packed = 0
+    for f, out, pr in procs:
+        log, _ = pr.communicate()
+        assert pr.returncode == 0, (f, log[-2000:])
+        lines = [l.strip() for l in open(out) if re.search(r"v_pk_(fma|mul|add)_f32", l)]
+        n_packed += len(lines)
+        bad = [l for l in lines if "op_sel:" in l and "op_sel_hi" not in l]
+        assert not bad, (f, bad[:5])
+    assert n_packed > 1000  # the check looked at real code
