@@ -631,6 +631,49 @@ __device__ __forceinline__ void team_finish(const VMTaps& t, const f32x4 raw[18]
   }
 }
 
+// ---- rolling form of the same gather (gather_basis_team<ROLL = true>): the 18-register load buffer is recycled line by line -----
+// A round's 18 loads are three lines of six taps.  Instead of "issue 18, wait, compute 12 products, issue the next 18", the six
+// registers of a line are refilled with the NEXT round's loads as soon as that line's four products are computed, so 12-18 loads
+// stay in flight all the time instead of the queue draining once per round (the gather is latency-bound, not issue-bound).
+struct TapPtrs {
+  const f32x4 *p00, *p01, *p10, *p11, *l0, *l1;
+  float w00, w01, w10, w11, wl0, wl1;
+};
+
+template <int I>
+__device__ __forceinline__ TapPtrs tap_ptrs(const DevField& F, const VMTaps& t, int g, int q) {
+  const Lin1 X = t.ax[vm_plane_x(I)], Y = t.ax[vm_plane_y(I)], Ln = t.ax[vm_line_ax(I)];
+  const int W = F.res[vm_plane_x(I)];
+  const float* P = (g ? F.plane[1][I] : F.plane[0][I]) + 4 * q;
+  const float* L = (g ? F.line[1][I] : F.line[0][I]) + 4 * q;
+  TapPtrs tp;
+  tp.p00 = (const f32x4*)(P + (uint32_t)((Y.i0 * W + X.i0) * APP_C));
+  tp.p01 = (const f32x4*)(P + (uint32_t)((Y.i0 * W + X.i1) * APP_C));
+  tp.p10 = (const f32x4*)(P + (uint32_t)((Y.i1 * W + X.i0) * APP_C));
+  tp.p11 = (const f32x4*)(P + (uint32_t)((Y.i1 * W + X.i1) * APP_C));
+  tp.l0 = (const f32x4*)(L + (uint32_t)(Ln.i0 * APP_C));
+  tp.l1 = (const f32x4*)(L + (uint32_t)(Ln.i1 * APP_C));
+  tp.w00 = __fmul_rn(Y.w0, X.w0); tp.w01 = __fmul_rn(Y.w0, X.w1);
+  tp.w10 = __fmul_rn(Y.w1, X.w0); tp.w11 = __fmul_rn(Y.w1, X.w1);
+  tp.wl0 = Ln.w0; tp.wl1 = Ln.w1;
+  // separate registers for the weights: see team_finish
+  asm volatile("" : "+v"(tp.w00)); asm volatile("" : "+v"(tp.w01)); asm volatile("" : "+v"(tp.w10)); asm volatile("" : "+v"(tp.w11));
+  asm volatile("" : "+v"(tp.wl0)); asm volatile("" : "+v"(tp.wl1));
+  return tp;
+}
+
+__device__ __forceinline__ void line_load(const TapPtrs& tp, int i, f32x4 r[6]) {
+  r[0] = tp.p00[4 * i]; r[1] = tp.p01[4 * i]; r[2] = tp.p10[4 * i]; r[3] = tp.p11[4 * i]; r[4] = tp.l0[4 * i]; r[5] = tp.l1[4 * i];
+}
+
+__device__ __forceinline__ void line_finish(const TapPtrs& tp, const f32x4 r[6], float out[4]) {
+#pragma clang fp contract(fast)
+  const f32x4 pv = r[0] * tp.w00 + r[1] * tp.w01 + r[2] * tp.w10 + r[3] * tp.w11;
+  const f32x4 lv = r[4] * tp.wl0 + r[5] * tp.wl1;
+  const f32x4 m = pv * lv;
+  out[0] = m.x; out[1] = m.y; out[2] = m.z; out[3] = m.w;
+}
+
 // ga = this lane's quad of the sample served in round 0 (tile column 2t), gb = of round 1 (column 2t + 1).  Even lanes own
 // column 2t: they keep ga (quad h) and take the odd neighbour's ga (quad h + 2); odd lanes keep gb and take the even
 // neighbour's gb.  v[0..11] = quad h, v[12..23] = quad h + 2 of the lane's own sample.
@@ -678,6 +721,9 @@ __device__ __forceinline__ void basis3(const u32x4* __restrict__ BASH, int lane,
   basis_step(f0, v, keep, fe); basis_step(f1, v + 8, keep, fe); basis_step(f2, v + 16, keep, fe);
 }
 
+// ROLL: the rolling form of the load buffer (tap_ptrs / line_load / line_finish above); it needs all 256 registers, so only the
+// fused inference kernel uses it (the dumping and stand-alone instantiations would spill)
+template <bool ROLL>
 __device__ __forceinline__ void gather_basis_team(const DevField& F, const TeamSample ts[2], const u32x4* __restrict__ BASH, int lane,
                                                   int g, bool mixed, int gu, f32x16& fe, float* vdump) {
   // EGO_GATHER_TEAMS 1: 4-lane teams (above).  0: no teams - both rounds serve the lane's OWN sample (ts[0] == ts[1]), round 0
@@ -696,6 +742,41 @@ __device__ __forceinline__ void gather_basis_team(const DevField& F, const TeamS
   // previous plane so that they overlap; the co-resident wave and the MLP phase hide the rest
   f32x4 raw[18];
   float ga[12], gb[12], v[24];
+  if (ROLL) {
+    f32x4 (*ln)[6] = (f32x4 (*)[6])raw;  // three lines of six taps
+    TapPtrs pa = tap_ptrs<0>(F, tA, ts[0].g, qa), pb = tap_ptrs<0>(F, tB, ts[1].g, qb);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) line_load(pa, i, ln[i]);
+#define EGO_ROLL_PLANE(PL, NEXT_A, STEP0, DUMPPTR)                                                        \
+    {                                                                                                     \
+      _Pragma("unroll") for (int i = 0; i < 3; ++i) {                                                     \
+        line_finish(pa, ln[i], ga + 4 * i);                                                               \
+        line_load(pb, i, ln[i]);                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                                \
+      }                                                                                                   \
+      NEXT_A;                                                                                             \
+      _Pragma("unroll") for (int i = 0; i < 3; ++i) {                                                     \
+        line_finish(pb, ln[i], gb + 4 * i);                                                               \
+        if (PL < 2) line_load(pa, i, ln[i]);                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                                \
+      }                                                                                                   \
+      team_to_halves(ga, gb, v);                                                                          \
+      dump24(DUMPPTR, v);                                                                                 \
+      basis3(BASH, lane, STEP0, g0, true, v, fe);                                                         \
+      if (mixed) basis3(BASH, lane, STEP0, 1, true, v, fe2);                                              \
+    }
+    EGO_ROLL_PLANE(0, pa = tap_ptrs<1>(F, tA, ts[0].g, qa), 0, vdump)
+    pb = tap_ptrs<1>(F, tB, ts[1].g, qb);
+    EGO_ROLL_PLANE(1, pa = tap_ptrs<2>(F, tA, ts[0].g, qa), 3, (vdump ? vdump + 6 * 256 : nullptr))
+    pb = tap_ptrs<2>(F, tB, ts[1].g, qb);
+    EGO_ROLL_PLANE(2, (void)0, 6, (vdump ? vdump + 12 * 256 : nullptr))
+#undef EGO_ROLL_PLANE
+    if (mixed) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) fe[r] = g ? fe2[r] : fe[r];
+    }
+    return;
+  }
   team_load<0>(F, tA, ts[0].g, qa, raw);
   team_finish<0>(tA, raw, ga);
   __builtin_amdgcn_sched_barrier(0);
@@ -888,7 +969,7 @@ __global__ __launch_bounds__(512) void k_shade_h(ShadeArgs A) {
         float* vd = (DUMP && valid) ? A.dump_v + dump_off(tile, 144, 0, hw, j) : nullptr;
         // one gather per tile; a border-straddling wave runs the basis steps of each plane twice (yin weights with the
         // yang lanes zeroed, then the reverse) inside gather_basis_team
-        gather_basis_team(A.F, ts, BASH, lw, g, mixed, gu, fe, vd);
+        gather_basis_team<(MODE == MODE_SHADE && !DUMP)>(A.F, ts, BASH, lw, g, mixed, gu, fe, vd);
       }
     }
 
