@@ -5,9 +5,9 @@ The differentiable call is a `torch.autograd.Function` whose forward is the same
 (coarse march on the pooled tables -> inverse-CDF resampling -> fine march -> shade -> composite; the fine
 sample positions are detached like EgoNeRF.py:534) and whose backward runs `ego_march_backward`
 (compositing + density, scatter-add into the density tables) and `ego_shade_backward` (MLP / basis data
-gradients on the fp16-split MFMA path, scatter-add into the appearance tables).  The basis / MLP weight
-gradients are plain library GEMMs (rocBLAS through torch.matmul) over the per-sample buffers the kernels
-leave behind, un-permuted with the column maps of `ego_train_layout`.
+gradients on the fp16-split MFMA path, scatter-add into the appearance tables).  The basis / MLP weight and
+bias gradients come from `ego_weight_grad` (csrc/ego_wgrad.hip: one bf16 hi/lo MFMA pass per layer over the per-sample
+buffers the kernels leave behind), un-permuted with the column maps of `ego_train_layout`.
 """
 from __future__ import annotations
 
@@ -57,31 +57,6 @@ def _zeros_like_many(tensors):
         out.append(torch.as_strided(flat, t.shape, t.stride(), off))
         off += t.numel()
     return out
-
-
-def _tgemm(a: torch.Tensor, b: torch.Tensor, chunk: int = 8192) -> torch.Tensor:
-    """a.T @ b for tall-skinny a [M,p], b [M,q] (M = all samples of the step): a plain sgemm with K = M gets one
-    poorly parallelised rocBLAS kernel, so the K axis is cut into a batch (bmm) and the partial products are summed."""
-    M = a.shape[0]
-    nb = M // chunk
-    out = None
-    if nb > 0:
-        av = a[: nb * chunk].view(nb, chunk, a.shape[1]).transpose(1, 2)
-        bv = b[: nb * chunk].view(nb, chunk, b.shape[1])
-        out = torch.bmm(av, bv).sum(0)
-    if nb * chunk < M:
-        tail = a[nb * chunk:].t() @ b[nb * chunk:]
-        out = tail if out is None else out + tail
-    return out
-
-
-def _colsum(a: torch.Tensor, rows: int) -> torch.Tensor:
-    """Column sums of a tall-skinny [M, c] matrix.  torch's reduction parallelises over the c output columns only (1 ms for
-    M = 2.1 M, c = 3), so fold M = rows * k first: [rows, k * c] -> sum over rows -> [k, c] -> sum."""
-    M, c = a.shape
-    if rows > 1 and M % rows == 0:
-        return a.view(rows, (M // rows) * c).sum(0).view(M // rows, c).sum(0)
-    return a.sum(0)
 
 
 def _grad_struct(tensors: List[torch.Tensor]) -> "_lib.VmGrad":
