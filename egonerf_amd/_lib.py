@@ -6,6 +6,7 @@ missing or a call fails, a RuntimeError is raised.
 from __future__ import annotations
 
 import ctypes as C
+import functools
 import os
 import re
 from typing import List
@@ -69,7 +70,7 @@ PROTOTYPES = {
     "ego_sizeof": (I64, [I32]),
     "ego_packed_floats": (I64, []),
     "ego_sample_ray_exp": (C.c_int, [P, P, P, F32, I64, I32, P, P, P]),
-    "ego_erp_rays": (C.c_int, [I32, I32, I32, I32, C.POINTER(C.c_float), P, P]),
+    "ego_erp_rays": (C.c_int, [I32, I32, I32, I32, C.POINTER(C.c_float), I32, P, P]),
     "ego_from_cartesian": (C.c_int, [SP, P, I64, P, P]),
     "ego_normalize_coord": (C.c_int, [SP, P, I64, P, P]),
     "ego_density_feature": (C.c_int, [SP, P, I64, I32, P, P]),
@@ -147,5 +148,40 @@ def ptr(t) -> int:
 
 
 def stream_handle() -> int:
-    import torch
+    """Raw hipStream_t of torch's current stream on the CURRENT device; entry points run under `device_guard`, which makes
+    the device of their tensors current first."""
     return torch.cuda.current_stream().cuda_stream
+
+
+def _device_of(args) -> "torch.device | None":
+    for a in args:
+        if torch.is_tensor(a):
+            if a.is_cuda:
+                return a.device
+        elif isinstance(a, torch.nn.Module):
+            p = next(a.parameters(), None)
+            if p is not None and p.is_cuda:
+                return p.device
+        elif isinstance(a, torch.optim.Optimizer):
+            for g in a.param_groups:
+                for p in g["params"]:
+                    if p.is_cuda:
+                        return p.device
+    return None
+
+
+def device_guard(fn):
+    """Decorator for every entry point that launches kernels: the C ABI takes raw pointers and a raw stream, so the launch
+    must happen with the device that owns the pointers current (and on THAT device's current stream).  The owning device is
+    the first HIP tensor among the positional arguments (or the first parameter of a module / optimiser argument); when it
+    differs from torch's current device the call runs inside `torch.cuda.device(owner)`."""
+
+    @functools.wraps(fn)
+    def guarded(*args, **kw):
+        dev = _device_of(args) or _device_of(kw.values())
+        if dev is None or dev.index == torch.cuda.current_device():
+            return fn(*args, **kw)
+        with torch.cuda.device(dev):
+            return fn(*args, **kw)
+
+    return guarded

@@ -50,6 +50,23 @@ class YinYangSphericalCoords:
         self.update_aabb(aabb)
         self.set_resolution(self.N_to_reso(N_voxel, aabb), r0=r0)
 
+    _REFERENCE_ATTRS = ("center", "device", "near", "far", "inv_diff", "exp_r", "interval_th", "N_r", "N_theta", "N_phi", "r0", "ratio")
+
+    def __reduce_ex__(self, protocol):
+        """Inside compat.reference_pickle_paths() (EgoNeRF.save) the object pickles as the reference's
+        models.coordinates.YinYangSphericalCoords with exactly its attribute set (no device LUT cache, no aabb copy)."""
+        from . import compat
+        if not compat.pickling_as_reference():
+            return super().__reduce_ex__(protocol)
+        state = {k: getattr(self, k) for k in self._REFERENCE_ATTRS if hasattr(self, k)}
+        state["device"] = str(state["device"])
+        return compat.reduce_as_reference("models.coordinates", "YinYangSphericalCoords", state)
+
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        state["_lut_dev"] = None  # device tensors: rebuilt on demand
+        return state
+
     def __setstate__(self, state):
         """Also accepts the attribute set of a pickled reference object (models.coordinates.YinYangSphericalCoords inside
         a `.th` checkpoint's kwargs, tensorBase.py:264): device, center, near, far, inv_diff, exp_r, interval_th, N_*, r0,
@@ -140,6 +157,7 @@ class YinYangSphericalCoords:
         r01 = (k_in + (new - G[k_in]) / (G[k_out] - G[k_in])) / self.N_r  # normalize_r, coordinates.py:125-131
         return r01 * 2 - 1
 
+    @_lib.device_guard
     def up_sampling_VM(self, weights: torch.Tensor, res_target, ids):
         """coordinates.py:226-266: `weights` (1, C, H, W) channel-last table; ids = [axis of H, axis of W] (plane) or
         [axis] (line) -> resampled channel-last nn.Parameter."""
@@ -194,6 +212,7 @@ class YinYangSphericalCoords:
         return sc
 
     # -- per-point ops (HIP) ---------------------------------------------------------------------------
+    @_lib.device_guard
     def from_cartesian(self, xyz_points: torch.Tensor) -> torch.Tensor:
         """[...,3] -> [...,7] (coordinates.py:468-498)."""
         _require_cuda(xyz_points, "from_cartesian")
@@ -206,6 +225,7 @@ class YinYangSphericalCoords:
                    "ego_from_cartesian")
         return out
 
+    @_lib.device_guard
     def normalize_coord(self, unnormalized_coords: torch.Tensor, downsample=None) -> torch.Tensor:
         """[...,7] -> [...,7] in [-1,1] (+flag) (coordinates.py:442-466).  `downsample` is ignored by the interval_th grid
         (coordinates.py:112-117) and coarsens the plain exponential one (coordinates.py:137-139)."""

@@ -544,14 +544,19 @@ __global__ void k_avgpool(const float* __restrict__ src, int H, int W, int C, fl
 // =============================================================================================
 struct Pose34 { float m[12]; };
 
-__global__ void k_erp_rays(int H, int W, int row0, int n_rows, Pose34 c2w, float* __restrict__ rays) {
+__global__ void k_erp_rays(int H, int W, int row0, int n_rows, Pose34 c2w, int normalize, float* __restrict__ rays) {
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (int64_t)n_rows * W) return;
   const int col = (int)(idx % W), row = row0 + (int)(idx / W);
   const float i = (float)col + 0.5f, j = (float)row + 0.5f;
   const float phi = __fmul_rn(__fsub_rn(1.f, __fdiv_rn(__fmul_rn(2.f, i), (float)W)), 3.14159265358979323846f);
   const float theta = __fdiv_rn(__fmul_rn(__fsub_rn(1.f, __fdiv_rn(__fmul_rn(2.f, j), (float)H)), 3.14159265358979323846f), 2.f);
-  const float ct = cosf(theta), d0 = -ct * sinf(phi), d1 = sinf(theta), d2 = -ct * cosf(phi);
+  const float ct = cosf(theta);
+  float d0 = -ct * sinf(phi), d1 = sinf(theta), d2 = -ct * cosf(phi);
+  if (normalize) {  // directions / torch.norm(directions, dim=-1): sqrt of the sum of squares, then three divisions
+    const float n = __fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(d0, d0), __fmul_rn(d1, d1)), __fmul_rn(d2, d2)));
+    d0 = __fdiv_rn(d0, n); d1 = __fdiv_rn(d1, n); d2 = __fdiv_rn(d2, n);
+  }
   float* o = rays + idx * 6;
   o[0] = c2w.m[3]; o[1] = c2w.m[7]; o[2] = c2w.m[11];
 #pragma unroll
@@ -576,13 +581,14 @@ int ego_sample_ray_exp(const float* rays, const float* r_sched, const float* jit
   return ego_launch_status("k_sample_ray_exp");
 }
 
-int ego_erp_rays(int32_t H, int32_t W, int32_t row0, int32_t n_rows, const float* c2w, float* rays, void* stream) {
+int ego_erp_rays(int32_t H, int32_t W, int32_t row0, int32_t n_rows, const float* c2w, int32_t normalize, float* rays,
+                 void* stream) {
   EGO_REQUIRE(H >= 1 && W >= 1 && row0 >= 0 && n_rows >= 0 && row0 + n_rows <= H, "erp_rays: bad image window");
   if (n_rows == 0) return EGO_OK;
   EGO_REQUIRE(c2w && rays, "erp_rays: null argument");
   Pose34 p;
   for (int i = 0; i < 12; ++i) p.m[i] = c2w[i];
-  k_erp_rays<<<nblk((int64_t)n_rows * W, 256), 256, 0, (hipStream_t)stream>>>(H, W, row0, n_rows, p, rays);
+  k_erp_rays<<<nblk((int64_t)n_rows * W, 256), 256, 0, (hipStream_t)stream>>>(H, W, row0, n_rows, p, normalize, rays);
   return ego_launch_status("k_erp_rays");
 }
 

@@ -1139,7 +1139,6 @@ __global__ __launch_bounds__(512) void k_shade_h(ShadeArgs A) {
 
 int check_shade_config(const ego_scene* sc, const char* who, bool need_tables, bool need_mlp) {
   if (!sc) return ego_fail(EGO_E_BADARG, "%s: null scene", who);
-  if (!sc->packed) return ego_fail(EGO_E_BADARG, "%s: scene.packed is null (call ego_pack_mlp first)", who);
   if (sc->app_dim != APP_DIM) return ego_fail(EGO_E_UNSUPPORTED, "%s: app_dim %d (supported: 27)", who, sc->app_dim);
   if (need_tables) {
     if (sc->app.n_comp != APP_C) return ego_fail(EGO_E_UNSUPPORTED, "%s: appearance n_comp %d (supported: 48)", who, sc->app.n_comp);
@@ -1150,6 +1149,7 @@ int check_shade_config(const ego_scene* sc, const char* who, bool need_tables, b
   if (need_mlp && (sc->mlp_in != MLP_IN || sc->mlp_hidden != HID || sc->view_pe != 2 || sc->fea_pe != 2))
     return ego_fail(EGO_E_UNSUPPORTED, "%s: MLP_Fea config in=%d hidden=%d view_pe=%d fea_pe=%d (supported: 150/128/2/2)", who,
                     sc->mlp_in, sc->mlp_hidden, sc->view_pe, sc->fea_pe);
+  if (!sc->packed) return ego_fail(EGO_E_BADARG, "%s: scene.packed is null (call ego_pack_mlp first)", who);
   return EGO_OK;
 }
 

@@ -31,6 +31,7 @@ class _TableReg(torch.autograd.Function):
     """value = sum over tables of one regulariser term; kind in {"tv", "l1", "ortho"}; scales[i] multiplies table i's term."""
 
     @staticmethod
+    @_lib.device_guard
     def forward(ctx, kind: str, scales: Sequence[float], *tables: torch.Tensor):
         lib, st = _lib.load(), _lib.stream_handle()
         dev = tables[0].device
@@ -81,6 +82,7 @@ class TVLoss(torch.nn.Module):
 
 class _RayEntropy(torch.autograd.Function):
     @staticmethod
+    @_lib.device_guard
     def forward(ctx, alpha: torch.Tensor):
         lib, st = _lib.load(), _lib.stream_handle()
         _require_cuda(alpha, "ray_entropy_loss")

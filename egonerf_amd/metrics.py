@@ -9,6 +9,7 @@ import torch
 from . import _lib
 
 
+@_lib.device_guard
 def rgb_ssim(img0: torch.Tensor, img1: torch.Tensor, max_val, filter_size=11, filter_sigma=1.5, k1=0.01, k2=0.03, return_map=False):
     """utils.py:104-152 with the same signature; img0/img1 [H, W, 3] on the HIP device -> float (or the map tensor)."""
     assert img0.dim() == 3 and img0.shape[-1] == 3 and img0.shape == img1.shape

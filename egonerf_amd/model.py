@@ -65,6 +65,7 @@ def _table_ptr(t: torch.Tensor) -> int:
 # ---------------------------------------------------------------------------------------------------
 # models/tensorBase.py
 # ---------------------------------------------------------------------------------------------------
+@_lib.device_guard
 def raw2alpha(sigma: torch.Tensor, dist: torch.Tensor):
     """alpha, weights, bg_weight of tensorBase.py:22-27 (sigma, dist: [N_rays, N_samples])."""
     _require_cuda(sigma, "raw2alpha")
@@ -88,6 +89,7 @@ class EnvironmentMap:
         else:
             raise ValueError("Unknown environment map initialization: {}".format(init_strategy))
 
+    @_lib.device_guard
     def get_radiance(self, direction: torch.Tensor) -> torch.Tensor:
         _require_cuda(direction, "EnvironmentMap.get_radiance")
         d = _f32c(direction)
@@ -101,11 +103,19 @@ class EnvironmentMap:
         _call("ego_envmap_radiance", sc, d.data_ptr(), d.shape[0], out.data_ptr(), _lib.stream_handle())
         return out
 
+    def __reduce_ex__(self, protocol):
+        """Inside compat.reference_pickle_paths() (EgoNeRF.save): pickles as models.envmap.EnvironmentMap {emission}."""
+        from . import compat
+        if not compat.pickling_as_reference():
+            return super().__reduce_ex__(protocol)
+        return compat.reduce_as_reference("models.envmap", "EnvironmentMap", {"emission": self.emission})
+
     def load_envmap(self, emission, device):
         self.emission = torch.tensor(np.asarray(emission.detach().cpu() if torch.is_tensor(emission) else emission),
                                      requires_grad=True, device=device, dtype=torch.float32)
 
 
+@_lib.device_guard
 def SHRender(xyz_sampled, viewdirs: torch.Tensor, features: torch.Tensor) -> torch.Tensor:
     """models/tensorBase.py:30-34: degree-2 SH colour head, viewdirs [M,3], features [M,27] -> rgb [M,3] = relu(SH . f + 0.5).
     (`xyz_sampled` is unused, as in the reference.  The reference's EgoNeRF.forward cannot run with this head — it hands
@@ -134,6 +144,7 @@ class MLPRender_Fea(torch.nn.Module):
         torch.nn.init.constant_(self.mlp[-1].bias, 0)
         self._owner = None  # set by the model: provides the packed weights
 
+    @_lib.device_guard
     def forward(self, pts, viewdirs, features):
         _require_cuda(features, "MLPRender_Fea")
         if self._owner is None:
@@ -202,6 +213,7 @@ class TensorBase(torch.nn.Module):
                 "coordinates": self.coordinates, "use_envmap": self.envmap is not None, "envmap": self.envmap,
                 "coarse_sigma_grid_update_rule": self.coarse_sigma_grid_update_rule}
 
+    @_lib.device_guard
     def feature2density(self, density_features: torch.Tensor) -> torch.Tensor:
         """tensorBase.py:415-419."""
         _require_cuda(density_features, "feature2density")
@@ -237,6 +249,7 @@ class YinYangAlphaGridMask(torch.nn.Module):
         sc.occ = vol.data_ptr()
         sc.occ_res[:] = [vol.shape[3], vol.shape[2], vol.shape[1]]
 
+    @_lib.device_guard
     def sample_alpha(self, norm_samples):
         _require_cuda(norm_samples, "sample_alpha")
         _last_dim(norm_samples, 7, "sample_alpha")
@@ -266,6 +279,7 @@ class EgoNeRF(TensorBase):
         # opt-in skipping (EgoNeRF.forward itself evaluates every sample; see include/egonerf_hip.h):
         self.use_alpha_mask = False          # apply self.alphaMask with TensorBase.forward's semantics (sigma = 0 where empty)
         self.early_termination_eps = 0.0     # > 0: zero the weight of samples behind transmittance < eps
+        self.use_weight_thres = False        # TensorBase.forward's app skip: samples with weight <= rayMarch_weight_thres get rgb = 0
         self.coarse_sigma_plane_yin, self.coarse_sigma_line_yin = [None] * 3, [None] * 3
         self.coarse_sigma_plane_yang, self.coarse_sigma_line_yang = [None] * 3, [None] * 3
         if self.coarse_sigma_grid_update_rule is not None:
@@ -366,6 +380,7 @@ class EgoNeRF(TensorBase):
         print(f"upsamping to {res_target}")
 
     @torch.no_grad()
+    @_lib.device_guard
     def update_coarse_sigma_grid(self):
         """2x average-pooled density tables (EgoNeRF.py:124-133), kept channel-last."""
         if self.coarse_sigma_grid_update_rule != "conv":
@@ -450,6 +465,7 @@ class EgoNeRF(TensorBase):
                 f.plane[gi][i] = _table_ptr(planes[i])
                 f.line[gi][i] = _table_ptr(lines[i])
 
+    @_lib.device_guard
     def scene(self) -> "_lib.Scene":
         """The ego_scene struct for the current parameters (re-packs the MFMA weights when they changed)."""
         dev = self.density_plane_yin[0].device
@@ -459,14 +475,19 @@ class EgoNeRF(TensorBase):
         versions = tuple((t.data_ptr(), t._version) for t in mlp)
         if self._app_table_dtype == "f16":  # the half copy follows the appearance tables' versions
             versions += tuple((t.data_ptr(), t._version) for t in self._app_tables())
+        co = self.coordinates
+        luts = [co.lut_device(dev, 2)] + ([] if co.interval_th else [co.lut_device(dev, None)])  # held by the cache entry below
         keys = tuple(p.data_ptr() for p in self.parameters()) + (None if self.envmap is None else self.envmap.emission.data_ptr(),
                                                                   self.use_alpha_mask, id(self.alphaMask), float(self.early_termination_eps),
-                                                                  self.coordinates.N_r, float(self.coordinates.r0))
+                                                                  float(self.rayMarch_weight_thres) if self.use_weight_thres else None,
+                                                                  co.N_r, float(co.r0), float(co.far[0]), tuple(co.center.tolist()),
+                                                                  tuple(t.data_ptr() for t in luts), float(self.distance_scale),
+                                                                  float(self.density_shift), self.fea2denseAct)
         if self._scene_cache is not None and self._scene_cache[0] == keys and self._packed_versions == versions:
             return self._scene_cache[1]
         lib = _lib.load()
         sc = _lib.Scene()
-        self.coordinates.fill_scene(sc, dev)
+        co.fill_scene(sc, dev)
         sc.act_softplus = int(self.fea2denseAct == "softplus")
         sc.density_shift, sc.distance_scale = float(self.density_shift), float(self.distance_scale)
         g = self.gridSize.tolist()
@@ -482,10 +503,13 @@ class EgoNeRF(TensorBase):
         sc.mlp_in, sc.mlp_hidden = self.renderModule.in_mlpC, self.featureC
         sc.view_pe, sc.fea_pe = self.view_pe, self.fea_pe
         sc.mlp_precision = 1 if self._mlp_precision == "f32" else 0
-        if self._packed is None or self._packed.device != dev:
-            self._packed = torch.empty(lib.ego_packed_floats(), device=dev)
-        _call("ego_pack_mlp", sc, self._packed.data_ptr(), _lib.stream_handle())
-        sc.packed = self._packed.data_ptr()
+        if (self.app_dim, self.app_n_comp[0], self.featureC, self.view_pe, self.fea_pe) == (27, 48, 128, 2, 2):
+            if self._packed is None or self._packed.device != dev:
+                self._packed = torch.empty(lib.ego_packed_floats(), device=dev)
+            _call("ego_pack_mlp", sc, self._packed.data_ptr(), _lib.stream_handle())
+            sc.packed = self._packed.data_ptr()
+        # any other head shape: sc.packed stays NULL; the density-side stage ops work, every shading entry point then fails with
+        # the library's "unsupported configuration" error instead of failing here for calls that never shade
         if self._app_table_dtype == "f16":
             self._fill_app16(sc)
         if self.use_alpha_mask and self.alphaMask is not None:
@@ -496,15 +520,16 @@ class EgoNeRF(TensorBase):
             if not em.is_contiguous():
                 raise RuntimeError("envmap.emission must be contiguous [3][2h][h]")
             sc.envmap, sc.envmap_h = em.data_ptr(), em.shape[2]
-        self._scene_cache = (keys, sc, holds)
+        self._scene_cache = (keys, sc, holds, luts)
         self._packed_versions = versions
         return sc
 
     # -- stage methods (reference public API) ----------------------------------------------------------------
     def _sched(self, n_samples: int, device) -> torch.Tensor:
-        key = (n_samples, str(device), float(self.coordinates.r0))  # set_resolution() may move r0 (coordinates.py:214)
+        near, far = self.near_far
+        key = (n_samples, str(device), float(self.coordinates.r0), float(near), float(far),
+               bool(self.coordinates.interval_th))  # set_resolution() may move r0 (coordinates.py:214)
         if key not in self._sched_cache:
-            near, far = self.near_far
             self._sched_cache[key] = self.coordinates.sample_schedule(near, far, n_samples).to(device)
         return self._sched_cache[key]
 
@@ -532,6 +557,17 @@ class EgoNeRF(TensorBase):
         aabb = self.aabb.to(pts.device)
         return pts, z, ~((aabb[0] > pts) | (pts > aabb[1])).any(dim=-1)
 
+    def _plain_exp_train_z(self, n: int, jitter: torch.Tensor) -> torch.Tensor:
+        """Plain exponential schedule in training (EgoNeRF.py:59-67): the noise goes into the exponent and the distances are an
+        exclusive prefix sum; the reference's own expression, handed to the kernels as explicit distances [N, n]."""
+        near, far = float(self.near_far[0]), float(self.near_far[1])
+        ratio = 1 + (math.pi / 2.0) / n
+        r0 = (far - near) * (ratio - 1) / (pow(ratio, n) - 1)
+        rng = torch.arange(n, device=jitter.device)[None].float() + _f32c(jitter)
+        tri = torch.tril(torch.ones(n, n, device=jitter.device), diagonal=-1).T
+        return (near + torch.pow(ratio, rng) @ tri * r0).contiguous()
+
+    @_lib.device_guard
     def sample_ray_exp(self, rays_o, rays_d, is_train=True, N_samples=-1, jitter: Optional[torch.Tensor] = None):
         """EgoNeRF.py:56-87 -> (rays_pts [N,S,3], interpx [N,S], ~mask_outbbox [N,S]).  `jitter` [N,S] pins the
         training noise (the reference draws it with torch.rand_like on the CPU generator)."""
@@ -542,14 +578,19 @@ class EgoNeRF(TensorBase):
         if is_train and jitter is None:
             jitter = torch.rand(N, S).to(rays.device)
         jit = _f32c(jitter) if is_train else None
-        xyz = torch.empty(N, S, 3, device=rays.device)
-        z = torch.empty(N, S, device=rays.device)
-        _call("ego_sample_ray_exp", rays.data_ptr(), self._sched(S, rays.device).data_ptr(), _lib.ptr(jit),
-              float(self.near_far[0]), N, S, xyz.data_ptr(), z.data_ptr(), _lib.stream_handle())
+        if is_train and not self.coordinates.interval_th:
+            z = self._plain_exp_train_z(S, jit.to(rays.device))
+            xyz = rays[:, None, :3] + rays[:, None, 3:6] * z[..., None]
+        else:
+            xyz = torch.empty(N, S, 3, device=rays.device)
+            z = torch.empty(N, S, device=rays.device)
+            _call("ego_sample_ray_exp", rays.data_ptr(), self._sched(S, rays.device).data_ptr(), _lib.ptr(jit),
+                  float(self.near_far[0]), N, S, xyz.data_ptr(), z.data_ptr(), _lib.stream_handle())
         aabb = self.aabb.to(rays.device)
         mask_outbbox = ((aabb[0] > xyz) | (xyz > aabb[1])).any(dim=-1)
         return xyz, z, ~mask_outbbox
 
+    @_lib.device_guard
     def _density(self, coords_sampled, coarse: int):
         _require_cuda(coords_sampled, "compute_densityfeature")
         _last_dim(coords_sampled, 7, "compute_densityfeature")
@@ -566,6 +607,7 @@ class EgoNeRF(TensorBase):
         """EgoNeRF.py:232-289."""
         return self._density(coords_sampled, 1)
 
+    @_lib.device_guard
     def compute_appfeature(self, coords_sampled):
         """EgoNeRF.py:349-413: [...,7] -> [..., app_dim]."""
         _require_cuda(coords_sampled, "compute_appfeature")
@@ -616,6 +658,7 @@ class EgoNeRF(TensorBase):
         return float((vols[0].sum() + vols[1].sum()) / (2 * g[0] * g[1] * g[2]))
 
     # -- the hot path -------------------------------------------------------------------------------------------
+    @_lib.device_guard
     def forward(self, rays_chunk, white_bg=True, is_train=False, ndc_ray=False, n_coarse=-1, n_fine=0, exp_sampling=False,
                 pretrain_envmap=False, pivotal_sample_th=0.0, resampling=False, use_coarse_sample=True, interval_th=False,
                 jitter: Optional[torch.Tensor] = None, u: Optional[torch.Tensor] = None):
@@ -644,16 +687,9 @@ class EgoNeRF(TensorBase):
                                               "the reference then measures every ray with ray 0's distances (EgoNeRF.py:515-516)")
             jitter = None
         if is_train and exp_sampling and not self.coordinates.interval_th:
-            # plain exponential schedule in training (EgoNeRF.py:59-67): the noise goes into the exponent and the distances are
-            # an exclusive prefix sum; computed here with the reference's own expression and handed over as explicit distances
             if jitter is None:
                 jitter = torch.rand(N, n_coarse)
-            near, far = float(self.near_far[0]), float(self.near_far[1])
-            ratio = 1 + (math.pi / 2.0) / n_coarse
-            r0 = (far - near) * (ratio - 1) / (pow(ratio, n_coarse) - 1)
-            rng = torch.arange(n_coarse, device=dev)[None].float() + _f32c(jitter.to(dev))
-            tri = torch.tril(torch.ones(n_coarse, n_coarse, device=dev), diagonal=-1).T
-            z_coarse = (near + torch.pow(ratio, rng) @ tri * r0).contiguous()
+            z_coarse = self._plain_exp_train_z(n_coarse, jitter.to(dev))
             jitter = None
         if is_train:
             if jitter is None:
@@ -706,7 +742,9 @@ class EgoNeRF(TensorBase):
         if self.envmap is not None:
             ckpt.update({"envmap.emission": self.envmap.emission.detach().cpu().numpy(),
                          "envmap_res_H": self.envmap.emission.shape[2]})
-        torch.save(ckpt, path)
+        from .compat import reference_pickle_paths
+        with reference_pickle_paths():  # kwargs' coordinates / envmap objects go out under the reference's class paths
+            torch.save(ckpt, path)
 
     def load(self, ckpt):
         if "alphaMask_yin.shape" in ckpt:  # EgoNeRF.py:175-180

@@ -17,6 +17,7 @@ class FusedAdam(torch.optim.Optimizer):
         super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps))
 
     @torch.no_grad()
+    @_lib.device_guard
     def step(self, closure=None):
         loss = None
         if closure is not None:

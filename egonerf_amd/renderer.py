@@ -25,7 +25,7 @@ def volume_renderer(rays, model, chunk=4096, n_coarse=-1, n_fine=0, ndc_ray=Fals
         return model(rays_chunk=rays.to(device), pretrain_envmap=True)
     outs: List[Tuple] = []
     n_all = rays.shape[0]
-    for lo in range(0, n_all, chunk):
+    for lo in range(0, max(n_all, 1), chunk):  # an empty ray list still makes one (empty) call, so the outputs keep their shapes
         rays_chunk = rays[lo:lo + chunk].to(device)
         o = model(rays_chunk, is_train=is_train, white_bg=white_bg, ndc_ray=ndc_ray, n_coarse=n_coarse, n_fine=n_fine,
                   exp_sampling=exp_sampling, pivotal_sample_th=pivotal_sample_th, resampling=resampling,
@@ -41,16 +41,17 @@ def volume_renderer(rays, model, chunk=4096, n_coarse=-1, n_fine=0, ndc_ray=Fals
     return col(0), col(1), col(2), col(3), col(4)
 
 
-def erp_rays(H: int, W: int, c2w, device, row0: int = 0, n_rows: Optional[int] = None) -> torch.Tensor:
+def erp_rays(H: int, W: int, c2w, device, row0: int = 0, n_rows: Optional[int] = None, normalize: bool = True) -> torch.Tensor:
     """[n_rows*W, 6] rays of an equirectangular camera, generated on the device (no [H*W,6] host transfer):
-    dataLoader/ray_utils.py:24-40 (get_ray_directions_360) + :85-113 (get_rays)."""
+    dataLoader/ray_utils.py:24-40 (get_ray_directions_360) + :85-113 (get_rays); `normalize` = the division by the norm both
+    ERP datasets apply to the camera directions first (dataset_egocentric_video.py:57-58, dataset_omniblender.py:42-43)."""
     import ctypes
     from . import _lib
     n_rows = H - row0 if n_rows is None else n_rows
     pose = (ctypes.c_float * 12)(*[float(v) for v in np.asarray(c2w, dtype=np.float32).reshape(-1)[:12]])
     rays = torch.empty(n_rows * W, 6, device=device, dtype=torch.float32)
     with torch.cuda.device(rays.device):
-        _lib.check(_lib.load().ego_erp_rays(H, W, row0, n_rows, pose, rays.data_ptr(), _lib.stream_handle()), "ego_erp_rays")
+        _lib.check(_lib.load().ego_erp_rays(H, W, row0, n_rows, pose, int(bool(normalize)), rays.data_ptr(), _lib.stream_handle()), "ego_erp_rays")
     return rays
 
 
@@ -83,6 +84,8 @@ def sharded_render(render_fn: Callable[[torch.Tensor], torch.Tensor], rays: torc
     rank = dist.get_rank(group) if distributed else 0
     lo, hi = shard_bounds(rays.shape[0], world, rank)
     rgb = render_fn(rays[lo:hi])
+    if isinstance(rgb, np.ndarray):  # a render_fn built on volume_renderer(empty_gpu_cache=True)
+        rgb = torch.from_numpy(rgb).to(rays.device if rays.is_cuda else "cpu")
     out = dict(rgb_local=rgb, lo=lo, hi=hi)
     if gt is not None:
         diff = rgb.double().clamp(0.0, 1.0) - gt[lo:hi].to(rgb.device).double()
@@ -111,6 +114,7 @@ def evaluation_psnr(images_rays: Sequence[torch.Tensor], images_gt: Sequence[tor
     """Per-image PSNR list with renderer.py:125-157 semantics (render -> clamp -> MSE -> dB), rays sharded over
     the ranks of the default process group when one is initialised."""
     psnrs = []
+    render_kw = dict(render_kw, empty_gpu_cache=False)  # the reductions below need device tensors, not the numpy D2H variant
     for rays, gt in zip(images_rays, images_gt):
         fn = lambda block: volume_renderer(block, model, chunk=chunk, device=device, keep_alpha=False, **render_kw)[0]
         psnrs.append(sharded_render(fn, rays.view(-1, rays.shape[-1]), gt.view(-1, 3))["psnr"])
@@ -131,6 +135,7 @@ def evaluation(images_rays: Sequence[torch.Tensor], images_gt: Sequence[torch.Te
     was_training = model.training
     model.eval()
     psnrs, ssims = [], []
+    render_kw = dict(render_kw, empty_gpu_cache=False)  # see evaluation_psnr
     for rays, gt in zip(images_rays, images_gt):
         fn = lambda block: volume_renderer(block, model, chunk=chunk, device=device, keep_alpha=False, **render_kw)[0]
         out = sharded_render(fn, rays.view(-1, rays.shape[-1]), gt.view(-1, 3), gather_image=compute_extra_metrics)

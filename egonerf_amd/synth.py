@@ -167,6 +167,11 @@ def make_weights(cfg: SceneConfig, seed: int = 1234, mlp_gain: float = 3.0) -> D
     return out
 
 
+def white_envmap(seed: int, h: int) -> np.ndarray:
+    """[3, 2h, h] fp32 emission map of independent uniforms in [-3, 3) (pre-sigmoid), for index-exact envmap tests."""
+    return ((hash_uniform(seed, 7, 3 * 2 * h * h) * 6 - 3).reshape(3, 2 * h, h)).astype(np.float32)
+
+
 def make_rays(n: int, seed: int = 1, origin_extent: float = 0.25) -> np.ndarray:
     """[n,6] fp32: o ~ U(-e,e)^3, d = normalised approx-normal vector (sqrt is IEEE-exact)."""
     o = (hash_uniform(seed, 1, n * 3).reshape(n, 3) * 2 - 1) * origin_extent

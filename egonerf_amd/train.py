@@ -86,6 +86,7 @@ def differentiable_params(model) -> List[torch.nn.Parameter]:
 
 class RenderFunction(torch.autograd.Function):
     @staticmethod
+    @_lib.device_guard
     def forward(ctx, model, rays, opts, *params):
         """params = differentiable_params(model) (+ envmap.emission last when the model has an envmap)."""
         lib, st = _lib.load(), _lib.stream_handle()
@@ -150,6 +151,7 @@ class RenderFunction(torch.autograd.Function):
         return rgb_map, depth, alpha
 
     @staticmethod
+    @_lib.device_guard
     def backward(ctx, g_rgb, _g_depth=None, g_alpha=None, *_unused):
         lib, st = _lib.load(), _lib.stream_handle()
         model, N, S, sv = ctx.model, ctx.N, ctx.S, ctx.saved
@@ -233,6 +235,7 @@ class EnvRadianceFunction(torch.autograd.Function):
     """EnvironmentMap.get_radiance with a gradient to `emission` (the reference's envmap pre-training, train.py:218-236)."""
 
     @staticmethod
+    @_lib.device_guard
     def forward(ctx, emission, dirs):
         lib, st = _lib.load(), _lib.stream_handle()
         sc = _lib.Scene()
@@ -244,6 +247,7 @@ class EnvRadianceFunction(torch.autograd.Function):
         return out
 
     @staticmethod
+    @_lib.device_guard
     def backward(ctx, g):
         lib, st = _lib.load(), _lib.stream_handle()
         dirs, out = ctx.saved_tensors

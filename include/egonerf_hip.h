@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define EGO_ABI_VERSION 5
+#define EGO_ABI_VERSION 6
 
 enum { EGO_PREC_F16X3 = 0, EGO_PREC_F32 = 1 };
 
@@ -136,8 +136,11 @@ int ego_sample_ray_exp(const float* rays, const float* r_sched, const float* jit
                        float* xyz, float* z, void* stream);
 
 /* Equirectangular rays of rows [row0, row0+n_rows) of an H x W panorama for the camera-to-world pose c2w (HOST pointer,
- * 3x4 row-major): get_ray_directions_360 + get_rays (dataLoader/ray_utils.py:24-40, :85-113).  rays [n_rows*W][6] dev. */
-int ego_erp_rays(int32_t H, int32_t W, int32_t row0, int32_t n_rows, const float* c2w, float* rays, void* stream);
+ * 3x4 row-major): get_ray_directions_360 + get_rays (dataLoader/ray_utils.py:24-40, :85-113).  normalize != 0 divides the
+ * camera-space direction by its norm first, as both ERP datasets do before get_rays (dataset_egocentric_video.py:57-58,
+ * dataset_omniblender.py:42-43).  rays [n_rows*W][6] dev. */
+int ego_erp_rays(int32_t H, int32_t W, int32_t row0, int32_t n_rows, const float* c2w, int32_t normalize, float* rays,
+                 void* stream);
 
 int ego_from_cartesian(const ego_scene* sc, const float* xyz, int64_t M, float* c7, void* stream);
 int ego_normalize_coord(const ego_scene* sc, const float* c7, int64_t M, float* c7n, void* stream);

@@ -247,6 +247,84 @@ def capture_full():
     np.savez_compressed(os.path.join(OUT, "full.npz"), **fx)
 
 
+def erp_subset(H: int, W: int):
+    """Strided subset of an H x W equirectangular image that keeps the poles, the phi = +-pi seam (columns 0 / W-1), the image
+    centre and the yin/yang border latitudes/longitudes: flat ray indices, ~500 rays."""
+    rows = sorted(set([0, 1, 2, H // 4 - 1, H // 4, H // 4 + 1, H // 2 - 1, H // 2, 3 * H // 4 - 1, 3 * H // 4, H - 2, H - 1]) | set(range(5, H, 97)))
+    cols = sorted(set([0, 1, W // 4 - 1, W // 4, W // 2 - 1, W // 2, 3 * W // 4 - 1, 3 * W // 4, W - 2, W - 1]) | set(range(7, W, 173)))
+    rr, cc = np.meshgrid(np.array(rows), np.array(cols), indexing="ij")
+    return (rr * W + cc).reshape(-1).astype(np.int64)
+
+
+def ricoh_poses():
+    """Identity at the origin + a general rotation (all nine entries non-trivial) with an off-centre camera position inside the
+    0.5 trajectory radius; [2,3,4] float32 camera-to-world matrices."""
+    from scipy.spatial.transform import Rotation
+    R1 = Rotation.from_rotvec(np.array([0.3, -1.1, 0.5])).as_matrix()
+    P = np.zeros((2, 3, 4), np.float32)
+    P[0, :, :3] = np.eye(3)
+    P[1, :, :3] = R1.astype(np.float32)
+    P[1, :, 3] = [0.21, -0.13, 0.30]
+    return P
+
+
+def capture_ricoh():
+    """BASELINE config 3 (Ricoh360 scene: configs/EgoNeRF/ricoh/common.txt:5-13 + common.txt): near_far [0.1, 300], r0 0.05,
+    density_shift -10, envmap 3 x 3840 x 1920, full [150,172,516] grid; rays from the reference's own ERP generator
+    (dataLoader/ray_utils.py:24-40 get_ray_directions_360 + the dataset's normalisation, dataset_egocentric_video.py:57-58, +
+    :85-113 get_rays) for 1024 x 2048 images; a ~500-ray subset rendered at 128+128 (default) and 512 samples.
+    Seeds + outputs only (weights and the envmap are regenerated by seed)."""
+    from dataLoader.ray_utils import get_ray_directions_360, get_rays
+    H, W = 1024, 2048
+    cfg = synth.SceneConfig(**synth.RICOH)
+    weights = synth.make_weights(cfg, seed=1234)
+    model, _ = build_reference(cfg, weights)
+    dirs = get_ray_directions_360(H, W)
+    dirs_n = dirs / torch.norm(dirs, dim=-1, keepdim=True)
+    idx = erp_subset(H, W)
+    poses = ricoh_poses()
+    fx = dict(seed_weights=1234, H=H, W=W, idx=idx, poses=poses, grid=np.array(cfg.grid))
+    # a larger slice for the ray generator alone: the subset + two full rows + two full columns
+    gen_idx = np.unique(np.concatenate([idx, np.arange(W) + 300 * W, np.arange(W) + (H - 1) * W, np.arange(H) * W, np.arange(H) * W + 1234]))
+    fx["gen_idx"] = gen_idx
+    for k in range(2):
+        c2w = torch.from_numpy(poses[k])
+        o_raw, d_raw = get_rays(dirs, c2w)      # un-normalised camera directions
+        o, d = get_rays(dirs_n, c2w)            # what the datasets feed the renderer
+        fx[f"gen_rays_raw/{k}"] = np_(torch.cat([o_raw, d_raw], 1)[gen_idx])
+        fx[f"gen_rays/{k}"] = np_(torch.cat([o, d], 1)[gen_idx])
+        rays = torch.cat([o, d], 1)[idx].contiguous()
+        fx[f"rays/{k}"] = np_(rays)
+        out = run_forward(model, rays, n_coarse=128, n_fine=128, resampling=True, use_coarse_sample=True)
+        fx.update({f"rs128/{k}/rgb": np_(out[0]), f"rs128/{k}/depth": np_(out[1]), f"rs128/{k}/bg": np_(out[2]),
+                   f"rs128/{k}/env": np_(out[3]), f"rs128/{k}/acc_alpha_sum": np_(out[4].sum(-1))})
+        out = run_forward(model, rays, n_coarse=512, n_fine=0, resampling=False)
+        fx.update({f"nr512/{k}/rgb": np_(out[0]), f"nr512/{k}/depth": np_(out[1]), f"nr512/{k}/bg": np_(out[2]),
+                   f"nr512/{k}/env": np_(out[3])})
+    # schedule / LUT known answers of this scene (far_r = 520.5, z up to ~300)
+    _, z, _ = model.sample_ray_exp(torch.zeros(1, 3), torch.tensor([[0.0, 0.0, 1.0]]), is_train=False, N_samples=128)
+    fx["sched128"] = np_(z[0])
+    fx["far_r"] = np_(model.coordinates.far[0])
+    np.savez_compressed(os.path.join(OUT, "ricoh.npz"), **fx)
+
+
+def capture_envmap_full():
+    """EnvironmentMap.get_radiance (models/envmap.py:6-34) at the shipped sizes h = 1000 (opt.py default) and h = 1920
+    (ricoh/common.txt:10) on a white-noise emission map (every texel independent, so any index slip shows), regenerated by
+    seed; directions: axis-aligned ones (poles of the map, the atan2 seam), and hashed random ones."""
+    special = [[0, 0, 1], [0, 0, -1], [1, 0, 0], [-1, 0, 0], [0, 1, 0], [0, -1, 0], [-1, 1e-7, 0], [-1, -1e-7, 0],
+               [-1, 0, 1e-3], [1, 1, 1], [-1, -1, -1], [0.3, -0.2, 0.93], [2.0, 0.0, 0.0], [0, 3.0, 4.0]]
+    rnd = synth.hash_uniform(51, 0, 2048 * 3).reshape(2048, 3) * 2 - 1
+    d = torch.cat([torch.tensor(special, dtype=torch.float32), torch.from_numpy(rnd.astype(np.float32))])
+    fx = dict(dirs=np_(d), seed=52)
+    for h in (1000, 1920):
+        em = synth.white_envmap(52, h)
+        env = EnvironmentMap(h=4, init_strategy="zero", device="cpu")
+        env.load_envmap(em, device="cpu")
+        fx[f"radiance/{h}"] = np_(env.get_radiance(d))
+    np.savez_compressed(os.path.join(OUT, "envmap_full.npz"), **fx)
+
+
 def capture_alpha_mask():
     """Occupancy semantics: updateAlphaMask + sample_alpha on the tiny grid."""
     import warnings
@@ -450,7 +528,7 @@ def capture_uniform():
 
 if __name__ == "__main__":
     torch.manual_seed(0)
-    which = sys.argv[1:] or ["tiny", "stages", "full", "alpha_mask", "checkpoint", "train_extras", "metrics", "plainexp", "sh", "uniform"]
+    which = sys.argv[1:] or ["tiny", "stages", "full", "alpha_mask", "checkpoint", "train_extras", "metrics", "plainexp", "sh", "uniform", "ricoh", "envmap_full"]
     for name in which:
         globals()["capture_" + name]()
         print("captured", name)

@@ -471,6 +471,22 @@ def ray_entropy_loss(alpha: torch.Tensor) -> torch.Tensor:
     return (-(p * torch.log2(p + 1e-10)).sum(-1)).mean()
 
 
+def erp_rays_reference(H: int, W: int, c2w: torch.Tensor, normalize: bool = True) -> torch.Tensor:
+    """[H*W, 6] rays of an equirectangular camera: dataLoader/ray_utils.py:24-40 (get_ray_directions_360: pixel centres,
+    phi = (1 - 2i/W) pi, theta = (1 - 2j/H) pi/2, d = [-cos(theta) sin(phi), sin(theta), -cos(theta) cos(phi)]), the datasets'
+    normalisation (dataset_egocentric_video.py:57-58 / dataset_omniblender.py:42-43) and :85-113 (get_rays: d @ R^T, o = t)."""
+    i = torch.tile(torch.arange(W), (H, 1)) + 0.5
+    j = torch.tile(torch.arange(H), (W, 1)).T + 0.5
+    phi = (1 - 2 * i / W) * np.pi
+    theta = (1 - 2 * j / H) * np.pi / 2
+    d = torch.stack([-torch.cos(theta) * torch.sin(phi), torch.sin(theta), -torch.cos(theta) * torch.cos(phi)], -1)
+    if normalize:
+        d = d / torch.norm(d, dim=-1, keepdim=True)
+    rays_d = d @ c2w[:3, :3].T
+    rays_o = c2w[:3, 3].expand(rays_d.shape)
+    return torch.cat([rays_o.reshape(-1, 3), rays_d.reshape(-1, 3)], 1)
+
+
 def volume_render(scene: OracleScene, rays: torch.Tensor, chunk: int = 4096, **kw):
     """Chunk loop of renderer.py:11-79 (torch outputs, no D2H variant)."""
     outs = [scene.forward(rays[i:i + chunk], **kw) for i in range(0, rays.shape[0], chunk)]

@@ -22,7 +22,7 @@ def test_library_exports_every_header_symbol():
     for n in names:
         assert hasattr(lib, n), n
     assert set(names) == set(_lib.PROTOTYPES)  # the binding covers the whole header, nothing extra
-    assert lib.ego_abi_version() == 5
+    assert lib.ego_abi_version() == 6
     assert [lib.ego_sizeof(i) for i in range(3)] == [ctypes.sizeof(_lib.Scene), ctypes.sizeof(_lib.RenderArgs),
                                                      ctypes.sizeof(_lib.VmField)]
     assert lib.ego_packed_floats() == 2 * 46852 + 9216  # fp32 layout + fp16-split layout + fp16-table basis fragments
@@ -155,6 +155,94 @@ def test_reference_checkpoint_loads_on_cpu(golden):
     assert np.array_equal(model.envmap.emission.detach().numpy(), w["envmap.emission"])
     assert model.alphaMask is not None and tuple(model.alphaMask.alpha_volume_yin.shape) == (1, 1, 30, 10, 10)
     assert model.near_far == [0.01, 15.0] and model.density_shift == -8 and model.fea2denseAct == "softplus"
+
+
+def _write_ckpt(tmp_path):
+    cfg = synth.SceneConfig(n_voxel=20 ** 3, use_envmap=True, envmap_res_H=16)
+    w = synth.make_weights(cfg, seed=77)
+    model = make_model(cfg, w, "cpu")
+    model.coordinates.lut_device("cpu")  # a populated LUT cache must not leak into the file
+    path = str(tmp_path / "ours.th")
+    model.save(path, 17)
+    return cfg, w, model, path
+
+
+def test_saved_checkpoint_uses_only_reference_class_paths(tmp_path):
+    """EgoNeRF.save writes kwargs['coordinates'] / ['envmap'] as models.coordinates.YinYangSphericalCoords /
+    models.envmap.EnvironmentMap with the reference's attribute sets (models/coordinates.py:75-82,206-215,500-505;
+    models/envmap.py:17-24): the pickle names no egonerf_amd class and unpickles into bare stand-ins of those paths."""
+    import copy, sys, types, zipfile
+    cfg, w, model, path = _write_ckpt(tmp_path)
+    with zipfile.ZipFile(path) as z:
+        pkl = z.read([n for n in z.namelist() if n.endswith("data.pkl")][0])
+    assert b"egonerf_amd" not in pkl and b"models.coordinates" in pkl and b"models.envmap" in pkl
+    assert "models" not in sys.modules and "models.coordinates" not in sys.modules  # the save-time stand-ins are gone again
+    pkg, mc, me = types.ModuleType("models"), types.ModuleType("models.coordinates"), types.ModuleType("models.envmap")
+    pkg.__path__ = []
+    mc.YinYangSphericalCoords = type("YinYangSphericalCoords", (), {"__module__": "models.coordinates"})
+    me.EnvironmentMap = type("EnvironmentMap", (), {"__module__": "models.envmap"})
+    sys.modules.update({"models": pkg, "models.coordinates": mc, "models.envmap": me})
+    try:
+        ck = torch.load(path, map_location="cpu", weights_only=False)
+    finally:
+        for n in ("models", "models.coordinates", "models.envmap"):
+            sys.modules.pop(n, None)
+    c, e = ck["kwargs"]["coordinates"], ck["kwargs"]["envmap"]
+    assert type(c) is mc.YinYangSphericalCoords and type(e) is me.EnvironmentMap
+    assert set(vars(c)) == {"center", "device", "near", "far", "inv_diff", "exp_r", "interval_th", "N_r", "N_theta", "N_phi", "r0", "ratio"}
+    assert set(vars(e)) == {"emission"} and np.array_equal(e.emission.detach().numpy(), w["envmap.emission"])
+    assert (c.N_r, c.N_theta, c.N_phi, c.r0, c.exp_r, c.interval_th) == (10, 10, 30, cfg.r0, True, True)
+    assert torch.equal(c.far, model.coordinates.far) and c.ratio.dim() == 0
+    assert set(ck) == {"kwargs", "state_dict", "global_step", "envmap.emission", "envmap_res_H"} and ck["global_step"] == 17
+    # outside save(), ordinary pickling / deepcopy of the product's objects is untouched
+    c2 = copy.deepcopy(model.coordinates)
+    assert type(c2) is type(model.coordinates) and c2.resolution == [10, 10, 30]
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/models"), reason="needs the reference checkout (build container only)")
+def test_reference_opens_a_checkpoint_written_here(tmp_path):
+    """The real reference (subprocess, stub modules for its missing third-party imports) torch.loads a file written by
+    EgoNeRF.save, rebuilds `EgoNeRF(**ckpt['kwargs'])`, `load(ckpt)`s it (train.py:52-56) and renders; compared with the oracle."""
+    import subprocess, sys, textwrap
+    from oracle.egonerf_oracle import OracleScene
+    cfg, w, model, path = _write_ckpt(tmp_path)
+    rays = synth.make_rays(32, seed=5)
+    np.save(str(tmp_path / "rays.npy"), rays)
+    code = textwrap.dedent(f"""
+        import sys, types, io, contextlib
+        sys.dont_write_bytecode = True
+        sys.path.insert(0, "/root/reference")
+        import numpy as np, torch
+        def stub(name, **a):
+            m = types.ModuleType(name); m.__dict__.update(a); sys.modules[name] = m; return m
+        stub("kornia", create_meshgrid=None); stub("cv2", COLORMAP_JET=2)
+        tv = stub("torchvision"); tv.transforms = stub("torchvision.transforms")
+        stub("imageio"); stub("plyfile", PlyData=None, PlyElement=None)
+        sk = stub("skimage"); sk.measure = stub("skimage.measure"); stub("lpips")
+        # the reference builds its EnvironmentMap on "cuda" by default (models/envmap.py:18-20): keep its allocations on the CPU
+        _rand, _zeros = torch.rand, torch.zeros
+        torch.rand = lambda *a, **k: _rand(*a, **{{**k, "device": "cpu"}})
+        torch.zeros = lambda *a, **k: _zeros(*a, **{{**k, "device": "cpu"}})
+        with contextlib.redirect_stdout(io.StringIO()):
+            from models.EgoNeRF import EgoNeRF
+            from renderer import volume_renderer
+            ckpt = torch.load({path!r}, map_location="cpu", weights_only=False)
+            kwargs = ckpt["kwargs"]; kwargs.update({{"device": "cpu"}})
+            model = EgoNeRF(**kwargs)
+            step = model.load(ckpt)
+            model.eval()
+            rays = torch.from_numpy(np.load({str(tmp_path / "rays.npy")!r}))
+            o = volume_renderer(rays, model, chunk=4096, n_coarse=16, n_fine=16, exp_sampling=True, resampling=True,
+                                use_coarse_sample=True, device="cpu", interval_th=True)
+        np.savez({str(tmp_path / "out.npz")!r}, step=step, rgb=o[0].detach().numpy(), depth=o[1].detach().numpy(), env=o[3].detach().numpy())
+    """)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = np.load(str(tmp_path / "out.npz"))
+    assert int(out["step"]) == 17
+    ref = OracleScene(cfg, w).forward(torch.from_numpy(rays), n_coarse=16, n_fine=16, resampling=True)
+    assert np.abs(out["rgb"] - ref[0].numpy()).max() <= 2e-6 and np.abs(out["depth"] - ref[1].numpy()).max() <= 2e-5
+    assert np.abs(out["env"] - ref[3].numpy()).max() <= 1e-6
 
 
 def test_kernels_have_no_high_half_broadcast_packed_fp32_ops(tmp_path):

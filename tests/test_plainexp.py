@@ -73,6 +73,9 @@ def test_hip_plain_exponential_grid(golden):
         rgb, depth, *_ = model(rays, n_coarse=16, n_fine=16, exp_sampling=True, resampling=True)
         assert float((rgb.cpu() - T(fx["rs_rgb"])).abs().max()) <= 1e-4
         assert float((depth.cpu() - T(fx["rs_depth"])).abs().max()) <= 1e-3
+        # the public stage method in training mode: noise in the exponent (EgoNeRF.py:63-67), not the interval-jitter formula
+        _, z_tr, _ = model.sample_ray_exp(rays[:, :3], rays[:, 3:6], is_train=True, N_samples=16, jitter=T(fx["tr_jitter"]).cuda())
+        assert float((z_tr.cpu() - T(fx["tr_z"])).abs().max()) <= 2e-5
         rgb, depth, *_ = model(rays, is_train=True, n_coarse=16, n_fine=16, exp_sampling=True, resampling=True,
                                jitter=T(fx["tr_jitter"]).cuda(), u=T(fx["tr_u"]).cuda())
         assert float((rgb.cpu() - T(fx["tr_rgb"])).abs().max()) <= 1e-4
