@@ -1,19 +1,27 @@
 #!/usr/bin/env python
-"""Headline benchmark: rays/s of EgoNeRF's volume-rendering hot path at BASELINE config 2
-(OmniBlender-barbershop shape: grid [150,172,516], 4096-ray batch, 512 samples/ray, eval, no resampling).
+"""Benchmarks of EgoNeRF's volume-rendering hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config render|train|erp]
 
-A step = one EgoNeRF.forward over one 4096-ray batch already resident in HBM (ego_render_forward:
-march/density -> shade (app gather + basis + PE + MLP on the fp32 matrix cores) -> composite).
-Rank 0 prints ONE JSON line.  Rays are independent, so ranks shard work with no data-path collective
-("scaling": "weak": every rank renders its own batch per step).
+`--config render` (default) is the headline: BASELINE configs[1] — OmniBlender-barbershop shape (grid [150,172,516]),
+4096-ray batch, 512 samples/ray, eval, no resampling.  A step = one EgoNeRF.forward over one batch already resident in HBM
+(ego_render_forward: march/density -> shade (appearance gather + basis + PE + MLP on the matrix cores) -> composite).
+`--config train` is BASELINE configs[3] (8192 rays x (128+128), forward + backward + FusedAdam + coarse-table refresh per step);
+`--config erp` is configs[2] / [4] (Ricoh-like scene, 1024 x 2048 equirectangular images, 128+128 samples, envmap on, rows
+sharded over the ranks, per-image PSNR all-reduced).
+
+N > 1: one process per GPU over RCCL.  Either the caller launches the ranks (torch.distributed.run sets RANK / WORLD_SIZE /
+LOCAL_RANK / MASTER_*), or — when WORLD_SIZE is absent — this script re-executes itself through torch.distributed.run on
+127.0.0.1.  Rays are independent, so ranks shard work with no data-path collective.  Rank 0 prints ONE JSON line.
 """
 from __future__ import annotations
 
 import argparse
+import glob
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -26,9 +34,13 @@ sys.path.insert(0, REPO)
 from egonerf_amd import synth  # noqa: E402
 
 N_RAYS, N_SAMPLES = 4096, 512
-HBM_PEAK_GBPS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-MFMA_F32_PEAK_TFLOPS = 157.3  # fp32-input MFMA dense peak
+HBM_PEAK_GBPS = 8000.0         # MI355X_MICROARCH.md: HBM3E 8 TB/s
+MFMA_F32_PEAK_TFLOPS = 157.3   # fp32-input MFMA dense peak
 MFMA_F16_PEAK_TFLOPS = 2500.0  # dense fp16/bf16 MFMA peak
+N_SIMD = 256 * 4
+FLOP_PER_MFMA = {"f16x3": 2 * 32 * 32 * 16, "f32": 2 * 32 * 32 * 2}  # v_mfma_f32_32x32x16_f16 / v_mfma_f32_32x32x2_f32
+CLK_PER_MFMA = {"f16x3": 32, "f32": 64}   # issue-to-issue cycles of a dependent-free MFMA stream (tools/coissue_probe.hip)
+CLK_PER_VALU = 4                          # a wave64 VALU instruction occupies its SIMD for 4 cycles (16 lanes x 4)
 # algorithmic bytes / flops per sample: density 3*(4+2) taps * 16 ch * 4 B, appearance ... * 48 ch
 B_DENSITY, B_APP = 1152, 3456
 FLOP_SAMPLE_SHADE = 2 * (150 * 128 + 128 * 128 + 128 * 3) + 2 * 144 * 27  # MLP + basis
@@ -37,24 +49,156 @@ FLOP_SAMPLE_SHADE = 2 * (150 * 128 + 128 * 128 + 128 * 3) + 2 * 144 * 27  # MLP 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)  # 0.7 ms each: amortises the barrier + synchronize bracket
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--config", choices=["render", "train", "erp"], default="render")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-rays", type=int, default=1024, help="rays in the bounded CPU-baseline sample")
-    return ap.parse_args()
+    ap.add_argument("--cpu-rays", type=int, default=1024, help="rays in the single-process CPU-baseline sample")
+    ap.add_argument("--train-reg", action="store_true", help="train: add the Ricoh configs' TV / L1 / ortho / entropy terms")
+    ap.add_argument("--views", type=int, default=None, help="erp: images per step sequence (default = --steps)")
+    ap.add_argument("--erp-size", type=int, nargs=2, default=[1024, 2048], metavar=("H", "W"))
+    ap.add_argument("--mask", action="store_true", help="erp: build the reference's alpha mask and apply it (TensorBase.forward semantics)")
+    ap.add_argument("--term-eps", type=float, default=0.0, help="erp: early-termination threshold on the transmittance")
+    ap.add_argument("--cpu-worker", nargs=2, type=int, metavar=("N_RAYS", "THREADS"), help=argparse.SUPPRESS)
+    a = ap.parse_args()
+    dflt = dict(render=(200, 10), train=(20, 3), erp=(4, 1))[a.config]  # render: 0.7 ms steps, amortise the barrier bracket
+    a.steps = dflt[0] if a.steps is None else a.steps
+    a.warmup = dflt[1] if a.warmup is None else a.warmup
+    return a
 
 
-def cpu_baseline(cfg, weights, n_rays):
-    """The oracle (= CPU restatement of the reference's PyTorch path, kind 'port') on this box's host cores.
-    ATen's intra-op threading does not scale to hundreds of cores on these small ops, so the thread count is
-    picked by a short calibration (the best one is used and reported as `cores`)."""
+# =====================================================================================================
+# launch
+# =====================================================================================================
+def self_launch(a) -> None:
+    """`python bench.py --gpus N` without a launcher: re-execute through torch.distributed.run (one rank per GPU)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
+               OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", "8"))
+    sys.exit(subprocess.call(cmd, env=env))
+
+
+class Ranks:
+    """Process-group plumbing shared by the configs: device binding, barrier bracket, max-over-ranks wall time."""
+
+    def __init__(self, a):
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        if self.world != a.gpus:
+            raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={self.world} (launcher and flag disagree)")
+        # EGO_BENCH_TEST_SHARED_GPU=1: dry-run of the multi-rank path on a box with one GPU (all ranks on cuda:0, gloo)
+        self.shared = os.environ.get("EGO_BENCH_TEST_SHARED_GPU") == "1"
+        if self.shared:
+            local = 0
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py: no HIP device visible (the EgoNeRF hot path has no CPU fallback)")
+        if local >= torch.cuda.device_count():
+            raise SystemExit(f"bench.py: rank {self.rank} needs GPU {local} but only {torch.cuda.device_count()} are visible")
+        torch.cuda.set_device(local)
+        self.dev = torch.device("cuda", local)
+        self.dist = None
+        if self.world > 1:
+            import torch.distributed as dist
+            self.dist = dist
+            if self.shared:
+                dist.init_process_group("gloo")
+            else:
+                dist.init_process_group("nccl", device_id=self.dev)  # RCCL on ROCm
+
+    def barrier(self):
+        if self.dist is not None:
+            self.dist.barrier()
+        torch.cuda.synchronize()
+
+    def max_over_ranks(self, seconds: float) -> float:
+        t = torch.tensor([seconds], device="cpu" if self.shared else self.dev, dtype=torch.float64)
+        if self.dist is not None:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def finish(self):
+        if self.dist is not None:
+            self.dist.barrier()
+            self.dist.destroy_process_group()
+
+
+def timed(rk: Ranks, step, steps: int, warmup: int) -> float:
+    """W untimed warm-up steps, then exactly K steps bracketed by barrier + synchronize; MAX over ranks."""
+    for _ in range(warmup):
+        step()
+    rk.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    rk.barrier()
+    return rk.max_over_ranks(time.perf_counter() - t0)
+
+
+# =====================================================================================================
+# CPU baseline (oracle = CPU restatement of the reference's PyTorch path; kind "port")
+# =====================================================================================================
+def cpu_worker(n_rays: int, threads: int) -> None:
+    """One process of the all-cores baseline: build the scene, signal READY, wait for GO, render n_rays in 128-ray chunks."""
+    from oracle.egonerf_oracle import OracleScene
+    torch.set_num_threads(threads)
+    cfg = synth.SceneConfig()
+    sc = OracleScene(cfg, synth.make_weights(cfg, seed=1234))
+    rays = torch.from_numpy(synth.make_rays(n_rays, seed=100 + os.getpid() % 1000))
+    with torch.no_grad():
+        sc.forward(rays[:32], n_coarse=N_SAMPLES)
+        print("READY", flush=True)
+        sys.stdin.readline()
+        t = time.perf_counter()
+        for lo in range(0, n_rays, 128):
+            sc.forward(rays[lo:lo + 128], n_coarse=N_SAMPLES)
+        print("DONE", time.perf_counter() - t, flush=True)
+
+
+def cpu_baseline_all_cores(threads: int = 8, rays_per_proc: int = 1024, max_procs: int = 32):
+    """Rays sharded over logical_cores / `threads` processes of `threads` ATen threads each (ATen's intra-op threading alone
+    does not scale these small ops past ~16 cores).  Wall time from a common GO to the last DONE."""
+    logical = os.cpu_count() or 1
+    procs = max(1, min(max_procs, logical // threads))
+    env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads), HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="")
+    ps = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", str(rays_per_proc), str(threads)], env=env,
+                           stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True) for _ in range(procs)]
+    try:
+        for p in ps:
+            if p.stdout.readline().strip() != "READY":
+                raise RuntimeError("cpu baseline worker failed to start")
+        t0 = time.perf_counter()
+        for p in ps:
+            p.stdin.write("GO\n")
+            p.stdin.flush()
+        per = [float(p.stdout.readline().split()[1]) for p in ps]
+        wall = time.perf_counter() - t0
+    finally:
+        for p in ps:
+            try:
+                p.stdin.close()
+                p.wait(timeout=30)
+            except Exception:
+                p.kill()
+    return dict(value=procs * rays_per_proc / wall, unit="rays/s", cores=procs * threads, kind="port",
+                sample=f"{procs} processes x {threads} ATen threads, {rays_per_proc} rays x {N_SAMPLES} samples each (128-ray chunks), eval, "
+                       f"no resampling; wall {wall:.2f} s from a common start to the last finish (slowest worker {max(per):.2f} s, "
+                       f"fastest {min(per):.2f} s); {logical} logical cores; torch {torch.__version__} CPU")
+
+
+def cpu_baseline_single(cfg, weights, n_rays):
+    """One process, ATen thread count picked by a short calibration (the best one is used and reported as `cores`)."""
     from oracle.egonerf_oracle import OracleScene
     logical = os.cpu_count() or 1
     sc = OracleScene(cfg, weights)
     rays = torch.from_numpy(synth.make_rays(n_rays, seed=1))
     cal = {}
     with torch.no_grad():
-        for th in sorted({t for t in (8, 16, 32, 64, 128) if t <= logical} | {min(8, logical)}):
+        for th in sorted({t for t in (8, 16, 32) if t <= logical} | {min(8, logical)}):
             torch.set_num_threads(th)
             sc.forward(rays[:64], n_coarse=N_SAMPLES)
             t = time.perf_counter()
@@ -68,147 +212,278 @@ def cpu_baseline(cfg, weights, n_rays):
             out = sc.forward(rays, n_coarse=N_SAMPLES)
             best = min(best, time.perf_counter() - t)
     return dict(value=n_rays / best, unit="rays/s", cores=best_th, kind="port",
-                sample=f"{n_rays} rays x {N_SAMPLES} samples, eval, no resampling, best of 2 ({best:.2f} s) with "
-                       f"{best_th} ATen threads (calibration rays/s by thread count: "
-                       f"{ {k: round(v) for k, v in cal.items()} }; {logical} logical cores; torch {torch.__version__} CPU)"), out, rays
+                sample=f"{n_rays} rays x {N_SAMPLES} samples, eval, no resampling, best of 2 ({best:.2f} s) with {best_th} ATen threads "
+                       f"(calibration rays/s by thread count: { {k: round(v) for k, v in cal.items()} })"), out, rays
+
+
+# =====================================================================================================
+# roofline inputs from the committed PMC passes
+# =====================================================================================================
+def load_pmc(kname: str):
+    """Per-launch counter means of `kname` from the newest profiles/r*/pmc_traffic.json (rocprofv3 --pmc passes of bench.py's
+    own step, tools/profile_gpu.sh + tools/pmc_traffic.py).  bench.py cannot collect PMC counters live; `stale` says whether
+    the library sources changed since that profile was taken."""
+    from egonerf_amd.build import source_hash
+    for path in sorted(glob.glob(os.path.join(REPO, "profiles", "r*", "pmc_traffic.json")), reverse=True):
+        try:
+            pmc = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        if kname in pmc and "SQ_INSTS_MFMA_per_SE" in pmc[kname]:
+            return pmc[kname], os.path.relpath(path, REPO), pmc.get("_source_hash") != source_hash()
+    return None, None, None
+
+
+def shade_roofline(prec: str, t_shade: float, M: int):
+    """The binding resource of the shade kernel is the SIMD's issue port: on CDNA4 VALU and MFMA time add up
+    (tools/coissue_probe.hip), so the headline is the matrix pipe (executed MFMA flop / dense peak, frac <= 1) with the
+    additive VALU+MFMA issue bound next to it; algorithmic bytes / HBM peak is kept as a labelled secondary that exceeds 1
+    because the 94 MB table set is L2 / Infinity-Cache resident."""
+    kname = "k_shade_h<SHADE>" if prec == "f16x3" else "k_shade<SHADE>"
+    pmc, src, stale = load_pmc(kname)
+    shade_bytes = (B_APP + 16 + 12) * M      # gathered taps + 16 B coords read + 12 B rgb write, per sample
+    alg_tflops = FLOP_SAMPLE_SHADE * M / t_shade / 1e12
+    peak = MFMA_F16_PEAK_TFLOPS if prec == "f16x3" else MFMA_F32_PEAK_TFLOPS
+    out = dict(bound="mfma", kernel=kname, unit="TFLOP/s", peak=peak, ms=t_shade * 1e3, traffic=None)
+    if pmc is not None:
+        n_se = 32
+        mfma = pmc["SQ_INSTS_MFMA_per_SE"] * n_se
+        valu = pmc["SQ_INSTS_VALU_per_SE"] * n_se
+        executed = mfma * FLOP_PER_MFMA[prec] / t_shade / 1e12
+        clock_ghz = pmc["GRBM_GUI_ACTIVE"] / (pmc["duration_us"] * 1e3) if "duration_us" in pmc else None
+        tiles = M / 32
+        bound_clk = (mfma * CLK_PER_MFMA[prec] + valu * CLK_PER_VALU) / N_SIMD
+        out.update(achieved=executed, frac=executed / peak, traffic=pmc.get("traffic_bytes"),
+                   inputs=dict(source=src, stale_vs_current_sources=stale, mfma_insts_per_launch=mfma, valu_insts_per_launch=valu,
+                               mfma_per_tile=mfma / tiles, valu_per_tile=valu / tiles, flop_per_mfma=FLOP_PER_MFMA[prec],
+                               effective_clock_GHz=clock_ghz),
+                   issue=None if clock_ghz is None else dict(
+                       note="additive VALU + MFMA issue bound per SIMD (the two do not overlap on this SIMD)",
+                       clk_per_mfma=CLK_PER_MFMA[prec], clk_per_valu=CLK_PER_VALU, bound_ms=bound_clk / (clock_ghz * 1e6),
+                       frac=bound_clk / (clock_ghz * 1e6) / (t_shade * 1e3)))
+    else:  # no committed counters: fall back to the algorithmic flop count (a lower bound of what the pipe executes)
+        out.update(achieved=alg_tflops, frac=alg_tflops / peak, inputs=dict(source=None, note="no profiles/r*/pmc_traffic.json"))
+    out["algorithmic"] = dict(flop_per_sample=FLOP_SAMPLE_SHADE, achieved_TFLOPs=alg_tflops, frac_of_peak=alg_tflops / peak,
+                              note="f16x3 executes 3 MFMA flops per algorithmic flop" if prec == "f16x3" else None)
+    gbps = shade_bytes / t_shade / 1e9
+    out["hbm_algorithmic"] = dict(bytes_per_launch=shade_bytes, achieved=gbps, peak=HBM_PEAK_GBPS, unit="GB/s", frac=gbps / HBM_PEAK_GBPS,
+                                  note="frac > 1 = cache-resident: algorithmic tap bytes are served by L1/L2/Infinity Cache, "
+                                       "not HBM; `traffic` is the counter-measured HBM bytes per launch")
+    return out
+
+
+# =====================================================================================================
+# --config render (headline, BASELINE configs[1])
+# =====================================================================================================
+def run_render(a, rk: Ranks):
+    from egonerf_amd import _lib
+    dev = rk.dev
+    cfg = synth.SceneConfig()
+    weights = synth.make_weights(cfg, seed=1234)
+    model = synth.build_model(cfg, weights, dev)
+    rays = torch.from_numpy(synth.make_rays(N_RAYS, seed=1 + rk.rank)).to(dev)
+    kw = dict(n_coarse=N_SAMPLES, exp_sampling=True)
+    with torch.no_grad():
+        dt = timed(rk, lambda: model(rays, **kw), a.steps, a.warmup)
+    if rk.rank != 0:
+        return None
+    # ---- per-kernel durations, measured live with events on the launch stream (same work as a step) ----
+    lib, st = _lib.load(), _lib.stream_handle()
+    sc = model.scene()
+    M = N_RAYS * N_SAMPLES
+    sched = model._sched(N_SAMPLES, dev)
+    z = torch.empty(N_RAYS, N_SAMPLES, device=dev)
+    alpha, w = torch.empty_like(z), torch.empty_like(z)
+    bg = torch.empty(N_RAYS, device=dev)
+    rgb = torch.empty(N_RAYS, N_SAMPLES, 3, device=dev)
+    crd = torch.empty(N_RAYS, N_SAMPLES, 4, device=dev)
+    rgb_map, depth = torch.empty(N_RAYS, 3, device=dev), torch.empty(N_RAYS, device=dev)
+    reps = max(min(a.steps, 200), 5)
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(reps)]
+    for i in range(reps + 2):
+        e = ev[max(i - 2, 0)]
+        e[0].record()
+        _lib.check(lib.ego_march_density(sc, rays.data_ptr(), N_RAYS, N_SAMPLES, None, sched.data_ptr(), None, cfg.near, 0,
+                                         z.data_ptr(), alpha.data_ptr(), 0, w.data_ptr(), bg.data_ptr(), crd.data_ptr(), None, None, st), "march")
+        e[1].record()
+        _lib.check(lib.ego_shade(sc, rays.data_ptr(), z.data_ptr(), crd.data_ptr(), N_RAYS, N_SAMPLES, rgb.data_ptr(), None, None, st), "shade")
+        e[2].record()
+        _lib.check(lib.ego_composite(sc, rays.data_ptr(), z.data_ptr(), w.data_ptr(), bg.data_ptr(), rgb.data_ptr(), N_RAYS,
+                                     N_SAMPLES, rgb_map.data_ptr(), depth.data_ptr(), None, None, None, st), "composite")
+        e[3].record()
+    torch.cuda.synchronize()
+    ms = np.array([[e[k].elapsed_time(e[k + 1]) for k in range(3)] for e in ev]).mean(0)
+    t_march, t_shade, t_comp = (float(x) * 1e-3 for x in ms)
+    roofline = shade_roofline(model.mlp_precision, t_shade, M)
+    march_gbps = (B_DENSITY + 28) * M / t_march / 1e9
+    roofline.update(other_kernels_ms=dict(k_march_density=t_march * 1e3, k_composite=t_comp * 1e3),
+                    march_density=dict(hbm_algorithmic_GBps=march_gbps, frac_of_hbm_peak=march_gbps / HBM_PEAK_GBPS,
+                                       note="cache-resident like the shade gather (24.7 MB of density tables)"),
+                    path_algorithmic_GBps=(B_DENSITY + B_APP) * M / (t_march + t_shade + t_comp) / 1e9)
+
+    cpu = cpu_single = parity = None
+    if not a.no_cpu_baseline and rk.world == 1:  # the CPU baseline is timed at N=1 only
+        cpu_single, ref, cpu_rays = cpu_baseline_single(cfg, weights, a.cpu_rays)
+        with torch.no_grad():
+            got = model(cpu_rays.to(dev), **kw)
+        err = float((got[0].cpu() - ref[0]).abs().max())
+        mse = float(((got[0].cpu() - ref[0]) ** 2).mean())
+        parity = dict(max_abs_rgb_err=err, psnr_vs_oracle_db=float(-10 * np.log10(max(mse, 1e-30))),
+                      max_abs_depth_err=float((got[1].cpu() - ref[1]).abs().max()), rays=a.cpu_rays)
+        try:
+            cpu = cpu_baseline_all_cores()
+        except Exception as e:  # the single-process figure still stands
+            cpu = dict(cpu_single, note=f"all-cores run failed: {e!r}")
+    rays_per_s = rk.world * N_RAYS * a.steps / dt
+    return dict(metric="rays/sec at 4096-ray batch, 512 samples (EgoNeRF volume-rendering forward)", value=rays_per_s,
+                unit="rays/s", samples_per_s=rays_per_s * N_SAMPLES, n_gpus=rk.world, steps=a.steps, warmup=a.warmup,
+                ms_per_step=dt / a.steps * 1e3, higher_is_better=True, scaling="weak", vs_baseline=None,
+                dtype="f32 (tables, interpolation, compositing; matrix products as 3x fp16 MFMA with fp32 accumulate)"
+                if model.mlp_precision == "f16x3" else "f32",
+                data="synthetic",
+                config=dict(workload="OmniBlender barbershop shape: grid [150,172,516], 16x3/48x3 comps, MLP_Fea; "
+                                     "4096 rays x 512 samples, eval, no resampling (BASELINE configs[1])",
+                            rays_per_step_per_gpu=N_RAYS, samples_per_ray=N_SAMPLES, parallelism=f"ray-sharded x{rk.world}"),
+                roofline=roofline, cpu_baseline=cpu, cpu_baseline_single_process=cpu_single, parity=parity,
+                speedup_vs_cpu=None if cpu is None else rays_per_s / cpu["value"])
+
+
+# =====================================================================================================
+# --config train (BASELINE configs[3])
+# =====================================================================================================
+def run_train(a, rk: Ranks):
+    from egonerf_amd.losses import TVLoss, ray_entropy_loss
+    from egonerf_amd.optim import FusedAdam
+    dev, N = rk.dev, 8192
+    cfg = synth.SceneConfig()
+    model = synth.build_model(cfg, synth.make_weights(cfg, seed=1234), dev)
+    model.train()
+    rays = torch.from_numpy(synth.make_rays(N, seed=1 + rk.rank)).to(dev)
+    gt = torch.from_numpy(synth.hash_uniform(3 + rk.rank, 0, N * 3).reshape(N, 3).astype(np.float32)).to(dev)
+    opt = FusedAdam(model.get_optparam_groups(0.02, 1e-3), betas=(0.9, 0.99))  # train.py:176-186
+    tv = TVLoss()
+    kw = dict(is_train=True, n_coarse=128, n_fine=128, exp_sampling=True, resampling=True, use_coarse_sample=True)
+    losses = []
+
+    def forward():
+        rgb, _, _, _, alpha = model(rays, jitter=torch.rand(N, 128, device=dev), u=torch.rand(N, 128, device=dev), **kw)
+        loss = torch.mean((rgb - gt) ** 2)
+        if a.train_reg:  # configs/EgoNeRF/ricoh/common.txt:12-13 + opt.py defaults
+            loss = loss + 1e-4 * model.vector_comp_diffs() + 8e-5 * model.density_L1() + 0.1 * model.TV_loss_density(tv) \
+                + 0.01 * model.TV_loss_app(tv) + 1e-3 * ray_entropy_loss(alpha)
+        return loss
+
+    def step():
+        loss = forward()
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+        model.update_coarse_sigma_grid()  # every step when resampling (train.py:356-357)
+        losses.append(loss.detach())
+
+    dt = timed(rk, step, a.steps, a.warmup)
+    if rk.rank != 0:
+        return None
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    ev[0].record()
+    loss = forward()
+    ev[1].record()
+    opt.zero_grad(set_to_none=True)
+    loss.backward()
+    ev[2].record()
+    opt.step()
+    model.update_coarse_sigma_grid()
+    ev[3].record()
+    torch.cuda.synchronize()
+    rays_per_s = rk.world * N * a.steps / dt
+    return dict(metric="rays/sec, training step (forward + backward + FusedAdam + coarse-table refresh)", value=rays_per_s, unit="rays/s",
+                samples_per_s=rays_per_s * 384, n_gpus=rk.world, steps=a.steps, warmup=a.warmup, ms_per_step=dt / a.steps * 1e3,
+                higher_is_better=True, scaling="weak", vs_baseline=None,
+                dtype="f32 (tables, gradients, optimiser state; matrix products as fp16 / bf16 hi+lo MFMA with fp32 accumulate)",
+                data="synthetic",
+                config=dict(workload="OmniBlender barbershop shape: grid [150,172,516]; 8192 rays x (128 coarse + 128 fine) per step, "
+                                     "is_train noise, MSE vs random targets" + (" + TV/L1/ortho/entropy" if a.train_reg else "") +
+                                     " (BASELINE configs[3])",
+                            rays_per_step_per_gpu=N, parallelism="independent replicas" if rk.world > 1 else "1 GPU"),
+                phases_ms=dict(forward=ev[0].elapsed_time(ev[1]), backward=ev[1].elapsed_time(ev[2]), adam_and_refresh=ev[2].elapsed_time(ev[3])),
+                loss_first=float(losses[a.warmup]), loss_last=float(losses[-1]), peak_mem_GB=torch.cuda.max_memory_allocated() / 2 ** 30,
+                roofline=None, cpu_baseline=None)
+
+
+# =====================================================================================================
+# --config erp (BASELINE configs[2] and [4])
+# =====================================================================================================
+def erp_pose(k: int, K: int) -> np.ndarray:
+    ang = 2 * np.pi * k / max(K, 1)
+    c, s = np.cos(ang), np.sin(ang)
+    return np.array([[c, 0, s, 0.3 * c], [0, 1, 0, 0.05 * (k % 5)], [-s, 0, c, 0.3 * s]], np.float32)
+
+
+def run_erp(a, rk: Ranks):
+    from egonerf_amd.renderer import erp_rays, psnr_from_sse, shard_bounds, volume_renderer
+    dev = rk.dev
+    H, W = a.erp_size
+    cfg = synth.SceneConfig(**synth.RICOH)
+    model = synth.build_model(cfg, synth.make_weights(cfg, seed=1234), dev)
+    kw = dict(chunk=65536, n_coarse=128, n_fine=128, exp_sampling=True, resampling=True, use_coarse_sample=True, device=dev,
+              keep_alpha=False)  # an image render reads rgb only (renderer.py:125-157)
+    row0, row1 = shard_bounds(H, rk.world, rk.rank)  # contiguous block of rows per rank
+    K = a.views or max(a.steps, 1)
+    state = dict(k=0)
+
+    def render(k):
+        rays = erp_rays(H, W, erp_pose(k, K), dev, row0, row1 - row0)
+        return volume_renderer(rays, model, **kw)[0]
+
+    def step():
+        state["last"] = render(state["k"] % K)
+        state["k"] += 1
+
+    # reference images for the PSNR column: the same views with the fp32-MFMA arithmetic and no skipping
+    with torch.no_grad():
+        model.mlp_precision = "f32"
+        refs = [render(k) for k in range(min(K, 2))]
+        model.mlp_precision = "f16x3"
+        occupied = None
+        if a.mask:
+            occupied = model.updateAlphaMask()
+            model.use_alpha_mask = True
+        model.early_termination_eps = a.term_eps
+        dt = timed(rk, step, a.steps, a.warmup)
+        psnrs = []
+        for k, ref in enumerate(refs):
+            d = render(k).double() - ref.double()
+            stat = torch.stack([(d * d).sum(), torch.tensor(float(d.numel()), device=dev, dtype=torch.float64)])
+            if rk.dist is not None:
+                stat = stat.cpu() if rk.shared else stat
+                rk.dist.all_reduce(stat)
+            psnrs.append(psnr_from_sse(max(stat[0].item(), 1e-300), stat[1].item()))
+    if rk.rank != 0:
+        return None
+    rays_per_s = a.steps * H * W / dt
+    return dict(metric="rays/sec, full equirectangular image render (128 coarse + 128 fine samples, envmap on)", value=rays_per_s,
+                unit="rays/s", samples_per_s=rays_per_s * 384, n_gpus=rk.world, steps=a.steps, warmup=a.warmup, ms_per_step=dt / a.steps * 1e3,
+                s_per_image=dt / a.steps, higher_is_better=True, scaling="strong", vs_baseline=None,
+                dtype="f32 (matrix products as 3x fp16 MFMA with fp32 accumulate)", data="synthetic",
+                config=dict(workload=f"Ricoh360-like scene (near_far [0.1,300], r0 0.05, shift -10, envmap 3x3840x1920, grid [150,172,516]); "
+                                     f"a step = one {H}x{W} ERP image, rays generated on the device, rows sharded over the ranks "
+                                     f"(BASELINE configs[2]; configs[4] at --gpus 8)",
+                            alpha_mask=bool(a.mask), alpha_mask_occupied_fraction=occupied, term_eps=a.term_eps,
+                            parallelism=f"row-sharded x{rk.world}"),
+                psnr_vs_f32_unskipped_db=psnrs, roofline=None, cpu_baseline=None)
 
 
 def main():
     a = parse()
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}"
-    # EGO_BENCH_TEST_SHARED_GPU=1: dry-run of the multi-rank path on a box with one GPU (all ranks on cuda:0, gloo)
-    shared = os.environ.get("EGO_BENCH_TEST_SHARED_GPU") == "1"
-    if shared:
-        local = 0
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    if world > 1:
-        import torch.distributed as dist
-        if shared:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=dev)  # RCCL on ROCm
-
-    from egonerf_amd.synth import build_model as make_model
-    cfg = synth.SceneConfig()
-    weights = synth.make_weights(cfg, seed=1234)
-    model = make_model(cfg, weights, dev)
-    rays = torch.from_numpy(synth.make_rays(N_RAYS, seed=1 + rank)).to(dev)
-    kw = dict(n_coarse=N_SAMPLES, exp_sampling=True)
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    with torch.no_grad():
-        for _ in range(a.warmup):
-            out = model(rays, **kw)
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(a.steps):
-            out = model(rays, **kw)
-        barrier()
-        dt = time.perf_counter() - t0
-    t = torch.tensor([dt], device="cpu" if shared else dev, dtype=torch.float64)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)  # MAX over ranks of the barrier-bracketed wall time
-    dt = float(t.item())
-
-    if rank == 0:
-        # ---- per-kernel durations, measured live with events on the launch stream (same work as a step) ----
-        from egonerf_amd import _lib
-        lib, st = _lib.load(), _lib.stream_handle()
-        sc = model.scene()
-        M = N_RAYS * N_SAMPLES
-        sched = model._sched(N_SAMPLES, dev)
-        z = torch.empty(N_RAYS, N_SAMPLES, device=dev)
-        alpha, w = torch.empty_like(z), torch.empty_like(z)
-        bg = torch.empty(N_RAYS, device=dev)
-        rgb = torch.empty(N_RAYS, N_SAMPLES, 3, device=dev)
-        crd = torch.empty(N_RAYS, N_SAMPLES, 4, device=dev)
-        rgb_map, depth = torch.empty(N_RAYS, 3, device=dev), torch.empty(N_RAYS, device=dev)
-        reps = max(a.steps, 5)
-        ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(reps)]
-        for i in range(reps + 2):
-            e = ev[max(i - 2, 0)]
-            e[0].record()
-            _lib.check(lib.ego_march_density(sc, rays.data_ptr(), N_RAYS, N_SAMPLES, None, sched.data_ptr(), None, cfg.near, 0,
-                                             z.data_ptr(), alpha.data_ptr(), 0, w.data_ptr(), bg.data_ptr(), crd.data_ptr(), None, None, st), "march")
-            e[1].record()
-            _lib.check(lib.ego_shade(sc, rays.data_ptr(), z.data_ptr(), crd.data_ptr(), N_RAYS, N_SAMPLES, rgb.data_ptr(), None, None, st), "shade")
-            e[2].record()
-            _lib.check(lib.ego_composite(sc, rays.data_ptr(), z.data_ptr(), w.data_ptr(), bg.data_ptr(), rgb.data_ptr(), N_RAYS,
-                                         N_SAMPLES, rgb_map.data_ptr(), depth.data_ptr(), None, None, None, st), "composite")
-            e[3].record()
-        torch.cuda.synchronize()
-        ms = np.array([[e[k].elapsed_time(e[k + 1]) for k in range(3)] for e in ev]).mean(0)
-        t_march, t_shade, t_comp = (float(x) * 1e-3 for x in ms)
-        shade_bytes = (B_APP + 16 + 12) * M         # gathered taps + 16 B coords read + 12 B rgb write, per sample
-        shade_gbps = shade_bytes / t_shade / 1e9
-        shade_tflops = FLOP_SAMPLE_SHADE * M / t_shade / 1e12
-        prec = model.mlp_precision
-        kname = "k_shade_h<SHADE>" if prec == "f16x3" else "k_shade<SHADE>"
-        # HBM bytes per launch from the committed PMC passes of this build (bench.py cannot collect PMC counters live)
-        traffic, traffic_src = None, None
-        try:
-            pmc = json.load(open(os.path.join(REPO, "profiles", "r01", "pmc_traffic.json")))
-            if kname in pmc:
-                traffic, traffic_src = pmc[kname]["traffic_bytes"], "profiles/r01/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE)"
-        except OSError:
-            pass
-        # matrix-pipe view: f16x3 executes 3 fp16 MFMA flops per algorithmic flop (dense fp16 peak ~2.5 PF)
-        mfma = (dict(mode="f16x3", achieved_algorithmic=shade_tflops, executed=3 * shade_tflops, peak=MFMA_F16_PEAK_TFLOPS,
-                     unit="TFLOP/s", frac=3 * shade_tflops / MFMA_F16_PEAK_TFLOPS) if prec == "f16x3" else
-                dict(mode="f32", achieved=shade_tflops, peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s", frac=shade_tflops / MFMA_F32_PEAK_TFLOPS))
-        l1_peak = 256 * 64 * 2.4  # GB/s: 64 B/clk/CU vector-L1 return path x 256 CUs x 2.4 GHz
-        roofline = dict(bound="hbm", kernel=kname, achieved=shade_gbps, peak=HBM_PEAK_GBPS, unit="GB/s",
-                        frac=shade_gbps / HBM_PEAK_GBPS, traffic=traffic, traffic_source=traffic_src, ms=t_shade * 1e3,
-                        algorithmic_bytes_per_launch=shade_bytes,
-                        note="the 94 MB table set is L2/Infinity-Cache resident, so algorithmic bytes/s exceeds the HBM peak; "
-                             "the binding resource is instruction issue: VALU and MFMA time add up on a CDNA4 SIMD "
-                             "(tools/coissue_probe.hip), see `issue`",
-                        issue=dict(mfma_per_tile=243, mfma_cycles_per_tile=243 * 32, valu_per_tile=1800, valu_cycles_per_tile=1800 * 4,
-                                   tiles_per_simd=M / 32 / 1024, clock_GHz=2.1,
-                                   additive_bound_ms=(243 * 32 + 1800 * 4) * (M / 32 / 1024) / 2.1e6,
-                                   frac=(243 * 32 + 1800 * 4) * (M / 32 / 1024) / 2.1e6 / (t_shade * 1e3)),
-                        l1=dict(achieved=shade_gbps, peak=l1_peak, unit="GB/s", frac=shade_gbps / l1_peak),
-                        mfma=mfma,
-                        other_kernels_ms=dict(k_march_density=t_march * 1e3, k_composite=t_comp * 1e3),
-                        march_density=dict(achieved=(B_DENSITY + 28) * M / t_march / 1e9, unit="GB/s",
-                                           frac=(B_DENSITY + 28) * M / t_march / 1e9 / HBM_PEAK_GBPS),
-                        path_algorithmic_GBps=(B_DENSITY + B_APP) * M / (t_march + t_shade + t_comp) / 1e9)
-
-        cpu = None
-        parity = None
-        if not a.no_cpu_baseline and world == 1:  # the CPU baseline is timed at N=1 only
-            cpu, ref, cpu_rays = cpu_baseline(cfg, weights, a.cpu_rays)
-            with torch.no_grad():
-                got = model(cpu_rays.to(dev), **kw)
-            err = float((got[0].cpu() - ref[0]).abs().max())
-            mse = float(((got[0].cpu() - ref[0]) ** 2).mean())
-            parity = dict(max_abs_rgb_err=err, psnr_vs_oracle_db=float(-10 * np.log10(max(mse, 1e-30))),
-                          max_abs_depth_err=float((got[1].cpu() - ref[1]).abs().max()), rays=a.cpu_rays)
-
-        rays_per_s = world * N_RAYS * a.steps / dt
-        line = dict(metric="rays/sec at 4096-ray batch, 512 samples (EgoNeRF volume-rendering forward)", value=rays_per_s,
-                    unit="rays/s", samples_per_s=rays_per_s * N_SAMPLES, n_gpus=world, steps=a.steps, warmup=a.warmup,
-                    ms_per_step=dt / a.steps * 1e3, higher_is_better=True, scaling="weak", vs_baseline=None,
-                    dtype="f32 (tables, interpolation, compositing; matrix products as 3x fp16 MFMA with fp32 accumulate)"
-                    if model.mlp_precision == "f16x3" else "f32",
-                    data="synthetic",
-                    config=dict(workload="OmniBlender barbershop shape: grid [150,172,516], 16x3/48x3 comps, MLP_Fea; "
-                                         "4096 rays x 512 samples, eval, no resampling (BASELINE configs[1])",
-                                rays_per_step_per_gpu=N_RAYS, samples_per_ray=N_SAMPLES, parallelism=f"ray-sharded x{world}"),
-                    roofline=roofline, cpu_baseline=cpu, parity=parity,
-                    speedup_vs_cpu=None if cpu is None else rays_per_s / cpu["value"])
-        print(json.dumps(line))
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    if a.cpu_worker:
+        return cpu_worker(*a.cpu_worker)
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(a)
+    rk = Ranks(a)
+    line = dict(render=run_render, train=run_train, erp=run_erp)[a.config](a, rk)
+    if rk.rank == 0:
+        print(json.dumps(line), flush=True)
+    rk.finish()
 
 
 if __name__ == "__main__":

@@ -20,12 +20,34 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found (need ROCm's hipcc to build libegonerf_hip.so)")
 
 
+TESTED_HIPCC = ("7.2.",)  # HIP versions whose code generation passed the determinism soak of DESIGN.md 5.1
+
+
+def hipcc_version() -> str:
+    out = subprocess.run([_hipcc(), "--version"], capture_output=True, text=True).stdout
+    for line in out.splitlines():
+        if line.startswith("HIP version:"):
+            return line.split(":", 1)[1].strip()
+    return "unknown"
+
+
+def source_hash() -> str:
+    """sha256 over the library's sources, headers and compile flags: what `libegonerf_hip.so.hash` records for the binary next
+    to it, and what profiles/r*/pmc_traffic.json records for the build its counters were taken from."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in SOURCES + HEADERS:
+        h.update(f.encode())
+        h.update(open(os.path.join(CSRC, f), "rb").read())
+    h.update(repr((COMMON_FLAGS, sorted(EXTRA_FLAGS.items()))).encode())
+    return h.hexdigest()[:16]
+
+
 def is_stale() -> bool:
-    if not os.path.exists(LIB):
+    """True unless the binary's recorded source hash equals the tree's (mtimes do not survive a snapshot copy)."""
+    if not os.path.exists(LIB) or not os.path.exists(LIB + ".hash"):
         return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS]
-    return any(os.path.getmtime(d) > t for d in deps)
+    return open(LIB + ".hash").read().strip() != source_hash()
 
 
 # Per-source extra flags.  ego_shade.hip is built without the SLP vectoriser: it forms {w00, w01}-style pairs of the interpolation
@@ -43,6 +65,12 @@ def build_library(force: bool = False, verbose: bool = False, extra: list | None
     out = out or os.environ.get("EGO_LIB_OUT") or LIB
     if not force and not extra and out == LIB and not is_stale():
         return LIB
+    ver = hipcc_version()
+    if not ver.startswith(TESTED_HIPCC) and not os.environ.get("EGO_ALLOW_UNTESTED_HIPCC"):
+        # a code-generation-dependent fault was found and fenced off with this compiler; another one must
+        # pass tests/test_hip_determinism.py (3000 repetitions per op) before its binaries are trusted
+        raise RuntimeError(f"hipcc {ver} is not a tested compiler ({TESTED_HIPCC}); set EGO_ALLOW_UNTESTED_HIPCC=1 to build anyway "
+                           "and run tests/test_hip_determinism.py on the result")
     objdir = os.path.join(HERE, "build" + ("_" + os.path.basename(out) if out != LIB else ""))
     os.makedirs(objdir, exist_ok=True)
     procs, objs = [], []
@@ -65,6 +93,8 @@ def build_library(force: bool = False, verbose: bool = False, extra: list | None
     if r.returncode != 0:
         raise RuntimeError("hipcc (link) failed:\n" + r.stdout + r.stderr)
     os.replace(out + ".tmp", out)
+    if out == LIB and not extra:
+        open(LIB + ".hash", "w").write(source_hash() + "\n")
     if out != LIB:
         shutil.rmtree(objdir, ignore_errors=True)
     return out

@@ -457,6 +457,29 @@ def capture_metrics():
     np.savez_compressed(os.path.join(OUT, "metrics.npz"), **fx)
 
 
+def capture_ws():
+    """extra/ws_ssim.py:12-33: the cos-latitude row weights (generate_ws / estws) and the weighted mean of an SSIM map exactly as
+    ws_ssim forms it (`np.sum(map * ws) / ws.sum()`).  torchmetrics is absent, so the map fed to that expression is the
+    reference's own utils.rgb_ssim(..., return_map=True) map (channel mean), not torchmetrics' padded one."""
+    import importlib
+    _stub("torchmetrics", StructuralSimilarityIndexMeasure=None)
+    if "scipy.constants.constants" not in sys.modules:
+        try:
+            importlib.import_module("scipy.constants.constants")
+        except Exception:
+            _stub("scipy.constants.constants", pi=np.pi)
+    ws_mod = importlib.import_module("extra.ws_ssim")
+    from utils import rgb_ssim
+    mx = np.load(os.path.join(OUT, "metrics.npz"))
+    img0, img1 = torch.from_numpy(mx["img0"]), torch.from_numpy(mx["img1"])
+    smap = np.asarray(rgb_ssim(img0, img1, 1, return_map=True)).mean(-1)     # [Ho, Wo]
+    ws = ws_mod.estws(smap)
+    fx = dict(ws_30x46=ws, wsssim=np.float64(np.sum(smap * ws) / ws.sum()), ssim_map_mean=smap)
+    for n in (7, 64, 1024):
+        fx[f"ws_rows/{n}"] = ws_mod.estws(np.zeros((n, 3)))[:, 0]
+    np.savez_compressed(os.path.join(OUT, "ws_metrics.npz"), **fx)
+
+
 def capture_plainexp():
     """interval_th=False: the plain exponential r grid (coordinates.py:132-155, with the `downsample=2` the forward passes,
     EgoNeRF.py:524) and the matching sample schedule (EgoNeRF.py:59-67).  Eval mode."""
@@ -528,7 +551,7 @@ def capture_uniform():
 
 if __name__ == "__main__":
     torch.manual_seed(0)
-    which = sys.argv[1:] or ["tiny", "stages", "full", "alpha_mask", "checkpoint", "train_extras", "metrics", "plainexp", "sh", "uniform", "ricoh", "envmap_full"]
+    which = sys.argv[1:] or ["tiny", "stages", "full", "alpha_mask", "checkpoint", "train_extras", "metrics", "plainexp", "sh", "uniform", "ricoh", "envmap_full", "ws"]
     for name in which:
         globals()["capture_" + name]()
         print("captured", name)

@@ -525,6 +525,24 @@ def rgb_ssim(img0, img1, max_val, filter_size=11, filter_sigma=1.5, k1=0.01, k2=
 
 
 
+def ws_rows(n: int) -> np.ndarray:
+    """extra/ws_ssim.py:12-24 (generate_ws / estws): the weight of row i of an n-row equirectangular map, float64."""
+    return np.array([np.cos((i + 0.5 - n / 2) * np.pi / n) for i in range(n)])
+
+
+def ws_mean(smap: np.ndarray) -> float:
+    """extra/ws_ssim.py:29-31: sum(map * ws) / sum(ws), ws = row weights broadcast over the columns."""
+    ws = np.repeat(ws_rows(smap.shape[0])[:, None], smap.shape[1], 1)
+    return float(np.sum(smap * ws) / ws.sum())
+
+
+def ws_psnr(img: np.ndarray, gt: np.ndarray) -> float:
+    """Latitude-weighted PSNR (the WS-PSNR of the 360-video literature with extra/ws_ssim.py's weights), float64."""
+    w = ws_rows(img.shape[0])[:, None, None]
+    d = np.asarray(img, np.float64) - np.asarray(gt, np.float64)
+    return float(10 * np.log10(1.0 / ((d * d * w).sum() / (w.sum() * img.shape[1] * img.shape[2]))))
+
+
 def sh_render(viewdirs: torch.Tensor, features: torch.Tensor) -> torch.Tensor:
     """models/tensorBase.py:30-34 with the degree-2 bases of models/sh.py:87-112."""
     x, y, z = viewdirs.unbind(-1)

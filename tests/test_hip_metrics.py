@@ -56,3 +56,25 @@ def test_evaluation_psnr_and_ssim_of_an_erp_render():
     assert abs(psnrs[0] - (-10 * np.log10(mse))) <= 1e-3
     assert abs(ssims[0] - ref_ssim(img.view(H, W, 3).cpu().numpy(), gt.view(H, W, 3).cpu().numpy(), 1)) <= 1e-6
     assert 0.3 < ssims[0] < 1.0
+
+
+def test_ws_metrics(golden):
+    """WS-SSIM / WS-PSNR (extra/ws_ssim.py:12-33) on the device vs the reference-pinned oracle restatement."""
+    from oracle.egonerf_oracle import rgb_ssim as ref_ssim, ws_psnr as ref_ws_psnr, ws_rows
+    mx, fx = golden("metrics"), golden("ws_metrics")
+    a, b = torch.from_numpy(mx["img0"]).to(DEV), torch.from_numpy(mx["img1"]).to(DEV)
+    # the reference's weighting applied to the map's own rows (what capture_ws stored)
+    m = metrics.rgb_ssim(a, b, 1, return_map=True).double().mean(-1)
+    assert abs(metrics.weighted_map_mean(m, metrics.ws_weights(30)) - float(fx["wsssim"])) <= 1e-7   # float32 map
+    ssim, wsssim = metrics.ws_ssim(a, b)
+    assert abs(ssim - float(mx["ssim"])) <= 1e-7
+    smap = ref_ssim(mx["img0"], mx["img1"], 1, return_map=True).mean(-1)
+    w = ws_rows(40)[5:35]                                                      # map row i is centred on image row i + 5
+    assert abs(wsssim - float((smap * w[:, None]).sum() / (w.sum() * smap.shape[1]))) <= 1e-7
+    assert abs(metrics.ws_psnr(b, a) - ref_ws_psnr(mx["img1"], mx["img0"])) <= 1e-9
+    # full ERP size: weights sum and a noise image with latitude-dependent error
+    H, W = 1024, 2048
+    g = torch.Generator().manual_seed(9)
+    x = torch.rand(H, W, 3, generator=g)
+    y = (x + 0.1 * torch.rand(H, W, 3, generator=g) * torch.linspace(0, 1, H)[:, None, None]).clamp(0, 1)
+    assert abs(metrics.ws_psnr(y.to(DEV), x.to(DEV)) - ref_ws_psnr(y.numpy(), x.numpy())) <= 1e-8

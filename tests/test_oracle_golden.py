@@ -258,3 +258,23 @@ def test_rgb_ssim_restatement(golden):
     assert abs(rgb_ssim(np.full_like(a, 0.25), b, 1) - float(fx["ssim_flat"])) < 1e-12
     assert abs(rgb_ssim(a, b, 1, filter_size=7, filter_sigma=1.0) - float(fx["ssim_fs7"])) < 1e-12
     assert abs(psnr(torch.from_numpy(b), torch.from_numpy(a)) - float(fx["psnr"])) < 1e-9
+
+
+def test_ws_weights_and_weighted_ssim_vs_reference(golden):
+    """extra/ws_ssim.py:12-33 (captured through the real file's estws): oracle restatement and the product's host weights."""
+    from egonerf_amd.metrics import weighted_map_mean, ws_weights
+    from oracle.egonerf_oracle import ws_mean, ws_psnr, ws_rows
+    fx = golden("ws_metrics")
+    for n in (7, 64, 1024):
+        assert np.array_equal(ws_rows(n), fx[f"ws_rows/{n}"]) and np.array_equal(ws_weights(n), fx[f"ws_rows/{n}"])
+    assert np.array_equal(np.repeat(ws_rows(30)[:, None], 46, 1), fx["ws_30x46"])
+    assert abs(ws_mean(fx["ssim_map_mean"]) - float(fx["wsssim"])) <= 1e-15
+    assert abs(weighted_map_mean(torch.from_numpy(fx["ssim_map_mean"]), ws_weights(30)) - float(fx["wsssim"])) <= 1e-14
+    assert np.array_equal(ws_weights(5, 3, 16), ws_rows(16)[3:8])   # a window of rows of a taller panorama
+    # constant weights would give the plain PSNR: check the weighted one against a direct double-loop evaluation
+    mx = golden("metrics")
+    a, b = mx["img0"].astype(np.float64), mx["img1"].astype(np.float64)
+    H = a.shape[0]
+    num = sum(np.cos((i + 0.5 - H / 2) * np.pi / H) * ((a[i] - b[i]) ** 2).sum() for i in range(H))
+    den = sum(np.cos((i + 0.5 - H / 2) * np.pi / H) for i in range(H)) * a.shape[1] * 3
+    assert abs(ws_psnr(mx["img1"], mx["img0"]) - 10 * np.log10(den / num)) <= 1e-10

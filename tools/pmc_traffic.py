@@ -1,27 +1,44 @@
-"""gpurun_out/prof_<tag>/pmc_*/**.db (tools/profile_gpu.sh) -> profiles/r01/pmc_traffic.json: per-launch counter means for the render
-kernels and the HBM traffic bench.py reports as roofline.traffic (FETCH_SIZE is in KB and counts 32-byte requests as 64 on gfx950:
-read bytes = FETCH_SIZE x 1024 x 2, /opt/skills/guides/MI355X_MICROARCH.md; WRITE_SIZE x 1024)."""
+"""gpurun_out/prof_<tag>/pmc_*/**.db (tools/profile_gpu.sh) -> profiles/<round>/pmc_traffic.json: per-launch counter means for the
+render kernels, the kernel duration of the GRBM pass (-> effective clock) and the HBM traffic bench.py reports as
+roofline.traffic (FETCH_SIZE is in KB and counts 32-byte requests as 64 on gfx950: read bytes = FETCH_SIZE x 1024 x 2,
+/opt/skills/guides/MI355X_MICROARCH.md; WRITE_SIZE x 1024).  `_source_hash` records the library sources the counters belong
+to (egonerf_amd.build.source_hash of the working tree: run this right after the profile, before editing kernels).
+
+    python tools/pmc_traffic.py <tag> [round]        e.g.  python tools/pmc_traffic.py v1 r02
+"""
 import glob, json, os, sqlite3, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "v9"
+sys.path.insert(0, root)
+from egonerf_amd.build import source_hash
+tag = sys.argv[1] if len(sys.argv) > 1 else "v1"
+rnd = sys.argv[2] if len(sys.argv) > 2 else "r02"
 src = os.path.join(root, "gpurun_out", f"prof_{tag}")
-names = {"k_shade_h<SHADE>": "%k_shade_h<0, false, false>%", "k_march_density<16>": "%k_march_density%", "k_composite": "%k_composite%"}
+names = {"k_shade_h<SHADE>": "%k_shade_h<0, false, false>%", "k_shade<SHADE>": "%k_shade<0%", "k_march_density<16>": "%k_march_density%",
+         "k_composite": "%k_composite%"}
 keys = {"FETCH_SIZE": "FETCH_SIZE_KB", "WRITE_SIZE": "WRITE_SIZE_KB", "TCC_HIT_sum": "TCC_HIT", "TCC_MISS_sum": "TCC_MISS",
         "TCP_TCC_READ_REQ_sum": "TCP_TCC_READ_REQ", "TCP_TOTAL_CACHE_ACCESSES_sum": "TCP_TOTAL_CACHE_ACCESSES", "TA_BUSY_avr": "TA_BUSY_avr",
         "GRBM_GUI_ACTIVE": "GRBM_GUI_ACTIVE", "SQ_INSTS_VALU": "SQ_INSTS_VALU_per_SE", "SQ_INSTS_MFMA": "SQ_INSTS_MFMA_per_SE",
-        "SQ_VALU_MFMA_BUSY_CYCLES": "SQ_VALU_MFMA_BUSY_CYCLES_per_SE", "SQ_WAIT_ANY": "SQ_WAIT_ANY_per_SE", "SQ_WAVE_CYCLES": "SQ_WAVE_CYCLES_per_SE"}
+        "SQ_VALU_MFMA_BUSY_CYCLES": "SQ_VALU_MFMA_BUSY_CYCLES_per_SE", "SQ_WAIT_ANY": "SQ_WAIT_ANY_per_SE", "SQ_WAVE_CYCLES": "SQ_WAVE_CYCLES_per_SE",
+        "SQ_INSTS_LDS": "SQ_INSTS_LDS_per_SE", "SQ_INSTS_VMEM_RD": "SQ_INSTS_VMEM_RD_per_SE", "SQ_INSTS_SALU": "SQ_INSTS_SALU_per_SE",
+        "SQ_BUSY_CYCLES": "SQ_BUSY_CYCLES_per_SE"}
 out = {k: {} for k in names}
 for p in glob.glob(src + "/pmc_*/**/*.db", recursive=True):
     db = sqlite3.connect(p)
     for short, like in names.items():
-        for ctr, val in db.execute("select counter_name, avg(counter_value) from pmc_events where name like ? group by counter_name", (like,)):
+        q = "select counter_name, avg(counter_value), avg(duration) from pmc_events where name like ? group by counter_name"
+        for ctr, val, dur in db.execute(q, (like,)):
             if ctr in keys:
                 out[short][keys[ctr]] = round(val, 1)
+            if ctr == "GRBM_GUI_ACTIVE":
+                out[short]["duration_us"] = round(dur / 1e3, 3)  # of the same dispatches the GRBM counter was read for
+out = {k: v for k, v in out.items() if v}
 for short, d in out.items():
     if "FETCH_SIZE_KB" in d and "WRITE_SIZE_KB" in d:
         d["hbm_read_bytes_corrected"] = d["FETCH_SIZE_KB"] * 1024 * 2
         d["hbm_write_bytes"] = d["WRITE_SIZE_KB"] * 1024
         d["traffic_bytes"] = d["hbm_read_bytes_corrected"] + d["hbm_write_bytes"]
-out["_source"] = f"gpurun_out/prof_{tag} (tools/profile_gpu.sh {tag}; separate rocprofv3 --pmc passes), build = commit of profiles/r01/{tag}_rocprofv3_summary.txt"
-json.dump(out, open(os.path.join(root, "profiles", "r01", "pmc_traffic.json"), "w"), indent=1)
+out["_source"] = f"gpurun_out/prof_{tag} (tools/profile_gpu.sh {tag}; separate rocprofv3 --pmc passes of `bench.py --steps 10 --warmup 2`)"
+out["_source_hash"] = source_hash()
+os.makedirs(os.path.join(root, "profiles", rnd), exist_ok=True)
+json.dump(out, open(os.path.join(root, "profiles", rnd, "pmc_traffic.json"), "w"), indent=1)
 print(json.dumps({k: v.get("traffic_bytes") for k, v in out.items() if isinstance(v, dict)}))

@@ -2,7 +2,7 @@
 # Runs on the GPU box (via gpurun): kernel-trace stats + separate PMC passes for bench.py's step.
 # Usage: tools/profile_gpu.sh <tag>     -> gpurun_out/prof_<tag>/
 set -u
-TAG=${1:-r01}
+TAG=${1:-v1}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
