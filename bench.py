@@ -248,7 +248,7 @@ def shade_roofline(prec: str, t_shade: float, M: int):
     if pmc is not None:
         n_se = 32
         mfma = pmc["SQ_INSTS_MFMA_per_SE"] * n_se
-        valu = pmc["SQ_INSTS_VALU_per_SE"] * n_se
+        valu = pmc["SQ_INSTS_VALU_per_SE"] * n_se - mfma   # SQ_INSTS_VALU counts the MFMAs too
         executed = mfma * FLOP_PER_MFMA[prec] / t_shade / 1e12
         clock_ghz = pmc["GRBM_GUI_ACTIVE"] / (pmc["duration_us"] * 1e3) if "duration_us" in pmc else None
         tiles = M / 32

@@ -143,20 +143,35 @@ class OracleScene:
         return xyz, z
 
     # ---- row B: Cartesian -> yin-yang 7-vector ----------------------------------------------
-    def from_cartesian(self, xyz: torch.Tensor) -> torch.Tensor:
-        """coordinates.py:468-498: [r,th,ph,0,0,0,0] (yin) or [0,0,0,r,th_e,ph_e,1] (yang)."""
+    def from_cartesian(self, xyz: torch.Tensor, grid_choice: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """coordinates.py:468-498: [r,th,ph,0,0,0,0] (yin) or [0,0,0,r,th_e,ph_e,1] (yang).
+        `grid_choice` (tests only; same leading shape, 0 = yin, 1 = yang) overrides the inclusive border test: a point within
+        an ulp of a region border lands on either grid depending on the libm's acos/atan2 rounding (the reference itself
+        chooses differently on CPU and GPU), and the two grids hold independent tables."""
         pi = math.pi
         d = xyz - self.center.to(xyz.dtype)
         r = d.pow(2).sum(-1).sqrt()
         th_n = torch.acos(d[..., 2] / r).nan_to_num_()
         ph_n = torch.atan2(d[..., 1], d[..., 0])
         yin = (pi / 4 <= th_n) & (th_n <= 3 * pi / 4) & (-3 * pi / 4 <= ph_n) & (ph_n <= 3 * pi / 4)
+        if grid_choice is not None:
+            yin = grid_choice.to(yin.device) == 0
         th_e = torch.acos(d[..., 1] / r).nan_to_num_()
         ph_e = torch.atan2(d[..., 2], -d[..., 0])
         zero = torch.zeros_like(r)
         as_yin = torch.stack([r, th_n, ph_n, zero, zero, zero, zero], -1)
         as_yang = torch.stack([zero, zero, zero, r, th_e, ph_e, torch.ones_like(r)], -1)
         return torch.where(yin[..., None], as_yin, as_yang)
+
+    def yin_margin(self, xyz: torch.Tensor) -> torch.Tensor:
+        """Signed angular margin (radians, float64) of the yin/yang decision of from_cartesian: > 0 inside the yin region,
+        < 0 outside; |margin| below a few float32 ulps of pi (~5e-7) means the grid choice depends on the libm."""
+        pi = math.pi
+        d = xyz.double() - self.center.double()
+        r = d.pow(2).sum(-1).sqrt()
+        th = torch.acos((d[..., 2] / r).clamp(-1, 1)).nan_to_num()
+        ph = torch.atan2(d[..., 1], d[..., 0])
+        return torch.stack([th - pi / 4, 3 * pi / 4 - th, ph + 3 * pi / 4, 3 * pi / 4 - ph], -1).amin(-1)
 
     # ---- row C: normalisation ----------------------------------------------------------------
     def normalize_r(self, r: torch.Tensor, downsample=None) -> torch.Tensor:
@@ -335,7 +350,7 @@ class OracleScene:
     def forward(self, rays: torch.Tensor, n_coarse: int, n_fine: int = 0, resampling: bool = False,
                 use_coarse_sample: bool = True, is_train: bool = False,
                 jitter: Optional[torch.Tensor] = None, u: Optional[torch.Tensor] = None,
-                keep: bool = False, exp_sampling: bool = True):
+                keep: bool = False, exp_sampling: bool = True, grid_choice: Optional[torch.Tensor] = None):
         """EgoNeRF.forward (EgoNeRF.py:491-602), exp_sampling + interval_th path.
 
         Returns (rgb[N,3], depth[N], bg|None, env|None, alpha[N,S(+1)]) and, if keep, a dict of
@@ -352,9 +367,9 @@ class OracleScene:
             z = z[0].repeat(xyz.shape[0], 1)  # EgoNeRF.py:515-516 (ray 0's distances for every ray, also with sample_ray)
         dists = z[..., 1:] - z[..., :-1]
         dists = torch.cat([dists, dists[..., -1:]], -1)
-        c7 = self.from_cartesian(xyz)
+        c7 = self.from_cartesian(xyz, None if resampling else grid_choice)  # `grid_choice` addresses the rendered samples
         c7n = self.normalize_coord(c7)
-        inter = dict(z_coarse=z, c7=c7, c7n=c7n) if keep else None
+        inter = dict(z_coarse=z, c7=c7, c7n=c7n, xyz_coarse=xyz) if keep else None
 
         if resampling:
             sf = self.density_feature(c7n, coarse=True)
@@ -370,9 +385,9 @@ class OracleScene:
             dists = z[..., 1:] - z[..., :-1]
             dists = torch.cat([dists, dists[..., -1:]], -1)
             xyz = o[:, None, :] + viewdirs[:, None, :] * z[..., None]
-            c7n = self.normalize_coord(self.from_cartesian(xyz), downsample=None)  # the fine pass: full grid (EgoNeRF.py:546)
+            c7n = self.normalize_coord(self.from_cartesian(xyz, grid_choice), downsample=None)  # the fine pass: full grid (EgoNeRF.py:546)
             if keep:
-                inter.update(coarse_sigma_feat=sf, coarse_weight=cw, z_new=z_new, z_fine=z)
+                inter.update(coarse_sigma_feat=sf, coarse_weight=cw, z_new=z_new, z_fine=z, xyz_fine=xyz)
 
         sf = self.density_feature(c7n)
         sigma = self.feature2density(sf)

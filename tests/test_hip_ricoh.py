@@ -9,7 +9,7 @@ import torch
 
 from egonerf_amd import synth
 from egonerf_amd.renderer import erp_rays, shard_bounds, volume_renderer
-from tests.helpers import make_model, maxerr
+from tests.helpers import make_model, make_oracle, maxerr
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -25,9 +25,44 @@ def T(a):
 def ricoh(golden):
     fx = golden("ricoh")
     cfg = synth.SceneConfig(**synth.RICOH)
-    model = make_model(cfg, synth.make_weights(cfg, seed=int(fx["seed_weights"])), DEV)
+    w = synth.make_weights(cfg, seed=int(fx["seed_weights"]))
+    model = make_model(cfg, w, DEV)
     assert model.envmap.emission.shape == (3, 3840, 1920)
+    model.oracle = make_oracle(cfg, w)
     return fx, cfg, model
+
+
+BORDER_EPS = 2e-6  # radians: a few float32 ulps of pi; inside it acos/atan2 rounding (ocml here, sleef in the CPU reference) picks the grid
+
+
+def assert_matches_reference(model, rays, got, want_rgb, want_depth, kw):
+    """got = (rgb, depth, ...) of the HIP render of `rays`; want_* = the reference's.  Every ray must meet the tolerances,
+    except rays with a sample on a yin/yang region border (coordinates.py:478-481's inclusive comparisons on float32
+    acos/atan2 results): there the grid choice is libm-dependent and the two grids hold independent tables.  Those rays are
+    few, each must really have a sample within BORDER_EPS of a border, and (single-pass renders) the HIP result must equal
+    the oracle evaluated with the HIP's grid choice."""
+    e_rgb = (got[0].cpu() - torch.from_numpy(want_rgb)).abs().amax(1)
+    e_d = (got[1].cpu() - torch.from_numpy(want_depth)).abs()
+    bad = ((e_rgb > RGB_TOL) | (e_d > DEPTH_TOL)).nonzero().flatten()
+    if bad.numel() == 0:
+        return 0
+    assert bad.numel() <= max(2, rays.shape[0] // 200), f"{bad.numel()} rays off: not a border effect"
+    orc = model.oracle
+    with torch.no_grad():
+        _, inter = orc.forward(rays[bad].cpu(), keep=True, **{k: v for k, v in kw.items() if k not in ("exp_sampling", "device")})
+        pts = [inter["xyz_coarse"]] + ([inter["xyz_fine"]] if "xyz_fine" in inter else [])
+        margin = torch.stack([orc.yin_margin(p).abs().amin(1) for p in pts]).amin(0)
+        assert bool((margin < BORDER_EPS).all()), f"rays {bad.tolist()} are off without a border sample (margins {margin.tolist()})"
+        if not kw.get("resampling"):
+            r = rays[bad]
+            xyz, _, _ = model.sample_ray_exp(r[:, :3], r[:, 3:6], is_train=False, N_samples=kw["n_coarse"])
+            flags = model.coordinates.from_cartesian(xyz)[..., 6].cpu()
+            ref_flags = inter["c7n"][..., 6]
+            diff = flags != ref_flags
+            assert 0 < int(diff.sum()) <= 2 * bad.numel() and bool((orc.yin_margin(inter["xyz_coarse"])[diff].abs() < BORDER_EPS).all())
+            forced = orc.forward(r.cpu(), grid_choice=flags, **{k: v for k, v in kw.items() if k not in ("exp_sampling", "device")})
+            assert maxerr(got[0][bad], forced[0]) <= RGB_TOL and maxerr(got[1][bad], forced[1]) <= DEPTH_TOL
+    return int(bad.numel())
 
 
 @pytest.fixture(params=["f16x3", "f32"])
@@ -58,15 +93,18 @@ def test_config3_subset_vs_reference(ricoh, precision, k):
     fx, _, model = ricoh
     rays = T(fx[f"rays/{k}"])
     with torch.no_grad():
-        rgb, depth, bg, env, alpha = volume_renderer(rays, model, chunk=4096, **KW)
-    assert maxerr(rgb, fx[f"rs128/{k}/rgb"]) <= RGB_TOL
-    assert maxerr(depth, fx[f"rs128/{k}/depth"]) <= DEPTH_TOL
-    assert maxerr(bg, fx[f"rs128/{k}/bg"]) <= RGB_TOL and maxerr(env, fx[f"rs128/{k}/env"]) <= 1e-5
-    assert alpha.shape == (rays.shape[0], 257)
+        out = volume_renderer(rays, model, chunk=4096, **KW)
+    n_border = assert_matches_reference(model, rays, out, fx[f"rs128/{k}/rgb"], fx[f"rs128/{k}/depth"], KW)
+    assert maxerr(out[3], fx[f"rs128/{k}/env"]) <= 1e-5
+    if n_border == 0:
+        assert maxerr(out[2], fx[f"rs128/{k}/bg"]) <= RGB_TOL
+    assert out[4].shape == (rays.shape[0], 257)
+    kw = dict(n_coarse=512, exp_sampling=True, device=DEV)
     with torch.no_grad():
-        rgb, depth, bg, env, _ = volume_renderer(rays, model, chunk=4096, n_coarse=512, exp_sampling=True, device=DEV)
-    assert maxerr(rgb, fx[f"nr512/{k}/rgb"]) <= RGB_TOL and maxerr(depth, fx[f"nr512/{k}/depth"]) <= DEPTH_TOL
-    assert maxerr(bg, fx[f"nr512/{k}/bg"]) <= RGB_TOL
+        out = volume_renderer(rays, model, chunk=4096, **kw)
+    n_border = assert_matches_reference(model, rays, out, fx[f"nr512/{k}/rgb"], fx[f"nr512/{k}/depth"], kw)
+    if n_border == 0:
+        assert maxerr(out[2], fx[f"nr512/{k}/bg"]) <= RGB_TOL
 
 
 def test_config3_full_image(ricoh, precision):
@@ -83,7 +121,8 @@ def test_config3_full_image(ricoh, precision):
         assert bool(torch.isfinite(rgb).all()) and bool(torch.isfinite(depth).all())
         assert float(rgb.min()) >= 0.0 and float(rgb.max()) <= 1.0
         idx = T(fx["idx"])
-        assert maxerr(rgb[idx], fx[f"rs128/{k}/rgb"]) <= RGB_TOL and maxerr(depth[idx], fx[f"rs128/{k}/depth"]) <= DEPTH_TOL
+        assert maxerr(rays[idx], fx[f"rays/{k}"]) <= 1e-6
+        assert_matches_reference(model, T(fx[f"rays/{k}"]), (rgb[idx], depth[idx]), fx[f"rs128/{k}/rgb"], fx[f"rs128/{k}/depth"], KW)
         again = volume_renderer(rays, model, **kw)
         assert torch.equal(again[0], rgb) and torch.equal(again[1], depth)
         parts = []
@@ -95,11 +134,17 @@ def test_config3_full_image(ricoh, precision):
 
 @pytest.mark.parametrize("h", [1000, 1920])
 def test_envmap_radiance_at_shipped_sizes(golden, h):
-    """models/envmap.py:26-34 at h = 1000 / 1920 on a white-noise map (any index slip would show as an O(1) error)."""
+    """models/envmap.py:26-34 at h = 1000 / 1920 on a white-noise map: every texel is independent (range +-3 before the sigmoid),
+    so an index slip shows as an O(0.1 .. 1) error, while the float32 rounding of (u, v) itself (1 ulp = 6e-8 of the map =
+    1e-4 texel at 3840 texels, times a texel-to-texel step of up to 6, times sigmoid' <= 1/4) already moves values by ~2e-4
+    between two correct libms.  Hence: max error <= 2e-3, mean error <= 5e-5; the smooth-map goldens (env in ricoh.npz,
+    tiny_envmap.npz) hold to 1e-5."""
     from egonerf_amd.model import EnvironmentMap
     fx = golden("envmap_full")
     env = EnvironmentMap(h=4, init_strategy="zero", device=DEV)
     env.load_envmap(synth.white_envmap(int(fx["seed"]), h), device=DEV)
     with torch.no_grad():
         got = env.get_radiance(T(fx["dirs"]))
-    assert maxerr(got, fx[f"radiance/{h}"]) <= 1e-5
+    err = np.abs(got.cpu().numpy().astype(np.float64) - fx[f"radiance/{h}"])
+    assert err.max() <= 2e-3 and err.mean() <= 5e-5, (err.max(), err.mean())
+    assert err[:4].max() <= 1e-6   # +-z and +-x: (u, v) are exact binary fractions there, no rounding slack
