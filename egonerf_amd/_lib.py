@@ -37,8 +37,15 @@ class Scene(C.Structure):
         ("packed", C.c_void_p), ("envmap", C.c_void_p), ("envmap_h", C.c_int32), ("mlp_precision", C.c_int32),
         ("occ", C.c_void_p), ("occ_res", C.c_int32 * 3), ("term_eps", C.c_float),
         ("app16", VmField), ("app_f16", C.c_int32), ("n_r_lut_fine", C.c_int32), ("r_lut_fine", C.c_void_p), ("n_r_fine", C.c_int32),
-        ("reserved2", C.c_int32),
+        ("weight_thres", C.c_float),
     ]
+
+
+def new_scene() -> "Scene":
+    """A zero-initialised ego_scene with the opt-in fields that are not 'off' at zero set to off."""
+    sc = Scene()
+    sc.weight_thres = -1.0
+    return sc
 
 
 class RenderArgs(C.Structure):

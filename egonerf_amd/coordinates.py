@@ -207,7 +207,7 @@ class YinYangSphericalCoords:
             sc.r_lut_fine, sc.n_r_lut_fine, sc.n_r_fine = fine.data_ptr(), fine.numel(), fine.numel() - 1
 
     def _scene(self, device, downsample=2):
-        sc = _lib.Scene()
+        sc = _lib.new_scene()
         self.fill_scene(sc, device, downsample)
         return sc
 

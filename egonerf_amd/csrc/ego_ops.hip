@@ -215,7 +215,7 @@ __global__ __launch_bounds__(256) void k_march_density(DevCoords c, DevField F, 
                                                        int alpha_stride, float* __restrict__ weight,
                                                        float* __restrict__ bg, float* __restrict__ coords_out,
                                                        float* __restrict__ sigma_out, DevOcc occ, float term_eps,
-                                                       uint8_t* __restrict__ tile_active) {
+                                                       float shade_above, uint8_t* __restrict__ tile_active) {
   __shared__ float lut[1024];
   for (int i = threadIdx.x; i < c.n_lut; i += blockDim.x) lut[i] = c.r_lut[i];
   __syncthreads();
@@ -276,7 +276,8 @@ __global__ __launch_bounds__(256) void k_march_density(DevCoords c, DevField F, 
     const float wgt = (term_eps > 0.f && T < term_eps) ? 0.f : a * T;  // early termination (opt-in)
     if (tile_active) {
       // 32-sample shade tiles are cut from the flat [N*S] order: lanes 0-31 / 32-63 of this pass are (parts of) tiles
-      const unsigned long long nz = __ballot(ok && wgt != 0.f);
+      // a tile is shaded iff it holds a sample whose colour is read: weight > shade_above (0, or rayMarch_weight_thres)
+      const unsigned long long nz = __ballot(ok && wgt > shade_above);
       const int64_t o = ray * S + s;
       if (ok && (nz >> (lane & 32) & 0xffffffffull) != 0ull && ((lane & 31) == 0 || (o & 31) == 0)) tile_active[o >> 5] = 1;
     }
@@ -389,7 +390,7 @@ __global__ void k_composite(const float* __restrict__ em, int em_h, const float*
                             const float* __restrict__ z, const float* __restrict__ weight,
                             const float* __restrict__ bgw, const float* __restrict__ rgb, int64_t N, int S,
                             float* __restrict__ rgb_map, float* __restrict__ depth, float* __restrict__ bg_map,
-                            float* __restrict__ env_map, float* __restrict__ rgb_raw) {
+                            float* __restrict__ env_map, float* __restrict__ rgb_raw, float shade_above) {
   const int lane = threadIdx.x & 63;
   const int64_t ray = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (ray >= N) return;
@@ -397,12 +398,14 @@ __global__ void k_composite(const float* __restrict__ em, int em_h, const float*
   for (int s = lane; s < S; s += 64) {
     const int64_t o = ray * S + s;
     const float w = weight[o];
-    if (w != 0.f) {  // tiles skipped by ego_shade (mask / early termination) never wrote their rgb
-      acc += w;
+    acc += w;
+    dp += w * z[o];
+    // colour only from samples above the threshold (tensorBase.py:482-487; 0 without one: weights are >= 0, and tiles
+    // skipped by ego_shade — mask / early termination / all below the threshold — never wrote their rgb)
+    if (w > shade_above) {
       cr += w * rgb[o * 3];
       cg += w * rgb[o * 3 + 1];
       cb += w * rgb[o * 3 + 2];
-      dp += w * z[o];
     }
   }
   acc = wave_sum(acc); cr = wave_sum(cr); cg = wave_sum(cg); cb = wave_sum(cb); dp = wave_sum(dp);
@@ -722,7 +725,7 @@ int ego_march_density(const ego_scene* sc, const float* rays, int64_t N, int32_t
   k_march_density<16><<<nblk(N, 4), 256, 0, (hipStream_t)stream>>>(
       make_coords(*sc, (coarse & 2) != 0), make_field(f), rays, N, S, z_in, r_sched, jitter, near_, sc->act_softplus, sc->density_shift,
       sc->distance_scale, z_out, alpha, alpha_stride, weight, bg_weight, coords_out, sigma_out, make_occ(*sc, coarse & 1), sc->term_eps,
-      tile_active);
+      fmaxf(sc->weight_thres, 0.f), tile_active);
   return ego_launch_status("k_march_density");
 }
 
@@ -733,7 +736,7 @@ int ego_composite(const ego_scene* sc, const float* rays, const float* z, const 
   EGO_REQUIRE(!sc->envmap || bg_weight, "composite: envmap needs bg_weight");
   if (N == 0) return EGO_OK;
   k_composite<<<nblk(N, 4), 256, 0, (hipStream_t)stream>>>(sc->envmap, sc->envmap_h, rays, z, weight, bg_weight, rgb, N, S,
-                                                          rgb_map, depth, bg_map, env_map, rgb_raw);
+                                                          rgb_map, depth, bg_map, env_map, rgb_raw, fmaxf(sc->weight_thres, 0.f));
   return ego_launch_status("k_composite");
 }
 

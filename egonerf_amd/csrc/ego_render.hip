@@ -54,8 +54,8 @@ int ego_render_forward(const ego_scene* sc, const ego_render_args* a, const floa
   const int32_t astride = sc->envmap ? S + 1 : S;
   int e;
   const float* z;
-  // tile-level skipping only when a mask or early termination is switched on (otherwise no weight is exactly zero)
-  uint8_t* act = (sc->occ || sc->term_eps > 0.f) ? (uint8_t*)(ws + p.act) : nullptr;
+  // tile-level skipping only when a mask, early termination or the weight threshold is switched on (otherwise every sample is shaded)
+  uint8_t* act = (sc->occ || sc->term_eps > 0.f || sc->weight_thres >= 0.f) ? (uint8_t*)(ws + p.act) : nullptr;
   if (act) {
     const hipError_t me = hipMemsetAsync(act, 0, (size_t)(N * (int64_t)S / 32 + 1), (hipStream_t)stream);
     if (me != hipSuccess) return ego_fail((int)me, "render_forward: hipMemsetAsync failed: %s", hipGetErrorString(me));

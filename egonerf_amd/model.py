@@ -97,7 +97,7 @@ class EnvironmentMap:
             from .train import EnvRadianceFunction
             return EnvRadianceFunction.apply(self.emission, d)
         out = torch.empty(d.shape[0], 3, device=d.device)
-        sc = _lib.Scene()
+        sc = _lib.new_scene()
         em = self.emission.detach().contiguous()
         sc.envmap, sc.envmap_h = em.data_ptr(), em.shape[2]
         _call("ego_envmap_radiance", sc, d.data_ptr(), d.shape[0], out.data_ptr(), _lib.stream_handle())
@@ -219,7 +219,7 @@ class TensorBase(torch.nn.Module):
         _require_cuda(density_features, "feature2density")
         f = _f32c(density_features)
         out = torch.empty_like(f)
-        sc = _lib.Scene()
+        sc = _lib.new_scene()
         sc.act_softplus, sc.density_shift = int(self.fea2denseAct == "softplus"), float(self.density_shift)
         _call("ego_feature2density", sc, f.data_ptr(), f.numel(), out.data_ptr(), _lib.stream_handle())
         return out
@@ -255,7 +255,7 @@ class YinYangAlphaGridMask(torch.nn.Module):
         _last_dim(norm_samples, 7, "sample_alpha")
         c = _f32c(norm_samples)
         out = torch.empty(c.shape[:-1], device=c.device)
-        sc = _lib.Scene()
+        sc = _lib.new_scene()
         self.fill_scene(sc)
         _call("ego_alpha_mask_sample", sc, c.data_ptr(), c.numel() // 7, out.data_ptr(), _lib.stream_handle())
         return out
@@ -276,7 +276,8 @@ class EgoNeRF(TensorBase):
         self._mlp_precision = "f16x3"
         self._app_table_dtype = "f32"   # "f16": inference gathers appearance taps from a half-precision copy of the tables
         self._app16 = None              # (versions, [12 half tensors])
-        # opt-in skipping (EgoNeRF.forward itself evaluates every sample; see include/egonerf_hip.h):
+        # opt-in skipping (EgoNeRF.forward itself evaluates every sample; TensorBase.forward's semantics, tensorBase.py:464-487,
+        # pinned to the reference by tests/golden/skip_semantics.npz; see include/egonerf_hip.h):
         self.use_alpha_mask = False          # apply self.alphaMask with TensorBase.forward's semantics (sigma = 0 where empty)
         self.early_termination_eps = 0.0     # > 0: zero the weight of samples behind transmittance < eps
         self.use_weight_thres = False        # TensorBase.forward's app skip: samples with weight <= rayMarch_weight_thres get rgb = 0
@@ -486,7 +487,7 @@ class EgoNeRF(TensorBase):
         if self._scene_cache is not None and self._scene_cache[0] == keys and self._packed_versions == versions:
             return self._scene_cache[1]
         lib = _lib.load()
-        sc = _lib.Scene()
+        sc = _lib.new_scene()
         co.fill_scene(sc, dev)
         sc.act_softplus = int(self.fea2denseAct == "softplus")
         sc.density_shift, sc.distance_scale = float(self.density_shift), float(self.distance_scale)
@@ -515,6 +516,7 @@ class EgoNeRF(TensorBase):
         if self.use_alpha_mask and self.alphaMask is not None:
             self.alphaMask.fill_scene(sc)
         sc.term_eps = float(self.early_termination_eps)
+        sc.weight_thres = float(self.rayMarch_weight_thres) if self.use_weight_thres else -1.0
         if self.envmap is not None:
             em = self.envmap.emission.detach()
             if not em.is_contiguous():

@@ -93,9 +93,12 @@ class RenderFunction(torch.autograd.Function):
         ctx.set_materialize_grads(False)
         dev = rays.device
         sc = model.scene()
-        if sc.app_f16:  # training gathers from the fp32 parameters (the backward re-gathers from them)
+        if sc.app_f16 or sc.weight_thres >= 0:
+            # training gathers from the fp32 parameters (the backward re-gathers from them) and shades every sample, like
+            # EgoNeRF.forward (the appearance skip is an inference option)
             sc = _lib.Scene.from_buffer_copy(sc)
             sc.app_f16 = 0
+            sc.weight_thres = -1.0
         if sc.mlp_precision != 0:
             raise NotImplementedError("training uses the f16x3 matrix path (model.mlp_precision = 'f16x3')")
         N = rays.shape[0]
@@ -238,7 +241,7 @@ class EnvRadianceFunction(torch.autograd.Function):
     @_lib.device_guard
     def forward(ctx, emission, dirs):
         lib, st = _lib.load(), _lib.stream_handle()
-        sc = _lib.Scene()
+        sc = _lib.new_scene()
         sc.envmap, sc.envmap_h = emission.data_ptr(), emission.shape[2]
         out = torch.empty(dirs.shape[0], 3, device=dirs.device)
         _lib.check(lib.ego_envmap_radiance(sc, dirs.data_ptr(), dirs.shape[0], out.data_ptr(), st), "ego_envmap_radiance")
@@ -252,7 +255,7 @@ class EnvRadianceFunction(torch.autograd.Function):
         lib, st = _lib.load(), _lib.stream_handle()
         dirs, out = ctx.saved_tensors
         N = dirs.shape[0]
-        sc = _lib.Scene()
+        sc = _lib.new_scene()
         sc.envmap_h = ctx.shape[2]
         g_em = torch.zeros(ctx.shape, device=dirs.device)
         ones, inside = torch.ones(N, device=dirs.device), torch.zeros(N, 3, device=dirs.device)

@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define EGO_ABI_VERSION 6
+#define EGO_ABI_VERSION 7
 
 enum { EGO_PREC_F16X3 = 0, EGO_PREC_F32 = 1 };
 
@@ -115,7 +115,10 @@ typedef struct ego_scene {
   int32_t n_r_lut_fine;
   const float* r_lut_fine;
   int32_t n_r_fine;
-  int32_t reserved2;
+  /* Opt-in appearance skip of TensorBase.forward (models/tensorBase.py:482-487, `rayMarch_weight_thres`): < 0 = off (as in
+   * EgoNeRF.forward, which shades every sample); >= 0: a sample whose weight is <= weight_thres contributes colour 0 — its
+   * weight still counts in acc / depth — and 32-sample tiles without any sample above the threshold are not shaded. */
+  float weight_thres;
 } ego_scene;
 
 /* number of floats ego_pack_mlp writes: the packed weight blob used by ego_shade / ego_mlp_fea / ego_app_feature

@@ -480,6 +480,64 @@ def capture_ws():
     np.savez_compressed(os.path.join(OUT, "ws_metrics.npz"), **fx)
 
 
+def capture_skip():
+    """Skip semantics of TensorBase.forward (models/tensorBase.py:438-510), which is the only place the reference applies an
+    alpha mask and the rayMarch_weight_thres appearance skip — run through TensorVMSplit (models/tensoRF.py:127-284) with
+    CartesianCoords, an AlphaGridMask over a hashed {0,1} volume and a large threshold so that both branches bite.
+    Stored: the dense per-sample quantities the skip logic consumes (density feature, mask lookups, inside-aabb flags,
+    distances, per-sample colours) and what forward returns, for exp_sampling False/True.  The oracle's restatement of the
+    skip logic is checked against these; the HIP path is then compared with that restatement on the EgoNeRF field."""
+    from models.tensoRF import TensorVMSplit
+    from models.tensorBase import AlphaGridMask
+    from models.coordinates import CartesianCoords
+    torch.manual_seed(7)
+    aabb = torch.tensor([[-1.5, -1.5, -1.5], [1.5, 1.5, 1.5]])
+    grid = [16, 16, 16]
+    with contextlib.redirect_stdout(io.StringIO()):
+        coords = CartesianCoords("cpu", aabb)
+        coords.invgridSize = 1.0 / (aabb[1] - aabb[0])  # what train.py's dataset plumbing leaves on the object (coordinates.py:50)
+        model = TensorVMSplit(aabb, grid, "cpu", coords, density_n_comp=[4, 4, 4], appearance_n_comp=[8, 8, 8], app_dim=27,
+                              near_far=[0.05, 2.5], shadingMode="MLP_Fea", alphaMask_thres=1e-4, density_shift=-1.0,
+                              distance_scale=25, rayMarch_weight_thres=2e-2, pos_pe=6, view_pe=2, fea_pe=2, featureC=32,
+                              step_ratio=0.5, fea2denseAct="softplus")
+    with torch.no_grad():
+        for p in list(model.density_plane) + list(model.density_line):
+            p.mul_(8.0)  # enough density for rays to saturate
+        for p in list(model.app_plane) + list(model.app_line) + [model.basis_mat.weight] + [m.weight for m in model.renderModule.mlp if hasattr(m, "weight")]:
+            p.mul_(3.0)  # a colour range worth comparing
+    # blocky occupancy: a hashed 4^3 lattice blown up to 16^3 (a per-voxel random volume is "occupied" almost everywhere once
+    # it is looked up trilinearly)
+    coarse = (synth.hash_uniform(61, 0, 4 ** 3) > 0.45).astype(np.float32).reshape(4, 4, 4)
+    vol = torch.from_numpy(np.kron(coarse, np.ones((4, 4, 4), np.float32)))
+    model.alphaMask = AlphaGridMask("cpu", vol)
+    model.eval()
+    rays = torch.from_numpy(synth.make_rays(48, seed=23, origin_extent=0.4))
+    fx = dict(rays=rays.numpy(), weight_thres=np.float32(2e-2), distance_scale=np.float32(25), density_shift=np.float32(-1.0),
+              mask_volume=vol.numpy().astype(np.uint8))
+    for tag, exp in (("uni", False), ("exp", True)):
+        S = 40
+        with torch.no_grad():
+            sampler = model.sample_ray_exp if exp else model.sample_ray
+            xyz, z, ray_valid = sampler(rays[:, :3], rays[:, 3:6], is_train=False, N_samples=S)
+            if z.shape[0] == 1:
+                z = z.expand(rays.shape[0], S)
+            c = coords.normalize_coord(coords.from_cartesian(xyz))
+            flat = c.reshape(-1, 3)
+            mask_alpha = model.alphaMask.sample_alpha(flat).view(c.shape[:2])
+            sigma_feat = model.compute_densityfeature(flat).view(c.shape[:2])
+            vd = rays[:, 3:6].view(-1, 1, 3).expand(xyz.shape)
+            rgb_dense = model.renderModule(flat, vd.reshape(-1, 3), model.compute_appfeature(flat)).view(*c.shape[:2], 3)
+            out = model(rays, is_train=False, white_bg=False, ndc_ray=False, N_samples=S, exp_sampling=exp)
+            model.alphaMask, keep = None, model.alphaMask
+            out_nomask = model(rays, is_train=False, white_bg=False, ndc_ray=False, N_samples=S, exp_sampling=exp)
+            model.alphaMask = keep
+        fx.update({f"{tag}/z": np_(z), f"{tag}/ray_valid": np_(ray_valid), f"{tag}/mask_alpha": np_(mask_alpha),
+                   f"{tag}/sigma_feat": np_(sigma_feat), f"{tag}/rgb_dense": np_(rgb_dense),
+                   f"{tag}/rgb": np_(out[0]), f"{tag}/depth": np_(out[1]), f"{tag}/alpha": np_(out[4]),
+                   f"{tag}/nomask_rgb": np_(out_nomask[0]), f"{tag}/nomask_depth": np_(out_nomask[1]), f"{tag}/nomask_alpha": np_(out_nomask[4])})
+    np.savez_compressed(os.path.join(OUT, "skip_semantics.npz"), **fx)
+
+
 def capture_plainexp():
     """interval_th=False: the plain exponential r grid (coordinates.py:132-155, with the `downsample=2` the forward passes,
     EgoNeRF.py:524) and the matching sample schedule (EgoNeRF.py:59-67).  Eval mode."""
@@ -551,7 +609,7 @@ def capture_uniform():
 
 if __name__ == "__main__":
     torch.manual_seed(0)
-    which = sys.argv[1:] or ["tiny", "stages", "full", "alpha_mask", "checkpoint", "train_extras", "metrics", "plainexp", "sh", "uniform", "ricoh", "envmap_full", "ws"]
+    which = sys.argv[1:] or ["tiny", "stages", "full", "alpha_mask", "checkpoint", "train_extras", "metrics", "plainexp", "sh", "uniform", "ricoh", "envmap_full", "ws", "skip"]
     for name in which:
         globals()["capture_" + name]()
         print("captured", name)

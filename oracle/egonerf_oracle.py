@@ -72,9 +72,10 @@ class OracleScene:
         self.set_resolution(self.grid, r0=cfg.r0)
         self.coarse = None
         self.update_coarse_sigma_grid()
-        # opt-in skipping, mirrored from the product for parity tests (the reference's EgoNeRF.forward has neither):
+        # opt-in skipping (the reference's EgoNeRF.forward has none; TensorBase.forward, tensorBase.py:464-487, defines it):
         self.alpha_mask = None   # (vol_yin, vol_yang) float {0,1} volumes (1,1,N_phi,N_theta,N_r), TensorBase.forward semantics
         self.term_eps = 0.0      # early termination: weight := 0 where the incoming transmittance < term_eps
+        self.weight_thres = None  # TensorBase.forward's rayMarch_weight_thres appearance skip (None = off, as in EgoNeRF.forward)
 
     def set_resolution(self, resolution, r0=None):
         """coordinates.py:206-215.  Quirk kept: without an explicit r0 (as train.py:377 calls it after an upsample) the
@@ -391,18 +392,22 @@ class OracleScene:
 
         sf = self.density_feature(c7n)
         sigma = self.feature2density(sf)
-        if self.alpha_mask is not None:  # tensorBase.py:464-478: masked samples keep sigma = 0
-            sigma = torch.where(self.sample_alpha(c7n) > 0, sigma, torch.zeros_like(sigma))
-        alpha, weight, bg_w = self.raw2alpha(sigma, dists * c.distance_scale)
-        if self.term_eps > 0:
-            T = torch.cumprod(torch.cat([torch.ones_like(alpha[:, :1]), 1.0 - alpha + 1e-10], -1), -1)[:, :-1]
-            weight = torch.where(T < self.term_eps, torch.zeros_like(weight), weight)
         af = self.app_feature(c7n)
         vd = viewdirs.view(-1, 1, 3).expand(xyz.shape)
         rgb = self.mlp_fea(vd.reshape(-1, 3), af.reshape(-1, c.app_dim)).view(*xyz.shape[:2], 3)
-
+        # mask application + appearance skip with TensorBase.forward's semantics (pinned to the reference through
+        # tensorbase_skip_composite / tests/golden/skip_semantics.npz); both off = EgoNeRF.forward (EgoNeRF.py:579-598)
+        mask_alpha = self.sample_alpha(c7n) if self.alpha_mask is not None else None
+        rgb_map, depth, alpha, weight, bg_w, app_mask = tensorbase_skip_composite(sigma, mask_alpha, None, dists, z, rgb, rays[..., -1],
+                                                                           c.distance_scale, self.weight_thres)
+        if mask_alpha is not None:
+            sigma = torch.where(mask_alpha > 0, sigma, torch.zeros_like(sigma))
+        if self.term_eps > 0:  # product extension (no reference counterpart): weights behind transmittance < eps are dropped
+            T = torch.cumprod(torch.cat([torch.ones_like(alpha[:, :1]), 1.0 - alpha + 1e-10], -1), -1)[:, :-1]
+            weight = torch.where(T < self.term_eps, torch.zeros_like(weight), weight)
+            rgb_map = (weight[..., None] * torch.where(app_mask[..., None], rgb, torch.zeros_like(rgb))).sum(-2)
+            depth = (weight * z).sum(-1) + (1.0 - weight.sum(-1)) * rays[..., -1]
         acc = weight.sum(-1)
-        rgb_map = (weight[..., None] * rgb).sum(-2)
         bg_map = env_map = None
         if c.use_envmap:
             alpha = torch.cat([alpha, torch.ones_like(alpha[..., :1])], -1)
@@ -410,7 +415,7 @@ class OracleScene:
             bg_map = bg_w * env_map
             rgb_map = rgb_map + bg_map
         rgb_map = rgb_map.clamp(0, 1)
-        depth = ((weight * z).sum(-1) + (1.0 - acc) * rays[..., -1]).detach()  # EgoNeRF.py:595-598 (no_grad; d_z quirk)
+        depth = depth.detach()  # EgoNeRF.py:595-598 (no_grad; d_z quirk)
         if keep:
             inter.update(sigma_feat=sf, sigma=sigma, weight=weight, bg_weight=bg_w, app_feat=af,
                          rgb_samples=rgb, z=z, acc=acc)
@@ -484,6 +489,31 @@ def ray_entropy_loss(alpha: torch.Tensor) -> torch.Tensor:
     """utils.py:175-183."""
     p = alpha / (alpha.sum(-1, keepdim=True) + 1e-10)
     return (-(p * torch.log2(p + 1e-10)).sum(-1)).mean()
+
+
+def tensorbase_skip_composite(sigma_dense: torch.Tensor, mask_alpha: Optional[torch.Tensor], ray_valid: Optional[torch.Tensor],
+                              dists: torch.Tensor, z: torch.Tensor, rgb_dense: torch.Tensor, rays_last: torch.Tensor,
+                              distance_scale: float, weight_thres: Optional[float]):
+    """The skip logic of TensorBase.forward (models/tensorBase.py:464-507), on dense per-sample inputs:
+      * :464-469  a sample is kept iff it is inside the aabb (`ray_valid`) and its alpha-mask lookup is > 0;
+      * :471-478  sigma = 0 for every other sample (its density is never evaluated);
+      * :480      alpha / weight / bg_weight = raw2alpha(sigma, dists * distance_scale);
+      * :482-487  colour = 0 for samples with weight <= rayMarch_weight_thres (appearance + MLP never evaluated);
+      * :489-490,503-507  acc = sum w, rgb = sum w c, depth = sum w z + (1 - acc) * rays[..., -1]   (weights are NOT zeroed).
+    sigma_dense [N,S] = feature2density of every sample; mask_alpha [N,S] or None (no mask); ray_valid [N,S] bool or None
+    (EgoNeRF.forward ignores the aabb flags, EgoNeRF.py:85); weight_thres None = no appearance skip.
+    -> (rgb_map before the background / clamp, depth, alpha, weight, bg_weight, app_mask)."""
+    keep = torch.ones_like(sigma_dense, dtype=torch.bool) if ray_valid is None else ray_valid.clone()
+    if mask_alpha is not None:
+        keep &= mask_alpha > 0
+    sigma = torch.where(keep, sigma_dense, torch.zeros_like(sigma_dense))
+    alpha, weight, bg_w = OracleScene.raw2alpha(sigma, dists * distance_scale)
+    app_mask = torch.ones_like(keep) if weight_thres is None else weight > weight_thres
+    rgb = torch.where(app_mask[..., None], rgb_dense, torch.zeros_like(rgb_dense))
+    acc = weight.sum(-1)
+    rgb_map = (weight[..., None] * rgb).sum(-2)
+    depth = (weight * z).sum(-1) + (1.0 - acc) * rays_last
+    return rgb_map, depth, alpha, weight, bg_w, app_mask
 
 
 def erp_rays_reference(H: int, W: int, c2w: torch.Tensor, normalize: bool = True) -> torch.Tensor:

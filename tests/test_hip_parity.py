@@ -46,7 +46,7 @@ def precision(request, tiny, full):
 
 def test_native_library_is_the_path(tiny):
     from egonerf_amd import _lib
-    assert _lib.load().ego_abi_version() == 6
+    assert _lib.load().ego_abi_version() == 7
     with pytest.raises(RuntimeError):  # CPU tensors never silently fall back
         tiny[3](torch.zeros(4, 6), n_coarse=8, exp_sampling=True)
 
@@ -307,9 +307,58 @@ def test_alpha_mask_matches_reference(golden, tiny):
     model._scene_cache = None
 
 
+def test_skip_semantics_on_reference_mask(golden, tiny):
+    """Row M end to end: the mask volumes the REFERENCE built (tests/golden/alpha_mask.npz: its updateAlphaMask on this scene)
+    + rayMarch_weight_thres, applied by the HIP path and by the oracle, whose skip logic is pinned to the reference's
+    TensorBase.forward (tests/test_oracle_golden.py::test_skip_semantics_vs_tensorbase_forward)."""
+    from egonerf_amd.model import YinYangAlphaGridMask
+    fx = golden("alpha_mask")
+    _, cfg, w, model = tiny
+    oracle = make_oracle(cfg, w)
+    rays = torch.from_numpy(synth.make_rays(300, seed=31))
+    vols = [fx["vol_yin"].astype(np.float32), fx["vol_yang"].astype(np.float32)]
+    # the reference's mask of this smooth synthetic field is almost full; carve two radial shells and a wedge out of it so
+    # the mask really removes samples (still {0,1} volumes (1,1,N_phi,N_theta,N_r) as the reference stores them)
+    for v in vols:
+        v[..., 3:5] = 0
+        v[0, 0, :8, :, 6:] = 0
+    try:
+        model.alphaMask = YinYangAlphaGridMask(DEV, T(vols[0]), T(vols[1]))
+        oracle.alpha_mask = (torch.from_numpy(vols[0]), torch.from_numpy(vols[1]))
+        for thres, kw in ((1e-4, dict(n_coarse=64)), (2e-2, dict(n_coarse=64)), (2e-2, dict(n_coarse=32, n_fine=32, resampling=True)),
+                          (5e-2, dict(n_coarse=40))):
+            model.use_alpha_mask, model.use_weight_thres, model.rayMarch_weight_thres = True, True, thres
+            oracle.weight_thres = thres
+            with torch.no_grad():
+                got = model(rays.to(DEV), exp_sampling=True, **kw)
+            ref, inter = oracle.forward(rays, keep=True, **kw)
+            # a weight within rounding of the threshold flips between two fp32 evaluations and moves a colour by up to
+            # `thres`: rays holding such a sample are compared for depth / alpha only
+            ok = ~((inter["weight"] - thres).abs() < 2e-6).any(-1)
+            assert int(ok.sum()) >= 290
+            assert maxerr(got[0][ok.to(DEV)], ref[0][ok]) <= RGB_TOL and maxerr(got[1], ref[1]) <= 1e-3 * 15.0
+            if not kw.get("resampling"):
+                assert maxerr(got[4], ref[4]) <= 2e-5
+                skipped = ((inter["weight"] <= thres) & (inter["weight"] > 0)).float().mean()
+                assert float(skipped) > 0.02
+        # the options change the image (they are not no-ops) ...
+        model.use_alpha_mask = model.use_weight_thres = False
+        oracle.alpha_mask, oracle.weight_thres = None, None
+        with torch.no_grad():
+            unskipped = model(rays.to(DEV), exp_sampling=True, n_coarse=40)
+        assert maxerr(unskipped[0], oracle.forward(rays, n_coarse=40)[0]) <= RGB_TOL
+        assert maxerr(unskipped[0], got[0]) > 1e-2
+    finally:
+        model.use_alpha_mask = model.use_weight_thres = False
+        model.rayMarch_weight_thres = 1e-4
+        model.alphaMask = None
+        model._scene_cache = None
+
+
 def test_masked_and_terminated_render_vs_oracle(full):
-    """Opt-in skipping on the full-size grid: same mask + early termination in the oracle; plus the error bound of
-    early termination against the unskipped render (|d rgb| <= eps)."""
+    """Opt-in skipping on the full-size grid: mask (built here, construction pinned by test_alpha_mask_matches_reference) +
+    early termination + the reference's default weight threshold in HIP and oracle; plus the error bound of early
+    termination against the unskipped render (|d rgb| <= eps)."""
     _, cfg, w, model = full
     oracle = make_oracle(cfg, w)
     rays = torch.from_numpy(synth.make_rays(96, seed=13))

@@ -278,3 +278,30 @@ def test_ws_weights_and_weighted_ssim_vs_reference(golden):
     num = sum(np.cos((i + 0.5 - H / 2) * np.pi / H) * ((a[i] - b[i]) ** 2).sum() for i in range(H))
     den = sum(np.cos((i + 0.5 - H / 2) * np.pi / H) for i in range(H)) * a.shape[1] * 3
     assert abs(ws_psnr(mx["img1"], mx["img0"]) - 10 * np.log10(den / num)) <= 1e-10
+
+
+@pytest.mark.parametrize("tag", ["uni", "exp"])
+def test_skip_semantics_vs_tensorbase_forward(golden, tag):
+    """Row M: the oracle's restatement of TensorBase.forward's mask application + rayMarch_weight_thres appearance skip
+    (tensorBase.py:464-507) against the reference's own forward run through TensorVMSplit with an AlphaGridMask
+    (tests/golden/skip_semantics.npz), with and without the mask."""
+    import torch.nn.functional as F
+    from oracle.egonerf_oracle import tensorbase_skip_composite
+    fx = golden("skip_semantics")
+    z = T(fx[f"{tag}/z"])
+    dists = torch.cat([z[:, 1:] - z[:, :-1], z[:, -1:] - z[:, -2:-1]], -1)
+    sigma = F.softplus(T(fx[f"{tag}/sigma_feat"]) + float(fx["density_shift"]))
+    rays = T(fx["rays"])
+    valid, mask_alpha = T(fx[f"{tag}/ray_valid"]), T(fx[f"{tag}/mask_alpha"])
+    assert 0.05 < float((valid & (mask_alpha <= 0)).float().mean()) < 0.5          # the mask really removes samples
+    for pre, ma in (("", mask_alpha), ("nomask_", None)):
+        rgb, depth, alpha, w, _, app = tensorbase_skip_composite(sigma, ma, valid, dists, z, T(fx[f"{tag}/rgb_dense"]), rays[:, -1],
+                                                                 float(fx["distance_scale"]), float(fx["weight_thres"]))
+        close(rgb.clamp(0, 1), fx[f"{tag}/{pre}rgb"], 1e-6)
+        close(depth, fx[f"{tag}/{pre}depth"], 2e-6)
+        close(alpha, fx[f"{tag}/{pre}alpha"], 1e-6)
+        assert 0.02 < float(((w > 0) & ~app).float().mean())                      # ... and so does the weight threshold
+    # the threshold matters: without it the colours move by more than the parity tolerance
+    rgb_all, *_ = tensorbase_skip_composite(sigma, mask_alpha, valid, dists, z, T(fx[f"{tag}/rgb_dense"]), rays[:, -1],
+                                            float(fx["distance_scale"]), None)
+    assert float((rgb_all.clamp(0, 1) - T(fx[f"{tag}/rgb"])).abs().max()) > 1e-3
