@@ -33,6 +33,21 @@ def _layout(which: int, n: int, device) -> torch.Tensor:
 
 _INDEX_CACHE = {}
 
+# The two table scatters (VALU / atomic bound) run on a side stream next to the shade backward and the weight-gradient passes
+# (HBM bound).  Every buffer the side stream reads stays referenced until the main stream has waited for it: a tensor freed
+# earlier goes back to the main stream's allocator pool and the next main-stream allocation may overwrite it while the side
+# stream still reads (the intermittent wrong appearance gradient of the first attempt).  EGO_TRAIN_SIDE_STREAM=0
+# serialises everything on one stream.
+SIDE_STREAM_SCATTER = __import__("os").environ.get("EGO_TRAIN_SIDE_STREAM", "1") != "0"
+_SIDE_STREAMS = {}
+
+
+def _side_stream(device) -> "torch.cuda.Stream":
+    key = torch.device(device).index
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+    return _SIDE_STREAMS[key]
+
 
 def _grad_indices(device):
     """Index tensors that un-permute the lane-order columns of the weight-gradient products, derived once from the layouts
@@ -177,8 +192,20 @@ class RenderFunction(torch.autograd.Function):
                                           sv["sigma"].data_ptr(), sv["bg"].data_ptr(), sv["rgb"].data_ptr(), g_rgb.data_ptr(),
                                           _lib.ptr(g_alpha), sv["raw"].data_ptr(), _lib.ptr(sv["env"]), N, S, dc.data_ptr(),
                                           dfeat.data_ptr(), st), "ego_march_backward")
+        main = torch.cuda.current_stream(dev)
+        side = _side_stream(dev) if SIDE_STREAM_SCATTER else None
         gd = _grad_struct(g_dens)
-        _lib.check(lib.ego_scatter_density(sc, C.byref(gd), sv["coords"].data_ptr(), dfeat.data_ptr(), N, S, st), "ego_scatter_density")
+
+        def on_side(fn):
+            """Run fn(stream handle) on the side stream once everything queued on the main stream so far has finished."""
+            if side is None:
+                return fn(st)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                fn(_lib.stream_handle())
+
+        on_side(lambda s_: _lib.check(lib.ego_scatter_density(sc, C.byref(gd), sv["coords"].data_ptr(), dfeat.data_ptr(), N, S, s_),
+                                      "ego_scatter_density"))
         tp = f(lib.ego_train_packed_floats())
         _lib.check(lib.ego_pack_train(sc, tp.data_ptr(), st), "ego_pack_train")
         Mp = (M + 31) // 32 * 32
@@ -187,8 +214,9 @@ class RenderFunction(torch.autograd.Function):
         _lib.check(lib.ego_shade_backward(sc, tp.data_ptr(), sv["coords"].data_ptr(), dc.data_ptr(), sv["rgb"].data_ptr(), C.byref(ds),
                                           dh2.data_ptr(), dh1.data_ptr(), dfe.data_ptr(), dv.data_ptr(), N, S, st), "ego_shade_backward")
         ga = _grad_struct(g_app)
-        _lib.check(lib.ego_scatter_app(sc, C.byref(ga), sv["coords"].data_ptr(), dv.data_ptr(), N, S, st), "ego_scatter_app")
-        del dv
+        on_side(lambda s_: _lib.check(lib.ego_scatter_app(sc, C.byref(ga), sv["coords"].data_ptr(), dv.data_ptr(), N, S, s_), "ego_scatter_app"))
+        if side is None:
+            del dv
         # ---- weight gradients: one pass of ego_weight_grad (bf16 hi/lo MFMA over transposed LDS tiles, bias gradients from a
         # ones column) per layer over the dumped buffers, then un-permute the lane-order columns ----
         do = dc.view(M, 3)  # now d(pre-sigmoid)
@@ -230,6 +258,8 @@ class RenderFunction(torch.autograd.Function):
             _lib.check(lib.ego_envmap_backward(sc, rays.data_ptr() + 12, 6, g_rgb.data_ptr(), sv["raw"].data_ptr(), sv["bg"].data_ptr(),
                                                sv["env"].data_ptr(), N, g_em.data_ptr(), st), "ego_envmap_backward")
             grads.append(g_em)
+        if side is not None:
+            main.wait_stream(side)  # the table gradients are complete; dv / dfeat / coords may be released from here on
         ctx.saved = None
         return (None, None, None, *grads)
 

@@ -18,11 +18,13 @@ def test_oracle_plain_exponential_grid(golden):
     fx = golden("tiny_plainexp")
     cfg = _cfg()
     sc = make_oracle(cfg, synth.make_weights(cfg, seed=int(fx["seed_weights"])))
+    # this schedule goes through torch.pow and a matmul prefix sum (EgoNeRF.py:59-67): ATen's CPU kernels differ in the last
+    # bit between CPU generations (AVX2 / AVX-512 paths), so it is compared to 1 ulp, not bit for bit
     for S in (16, 24, 64):
-        assert np.array_equal((cfg.near + sc.sample_schedule(S)).numpy(), fx[f"sched/{S}"])
+        assert np.allclose((cfg.near + sc.sample_schedule(S)).numpy(), fx[f"sched/{S}"], rtol=2.4e-7, atol=0)
     r = T(fx["normr/r"])
-    assert np.array_equal(sc.normalize_r(r).numpy(), fx["normr/out"])
-    assert np.array_equal(sc.normalize_r(r, 2).numpy(), fx["normr/out_ds2"])
+    assert np.allclose(sc.normalize_r(r).numpy(), fx["normr/out"], rtol=0, atol=2.4e-7, equal_nan=True)
+    assert np.allclose(sc.normalize_r(r, 2).numpy(), fx["normr/out_ds2"], rtol=0, atol=2.4e-7, equal_nan=True)
     rgb, depth, _, _, alpha = sc.forward(T(fx["rays"]), n_coarse=24)
     assert float((rgb - T(fx["nr_rgb"])).abs().max()) <= 1e-6 and float((alpha - T(fx["nr_alpha"])).abs().max()) <= 1e-6
     rgb, depth, *_ = sc.forward(T(fx["rays"]), n_coarse=16, n_fine=16, resampling=True)
@@ -36,13 +38,13 @@ def test_oracle_plain_exponential_grid(golden):
 
 
 def test_host_schedule_and_lut_reproduce_the_reference(golden):
-    """The product's host-built schedule is bit-exact; its LUT + searchsorted/lerp rule (numpy restatement of the kernel's
+    """The product's host-built schedule matches to 1 ulp; its LUT + searchsorted/lerp rule (numpy restatement of the kernel's
     normalize_r) reproduces the reference's log-based cell search."""
     fx = golden("tiny_plainexp")
     cfg = _cfg()
     c = make_coords(cfg, "cpu")
-    for S in (16, 24, 64):
-        assert np.array_equal((cfg.near + c.sample_schedule(cfg.near, cfg.far, S)).numpy(), fx[f"sched/{S}"])
+    for S in (16, 24, 64):  # torch.pow + matmul on the host: 1 ulp across CPU generations (see above)
+        assert np.allclose((cfg.near + c.sample_schedule(cfg.near, cfg.far, S)).numpy(), fx[f"sched/{S}"], rtol=2.4e-7, atol=0)
     r = fx["normr/r"]
     for ds, key in ((None, "normr/out"), (2, "normr/out_ds2")):
         G = c.reference_r_grid(ds).numpy()
