@@ -219,7 +219,7 @@ def cpu_baseline_single(cfg, weights, n_rays):
 # =====================================================================================================
 # roofline inputs from the committed PMC passes
 # =====================================================================================================
-def load_pmc(kname: str):
+def load_pmc(kname: str, need: str = "SQ_INSTS_MFMA_per_SE"):
     """Per-launch counter means of `kname` from the newest profiles/r*/pmc_traffic.json (rocprofv3 --pmc passes of bench.py's
     own step, tools/profile_gpu.sh + tools/pmc_traffic.py).  bench.py cannot collect PMC counters live; `stale` says whether
     the library sources changed since that profile was taken."""
@@ -229,7 +229,7 @@ def load_pmc(kname: str):
             pmc = json.load(open(path))
         except (OSError, ValueError):
             continue
-        if kname in pmc and "SQ_INSTS_MFMA_per_SE" in pmc[kname]:
+        if kname in pmc and need in pmc[kname]:
             return pmc[kname], os.path.relpath(path, REPO), pmc.get("_source_hash") != source_hash()
     return None, None, None
 
@@ -316,9 +316,17 @@ def run_render(a, rk: Ranks):
     t_march, t_shade, t_comp = (float(x) * 1e-3 for x in ms)
     roofline = shade_roofline(model.mlp_precision, t_shade, M)
     march_gbps = (B_DENSITY + 28) * M / t_march / 1e9
+    march = dict(hbm_algorithmic_GBps=march_gbps, frac_of_hbm_peak=march_gbps / HBM_PEAK_GBPS,
+                 note="cache-resident like the shade gather (24.7 MB of density tables); the binding resource is VALU issue")
+    mp, msrc, mstale = load_pmc("k_march_density<16>", need="SQ_INSTS_VALU_per_SE")
+    if mp is not None and "duration_us" in mp:
+        clk = mp["GRBM_GUI_ACTIVE"] / (mp["duration_us"] * 1e3)
+        valu = mp["SQ_INSTS_VALU_per_SE"] * 32
+        bound_ms = valu * CLK_PER_VALU / N_SIMD / (clk * 1e6)
+        march["issue"] = dict(source=msrc, stale_vs_current_sources=mstale, valu_insts_per_launch=valu, valu_per_64_samples=valu / (M / 64),
+                              effective_clock_GHz=clk, bound_ms=bound_ms, frac=bound_ms / (t_march * 1e3))
     roofline.update(other_kernels_ms=dict(k_march_density=t_march * 1e3, k_composite=t_comp * 1e3),
-                    march_density=dict(hbm_algorithmic_GBps=march_gbps, frac_of_hbm_peak=march_gbps / HBM_PEAK_GBPS,
-                                       note="cache-resident like the shade gather (24.7 MB of density tables)"),
+                    march_density=march,
                     path_algorithmic_GBps=(B_DENSITY + B_APP) * M / (t_march + t_shade + t_comp) / 1e9)
 
     cpu = cpu_single = parity = None

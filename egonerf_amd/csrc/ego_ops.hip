@@ -110,9 +110,12 @@ __device__ __forceinline__ float density_team16(const DevField& F, int g, float 
     const int W = F.res[vm_plane_x(i)];
     const float* P = (g ? F.plane[1][i] : F.plane[0][i]) + 4 * p;
     const float* L = (g ? F.line[1][i] : F.line[0][i]) + 4 * p;
-    const f32x4 t00 = *(const f32x4*)(P + ((int64_t)Y.i0 * W + X.i0) * C), t01 = *(const f32x4*)(P + ((int64_t)Y.i0 * W + X.i1) * C);
-    const f32x4 t10 = *(const f32x4*)(P + ((int64_t)Y.i1 * W + X.i0) * C), t11 = *(const f32x4*)(P + ((int64_t)Y.i1 * W + X.i1) * C);
-    const f32x4 u0 = *(const f32x4*)(L + (int64_t)Ln.i0 * C), u1 = *(const f32x4*)(L + (int64_t)Ln.i1 * C);
+    // unsigned 32-bit element offsets (a table holds < 2^31 floats): zero-extension into the address is free, a 64-bit
+    // multiply-add per tap (v_mad_i64_i32, quarter rate) is not
+    const uint32_t r0 = (uint32_t)(Y.i0 * W) * C, r1 = (uint32_t)(Y.i1 * W) * C, c0 = (uint32_t)X.i0 * C, c1 = (uint32_t)X.i1 * C;
+    const f32x4 t00 = *(const f32x4*)(P + (r0 + c0)), t01 = *(const f32x4*)(P + (r0 + c1));
+    const f32x4 t10 = *(const f32x4*)(P + (r1 + c0)), t11 = *(const f32x4*)(P + (r1 + c1));
+    const f32x4 u0 = *(const f32x4*)(L + (uint32_t)Ln.i0 * C), u1 = *(const f32x4*)(L + (uint32_t)Ln.i1 * C);
     const float w00 = __fmul_rn(Y.w0, X.w0), w01 = __fmul_rn(Y.w0, X.w1);
     const float w10 = __fmul_rn(Y.w1, X.w0), w11 = __fmul_rn(Y.w1, X.w1);
     const f32x4 pv = t00 * w00 + t01 * w01 + t10 * w10 + t11 * w11;

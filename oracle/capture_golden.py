@@ -538,6 +538,43 @@ def capture_skip():
     np.savez_compressed(os.path.join(OUT, "skip_semantics.npz"), **fx)
 
 
+def capture_omniblender():
+    """dataLoader/dataset_omniblender.py:11-95 on a three-frame synthetic dataset (transform.json + split lists + 8 x 4 PNGs written
+    to a temp dir; downsample 250 -> img_wh (8, 4)): poses, centre, scene_bbox, radius, all_rays (both is_stack settings), all_rgbs.
+    The fixture keeps the frame matrices / file names / pixels so the test can rebuild the same directory."""
+    import json, tempfile
+    from PIL import Image
+    _tv.transforms.ToTensor = lambda: (lambda img: torch.from_numpy(np.asarray(img)).permute(2, 0, 1).float().div(255.0))
+    import tqdm as _tqdm
+    from dataLoader.dataset_omniblender import OmniBlenderDataset
+    from scipy.spatial.transform import Rotation
+    frames, pix = [], {}
+    for k in range(3):
+        M = np.eye(4)
+        M[:3, :3] = Rotation.from_rotvec(np.array([0.2 * k, 0.5 - 0.3 * k, 0.1 + 0.4 * k])).as_matrix()
+        M[:3, 3] = [0.3 * np.cos(2.0 * k), 0.05 * k, 0.3 * np.sin(2.0 * k)]
+        frames.append(dict(file_path=f"{k:04d}.png", transform_matrix=M.tolist()))
+        pix[f"{k:04d}"] = (synth.hash_uniform(71 + k, 0, 4 * 8 * 4).reshape(4, 8, 4) * 255).astype(np.uint8)   # RGBA
+    fx = dict(frames_json=np.array(json.dumps(dict(indoor=True, frames=frames))), train_list=np.array("0000\n0002\n"), test_list=np.array("0001\n"))
+    with tempfile.TemporaryDirectory() as d:
+        os.makedirs(os.path.join(d, "images"))
+        json.dump(dict(indoor=True, frames=frames), open(os.path.join(d, "transform.json"), "w"))
+        open(os.path.join(d, "train.txt"), "w").write("0000\n0002\n")
+        open(os.path.join(d, "test.txt"), "w").write("0001\n")
+        for name, a in pix.items():
+            Image.fromarray(a, "RGBA").save(os.path.join(d, "images", name + ".png"))
+            fx["png/" + name] = a
+        with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
+            for split, stack in (("train", False), ("test", True)):
+                ds = OmniBlenderDataset(data_dir=d, split=split, near_far=[0.01, 15.0], downsample=250.0, is_stack=stack)
+                fx.update({f"{split}/poses": np_(ds.poses), f"{split}/center": np_(ds.center), f"{split}/scene_bbox": np_(ds.scene_bbox),
+                           f"{split}/radius": np_(ds.radius), f"{split}/all_rays": np_(ds.all_rays), f"{split}/all_rgbs": np_(ds.all_rgbs),
+                           f"{split}/img_wh": np.array(ds.img_wh)})
+            ds = OmniBlenderDataset(data_dir=d, split="train", near_far=[0.01, 15.0], downsample=250.0, roi=[0.25, 1.0, 0.0, 0.5])
+            fx["roi/all_rays"] = np_(ds.all_rays)
+    np.savez_compressed(os.path.join(OUT, "omniblender.npz"), **fx)
+
+
 def capture_plainexp():
     """interval_th=False: the plain exponential r grid (coordinates.py:132-155, with the `downsample=2` the forward passes,
     EgoNeRF.py:524) and the matching sample schedule (EgoNeRF.py:59-67).  Eval mode."""
@@ -609,7 +646,7 @@ def capture_uniform():
 
 if __name__ == "__main__":
     torch.manual_seed(0)
-    which = sys.argv[1:] or ["tiny", "stages", "full", "alpha_mask", "checkpoint", "train_extras", "metrics", "plainexp", "sh", "uniform", "ricoh", "envmap_full", "ws", "skip"]
+    which = sys.argv[1:] or ["tiny", "stages", "full", "alpha_mask", "checkpoint", "train_extras", "metrics", "plainexp", "sh", "uniform", "ricoh", "envmap_full", "ws", "skip", "omniblender"]
     for name in which:
         globals()["capture_" + name]()
         print("captured", name)
