@@ -141,6 +141,7 @@ __global__ void k_pack_mlp(const float* __restrict__ w1, const float* __restrict
 // one ds_read_b128 / global_load_dwordx4 per (step, tile, term) per lane, conflict-free.  A lane's 8 k of a step
 // are its values 8*step .. 8*step+7 in the same per-half K order as the fp32 layout.
 constexpr int KH1 = KS1 / 8, KH2 = KS2 / 8, KHB = KS_BASIS / 8;
+constexpr int BASIS16_FLOATS_C = 2 * KHB * 2 * 64 * 4;  // third blob region (basis fragments for the fp16-table gather)
 
 __device__ inline void split_weight(float w, _Float16& hi, _Float16& lo) {
   hi = (_Float16)w;
@@ -215,6 +216,69 @@ __global__ void k_pack_basis16(const float* __restrict__ basis_yin, const float*
   typedef _Float16 h2v __attribute__((ext_vector_type(2)));
   h2v v = {pr[0], pr[1]};
   out[idx] = __builtin_bit_cast(float, v);
+}
+
+// ---- fp16 main term + fp8 correction terms ("f16f8") weight layout ----------------------------------------------------
+// w*x = w_hi*x_hi (one v_mfma_f32_32x32x16_f16 per k-step, as in f16x3) + [w_lo*x_hi + w_hi*x_lo] on the block-scaled fp8 path:
+// ONE v_mfma_scale_f32_32x32x64_f8f6f4 per PAIR of k-steps carries both correction terms (K = 64 = 2 terms x 2 steps x 8 values
+// x 2 lane halves), at ~1.9x the matrix-pipe time of one fp16 instruction instead of 4x.  The corrections are ~2^-11 of the main
+// term, so e4m3's 4 significant bits leave ~2^-16 relative error per product (measured: DESIGN.md 4.1, profiles/r02/precision_sweep.json).
+// Operand bytes of a lane (row i = lane & 31 of m-tile mt, half h = lane >> 5; probed layout: byte b = k offset b of the lane's
+// 32-wide K block, tools/fp8_layout_probe.hip):
+//   A: [0..7] e4m3(w_lo * 2^11) step 2p | [8..15] same, step 2p+1 | [16..23] e4m3(w_hi) step 2p | [24..31] e4m3(w_hi) step 2p+1
+//   B: [0..7] e4m3(x)           step 2p | [8..15] same, step 2p+1 | [16..23] e4m3(x_lo * 2^11) step 2p | [24..31] ..., step 2p+1
+// and the instruction's E8M0 block scale of A is 2^-11 (exponent byte 116), of B 2^0 (127).
+// Region layout (32-bit slots, same OFF_W1 / OFF_W2 extents as the other layouts, so the LDS image keeps its size):
+//   per layer: hi fragments [step][m-tile][lane][8 halves], then fp8 fragments [pair][m-tile][part 0|1][lane][16 bytes]
+constexpr int F8_HI1 = KH1 * 4 * 64 * 4;          // 32-bit slots of layer 1's hi part (10240)
+constexpr int F8_HI2 = KH2 * 4 * 64 * 4;          // layer 2 (8192)
+constexpr int F8_FLOATS = OFF_B1;                 // W1 + W2 regions only; biases / W3 come from the f16x3 blob
+
+__device__ inline uint32_t e4m3_byte(float v) {
+  return (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(v, 0.f, 0, false) & 0xffu;
+}
+
+__global__ void k_pack_mlp_f8(const float* __restrict__ w1, const float* __restrict__ w2, float* __restrict__ out) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;  // one 32-bit slot
+  if (idx >= F8_FLOATS) return;
+  const bool l2 = idx >= OFF_W2;
+  const int e0 = l2 ? idx - OFF_W2 : idx;
+  const int hi_slots = l2 ? F8_HI2 : F8_HI1;
+  auto weight = [&](int step, int e, int lane, int mt) -> float {
+    if (!l2) {
+      const int ch = x_channel(step * 8 + e, lane >> 5);
+      return ch >= 0 ? w1[(mt * 32 + (lane & 31)) * MLP_IN + ch] : 0.f;
+    }
+    const int kk = step * 8 + e;
+    return w2[(mt * 32 + (lane & 31)) * HID + (kk >> 4) * 32 + slot_row(kk & 15, lane >> 5)];
+  };
+  uint32_t word = 0;
+  if (e0 < hi_slots) {  // [step][mt][lane][8 halves]
+    _Float16 pr[2];
+    for (int p = 0; p < 2; ++p) {
+      const int hidx = e0 * 2 + p;
+      const int e = hidx & 7, lane = (hidx >> 3) & 63, mt = (hidx >> 9) & 3, step = hidx >> 11;
+      _Float16 hi, lo;
+      split_weight(weight(step, e, lane, mt), hi, lo);
+      pr[p] = hi;
+    }
+    typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+    h2v v = {pr[0], pr[1]};
+    word = __builtin_bit_cast(uint32_t, v);
+  } else {  // [pair][mt][part][lane][16 bytes]
+    for (int b = 0; b < 4; ++b) {
+      const int bidx = (e0 - hi_slots) * 4 + b;
+      const int byte = bidx & 15, lane = (bidx >> 4) & 63, part = (bidx >> 10) & 1, mt = (bidx >> 11) & 3, pair = bidx >> 13;
+      const int pos = part * 16 + byte;                    // byte of the 32-byte operand
+      const int step = 2 * pair + ((pos >> 3) & 1), e = pos & 7;
+      const float w = weight(step, e, lane, mt);
+      _Float16 hi, lo;
+      split_weight(w, hi, lo);
+      const float v = pos < 16 ? (w - (float)hi) * 2048.0f : (float)hi;
+      word |= e4m3_byte(v) << (8 * b);
+    }
+  }
+  out[idx] = __builtin_bit_cast(float, word);
 }
 
 enum { MODE_SHADE = 0, MODE_APP = 1, MODE_MLP = 2 };
@@ -544,7 +608,52 @@ __device__ __forceinline__ HL split8(const float x[8], bool keep) {
   return o;
 }
 
+// ---- f16f8 arithmetic: main term in fp16, both correction terms in one block-scaled fp8 MFMA per pair of k-steps -------------
+typedef int v8i __attribute__((ext_vector_type(8)));
+typedef short v2s __attribute__((ext_vector_type(2)));
+#define MFMA8(a, b, c) __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4((a), (b), (c), 0, 0, 0, 116 /* A block scale 2^-11 */, 0, 127)
+
+// 8 values of one k-step -> fp16 main operand (returned) + this step's 16 bytes of the pair's fp8 operand b8:
+// bytes [8 odd .. 8 odd + 7] = e4m3(x), bytes [16 + 8 odd .. ] = e4m3((x - fp16(x)) * 2^11)
+__device__ __forceinline__ h8 split8_f8(const float x[8], v8i& b8, int odd) {
+  u32x4 hi;
+  uint32_t xh[2], xl[2];
+  float neg1 = -1.0f;
+  asm("" : "+v"(neg1));
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float a = x[2 * q], b = x[2 * q + 1];
+    // round-to-nearest fp16 (v_cvt_pk_f16_f32) rather than the truncating v_cvt_pkrtz of the three-term split: it halves the
+    // residual, and with it the error the 4-bit fp8 copy of the residual leaves
+    typedef float f2v __attribute__((ext_vector_type(2)));
+    typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+    const h2v hp = __builtin_convertvector(f2v{a, b}, h2v);
+    hi[q] = __builtin_bit_cast(uint32_t, hp);
+    const float ra = __builtin_fmaf((float)hp[0], neg1, a), rb = __builtin_fmaf((float)hp[1], neg1, b);
+    if ((q & 1) == 0) {
+      // the low-half conversion keeps the other half of its destination, which the high-half conversion of the next value pair
+      // overwrites: seed the destination with a value that is about to die (the operands themselves) rather than with a zero,
+      // which costs a v_mov per operand register
+      xh[q >> 1] = (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(a, b, __builtin_bit_cast(int, b), false);
+      xl[q >> 1] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(__builtin_bit_cast(v2s, rb), ra, rb, 1.0f / 2048.0f, false));
+    } else {
+      xh[q >> 1] = (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(a, b, (int)xh[q >> 1], true);
+      xl[q >> 1] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(__builtin_bit_cast(v2s, xl[q >> 1]), ra, rb,
+                                                                                         1.0f / 2048.0f, true));
+    }
+  }
+  b8[2 * odd] = (int)xh[0]; b8[2 * odd + 1] = (int)xh[1];
+  b8[4 + 2 * odd] = (int)xl[0]; b8[4 + 2 * odd + 1] = (int)xl[1];
+  return __builtin_bit_cast(h8, hi);
+}
+
+__device__ __forceinline__ v8i load_a8(const u32x4* __restrict__ WF, int pair, int mt, int lane) {
+  const u32x4 p0 = WF[((pair * 4 + mt) * 2 + 0) * 64 + lane], p1 = WF[((pair * 4 + mt) * 2 + 1) * 64 + lane];
+  return v8i{(int)p0.x, (int)p0.y, (int)p0.z, (int)p0.w, (int)p1.x, (int)p1.y, (int)p1.z, (int)p1.w};
+}
+
 struct BasisFrag {
+
   h8 hi, lo;
 };
 
@@ -869,16 +978,24 @@ __device__ __forceinline__ void gather_basis_f16(const DevField& F, const VMTaps
   basis_step(f0, v2, keep, fe); basis_step(f1, v2 + 8, keep, fe); basis_step(f2, v2 + 16, keep, fe);
 }
 
-template <int MODE, bool DUMP = false, bool TAB16 = false>
+template <int MODE, bool DUMP = false, bool TAB16 = false, bool P8 = false>
 __global__ __launch_bounds__(512) void k_shade_h(ShadeArgs A) {
+  static_assert(!P8 || (!DUMP && MODE != MODE_APP), "the fp8-correction arithmetic exists for the inference MLP only");
   __shared__ __attribute__((aligned(16))) float lds[(MODE == MODE_APP ? 0 : LDS_W_FLOATS) + 4];
   const float* blob = A.packed + PACKED_FLOATS;  // the f16x3 half of the packed blob
   if (MODE != MODE_APP) {
     const f32x4* src = (const f32x4*)blob;
+    const f32x4* src8 = (const f32x4*)(A.packed + 2 * PACKED_FLOATS + BASIS16_FLOATS_C);  // f16f8 layout of W1 / W2
     f32x4* dst = (f32x4*)lds;
-    for (int i = threadIdx.x; i < LDS_W_FLOATS / 4; i += 512) dst[i] = src[i];
+    for (int i = threadIdx.x; i < LDS_W_FLOATS / 4; i += 512) dst[i] = (P8 && i < F8_FLOATS / 4) ? src8[i] : src[i];
   }
   __syncthreads();
+  if (P8) {
+    // MODE.FP16_OVFL = 1: an out-of-range f32 -> fp8 / f16 conversion saturates to the largest finite value instead of producing
+    // NaN / inf (v_cvt_pk_fp8_f32 returns NaN above 448, tools/fp8_layout_probe.hip); a saturated correction operand costs accuracy
+    // of one low-order term, a NaN would poison the pixel
+    __builtin_amdgcn_s_setreg(1 | (23 << 6) | (0 << 11), 1);
+  }
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 31, h = lane >> 5;
@@ -1003,6 +1120,49 @@ __global__ __launch_bounds__(512) void k_shade_h(ShadeArgs A) {
         const f32x4 b = B1[(mt * 2 + hw) * 4 + q];
         H[mt][q * 4 + 0] = b.x; H[mt][q * 4 + 1] = b.y; H[mt][q * 4 + 2] = b.z; H[mt][q * 4 + 3] = b.w;
       }
+    if (P8) {
+      float s1 = 0.f, c1 = 0.f, s2 = 0.f, c2 = 0.f;
+      float xs[8];
+      const u32x4* W1F = W1 + F8_HI1 / 4;   // fp8 fragments [pair][mt][part][lane]
+      h8 ah[4], nh[4];
+      v8i a8[4], b8;
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) nh[mt] = __builtin_bit_cast(h8, W1[mt * 64 + lw]);
+#pragma unroll
+      for (int kk = 0; kk < KS1; ++kk) {
+        float x;
+        if (kk < 5 * NSLOT) {
+          const int r = kk / 5, kind = kk % 5;
+          if (kind == 0) sincos_x_2x_hw(fe[r], s1, c1, s2, c2);
+          x = kind == 0 ? fe[r] : (kind == 1 ? s1 : (kind == 2 ? s2 : (kind == 3 ? c1 : c2)));
+        } else if (kk < 5 * NSLOT + 8) {
+          x = vw[kk - 5 * NSLOT];
+        } else {
+          x = 0.f;
+        }
+        xs[kk & 7] = x;
+        if ((kk & 7) == 7) {
+          const int step = kk >> 3;
+          const h8 bh = split8_f8(xs, b8, step & 1);
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt) ah[mt] = nh[mt];
+          if (step + 1 < KH1) {
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) nh[mt] = __builtin_bit_cast(h8, W1[((step + 1) * 4 + mt) * 64 + lw]);
+          }
+          if ((step & 1) == 0) {  // the pair's fp8 fragments: needed after the second step's main-term MFMAs
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) a8[mt] = load_a8(W1F, step >> 1, mt, lw);
+          }
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt) H[mt] = MFMAH(ah[mt], bh, H[mt]);
+          if (step & 1) {
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) H[mt] = MFMA8(a8[mt], b8, H[mt]);
+          }
+        }
+      }
+    } else
     {
       float s1 = 0.f, c1 = 0.f, s2 = 0.f, c2 = 0.f;
       float xs[8];
@@ -1071,6 +1231,36 @@ __global__ __launch_bounds__(512) void k_shade_h(ShadeArgs A) {
         const f32x4 b = B2[(mt * 2 + hw) * 4 + q];
         G[mt][q * 4 + 0] = b.x; G[mt][q * 4 + 1] = b.y; G[mt][q * 4 + 2] = b.z; G[mt][q * 4 + 3] = b.w;
       }
+    if (P8) {
+      const u32x4* W2F = W2 + F8_HI2 / 4;
+      h8 ah[4], nh[4];
+      v8i a8[4], b8;
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) nh[mt] = __builtin_bit_cast(h8, W2[mt * 64 + lw]);
+#pragma unroll
+      for (int step = 0; step < KH2; ++step) {
+        float xs[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) xs[e] = H[(step * 8 + e) >> 4][(step * 8 + e) & 15];
+        const h8 bh = split8_f8(xs, b8, step & 1);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) ah[mt] = nh[mt];
+        if (step + 1 < KH2) {
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt) nh[mt] = __builtin_bit_cast(h8, W2[((step + 1) * 4 + mt) * 64 + lw]);
+        }
+        if ((step & 1) == 0) {
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt) a8[mt] = load_a8(W2F, step >> 1, mt, lw);
+        }
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) G[mt] = MFMAH(ah[mt], bh, G[mt]);
+        if (step & 1) {
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt) G[mt] = MFMA8(a8[mt], b8, G[mt]);
+        }
+      }
+    } else
     {
       h8 ah[4], al[4], nh[4], nl[4];
 #pragma unroll
@@ -1173,7 +1363,7 @@ extern "C" {
 
 constexpr int BASIS16_FLOATS = 2 * KHB * 2 * 64 * 4;  // [2 g][9 steps][2 terms][64 lanes][8 halves]
 
-int64_t ego_packed_floats(void) { return 2 * (int64_t)PACKED_FLOATS + BASIS16_FLOATS; }
+int64_t ego_packed_floats(void) { return 2 * (int64_t)PACKED_FLOATS + BASIS16_FLOATS + F8_FLOATS; }
 
 int ego_pack_mlp(const ego_scene* sc, float* packed_out, void* stream) {
   EGO_REQUIRE(sc && packed_out, "pack_mlp: null argument");
@@ -1191,7 +1381,11 @@ int ego_pack_mlp(const ego_scene* sc, float* packed_out, void* stream) {
                                                                             packed_out, packed_out + PACKED_FLOATS);
   if (int e = ego_launch_status("k_pack_mlp_h")) return e;
   k_pack_basis16<<<(BASIS16_FLOATS + 255) / 256, 256, 0, (hipStream_t)stream>>>(sc->basis[0], sc->basis[1], packed_out + 2 * PACKED_FLOATS);
-  return ego_launch_status("k_pack_basis16");
+  if (int e = ego_launch_status("k_pack_basis16")) return e;
+  static_assert(BASIS16_FLOATS == BASIS16_FLOATS_C, "blob region sizes");
+  k_pack_mlp_f8<<<(F8_FLOATS + 255) / 256, 256, 0, (hipStream_t)stream>>>(sc->mlp_w[0], sc->mlp_w[1],
+                                                                          packed_out + 2 * PACKED_FLOATS + BASIS16_FLOATS);
+  return ego_launch_status("k_pack_mlp_f8");
 }
 
 int ego_app_feature(const ego_scene* sc, const float* c7n, int64_t M, float* out, void* stream) {
@@ -1218,6 +1412,7 @@ int ego_mlp_fea(const ego_scene* sc, const float* viewdirs, const float* feat, i
   ShadeArgs a{};
   a.c = make_coords(*sc); a.packed = sc->packed; a.feat = feat; a.dirs = viewdirs; a.out = rgb; a.M = M; a.S = 1;
   if (sc->mlp_precision == EGO_PREC_F32) k_shade<MODE_MLP><<<shade_grid(M), 512, 0, (hipStream_t)stream>>>(a);
+  else if (sc->mlp_precision == EGO_PREC_F16F8) k_shade_h<MODE_MLP, false, false, true><<<shade_grid(M), 512, 0, (hipStream_t)stream>>>(a);
   else k_shade_h<MODE_MLP><<<shade_grid(M), 512, 0, (hipStream_t)stream>>>(a);
   return ego_launch_status("k_shade<MLP>");
 }
@@ -1233,16 +1428,18 @@ int ego_shade(const ego_scene* sc, const float* rays, const float* z, const floa
   a.c = make_coords(*sc); a.F = make_field(sc->app); a.packed = sc->packed; a.rays = rays; a.z = z; a.coords = coords; a.out = rgb; a.tile_active = tile_active;
   a.M = N * (int64_t)S; a.S = S;
   if (dump) {
-    EGO_REQUIRE(sc->mlp_precision == EGO_PREC_F16X3 && dump->x && dump->h1 && dump->h2 && dump->v,
-                "shade: activation dumps need mlp_precision = EGO_PREC_F16X3 and four non-null buffers");
+    EGO_REQUIRE(sc->mlp_precision != EGO_PREC_F32 && dump->x && dump->h1 && dump->h2 && dump->v,
+                "shade: activation dumps need the fp16-split arithmetic (not EGO_PREC_F32) and four non-null buffers");
     a.dump_x = dump->x; a.dump_h1 = dump->h1; a.dump_h2 = dump->h2; a.dump_v = dump->v;
     k_shade_h<MODE_SHADE, true><<<shade_grid(a.M), 512, 0, (hipStream_t)stream>>>(a);
   } else if (sc->mlp_precision == EGO_PREC_F32) k_shade<MODE_SHADE><<<shade_grid(a.M), 512, 0, (hipStream_t)stream>>>(a);
   else if (sc->app_f16) {
     if (int e = check_app16(sc, "shade")) return e;
     a.F = make_field(sc->app16);
-    k_shade_h<MODE_SHADE, false, true><<<shade_grid(a.M), 512, 0, (hipStream_t)stream>>>(a);
-  } else k_shade_h<MODE_SHADE><<<shade_grid(a.M), 512, 0, (hipStream_t)stream>>>(a);
+    if (sc->mlp_precision == EGO_PREC_F16F8) k_shade_h<MODE_SHADE, false, true, true><<<shade_grid(a.M), 512, 0, (hipStream_t)stream>>>(a);
+    else k_shade_h<MODE_SHADE, false, true><<<shade_grid(a.M), 512, 0, (hipStream_t)stream>>>(a);
+  } else if (sc->mlp_precision == EGO_PREC_F16F8) k_shade_h<MODE_SHADE, false, false, true><<<shade_grid(a.M), 512, 0, (hipStream_t)stream>>>(a);
+  else k_shade_h<MODE_SHADE><<<shade_grid(a.M), 512, 0, (hipStream_t)stream>>>(a);
   return ego_launch_status("k_shade<SHADE>");
 }
 

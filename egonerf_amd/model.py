@@ -400,14 +400,15 @@ class EgoNeRF(TensorBase):
 
     @property
     def mlp_precision(self) -> str:
-        """Arithmetic of the basis/MLP products: "f16x3" (three fp16 MFMAs per product, fp32-grade, default) or
-        "f32" (fp32-input MFMA; bit-for-bit fp32 FMA chains)."""
+        """Arithmetic of the basis/MLP products: "f16x3" (three fp16 MFMAs per product, fp32-grade), "f16f8" (layers 1 and 2:
+        main term in fp16, both correction terms in one block-scaled fp8 MFMA per pair of k-steps; ~8e-6 on a composited
+        colour, inference only — a differentiable call uses "f16x3") or "f32" (fp32-input MFMA; bit-for-bit fp32 FMA chains)."""
         return self._mlp_precision
 
     @mlp_precision.setter
     def mlp_precision(self, value: str):
-        if value not in ("f16x3", "f32"):
-            raise ValueError("mlp_precision must be 'f16x3' or 'f32'")
+        if value not in ("f16x3", "f16f8", "f32"):
+            raise ValueError("mlp_precision must be 'f16x3', 'f16f8' or 'f32'")
         self._mlp_precision = value
         self._scene_cache = None
 
@@ -503,7 +504,7 @@ class EgoNeRF(TensorBase):
         sc.app_dim = self.app_dim
         sc.mlp_in, sc.mlp_hidden = self.renderModule.in_mlpC, self.featureC
         sc.view_pe, sc.fea_pe = self.view_pe, self.fea_pe
-        sc.mlp_precision = 1 if self._mlp_precision == "f32" else 0
+        sc.mlp_precision = {"f16x3": 0, "f32": 1, "f16f8": 2}[self._mlp_precision]
         if (self.app_dim, self.app_n_comp[0], self.featureC, self.view_pe, self.fea_pe) == (27, 48, 128, 2, 2):
             if self._packed is None or self._packed.device != dev:
                 self._packed = torch.empty(lib.ego_packed_floats(), device=dev)

@@ -108,14 +108,15 @@ class RenderFunction(torch.autograd.Function):
         ctx.set_materialize_grads(False)
         dev = rays.device
         sc = model.scene()
-        if sc.app_f16 or sc.weight_thres >= 0:
-            # training gathers from the fp32 parameters (the backward re-gathers from them) and shades every sample, like
-            # EgoNeRF.forward (the appearance skip is an inference option)
+        if sc.mlp_precision == 1:
+            raise NotImplementedError("training uses the fp16-split matrix path (model.mlp_precision = 'f16x3' or 'f16f8')")
+        if sc.app_f16 or sc.weight_thres >= 0 or sc.mlp_precision != 0:
+            # training gathers from the fp32 parameters (the backward re-gathers from them), shades every sample like
+            # EgoNeRF.forward (the appearance skip is an inference option) and keeps all three fp16 terms of every product
             sc = _lib.Scene.from_buffer_copy(sc)
             sc.app_f16 = 0
             sc.weight_thres = -1.0
-        if sc.mlp_precision != 0:
-            raise NotImplementedError("training uses the f16x3 matrix path (model.mlp_precision = 'f16x3')")
+            sc.mlp_precision = 0
         N = rays.shape[0]
         n_coarse, n_fine = opts["n_coarse"], opts["n_fine"]
         resampling, use_coarse = opts["resampling"], opts["use_coarse_sample"]

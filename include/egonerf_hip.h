@@ -44,7 +44,7 @@ extern "C" {
 
 #define EGO_ABI_VERSION 7
 
-enum { EGO_PREC_F16X3 = 0, EGO_PREC_F32 = 1 };
+enum { EGO_PREC_F16X3 = 0, EGO_PREC_F32 = 1, EGO_PREC_F16F8 = 2 };
 
 enum {
   EGO_OK = 0,
@@ -92,8 +92,11 @@ typedef struct ego_scene {
   /* environment map (models/envmap.py): emission [3][2h][h] or NULL */
   const float* envmap;
   int32_t envmap_h;
-  /* arithmetic of the basis/MLP matrix products: EGO_PREC_F16X3 (default, 0) = three fp16 MFMAs per product
-   * (hi*hi + lo*hi + hi*lo, fp32 accumulate, ~2^-21 relative: fp32-grade), EGO_PREC_F32 = fp32-input MFMA */
+  /* arithmetic of the basis/MLP matrix products: EGO_PREC_F16X3 (0) = three fp16 MFMAs per product (hi*hi + lo*hi + hi*lo,
+   * fp32 accumulate, ~2^-21 relative: fp32-grade); EGO_PREC_F32 = fp32-input MFMA; EGO_PREC_F16F8 = layers 1 and 2 of the MLP
+   * with the main term in fp16 and both correction terms in one block-scaled fp8 (e4m3) MFMA per pair of k-steps (~2^-16
+   * relative per product; composited max |d RGB| ~8e-6, i.e. > 10x inside the 1e-4 bar; inference only, the training forward
+   * keeps the fp16 split) */
   int32_t mlp_precision;
   /* Opt-in skipping (EgoNeRF.forward itself evaluates every sample; these follow TensorBase.forward's mask semantics,
    * models/tensorBase.py:464-478, and YinYangAlphaGridMask, models/EgoNeRF.py:11-24):

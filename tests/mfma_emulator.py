@@ -190,3 +190,52 @@ def app_channel_g(kk, h):
     channel plane*48 + 16 i + 4 (h + 2 half) + c."""
     within = kk % APP_HALF
     return (kk // APP_HALF) * APP_C + ((within % 12) // 4) * 16 + 4 * (h + 2 * (within // 12)) + kk % 4
+
+
+def e4m3_bytes(x):
+    """float -> OCP e4m3fn code (round to nearest even, subnormals down to 2^-9, saturating at 448: what v_cvt_pk_fp8_f32 writes
+    for in-range inputs, tools/fp8_layout_probe.hip)."""
+    x = np.asarray(x, np.float64)
+    s = (np.signbit(x)).astype(np.uint8) << 7
+    a = np.minimum(np.abs(x), 448.0)
+    e = np.maximum(np.floor(np.log2(np.maximum(a, 2.0 ** -40))), -6.0)
+    m = np.rint(a / 2.0 ** (e - 3))                     # 8..16 for normals (16 = carry into the next binade), 0..8 below 2^-6
+    carry = m >= 16
+    e = np.where(carry, e + 1, e)
+    m = np.where(carry, 8, m)
+    normal = m >= 8
+    code = np.where(normal, ((e + 7).astype(np.int64) << 3) | (m.astype(np.int64) - 8), m.astype(np.int64))
+    return (code.astype(np.uint8) | s).astype(np.uint8)
+
+
+F8_FLOATS = OFF_B1
+
+
+def pack_mlp_f8(w):
+    """Fourth region of the packed blob (k_pack_mlp_f8): per layer the fp16 hi fragments [step][m-tile][lane][8], then the fp8
+    fragments [pair][m-tile][part][lane][16 bytes]; operand byte pos: [0..7] e4m3(w_lo 2^11) step 2p, [8..15] step 2p+1,
+    [16..23] e4m3(w_hi) step 2p, [24..31] step 2p+1."""
+    f32 = pack_mlp(w)
+    out = np.zeros(F8_FLOATS, np.float32)
+
+    def region(src_f32_frag, steps):
+        kk = src_f32_frag.reshape(steps * 2, 4, 64, 4).transpose(1, 2, 0, 3).reshape(4, 64, steps * 8)   # [mt][lane][k]
+        hi = kk.astype(np.float16)
+        lo = kk - hi.astype(np.float32)
+        hi_part = np.zeros((steps, 4, 64, 8), np.float16)
+        for st in range(steps):
+            hi_part[st] = hi[:, :, st * 8:st * 8 + 8]
+        f8 = np.zeros((steps // 2, 4, 2, 64, 16), np.uint8)
+        for p in range(steps // 2):
+            op = np.zeros((4, 64, 32), np.uint8)
+            for half in range(2):
+                sl = slice((2 * p + half) * 8, (2 * p + half) * 8 + 8)
+                op[:, :, 8 * half:8 * half + 8] = e4m3_bytes(lo[:, :, sl].astype(np.float64) * 2048.0)
+                op[:, :, 16 + 8 * half:16 + 8 * half + 8] = e4m3_bytes(hi[:, :, sl].astype(np.float64))
+            f8[p, :, 0] = op[:, :, :16]
+            f8[p, :, 1] = op[:, :, 16:]
+        return np.concatenate([hi_part.reshape(-1).view(np.float32), f8.reshape(-1).view(np.float32)])
+
+    out[OFF_W1:OFF_W2] = region(f32[OFF_W1:OFF_W2], KS1 // 8)
+    out[OFF_W2:OFF_B1] = region(f32[OFF_W2:OFF_B1], KS2 // 8)
+    return out

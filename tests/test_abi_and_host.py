@@ -25,7 +25,7 @@ def test_library_exports_every_header_symbol():
     assert lib.ego_abi_version() == 7
     assert [lib.ego_sizeof(i) for i in range(3)] == [ctypes.sizeof(_lib.Scene), ctypes.sizeof(_lib.RenderArgs),
                                                      ctypes.sizeof(_lib.VmField)]
-    assert lib.ego_packed_floats() == 2 * 46852 + 9216  # fp32 layout + fp16-split layout + fp16-table basis fragments
+    assert lib.ego_packed_floats() == 2 * 46852 + 9216 + 36864  # fp32 layout + fp16-split layout + fp16-table basis fragments + f16f8 W1/W2
 
 
 def test_argument_validation_needs_no_gpu():

@@ -36,9 +36,9 @@ def full(golden):
     return fx, cfg, w, make_model(cfg, w, DEV)
 
 
-@pytest.fixture(params=["f16x3", "f32"], autouse=True)
+@pytest.fixture(params=["f16x3", "f16f8", "f32"], autouse=True)
 def precision(request, tiny, full):
-    """Every test runs with both matrix-product arithmetics (default fp16-split MFMA, and fp32 MFMA)."""
+    """Every test runs with all three matrix-product arithmetics (fp16-split MFMA, fp16 + fp8 corrections, fp32 MFMA)."""
     tiny[3].mlp_precision = request.param
     full[3].mlp_precision = request.param
     return request.param
@@ -58,7 +58,8 @@ def test_device_packer_is_bit_exact(tiny):
     blob = model._packed.cpu().numpy()
     assert np.array_equal(blob[:em.PACKED_FLOATS], em.pack_mlp(w))
     assert np.array_equal(blob[em.PACKED_FLOATS:2 * em.PACKED_FLOATS].view(np.uint32), em.pack_mlp_f16(w).view(np.uint32))
-    assert blob.shape[0] == 2 * em.PACKED_FLOATS + 9216  # + basis fragments in the fp16-table K order
+    assert blob.shape[0] == 2 * em.PACKED_FLOATS + 9216 + em.F8_FLOATS  # + basis fragments in the fp16-table K order + f16f8 region
+    assert np.array_equal(blob[2 * em.PACKED_FLOATS + 9216:].view(np.uint32), em.pack_mlp_f8(w).view(np.uint32))
 
 
 def test_stage_sample_and_coords(tiny):
@@ -114,7 +115,7 @@ def test_stage_lookups(tiny):
     assert model.compute_densityfeature(q[:0]).shape == (0,)  # empty input
 
 
-def test_stage_density_alpha_mlp(tiny):
+def test_stage_density_alpha_mlp(tiny, precision):
     from egonerf_amd.model import raw2alpha
     fx, cfg, _, model = tiny
     sigma = model.feature2density(T(fx["st_sigma_feat"]))
@@ -126,7 +127,9 @@ def test_stage_density_alpha_mlp(tiny):
     rays = T(fx["rays"])
     vd = rays[:, 3:6].view(-1, 1, 3).expand(64, 24, 3)
     rgb = model.renderModule(None, vd, T(fx["st_app_feat"]))
-    assert maxerr(rgb, fx["st_rgb_samples"]) <= 5e-6
+    # per-sample colour: fp32-grade for the three-term arithmetics; with fp8 correction terms a single sample may be off by
+    # a few 1e-5 (the composited colour, which is what the 1e-4 bar applies to, by < 1e-5: see the end-to-end tests)
+    assert maxerr(rgb, fx["st_rgb_samples"]) <= (5e-5 if precision == "f16f8" else 5e-6)
 
 
 def test_stage_sample_pdf(golden):
@@ -445,8 +448,8 @@ def test_fp16_appearance_tables(full):
     """Optional half-precision shadow of the appearance tables (inference): parity against the oracle on the fp32 tables
     (tolerance 1e-4 like every other path), and against the fp32-table render to bound what the storage format costs."""
     _, cfg, w, model = full
-    if model.mlp_precision != "f16x3":
-        pytest.skip("the fp16-table gather exists in the f16x3 kernel")
+    if model.mlp_precision == "f32":
+        pytest.skip("the fp16-table gather exists in the fp16-split kernels")
     rays = torch.from_numpy(synth.make_rays(256, seed=4))
     oracle = make_oracle(cfg, w)
     try:

@@ -65,7 +65,7 @@ def assert_matches_reference(model, rays, got, want_rgb, want_depth, kw):
     return int(bad.numel())
 
 
-@pytest.fixture(params=["f16x3", "f32"])
+@pytest.fixture(params=["f16x3", "f16f8", "f32"])
 def precision(request, ricoh):
     ricoh[2].mlp_precision = request.param
     yield request.param

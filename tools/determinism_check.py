@@ -21,27 +21,48 @@ def run(reps=200, full=False, verbose=True):
     rays = torch.from_numpy(synth.make_rays(256, seed=7)).to(dev)
     vd = rays[:, 3:6].repeat(2, 1).contiguous()
 
+    default_prec = model.mlp_precision
+
     def appf(prec, tab, pts):
         def f():
             model.mlp_precision, model.app_table_dtype = prec, tab
             r = model.compute_appfeature(pts)
-            model.mlp_precision, model.app_table_dtype = "f16x3", "f32"
+            model.mlp_precision, model.app_table_dtype = default_prec, "f32"
             return r
         return f
 
+    def withprec(prec, fn):
+        def f():
+            model.mlp_precision = prec
+            try:
+                return fn()
+            finally:
+                model.mlp_precision = default_prec
+        return f
+
+    default_prec = model.mlp_precision
     feat = model.compute_appfeature(q_in)
     cases = [("appfeature scattered", appf("f16x3", "f32", q)), ("appfeature in-range", appf("f16x3", "f32", q_in)),
              ("appfeature one grid", appf("f16x3", "f32", q_one)), ("appfeature f32-MFMA", appf("f32", "f32", q)),
              ("appfeature f16 tables", appf("f16x3", "f16", q)), ("densityfeature", lambda: model.compute_densityfeature(q)),
-             ("renderModule", lambda: model.renderModule(q_in, vd, feat)),
-             ("forward 24", lambda: model(rays, n_coarse=24, exp_sampling=True)[0]),
-             ("forward 16+16", lambda: model(rays, n_coarse=16, n_fine=16, exp_sampling=True, resampling=True)[0])]
+             ("renderModule f16x3", withprec("f16x3", lambda: model.renderModule(q_in, vd, feat))),
+             ("renderModule f16f8", withprec("f16f8", lambda: model.renderModule(q_in, vd, feat))),
+             ("forward 24 f16x3", withprec("f16x3", lambda: model(rays, n_coarse=24, exp_sampling=True)[0])),
+             ("forward 24 f16f8", withprec("f16f8", lambda: model(rays, n_coarse=24, exp_sampling=True)[0])),
+             ("forward 16+16 f16x3", withprec("f16x3", lambda: model(rays, n_coarse=16, n_fine=16, exp_sampling=True, resampling=True)[0])),
+             ("forward 16+16 f16f8", withprec("f16f8", lambda: model(rays, n_coarse=16, n_fine=16, exp_sampling=True, resampling=True)[0]))]
     if full:
         cfg2 = synth.SceneConfig()
         big = build_model(cfg2, synth.make_weights(cfg2, seed=1234), dev)
         rays2 = torch.from_numpy(synth.make_rays(4096, seed=1)).to(dev)
-        cases.append(("forward 4096 x 512 (rgb)", lambda: big(rays2, n_coarse=512, exp_sampling=True)[0]))
-        cases.append(("forward 4096 x (128+128)", lambda: big(rays2, n_coarse=128, n_fine=128, exp_sampling=True, resampling=True)[0]))
+        for prec in ("f16x3", "f16f8"):
+            def big_fn(kw, prec=prec):
+                def f():
+                    big.mlp_precision = prec
+                    return big(rays2, exp_sampling=True, **kw)[0]
+                return f
+            cases.append((f"forward 4096 x 512 {prec}", big_fn(dict(n_coarse=512))))
+            cases.append((f"forward 4096 x (128+128) {prec}", big_fn(dict(n_coarse=128, n_fine=128, resampling=True))))
     out = {}
     with torch.no_grad():
         for name, fn in cases:

@@ -9,7 +9,7 @@
 enum Op {
   FMA, PK_FMA, PK_MUL, PK_ADD, MUL_LO_U32, MUL_U32_U24, MAD_U32_U24, LSHL_ADD_U64, LSHL_ADD_U32, ADD_U32, CNDMASK, CVT_PKRTZ,
   FMA_MIX, MAX_I32, SIN, EXP, RCP, CVT_F32_F16, PERMLANE32_SWAP, PERMLANE16_SWAP, MOV, DOT2_F32_F16, MAD_U64_U32, ASHRREV, MED3,
-  CNDMASK_E64, CNDMASK_IND, CMP_VCC, CMP_SGPR, ADD_CO, FLOOR, CVT_I32, AND_B32, MOV_DPP, FMA_SGPR, CNDMASK_CONST, V_MAX_F32, FMAC, CNDMASK_E64_VCC, PAIR_VCC, PAIR_SGPR,
+  CNDMASK_E64, CNDMASK_IND, CMP_VCC, CMP_SGPR, ADD_CO, FLOOR, CVT_I32, AND_B32, MOV_DPP, FMA_SGPR, CNDMASK_CONST, V_MAX_F32, FMAC, CNDMASK_E64_VCC, PAIR_VCC, PAIR_SGPR, CVT_PK_FP8, CVT_SCALE_PK_FP8, CVT_PK_F16, CVT_PK_FP8_HI,
   N_OPS
 };
 static const char* NAMES[N_OPS] = {
@@ -18,7 +18,8 @@ static const char* NAMES[N_OPS] = {
   "v_rcp_f32", "v_cvt_f32_f16", "v_permlane32_swap", "v_permlane16_swap", "v_mov_b32", "v_dot2c_f32_f16", "v_mad_u64_u32",
   "v_ashrrev_i32", "v_med3_f32", "v_cndmask_b32 e64 s[10:11]", "v_cndmask_b32 (dst!=src)", "v_cmp_lt_f32 vcc",
   "v_cmp_lt_f32 s[10:11]", "v_add_co_u32 vcc", "v_floor_f32", "v_cvt_i32_f32", "v_and_b32", "v_mov_b32 dpp row_shr:1", "v_fma_f32 with SGPR src",
-  "v_cndmask_b32 0, 1.0, vcc", "v_max_f32", "v_fmac_f32", "v_cndmask_b32_e64 v,v,vcc", "cmp+cndmask via vcc (2)", "cmp+cndmask via s[10:11] (2)"};
+  "v_cndmask_b32 0, 1.0, vcc", "v_max_f32", "v_fmac_f32", "v_cndmask_b32_e64 v,v,vcc", "cmp+cndmask via vcc (2)", "cmp+cndmask via s[10:11] (2)", "v_cvt_pk_fp8_f32", "v_cvt_scalef32_pk_fp8_f32",
+  "v_cvt_pk_f16_f32", "v_cvt_pk_fp8_f32 op_sel hi"};
 
 template <int OP>
 __device__ __forceinline__ void one(float& a, float& b, uint64_t& w, float c0, float c1) {
@@ -62,6 +63,10 @@ __device__ __forceinline__ void one(float& a, float& b, uint64_t& w, float c0, f
   if (OP == CNDMASK_E64_VCC) asm volatile("v_cndmask_b32_e64 %0, %0, %1, vcc" : "+v"(a) : "v"(c0));
   if (OP == PAIR_VCC) asm volatile("v_cmp_lt_f32 vcc, %0, %1\n v_cndmask_b32 %0, %0, %2, vcc" : "+v"(a) : "v"(c0), "v"(c1) : "vcc");
   if (OP == PAIR_SGPR) asm volatile("v_cmp_lt_f32_e64 s[10:11], %0, %1\n s_nop 1\n v_cndmask_b32_e64 %0, %0, %2, s[10:11]" : "+v"(a) : "v"(c0), "v"(c1) : "s10", "s11");
+  if (OP == CVT_PK_FP8) asm volatile("v_cvt_pk_fp8_f32 %0, %1, %2" : "+v"(a) : "v"(c0), "v"(c1));
+  if (OP == CVT_SCALE_PK_FP8) asm volatile("v_cvt_scalef32_pk_fp8_f32 %0, %1, %2, %3" : "+v"(a) : "v"(c0), "v"(c1), "v"(b));
+  if (OP == CVT_PK_F16) asm volatile("v_cvt_pk_f16_f32 %0, %0, %1" : "+v"(a) : "v"(c0));
+  if (OP == CVT_PK_FP8_HI) asm volatile("v_cvt_pk_fp8_f32 %0, %1, %2 op_sel:[0,0,1]" : "+v"(a) : "v"(c0), "v"(c1));
   if (OP == MED3) asm volatile("v_med3_f32 %0, %0, %1, %2" : "+v"(a) : "v"(c0), "v"(c1));
 }
 
