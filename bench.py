@@ -38,8 +38,12 @@ HBM_PEAK_GBPS = 8000.0         # MI355X_MICROARCH.md: HBM3E 8 TB/s
 MFMA_F32_PEAK_TFLOPS = 157.3   # fp32-input MFMA dense peak
 MFMA_F16_PEAK_TFLOPS = 2500.0  # dense fp16/bf16 MFMA peak
 N_SIMD = 256 * 4
-FLOP_PER_MFMA = {"f16x3": 2 * 32 * 32 * 16, "f32": 2 * 32 * 32 * 2}  # v_mfma_f32_32x32x16_f16 / v_mfma_f32_32x32x2_f32
-CLK_PER_MFMA = {"f16x3": 32, "f32": 64}   # issue-to-issue cycles of a dependent-free MFMA stream (tools/coissue_probe.hip)
+FLOP_PER_MFMA = {"f16x3": 2 * 32 * 32 * 16, "f16f8": 2 * 32 * 32 * 16, "f32": 2 * 32 * 32 * 2}  # v_mfma_f32_32x32x16_f16 / ..x2_f32
+CLK_PER_MFMA = {"f16x3": 32, "f16f8": 32, "f32": 64}   # issue-to-issue cycles of a dependent-free MFMA stream (tools/coissue_probe.hip)
+FP8_MFMA_PER_TILE = 36        # f16f8: v_mfma_scale_f32_32x32x64_f8f6f4 per 32-sample tile (5 + 4 step pairs x 4 m-tiles, csrc/ego_shade.hip)
+FLOP_PER_FP8_MFMA, CLK_PER_FP8_MFMA = 2 * 32 * 32 * 64, 61   # 1.9x an fp16 instruction (tools/fp8_mfma_probe.hip)
+FP8_CVT_PER_TILE = 144        # v_cvt_[scalef32_]pk_fp8_f32 per tile: 8 clk each, twice a plain conversion (tools/valu_rate_probe.hip)
+MFMA_F8_PEAK_TFLOPS = 5000.0  # dense MX-fp8 peak
 CLK_PER_VALU = 4                          # a wave64 VALU instruction occupies its SIMD for 4 cycles (16 lanes x 4)
 # algorithmic bytes / flops per sample: density 3*(4+2) taps * 16 ch * 4 B, appearance ... * 48 ch
 B_DENSITY, B_APP = 1152, 3456
@@ -239,32 +243,41 @@ def shade_roofline(prec: str, t_shade: float, M: int):
     (tools/coissue_probe.hip), so the headline is the matrix pipe (executed MFMA flop / dense peak, frac <= 1) with the
     additive VALU+MFMA issue bound next to it; algorithmic bytes / HBM peak is kept as a labelled secondary that exceeds 1
     because the 94 MB table set is L2 / Infinity-Cache resident."""
-    kname = "k_shade_h<SHADE>" if prec == "f16x3" else "k_shade<SHADE>"
+    kname = {"f16x3": "k_shade_h<SHADE>", "f16f8": "k_shade_h<SHADE,f16f8>", "f32": "k_shade<SHADE>"}[prec]
     pmc, src, stale = load_pmc(kname)
     shade_bytes = (B_APP + 16 + 12) * M      # gathered taps + 16 B coords read + 12 B rgb write, per sample
     alg_tflops = FLOP_SAMPLE_SHADE * M / t_shade / 1e12
-    peak = MFMA_F16_PEAK_TFLOPS if prec == "f16x3" else MFMA_F32_PEAK_TFLOPS
+    peak = MFMA_F32_PEAK_TFLOPS if prec == "f32" else MFMA_F16_PEAK_TFLOPS
     out = dict(bound="mfma", kernel=kname, unit="TFLOP/s", peak=peak, ms=t_shade * 1e3, traffic=None)
     if pmc is not None:
         n_se = 32
+        tiles = M / 32
         mfma = pmc["SQ_INSTS_MFMA_per_SE"] * n_se
         valu = pmc["SQ_INSTS_VALU_per_SE"] * n_se - mfma   # SQ_INSTS_VALU counts the MFMAs too
-        executed = mfma * FLOP_PER_MFMA[prec] / t_shade / 1e12
+        n8 = FP8_MFMA_PER_TILE * tiles if prec == "f16f8" else 0.0
+        n16 = mfma - n8
+        flops16, flops8 = n16 * FLOP_PER_MFMA[prec], n8 * FLOP_PER_FP8_MFMA
+        executed = (flops16 + flops8) / t_shade / 1e12
+        # fraction of the matrix pipe's time: each instruction kind against its own dense peak (fp16 2.5 PF, MX-fp8 5 PF)
+        frac = (flops16 / (peak * 1e12) + flops8 / (MFMA_F8_PEAK_TFLOPS * 1e12)) / t_shade
         clock_ghz = pmc["GRBM_GUI_ACTIVE"] / (pmc["duration_us"] * 1e3) if "duration_us" in pmc else None
-        tiles = M / 32
-        bound_clk = (mfma * CLK_PER_MFMA[prec] + valu * CLK_PER_VALU) / N_SIMD
-        out.update(achieved=executed, frac=executed / peak, traffic=pmc.get("traffic_bytes"),
-                   inputs=dict(source=src, stale_vs_current_sources=stale, mfma_insts_per_launch=mfma, valu_insts_per_launch=valu,
-                               mfma_per_tile=mfma / tiles, valu_per_tile=valu / tiles, flop_per_mfma=FLOP_PER_MFMA[prec],
-                               effective_clock_GHz=clock_ghz),
+        cvt8 = FP8_CVT_PER_TILE * tiles if prec == "f16f8" else 0.0
+        bound_clk = (n16 * CLK_PER_MFMA[prec] + n8 * CLK_PER_FP8_MFMA + (valu + cvt8) * CLK_PER_VALU) / N_SIMD
+        out.update(achieved=executed, frac=frac, peak=executed / frac, traffic=pmc.get("traffic_bytes"),
+                   inputs=dict(source=src, stale_vs_current_sources=stale, mfma_insts_per_launch=mfma, fp8_mfma_insts_per_launch=n8,
+                               valu_insts_per_launch=valu, mfma_per_tile=mfma / tiles, valu_per_tile=valu / tiles,
+                               flop_per_mfma=FLOP_PER_MFMA[prec], flop_per_fp8_mfma=FLOP_PER_FP8_MFMA if n8 else None,
+                               peak_note="peak = executed flops / (time the same instruction mix takes at the dense peaks: fp16 2.5 PF, "
+                                         "MX-fp8 5 PF)" if n8 else None, effective_clock_GHz=clock_ghz),
                    issue=None if clock_ghz is None else dict(
                        note="additive VALU + MFMA issue bound per SIMD (the two do not overlap on this SIMD)",
-                       clk_per_mfma=CLK_PER_MFMA[prec], clk_per_valu=CLK_PER_VALU, bound_ms=bound_clk / (clock_ghz * 1e6),
-                       frac=bound_clk / (clock_ghz * 1e6) / (t_shade * 1e3)))
+                       clk_per_mfma=CLK_PER_MFMA[prec], clk_per_fp8_mfma=CLK_PER_FP8_MFMA if n8 else None, clk_per_valu=CLK_PER_VALU,
+                       bound_ms=bound_clk / (clock_ghz * 1e6), frac=bound_clk / (clock_ghz * 1e6) / (t_shade * 1e3)))
     else:  # no committed counters: fall back to the algorithmic flop count (a lower bound of what the pipe executes)
-        out.update(achieved=alg_tflops, frac=alg_tflops / peak, inputs=dict(source=None, note="no profiles/r*/pmc_traffic.json"))
+        out.update(achieved=alg_tflops, frac=alg_tflops / peak, inputs=dict(source=None, note="no profiles/r*/pmc_traffic.json entry for " + kname))
     out["algorithmic"] = dict(flop_per_sample=FLOP_SAMPLE_SHADE, achieved_TFLOPs=alg_tflops, frac_of_peak=alg_tflops / peak,
-                              note="f16x3 executes 3 MFMA flops per algorithmic flop" if prec == "f16x3" else None)
+                              note={"f16x3": "f16x3 executes 3 MFMA flops per algorithmic flop", "f32": None,
+                                    "f16f8": "per algorithmic flop of layers 1/2: one fp16 MFMA flop + two fp8 MFMA flops"}[prec])
     gbps = shade_bytes / t_shade / 1e9
     out["hbm_algorithmic"] = dict(bytes_per_launch=shade_bytes, achieved=gbps, peak=HBM_PEAK_GBPS, unit="GB/s", frac=gbps / HBM_PEAK_GBPS,
                                   note="frac > 1 = cache-resident: algorithmic tap bytes are served by L1/L2/Infinity Cache, "
@@ -329,6 +342,24 @@ def run_render(a, rk: Ranks):
                     march_density=march,
                     path_algorithmic_GBps=(B_DENSITY + B_APP) * M / (t_march + t_shade + t_comp) / 1e9)
 
+    # A/B of the other fp16-split arithmetic on the same launch (shade kernel only; the rest of the step does not depend on it)
+    main_prec = model.mlp_precision
+    alt = {}
+    for prec in ("f16x3", "f16f8"):
+        if prec == main_prec:
+            continue
+        model.mlp_precision = prec
+        sc2 = model.scene()
+        e2 = [torch.cuda.Event(enable_timing=True) for _ in range(21)]
+        for i in range(23):
+            if i >= 2:
+                e2[i - 2].record()
+            _lib.check(lib.ego_shade(sc2, rays.data_ptr(), z.data_ptr(), crd.data_ptr(), N_RAYS, N_SAMPLES, rgb.data_ptr(), None, None, st), "shade")
+        torch.cuda.synchronize()
+        alt[prec] = dict(shade_ms=float(np.mean([e2[i].elapsed_time(e2[i + 1]) for i in range(20)])))
+    model.mlp_precision = main_prec
+    roofline["alt_precision"] = alt
+
     cpu = cpu_single = parity = None
     if not a.no_cpu_baseline and rk.world == 1:  # the CPU baseline is timed at N=1 only
         cpu_single, ref, cpu_rays = cpu_baseline_single(cfg, weights, a.cpu_rays)
@@ -337,7 +368,14 @@ def run_render(a, rk: Ranks):
         err = float((got[0].cpu() - ref[0]).abs().max())
         mse = float(((got[0].cpu() - ref[0]) ** 2).mean())
         parity = dict(max_abs_rgb_err=err, psnr_vs_oracle_db=float(-10 * np.log10(max(mse, 1e-30))),
-                      max_abs_depth_err=float((got[1].cpu() - ref[1]).abs().max()), rays=a.cpu_rays)
+                      max_abs_depth_err=float((got[1].cpu() - ref[1]).abs().max()), rays=a.cpu_rays, mlp_precision=main_prec,
+                      tolerance=dict(rgb=1e-4, depth=1e-3 * 23.3))
+        for prec in alt:
+            model.mlp_precision = prec
+            with torch.no_grad():
+                g2 = model(cpu_rays.to(dev), **kw)
+            alt[prec]["max_abs_rgb_err"] = float((g2[0].cpu() - ref[0]).abs().max())
+        model.mlp_precision = main_prec
         try:
             cpu = cpu_baseline_all_cores()
         except Exception as e:  # the single-process figure still stands
@@ -346,8 +384,9 @@ def run_render(a, rk: Ranks):
     return dict(metric="rays/sec at 4096-ray batch, 512 samples (EgoNeRF volume-rendering forward)", value=rays_per_s,
                 unit="rays/s", samples_per_s=rays_per_s * N_SAMPLES, n_gpus=rk.world, steps=a.steps, warmup=a.warmup,
                 ms_per_step=dt / a.steps * 1e3, higher_is_better=True, scaling="weak", vs_baseline=None,
-                dtype="f32 (tables, interpolation, compositing; matrix products as 3x fp16 MFMA with fp32 accumulate)"
-                if model.mlp_precision == "f16x3" else "f32",
+                dtype={"f16x3": "f32 (tables, interpolation, compositing; matrix products as 3x fp16 MFMA with fp32 accumulate)",
+                       "f16f8": "f32 (tables, interpolation, compositing; matrix products: fp16 MFMA main term + block-scaled fp8 MFMA "
+                                "correction terms in the MLP, 3x fp16 MFMA in the basis, fp32 accumulate)", "f32": "f32"}[model.mlp_precision],
                 data="synthetic",
                 config=dict(workload="OmniBlender barbershop shape: grid [150,172,516], 16x3/48x3 comps, MLP_Fea; "
                                      "4096 rays x 512 samples, eval, no resampling (BASELINE configs[1])",
@@ -449,9 +488,10 @@ def run_erp(a, rk: Ranks):
 
     # reference images for the PSNR column: the same views with the fp32-MFMA arithmetic and no skipping
     with torch.no_grad():
+        default_prec = model.mlp_precision
         model.mlp_precision = "f32"
         refs = [render(k) for k in range(min(K, 2))]
-        model.mlp_precision = "f16x3"
+        model.mlp_precision = default_prec
         occupied = None
         if a.mask:
             occupied = model.updateAlphaMask()
@@ -472,7 +512,7 @@ def run_erp(a, rk: Ranks):
     return dict(metric="rays/sec, full equirectangular image render (128 coarse + 128 fine samples, envmap on)", value=rays_per_s,
                 unit="rays/s", samples_per_s=rays_per_s * 384, n_gpus=rk.world, steps=a.steps, warmup=a.warmup, ms_per_step=dt / a.steps * 1e3,
                 s_per_image=dt / a.steps, higher_is_better=True, scaling="strong", vs_baseline=None,
-                dtype="f32 (matrix products as 3x fp16 MFMA with fp32 accumulate)", data="synthetic",
+                dtype=f"f32 (matrix products: mlp_precision = {model.mlp_precision}, fp32 accumulate)", data="synthetic",
                 config=dict(workload=f"Ricoh360-like scene (near_far [0.1,300], r0 0.05, shift -10, envmap 3x3840x1920, grid [150,172,516]); "
                                      f"a step = one {H}x{W} ERP image, rays generated on the device, rows sharded over the ranks "
                                      f"(BASELINE configs[2]; configs[4] at --gpus 8)",

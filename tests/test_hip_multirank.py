@@ -93,7 +93,7 @@ def test_bench_default_line_contract():
               "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
     rf, cb = d["roofline"], d["cpu_baseline"]
-    assert rf["bound"] == "mfma" and 0 < rf["frac"] <= 1.0 and rf["unit"] == "TFLOP/s" and rf["peak"] == 2500.0
+    assert rf["bound"] == "mfma" and 0 < rf["frac"] <= 1.0 and rf["unit"] == "TFLOP/s" and 2500.0 <= rf["peak"] <= 5000.0
     assert rf["hbm_algorithmic"]["frac"] > 0 and rf["traffic"] is None or rf["traffic"] > 0
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "processes" in cb["sample"]
     assert d["parity"]["max_abs_rgb_err"] <= 1e-4

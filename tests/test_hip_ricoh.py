@@ -69,7 +69,7 @@ def assert_matches_reference(model, rays, got, want_rgb, want_depth, kw):
 def precision(request, ricoh):
     ricoh[2].mlp_precision = request.param
     yield request.param
-    ricoh[2].mlp_precision = "f16x3"
+    ricoh[2].mlp_precision = "f16f8"
 
 
 def test_erp_rays_vs_reference_generator(ricoh):

@@ -18,9 +18,13 @@ __global__ __launch_bounds__(512) void k_rate(float* out, int reps) {
   const int one = 127;  // E8M0 scale 2^0
   for (int it = 0; it < reps; ++it) {
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
+    for (int k = 0; k < (KIND == 2 ? 24 : 16); ++k) {
       if (KIND == 0) acc[k & 3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[k & 3], 0, 0, 0);
-      else acc[k & 3] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, acc[k & 3], 0, 0, 0, one, 0, one);
+      else if (KIND == 1) acc[k & 3] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, acc[k & 3], 0, 0, 0, one, 0, one);
+      else if (KIND == 2) {  // the f16f8 kernel's pattern: per pair of k-steps 4 + 4 fp16 MFMAs, then 4 fp8 ones, on 4 accumulators
+        if ((k % 12) < 8) acc[k & 3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[k & 3], 0, 0, 0);
+        else acc[k & 3] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, acc[k & 3], 0, 0, 0, one, 0, one);
+      }
     }
   }
   float s = 0.f;
@@ -41,7 +45,7 @@ float run(float* out, int waves_per_simd) {
   (void)hipEventSynchronize(e1);
   float ms = 0.f;
   (void)hipEventElapsedTime(&ms, e0, e1);
-  return ms * 1e6f / (reps * 16.0f);  // ns per instruction per wave
+  return ms * 1e6f / (reps * (KIND == 2 ? 24.0f : 16.0f));  // ns per instruction per wave
 }
 
 __global__ void k_check(float* out) {
@@ -57,7 +61,9 @@ int main() {
   float* out;
   (void)hipMalloc(&out, 512 * 256 * 4);
   for (int w = 1; w <= 2; ++w) {
-    const float f16 = run<0>(out, w), f8 = run<1>(out, w);
+    const float f16 = run<0>(out, w), f8 = run<1>(out, w), mix = run<2>(out, w);
+    printf("waves/SIMD %d: mixed pattern (8 fp16 + 4 fp8 per 12, 4 accumulators): %.2f ns per instruction; sum of parts %.2f ns\n", w, mix,
+           (8 * f16 + 4 * f8) / 12);
     printf("waves/SIMD %d: v_mfma_f32_32x32x16_f16 %.2f ns, v_mfma_scale_f32_32x32x64_f8f6f4 (fp8) %.2f ns per instruction per wave -> fp8 / f16 = %.2f for 4x the K\n",
            w, f16, f8, f8 / f16);
   }

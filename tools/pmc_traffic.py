@@ -13,7 +13,8 @@ from egonerf_amd.build import source_hash
 tag = sys.argv[1] if len(sys.argv) > 1 else "v1"
 rnd = sys.argv[2] if len(sys.argv) > 2 else "r02"
 src = os.path.join(root, "gpurun_out", f"prof_{tag}")
-names = {"k_shade_h<SHADE>": "%k_shade_h<0, false, false>%", "k_shade<SHADE>": "%k_shade<0%", "k_march_density<16>": "%k_march_density%",
+names = {"k_shade_h<SHADE>": "%k_shade_h<0, false, false, false>%", "k_shade_h<SHADE,f16f8>": "%k_shade_h<0, false, false, true>%",
+         "k_shade<SHADE>": "%k_shade<0%", "k_march_density<16>": "%k_march_density%",
          "k_composite": "%k_composite%"}
 keys = {"FETCH_SIZE": "FETCH_SIZE_KB", "WRITE_SIZE": "WRITE_SIZE_KB", "TCC_HIT_sum": "TCC_HIT", "TCC_MISS_sum": "TCC_MISS",
         "TCP_TCC_READ_REQ_sum": "TCP_TCC_READ_REQ", "TCP_TOTAL_CACHE_ACCESSES_sum": "TCP_TOTAL_CACHE_ACCESSES", "TA_BUSY_avr": "TA_BUSY_avr",
