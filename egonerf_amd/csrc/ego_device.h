@@ -18,6 +18,13 @@ struct DevField {
   const float* plane[2][3];
   const float* line[2][3];
   int32_t res[3];  // N_r, N_theta, N_phi
+  // compact addressing for the forward gathers: the 12 tables of a field lie within 4 GB of `base` (the lowest of them), so a tap
+  // is `base + 32-bit byte offset`: one scalar base register pair + one VGPR per address (global_load saddr form) instead of a
+  // per-lane 64-bit pointer select and 64-bit adds.  ego_field_is_compact() checks it on the host; the backward kernels keep
+  // using the pointer arrays.
+  const char* base;
+  uint32_t poff[2][3];
+  uint32_t loff[2][3];
 };
 
 struct DevCoords {
@@ -30,13 +37,39 @@ struct DevCoords {
 
 __host__ inline DevField make_field(const ego_vm_field& f) {
   DevField d;
+  uintptr_t lo = ~(uintptr_t)0;
   for (int g = 0; g < 2; ++g)
     for (int i = 0; i < 3; ++i) {
       d.plane[g][i] = f.plane[g][i];
       d.line[g][i] = f.line[g][i];
+      if (f.plane[g][i] && (uintptr_t)f.plane[g][i] < lo) lo = (uintptr_t)f.plane[g][i];
+      if (f.line[g][i] && (uintptr_t)f.line[g][i] < lo) lo = (uintptr_t)f.line[g][i];
     }
   for (int i = 0; i < 3; ++i) d.res[i] = f.res[i];
+  d.base = (const char*)lo;
+  for (int g = 0; g < 2; ++g)
+    for (int i = 0; i < 3; ++i) {
+      d.poff[g][i] = (uint32_t)((uintptr_t)f.plane[g][i] - lo);
+      d.loff[g][i] = (uint32_t)((uintptr_t)f.line[g][i] - lo);
+    }
   return d;
+}
+
+// true iff every table of the field (elem_bytes per element, n_comp channels) ends within 4 GB of the lowest table address, i.e.
+// DevField's 32-bit byte offsets address all of it.  The host layer allocates the tables of a field from one buffer.
+__host__ inline bool ego_field_is_compact(const ego_vm_field& f, int elem_bytes) {
+  uintptr_t lo = ~(uintptr_t)0, hi = 0;
+  const int ax_x[3] = {0, 0, 1}, ax_y[3] = {1, 2, 2}, ax_l[3] = {2, 1, 0};
+  for (int g = 0; g < 2; ++g)
+    for (int i = 0; i < 3; ++i) {
+      if (!f.plane[g][i] || !f.line[g][i]) return false;
+      const uintptr_t p = (uintptr_t)f.plane[g][i], l = (uintptr_t)f.line[g][i];
+      const uintptr_t pe = p + (uintptr_t)f.res[ax_x[i]] * f.res[ax_y[i]] * f.n_comp * elem_bytes;
+      const uintptr_t le = l + (uintptr_t)f.res[ax_l[i]] * f.n_comp * elem_bytes;
+      lo = p < lo ? p : lo; lo = l < lo ? l : lo;
+      hi = pe > hi ? pe : hi; hi = le > hi ? le : hi;
+    }
+  return hi - lo < ((uintptr_t)1 << 32);
 }
 
 __host__ inline DevCoords make_coords(const ego_scene& s, bool fine_pass = false) {

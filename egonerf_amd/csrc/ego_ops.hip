@@ -108,14 +108,14 @@ __device__ __forceinline__ float density_team16(const DevField& F, int g, float 
   for (int i = 0; i < 3; ++i) {
     const Lin1 X = t.ax[vm_plane_x(i)], Y = t.ax[vm_plane_y(i)], Ln = t.ax[vm_line_ax(i)];
     const int W = F.res[vm_plane_x(i)];
-    const float* P = (g ? F.plane[1][i] : F.plane[0][i]) + 4 * p;
-    const float* L = (g ? F.line[1][i] : F.line[0][i]) + 4 * p;
-    // unsigned 32-bit element offsets (a table holds < 2^31 floats): zero-extension into the address is free, a 64-bit
-    // multiply-add per tap (v_mad_i64_i32, quarter rate) is not
-    const uint32_t r0 = (uint32_t)(Y.i0 * W) * C, r1 = (uint32_t)(Y.i1 * W) * C, c0 = (uint32_t)X.i0 * C, c1 = (uint32_t)X.i1 * C;
-    const f32x4 t00 = *(const f32x4*)(P + (r0 + c0)), t01 = *(const f32x4*)(P + (r0 + c1));
-    const f32x4 t10 = *(const f32x4*)(P + (r1 + c0)), t11 = *(const f32x4*)(P + (r1 + c1));
-    const f32x4 u0 = *(const f32x4*)(L + (uint32_t)Ln.i0 * C), u1 = *(const f32x4*)(L + (uint32_t)Ln.i1 * C);
+    // compact addressing (DevField): scalar base + 32-bit byte offset per tap (a table set spans < 4 GB)
+    const uint32_t pb = (g ? F.poff[1][i] : F.poff[0][i]) + 16u * (uint32_t)p;
+    const uint32_t lb = (g ? F.loff[1][i] : F.loff[0][i]) + 16u * (uint32_t)p;
+    const uint32_t r0 = pb + (uint32_t)(Y.i0 * W) * (C * 4), r1 = pb + (uint32_t)(Y.i1 * W) * (C * 4);
+    const uint32_t c0 = (uint32_t)X.i0 * (C * 4), c1 = (uint32_t)X.i1 * (C * 4);
+    const f32x4 t00 = *(const f32x4*)(F.base + (r0 + c0)), t01 = *(const f32x4*)(F.base + (r0 + c1));
+    const f32x4 t10 = *(const f32x4*)(F.base + (r1 + c0)), t11 = *(const f32x4*)(F.base + (r1 + c1));
+    const f32x4 u0 = *(const f32x4*)(F.base + (lb + (uint32_t)Ln.i0 * (C * 4))), u1 = *(const f32x4*)(F.base + (lb + (uint32_t)Ln.i1 * (C * 4)));
     const float w00 = __fmul_rn(Y.w0, X.w0), w01 = __fmul_rn(Y.w0, X.w1);
     const float w10 = __fmul_rn(Y.w1, X.w0), w11 = __fmul_rn(Y.w1, X.w1);
     const f32x4 pv = t00 * w00 + t01 * w01 + t10 * w10 + t11 * w11;
@@ -626,6 +626,9 @@ static int check_field(const ego_vm_field& f, const char* what) {
     for (int i = 0; i < 3; ++i)
       if (!f.plane[g][i] || !f.line[g][i]) return ego_fail(EGO_E_BADARG, "%s: null table pointer", what);
   if (f.res[0] < 2 || f.res[1] < 2 || f.res[2] < 2) return ego_fail(EGO_E_BADARG, "%s: resolution < 2", what);
+  if (!ego_field_is_compact(f, 4))
+    return ego_fail(EGO_E_BADARG, "%s: the 12 tables of a field must lie within 4 GB of each other (allocate them from one buffer): "
+                                  "the gathers address taps as base + 32-bit offset", what);
   return EGO_OK;
 }
 

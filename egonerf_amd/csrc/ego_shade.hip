@@ -700,19 +700,21 @@ template <int I>
 __device__ __forceinline__ void team_load(const DevField& F, const VMTaps& t, int g, int q, f32x4 raw[18]) {
   const Lin1 X = t.ax[vm_plane_x(I)], Y = t.ax[vm_plane_y(I)], Ln = t.ax[vm_line_ax(I)];
   const int W = F.res[vm_plane_x(I)];
-  const float* P = (g ? F.plane[1][I] : F.plane[0][I]) + 4 * q;
-  const float* L = (g ? F.line[1][I] : F.line[0][I]) + 4 * q;
-  // unsigned element offsets: zero-extension into the 64-bit address is free, sign-extension is an extra VALU instruction
-  const f32x4* p00 = (const f32x4*)(P + (uint32_t)((Y.i0 * W + X.i0) * APP_C));
-  const f32x4* p01 = (const f32x4*)(P + (uint32_t)((Y.i0 * W + X.i1) * APP_C));
-  const f32x4* p10 = (const f32x4*)(P + (uint32_t)((Y.i1 * W + X.i0) * APP_C));
-  const f32x4* p11 = (const f32x4*)(P + (uint32_t)((Y.i1 * W + X.i1) * APP_C));
-  const f32x4* l0 = (const f32x4*)(L + (uint32_t)(Ln.i0 * APP_C));
-  const f32x4* l1 = (const f32x4*)(L + (uint32_t)(Ln.i1 * APP_C));
+  // compact addressing (DevField): one scalar base + a 32-bit byte offset per tap; quad 4i + q is 64 i bytes further on
+  const uint32_t pb = (g ? F.poff[1][I] : F.poff[0][I]) + 16u * (uint32_t)q;
+  const uint32_t lb = (g ? F.loff[1][I] : F.loff[0][I]) + 16u * (uint32_t)q;
+  const uint32_t r0 = pb + (uint32_t)(Y.i0 * W) * (APP_C * 4), r1 = pb + (uint32_t)(Y.i1 * W) * (APP_C * 4);
+  const uint32_t c0 = (uint32_t)X.i0 * (APP_C * 4), c1 = (uint32_t)X.i1 * (APP_C * 4);
+  const char* p00 = F.base + (r0 + c0);
+  const char* p01 = F.base + (r0 + c1);
+  const char* p10 = F.base + (r1 + c0);
+  const char* p11 = F.base + (r1 + c1);
+  const char* l0 = F.base + (lb + (uint32_t)Ln.i0 * (APP_C * 4));
+  const char* l1 = F.base + (lb + (uint32_t)Ln.i1 * (APP_C * 4));
 #pragma unroll
-  for (int i = 0; i < 3; ++i) {  // quad 4i + q: f32x4 index 4i from the q-shifted base
-    raw[i] = p00[4 * i]; raw[3 + i] = p01[4 * i]; raw[6 + i] = p10[4 * i]; raw[9 + i] = p11[4 * i];
-    raw[12 + i] = l0[4 * i]; raw[15 + i] = l1[4 * i];
+  for (int i = 0; i < 3; ++i) {
+    raw[i] = *(const f32x4*)(p00 + 64 * i); raw[3 + i] = *(const f32x4*)(p01 + 64 * i); raw[6 + i] = *(const f32x4*)(p10 + 64 * i);
+    raw[9 + i] = *(const f32x4*)(p11 + 64 * i); raw[12 + i] = *(const f32x4*)(l0 + 64 * i); raw[15 + i] = *(const f32x4*)(l1 + 64 * i);
   }
 }
 
@@ -745,7 +747,7 @@ __device__ __forceinline__ void team_finish(const VMTaps& t, const f32x4 raw[18]
 // registers of a line are refilled with the NEXT round's loads as soon as that line's four products are computed, so 12-18 loads
 // stay in flight all the time instead of the queue draining once per round (the gather is latency-bound, not issue-bound).
 struct TapPtrs {
-  const f32x4 *p00, *p01, *p10, *p11, *l0, *l1;
+  uint32_t p00, p01, p10, p11, l0, l1;   // byte offsets from DevField::base (compact addressing: half the registers of pointers)
   float w00, w01, w10, w11, wl0, wl1;
 };
 
@@ -753,15 +755,14 @@ template <int I>
 __device__ __forceinline__ TapPtrs tap_ptrs(const DevField& F, const VMTaps& t, int g, int q) {
   const Lin1 X = t.ax[vm_plane_x(I)], Y = t.ax[vm_plane_y(I)], Ln = t.ax[vm_line_ax(I)];
   const int W = F.res[vm_plane_x(I)];
-  const float* P = (g ? F.plane[1][I] : F.plane[0][I]) + 4 * q;
-  const float* L = (g ? F.line[1][I] : F.line[0][I]) + 4 * q;
+  const uint32_t pb = (g ? F.poff[1][I] : F.poff[0][I]) + 16u * (uint32_t)q;
+  const uint32_t lb = (g ? F.loff[1][I] : F.loff[0][I]) + 16u * (uint32_t)q;
+  const uint32_t r0 = pb + (uint32_t)(Y.i0 * W) * (APP_C * 4), r1 = pb + (uint32_t)(Y.i1 * W) * (APP_C * 4);
+  const uint32_t c0 = (uint32_t)X.i0 * (APP_C * 4), c1 = (uint32_t)X.i1 * (APP_C * 4);
   TapPtrs tp;
-  tp.p00 = (const f32x4*)(P + (uint32_t)((Y.i0 * W + X.i0) * APP_C));
-  tp.p01 = (const f32x4*)(P + (uint32_t)((Y.i0 * W + X.i1) * APP_C));
-  tp.p10 = (const f32x4*)(P + (uint32_t)((Y.i1 * W + X.i0) * APP_C));
-  tp.p11 = (const f32x4*)(P + (uint32_t)((Y.i1 * W + X.i1) * APP_C));
-  tp.l0 = (const f32x4*)(L + (uint32_t)(Ln.i0 * APP_C));
-  tp.l1 = (const f32x4*)(L + (uint32_t)(Ln.i1 * APP_C));
+  tp.p00 = r0 + c0; tp.p01 = r0 + c1; tp.p10 = r1 + c0; tp.p11 = r1 + c1;
+  tp.l0 = lb + (uint32_t)Ln.i0 * (APP_C * 4);
+  tp.l1 = lb + (uint32_t)Ln.i1 * (APP_C * 4);
   tp.w00 = __fmul_rn(Y.w0, X.w0); tp.w01 = __fmul_rn(Y.w0, X.w1);
   tp.w10 = __fmul_rn(Y.w1, X.w0); tp.w11 = __fmul_rn(Y.w1, X.w1);
   tp.wl0 = Ln.w0; tp.wl1 = Ln.w1;
@@ -771,8 +772,10 @@ __device__ __forceinline__ TapPtrs tap_ptrs(const DevField& F, const VMTaps& t, 
   return tp;
 }
 
-__device__ __forceinline__ void line_load(const TapPtrs& tp, int i, f32x4 r[6]) {
-  r[0] = tp.p00[4 * i]; r[1] = tp.p01[4 * i]; r[2] = tp.p10[4 * i]; r[3] = tp.p11[4 * i]; r[4] = tp.l0[4 * i]; r[5] = tp.l1[4 * i];
+__device__ __forceinline__ void line_load(const DevField& F, const TapPtrs& tp, int i, f32x4 r[6]) {
+  const char* b = F.base + 64 * i;
+  r[0] = *(const f32x4*)(b + tp.p00); r[1] = *(const f32x4*)(b + tp.p01); r[2] = *(const f32x4*)(b + tp.p10);
+  r[3] = *(const f32x4*)(b + tp.p11); r[4] = *(const f32x4*)(b + tp.l0); r[5] = *(const f32x4*)(b + tp.l1);
 }
 
 __device__ __forceinline__ void line_finish(const TapPtrs& tp, const f32x4 r[6], float out[4]) {
@@ -855,18 +858,18 @@ __device__ __forceinline__ void gather_basis_team(const DevField& F, const TeamS
     f32x4 (*ln)[6] = (f32x4 (*)[6])raw;  // three lines of six taps
     TapPtrs pa = tap_ptrs<0>(F, tA, ts[0].g, qa), pb = tap_ptrs<0>(F, tB, ts[1].g, qb);
 #pragma unroll
-    for (int i = 0; i < 3; ++i) line_load(pa, i, ln[i]);
+    for (int i = 0; i < 3; ++i) line_load(F, pa, i, ln[i]);
 #define EGO_ROLL_PLANE(PL, NEXT_A, STEP0, DUMPPTR)                                                        \
     {                                                                                                     \
       _Pragma("unroll") for (int i = 0; i < 3; ++i) {                                                     \
         line_finish(pa, ln[i], ga + 4 * i);                                                               \
-        line_load(pb, i, ln[i]);                                                                          \
+        line_load(F, pb, i, ln[i]);                                                                       \
         __builtin_amdgcn_sched_barrier(0);                                                                \
       }                                                                                                   \
       NEXT_A;                                                                                             \
       _Pragma("unroll") for (int i = 0; i < 3; ++i) {                                                     \
         line_finish(pb, ln[i], gb + 4 * i);                                                               \
-        if (PL < 2) line_load(pa, i, ln[i]);                                                              \
+        if (PL < 2) line_load(F, pa, i, ln[i]);                                                           \
         __builtin_amdgcn_sched_barrier(0);                                                                \
       }                                                                                                   \
       team_to_halves(ga, gb, v);                                                                          \
@@ -1335,6 +1338,9 @@ int check_shade_config(const ego_scene* sc, const char* who, bool need_tables, b
     for (int g = 0; g < 2; ++g)
       for (int i = 0; i < 3; ++i)
         if (!sc->app.plane[g][i] || !sc->app.line[g][i]) return ego_fail(EGO_E_BADARG, "%s: null appearance table", who);
+    if (sc->app.res[0] < 2 || sc->app.res[1] < 2 || sc->app.res[2] < 2) return ego_fail(EGO_E_BADARG, "%s: appearance resolution < 2", who);
+    if (!ego_field_is_compact(sc->app, 4))
+      return ego_fail(EGO_E_BADARG, "%s: the 12 appearance tables must lie within 4 GB of each other (allocate them from one buffer)", who);
   }
   if (need_mlp && (sc->mlp_in != MLP_IN || sc->mlp_hidden != HID || sc->view_pe != 2 || sc->fea_pe != 2))
     return ego_fail(EGO_E_UNSUPPORTED, "%s: MLP_Fea config in=%d hidden=%d view_pe=%d fea_pe=%d (supported: 150/128/2/2)", who,

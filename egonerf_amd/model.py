@@ -54,6 +54,20 @@ def _channel_last_param(C_: int, H: int, W: int, scale: float, device) -> torch.
     return torch.nn.Parameter(mem.permute(0, 3, 1, 2))
 
 
+def _carve_channel_last(shapes, device, dtype=torch.float32) -> List[torch.Tensor]:
+    """One flat allocation carved into [1,H,W,C]-memory tables, returned as reference-shaped (1,C,H,W) views.  The tables of a
+    field come from one buffer so that the kernels can address every tap as `base + 32-bit byte offset` (csrc/ego_device.h
+    DevField; the library rejects a field whose tables span 4 GB or more).  Each table starts on a 256-byte boundary."""
+    esz = torch.empty((), dtype=dtype).element_size()
+    align = 256 // esz
+    offs, total = [], 0
+    for (C_, H, W) in shapes:
+        offs.append(total)
+        total += (C_ * H * W + align - 1) // align * align
+    flat = torch.empty(total, device=device, dtype=dtype)
+    return [flat[o:o + C_ * H * W].view(1, H, W, C_).permute(0, 3, 1, 2) for o, (C_, H, W) in zip(offs, shapes)]
+
+
 def _table_ptr(t: torch.Tensor) -> int:
     """Device pointer of a (1,C,H,W) tensor after checking its memory really is [H][W][C]."""
     if not t.permute(0, 2, 3, 1).is_contiguous():
@@ -292,15 +306,35 @@ class EgoNeRF(TensorBase):
     # -- parameters -------------------------------------------------------------------------------------
     def init_one_svd(self, n_component, gridSize, scale, device):
         """EgoNeRF.py:102-122, channel-last memory."""
-        out = []
+        shapes = []
         for _grid in ("yin", "yang"):
-            planes, lines = [], []
             for i in range(3):
                 m0, m1 = MAT_MODE[i]
-                planes.append(_channel_last_param(n_component[i], gridSize[m1], gridSize[m0], scale, device))
-                lines.append(_channel_last_param(n_component[i], gridSize[VEC_MODE[i]], 1, scale, device))
-            out += [torch.nn.ParameterList(planes), torch.nn.ParameterList(lines)]
-        return out
+                shapes.append((n_component[i], gridSize[m1], gridSize[m0]))
+            for i in range(3):
+                shapes.append((n_component[i], gridSize[VEC_MODE[i]], 1))
+        views = _carve_channel_last(shapes, device)   # [plane x3, line x3] yin, then yang: one buffer per field
+        for v, (C_, H, W) in zip(views, shapes):
+            v.copy_(scale * torch.randn(1, C_, H, W))
+        params = [torch.nn.Parameter(v) for v in views]
+        return [torch.nn.ParameterList(params[0:3]), torch.nn.ParameterList(params[3:6]),
+                torch.nn.ParameterList(params[6:9]), torch.nn.ParameterList(params[9:12])]
+
+    @torch.no_grad()
+    def _reflatten_tables(self, kind: str):
+        """Move the 12 tables of `kind` ("density" | "app") into one fresh buffer (after they were replaced one by one, e.g. by
+        upsample_volume_grid): new Parameters, so an optimiser must be rebuilt afterwards (the reference does, train.py:380)."""
+        lists = [getattr(self, f"{kind}_{what}_{g}") for g in ("yin", "yang") for what in ("plane", "line")]
+        olds = [p for l in lists for p in l]
+        views = _carve_channel_last([(p.shape[1], p.shape[2], p.shape[3]) for p in olds], olds[0].device)
+        for v, p in zip(views, olds):
+            v.copy_(p.data)
+        k = 0
+        for l in lists:
+            for i in range(len(l)):
+                l[i] = torch.nn.Parameter(views[k], requires_grad=olds[k].requires_grad)
+                k += 1
+        self._scene_cache = None
 
     def init_svd_volume(self, res, device):
         g = self.gridSize.tolist()
@@ -376,6 +410,8 @@ class EgoNeRF(TensorBase):
         self.density_plane_yin, self.density_line_yin = self.up_sampling_VM(self.density_plane_yin, self.density_line_yin, res_target)
         self.app_plane_yang, self.app_line_yang = self.up_sampling_VM(self.app_plane_yang, self.app_line_yang, res_target)
         self.density_plane_yang, self.density_line_yang = self.up_sampling_VM(self.density_plane_yang, self.density_line_yang, res_target)
+        self._reflatten_tables("app")
+        self._reflatten_tables("density")
         self.update_stepSize(res_target)
         self._scene_cache = None
         print(f"upsamping to {res_target}")
@@ -387,15 +423,15 @@ class EgoNeRF(TensorBase):
         if self.coarse_sigma_grid_update_rule != "conv":
             raise NotImplementedError
         st = _lib.stream_handle()
-        for g in ("yin", "yang"):
-            for i in range(3):
-                for what in ("plane", "line"):
-                    src = getattr(self, f"density_{what}_{g}")[i]
-                    _require_cuda(src, "update_coarse_sigma_grid")
-                    _, C_, H, W = src.shape
-                    dst = torch.empty(1, H // 2, 1 if W == 1 else W // 2, C_, device=src.device)
-                    _call("ego_avgpool_table", _table_ptr(src), H, W, C_, dst.data_ptr(), st)
-                    getattr(self, f"coarse_sigma_{what}_{g}")[i] = dst.permute(0, 3, 1, 2)
+        srcs = [(g, what, i, getattr(self, f"density_{what}_{g}")[i]) for g in ("yin", "yang") for what in ("plane", "line") for i in range(3)]
+        for *_k, src in srcs:
+            _require_cuda(src, "update_coarse_sigma_grid")
+        shapes = [(src.shape[1], src.shape[2] // 2, 1 if src.shape[3] == 1 else src.shape[3] // 2) for *_k, src in srcs]
+        dsts = _carve_channel_last(shapes, srcs[0][3].device)   # one buffer: compact addressing like the full tables
+        for (g, what, i, src), dst in zip(srcs, dsts):
+            _, C_, H, W = src.shape
+            _call("ego_avgpool_table", _table_ptr(src), H, W, C_, dst.data_ptr(), st)
+            getattr(self, f"coarse_sigma_{what}_{g}")[i] = dst
         self._scene_cache = None
 
     @property
@@ -439,8 +475,12 @@ class EgoNeRF(TensorBase):
         tabs = self._app_tables()
         ver = tuple((t.data_ptr(), t._version) for t in tabs)
         if self._app16 is None or self._app16[0] != ver:
-            # [1,H,W,C] channel-last memory of the (1,C,H,W) parameter, converted to half (a cast, done when weights change)
-            self._app16 = (ver, [t.detach().permute(0, 2, 3, 1).contiguous().half() for t in tabs])
+            # [1,H,W,C] channel-last memory of the (1,C,H,W) parameters, converted to half (a cast, done when weights change), in
+            # one buffer
+            halves = _carve_channel_last([(t.shape[1], t.shape[2], t.shape[3]) for t in tabs], tabs[0].device, torch.float16)
+            for hv, t in zip(halves, tabs):
+                hv.copy_(t.detach())
+            self._app16 = (ver, halves)
         halves = self._app16[1]
         sc.app16.n_comp = self.app_n_comp[0]
         sc.app16.res[:] = self.gridSize.tolist()

@@ -57,6 +57,9 @@ enum {
  *   plane[g][0]: [N_theta][N_r][C]   line[g][0]: [N_phi][C]
  *   plane[g][1]: [N_phi][N_r][C]     line[g][1]: [N_theta][C]
  *   plane[g][2]: [N_phi][N_theta][C] line[g][2]: [N_r][C]                                      */
+/* The 12 tables of one field must lie within 4 GB of each other (allocate them from one buffer, as the Python host layer
+ * does): the forward gathers address every tap as lowest-table-address + 32-bit byte offset (scalar base + one VGPR per
+ * address).  Entry points return EGO_E_BADARG for a field that does not. */
 typedef struct ego_vm_field {
   const float* plane[2][3]; /* dev */
   const float* line[2][3];  /* dev */
