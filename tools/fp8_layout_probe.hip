@@ -11,9 +11,10 @@ typedef int v8i __attribute__((ext_vector_type(8)));
 typedef float v16f __attribute__((ext_vector_type(16)));
 typedef short v2s __attribute__((ext_vector_type(2)));
 
-__global__ void k_cvt(const float* x, int n, uint32_t* o, float sc) {
+__global__ void k_cvt(const float* x, int n, uint32_t* o, float sc, int ovfl) {
   const int i = threadIdx.x;
   if (i >= n) return;
+  if (ovfl) __builtin_amdgcn_s_setreg(1 | (23 << 6) | (0 << 11), 1);  // MODE.FP16_OVFL: saturate instead of NaN / inf
   int r = 0;
   r = __builtin_amdgcn_cvt_pk_fp8_f32(x[i], -x[i], r, false);
   o[i] = (uint32_t)r;
@@ -59,7 +60,7 @@ int main() {
   (void)hipMalloc(&dx, 256); (void)hipMalloc(&dout, 1024);
   (void)hipMemcpy(dx, hx, 64, hipMemcpyHostToDevice);
   for (float sc : {1.0f, 2.0f, 0.5f, 2048.0f, 1.0f / 2048.0f}) {
-    k_cvt<<<1, 64>>>(dx, n, dout, sc);
+    k_cvt<<<1, 64>>>(dx, n, dout, sc, 0);
     uint32_t ho[128];
     (void)hipMemcpy(ho, dout, 512, hipMemcpyDeviceToHost);
     printf("scale operand %g:\n", sc);
@@ -67,6 +68,14 @@ int main() {
       printf("  x=%-12g cvt_pk: %02x (%g) / %02x   scalef32: %02x (%g)\n", hx[i], ho[i] & 255, e4m3_decode(ho[i] & 255), (ho[i] >> 8) & 255,
              ho[64 + i] & 255, e4m3_decode(ho[64 + i] & 255));
     if (sc != 1.0f) continue;
+  }
+  {
+    k_cvt<<<1, 64>>>(dx, n, dout, 1.0f, 1);
+    uint32_t ho[128];
+    (void)hipMemcpy(ho, dout, 512, hipMemcpyDeviceToHost);
+    printf("with MODE.FP16_OVFL = 1:\n");
+    for (int i = 0; i < n; ++i)
+      if (hx[i] > 400.f) printf("  x=%-12g cvt_pk: %02x (%g)   scalef32: %02x (%g)\n", hx[i], ho[i] & 255, e4m3_decode(ho[i] & 255), ho[64 + i] & 255, e4m3_decode(ho[64 + i] & 255));
   }
   // layout check with exactly representable small integers
   uint8_t hA[32 * 64], hB[64 * 32];
