@@ -505,6 +505,38 @@ __global__ __launch_bounds__(256) void k_sample_pdf_merge(const float* __restric
   }
   if (use_coarse)
     for (int i = tid; i < Sc; i += 256) keys[i] = zr[i];
+  __syncthreads();
+  // In eval mode u is a linspace, so the fine samples come out non-decreasing, and the coarse schedule always is: the sort is then
+  // a merge of two sorted runs — every key finds its output slot with one binary search in the other run (stable: coarse keys
+  // before equal fine ones) — instead of 36 barrier-separated bitonic stages.  Sortedness is checked, not assumed (training
+  // draws random u; rounding may invert neighbours by an ulp): any inversion falls back to the bitonic network.
+  const int base_f = use_coarse ? Sc : 0;
+  bool inv = false;
+  for (int j = tid; j + 1 < n_fine; j += 256) inv |= keys[base_f + j] > keys[base_f + j + 1];
+  if (use_coarse)
+    for (int i = tid; i + 1 < Sc; i += 256) inv |= keys[i] > keys[i + 1];
+  if (!__syncthreads_or(inv)) {
+    if (use_coarse) {
+      float* outk = cdf;  // the cdf is no longer needed
+      for (int i = tid; i < Sc; i += 256) {
+        const float v = keys[i];
+        int lo = 0, hi = n_fine;  // number of fine keys < v
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (keys[Sc + mid] < v) lo = mid + 1; else hi = mid; }
+        outk[i + lo] = v;
+      }
+      for (int j = tid; j < n_fine; j += 256) {
+        const float v = keys[Sc + j];
+        int lo = 0, hi = Sc;      // number of coarse keys <= v
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (keys[mid] <= v) lo = mid + 1; else hi = mid; }
+        outk[j + lo] = v;
+      }
+      __syncthreads();
+      for (int i = tid; i < n_out; i += 256) z_out[ray * n_out + i] = outk[i];
+    } else {
+      for (int i = tid; i < n_out; i += 256) z_out[ray * n_out + i] = keys[i];
+    }
+    return;
+  }
   // bitonic sort of n_out keys padded to a power of two with +inf
   int P = 1;
   while (P < n_out) P <<= 1;
