@@ -281,7 +281,7 @@ def shade_roofline(prec: str, t_shade: float, M: int):
                                peak_note="peak = executed flops / (time the same instruction mix takes at the dense peaks: fp16 2.5 PF, "
                                          "MX-fp8 5 PF)" if n8 else None, effective_clock_GHz=clock_ghz),
                    issue=None if clock_ghz is None else dict(
-                       note="additive VALU + MFMA issue bound per SIMD (the two do not overlap on this SIMD)",
+                       note="VALU + MFMA issue time per SIMD summed (fp32-FMA-class VALU competes with the matrix pipe, conversion-class VALU can run beside it: tools/agpr_coissue_probe.hip; an upper estimate of the issue time, not a hard bound)",
                        clk_per_mfma=CLK_PER_MFMA[prec], clk_per_fp8_mfma=CLK_PER_FP8_MFMA if n8 else None, clk_per_valu=CLK_PER_VALU,
                        bound_ms=bound_clk / (clock_ghz * 1e6), frac=bound_clk / (clock_ghz * 1e6) / (t_shade * 1e3)))
     else:  # no committed counters: fall back to the algorithmic flop count (a lower bound of what the pipe executes)
