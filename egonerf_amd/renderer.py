@@ -123,31 +123,42 @@ def evaluation_psnr(images_rays: Sequence[torch.Tensor], images_gt: Sequence[tor
 
 @torch.no_grad()
 def evaluation(images_rays: Sequence[torch.Tensor], images_gt: Sequence[torch.Tensor], img_wh: Tuple[int, int], model, chunk=4096,
-               device="cuda", compute_extra_metrics=True, **render_kw):
+               device="cuda", compute_extra_metrics=True, ws_metrics=False, **render_kw):
     """renderer.py:82-196 without the file output: per image render -> clamp -> PSNR (:156-157) and, with
     compute_extra_metrics, rgb_ssim (:160; LPIPS omitted).  Rays are sharded over the ranks of the default process group; the
-    image is gathered to rank 0 for the windowed SSIM, whose value is then broadcast.  Returns (PSNRs, ssims)."""
+    image is gathered to rank 0 for the windowed SSIM, whose value is then broadcast.  Returns (PSNRs, ssims); with
+    ws_metrics=True (the reference's `TODO: add WS-PSNR, WS-SSIM`, renderer.py:89, with extra/ws_ssim.py's latitude weights)
+    (PSNRs, ssims, ws_psnrs, ws_ssims) for equirectangular images."""
     import torch.distributed as dist
-    from .metrics import rgb_ssim
+    from .metrics import rgb_ssim, ws_psnr, ws_ssim
     W, H = img_wh
     distributed = dist.is_available() and dist.is_initialized()
     rank = dist.get_rank() if distributed else 0
     was_training = model.training
     model.eval()
-    psnrs, ssims = [], []
+    psnrs, ssims, wpsnrs, wssims = [], [], [], []
     render_kw = dict(render_kw, empty_gpu_cache=False)  # see evaluation_psnr
     for rays, gt in zip(images_rays, images_gt):
         fn = lambda block: volume_renderer(block, model, chunk=chunk, device=device, keep_alpha=False, **render_kw)[0]
-        out = sharded_render(fn, rays.view(-1, rays.shape[-1]), gt.view(-1, 3), gather_image=compute_extra_metrics)
+        out = sharded_render(fn, rays.view(-1, rays.shape[-1]), gt.view(-1, 3), gather_image=compute_extra_metrics or ws_metrics)
         psnrs.append(out["psnr"])
-        if compute_extra_metrics:
-            val = torch.zeros(1, dtype=torch.float64, device=out["rgb_local"].device)
+        if compute_extra_metrics or ws_metrics:
+            val = torch.zeros(3, dtype=torch.float64, device=out["rgb_local"].device)
             if rank == 0:
                 img = out["image"].clamp(0.0, 1.0).reshape(H, W, 3)
-                val[0] = rgb_ssim(img, gt.view(H, W, 3).to(img.device), 1)
+                ref = gt.view(H, W, 3).to(img.device)
+                if ws_metrics:
+                    val[0], val[2] = ws_ssim(img, ref, 1)
+                    val[1] = ws_psnr(img, ref)
+                else:
+                    val[0] = rgb_ssim(img, ref, 1)
             if distributed:
                 dist.broadcast(val, src=0)
-            ssims.append(float(val.item()))
+            if compute_extra_metrics:
+                ssims.append(float(val[0].item()))
+            if ws_metrics:
+                wpsnrs.append(float(val[1].item()))
+                wssims.append(float(val[2].item()))
     model.train(was_training)
-    return psnrs, ssims
+    return (psnrs, ssims, wpsnrs, wssims) if ws_metrics else (psnrs, ssims)
 

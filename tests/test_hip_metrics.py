@@ -56,6 +56,11 @@ def test_evaluation_psnr_and_ssim_of_an_erp_render():
     assert abs(psnrs[0] - (-10 * np.log10(mse))) <= 1e-3
     assert abs(ssims[0] - ref_ssim(img.view(H, W, 3).cpu().numpy(), gt.view(H, W, 3).cpu().numpy(), 1)) <= 1e-6
     assert 0.3 < ssims[0] < 1.0
+    # the same call with the latitude-weighted variants (extra/ws_ssim.py weights)
+    p2, s2, wp, wsim = evaluation([rays], [gt], (W, H), model, n_coarse=32, exp_sampling=True, ws_metrics=True)
+    assert p2 == psnrs and abs(s2[0] - ssims[0]) <= 1e-9
+    assert abs(wp[0] - metrics.ws_psnr(img.view(H, W, 3), gt.view(H, W, 3))) <= 1e-9
+    assert abs(wsim[0] - metrics.ws_ssim(img.view(H, W, 3), gt.view(H, W, 3))[1]) <= 1e-9 and 0.3 < wsim[0] < 1.0
 
 
 def test_ws_metrics(golden):
