@@ -3,8 +3,6 @@
 writable so train.py:328-329's per-step exponential decay reads unchanged.  One launch updates all 33 tensors."""
 from __future__ import annotations
 
-import ctypes as C
-
 import torch
 
 from . import _lib

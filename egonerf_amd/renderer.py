@@ -8,7 +8,6 @@ gloo in the CPU tests).
 """
 from __future__ import annotations
 
-import time
 from typing import Callable, List, Optional, Sequence, Tuple
 
 import numpy as np

@@ -545,7 +545,6 @@ def capture_omniblender():
     import json, tempfile
     from PIL import Image
     _tv.transforms.ToTensor = lambda: (lambda img: torch.from_numpy(np.asarray(img)).permute(2, 0, 1).float().div(255.0))
-    import tqdm as _tqdm
     from dataLoader.dataset_omniblender import OmniBlenderDataset
     from scipy.spatial.transform import Rotation
     frames, pix = [], {}
