@@ -37,7 +37,8 @@ N_RAYS, N_SAMPLES = 4096, 512
 HBM_PEAK_GBPS = 8000.0         # MI355X_MICROARCH.md: HBM3E 8 TB/s
 MFMA_F32_PEAK_TFLOPS = 157.3   # fp32-input MFMA dense peak
 MFMA_F16_PEAK_TFLOPS = 2500.0  # dense fp16/bf16 MFMA peak
-N_SIMD = 256 * 4
+N_CU = 256
+N_SIMD = N_CU * 4
 FLOP_PER_MFMA = {"f16x3": 2 * 32 * 32 * 16, "f16f8": 2 * 32 * 32 * 16, "f32": 2 * 32 * 32 * 2}  # v_mfma_f32_32x32x16_f16 / ..x2_f32
 CLK_PER_MFMA = {"f16x3": 32, "f16f8": 32, "f32": 64}   # issue-to-issue cycles of a dependent-free MFMA stream (tools/coissue_probe.hip)
 FP8_MFMA_PER_TILE = 36        # f16f8: v_mfma_scale_f32_32x32x64_f8f6f4 per 32-sample tile (5 + 4 step pairs x 4 m-tiles, csrc/ego_shade.hip)
@@ -284,6 +285,14 @@ def shade_roofline(prec: str, t_shade: float, M: int):
                        note="VALU + MFMA issue time per SIMD summed (fp32-FMA-class VALU competes with the matrix pipe, conversion-class VALU can run beside it: tools/agpr_coissue_probe.hip; an upper estimate of the issue time, not a hard bound)",
                        clk_per_mfma=CLK_PER_MFMA[prec], clk_per_fp8_mfma=CLK_PER_FP8_MFMA if n8 else None, clk_per_valu=CLK_PER_VALU,
                        bound_ms=bound_clk / (clock_ghz * 1e6), frac=bound_clk / (clock_ghz * 1e6) / (t_shade * 1e3)))
+        if clock_ghz is not None and "TA_BUSY_avr" in pmc and "SQ_INSTS_VMEM_RD_per_SE" in pmc:
+            # third resource: the vector L1's address / data path.  A wave64 global_load_dwordx4 occupies it for 16 clk whatever its
+            # active lanes (6.8 ns per instruction per CU at any occupancy: tools/l1_exec_probe.hip), so its floor is the load count
+            vmem = pmc["SQ_INSTS_VMEM_RD_per_SE"] * n_se
+            ta_ms = vmem * 16 / N_CU / (clock_ghz * 1e6)
+            out["l1"] = dict(note="vector L1 / texture-addresser path: 16 clk per wave64 dwordx4 load (tools/l1_exec_probe.hip); busy = TA_BUSY_avr / GRBM_GUI_ACTIVE of the counter pass",
+                             vmem_rd_insts_per_tile=vmem / tiles, bound_ms=ta_ms, frac=ta_ms / (t_shade * 1e3),
+                             ta_busy_frac_counter_pass=pmc["TA_BUSY_avr"] / pmc["GRBM_GUI_ACTIVE"])
     else:  # no committed counters: fall back to the algorithmic flop count (a lower bound of what the pipe executes)
         out.update(achieved=alg_tflops, frac=alg_tflops / peak, inputs=dict(source=None, note="no profiles/r*/pmc_traffic.json entry for " + kname))
     out["algorithmic"] = dict(flop_per_sample=FLOP_SAMPLE_SHADE, achieved_TFLOPs=alg_tflops, frac_of_peak=alg_tflops / peak,
