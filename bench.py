@@ -64,6 +64,8 @@ def parse():
     ap.add_argument("--erp-size", type=int, nargs=2, default=[1024, 2048], metavar=("H", "W"))
     ap.add_argument("--mask", action="store_true", help="erp: build the reference's alpha mask and apply it (TensorBase.forward semantics)")
     ap.add_argument("--term-eps", type=float, default=0.0, help="erp: early-termination threshold on the transmittance")
+    ap.add_argument("--density-shift", type=float, default=None, help="render: override the scene's density_shift (-8) to make the synthetic "
+                    "field more / less opaque: shows what the exact zero-weight tile skip does on surface-like scenes (not the headline workload)")
     ap.add_argument("--cpu-worker", nargs=2, type=int, metavar=("N_RAYS", "THREADS"), help=argparse.SUPPRESS)
     a = ap.parse_args()
     dflt = dict(render=(200, 10), train=(20, 3), erp=(4, 1))[a.config]  # render: 0.7 ms steps, amortise the barrier bracket
@@ -311,7 +313,7 @@ def shade_roofline(prec: str, t_shade: float, M: int):
 def run_render(a, rk: Ranks):
     from egonerf_amd import _lib
     dev = rk.dev
-    cfg = synth.SceneConfig()
+    cfg = synth.SceneConfig() if a.density_shift is None else synth.SceneConfig(density_shift=a.density_shift)
     weights = synth.make_weights(cfg, seed=1234)
     model = synth.build_model(cfg, weights, dev)
     rays = torch.from_numpy(synth.make_rays(N_RAYS, seed=1 + rk.rank)).to(dev)
@@ -358,7 +360,13 @@ def run_render(a, rk: Ranks):
         bound_ms = valu * CLK_PER_VALU / N_SIMD / (clk * 1e6)
         march["issue"] = dict(source=msrc, stale_vs_current_sources=mstale, valu_insts_per_launch=valu, valu_per_64_samples=valu / (M / 64),
                               effective_clock_GHz=clk, bound_ms=bound_ms, frac=bound_ms / (t_march * 1e3))
+    # exact tile skipping (always on in EgoNeRF.forward's eval path: 32-sample tiles whose weights are all exactly 0 are not shaded;
+    # the per-kernel timings above shade every tile): how much of THIS synthetic batch it skips
+    zero_tiles = float((w.view(-1, 32).max(dim=1).values == 0).float().mean()) if M % 32 == 0 else None
     roofline.update(other_kernels_ms=dict(k_march_density=t_march * 1e3, k_composite=t_comp * 1e3),
+                    exact_zero_weight_tile_skip=dict(enabled=os.environ.get("EGO_EXACT_SKIP", "1") != "0", tiles_skipped_frac=zero_tiles,
+                                                     note="bit-identical outputs (the reference adds w * rgb = 0 for those samples); the synthetic "
+                                                          "field is semi-transparent, so almost nothing is skipped here"),
                     march_density=march,
                     path_algorithmic_GBps=(B_DENSITY + B_APP) * M / (t_march + t_shade + t_comp) / 1e9)
 
@@ -410,7 +418,8 @@ def run_render(a, rk: Ranks):
                                 "correction terms in the MLP, 3x fp16 MFMA in the basis, fp32 accumulate)", "f32": "f32"}[model.mlp_precision],
                 data="synthetic",
                 config=dict(workload="OmniBlender barbershop shape: grid [150,172,516], 16x3/48x3 comps, MLP_Fea; "
-                                     "4096 rays x 512 samples, eval, no resampling (BASELINE configs[1])",
+                                     "4096 rays x 512 samples, eval, no resampling (BASELINE configs[1])"
+                                     + ("" if a.density_shift is None else f"; NON-HEADLINE variant: density_shift {a.density_shift}"),
                             rays_per_step_per_gpu=N_RAYS, samples_per_ray=N_SAMPLES, parallelism=f"ray-sharded x{rk.world}"),
                 roofline=roofline, cpu_baseline=cpu, cpu_baseline_single_process=cpu_single, parity=parity,
                 speedup_vs_cpu=None if cpu is None else rays_per_s / cpu["value"])

@@ -1021,9 +1021,11 @@ __global__ __launch_bounds__(512) void k_shade_h(ShadeArgs A) {
   const u32x4* BASH = TAB16 ? (const u32x4*)(A.packed + 2 * PACKED_FLOATS) : (const u32x4*)(blob + OFF_BASIS);
 
   // Tile order: a wave walks a contiguous run of tiles, i.e. along its rays (the angular taps of the next tile are the lines this
-  // wave's L1 just served: -1.5 % kernel time, A/B on one box).  With a tile mask (opt-in skipping) the tiles are dealt round-robin
-  // over all waves of the grid instead, so that runs of skipped tiles do not leave waves idle (EGO_SHADE_TILE_ORDER 0: always).
-  const bool walk = EGO_SHADE_TILE_ORDER && !(MODE == MODE_SHADE && A.tile_active);
+  // wave's L1 just served: -1.5..2.3 % kernel time against tiles dealt round-robin over the grid, A/B on one box).  Skipped tiles
+  // (tile mask) are the tails of rays and every wave owns whole rays; sharing the ACTIVE tiles evenly instead (prefix sums over the
+  // mask in the prologue, or chunks dealt through an atomic counter) was built and measured: DESIGN.md 4.3 (EGO_SHADE_TILE_ORDER 0:
+  // round-robin).
+  const bool walk = EGO_SHADE_TILE_ORDER;
   const int64_t n_wv = (int64_t)gridDim.x * 8;
   const int64_t per_wave = (n_tiles + n_wv - 1) / n_wv;
   const int64_t tile0 = walk ? ((int64_t)blockIdx.x * 8 + wave) * per_wave : (int64_t)blockIdx.x * 8 + wave;

@@ -18,6 +18,7 @@ reference's, so checkpoints interchange.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import List, Optional
 
 import math
@@ -295,6 +296,11 @@ class EgoNeRF(TensorBase):
         self.use_alpha_mask = False          # apply self.alphaMask with TensorBase.forward's semantics (sigma = 0 where empty)
         self.early_termination_eps = 0.0     # > 0: zero the weight of samples behind transmittance < eps
         self.use_weight_thres = False        # TensorBase.forward's app skip: samples with weight <= rayMarch_weight_thres get rgb = 0
+        # Exact skipping, on by default: 32-sample tiles whose weights are all exactly 0 are not shaded (ego_scene.weight_thres = 0).
+        # The outputs are bit-identical - the reference adds w * rgb = 0 for such samples (EgoNeRF.py:583) - and behind an opaque
+        # surface the fp32 transmittance underflows to 0 within a few samples, so this is what early termination amounts to.
+        # EGO_EXACT_SKIP=0 in the environment switches it off for A/B measurements.
+        self.skip_zero_weight_tiles = os.environ.get("EGO_EXACT_SKIP", "1") != "0"
         self.coarse_sigma_plane_yin, self.coarse_sigma_line_yin = [None] * 3, [None] * 3
         self.coarse_sigma_plane_yang, self.coarse_sigma_line_yang = [None] * 3, [None] * 3
         if self.coarse_sigma_grid_update_rule is not None:
@@ -525,7 +531,7 @@ class EgoNeRF(TensorBase):
         keys = tuple(p.data_ptr() for p in self.parameters()) + (None if self.envmap is None else self.envmap.emission.data_ptr(),
                                                                   self.use_alpha_mask, id(self.alphaMask), float(self.early_termination_eps),
                                                                   float(self.rayMarch_weight_thres) if self.use_weight_thres else None,
-                                                                  co.N_r, float(co.r0), float(co.far[0]), tuple(co.center.tolist()),
+                                                                  bool(self.skip_zero_weight_tiles), co.N_r, float(co.r0), float(co.far[0]), tuple(co.center.tolist()),
                                                                   tuple(t.data_ptr() for t in luts), float(self.distance_scale),
                                                                   float(self.density_shift), self.fea2denseAct)
         if self._scene_cache is not None and self._scene_cache[0] == keys and self._packed_versions == versions:
@@ -560,7 +566,7 @@ class EgoNeRF(TensorBase):
         if self.use_alpha_mask and self.alphaMask is not None:
             self.alphaMask.fill_scene(sc)
         sc.term_eps = float(self.early_termination_eps)
-        sc.weight_thres = float(self.rayMarch_weight_thres) if self.use_weight_thres else -1.0
+        sc.weight_thres = float(self.rayMarch_weight_thres) if self.use_weight_thres else (0.0 if self.skip_zero_weight_tiles else -1.0)
         if self.envmap is not None:
             em = self.envmap.emission.detach()
             if not em.is_contiguous():

@@ -121,9 +121,10 @@ typedef struct ego_scene {
   int32_t n_r_lut_fine;
   const float* r_lut_fine;
   int32_t n_r_fine;
-  /* Opt-in appearance skip of TensorBase.forward (models/tensorBase.py:482-487, `rayMarch_weight_thres`): < 0 = off (as in
-   * EgoNeRF.forward, which shades every sample); >= 0: a sample whose weight is <= weight_thres contributes colour 0 — its
-   * weight still counts in acc / depth — and 32-sample tiles without any sample above the threshold are not shaded. */
+  /* Appearance skip of TensorBase.forward (models/tensorBase.py:482-487, `rayMarch_weight_thres`): < 0 = off (every sample is
+   * shaded); >= 0: a sample whose weight is <= weight_thres contributes colour 0 — its weight still counts in acc / depth — and
+   * 32-sample tiles without any sample above the threshold are not shaded.  weight_thres = 0 is EXACT (EgoNeRF.forward adds
+   * w * rgb = 0 for those samples, models/EgoNeRF.py:583) and is what the host layer sets by default. */
   float weight_thres;
 } ego_scene;
 

@@ -465,3 +465,36 @@ def test_fp16_appearance_tables(full):
         assert bool(torch.isfinite(feat16).all())
     finally:
         model.app_table_dtype = "f32"
+
+
+@pytest.mark.parametrize("kw", [dict(n_coarse=512), dict(n_coarse=96, n_fine=96, resampling=True, use_coarse_sample=True), dict(n_coarse=77)])
+def test_zero_weight_tile_skip_is_exact(kw, precision):
+    """The default-on tile skip (32-sample tiles whose weights are all exactly 0 are not shaded, ego_scene.weight_thres = 0) must
+    not change a bit of any output: the reference adds w * rgb = 0 for those samples (EgoNeRF.py:583).  Opaque variant of the
+    synthetic field (density_shift 0: the transmittance underflows behind the first surfaces), where most tiles are skipped."""
+    cfg = synth.SceneConfig(n_voxel=40 ** 3, density_shift=0.0)
+    model = make_model(cfg, synth.make_weights(cfg, seed=77), DEV)
+    model.mlp_precision = precision
+    rays = T(synth.make_rays(300, seed=5))
+    kw = dict(kw, exp_sampling=True)
+    assert model.skip_zero_weight_tiles  # the default
+    with torch.no_grad():
+        on = model(rays, **kw)
+        model.skip_zero_weight_tiles = False
+        off = model(rays, **kw)
+        # what the skip had to work with: weights of the last march, per 32-sample tile of the flat [N * S] order
+        xyz, z = model.sample_ray_exp(rays[:, :3], rays[:, 3:], is_train=False, N_samples=kw["n_coarse"])[:2] if "n_fine" not in kw else (None, None)
+    for a, b in zip(on, off):
+        if a is not None:
+            assert torch.equal(a, b)
+    if z is not None:
+        S = kw["n_coarse"]
+        c7 = model.coordinates.normalize_coord(model.coordinates.from_cartesian(xyz.reshape(-1, 3)))
+        sigma = model.feature2density(model.compute_densityfeature(c7)).view(-1, S)
+        dist = torch.cat([z[:, 1:] - z[:, :-1], z[:, -1:] - z[:, -2:-1]], -1)
+        from egonerf_amd.model import raw2alpha
+        w = raw2alpha(sigma, dist * model.distance_scale)[1].reshape(-1)
+        pad = (-w.numel()) % 32
+        tiles = torch.cat([w, w.new_zeros(pad)]).view(-1, 32)
+        frac = float((tiles.max(dim=1).values == 0).float().mean())
+        assert frac > (0.3 if S == 512 else 0.0)   # the scene really exercises the skip (tiles straddle rays at S = 77)
