@@ -236,6 +236,10 @@ __global__ __launch_bounds__(256) void k_march_density(DevCoords c, DevField F, 
   const float* R = rays + ray * 6;
   const float ox = R[0], oy = R[1], oz = R[2], dx = R[3], dy = R[4], dz = R[5];
   float carry = 1.f;
+  // Exact early termination: once the transmittance in front of a pass is exactly 0 (fp32 underflow behind opaque samples), every
+  // remaining weight is a * 0 = 0 and bg stays 0, so the rest of the ray only needs its distances and zero weights - unless the
+  // caller wants per-sample alpha / sigma, which are independent of what lies in front.
+  const bool may_stop = !alpha && !sigma_out;
   for (int s0 = 0; s0 < S; s0 += 64) {
     const int s = min(s0 + lane, S - 1);
     const bool ok = (s0 + lane) < S;
@@ -248,6 +252,15 @@ __global__ __launch_bounds__(256) void k_march_density(DevCoords c, DevField F, 
     } else {
       z = sched_z(r_sched, jitter, ray, s, S, near_);
       zn = sched_z(r_sched, jitter, ray, sn, S, near_);
+    }
+    if (may_stop && carry == 0.f) {  // wave-uniform
+      if (ok) {
+        const int64_t o = ray * S + s;
+        if (z_out) z_out[o] = z;
+        if (coords_out) ((f32x4*)coords_out)[o] = f32x4{0.f, 0.f, 0.f, 0.f};  // never shaded (tile flags stay 0); defined values anyway
+        if (weight) weight[o] = 0.f;
+      }
+      continue;
     }
     const float dist = (s < S - 1) ? __fsub_rn(zn, z) : __fsub_rn(z, zn);
     const float px = __fadd_rn(ox, __fmul_rn(dx, z)), py = __fadd_rn(oy, __fmul_rn(dy, z)),

@@ -277,6 +277,7 @@ class YinYangAlphaGridMask(torch.nn.Module):
 
 
 class EgoNeRF(TensorBase):
+    supports_need_alpha = True  # forward(..., need_alpha=False): see volume_renderer(keep_alpha=False)
     def __init__(self, aabb, gridSize, device, coordinates, **kargs):
         super().__init__(aabb, gridSize, device, coordinates, **kargs)
         assert isinstance(coordinates, YinYangSphericalCoords), "EgoNeRF needs YinYangSphericalCoords (EgoNeRF.py:522)"
@@ -713,10 +714,12 @@ class EgoNeRF(TensorBase):
     @_lib.device_guard
     def forward(self, rays_chunk, white_bg=True, is_train=False, ndc_ray=False, n_coarse=-1, n_fine=0, exp_sampling=False,
                 pretrain_envmap=False, pivotal_sample_th=0.0, resampling=False, use_coarse_sample=True, interval_th=False,
-                jitter: Optional[torch.Tensor] = None, u: Optional[torch.Tensor] = None):
+                jitter: Optional[torch.Tensor] = None, u: Optional[torch.Tensor] = None, need_alpha: bool = True):
         """EgoNeRF.forward (EgoNeRF.py:491-602) -> (rgb_map [N,3], depth_map [N], bg_map|None, env_map|None,
         alpha [N, S(+1)]).  `white_bg`, `pivotal_sample_th`, `interval_th` are accepted and unused, as in the
-        reference.  `jitter` [N,n_coarse] / `u` [N,n_fine] pin the is_train noise."""
+        reference.  `jitter` [N,n_coarse] / `u` [N,n_fine] pin the is_train noise.  `need_alpha=False` (eval only; what
+        `volume_renderer(keep_alpha=False)` passes) returns None for the per-sample alpha, which also lets the ray march stop
+        evaluating a ray once its transmittance is exactly 0 (the remaining weights are exactly 0 either way)."""
         _require_cuda(rays_chunk, "EgoNeRF.forward")
         if rays_chunk.dim() != 2 or rays_chunk.shape[1] < 6:
             raise IndexError(f"EgoNeRF.forward: rays_chunk must be [N, >=6] (origin, direction), got {tuple(rays_chunk.shape)}")
@@ -776,11 +779,11 @@ class EgoNeRF(TensorBase):
         has_env = self.envmap is not None
         rgb_map = torch.empty(N, 3, device=dev)
         depth = torch.empty(N, device=dev)
-        alpha = torch.empty(N, S + int(has_env), device=dev)
+        alpha = torch.empty(N, S + int(has_env), device=dev) if need_alpha else None
         bg_map = torch.empty(N, 3, device=dev) if has_env else None
         env_map = torch.empty(N, 3, device=dev) if has_env else None
         _call("ego_render_forward", sc, C.byref(args), rays.data_ptr(), N, ws.data_ptr(), rgb_map.data_ptr(), depth.data_ptr(),
-              alpha.data_ptr(), _lib.ptr(bg_map), _lib.ptr(env_map), _lib.stream_handle())
+              _lib.ptr(alpha), _lib.ptr(bg_map), _lib.ptr(env_map), _lib.stream_handle())
         return rgb_map, depth, bg_map, env_map, alpha
 
     # -- checkpoints (EgoNeRF.py:158-187) -----------------------------------------------------------------------------

@@ -26,10 +26,12 @@ def volume_renderer(rays, model, chunk=4096, n_coarse=-1, n_fine=0, ndc_ray=Fals
     n_all = rays.shape[0]
     for lo in range(0, max(n_all, 1), chunk):  # an empty ray list still makes one (empty) call, so the outputs keep their shapes
         rays_chunk = rays[lo:lo + chunk].to(device)
+        kw = dict(jitter=None if jitter is None else jitter[lo:lo + chunk], u=None if u is None else u[lo:lo + chunk])
+        if not keep_alpha and getattr(model, "supports_need_alpha", False):
+            kw["need_alpha"] = False  # this package's EgoNeRF: no [N,S] alpha buffer, and the march may stop at transmittance 0
         o = model(rays_chunk, is_train=is_train, white_bg=white_bg, ndc_ray=ndc_ray, n_coarse=n_coarse, n_fine=n_fine,
                   exp_sampling=exp_sampling, pivotal_sample_th=pivotal_sample_th, resampling=resampling,
-                  use_coarse_sample=use_coarse_sample, interval_th=interval_th,
-                  jitter=None if jitter is None else jitter[lo:lo + chunk], u=None if u is None else u[lo:lo + chunk])
+                  use_coarse_sample=use_coarse_sample, interval_th=interval_th, **kw)
         if not keep_alpha:
             o = o[:4] + (None,)
         if empty_gpu_cache:

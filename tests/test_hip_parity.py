@@ -480,13 +480,19 @@ def test_zero_weight_tile_skip_is_exact(kw, precision):
     assert model.skip_zero_weight_tiles  # the default
     with torch.no_grad():
         on = model(rays, **kw)
+        lean = model(rays, need_alpha=False, **kw)   # + the march stops evaluating a ray behind transmittance 0 (exact as well)
         model.skip_zero_weight_tiles = False
         off = model(rays, **kw)
+        lean_off = model(rays, need_alpha=False, **kw)
         # what the skip had to work with: weights of the last march, per 32-sample tile of the flat [N * S] order
         xyz, z = model.sample_ray_exp(rays[:, :3], rays[:, 3:], is_train=False, N_samples=kw["n_coarse"])[:2] if "n_fine" not in kw else (None, None)
     for a, b in zip(on, off):
         if a is not None:
             assert torch.equal(a, b)
+    assert lean[4] is None and lean_off[4] is None
+    for k in range(4):
+        if off[k] is not None:
+            assert torch.equal(lean[k], off[k]) and torch.equal(lean_off[k], off[k])
     if z is not None:
         S = kw["n_coarse"]
         c7 = model.coordinates.normalize_coord(model.coordinates.from_cartesian(xyz.reshape(-1, 3)))
