@@ -259,6 +259,7 @@ __global__ __launch_bounds__(256) void k_march_density(DevCoords c, DevField F, 
         if (z_out) z_out[o] = z;
         if (coords_out) ((f32x4*)coords_out)[o] = f32x4{0.f, 0.f, 0.f, 0.f};  // never shaded (tile flags stay 0); defined values anyway
         if (weight) weight[o] = 0.f;
+        if (tile_active && (S & 31) == 0 && (lane & 31) == 0) tile_active[o >> 5] = 0;
       }
       continue;
     }
@@ -316,7 +317,12 @@ __global__ __launch_bounds__(256) void k_march_density(DevCoords c, DevField F, 
       // a tile is shaded iff it holds a sample whose colour is read: weight > shade_above (0, or rayMarch_weight_thres)
       const unsigned long long nz = __ballot(ok && wgt > shade_above);
       const int64_t o = ray * S + s;
-      if (ok && (nz >> (lane & 32) & 0xffffffffull) != 0ull && ((lane & 31) == 0 || (o & 31) == 0)) tile_active[o >> 5] = 1;
+      if ((S & 31) == 0) {
+        // whole tiles per pass half: written unconditionally (0 or 1), so the caller need not clear the flags first
+        if (ok && (lane & 31) == 0) tile_active[o >> 5] = (nz >> (lane & 32) & 0xffffffffull) != 0ull ? 1 : 0;
+      } else if (ok && (nz >> (lane & 32) & 0xffffffffull) != 0ull && ((lane & 31) == 0 || (o & 31) == 0)) {
+        tile_active[o >> 5] = 1;  // tiles straddle rays: flags are pre-zeroed by the caller and only set here
+      }
     }
     if (ok) {
       const int64_t o = ray * S + s;

@@ -56,7 +56,7 @@ int ego_render_forward(const ego_scene* sc, const ego_render_args* a, const floa
   const float* z;
   // tile-level skipping only when a mask, early termination or the weight threshold is switched on (otherwise every sample is shaded)
   uint8_t* act = (sc->occ || sc->term_eps > 0.f || sc->weight_thres >= 0.f) ? (uint8_t*)(ws + p.act) : nullptr;
-  if (act) {
+  if (act && (S & 31) != 0) {  // with whole tiles per ray the march writes every flag itself (0 or 1)
     const hipError_t me = hipMemsetAsync(act, 0, (size_t)(N * (int64_t)S / 32 + 1), (hipStream_t)stream);
     if (me != hipSuccess) return ego_fail((int)me, "render_forward: hipMemsetAsync failed: %s", hipGetErrorString(me));
   }

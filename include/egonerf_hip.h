@@ -191,8 +191,9 @@ int ego_pack_mlp(const ego_scene* sc, float* packed_out, void* stream);
  * columns S.. are filled with 1, the reference's trailing ones column when an envmap is present,
  * EgoNeRF.py:587), weight [N][S], bg_weight [N], coords_out [N][S][4] = normalised (r, theta, phi) of the sample's
  * grid + is_yang flag (what ego_shade needs; saves it the acos/atan2/LUT search), sigma_out [N][S] (kept for the
- * backward pass), tile_active [ceil(N*S/32)] bytes, pre-zeroed by the caller: set to 1 for every 32-sample tile that
- * holds a non-zero weight (lets ego_shade skip tiles that are fully masked / terminated). */
+ * backward pass), tile_active [ceil(N*S/32)] bytes: 1 for every 32-sample tile that holds a weight above the shading
+ * threshold, 0 otherwise (lets ego_shade skip tiles that are fully masked / terminated).  When S is a multiple of 32 every
+ * flag is written; otherwise tiles straddle rays, flags are only ever set to 1 and the caller must zero them first. */
 int ego_march_density(const ego_scene* sc, const float* rays, int64_t N, int32_t S, const float* z_in,
                       const float* r_sched, const float* jitter, float near_, int32_t coarse, float* z_out,
                       float* alpha, int32_t alpha_stride, float* weight, float* bg_weight, float* coords_out, float* sigma_out,

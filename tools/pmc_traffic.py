@@ -4,14 +4,18 @@ roofline.traffic (FETCH_SIZE is in KB and counts 32-byte requests as 64 on gfx95
 /opt/skills/guides/MI355X_MICROARCH.md; WRITE_SIZE x 1024).  `_source_hash` records the library sources the counters belong
 to (egonerf_amd.build.source_hash of the working tree: run this right after the profile, before editing kernels).
 
-    python tools/pmc_traffic.py <tag> [round]        e.g.  python tools/pmc_traffic.py v1 r02
+    python tools/pmc_traffic.py <tag> [round] [--out=file]       e.g.  python tools/pmc_traffic.py v1 r02
+(tools/profile_gpu.sh runs it on the GPU box with --out=gpurun_out/prof_<tag>/pmc_traffic.json and then deletes the rocprofv3
+databases, which exceed what gpurun copies back; copy that file to profiles/<round>/pmc_traffic.json)
 """
 import glob, json, os, sqlite3, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, root)
 from egonerf_amd.build import source_hash
-tag = sys.argv[1] if len(sys.argv) > 1 else "v1"
-rnd = sys.argv[2] if len(sys.argv) > 2 else "r02"
+argv = [a for a in sys.argv[1:] if not a.startswith("--out=")]
+out_path = next((a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--out=")), None)  # on the GPU box: write next to the passes
+tag = argv[0] if len(argv) > 0 else "v1"
+rnd = argv[1] if len(argv) > 1 else "r02"
 src = os.path.join(root, "gpurun_out", f"prof_{tag}")
 names = {"k_shade_h<SHADE>": "%k_shade_h<0, false, false, false>%", "k_shade_h<SHADE,f16f8>": "%k_shade_h<0, false, false, true>%",
          "k_shade<SHADE>": "%k_shade<0%", "k_march_density<16>": "%k_march_density%",
@@ -40,6 +44,7 @@ for short, d in out.items():
         d["traffic_bytes"] = d["hbm_read_bytes_corrected"] + d["hbm_write_bytes"]
 out["_source"] = f"gpurun_out/prof_{tag} (tools/profile_gpu.sh {tag}; separate rocprofv3 --pmc passes of `bench.py --steps 10 --warmup 2`)"
 out["_source_hash"] = source_hash()
-os.makedirs(os.path.join(root, "profiles", rnd), exist_ok=True)
-json.dump(out, open(os.path.join(root, "profiles", rnd, "pmc_traffic.json"), "w"), indent=1)
+dst = out_path or os.path.join(root, "profiles", rnd, "pmc_traffic.json")
+os.makedirs(os.path.dirname(dst), exist_ok=True)
+json.dump(out, open(dst, "w"), indent=1)
 print(json.dumps({k: v.get("traffic_bytes") for k, v in out.items() if isinstance(v, dict)}))

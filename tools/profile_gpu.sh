@@ -41,3 +41,7 @@ for p in sorted(glob.glob(out + "/pmc_*/**/*.db", recursive=True)):
 open(os.path.join(out, "summary.txt"), "w").write("\n".join(lines) + "\n")
 print("\n".join(lines)[:7000])
 PY
+# counters -> compact json next to the passes, then drop the databases (tens of MB; gpurun copies back at most 64 MB)
+python "$ROOT/tools/pmc_traffic.py" "$TAG" r02 --out="$OUT/pmc_traffic.json" > /dev/null
+find "$OUT" -name "*.db" -delete
+find "$OUT" -name "*.csv" -size +1M -delete
