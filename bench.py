@@ -388,6 +388,23 @@ def run_render(a, rk: Ranks):
     model.mlp_precision = main_prec
     roofline["alt_precision"] = alt
 
+    # opt-in lossy early termination (model.early_termination_eps; not the headline: EgoNeRF.forward shades every sample and the
+    # default path only skips what is exactly zero): same step with weights behind transmittance < 1e-5 dropped, and what it costs
+    with torch.no_grad():
+        exact = model(rays, **kw)
+        model.early_termination_eps = 1e-5
+        for _ in range(10):
+            lossy = model(rays, **kw)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(50):
+            model(rays, **kw)
+        e1.record()
+        torch.cuda.synchronize()
+        model.early_termination_eps = 0.0
+    roofline["alt_early_termination"] = dict(eps=1e-5, ms_per_step=e0.elapsed_time(e1) / 50, max_abs_rgb_diff_vs_default=float((lossy[0] - exact[0]).abs().max()),
+                                             note="opt-in (model.early_termination_eps), not part of `value`")
+
     cpu = cpu_single = parity = None
     if not a.no_cpu_baseline and rk.world == 1:  # the CPU baseline is timed at N=1 only
         cpu_single, ref, cpu_rays = cpu_baseline_single(cfg, weights, a.cpu_rays)
