@@ -127,6 +127,36 @@ def test_product_never_imports_the_oracle():
                 assert "import oracle" not in text and "from oracle" not in text, f
 
 
+def test_volume_renderer_passes_need_alpha_only_to_models_that_take_it():
+    """keep_alpha=False drops the per-sample alpha; only this package's EgoNeRF (supports_need_alpha) is told not to produce it
+    at all - a model with the reference's exact forward signature must keep working."""
+    import torch
+    from egonerf_amd.renderer import volume_renderer
+    seen = []
+
+    class RefLike:
+        def __call__(self, rays_chunk, is_train=False, white_bg=True, ndc_ray=False, n_coarse=-1, n_fine=0, exp_sampling=False,
+                     pivotal_sample_th=0.0, resampling=False, use_coarse_sample=True, interval_th=False, jitter=None, u=None):
+            n = rays_chunk.shape[0]
+            return torch.zeros(n, 3), torch.zeros(n), None, None, torch.ones(n, n_coarse)
+
+    class Ours(RefLike):
+        supports_need_alpha = True
+
+        def __call__(self, rays_chunk, need_alpha=True, **kw):
+            seen.append(need_alpha)
+            out = RefLike.__call__(self, rays_chunk, **kw)
+            return out if need_alpha else out[:4] + (None,)
+
+    rays = torch.zeros(10, 6)
+    for model in (RefLike(), Ours()):
+        o = volume_renderer(rays, model, chunk=4, n_coarse=8, device="cpu", keep_alpha=False)
+        assert o[0].shape == (10, 3) and o[4] is None
+        o = volume_renderer(rays, model, chunk=4, n_coarse=8, device="cpu")
+        assert o[4].shape == (10, 8)
+    assert seen == [False] * 3 + [True] * 3
+
+
 def test_shard_bounds_partition():
     for n, w in ((10, 3), (2048 * 1024, 8), (5, 8), (0, 2)):
         blocks = [shard_bounds(n, w, r) for r in range(w)]
