@@ -370,6 +370,37 @@ def run_render(a, rk: Ranks):
                     march_density=march,
                     path_algorithmic_GBps=(B_DENSITY + B_APP) * M / (t_march + t_shade + t_comp) / 1e9)
 
+    # SURVEY 8(d)'s second figure: the UNIQUE texel footprint of the batch (per ray: distinct taps of its samples in each plane / line
+    # of its grid), i.e. what the gathers would read if every ray kept its texels - between the algorithmic tap bytes (every tap of
+    # every sample) and the counter-measured HBM traffic (what the caches did not absorb)
+    def unique_taps(res):
+        flat = crd.view(N_RAYS, N_SAMPLES, 4)
+        g = (flat[..., 3] != 0).long()
+        idx = []
+        for a_, n in enumerate(res):
+            ix = ((flat[..., a_] + 1.0) * (0.5 * (n - 1))).floor().long()
+            idx.append((ix.clamp(0, n - 1), (ix + 1).clamp(0, n - 1)))
+
+        def distinct(keys):  # [N, K] -> number of distinct keys per ray, summed
+            ks, _ = torch.sort(keys, dim=1)
+            return int((1 + (ks[:, 1:] != ks[:, :-1]).sum(dim=1)).sum())
+        total = 0
+        for (ax, ay) in ((0, 1), (0, 2), (1, 2)):   # planes (x, y)
+            keys = [(g * res[ay] + y) * res[ax] + x for x in idx[ax] for y in idx[ay]]
+            total += distinct(torch.cat(keys, dim=1))
+        for al in (2, 1, 0):                         # lines
+            total += distinct(torch.cat([g * res[al] + l for l in idx[al]], dim=1))
+        return total
+    try:
+        taps = unique_taps([int(v) for v in model.gridSize.tolist()])
+        fp_app, fp_dens = taps * 48 * 4, taps * 16 * 4
+        roofline["unique_footprint"] = dict(texels_per_ray=taps / N_RAYS, app_bytes_per_launch=fp_app, density_bytes_per_launch=fp_dens,
+                                            shade_GBps=fp_app / t_shade / 1e9, frac_of_hbm_peak=fp_app / t_shade / 1e9 / HBM_PEAK_GBPS,
+                                            note="per-ray distinct taps x channel bytes (fp32): SURVEY 8(d)'s unique-footprint figure, "
+                                                 "next to hbm_algorithmic (every tap of every sample) and traffic (HBM counters)")
+    except Exception as e:  # a reporting extra: never fail the bench line over it
+        roofline["unique_footprint"] = dict(error=repr(e))
+
     # A/B of the other fp16-split arithmetic on the same launch (shade kernel only; the rest of the step does not depend on it)
     main_prec = model.mlp_precision
     alt = {}
