@@ -410,6 +410,11 @@ def run_render(a, rk: Ranks):
         model.mlp_precision = prec
         sc2 = model.scene()
         e2 = [torch.cuda.Event(enable_timing=True) for _ in range(21)]
+        t_end = time.perf_counter() + 0.1   # untimed ramp, as for the headline: the host-side work above let the clocks drop
+        while time.perf_counter() < t_end:
+            for _ in range(8):
+                _lib.check(lib.ego_shade(sc2, rays.data_ptr(), z.data_ptr(), crd.data_ptr(), N_RAYS, N_SAMPLES, rgb.data_ptr(), None, None, st), "shade")
+            torch.cuda.synchronize()
         for i in range(23):
             if i >= 2:
                 e2[i - 2].record()
