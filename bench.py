@@ -555,7 +555,9 @@ def run_erp(a, rk: Ranks):
     H, W = a.erp_size
     cfg = synth.SceneConfig(**synth.RICOH)
     model = synth.build_model(cfg, synth.make_weights(cfg, seed=1234), dev)
-    kw = dict(chunk=65536, n_coarse=128, n_fine=128, exp_sampling=True, resampling=True, use_coarse_sample=True, device=dev,
+    # 16384-ray chunks: the per-chunk workspace (coords, colours, weights: 150 MB at 256 samples) then stays inside the 256 MB Infinity
+    # Cache between the march that writes it and the shade / composite that read it (65536: 0.168-0.171 s per image, 16384: 0.165)
+    kw = dict(chunk=int(os.environ.get("EGO_ERP_CHUNK", "16384")), n_coarse=128, n_fine=128, exp_sampling=True, resampling=True, use_coarse_sample=True, device=dev,
               keep_alpha=False)  # an image render reads rgb only (renderer.py:125-157)
     row0, row1 = shard_bounds(H, rk.world, rk.rank)  # contiguous block of rows per rank
     K = a.views or max(a.steps, 1)
