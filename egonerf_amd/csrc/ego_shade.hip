@@ -838,6 +838,9 @@ __device__ __forceinline__ void basis3(const u32x4* __restrict__ BASH, int lane,
 #ifndef EGO_SHADE_TILE_ORDER
 #define EGO_SHADE_TILE_ORDER 1
 #endif
+#ifndef EGO_SHADE_WINDOWS
+#define EGO_SHADE_WINDOWS 1
+#endif
 template <bool ROLL>
 __device__ __forceinline__ void gather_basis_team(const DevField& F, const TeamSample ts[2], const u32x4* __restrict__ BASH, int lane,
                                                   int g, bool mixed, int gu, f32x16& fe, float* vdump) {
@@ -1031,8 +1034,23 @@ __global__ __launch_bounds__(512) void k_shade_h(ShadeArgs A) {
   const int64_t tile0 = walk ? ((int64_t)blockIdx.x * 8 + wave) * per_wave : (int64_t)blockIdx.x * 8 + wave;
   const int64_t tile1 = walk ? (tile0 + per_wave < n_tiles ? tile0 + per_wave : n_tiles) : n_tiles;
   const int64_t tstep = walk ? 1 : n_wv;
+#if EGO_SHADE_WINDOWS
+  // the tile mask is read 64 tiles at a time (one byte per lane + ballot) and walked with find-first-set: a skipped tile costs no
+  // memory round trip (the per-tile flag load sat on the critical path of every skipped tile)
+  for (int64_t wbase = tile0; wbase < tile1; wbase += 64 * tstep) {
+    unsigned long long wmask;
+    {
+      const int64_t t = wbase + (int64_t)lane * tstep;
+      const bool in = t < tile1;
+      wmask = (MODE == MODE_SHADE && A.tile_active) ? __ballot(in && A.tile_active[in ? t : tile0] != 0) : __ballot(in);
+    }
+  while (wmask != 0ull) {
+    const int64_t tile = wbase + (int64_t)__builtin_ctzll(wmask) * tstep;
+    wmask &= wmask - 1ull;
+#else
   for (int64_t tile = tile0; tile < tile1; tile += tstep) {
     if (MODE == MODE_SHADE && A.tile_active && !A.tile_active[tile]) continue;
+#endif
     int lw = lane;
     asm volatile("" : "+v"(lw));  // keeps the LDS weight reads inside the loop (see k_shade)
     if (EGO_PRIO_VARIANT == 0 && MODE != MODE_MLP) __builtin_amdgcn_s_setprio(2);
@@ -1340,6 +1358,9 @@ __global__ __launch_bounds__(512) void k_shade_h(ShadeArgs A) {
       o[2] = sigmoidf(o2 + b3[2]);
     }
   }
+#if EGO_SHADE_WINDOWS
+  }
+#endif
 }
 
 #include "ego_train.inc"
