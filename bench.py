@@ -37,18 +37,26 @@ N_RAYS, N_SAMPLES = 4096, 512
 HBM_PEAK_GBPS = 8000.0         # MI355X_MICROARCH.md: HBM3E 8 TB/s
 MFMA_F32_PEAK_TFLOPS = 157.3   # fp32-input MFMA dense peak
 MFMA_F16_PEAK_TFLOPS = 2500.0  # dense fp16/bf16 MFMA peak
+MFMA_F8_PEAK_TFLOPS = 5000.0   # dense MX-fp8 peak
 N_CU = 256
 N_SIMD = N_CU * 4
-FLOP_PER_MFMA = {"f16x3": 2 * 32 * 32 * 16, "f16f8": 2 * 32 * 32 * 16, "f32": 2 * 32 * 32 * 2}  # v_mfma_f32_32x32x16_f16 / ..x2_f32
 CLK_PER_MFMA = {"f16x3": 32, "f16f8": 32, "f32": 64}   # issue-to-issue cycles of a dependent-free MFMA stream (tools/coissue_probe.hip)
-FP8_MFMA_PER_TILE = 36        # f16f8: v_mfma_scale_f32_32x32x64_f8f6f4 per 32-sample tile (5 + 4 step pairs x 4 m-tiles, csrc/ego_shade.hip)
-FLOP_PER_FP8_MFMA, CLK_PER_FP8_MFMA = 2 * 32 * 32 * 64, 61   # 1.9x an fp16 instruction (tools/fp8_mfma_probe.hip)
-FP8_CVT_PER_TILE = 144        # v_cvt_[scalef32_]pk_fp8_f32 per tile: 8 clk each, twice a plain conversion (tools/valu_rate_probe.hip)
-MFMA_F8_PEAK_TFLOPS = 5000.0  # dense MX-fp8 peak
-CLK_PER_VALU = 4                          # a wave64 VALU instruction occupies its SIMD for 4 cycles (16 lanes x 4)
-# algorithmic bytes / flops per sample: density 3*(4+2) taps * 16 ch * 4 B, appearance ... * 48 ch
-B_DENSITY, B_APP = 1152, 3456
-FLOP_SAMPLE_SHADE = 2 * (150 * 128 + 128 * 128 + 128 * 3) + 2 * 144 * 27  # MLP + basis
+CLK_PER_FP8_MFMA = 61          # 1.9x an fp16 instruction (tools/fp8_mfma_probe.hip)
+CLK_PER_VALU = 4               # a wave64 VALU instruction occupies its SIMD for 4 cycles (16 lanes x 4)
+B_DENSITY = 1152               # algorithmic density tap bytes per sample: 3 * (4 + 2) taps * 16 channels * 4 B
+PREC_CODE = {"f16x3": 0, "f32": 1, "f16f8": 2}
+
+
+def kernel_info(prec: str) -> dict:
+    """Per-tile instruction counts and the algorithmic per-sample figures of the shade kernel, exported by the library itself
+    (ego_shade_kernel_info computes them from the constants its loops run over), so they cannot go stale against the kernel."""
+    import ctypes
+    from egonerf_amd import _lib
+    out = (ctypes.c_int32 * 8)()
+    _lib.check(_lib.load().ego_shade_kernel_info(PREC_CODE[prec], out, 8), "ego_shade_kernel_info")
+    keys = ("samples_per_tile", "mfma_per_tile", "fp8_mfma_per_tile", "flop_per_mfma", "flop_per_fp8_mfma", "fp8_cvt_per_tile",
+            "flop_per_sample", "app_tap_bytes_per_sample")
+    return dict(zip(keys, (int(v) for v in out)))
 
 
 def parse():
@@ -58,6 +66,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--config", choices=["render", "train", "erp"], default="render")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="render: skip the short train / erp runs that the default line carries as `secondary`")
     ap.add_argument("--cpu-rays", type=int, default=1024, help="rays in the single-process CPU-baseline sample")
     ap.add_argument("--train-reg", action="store_true", help="train: add the Ricoh configs' TV / L1 / ortho / entropy terms")
     ap.add_argument("--views", type=int, default=None, help="erp: images per step sequence (default = --steps)")
@@ -109,13 +118,21 @@ class Ranks:
         torch.cuda.set_device(local)
         self.dev = torch.device("cuda", local)
         self.dist = None
-        if self.world > 1:
+        # a launcher (torch.distributed.run sets RANK) gets a process group at ANY world size, so that `--nproc-per-node 1` exercises
+        # the RCCL code path (device-tensor all_reduce / barrier) on a one-GPU box
+        launched = all(k in os.environ for k in ("RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"))
+        if self.world > 1 or launched:
             import torch.distributed as dist
-            self.dist = dist
-            if self.shared:
-                dist.init_process_group("gloo")
-            else:
-                dist.init_process_group("nccl", device_id=self.dev)  # RCCL on ROCm
+            try:
+                if self.shared:
+                    dist.init_process_group("gloo")
+                else:
+                    dist.init_process_group("nccl", device_id=self.dev)  # RCCL on ROCm
+                self.dist = dist
+            except Exception:
+                if self.world > 1:
+                    raise
+                # one rank: the group is optional (a stray RANK in the environment must not cost the N = 1 line)
 
     def barrier(self):
         if self.dist is not None:
@@ -252,39 +269,47 @@ def load_pmc(kname: str, need: str = "SQ_INSTS_MFMA_per_SE"):
     return None, None, None
 
 
-def shade_roofline(prec: str, t_shade: float, M: int):
-    """The binding resource of the shade kernel is the SIMD's issue port: on CDNA4 VALU and MFMA time add up
-    (tools/coissue_probe.hip), so the headline is the matrix pipe (executed MFMA flop / dense peak, frac <= 1) with the
-    additive VALU+MFMA issue bound next to it; algorithmic bytes / HBM peak is kept as a labelled secondary that exceeds 1
-    because the 94 MB table set is L2 / Infinity-Cache resident."""
+def shade_roofline(prec: str, t_shade: float, M: int, kname_tag: str = "SHADE"):
+    """Roofline object of the dominant kernel (shade: appearance gather + basis + PE + MLP).
+
+    `achieved` / `frac` follow SURVEY 8(d): ALGORITHMIC flops per launch (basis + MLP_Fea, 79 712 flop per sample) / the kernel's
+    event-timed duration, against the dense fp16 MFMA datasheet peak (2.5 PFLOP/s; the fp32-input MFMA peak for `f32`).  Next to
+    it, clearly labelled: `matrix_pipe_busy` (EXECUTED MFMA work incl. the precision-split overhead, each instruction kind against
+    its own dense peak), `traffic` (counter-measured HBM bytes per launch) and `hbm_counter_frac` (traffic / time / 8 TB/s)."""
+    info = kernel_info(prec)
     kname = {"f16x3": "k_shade_h<SHADE>", "f16f8": "k_shade_h<SHADE,f16f8>", "f32": "k_shade<SHADE>"}[prec]
     pmc, src, stale = load_pmc(kname)
-    shade_bytes = (B_APP + 16 + 12) * M      # gathered taps + 16 B coords read + 12 B rgb write, per sample
-    alg_tflops = FLOP_SAMPLE_SHADE * M / t_shade / 1e12
     peak = MFMA_F32_PEAK_TFLOPS if prec == "f32" else MFMA_F16_PEAK_TFLOPS
-    out = dict(bound="mfma", kernel=kname, unit="TFLOP/s", peak=peak, ms=t_shade * 1e3, traffic=None)
+    alg_flop = info["flop_per_sample"] * M
+    alg_tflops = alg_flop / t_shade / 1e12
+    tap_bytes = (info["app_tap_bytes_per_sample"] + 16 + 12) * M   # gathered taps + 16 B coords read + 12 B rgb write, per sample
+    out = dict(bound="mfma", kernel=kname, unit="TFLOP/s", achieved=alg_tflops, peak=peak, frac=alg_tflops / peak, traffic=None,
+               ms=t_shade * 1e3, algorithmic_flop_per_launch=alg_flop, flop_per_sample=info["flop_per_sample"],
+               definition="achieved = algorithmic flops (basis + MLP_Fea, tensorBase.py:54-78) per launch / event-timed kernel duration; "
+                          "peak = dense fp16 MFMA datasheet peak" if prec != "f32" else "achieved = algorithmic flops / duration; peak = fp32-input MFMA peak")
+    tiles = M / info["samples_per_tile"]
     if pmc is not None:
         n_se = 32
-        tiles = M / 32
         mfma = pmc["SQ_INSTS_MFMA_per_SE"] * n_se
         valu = pmc["SQ_INSTS_VALU_per_SE"] * n_se - mfma   # SQ_INSTS_VALU counts the MFMAs too
-        n8 = FP8_MFMA_PER_TILE * tiles if prec == "f16f8" else 0.0
+        n8 = info["fp8_mfma_per_tile"] * tiles
         n16 = mfma - n8
-        flops16, flops8 = n16 * FLOP_PER_MFMA[prec], n8 * FLOP_PER_FP8_MFMA
-        executed = (flops16 + flops8) / t_shade / 1e12
-        # fraction of the matrix pipe's time: each instruction kind against its own dense peak (fp16 2.5 PF, MX-fp8 5 PF)
-        frac = (flops16 / (peak * 1e12) + flops8 / (MFMA_F8_PEAK_TFLOPS * 1e12)) / t_shade
+        flops16, flops8 = n16 * info["flop_per_mfma"], n8 * info["flop_per_fp8_mfma"]
+        busy = (flops16 / (peak * 1e12) + flops8 / (MFMA_F8_PEAK_TFLOPS * 1e12)) / t_shade
         clock_ghz = pmc["GRBM_GUI_ACTIVE"] / (pmc["duration_us"] * 1e3) if "duration_us" in pmc else None
-        cvt8 = FP8_CVT_PER_TILE * tiles if prec == "f16f8" else 0.0
+        cvt8 = info["fp8_cvt_per_tile"] * tiles
         bound_clk = (n16 * CLK_PER_MFMA[prec] + n8 * CLK_PER_FP8_MFMA + (valu + cvt8) * CLK_PER_VALU) / N_SIMD
-        out.update(achieved=executed, frac=frac, peak=executed / frac, traffic=pmc.get("traffic_bytes"),
+        traffic = pmc.get("traffic_bytes")
+        out.update(traffic=traffic,
+                   hbm_counter_frac=None if traffic is None else traffic / t_shade / (HBM_PEAK_GBPS * 1e9),
+                   matrix_pipe_busy=busy, executed_TFLOPs=(flops16 + flops8) / t_shade / 1e12,
                    inputs=dict(source=src, stale_vs_current_sources=stale, mfma_insts_per_launch=mfma, fp8_mfma_insts_per_launch=n8,
                                valu_insts_per_launch=valu, mfma_per_tile=mfma / tiles, valu_per_tile=valu / tiles,
-                               flop_per_mfma=FLOP_PER_MFMA[prec], flop_per_fp8_mfma=FLOP_PER_FP8_MFMA if n8 else None,
-                               peak_note="peak = executed flops / (time the same instruction mix takes at the dense peaks: fp16 2.5 PF, "
-                                         "MX-fp8 5 PF)" if n8 else None, effective_clock_GHz=clock_ghz),
+                               mfma_per_tile_from_library=info["mfma_per_tile"] + info["fp8_mfma_per_tile"],
+                               flop_per_mfma=info["flop_per_mfma"], flop_per_fp8_mfma=info["flop_per_fp8_mfma"] or None,
+                               effective_clock_GHz=clock_ghz),
                    issue=None if clock_ghz is None else dict(
-                       note="VALU + MFMA issue time per SIMD summed (fp32-FMA-class VALU competes with the matrix pipe, conversion-class VALU can run beside it: tools/agpr_coissue_probe.hip; an upper estimate of the issue time, not a hard bound)",
+                       note="VALU + MFMA issue time per SIMD summed (an upper estimate of the issue time, not a hard bound: conversion-class VALU runs beside the matrix pipe, fp32-FMA-class VALU competes with it, tools/agpr_coissue_probe.hip)",
                        clk_per_mfma=CLK_PER_MFMA[prec], clk_per_fp8_mfma=CLK_PER_FP8_MFMA if n8 else None, clk_per_valu=CLK_PER_VALU,
                        bound_ms=bound_clk / (clock_ghz * 1e6), frac=bound_clk / (clock_ghz * 1e6) / (t_shade * 1e3)))
         if clock_ghz is not None and "TA_BUSY_avr" in pmc and "SQ_INSTS_VMEM_RD_per_SE" in pmc:
@@ -295,15 +320,13 @@ def shade_roofline(prec: str, t_shade: float, M: int):
             out["l1"] = dict(note="vector L1 / texture-addresser path: 16 clk per wave64 dwordx4 load (tools/l1_exec_probe.hip); busy = TA_BUSY_avr / GRBM_GUI_ACTIVE of the counter pass",
                              vmem_rd_insts_per_tile=vmem / tiles, bound_ms=ta_ms, frac=ta_ms / (t_shade * 1e3),
                              ta_busy_frac_counter_pass=pmc["TA_BUSY_avr"] / pmc["GRBM_GUI_ACTIVE"])
-    else:  # no committed counters: fall back to the algorithmic flop count (a lower bound of what the pipe executes)
-        out.update(achieved=alg_tflops, frac=alg_tflops / peak, inputs=dict(source=None, note="no profiles/r*/pmc_traffic.json entry for " + kname))
-    out["algorithmic"] = dict(flop_per_sample=FLOP_SAMPLE_SHADE, achieved_TFLOPs=alg_tflops, frac_of_peak=alg_tflops / peak,
-                              note={"f16x3": "f16x3 executes 3 MFMA flops per algorithmic flop", "f32": None,
-                                    "f16f8": "per algorithmic flop of layers 1/2: one fp16 MFMA flop + two fp8 MFMA flops"}[prec])
-    gbps = shade_bytes / t_shade / 1e9
-    out["hbm_algorithmic"] = dict(bytes_per_launch=shade_bytes, achieved=gbps, peak=HBM_PEAK_GBPS, unit="GB/s", frac=gbps / HBM_PEAK_GBPS,
-                                  note="frac > 1 = cache-resident: algorithmic tap bytes are served by L1/L2/Infinity Cache, "
-                                       "not HBM; `traffic` is the counter-measured HBM bytes per launch")
+    else:
+        out["inputs"] = dict(source=None, note="no profiles/r*/pmc_traffic.json entry for " + kname)
+    out["hbm_algorithmic_GBps"] = tap_bytes / t_shade / 1e9
+    out["note"] = ("SURVEY 8(d)'s algorithmic tap bytes / time (hbm_algorithmic_GBps) exceed the 8 TB/s HBM peak because the 94 MB table set is "
+                   "resident in L2 / the 256 MiB Infinity Cache: the north_star's '>= 60 % HBM utilisation on the grid-sample kernel' is met on "
+                   "that algorithmic definition and does not apply physically (the counters see `traffic` bytes = hbm_counter_frac of the peak); "
+                   "the kernel is bound by SIMD instruction issue (`issue`), so the roofline is quoted against the matrix pipe")
     return out
 
 
@@ -368,7 +391,7 @@ def run_render(a, rk: Ranks):
                                                      note="bit-identical outputs (the reference adds w * rgb = 0 for those samples); the synthetic "
                                                           "field is semi-transparent, so almost nothing is skipped here"),
                     march_density=march,
-                    path_algorithmic_GBps=(B_DENSITY + B_APP) * M / (t_march + t_shade + t_comp) / 1e9)
+                    path_algorithmic_GBps=(B_DENSITY + kernel_info(model.mlp_precision)["app_tap_bytes_per_sample"]) * M / (t_march + t_shade + t_comp) / 1e9)
 
     # SURVEY 8(d)'s second figure: the UNIQUE texel footprint of the batch (per ray: distinct taps of its samples in each plane / line
     # of its grid), i.e. what the gathers would read if every ray kept its texels - between the algorithmic tap bytes (every tap of
@@ -401,27 +424,47 @@ def run_render(a, rk: Ranks):
     except Exception as e:  # a reporting extra: never fail the bench line over it
         roofline["unique_footprint"] = dict(error=repr(e))
 
-    # A/B of the other fp16-split arithmetic on the same launch (shade kernel only; the rest of the step does not depend on it)
+    # The other arithmetics on the same batch, each with its shade-kernel time AND its step-level time (the whole EgoNeRF.forward, event
+    # timed over 50 steps): "f16x3" = fp32-grade three-term fp16 split; "app_f16+f16f8" = the config name's literal "bf16" reading
+    # (half-precision appearance tables + f16f8 products).  Errors vs the oracle are filled in below (parity leg).
     main_prec = model.mlp_precision
     alt = {}
-    for prec in ("f16x3", "f16f8"):
-        if prec == main_prec:
-            continue
+
+    def time_variant(prec, app16):
         model.mlp_precision = prec
+        model.app_table_dtype = "f16" if app16 else "f32"
         sc2 = model.scene()
-        e2 = [torch.cuda.Event(enable_timing=True) for _ in range(21)]
+        shade = lambda: _lib.check(lib.ego_shade(sc2, rays.data_ptr(), z.data_ptr(), crd.data_ptr(), N_RAYS, N_SAMPLES, rgb.data_ptr(), None, None, st), "shade")
         t_end = time.perf_counter() + 0.1   # untimed ramp, as for the headline: the host-side work above let the clocks drop
         while time.perf_counter() < t_end:
             for _ in range(8):
-                _lib.check(lib.ego_shade(sc2, rays.data_ptr(), z.data_ptr(), crd.data_ptr(), N_RAYS, N_SAMPLES, rgb.data_ptr(), None, None, st), "shade")
+                shade()
             torch.cuda.synchronize()
+        e2 = [torch.cuda.Event(enable_timing=True) for _ in range(21)]
         for i in range(23):
             if i >= 2:
                 e2[i - 2].record()
-            _lib.check(lib.ego_shade(sc2, rays.data_ptr(), z.data_ptr(), crd.data_ptr(), N_RAYS, N_SAMPLES, rgb.data_ptr(), None, None, st), "shade")
+            shade()
         torch.cuda.synchronize()
-        alt[prec] = dict(shade_ms=float(np.mean([e2[i].elapsed_time(e2[i + 1]) for i in range(20)])))
-    model.mlp_precision = main_prec
+        shade_ms = float(np.mean([e2[i].elapsed_time(e2[i + 1]) for i in range(20)]))
+        with torch.no_grad():
+            for _ in range(10):
+                model(rays, **kw)
+            s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s0.record()
+            for _ in range(50):
+                model(rays, **kw)
+            s1.record()
+            torch.cuda.synchronize()
+        step_ms = s0.elapsed_time(s1) / 50
+        return dict(shade_ms=shade_ms, ms_per_step=step_ms, rays_per_s=N_RAYS / (step_ms * 1e-3))
+
+    variants = {"f16x3": ("f16x3", False), "f16f8": ("f16f8", False), "app_f16+f16f8": ("f16f8", True)}
+    for name, (prec, app16) in variants.items():
+        if name == main_prec:
+            continue
+        alt[name] = time_variant(prec, app16)
+    model.mlp_precision, model.app_table_dtype = main_prec, "f32"
     roofline["alt_precision"] = alt
 
     # opt-in lossy early termination (model.early_termination_eps; not the headline: EgoNeRF.forward shades every sample and the
@@ -451,12 +494,12 @@ def run_render(a, rk: Ranks):
         parity = dict(max_abs_rgb_err=err, psnr_vs_oracle_db=float(-10 * np.log10(max(mse, 1e-30))),
                       max_abs_depth_err=float((got[1].cpu() - ref[1]).abs().max()), rays=a.cpu_rays, mlp_precision=main_prec,
                       tolerance=dict(rgb=1e-4, depth=1e-3 * 23.3))
-        for prec in alt:
-            model.mlp_precision = prec
+        for name in alt:
+            model.mlp_precision, model.app_table_dtype = variants[name][0], ("f16" if variants[name][1] else "f32")
             with torch.no_grad():
                 g2 = model(cpu_rays.to(dev), **kw)
-            alt[prec]["max_abs_rgb_err"] = float((g2[0].cpu() - ref[0]).abs().max())
-        model.mlp_precision = main_prec
+            alt[name]["max_abs_rgb_err"] = float((g2[0].cpu() - ref[0]).abs().max())
+        model.mlp_precision, model.app_table_dtype = main_prec, "f32"
         try:
             cpu = cpu_baseline_all_cores()
         except Exception as e:  # the single-process figure still stands
@@ -481,22 +524,82 @@ def run_render(a, rk: Ranks):
 # =====================================================================================================
 # --config train (BASELINE configs[3])
 # =====================================================================================================
+TRAIN_RAYS, TRAIN_NC, TRAIN_NF = 8192, 128, 128
+
+
+def load_pmc_section(key: str):
+    """A whole-step section ("train_step" / "erp_image": HBM bytes summed over every kernel of one step, tools/pmc_traffic.py) of
+    the newest profiles/r*/pmc_traffic.json that has one."""
+    from egonerf_amd.build import source_hash
+    for path in sorted(glob.glob(os.path.join(REPO, "profiles", "r*", "pmc_traffic.json")), reverse=True):
+        try:
+            pmc = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        if key in pmc:
+            return pmc[key], os.path.relpath(path, REPO), pmc.get("_source_hash") != source_hash()
+    return None, None, None
+
+
+def cpu_baseline_train(cfg, weights, n_rays: int):
+    """The oracle's training step (EgoNeRF.forward is_train with 128+128 resampling -> MSE -> autograd backward -> torch.optim.Adam
+    over all 32 parameter tensors, train.py:245-330) on the host cores, on a bounded ray sample: rays/s = sample / (fwd + bwd) with
+    the Adam step (independent of the ray count) timed once and charged pro rata to a full 8192-ray step."""
+    from oracle.egonerf_oracle import OracleScene
+    logical = os.cpu_count() or 1
+    threads = min(32, logical)
+    torch.set_num_threads(threads)
+    sc = OracleScene(cfg, weights)
+    params = list(sc.w.values())
+    for v in params:
+        v.requires_grad_(True)
+    opt = torch.optim.Adam(params, lr=1e-3, betas=(0.9, 0.99))
+    rays = torch.from_numpy(synth.make_rays(n_rays, seed=1))
+    gt = torch.from_numpy(synth.hash_uniform(3, 0, n_rays * 3).reshape(n_rays, 3).astype(np.float32))
+    jit = torch.from_numpy(synth.hash_uniform(5, 0, n_rays * TRAIN_NC).reshape(n_rays, TRAIN_NC).astype(np.float32))
+    u = torch.from_numpy(synth.hash_uniform(6, 0, n_rays * TRAIN_NF).reshape(n_rays, TRAIN_NF).astype(np.float32))
+
+    def fwd_bwd(n):
+        sc.update_coarse_sigma_grid()
+        t0 = time.perf_counter()
+        rgb = sc.forward(rays[:n], n_coarse=TRAIN_NC, n_fine=TRAIN_NF, resampling=True, is_train=True, jitter=jit[:n], u=u[:n])[0]
+        loss = torch.mean((rgb - gt[:n]) ** 2)
+        t1 = time.perf_counter()
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        return t1 - t0, time.perf_counter() - t1
+
+    fwd_bwd(min(64, n_rays))          # warm-up (allocator, thread pool)
+    tf, tb = fwd_bwd(n_rays)
+    t0 = time.perf_counter()
+    opt.step()
+    t_adam = time.perf_counter() - t0
+    step_equiv = (tf + tb) * (TRAIN_RAYS / n_rays) + t_adam
+    return dict(value=TRAIN_RAYS / step_equiv, unit="rays/s", cores=threads, kind="port",
+                sample=f"oracle training step on {n_rays} rays x ({TRAIN_NC}+{TRAIN_NF}) samples with {threads} ATen threads: forward {tf:.2f} s, "
+                       f"backward {tb:.2f} s (scaled x{TRAIN_RAYS // n_rays} to the {TRAIN_RAYS}-ray step) + torch.optim.Adam over 24.7 M parameters "
+                       f"{t_adam:.2f} s (once per step) -> {step_equiv:.1f} s per {TRAIN_RAYS}-ray step (survey container, 8 threads: 22.8-27.1 s)",
+                forward_s=tf, backward_s=tb, adam_s=t_adam, seconds_per_8192_ray_step=step_equiv)
+
+
 def run_train(a, rk: Ranks):
+    from egonerf_amd import train as ego_train
     from egonerf_amd.losses import TVLoss, ray_entropy_loss
     from egonerf_amd.optim import FusedAdam
-    dev, N = rk.dev, 8192
+    dev, N = rk.dev, TRAIN_RAYS
     cfg = synth.SceneConfig()
-    model = synth.build_model(cfg, synth.make_weights(cfg, seed=1234), dev)
+    weights = synth.make_weights(cfg, seed=1234)
+    model = synth.build_model(cfg, weights, dev)
     model.train()
     rays = torch.from_numpy(synth.make_rays(N, seed=1 + rk.rank)).to(dev)
     gt = torch.from_numpy(synth.hash_uniform(3 + rk.rank, 0, N * 3).reshape(N, 3).astype(np.float32)).to(dev)
     opt = FusedAdam(model.get_optparam_groups(0.02, 1e-3), betas=(0.9, 0.99))  # train.py:176-186
     tv = TVLoss()
-    kw = dict(is_train=True, n_coarse=128, n_fine=128, exp_sampling=True, resampling=True, use_coarse_sample=True)
+    kw = dict(is_train=True, n_coarse=TRAIN_NC, n_fine=TRAIN_NF, exp_sampling=True, resampling=True, use_coarse_sample=True)
     losses = []
 
     def forward():
-        rgb, _, _, _, alpha = model(rays, jitter=torch.rand(N, 128, device=dev), u=torch.rand(N, 128, device=dev), **kw)
+        rgb, _, _, _, alpha = model(rays, jitter=torch.rand(N, TRAIN_NC, device=dev), u=torch.rand(N, TRAIN_NF, device=dev), **kw)
         loss = torch.mean((rgb - gt) ** 2)
         if a.train_reg:  # configs/EgoNeRF/ricoh/common.txt:12-13 + opt.py defaults
             loss = loss + 1e-4 * model.vector_comp_diffs() + 8e-5 * model.density_L1() + 0.1 * model.TV_loss_density(tv) \
@@ -525,10 +628,65 @@ def run_train(a, rk: Ranks):
     model.update_coarse_sigma_grid()
     ev[3].record()
     torch.cuda.synchronize()
-    rays_per_s = rk.world * N * a.steps / dt
+    # per-call split of one step on ONE stream (the timed steps overlap the two table scatters with the HBM-bound kernels on a side
+    # stream, so these intervals sum to more than ms_per_step): events after every library call of the differentiable render
+    side = ego_train.SIDE_STREAM_SCATTER
+    ego_train.SIDE_STREAM_SCATTER = False
+    kernels = {}
+    try:
+        for rep in range(3):
+            marks = ego_train.KERNEL_MARKS = []
+            ego_train.mark("begin")
+            loss = forward()
+            opt.zero_grad(set_to_none=True)
+            loss.backward()
+            ego_train.mark("autograd_tail")
+            opt.step()
+            model.update_coarse_sigma_grid()
+            ego_train.mark("adam_and_coarse_refresh")
+            torch.cuda.synchronize()
+            ego_train.KERNEL_MARKS = None
+            if rep == 0:
+                continue  # first serialised step: allocator warm-up
+            seen = {}
+            for (n0, e0), (n1, e1) in zip(marks[:-1], marks[1:]):
+                k = seen[n1] = seen.get(n1, 0) + 1
+                name = n1 if n1 not in ("ego_march_density", "ego_weight_grad") else f"{n1}#{k}"
+                kernels[name] = kernels.get(name, 0.0) + e0.elapsed_time(e1) / 2
+    finally:
+        ego_train.KERNEL_MARKS = None
+        ego_train.SIDE_STREAM_SCATTER = side
+    t_step = dt / a.steps
+    rays_per_s = rk.world * N / t_step
+    # design traffic of one step: what the kernels exchange through memory by construction (activation dumps written by the forward and
+    # read by the shade backward + the weight-gradient passes, gradient activations, coordinates; per fine sample, fp32)
+    M = N * (TRAIN_NC + TRAIN_NF)
+    design = dict(forward_dumps_written=(160 + 128 + 128 + 144) * 4 * M, shade_bwd_read=(160 + 128 + 128) * 4 * M,
+                  shade_bwd_written=(128 + 128 + 64 + 144) * 4 * M, wgrad_read=(128 + 160 + 128 + 128 + 3 + 128 + 64 + 144) * 4 * M,
+                  scatter_read=(144 + 1 + 4 + 4) * 4 * M, adam=24_721_123 * 28)
+    design_total = float(sum(design.values()))
+    pmc, src, stale = load_pmc_section("train_step")
+    traffic = None if pmc is None else pmc.get("traffic_bytes")
+    roofline = dict(bound="hbm", unit="GB/s", peak=HBM_PEAK_GBPS, traffic=traffic,
+                    achieved=None if traffic is None else traffic / t_step / 1e9,
+                    frac=None if traffic is None else traffic / t_step / 1e9 / HBM_PEAK_GBPS,
+                    definition="achieved = counter-measured HBM bytes of ONE training step (FETCH_SIZE x 2 + WRITE_SIZE summed over every kernel "
+                               "of the step, separate rocprofv3 --pmc passes of this command) / ms_per_step; the step has no single dominant "
+                               "kernel, so the roofline is the step's",
+                    inputs=dict(source=src, stale_vs_current_sources=stale, per_kernel=None if pmc is None else pmc.get("per_kernel")),
+                    design_bytes_per_step=design_total, design_GBps=design_total / t_step / 1e9, design_breakdown=design,
+                    kernels_ms_serialised=kernels, kernels_ms_serialised_sum=sum(kernels.values()),
+                    note="kernels_ms_serialised: one step with the side stream off, intervals between events recorded after each library "
+                         "call (torch glue in front of a call is charged to it); #k = k-th call of that entry point in the step")
+    cpu = None
+    if not a.no_cpu_baseline and rk.world == 1:
+        try:
+            cpu = cpu_baseline_train(cfg, weights, 512)
+        except Exception as e:
+            cpu = dict(error=repr(e))
     return dict(metric="rays/sec, training step (forward + backward + FusedAdam + coarse-table refresh)", value=rays_per_s, unit="rays/s",
                 samples_per_s=rays_per_s * 384, n_gpus=rk.world, steps=a.steps, warmup=a.warmup, clock_ramp_s=RAMP_SECONDS,
-                ms_per_step=dt / a.steps * 1e3, higher_is_better=True, scaling="weak", vs_baseline=None,
+                ms_per_step=t_step * 1e3, higher_is_better=True, scaling="weak", vs_baseline=None,
                 dtype="f32 (tables, gradients, optimiser state; matrix products as fp16 / bf16 hi+lo MFMA with fp32 accumulate)",
                 data="synthetic",
                 config=dict(workload="OmniBlender barbershop shape: grid [150,172,516]; 8192 rays x (128 coarse + 128 fine) per step, "
@@ -537,27 +695,58 @@ def run_train(a, rk: Ranks):
                             rays_per_step_per_gpu=N, parallelism="independent replicas" if rk.world > 1 else "1 GPU"),
                 phases_ms=dict(forward=ev[0].elapsed_time(ev[1]), backward=ev[1].elapsed_time(ev[2]), adam_and_refresh=ev[2].elapsed_time(ev[3])),
                 loss_first=float(losses[a.warmup]), loss_last=float(losses[-1]), peak_mem_GB=torch.cuda.max_memory_allocated() / 2 ** 30,
-                roofline=None, cpu_baseline=None)
+                roofline=roofline, cpu_baseline=cpu,
+                speedup_vs_cpu=None if not cpu or "value" not in cpu else rays_per_s / cpu["value"])
 
 
 # =====================================================================================================
 # --config erp (BASELINE configs[2] and [4])
 # =====================================================================================================
+ERP_NC, ERP_NF = 128, 128
+
+
 def erp_pose(k: int, K: int) -> np.ndarray:
     ang = 2 * np.pi * k / max(K, 1)
     c, s = np.cos(ang), np.sin(ang)
     return np.array([[c, 0, s, 0.3 * c], [0, 1, 0, 0.05 * (k % 5)], [-s, 0, c, 0.3 * s]], np.float32)
 
 
+def cpu_baseline_erp(cfg, weights, H: int, W: int, n_rays: int):
+    """The oracle's 128+128 render (resampling, envmap on) of `n_rays` rays of the first view, spread evenly over the image."""
+    from oracle.egonerf_oracle import OracleScene, erp_rays_reference
+    logical = os.cpu_count() or 1
+    threads = min(32, logical)
+    torch.set_num_threads(threads)
+    sc = OracleScene(cfg, weights)
+    pose = torch.from_numpy(erp_pose(0, 1))
+    allr = erp_rays_reference(H, W, pose)
+    pick = torch.linspace(0, allr.shape[0] - 1, n_rays).long()
+    rays = allr[pick]
+    with torch.no_grad():
+        sc.forward(rays[:64], n_coarse=ERP_NC, n_fine=ERP_NF, resampling=True)
+        best = float("inf")
+        for _ in range(2):
+            t = time.perf_counter()
+            out = sc.forward(rays, n_coarse=ERP_NC, n_fine=ERP_NF, resampling=True)
+            best = min(best, time.perf_counter() - t)
+    return dict(value=n_rays / best, unit="rays/s", cores=threads, kind="port",
+                sample=f"oracle render of {n_rays} rays (evenly spaced pixels of view 0 of the {H}x{W} image) x ({ERP_NC}+{ERP_NF}) samples, envmap on, "
+                       f"best of 2 ({best:.2f} s) with {threads} ATen threads (survey container, 8 threads, 4096 x (128+128): 1 208 rays/s)"), out, rays, pick
+
+
 def run_erp(a, rk: Ranks):
+    from egonerf_amd import _lib
     from egonerf_amd.renderer import erp_rays, psnr_from_sse, shard_bounds, volume_renderer
     dev = rk.dev
     H, W = a.erp_size
-    cfg = synth.SceneConfig(**synth.RICOH)
-    model = synth.build_model(cfg, synth.make_weights(cfg, seed=1234), dev)
+    over = {} if a.density_shift is None else dict(density_shift=a.density_shift)
+    cfg = synth.SceneConfig(**dict(synth.RICOH, **over))
+    weights = synth.make_weights(cfg, seed=1234)
+    model = synth.build_model(cfg, weights, dev)
     # 16384-ray chunks: the per-chunk workspace (coords, colours, weights: 150 MB at 256 samples) then stays inside the 256 MB Infinity
     # Cache between the march that writes it and the shade / composite that read it (65536: 0.168-0.171 s per image, 16384: 0.165)
-    kw = dict(chunk=int(os.environ.get("EGO_ERP_CHUNK", "16384")), n_coarse=128, n_fine=128, exp_sampling=True, resampling=True, use_coarse_sample=True, device=dev,
+    chunk = int(os.environ.get("EGO_ERP_CHUNK", "16384"))
+    kw = dict(chunk=chunk, n_coarse=ERP_NC, n_fine=ERP_NF, exp_sampling=True, resampling=True, use_coarse_sample=True, device=dev,
               keep_alpha=False)  # an image render reads rgb only (renderer.py:125-157)
     row0, row1 = shard_bounds(H, rk.world, rk.rank)  # contiguous block of rows per rank
     K = a.views or max(a.steps, 1)
@@ -593,17 +782,110 @@ def run_erp(a, rk: Ranks):
             psnrs.append(psnr_from_sse(max(stat[0].item(), 1e-300), stat[1].item()))
     if rk.rank != 0:
         return None
-    rays_per_s = a.steps * H * W / dt
+    # ---- per-chunk kernel split, event-timed through the stage entry points (the same five launches ego_render_forward queues) ----
+    lib, st = _lib.load(), _lib.stream_handle()
+    sc = model.scene()
+    N, S = chunk, ERP_NC + ERP_NF
+    rays_c = erp_rays(H, W, erp_pose(0, K), dev, H // 3, max(1, -(-N // W)))[:N].contiguous()   # a chunk from the image's middle third
+    N = rays_c.shape[0]
+    f = lambda *shape: torch.empty(*shape, device=dev, dtype=torch.float32)
+    sched = model._sched(ERP_NC, dev)
+    zc, wc, z, w, bg, crd, rgb = f(N, ERP_NC), f(N, ERP_NC), f(N, S), f(N, S), f(N), f(N, S, 4), f(N, S, 3)
+    act = torch.empty(N * S // 32 + 1, device=dev, dtype=torch.uint8)
+    rgb_map, depth, bgm, envm = f(N, 3), f(N), f(N, 3), f(N, 3)
+    near = float(model.near_far[0])
+    names = ("k_march_density(coarse)", "k_sample_pdf_merge", "k_march_density(fine)", "k_shade", "k_composite")
+    reps = 12
+    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(6)] for _ in range(reps)]
+    for i in range(reps + 2):
+        e = evs[max(i - 2, 0)]
+        e[0].record()
+        _lib.check(lib.ego_march_density(sc, rays_c.data_ptr(), N, ERP_NC, None, sched.data_ptr(), None, near, 1, zc.data_ptr(), None, 0,
+                                         wc.data_ptr(), None, None, None, None, st), "march coarse")
+        e[1].record()
+        _lib.check(lib.ego_sample_pdf_merge(zc.data_ptr(), wc.data_ptr(), None, N, ERP_NC, ERP_NF, 1, z.data_ptr(), None, st), "pdf merge")
+        e[2].record()
+        _lib.check(lib.ego_march_density(sc, rays_c.data_ptr(), N, S, z.data_ptr(), None, None, near, 2, None, None, 0, w.data_ptr(), bg.data_ptr(),
+                                         crd.data_ptr(), None, act.data_ptr(), st), "march fine")
+        e[3].record()
+        _lib.check(lib.ego_shade(sc, rays_c.data_ptr(), z.data_ptr(), crd.data_ptr(), N, S, rgb.data_ptr(), None, act.data_ptr(), st), "shade")
+        e[4].record()
+        _lib.check(lib.ego_composite(sc, rays_c.data_ptr(), z.data_ptr(), w.data_ptr(), bg.data_ptr(), rgb.data_ptr(), N, S, rgb_map.data_ptr(),
+                                     depth.data_ptr(), bgm.data_ptr(), envm.data_ptr(), None, st), "composite")
+        e[5].record()
+    torch.cuda.synchronize()
+    ms = np.array([[e[k].elapsed_time(e[k + 1]) for k in range(5)] for e in evs]).mean(0)
+    split = {n: float(v) for n, v in zip(names, ms)}
+    tiles_skipped = float((act[: N * S // 32] == 0).float().mean())
+    roofline = shade_roofline(model.mlp_precision, float(ms[3]) * 1e-3, N * S)
+    pmc, src, stale = load_pmc_section("erp_image")
+    t_img = dt / a.steps
+    if pmc is not None and pmc.get("traffic_bytes") is not None:   # whole-image counters replace the headline kernel's per-launch ones
+        roofline.update(traffic=pmc["traffic_bytes"], hbm_counter_frac=pmc["traffic_bytes"] / t_img / (HBM_PEAK_GBPS * 1e9),
+                        traffic_scope="one whole image (every kernel of every chunk), " + str(src), traffic_stale_vs_current_sources=stale)
+    else:
+        roofline.update(traffic=None, hbm_counter_frac=None)
+    for k in ("issue", "l1", "inputs", "matrix_pipe_busy", "executed_TFLOPs"):   # those are derived from the 4096 x 512 launch's counters
+        roofline.pop(k, None)
+    roofline.update(chunk_rays=N, chunk_samples_per_ray=S, chunk_kernels_ms=split, chunk_kernels_ms_sum=float(ms.sum()),
+                    chunks_per_image=-(-(row1 - row0) * W // chunk), exact_zero_weight_tiles_skipped_frac_in_chunk=tiles_skipped,
+                    note="dominant kernel = k_shade on one chunk (flops as in the headline); chunk_kernels_ms = the five launches of a chunk, event "
+                         "timed through the stage entry points; traffic = counter HBM bytes of one whole image")
+    cpu = parity = None
+    if not a.no_cpu_baseline and rk.world == 1:
+        try:
+            cpu, ref_out, cpu_rays, pick = cpu_baseline_erp(cfg, weights, H, W, 1024)
+            with torch.no_grad():
+                full = erp_rays(H, W, erp_pose(0, 1), dev)
+                got = volume_renderer(full[pick.to(dev)], model, **kw)
+            err = float((got[0].cpu() - ref_out[0]).abs().max())
+            mse = float(((got[0].cpu() - ref_out[0]) ** 2).mean())
+            parity = dict(max_abs_rgb_err=err, psnr_vs_oracle_db=float(-10 * np.log10(max(mse, 1e-30))), rays=int(pick.numel()),
+                          note="device-generated rays vs the oracle's libm rays: a sample within an ulp of a yin/yang border may land on the "
+                               "other grid (DESIGN.md 2); tests/test_hip_ricoh.py handles that explicitly", tolerance=dict(rgb=1e-4))
+        except Exception as e:
+            cpu = dict(error=repr(e))
+    rays_per_s = H * W / t_img
     return dict(metric="rays/sec, full equirectangular image render (128 coarse + 128 fine samples, envmap on)", value=rays_per_s,
                 unit="rays/s", samples_per_s=rays_per_s * 384, n_gpus=rk.world, steps=a.steps, warmup=a.warmup, clock_ramp_s=RAMP_SECONDS,
-                ms_per_step=dt / a.steps * 1e3, s_per_image=dt / a.steps, higher_is_better=True, scaling="strong", vs_baseline=None,
+                ms_per_step=t_img * 1e3, s_per_image=t_img, higher_is_better=True, scaling="strong", vs_baseline=None,
                 dtype=f"f32 (matrix products: mlp_precision = {model.mlp_precision}, fp32 accumulate)", data="synthetic",
-                config=dict(workload=f"Ricoh360-like scene (near_far [0.1,300], r0 0.05, shift -10, envmap 3x3840x1920, grid [150,172,516]); "
-                                     f"a step = one {H}x{W} ERP image, rays generated on the device, rows sharded over the ranks "
-                                     f"(BASELINE configs[2]; configs[4] at --gpus 8)",
+                config=dict(workload=f"Ricoh360-like scene (near_far [0.1,300], r0 0.05, shift {cfg.density_shift:g}, envmap 3x3840x1920, grid [150,172,516]); "
+                                     f"a step = one {H}x{W} ERP image, rays generated on the device, rows sharded over the ranks, exact zero-weight "
+                                     f"tile skip on (BASELINE configs[2]; configs[4] at --gpus 8)",
                             alpha_mask=bool(a.mask), alpha_mask_occupied_fraction=occupied, term_eps=a.term_eps,
                             parallelism=f"row-sharded x{rk.world}"),
-                psnr_vs_f32_unskipped_db=psnrs, roofline=None, cpu_baseline=None)
+                psnr_vs_f32_unskipped_db=psnrs, roofline=roofline, cpu_baseline=cpu, parity=parity,
+                speedup_vs_cpu=None if not cpu or "value" not in cpu else rays_per_s / cpu["value"])
+
+
+def run_secondary(a, rk: Ranks):
+    """Short runs of the other single-GPU BASELINE configs, folded into the default line as `secondary` (N = 1 only): configs[3]
+    (training step) and configs[2] (full ERP image; once more on an opaque field, density_shift 0, which is what a trained scene
+    looks like to the exact zero-weight tile skip).  Each carries its own roofline and cpu_baseline."""
+    import copy
+    out = {}
+
+    def sub(**over):
+        b = copy.copy(a)
+        for k, v in over.items():
+            setattr(b, k, v)
+        return b
+
+    jobs = (("train", run_train, sub(config="train", steps=5, warmup=2, train_reg=False)),
+            ("erp", run_erp, sub(config="erp", steps=2, warmup=1, views=2, erp_size=[1024, 2048], mask=False, term_eps=0.0, density_shift=None)),
+            ("erp_opaque_field", run_erp, sub(config="erp", steps=2, warmup=1, views=2, erp_size=[1024, 2048], mask=False, term_eps=0.0,
+                                              density_shift=0.0, no_cpu_baseline=True)))
+    for name, fn, args in jobs:
+        t0 = time.perf_counter()
+        try:
+            torch.cuda.empty_cache()
+            line = fn(args, rk)
+            line["wall_s_incl_setup_and_cpu_baseline"] = time.perf_counter() - t0
+            out[name] = line
+        except Exception as e:  # a secondary must never cost the headline its line
+            out[name] = dict(error=repr(e))
+    return out
 
 
 def main():
@@ -614,7 +896,10 @@ def main():
         return self_launch(a)
     rk = Ranks(a)
     line = dict(render=run_render, train=run_train, erp=run_erp)[a.config](a, rk)
+    if a.config == "render" and rk.world == 1 and not a.no_secondary and a.density_shift is None:
+        line["secondary"] = run_secondary(a, rk)
     if rk.rank == 0:
+        line["process_group"] = None if rk.dist is None else rk.dist.get_backend()   # "nccl" = RCCL on ROCm
         print(json.dumps(line), flush=True)
     rk.finish()
 

@@ -70,6 +70,11 @@ class ShadeDump(C.Structure):
 P, I32, I64, F32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 SP = C.POINTER(Scene)
 
+# The EGO_ABI_VERSION (include/egonerf_hip.h) the PROTOTYPES below were written against.  load() refuses a library that reports
+# another one: a stale libegonerf_hip.so can keep every struct size and still disagree on an argument list (ABI 5 -> 7 inserted
+# `normalize` before ego_erp_rays' output pointer), which ctypes would pass through as a wild pointer.
+EXPECTED_ABI_VERSION = 8
+
 # name -> (restype, argtypes); mirrors include/egonerf_hip.h one to one
 PROTOTYPES = {
     "ego_abi_version": (C.c_int, []),
@@ -90,6 +95,7 @@ PROTOTYPES = {
     "ego_avgpool_table": (C.c_int, [P, I32, I32, I32, P, P]),
     "ego_pack_mlp": (C.c_int, [SP, P, P]),
     "ego_march_density": (C.c_int, [SP, P, I64, I32, P, P, P, F32, I32, P, P, I32, P, P, P, P, P, P]),
+    "ego_shade_kernel_info": (C.c_int, [I32, C.POINTER(C.c_int32), I32]),
     "ego_shade": (C.c_int, [SP, P, P, P, I64, I32, P, P, P, P]),
     "ego_alpha_mask_sample": (C.c_int, [SP, P, I64, P, P]),
     "ego_composite": (C.c_int, [SP, P, P, P, P, P, I64, I32, P, P, P, P, P, P]),
@@ -135,6 +141,14 @@ def load() -> C.CDLL:
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)
         fn.restype, fn.argtypes = res, args
+    got = lib.ego_abi_version()
+    if got != EXPECTED_ABI_VERSION:
+        raise RuntimeError(f"ABI mismatch: {LIB} reports EGO_ABI_VERSION {got}, this binding was written for {EXPECTED_ABI_VERSION}; "
+                           "rebuild it (`python -m egonerf_amd.build`)")
+    from .build import is_stale
+    if is_stale() and not os.environ.get("EGO_ALLOW_STALE_LIB"):
+        raise RuntimeError(f"{LIB} was not built from the sources next to it (source hash differs from {LIB}.hash); rebuild it "
+                           "(`python -m egonerf_amd.build`) or set EGO_ALLOW_STALE_LIB=1 for an experiment build")
     for which, struct in ((0, Scene), (1, RenderArgs), (2, VmField), (3, AdamTensor)):
         if lib.ego_sizeof(which) != C.sizeof(struct):
             raise RuntimeError(f"ABI mismatch: struct {struct.__name__} is {C.sizeof(struct)} B here, "

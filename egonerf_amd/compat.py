@@ -43,6 +43,7 @@ def reference_pickle_paths():
     targets = (("models.coordinates", "YinYangSphericalCoords"), ("models.envmap", "EnvironmentMap"))
     saved = {n: sys.modules.get(n) for n in ("models", "models.coordinates", "models.envmap")}
     installed = []
+    entered = False
     try:
         for mod, name in targets:
             m = sys.modules.get(mod)
@@ -58,9 +59,11 @@ def reference_pickle_paths():
                 installed.append(mod)
             _REF_CLASSES[(mod, name)] = getattr(m, name)
         _PICKLE_AS_REFERENCE += 1
+        entered = True
         yield
     finally:
-        _PICKLE_AS_REFERENCE -= 1
+        if entered:  # a failure in the set-up above must not leave the counter negative (later saves would then pickle this package's paths)
+            _PICKLE_AS_REFERENCE -= 1
         for n in installed:
             if saved[n] is None:
                 sys.modules.pop(n, None)

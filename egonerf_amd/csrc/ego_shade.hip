@@ -20,6 +20,7 @@
 // SIMD, so one wave's gather overlaps the other's MFMA chain); the basis fragments stream from L2.
 #include "ego_device.h"
 #include "ego_host.h"
+#include "variants.h"
 
 namespace {
 
@@ -681,7 +682,7 @@ __device__ __forceinline__ void basis_step(const BasisFrag& a, const float x[8],
 // (sample j, half h = pa holds quads h and h + 2, K order app_channel_g): a lane's own sample is 2t + pb, so it keeps the
 // round that served it (quad h) and gets quad h + 2 of its sample from the lane next to it: two selects and one neighbour
 // exchange per value.
-// The exchange is a v_mov_b32_dpp quad_perm (EGO_TEAM_EXCHANGE 1; 2 = __shfl_xor, 0 = ds_swizzle).
+// The exchange is a v_mov_b32_dpp quad_perm (__shfl_xor and ds_swizzle forms were measured in round 1 and removed: DESIGN.md 5.1).
 // REPRODUCIBILITY: kernels of this family (fp32-table gather of the f16x3 kernel) have a build-dependent fault that is not
 // understood: in affected builds 0.3 % ... 100 % of the calls return one gather round's products wrong in lanes
 // 16-31 and 48-63 of a wave in slots 4-7 of its workgroup (the second wave of a SIMD).  It does not depend on the exchange (it also
@@ -789,12 +790,6 @@ __device__ __forceinline__ void line_finish(const TapPtrs& tp, const f32x4 r[6],
 // ga = this lane's quad of the sample served in round 0 (tile column 2t), gb = of round 1 (column 2t + 1).  Even lanes own
 // column 2t: they keep ga (quad h) and take the odd neighbour's ga (quad h + 2); odd lanes keep gb and take the even
 // neighbour's gb.  v[0..11] = quad h, v[12..23] = quad h + 2 of the lane's own sample.
-#ifndef EGO_TEAM_EXCHANGE
-#define EGO_TEAM_EXCHANGE 1
-#endif
-#ifndef EGO_GATHER_TEAMS
-#define EGO_GATHER_TEAMS 1
-#endif
 __device__ __forceinline__ void team_to_halves(const float ga[12], const float gb[12], float* v) {
   if (!EGO_GATHER_TEAMS) {
 #pragma unroll
@@ -806,12 +801,7 @@ __device__ __forceinline__ void team_to_halves(const float ga[12], const float g
   for (int idx = 0; idx < 12; ++idx) {
     const float give = even ? gb[idx] : ga[idx];
     v[idx] = even ? ga[idx] : gb[idx];
-    if (EGO_TEAM_EXCHANGE == 1)
-      v[12 + idx] = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(give), 0xB1 /* quad_perm [1,0,3,2] */, 0xf, 0xf, false));
-    else if (EGO_TEAM_EXCHANGE == 2)
-      v[12 + idx] = __shfl_xor(give, 1, 64);
-    else
-      v[12 + idx] = __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(give), 0x041F /* bit mode: lane ^ 1 */));
+    v[12 + idx] = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(give), 0xB1 /* quad_perm [1,0,3,2] */, 0xf, 0xf, false));
   }
 }
 
@@ -835,12 +825,6 @@ __device__ __forceinline__ void basis3(const u32x4* __restrict__ BASH, int lane,
 
 // ROLL: the rolling form of the load buffer (tap_ptrs / line_load / line_finish above); it needs all 256 registers, so only the
 // fused inference kernel uses it (the dumping and stand-alone instantiations would spill)
-#ifndef EGO_SHADE_TILE_ORDER
-#define EGO_SHADE_TILE_ORDER 1
-#endif
-#ifndef EGO_SHADE_WINDOWS
-#define EGO_SHADE_WINDOWS 1
-#endif
 template <bool ROLL>
 __device__ __forceinline__ void gather_basis_team(const DevField& F, const TeamSample ts[2], const u32x4* __restrict__ BASH, int lane,
                                                   int g, bool mixed, int gu, f32x16& fe, float* vdump) {
@@ -1008,12 +992,8 @@ __global__ __launch_bounds__(512) void k_shade_h(ShadeArgs A) {
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 31, h = lane >> 5;
-#ifndef EGO_PRIO_VARIANT
-#define EGO_PRIO_VARIANT 0
-#endif
   // wave priority follows the phase: high while gathering (latency-bound: get the loads out), low in the MLP phase, whose MFMAs
-  // fill the matrix pipe anyway - 0.9 % faster than the static priority of k_shade (EGO_PRIO_VARIANT 1: none, 2: static)
-  if (EGO_PRIO_VARIANT == 2 && wave >= 4) __builtin_amdgcn_s_setprio(1);
+  // fill the matrix pipe anyway - 0.9 % faster than the static priority of k_shade (no priority / static: measured, removed)
   const int64_t n_tiles = (A.M + 31) >> 5;
   const u32x4* W1 = (const u32x4*)(lds + OFF_W1);
   const u32x4* W2 = (const u32x4*)(lds + OFF_W2);
@@ -1026,34 +1006,26 @@ __global__ __launch_bounds__(512) void k_shade_h(ShadeArgs A) {
   // Tile order: a wave walks a contiguous run of tiles, i.e. along its rays (the angular taps of the next tile are the lines this
   // wave's L1 just served: -1.5..2.3 % kernel time against tiles dealt round-robin over the grid, A/B on one box).  Skipped tiles
   // (tile mask) are the tails of rays and every wave owns whole rays; sharing the ACTIVE tiles evenly instead (prefix sums over the
-  // mask in the prologue, or chunks dealt through an atomic counter) was built and measured: DESIGN.md 4.3 (EGO_SHADE_TILE_ORDER 0:
-  // round-robin).
-  const bool walk = EGO_SHADE_TILE_ORDER;
+  // mask in the prologue, or chunks dealt through an atomic counter) was built and measured: DESIGN.md 4.3.
   const int64_t n_wv = (int64_t)gridDim.x * 8;
   const int64_t per_wave = (n_tiles + n_wv - 1) / n_wv;
-  const int64_t tile0 = walk ? ((int64_t)blockIdx.x * 8 + wave) * per_wave : (int64_t)blockIdx.x * 8 + wave;
-  const int64_t tile1 = walk ? (tile0 + per_wave < n_tiles ? tile0 + per_wave : n_tiles) : n_tiles;
-  const int64_t tstep = walk ? 1 : n_wv;
-#if EGO_SHADE_WINDOWS
+  const int64_t tile0 = ((int64_t)blockIdx.x * 8 + wave) * per_wave;
+  const int64_t tile1 = tile0 + per_wave < n_tiles ? tile0 + per_wave : n_tiles;
   // the tile mask is read 64 tiles at a time (one byte per lane + ballot) and walked with find-first-set: a skipped tile costs no
-  // memory round trip (the per-tile flag load sat on the critical path of every skipped tile)
-  for (int64_t wbase = tile0; wbase < tile1; wbase += 64 * tstep) {
+  // memory round trip (a per-tile flag load sat on the critical path of every skipped tile)
+  for (int64_t wbase = tile0; wbase < tile1; wbase += 64) {
     unsigned long long wmask;
     {
-      const int64_t t = wbase + (int64_t)lane * tstep;
+      const int64_t t = wbase + (int64_t)lane;
       const bool in = t < tile1;
       wmask = (MODE == MODE_SHADE && A.tile_active) ? __ballot(in && A.tile_active[in ? t : tile0] != 0) : __ballot(in);
     }
   while (wmask != 0ull) {
-    const int64_t tile = wbase + (int64_t)__builtin_ctzll(wmask) * tstep;
+    const int64_t tile = wbase + (int64_t)__builtin_ctzll(wmask);
     wmask &= wmask - 1ull;
-#else
-  for (int64_t tile = tile0; tile < tile1; tile += tstep) {
-    if (MODE == MODE_SHADE && A.tile_active && !A.tile_active[tile]) continue;
-#endif
     int lw = lane;
     asm volatile("" : "+v"(lw));  // keeps the LDS weight reads inside the loop (see k_shade)
-    if (EGO_PRIO_VARIANT == 0 && MODE != MODE_MLP) __builtin_amdgcn_s_setprio(2);
+    if (MODE != MODE_MLP) __builtin_amdgcn_s_setprio(2);
     const int hw = lw >> 5;
     const int64_t m_raw = tile * 32 + j;
     const bool valid = m_raw < A.M;
@@ -1135,7 +1107,7 @@ __global__ __launch_bounds__(512) void k_shade_h(ShadeArgs A) {
       continue;
     }
 
-    if (EGO_PRIO_VARIANT == 0) __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_s_setprio(0);
     float vw[8];
     {
       float sa0, ca0, sb0, cb0, sa1, ca1, sb1, cb1, sa2, ca2, sb2, cb2;
@@ -1358,9 +1330,7 @@ __global__ __launch_bounds__(512) void k_shade_h(ShadeArgs A) {
       o[2] = sigmoidf(o2 + b3[2]);
     }
   }
-#if EGO_SHADE_WINDOWS
   }
-#endif
 }
 
 #include "ego_train.inc"
@@ -1427,6 +1397,23 @@ int ego_pack_mlp(const ego_scene* sc, float* packed_out, void* stream) {
   k_pack_mlp_f8<<<(F8_FLOATS + 255) / 256, 256, 0, (hipStream_t)stream>>>(sc->mlp_w[0], sc->mlp_w[1],
                                                                           packed_out + 2 * PACKED_FLOATS + BASIS16_FLOATS);
   return ego_launch_status("k_pack_mlp_f8");
+}
+
+int ego_shade_kernel_info(int32_t precision, int32_t* out, int32_t n) {
+  EGO_REQUIRE(out && n == 8, "shade_kernel_info: out must hold 8 values");
+  EGO_REQUIRE(precision == EGO_PREC_F16X3 || precision == EGO_PREC_F32 || precision == EGO_PREC_F16F8, "shade_kernel_info: unknown precision");
+  out[0] = 32;
+  if (precision == EGO_PREC_F32) {          // k_shade: one v_mfma_f32_32x32x2_f32 per k (basis) / per k and m-tile (layers 1, 2)
+    out[1] = KS_BASIS + 4 * (KS1 + KS2); out[2] = 0; out[3] = 2 * 32 * 32 * 2; out[4] = 0; out[5] = 0;
+  } else if (precision == EGO_PREC_F16X3) {  // three v_mfma_f32_32x32x16_f16 per 8-k step (and m-tile)
+    out[1] = 3 * (KHB + 4 * (KH1 + KH2)); out[2] = 0; out[3] = 2 * 32 * 32 * 16; out[4] = 0; out[5] = 0;
+  } else {                                   // basis as f16x3; layers 1, 2: one fp16 MFMA per step + one fp8 MFMA per pair of steps
+    out[1] = 3 * KHB + 4 * (KH1 + KH2); out[2] = 4 * (KH1 / 2 + KH2 / 2); out[3] = 2 * 32 * 32 * 16; out[4] = 2 * 32 * 32 * 64;
+    out[5] = (KS1 + KS2) / 2 * 2;            // per pair of values: one v_cvt_pk_fp8_f32 (x) and one v_cvt_scalef32_pk_fp8_f32 (residual)
+  }
+  out[6] = 2 * (3 * APP_C * APP_DIM + MLP_IN * HID + HID * HID + HID * 3);
+  out[7] = 3 * (4 + 2) * APP_C * 4;
+  return EGO_OK;
 }
 
 int ego_app_feature(const ego_scene* sc, const float* c7n, int64_t M, float* out, void* stream) {

@@ -343,6 +343,52 @@ class EgoNeRF(TensorBase):
                 k += 1
         self._scene_cache = None
 
+    # -- compact addressing guard -----------------------------------------------------------------------------
+    def _table_lists(self, kind: str):
+        return [getattr(self, f"{kind}_{what}_{g}") for g in ("yin", "yang") for what in ("plane", "line")]
+
+    def _is_compact(self, kind: str) -> bool:
+        """True iff the 12 tables of `kind` end within 4 GB of the lowest of them (what csrc/ego_device.h's 32-bit tap offsets
+        need; ego_field_is_compact is the library's own check)."""
+        ts = [p for l in self._table_lists(kind) for p in l]
+        lo = min(t.data_ptr() for t in ts)
+        hi = max(t.data_ptr() + t.numel() * t.element_size() for t in ts)
+        return hi - lo < (1 << 32)
+
+    @torch.no_grad()
+    def _recompact_tables(self, kind: str):
+        """Move the 12 tables of `kind` into one fresh buffer IN PLACE (`param.data = view`): the Parameter objects - and with
+        them an optimiser's references and state - stay.  Needed after anything that re-allocates the parameters one by one
+        (`Module._apply`: .to() / .cuda() / .float(); `load_state_dict(assign=True)`): separate hipMalloc segments of this size
+        have no bounded distance, and the forward gathers address a tap as base + 32-bit offset."""
+        olds = [p for l in self._table_lists(kind) for p in l]
+        views = _carve_channel_last([(p.shape[1], p.shape[2], p.shape[3]) for p in olds], olds[0].device)
+        for v, p in zip(views, olds):
+            v.copy_(p.data)
+            p.data = v
+        self._scene_cache = None
+
+    def _apply(self, fn, *args, **kwargs):
+        """nn.Module._apply re-allocates every parameter on its own; restore what the kernels rely on afterwards: one buffer per
+        field (compact addressing), the non-parameter device state (pooled density tables, packed weights, half copies) on
+        the new device."""
+        r = super()._apply(fn, *args, **kwargs)
+        self._scene_cache = None
+        self._packed = self._packed_versions = self._app16 = None
+        self._sched_cache = {}
+        if not hasattr(self, "density_plane_yin"):   # called from inside __init__ (renderModule.to(device)) before the tables exist
+            return r
+        dev = self.density_plane_yin[0].device
+        self.device = dev
+        if dev.type == "cuda":
+            for kind in ("density", "app"):
+                if not self._is_compact(kind):
+                    self._recompact_tables(kind)
+            stale = self.coarse_sigma_plane_yin[0] is None or self.coarse_sigma_plane_yin[0].device != dev
+            if self.coarse_sigma_grid_update_rule == "conv" and stale:
+                self.update_coarse_sigma_grid()
+        return r
+
     def init_svd_volume(self, res, device):
         g = self.gridSize.tolist()
         (self.density_plane_yin, self.density_line_yin, self.density_plane_yang,
@@ -523,6 +569,9 @@ class EgoNeRF(TensorBase):
         dev = self.density_plane_yin[0].device
         if dev.type != "cuda":
             raise RuntimeError(f"model parameters are on {dev}; the EgoNeRF hot path runs only on the HIP device")
+        for kind in ("density", "app"):  # e.g. after load_state_dict(assign=True); .to() / .cuda() / .float() are handled in _apply
+            if not self._is_compact(kind):
+                self._recompact_tables(kind)
         mlp = self._mlp_tensors()
         versions = tuple((t.data_ptr(), t._version) for t in mlp)
         if self._app_table_dtype == "f16":  # the half copy follows the appearance tables' versions

@@ -72,11 +72,11 @@ def psnr_from_sse(sse: float, count: float) -> float:
 
 
 def sharded_render(render_fn: Callable[[torch.Tensor], torch.Tensor], rays: torch.Tensor, gt: Optional[torch.Tensor] = None,
-                   gather_image: bool = False, group=None):
+                   gather_image=False, group=None):
     """Each rank renders its block of `rays` with `render_fn(rays_block) -> rgb [n,3]`.
 
-    Returns dict(rgb_local, lo, hi, psnr (if gt given; identical on every rank), image (rank 0, if gather_image)).
-    No data-path collective: only the [sse, count] all-reduce and the optional tile gather.
+    Returns dict(rgb_local, lo, hi, psnr (if gt given; identical on every rank), image (if gather_image: on rank 0, or on every
+    rank with gather_image="all")).  No data-path collective: only the [sse, count] all-reduce and the optional tile gather.
     """
     import torch.distributed as dist
 
@@ -100,9 +100,13 @@ def sharded_render(render_fn: Callable[[torch.Tensor], torch.Tensor], rays: torc
             pad = max(h - l for l, h in sizes)
             buf = torch.zeros(pad, 3, device=rgb.device, dtype=rgb.dtype)
             buf[: hi - lo] = rgb
-            tiles = [torch.empty_like(buf) for _ in range(world)] if rank == 0 else None
-            dist.gather(buf, tiles, dst=0, group=group)
-            if rank == 0:
+            if gather_image == "all":   # every rank gets the image (row-sharded SSIM in evaluation())
+                tiles = [torch.empty_like(buf) for _ in range(world)]
+                dist.all_gather(tiles, buf, group=group)
+            else:
+                tiles = [torch.empty_like(buf) for _ in range(world)] if rank == 0 else None
+                dist.gather(buf, tiles, dst=0, group=group)
+            if tiles is not None:
                 out["image"] = torch.cat([t[: h - l] for t, (l, h) in zip(tiles, sizes)])
         else:
             out["image"] = rgb
@@ -122,44 +126,71 @@ def evaluation_psnr(images_rays: Sequence[torch.Tensor], images_gt: Sequence[tor
     return psnrs
 
 
+def sharded_image_metrics(img: torch.Tensor, ref: torch.Tensor, ws: bool, filter_size: int = 11, group=None):
+    """SSIM (utils.py:106-152) and, with `ws`, WS-PSNR / WS-SSIM (extra/ws_ssim.py weights) of two [H, W, 3] images that EVERY rank
+    holds, with the work split by rows: rank r evaluates rows [lo, hi) of the 'valid' SSIM map from image rows [lo, hi + fs - 1)
+    and its share of the weighted squared error; three small float64 all-reduces combine them, so every rank returns the same
+    (ssim, ws_psnr | None, ws_ssim | None).  Without a process group it is the plain single-process computation."""
+    import torch.distributed as dist
+    from .metrics import rgb_ssim, ws_weights
+    distributed = dist.is_available() and dist.is_initialized()
+    world = dist.get_world_size(group) if distributed else 1
+    rank = dist.get_rank(group) if distributed else 0
+    H, W = img.shape[:2]
+    Ho, Wo = H - filter_size + 1, W - filter_size + 1
+    lo, hi = shard_bounds(Ho, world, rank)
+    stat = torch.zeros(5, dtype=torch.float64, device=img.device)  # sum ssim | sum w * ssim, sum w (map) | sum w * d^2, sum w (pixels)
+    if hi > lo:
+        a, b = img[lo:hi + filter_size - 1], ref[lo:hi + filter_size - 1]
+        if not ws:   # the kernel's own float64 sum of the map (no float32 map round trip)
+            stat[0] = rgb_ssim(a, b, 1, filter_size) * ((hi - lo) * Wo * 3)
+        else:
+            smap = rgb_ssim(a, b, 1, filter_size, return_map=True).to(torch.float64)
+            stat[0] = smap.sum()
+            w = torch.as_tensor(ws_weights(hi - lo, filter_size // 2 + lo, H), dtype=torch.float64, device=img.device)
+            stat[1] = (smap.mean(-1) * w[:, None]).sum()
+            stat[2] = w.sum() * Wo
+    if ws:
+        plo, phi = shard_bounds(H, world, rank)
+        if phi > plo:
+            w = torch.as_tensor(ws_weights(phi - plo, plo, H), dtype=torch.float64, device=img.device)
+            d = img[plo:phi].to(torch.float64) - ref[plo:phi].to(torch.float64)
+            stat[3] = ((d * d).sum((1, 2)) * w).sum()
+            stat[4] = w.sum() * W * 3
+    if distributed:
+        dist.all_reduce(stat, op=dist.ReduceOp.SUM, group=group)
+    ssim = float(stat[0].item() / (Ho * Wo * 3))
+    if not ws:
+        return ssim, None, None
+    return ssim, float(10.0 * np.log10(1.0 / (stat[3].item() / stat[4].item()))), float(stat[1].item() / stat[2].item())
+
+
 @torch.no_grad()
 def evaluation(images_rays: Sequence[torch.Tensor], images_gt: Sequence[torch.Tensor], img_wh: Tuple[int, int], model, chunk=4096,
                device="cuda", compute_extra_metrics=True, ws_metrics=False, **render_kw):
     """renderer.py:82-196 without the file output: per image render -> clamp -> PSNR (:156-157) and, with
-    compute_extra_metrics, rgb_ssim (:160; LPIPS omitted).  Rays are sharded over the ranks of the default process group; the
-    image is gathered to rank 0 for the windowed SSIM, whose value is then broadcast.  Returns (PSNRs, ssims); with
+    compute_extra_metrics, rgb_ssim (:160; LPIPS omitted).  Rays are sharded over the ranks of the default process group; for the
+    windowed metrics the tiles are all-gathered (25 MB per 1024 x 2048 image) and every rank evaluates its block of rows of the
+    SSIM map (sharded_image_metrics), so no rank idles while rank 0 filters a whole image.  Returns (PSNRs, ssims); with
     ws_metrics=True (the reference's `TODO: add WS-PSNR, WS-SSIM`, renderer.py:89, with extra/ws_ssim.py's latitude weights)
-    (PSNRs, ssims, ws_psnrs, ws_ssims) for equirectangular images."""
-    import torch.distributed as dist
-    from .metrics import rgb_ssim, ws_psnr, ws_ssim
+    (PSNRs, ssims, ws_psnrs, ws_ssims) for equirectangular images.  Every rank returns the same lists."""
     W, H = img_wh
-    distributed = dist.is_available() and dist.is_initialized()
-    rank = dist.get_rank() if distributed else 0
     was_training = model.training
     model.eval()
     psnrs, ssims, wpsnrs, wssims = [], [], [], []
     render_kw = dict(render_kw, empty_gpu_cache=False)  # see evaluation_psnr
     for rays, gt in zip(images_rays, images_gt):
         fn = lambda block: volume_renderer(block, model, chunk=chunk, device=device, keep_alpha=False, **render_kw)[0]
-        out = sharded_render(fn, rays.view(-1, rays.shape[-1]), gt.view(-1, 3), gather_image=compute_extra_metrics or ws_metrics)
+        extra = compute_extra_metrics or ws_metrics
+        out = sharded_render(fn, rays.view(-1, rays.shape[-1]), gt.view(-1, 3), gather_image="all" if extra else False)
         psnrs.append(out["psnr"])
-        if compute_extra_metrics or ws_metrics:
-            val = torch.zeros(3, dtype=torch.float64, device=out["rgb_local"].device)
-            if rank == 0:
-                img = out["image"].clamp(0.0, 1.0).reshape(H, W, 3)
-                ref = gt.view(H, W, 3).to(img.device)
-                if ws_metrics:
-                    val[0], val[2] = ws_ssim(img, ref, 1)
-                    val[1] = ws_psnr(img, ref)
-                else:
-                    val[0] = rgb_ssim(img, ref, 1)
-            if distributed:
-                dist.broadcast(val, src=0)
+        if extra:
+            img = out["image"].clamp(0.0, 1.0).reshape(H, W, 3)
+            ssim, wp, wsim = sharded_image_metrics(img, gt.view(H, W, 3).to(img.device), ws_metrics)
             if compute_extra_metrics:
-                ssims.append(float(val[0].item()))
+                ssims.append(ssim)
             if ws_metrics:
-                wpsnrs.append(float(val[1].item()))
-                wssims.append(float(val[2].item()))
+                wpsnrs.append(wp)
+                wssims.append(wsim)
     model.train(was_training)
     return (psnrs, ssims, wpsnrs, wssims) if ws_metrics else (psnrs, ssims)
-

@@ -49,6 +49,28 @@ def _side_stream(device) -> "torch.cuda.Stream":
     return _SIDE_STREAMS[key]
 
 
+# Optional per-call timing (bench.py): when KERNEL_MARKS is a list, an event is recorded on the current stream after every library
+# call of the step and appended as (name, event); the interval between two consecutive marks is that call's kernel time plus the
+# torch glue (zero fills, index scatters) queued in front of it.  Meaningful with SIDE_STREAM_SCATTER = False (one stream).
+KERNEL_MARKS = None
+
+
+def _chk(code: int, what: str) -> None:
+    _lib.check(code, what)
+    if KERNEL_MARKS is not None:
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        KERNEL_MARKS.append((what, ev))
+
+
+def mark(what: str) -> None:
+    """An extra mark (e.g. "begin") for callers that collect KERNEL_MARKS."""
+    if KERNEL_MARKS is not None:
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        KERNEL_MARKS.append((what, ev))
+
+
 def _grad_indices(device):
     """Index tensors that un-permute the lane-order columns of the weight-gradient products, derived once from the layouts
     (boolean masks / nonzero() in the backward pass would cost a host synchronisation each, every step)."""
@@ -131,18 +153,18 @@ class RenderFunction(torch.autograd.Function):
         astride = alpha.shape[1]
         if resampling:
             zc, wc = (f(N, n_coarse) if zc_in is None else zc_in), f(N, n_coarse)
-            _lib.check(lib.ego_march_density(sc, rays.data_ptr(), N, n_coarse, _lib.ptr(zc_in), None if zc_in is not None else sched.data_ptr(),
+            _chk(lib.ego_march_density(sc, rays.data_ptr(), N, n_coarse, _lib.ptr(zc_in), None if zc_in is not None else sched.data_ptr(),
                                              None if zc_in is not None else _lib.ptr(jitter), near, 1,
                                              None if zc_in is not None else zc.data_ptr(), None, 0, wc.data_ptr(), None, None, None, None, st),
                        "ego_march_density")
-            _lib.check(lib.ego_sample_pdf_merge(zc.data_ptr(), wc.data_ptr(), _lib.ptr(u), N, n_coarse, n_fine, int(use_coarse),
+            _chk(lib.ego_sample_pdf_merge(zc.data_ptr(), wc.data_ptr(), _lib.ptr(u), N, n_coarse, n_fine, int(use_coarse),
                                                 z.data_ptr(), None, st), "ego_sample_pdf_merge")
             # fine pass: full tables and the full-resolution r grid (bit 1; EgoNeRF.py:546 normalises without `downsample`)
-            _lib.check(lib.ego_march_density(sc, rays.data_ptr(), N, S, z.data_ptr(), None, None, near, 2, None, alpha.data_ptr(),
+            _chk(lib.ego_march_density(sc, rays.data_ptr(), N, S, z.data_ptr(), None, None, near, 2, None, alpha.data_ptr(),
                                              astride, weight.data_ptr(), bg.data_ptr(), coords.data_ptr(), sigma.data_ptr(), None, st),
                        "ego_march_density")
         else:
-            _lib.check(lib.ego_march_density(sc, rays.data_ptr(), N, S, _lib.ptr(zc_in), None if zc_in is not None else sched.data_ptr(),
+            _chk(lib.ego_march_density(sc, rays.data_ptr(), N, S, _lib.ptr(zc_in), None if zc_in is not None else sched.data_ptr(),
                                              None if zc_in is not None else _lib.ptr(jitter), near, 0,
                                              z.data_ptr(), alpha.data_ptr(), astride, weight.data_ptr(), bg.data_ptr(),
                                              coords.data_ptr(), sigma.data_ptr(), None, st), "ego_march_density")
@@ -151,12 +173,12 @@ class RenderFunction(torch.autograd.Function):
         Mp = (M + 31) // 32 * 32  # the dumps are tile-blocked ([tile][quad pair][lane][4], csrc/ego_shade.hip dump_off): whole tiles
         dump = dict(x=f(Mp, 160), h1=f(Mp, 128), h2=f(Mp, 128), v=f(Mp, 144))
         ds = _lib.ShadeDump(dump["x"].data_ptr(), dump["h1"].data_ptr(), dump["h2"].data_ptr(), dump["v"].data_ptr())
-        _lib.check(lib.ego_shade(sc, rays.data_ptr(), z.data_ptr(), coords.data_ptr(), N, S, rgb.data_ptr(), C.byref(ds), None, st), "ego_shade")
+        _chk(lib.ego_shade(sc, rays.data_ptr(), z.data_ptr(), coords.data_ptr(), N, S, rgb.data_ptr(), C.byref(ds), None, st), "ego_shade")
         rgb_map, depth, raw = f(N, 3), f(N), f(N, 3)
         has_env = model.envmap is not None
         bg_map = f(N, 3) if has_env else None
         env_map = f(N, 3) if has_env else None
-        _lib.check(lib.ego_composite(sc, rays.data_ptr(), z.data_ptr(), weight.data_ptr(), bg.data_ptr(), rgb.data_ptr(), N, S,
+        _chk(lib.ego_composite(sc, rays.data_ptr(), z.data_ptr(), weight.data_ptr(), bg.data_ptr(), rgb.data_ptr(), N, S,
                                      rgb_map.data_ptr(), depth.data_ptr(), _lib.ptr(bg_map), _lib.ptr(env_map), raw.data_ptr(), st),
                    "ego_composite")
         ctx.model, ctx.N, ctx.S = model, N, S
@@ -189,7 +211,7 @@ class RenderFunction(torch.autograd.Function):
             assert g.stride() == p.stride()
         f = lambda *shape: torch.empty(*shape, device=dev, dtype=torch.float32)
         dc, dfeat = f(N, S, 3), f(N, S)
-        _lib.check(lib.ego_march_backward(sc, sv["z"].data_ptr(), sv["alpha"].data_ptr(), astride, sv["weight"].data_ptr(),
+        _chk(lib.ego_march_backward(sc, sv["z"].data_ptr(), sv["alpha"].data_ptr(), astride, sv["weight"].data_ptr(),
                                           sv["sigma"].data_ptr(), sv["bg"].data_ptr(), sv["rgb"].data_ptr(), g_rgb.data_ptr(),
                                           _lib.ptr(g_alpha), sv["raw"].data_ptr(), _lib.ptr(sv["env"]), N, S, dc.data_ptr(),
                                           dfeat.data_ptr(), st), "ego_march_backward")
@@ -205,17 +227,30 @@ class RenderFunction(torch.autograd.Function):
             with torch.cuda.stream(side):
                 fn(_lib.stream_handle())
 
-        on_side(lambda s_: _lib.check(lib.ego_scatter_density(sc, C.byref(gd), sv["coords"].data_ptr(), dfeat.data_ptr(), N, S, s_),
+        try:
+            return RenderFunction._backward_body(ctx, lib, st, model, N, S, sv, dev, M, sc, g_rgb, astride, g_dens, g_app, dc, dfeat, gd,
+                                                 main, side, on_side, f)
+        finally:
+            # Whatever happens in between (a failing _lib.check raises), the main stream must have waited for the side stream before
+            # dfeat / dv / coords / the gradient buffer go back to the main stream's allocator pool: the side-stream kernels may still
+            # be reading or writing them.
+            if side is not None:
+                main.wait_stream(side)
+            ctx.saved = None
+
+    @staticmethod
+    def _backward_body(ctx, lib, st, model, N, S, sv, dev, M, sc, g_rgb, astride, g_dens, g_app, dc, dfeat, gd, main, side, on_side, f):
+        on_side(lambda s_: _chk(lib.ego_scatter_density(sc, C.byref(gd), sv["coords"].data_ptr(), dfeat.data_ptr(), N, S, s_),
                                       "ego_scatter_density"))
         tp = f(lib.ego_train_packed_floats())
-        _lib.check(lib.ego_pack_train(sc, tp.data_ptr(), st), "ego_pack_train")
+        _chk(lib.ego_pack_train(sc, tp.data_ptr(), st), "ego_pack_train")
         Mp = (M + 31) // 32 * 32
         dh2, dh1, dfe, dv = f(Mp, 128), f(Mp, 128), f(M, 64), f(Mp, 144)  # dh2 / dh1 / dv: tile-blocked like the dumps
         ds = _lib.ShadeDump(sv["x"].data_ptr(), sv["h1"].data_ptr(), sv["h2"].data_ptr(), sv["v"].data_ptr())
-        _lib.check(lib.ego_shade_backward(sc, tp.data_ptr(), sv["coords"].data_ptr(), dc.data_ptr(), sv["rgb"].data_ptr(), C.byref(ds),
+        _chk(lib.ego_shade_backward(sc, tp.data_ptr(), sv["coords"].data_ptr(), dc.data_ptr(), sv["rgb"].data_ptr(), C.byref(ds),
                                           dh2.data_ptr(), dh1.data_ptr(), dfe.data_ptr(), dv.data_ptr(), N, S, st), "ego_shade_backward")
         ga = _grad_struct(g_app)
-        on_side(lambda s_: _lib.check(lib.ego_scatter_app(sc, C.byref(ga), sv["coords"].data_ptr(), dv.data_ptr(), N, S, s_), "ego_scatter_app"))
+        on_side(lambda s_: _chk(lib.ego_scatter_app(sc, C.byref(ga), sv["coords"].data_ptr(), dv.data_ptr(), N, S, s_), "ego_scatter_app"))
         if side is None:
             del dv
         # ---- weight gradients: one pass of ego_weight_grad (bf16 hi/lo MFMA over transposed LDS tiles, bias gradients from a
@@ -227,7 +262,7 @@ class RenderFunction(torch.autograd.Function):
 
         def wgrad(A, ca, a_blocked, B, cb, ones_col):
             G = torch.zeros(32 * ((ca + 31) // 32), 160, device=dev)
-            _lib.check(lib.ego_weight_grad(A.data_ptr(), A.shape[1], ca, a_blocked, B.data_ptr(), B.shape[1], cb, 1, ones_col, M,
+            _chk(lib.ego_weight_grad(A.data_ptr(), A.shape[1], ca, a_blocked, B.data_ptr(), B.shape[1], cb, 1, ones_col, M,
                                            G.data_ptr(), 160, st), "ego_weight_grad")
             return G
 
@@ -256,12 +291,11 @@ class RenderFunction(torch.autograd.Function):
         if sv["env"] is not None:
             g_em = torch.zeros_like(model.envmap.emission)
             rays = sv["rays"]
-            _lib.check(lib.ego_envmap_backward(sc, rays.data_ptr() + 12, 6, g_rgb.data_ptr(), sv["raw"].data_ptr(), sv["bg"].data_ptr(),
+            _chk(lib.ego_envmap_backward(sc, rays.data_ptr() + 12, 6, g_rgb.data_ptr(), sv["raw"].data_ptr(), sv["bg"].data_ptr(),
                                                sv["env"].data_ptr(), N, g_em.data_ptr(), st), "ego_envmap_backward")
             grads.append(g_em)
         if side is not None:
             main.wait_stream(side)  # the table gradients are complete; dv / dfeat / coords may be released from here on
-        ctx.saved = None
         return (None, None, None, *grads)
 
 

@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define EGO_ABI_VERSION 7
+#define EGO_ABI_VERSION 8
 
 enum { EGO_PREC_F16X3 = 0, EGO_PREC_F32 = 1, EGO_PREC_F16F8 = 2 };
 
@@ -211,6 +211,15 @@ typedef struct ego_shade_dump {
   float* h2;
   float* v;
 } ego_shade_dump;
+
+/* Static facts about the shade kernel that implements `precision` (EGO_PREC_*), for roofline accounting by a caller that times it
+ * (bench.py): out[0] samples per tile (one wave-level unit of work), [1] fp16 / fp32-input MFMA instructions per tile of samples
+ * that lie in one grid, [2] block-scaled fp8 MFMA instructions per tile, [3] flop per instruction of [1], [4] flop per
+ * instruction of [2], [5] f32 -> fp8 conversion instructions per lane and tile, [6] algorithmic flop per sample (basis +
+ * MLP_Fea of tensorBase.py:54-78: 2 (144 x 27 + 150 x 128 + 128 x 128 + 128 x 3)), [7] gathered appearance tap bytes per
+ * sample (EgoNeRF.py:349-413: 3 x (4 + 2) taps x 48 channels x 4 B).  n must be 8.  The counts are computed from the same
+ * constants the kernel's loops run over. */
+int ego_shade_kernel_info(int32_t precision, int32_t* out, int32_t n);
 
 /* Appearance lookup -> basis -> positional encoding -> MLP for every sample: rgb [N][S][3].
  * z [N][S] sample distances (from ego_march_density); coords [N][S][4] optional (ego_march_density's coords_out),

@@ -14,6 +14,15 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (runs the HIP library through the C-ABI)")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _library_is_current():
+    """egonerf_amd._lib.load() refuses a binary that was not built from the sources next to it; (re)build before the first test
+    instead of failing every test after a kernel edit (a no-op when libegonerf_hip.so.hash matches; hipcc cross-compiles without
+    a GPU in ~10 s)."""
+    from egonerf_amd.build import build_library
+    build_library(force=False)
+
+
 @pytest.fixture(scope="session")
 def golden():
     import numpy as np

@@ -1,0 +1,89 @@
+"""GPU: host-layer guards found by review - per-parameter re-allocation (`Module._apply`) vs the kernels' compact
+`base + 32-bit offset` addressing, and the f16f8 arithmetic's behaviour on large / tiny activations."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from egonerf_amd import _lib, synth
+from tests.helpers import make_model, make_oracle, maxerr
+
+pytestmark = pytest.mark.gpu
+
+
+def _render(model, rays):
+    with torch.no_grad():
+        return model(rays, n_coarse=24, n_fine=24, resampling=True, exp_sampling=True)
+
+
+def test_model_built_on_cpu_then_moved_renders_and_stays_compact():
+    """model.to('cuda') / .cuda() / .float() re-allocate every parameter separately (nn.Module._apply); the model re-carves each
+    field's 12 tables from one buffer, keeps the Parameter objects (an optimiser's references stay valid) and rebuilds its
+    non-parameter device state (pooled density tables)."""
+    cfg = synth.SceneConfig(n_voxel=20 ** 3)
+    w = synth.make_weights(cfg, seed=1234)
+    ref_model = make_model(cfg, w, "cuda")
+    rays = torch.from_numpy(synth.make_rays(200, seed=3)).cuda()
+    want = _render(ref_model, rays)
+    cpu_model = make_model(cfg, w, "cpu")
+    with pytest.raises(RuntimeError):
+        cpu_model.scene()                       # no CPU fallback
+    ids = [id(p) for p in cpu_model.parameters()]
+    moved = cpu_model.to("cuda")
+    assert [id(p) for p in moved.parameters()] == ids
+    assert moved._is_compact("density") and moved._is_compact("app")
+    for kind in ("density", "app"):   # one buffer per field: every table lies inside the span of one allocation
+        ts = [p for l in moved._table_lists(kind) for p in l]
+        span = max(t.data_ptr() + t.numel() * 4 for t in ts) - min(t.data_ptr() for t in ts)
+        assert span < 2 * sum(t.numel() * 4 for t in ts) + 12 * 256
+    got = _render(moved, rays)
+    assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
+    again = _render(moved.float().cuda(), rays)   # no-op conversions must not break anything either
+    assert torch.equal(again[0], want[0])
+
+
+def test_non_compact_tables_are_recompacted_lazily():
+    """Parameters assigned one by one (what load_state_dict(assign=True) does): scene() notices a field that is not within one
+    4 GB window and re-carves it; here the window is shrunk artificially by planting one table far away is not possible in a
+    test, so the hook is exercised through _recompact_tables directly and the render compared."""
+    cfg = synth.SceneConfig(n_voxel=20 ** 3)
+    w = synth.make_weights(cfg, seed=77)
+    model = make_model(cfg, w, "cuda")
+    rays = torch.from_numpy(synth.make_rays(64, seed=5)).cuda()
+    want = _render(model, rays)
+    ids = [id(p) for p in model.parameters()]
+    for l in model._table_lists("app"):      # separate allocations, as after assign=True
+        for p in l:
+            p.data = p.data.clone(memory_format=torch.preserve_format)
+    model._recompact_tables("app")
+    model._recompact_tables("density")
+    assert [id(p) for p in model.parameters()] == ids and model._is_compact("app")
+    got = _render(model, rays)
+    assert torch.equal(got[0], want[0])
+
+
+@pytest.mark.parametrize("gain", [1.0, 6.0, 40.0])
+def test_f16f8_on_large_and_tiny_activations(gain):
+    """The default inference arithmetic keeps an e4m3 copy of every activation and of w_hi for the two low-order product terms:
+    e4m3 saturates at 448 (MODE.FP16_OVFL, set by the kernel) and flushes below 2^-9.  Scale the MLP weights so that hidden
+    activations reach hundreds to thousands (gain 6 / 40) and check the per-sample colour against the fp32-MFMA kernel: a
+    saturated correction operand may cost accuracy of a low-order term only, never a NaN or an O(1) error."""
+    cfg = synth.SceneConfig(n_voxel=20 ** 3)
+    w = synth.make_weights(cfg, seed=1234, mlp_gain=3.0 * gain)
+    model = make_model(cfg, w, "cuda")
+    M = 4096
+    feat = torch.from_numpy((synth.hash_normal(9, 1, M * 27).reshape(M, 27) * (2.0 if gain > 1 else 1.0)).astype(np.float32)).cuda()
+    feat[: M // 8] *= 1e-4                       # tiny activations: the fp8 copies flush to zero, the fp16 main term stays
+    dirs = torch.from_numpy(synth.make_rays(M, seed=2)[:, 3:6].copy()).cuda()
+    out = {}
+    for prec in ("f32", "f16x3", "f16f8"):
+        model.mlp_precision = prec
+        out[prec] = model.renderModule(None, dirs, feat)
+        assert bool(torch.isfinite(out[prec]).all())
+    # pre-sigmoid magnitudes: how hard the case is
+    h1 = torch.relu(torch.cat([feat, dirs], -1).abs().max())
+    assert maxerr(out["f16x3"], out["f32"]) <= 2e-5
+    # f16f8: ~2^-16 relative per product; through two 128-wide layers and the sigmoid (slope <= 1/4) the per-sample colour stays
+    # within 2e-4 even when the hidden activations are in the hundreds (composited errors are ~3x smaller: DESIGN.md 4.1a)
+    assert maxerr(out["f16f8"], out["f32"]) <= (5e-5 if gain == 1.0 else 2e-4), (gain, float(h1))

@@ -58,7 +58,7 @@ def test_evaluation_psnr_and_ssim_of_an_erp_render():
     assert 0.3 < ssims[0] < 1.0
     # the same call with the latitude-weighted variants (extra/ws_ssim.py weights)
     p2, s2, wp, wsim = evaluation([rays], [gt], (W, H), model, n_coarse=32, exp_sampling=True, ws_metrics=True)
-    assert p2 == psnrs and abs(s2[0] - ssims[0]) <= 1e-9
+    assert p2 == psnrs and abs(s2[0] - ssims[0]) <= 1e-7   # float32 SSIM map vs the kernel's own float64 sum
     assert abs(wp[0] - metrics.ws_psnr(img.view(H, W, 3), gt.view(H, W, 3))) <= 1e-9
     assert abs(wsim[0] - metrics.ws_ssim(img.view(H, W, 3), gt.view(H, W, 3))[1]) <= 1e-9 and 0.3 < wsim[0] < 1.0
 

@@ -63,6 +63,43 @@ def test_two_rank_hip_sharded_render_is_bit_identical_to_one_process():
     assert abs(res[0][3] - psnr_from_sse(float((d * d).sum()), d.numel())) < 1e-9 and res[0][3] == res[1][3]
 
 
+def _eval_worker(rank, world, port, q):
+    from egonerf_amd.renderer import erp_rays, evaluation
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    q.put((rank, _evaluate()))
+    dist.destroy_process_group()
+
+
+def _evaluate():
+    from egonerf_amd.renderer import erp_rays, evaluation
+    cfg = synth.SceneConfig(n_voxel=20 ** 3)
+    model = synth.build_model(cfg, synth.make_weights(cfg, seed=1234), "cuda:0")
+    H, W = 37, 64   # 27 SSIM-map rows over 2 / 3 ranks: uneven row blocks; ray blocks that are not whole rows
+    rays = erp_rays(H, W, torch.eye(4)[:3], "cuda:0")
+    gt = torch.from_numpy(synth.hash_uniform(4, 0, H * W * 3).reshape(H * W, 3).astype(np.float32)).cuda()
+    return evaluation([rays], [gt], (W, H), model, chunk=512, ws_metrics=True, n_coarse=16, n_fine=16, exp_sampling=True, resampling=True)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_row_sharded_ssim_and_ws_metrics_equal_single_process(world):
+    """evaluation(): tiles all-gathered, every rank filters its block of SSIM-map rows, float64 all-reduces combine them
+    (renderer.py:153-163 metrics; extra/ws_ssim.py weights) - same values on every rank and as one process."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_eval_worker, args=(r, world, port, q)) for r in range(world)]
+    [p.start() for p in procs]
+    res = sorted([q.get(timeout=600) for _ in range(world)], key=lambda t: t[0])
+    [p.join(timeout=120) for p in procs]
+    assert [p.exitcode for p in procs] == [0] * world
+    single = _evaluate()
+    for _rank, ev in res:
+        assert ev == res[0][1]          # identical on every rank
+        for got, ref in zip(ev, single):
+            assert abs(got[0] - ref[0]) <= 1e-9, (ev, single)
+
+
 def _bench(*args, env_extra=None):
     env = dict(os.environ, **(env_extra or {}))
     r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), *args], capture_output=True, text=True, timeout=1500, env=env)
@@ -84,26 +121,47 @@ def test_bench_self_launches_two_ranks():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 5 and d["scaling"] == "weak" and d["cpu_baseline"] is None
     assert d["value"] > 0 and abs(d["value"] - 2 * 4096 * 5 / (d["ms_per_step"] * 5e-3)) / d["value"] < 1e-9
-    assert d["roofline"]["frac"] <= 1.0 and d["roofline"]["bound"] == "mfma"
+    assert d["roofline"]["frac"] <= 1.0 and d["roofline"]["bound"] == "mfma" and "secondary" not in d and d["process_group"] == "gloo"
 
 
 def test_bench_default_line_contract():
+    """The driver's command: one JSON line whose headline is BASELINE configs[1] and whose `secondary` block carries short runs of
+    configs[3] (train) and configs[2] (erp), each with its own roofline and cpu_baseline."""
     d = _bench("--steps", "10", "--warmup", "2", "--cpu-rays", "128")
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
-              "data", "config", "roofline", "cpu_baseline"):
+              "data", "config", "roofline", "cpu_baseline", "secondary"):
         assert k in d, k
     rf, cb = d["roofline"], d["cpu_baseline"]
-    assert rf["bound"] == "mfma" and 0 < rf["frac"] <= 1.0 and rf["unit"] == "TFLOP/s" and 2500.0 <= rf["peak"] <= 5000.0
-    assert rf["hbm_algorithmic"]["frac"] > 0 and rf["traffic"] is None or rf["traffic"] > 0
+    # frac = ALGORITHMIC flops / event-timed kernel time / the dense fp16 datasheet peak (no derived peak)
+    assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and rf["peak"] == 2500.0
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and 0.05 < rf["frac"] < 1.0
+    assert abs(rf["achieved"] - rf["flop_per_sample"] * 4096 * 512 / (rf["ms"] * 1e-3) / 1e12) / rf["achieved"] < 1e-9
+    assert rf["flop_per_sample"] == 2 * (144 * 27 + 150 * 128 + 128 * 128 + 128 * 3)
+    assert rf["traffic"] is None or (rf["traffic"] > 0 and 0 < rf["hbm_counter_frac"] < 1.0 and rf["frac"] < rf["matrix_pipe_busy"] < 1.0)
+    assert "hbm_algorithmic" not in rf and "note" in rf
+    for name in ("f16x3", "app_f16+f16f8"):   # the other arithmetics: kernel AND step level, with their error vs the oracle
+        alt = rf["alt_precision"][name]
+        assert alt["ms_per_step"] > alt["shade_ms"] > 0 and alt["rays_per_s"] > 0 and alt["max_abs_rgb_err"] <= 1e-4
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "processes" in cb["sample"]
     assert d["parity"]["max_abs_rgb_err"] <= 1e-4
     assert d["ms_per_step"] >= rf["ms"]  # a step contains the dominant kernel
+    tr, erp, opaque = (d["secondary"][k] for k in ("train", "erp", "erp_opaque_field"))
+    assert "error" not in tr and "error" not in erp and "error" not in opaque, (tr.get("error"), erp.get("error"), opaque.get("error"))
+    assert tr["config"]["rays_per_step_per_gpu"] == 8192 and tr["value"] > 0 and np.isfinite(tr["loss_last"])
+    assert tr["roofline"]["bound"] == "hbm" and tr["roofline"]["peak"] == 8000.0 and len(tr["roofline"]["kernels_ms_serialised"]) >= 10
+    assert tr["roofline"]["traffic"] is None or 0 < tr["roofline"]["frac"] < 1.0
+    assert tr["cpu_baseline"]["value"] > 0 and tr["cpu_baseline"]["kind"] == "port" and tr["speedup_vs_cpu"] > 10
+    assert erp["value"] > 0 and erp["psnr_vs_f32_unskipped_db"][0] > 80 and erp["roofline"]["bound"] == "mfma"
+    assert set(erp["roofline"]["chunk_kernels_ms"]) == {"k_march_density(coarse)", "k_sample_pdf_merge", "k_march_density(fine)", "k_shade", "k_composite"}
+    assert erp["cpu_baseline"]["value"] > 0 and erp["speedup_vs_cpu"] > 10
+    assert opaque["roofline"]["exact_zero_weight_tiles_skipped_frac_in_chunk"] > erp["roofline"]["exact_zero_weight_tiles_skipped_frac_in_chunk"]
+    assert opaque["value"] > erp["value"]   # the exact skip pays on a surface-like field
 
 
 def test_bench_train_and_erp_configs_run():
-    d = _bench("--config", "train", "--steps", "2", "--warmup", "1")
-    assert d["config"]["rays_per_step_per_gpu"] == 8192 and d["value"] > 0 and np.isfinite(d["loss_last"])
-    d = _bench("--config", "erp", "--steps", "1", "--warmup", "1", "--erp-size", "128", "256")
+    d = _bench("--config", "train", "--steps", "2", "--warmup", "1", "--no-cpu-baseline")
+    assert d["config"]["rays_per_step_per_gpu"] == 8192 and d["value"] > 0 and np.isfinite(d["loss_last"]) and d["cpu_baseline"] is None
+    d = _bench("--config", "erp", "--steps", "1", "--warmup", "1", "--erp-size", "128", "256", "--no-cpu-baseline")
     assert d["scaling"] == "strong" and d["value"] > 0 and d["psnr_vs_f32_unskipped_db"][0] > 80
     env = {"EGO_BENCH_TEST_SHARED_GPU": "1"}
     d = _bench("--config", "erp", "--gpus", "2", "--steps", "1", "--warmup", "1", "--erp-size", "128", "256", env_extra=env)

@@ -42,7 +42,41 @@ for short, d in out.items():
         d["hbm_read_bytes_corrected"] = d["FETCH_SIZE_KB"] * 1024 * 2
         d["hbm_write_bytes"] = d["WRITE_SIZE_KB"] * 1024
         d["traffic_bytes"] = d["hbm_read_bytes_corrected"] + d["hbm_write_bytes"]
-out["_source"] = f"gpurun_out/prof_{tag} (tools/profile_gpu.sh {tag}; separate rocprofv3 --pmc passes of `bench.py --steps 10 --warmup 2`)"
+
+
+def whole_step(prefix: str, unit_like: str, what: str):
+    """HBM bytes of ONE step of a multi-kernel config: per kernel name, mean bytes per dispatch x dispatches per step, summed.
+    Dispatches per step = dispatch rows of the kernel / dispatch rows of `unit_like` (a kernel launched exactly once per step:
+    k_adam for the training step, k_erp_rays for an image)."""
+    per = {}
+    units = None
+    for ctr, key, scale in (("FETCH_SIZE", "read_bytes", 1024 * 2), ("WRITE_SIZE", "write_bytes", 1024)):
+        dbs = glob.glob(src + f"/{prefix}_{ctr}/**/*.db", recursive=True)
+        if not dbs:
+            return None
+        db = sqlite3.connect(dbs[0])
+        rows = list(db.execute("select name, avg(counter_value), count(*) from pmc_events where counter_name = ? group by name", (ctr,)))
+        unit_rows = [n for name, _v, n in rows if unit_like in name]
+        if not unit_rows:
+            return None
+        units = unit_rows[0]
+        for name, val, n in rows:
+            d = per.setdefault(name, {"read_bytes": 0.0, "write_bytes": 0.0, "dispatches_per_step": n / units})
+            d[key] = val * scale * n / units
+    total_r = sum(d["read_bytes"] for d in per.values())
+    total_w = sum(d["write_bytes"] for d in per.values())
+    top = sorted(per.items(), key=lambda kv: -(kv[1]["read_bytes"] + kv[1]["write_bytes"]))[:14]
+    return {"hbm_read_bytes_corrected": total_r, "hbm_write_bytes": total_w, "traffic_bytes": total_r + total_w, "steps_profiled": units,
+            "what": what,
+            "per_kernel": {k[:80]: {kk: round(vv, 1) for kk, vv in v.items()} for k, v in top}}
+
+
+for key, prefix, unit_like, what in (("train_step", "pmctrain", "k_adam", "one training step of bench.py --config train (8192 rays x (128+128), fwd + bwd + FusedAdam + coarse refresh)"),
+                                     ("erp_image", "pmcerp", "k_erp_rays", "one 1024 x 2048 image of bench.py --config erp (128+128 samples, envmap, 16384-ray chunks)")):
+    sec = whole_step(prefix, unit_like, what)
+    if sec is not None:
+        out[key] = sec
+out["_source"] = f"gpurun_out/prof_{tag} (tools/profile_r03.sh {tag}; separate rocprofv3 --pmc passes of `bench.py --steps 10 --warmup 2`, `--config train`, `--config erp`)"
 out["_source_hash"] = source_hash()
 dst = out_path or os.path.join(root, "profiles", rnd, "pmc_traffic.json")
 os.makedirs(os.path.dirname(dst), exist_ok=True)
