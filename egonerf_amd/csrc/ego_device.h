@@ -235,13 +235,19 @@ __device__ __forceinline__ void sincos_x_2x_hw(float x, float& s1, float& c1, fl
   c2 = fmaf(-d, s1, 1.0f);
 }
 
-// wave64 inclusive multiplicative scan (Kogge-Stone over __shfl_up)
-__device__ __forceinline__ float wave_scan_mul(float v, int lane) {
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const float o = __shfl_up(v, d, 64);
-    if (lane >= d) v *= o;
-  }
+// wave64 inclusive multiplicative scan on the DPP path (no LDS round trips; __shfl_up compiles to ds_bpermute_b32 + s_waitcnt):
+// row_shr 1, 2, 4, 8 inside the 16-lane rows, then row_bcast:15 into rows 1 / 3 and row_bcast:31 into rows 2 / 3.  Lanes without a
+// source keep `old` = 1.0, the identity, so no per-step select is needed.
+__device__ __forceinline__ float wave_scan_mul(float v, int /*lane*/) {
+  const int one = __float_as_int(1.0f);
+#define EGO_SCAN_STEP(ctrl, rmask) v *= __int_as_float(__builtin_amdgcn_update_dpp(one, __float_as_int(v), ctrl, rmask, 0xf, false))
+  EGO_SCAN_STEP(0x111, 0xf);  // row_shr:1
+  EGO_SCAN_STEP(0x112, 0xf);  // row_shr:2
+  EGO_SCAN_STEP(0x114, 0xf);  // row_shr:4
+  EGO_SCAN_STEP(0x118, 0xf);  // row_shr:8
+  EGO_SCAN_STEP(0x142, 0xa);  // row_bcast:15 -> rows 1, 3
+  EGO_SCAN_STEP(0x143, 0xc);  // row_bcast:31 -> rows 2, 3
+#undef EGO_SCAN_STEP
   return v;
 }
 

@@ -96,39 +96,6 @@ __device__ __forceinline__ float density_lookup(const DevField& F, int g, float 
   return feat;
 }
 
-// Density feature by 4-lane teams (C == 16: one texel = one 64-B line = the team's four float4 parts): lane = 16 p + s serves
-// sample slot s with part p, so a load instruction touches 16 whole lines instead of 64 quarter-used ones.  Returns the
-// feature of the team's sample in all four of its lanes (relu per plane, EgoNeRF.py:340,346).
-__device__ __forceinline__ float density_team16(const DevField& F, int g, float a_r, float a_th, float a_ph, int p) {
-#pragma clang fp contract(fast)
-  constexpr int C = 16;
-  const VMTaps t = vm_setup(a_r, a_th, a_ph, F.res);
-  float feat = 0.f;
-#pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    const Lin1 X = t.ax[vm_plane_x(i)], Y = t.ax[vm_plane_y(i)], Ln = t.ax[vm_line_ax(i)];
-    const int W = F.res[vm_plane_x(i)];
-    // compact addressing (DevField): scalar base + 32-bit byte offset per tap (a table set spans < 4 GB)
-    const uint32_t pb = (g ? F.poff[1][i] : F.poff[0][i]) + 16u * (uint32_t)p;
-    const uint32_t lb = (g ? F.loff[1][i] : F.loff[0][i]) + 16u * (uint32_t)p;
-    const uint32_t r0 = pb + (uint32_t)(Y.i0 * W) * (C * 4), r1 = pb + (uint32_t)(Y.i1 * W) * (C * 4);
-    const uint32_t c0 = (uint32_t)X.i0 * (C * 4), c1 = (uint32_t)X.i1 * (C * 4);
-    const f32x4 t00 = *(const f32x4*)(F.base + (r0 + c0)), t01 = *(const f32x4*)(F.base + (r0 + c1));
-    const f32x4 t10 = *(const f32x4*)(F.base + (r1 + c0)), t11 = *(const f32x4*)(F.base + (r1 + c1));
-    const f32x4 u0 = *(const f32x4*)(F.base + (lb + (uint32_t)Ln.i0 * (C * 4))), u1 = *(const f32x4*)(F.base + (lb + (uint32_t)Ln.i1 * (C * 4)));
-    const float w00 = __fmul_rn(Y.w0, X.w0), w01 = __fmul_rn(Y.w0, X.w1);
-    const float w10 = __fmul_rn(Y.w1, X.w0), w11 = __fmul_rn(Y.w1, X.w1);
-    const f32x4 pv = t00 * w00 + t01 * w01 + t10 * w10 + t11 * w11;
-    const f32x4 lv = u0 * Ln.w0 + u1 * Ln.w1;
-    const f32x4 m = pv * lv;
-    float dot = (m.x + m.y) + (m.z + m.w);
-    dot += __shfl_xor(dot, 1, 64);   // the team's four lanes are neighbours: two quad-local exchanges
-    dot += __shfl_xor(dot, 2, 64);
-    feat += fmaxf(dot, 0.f);
-  }
-  return feat;
-}
-
 template <int C>
 __global__ void k_density_feature(DevField F, const float* __restrict__ c7n, int64_t M, float* __restrict__ out) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -207,9 +174,72 @@ __global__ void k_alpha_mask_sample(DevOcc O, const float* __restrict__ c7n, int
 
 // =============================================================================================
 // Fused: rows A+B+C+D+E for one ray per wave.  models/EgoNeRF.py:507-529 (coarse) / 544-553 (fine)
+//
+// A pass = 64 consecutive samples of the ray, in three phases that hand data over through the wave's own LDS slab:
+//   A  lane = sample: distance, point, yin-yang coordinates, radius normalisation (O(1) knot estimate from the LUT's own linear
+//      run / exponential tail, checked against the four knots around it, binary search only if the check fails), the three axis
+//      tap set-ups -> byte offsets (grid table offsets folded in) + weights to LDS (6 x 16 B per sample)
+//   B  lane = (team t = lane >> 2, part p = lane & 3), four rounds of 16 samples x three planes: a team reads its sample's set-up
+//      (6 x ds_read_b128 per round: no per-lane recomputation of the set-up, no cross-lane bpermute, no table select), gathers
+//      the 18 taps as whole 64-byte lines (part p = one float4 of each) in a two-deep software pipeline (loads of stage k + 1
+//      issued before the arithmetic of stage k), reduces inside the quad with DPP; its leader leaves the feature in LDS
+//   C  lane = sample: softplus, alpha, DPP transmittance scan with carry, weights, tile flags, outputs
+// Round 2's form did phase B with four rounds of five __shfl hand-overs (ds_bpermute + wait each), two more per plane for the
+// channel reduction and six in the scan, and recomputed the tap set-up in each of a team's four lanes: 1 256 VALU instructions and
+// 66 LDS-queue round trips per pass against 1 000 and 32 here.  Measured (tools/march_timing.py, us old -> new): 4096 x 512
+// 106.1 -> 105.2, 16384 x 128 on the pooled tables 106.0 -> 99.7, 16384 x 256 with explicit distances 207.3 -> 183.2; with the
+// tap loads replaced by register values 52 us: the kernel is co-limited by the vector L1's 16 clk per load instruction (72 loads
+// per pass = 64 us at 16 waves per CU) and VALU issue, which overlap only partly.  Three waves per SIMD (167 VGPRs): at four the
+// two 24-register load buffers spill (92 B of scratch per lane, 31 MB per launch through L2: 124 us).  DESIGN.md 4.4.
 // =============================================================================================
-template <int C>
-__global__ __launch_bounds__(256) void k_march_density(DevCoords c, DevField F, const float* __restrict__ rays,
+struct LutHints {   // derived per workgroup from the LUT itself (so any monotone LUT works: the estimate is only a starting point)
+  float r0;         // first knot spacing (lut[1] - lut[0])
+  float lin_end;    // last knot of the arithmetic run
+  float inv_l2r;    // 1 / log2(ratio) of the exponential tail
+  float shift;      // tail knots: shift + r0' * ratio^k
+  float inv_r0;
+  float tail_k0;    // index offset of the tail estimate
+};
+
+// searchsorted(lut, r, right) clamped to [1, n - 1] (coordinates.py:125-127) without the 10-step dependent search: estimate the
+// knot from the closed forms, read the four knots around it, accept if they bracket r, else search.  Bit-identical to normalize_r.
+__device__ __forceinline__ float normalize_r_fast(float r, const float* lut, int n_lut, int n_r, const LutHints& H) {
+  float kf;
+  if (r < H.lin_end) kf = r * H.inv_r0;
+  else kf = fmaf(__log2f(fmaxf(r - H.shift, 1e-30f)), H.inv_l2r, H.tail_k0);
+  kf = fminf(fmaxf(kf, 0.f), (float)(n_lut - 1));
+  const int c0 = (int)kf + 1;                      // estimate of lo = #{i : lut[i] <= r}
+  // knots c0 - 2 .. c0 + 1; virtual knots below index 0 are <= r, beyond the end are > r
+  int lo = c0 - 2;
+  bool ok = r == r;
+#pragma unroll
+  for (int d = -2; d <= 1; ++d) {
+    const int j = c0 + d;
+    const bool in = (unsigned)j < (unsigned)n_lut;
+    const float v = lut[in ? j : 0];
+    const bool le = in ? (v <= r) : (j < 0);
+    lo += le ? 1 : 0;
+    if (d == -2) ok = ok && le;                    // the window's first knot must not exceed r
+    if (d == 1) ok = ok && (!le || j >= n_lut - 1);  // and its last one must (unless it is the LUT's end)
+  }
+  if (!ok) {   // rare: estimate off by more than a knot (or NaN): the reference's search
+    int l = 0, h = n_lut;
+    while (l < h) {
+      const int mid = (l + h) >> 1;
+      if (!(lut[mid] > r)) l = mid + 1; else h = mid;
+    }
+    lo = l;
+  }
+  const int k_out = lo < 1 ? 1 : (lo > n_lut - 1 ? n_lut - 1 : lo);
+  const int k_in = k_out - 1;
+  const float g0 = lut[k_in], g1 = lut[k_out];
+  const float frac = __fdiv_rn(__fsub_rn(r, g0), __fsub_rn(g1, g0));
+  const float v = __fdiv_rn(__fadd_rn((float)k_in, frac), (float)n_r);
+  return __fsub_rn(__fmul_rn(v, 2.0f), 1.0f);
+}
+
+template <int C, bool OCC>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_march_density(DevCoords c, DevField F, const float* __restrict__ rays,
                                                        int64_t N, int S, const float* __restrict__ z_in,
                                                        const float* __restrict__ r_sched,
                                                        const float* __restrict__ jitter, float near_,
@@ -219,20 +249,68 @@ __global__ __launch_bounds__(256) void k_march_density(DevCoords c, DevField F, 
                                                        float* __restrict__ bg, float* __restrict__ coords_out,
                                                        float* __restrict__ sigma_out, DevOcc occ, float term_eps,
                                                        float shade_above, uint8_t* __restrict__ tile_active) {
+  static_assert(C == 16, "one texel = one 64-byte line = the team's four float4 parts");
   __shared__ float lut[1024];
+  __shared__ __attribute__((aligned(16))) f32x4 stage[4][6][64];   // per wave: the pass's tap set-ups
+  __shared__ float fres[4][64];                                      // per wave: the pass's density features
+  __shared__ int s_nlin;
+  __shared__ LutHints s_hints;
   for (int i = threadIdx.x; i < c.n_lut; i += blockDim.x) lut[i] = c.r_lut[i];
+  if (threadIdx.x == 0) s_nlin = c.n_lut - 1;
   __syncthreads();
-  const int lane = threadIdx.x & 63;
-  const int64_t ray = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  {
+    // arithmetic run = the leading intervals equal to lut[1] - lut[0] up to float32 rounding of k * r0 (the reference replaces
+    // every shell thinner than r0 by a step of r0): the first interval that is not ends it
+    const float r0 = lut[1] - lut[0];
+    int first_other = c.n_lut - 1;
+    for (int i = threadIdx.x; i + 1 < c.n_lut; i += blockDim.x)
+      if (!(fabsf((lut[i + 1] - lut[i]) - r0) <= r0 * 1e-3f)) first_other = min(first_other, i);
+    if (first_other < c.n_lut - 1) atomicMin(&s_nlin, first_other);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const int n = c.n_lut, nl = s_nlin;
+      LutHints H;
+      H.r0 = r0; H.inv_r0 = 1.f / r0; H.lin_end = lut[nl];
+      // tail: lut[k] = shift + a * ratio^k: ratio from the last three knots, shift from the last two
+      float ratio = 2.f, sh = 0.f;
+      if (n - nl >= 4) {
+        const float a = lut[n - 3], b = lut[n - 2], cc = lut[n - 1];
+        ratio = (cc - b) / (b - a);
+        sh = b - (cc - b) / (ratio - 1.f);
+      }
+      H.shift = sh;
+      H.inv_l2r = 1.f / __log2f(fmaxf(ratio, 1.0000001f));
+      // kf = log2(r - shift) * inv_l2r + tail_k0 must give kf = k for r = lut[k]: calibrate on the last knot
+      H.tail_k0 = (float)(n - 1) - __log2f(fmaxf(lut[n - 1] - sh, 1e-30f)) * H.inv_l2r;
+      if (n - nl < 4) { H.lin_end = 3.0e38f; }   // (almost) all linear: never take the tail form
+      s_hints = H;
+    }
+    __syncthreads();
+  }
+  LutHints H;   // wave-uniform: keep the six values in SGPRs (read from LDS they would occupy six VGPRs for the whole kernel)
+  {
+    const auto sf = [](float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); };
+    H.r0 = sf(s_hints.r0); H.lin_end = sf(s_hints.lin_end); H.inv_l2r = sf(s_hints.inv_l2r); H.shift = sf(s_hints.shift);
+    H.inv_r0 = sf(s_hints.inv_r0); H.tail_k0 = sf(s_hints.tail_k0);
+  }
+  // the wave index is wave-uniform: readfirstlane puts it - and with it the ray index and every per-ray base address - into SGPRs
+  const int lane0 = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t ray = (int64_t)blockIdx.x * 4 + wv;
   if (ray >= N) return;
   const float* R = rays + ray * 6;
   const float ox = R[0], oy = R[1], oz = R[2], dx = R[3], dy = R[4], dz = R[5];
+  const int nr64 = F.res[0] * (C * 4), nth64 = F.res[1] * (C * 4);
   float carry = 1.f;
   // Exact early termination: once the transmittance in front of a pass is exactly 0 (fp32 underflow behind opaque samples), every
   // remaining weight is a * 0 = 0 and bg stays 0, so the rest of the ray only needs its distances and zero weights - unless the
   // caller wants per-sample alpha / sigma, which are independent of what lies in front.
   const bool may_stop = !alpha && !sigma_out;
   for (int s0 = 0; s0 < S; s0 += 64) {
+    // lane-derived values (team, part, LDS slab addresses, ...) are recomputed per pass from an opaque copy of the lane index:
+    // hoisted out of the loop they cost a dozen VGPRs for the whole kernel, which then spill around the 48-register load buffers
+    int lane = lane0;
+    asm volatile("" : "+v"(lane));
+    const int team = lane >> 2, part = lane & 3;
     const int s = min(s0 + lane, S - 1);
     const bool ok = (s0 + lane) < S;
     // z[s] and its right neighbour (left neighbour for the last sample: dists repeat the last interval)
@@ -255,39 +333,109 @@ __global__ __launch_bounds__(256) void k_march_density(DevCoords c, DevField F, 
       }
       continue;
     }
+    // ---- phase A: lane = sample -----------------------------------------------------------------------------------
     const float dist = (s < S - 1) ? __fsub_rn(zn, z) : __fsub_rn(z, zn);
     const float px = __fadd_rn(ox, __fmul_rn(dx, z)), py = __fadd_rn(oy, __fmul_rn(dy, z)),
                 pz = __fadd_rn(oz, __fmul_rn(dz, z));
     const YinYang y = yinyang_from_xyz(px, py, pz, c);
-    const float a_r = normalize_r(y.r, lut, c.n_lut, c.n_r);
+    const float a_r = normalize_r_fast(y.r, lut, c.n_lut, c.n_r, H);
     const float a_th = normalize_ang(y.th, c.th_near, c.th_inv);
     const float a_ph = normalize_ang(y.ph, c.ph_near, c.ph_inv);
     // occupancy mask (opt-in): unoccupied samples keep sigma = 0 and skip the 18-tap gather
-    const bool occupied = !occ.vol || occ_sample(occ, y.yang, a_r, a_th, a_ph) > 0.f;
-    float sg = 0.f;
-    if (C == 16) {
-      // four rounds of 16 samples: round rd serves samples 16 rd .. 16 rd + 15 of this pass; lane 16 p + s keeps round p's result
-      float f = 0.f;
-      const int yg = y.yang ? 1 : 0;
-#pragma unroll
-      for (int rd = 0; rd < 4; ++rd) {
-        // team = four NEIGHBOURING lanes (4 t .. 4 t + 3) serving sample 16 rd + t with parts 0..3: the 16 lanes of a row read 4
-        // lines (not 16 quarter-lines), consecutive samples of the ray - which mostly share their texel lines - sit in one row,
-        // and the channel reduction is quad-local (teams of lanes 16 apart: 0.109 vs 0.105 ms, removed)
-        const int src = 16 * rd + (lane >> 2);
-        const float tr = __shfl(a_r, src, 64), tt = __shfl(a_th, src, 64), tp = __shfl(a_ph, src, 64);
-        const int tg = __shfl(yg, src, 64);
-        const bool tocc = __shfl((int)occupied, src, 64) != 0;
-        float d = 0.f;
-        if (__ballot(tocc) != 0ull) d = density_team16(F, tg, tr, tt, tp, lane & 3);
-        const float got = __shfl(d, 4 * (lane & 15), 64);   // sample 16 rd + (lane & 15) was served by team lane & 15
-        if ((lane >> 4) == rd) f = got;
-      }
-      if (occupied) sg = softplus ? softplus_shift(f, shift) : fmaxf(f, 0.f);
-    } else if (occupied) {
-      const float f = density_lookup<C>(F, y.yang, a_r, a_th, a_ph);
-      sg = softplus ? softplus_shift(f, shift) : fmaxf(f, 0.f);
+    const bool occupied = !OCC || !occ.vol || occ_sample(occ, y.yang, a_r, a_th, a_ph) > 0.f;
+    {
+      // byte offsets of every tap row / line of the sample's grid (the grid's table offsets folded in here, once per sample, so
+      // that phase B needs no per-lane table select) + column offsets + the six axis weights
+      const Lin1 Rr = lin_setup(a_r, F.res[0]), Tt = lin_setup(a_th, F.res[1]), Pp = lin_setup(a_ph, F.res[2]);
+      const auto fu = [](uint32_t v) { return __uint_as_float(v); };
+      const bool yg = y.yang != 0;
+      const uint32_t pb0 = yg ? F.poff[1][0] : F.poff[0][0], pb1 = yg ? F.poff[1][1] : F.poff[0][1], pb2 = yg ? F.poff[1][2] : F.poff[0][2];
+      const uint32_t lb0 = yg ? F.loff[1][0] : F.loff[0][0], lb1 = yg ? F.loff[1][1] : F.loff[0][1], lb2 = yg ? F.loff[1][2] : F.loff[0][2];
+      constexpr uint32_t TX = C * 4;   // bytes per texel
+      stage[wv][0][lane] = f32x4{fu(Rr.i0 * TX), fu(Rr.i1 * TX), fu(Tt.i0 * TX), fu(Tt.i1 * TX)};                             // columns: r | theta
+      stage[wv][1][lane] = f32x4{fu(pb0 + Tt.i0 * nr64), fu(pb0 + Tt.i1 * nr64), fu(pb1 + Pp.i0 * nr64), fu(pb1 + Pp.i1 * nr64)};  // rows: plane 0 | plane 1
+      stage[wv][2][lane] = f32x4{fu(pb2 + Pp.i0 * nth64), fu(pb2 + Pp.i1 * nth64), fu(lb0 + Pp.i0 * TX), fu(lb0 + Pp.i1 * TX)};   // rows: plane 2 | line 0 (phi)
+      stage[wv][3][lane] = f32x4{fu(lb1 + Tt.i0 * TX), fu(lb1 + Tt.i1 * TX), fu(lb2 + Rr.i0 * TX), fu(lb2 + Rr.i1 * TX)};         // line 1 (theta) | line 2 (r)
+      stage[wv][4][lane] = f32x4{Rr.w0, Rr.w1, Tt.w0, Tt.w1};
+      stage[wv][5][lane] = f32x4{Pp.w0, Pp.w1, fu(occupied ? 1u : 0u), 0.f};
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // ---- phase B: lane = (team, part), four rounds of 16 samples x three planes = 12 stages of six 16-byte loads -------------
+    // Software pipeline: the loads of stage k + 1 are issued before the arithmetic of stage k (two 6-register-quad buffers), so
+    // six to twelve loads stay in flight instead of the queue draining once per plane; a round's set-up (6 x ds_read_b128) is
+    // fetched while the previous round's last plane computes.
+    {
+#pragma clang fp contract(fast)
+      f32x4 raw[2][6];
+      float wgt6[2][6];
+      f32x4 q[6];
+      float feat = 0.f;
+      const uint32_t p16 = 16u * (uint32_t)part;
+      const auto ui = [](float v) { return __float_as_uint(v); };
+      auto fetch_setup = [&](int rd, f32x4* dst) {
+        const int src = 16 * rd + team;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) dst[k] = stage[wv][k][src];
+      };
+      auto issue = [&](const f32x4* Q, int i, f32x4* r6, float* w6) {
+        // plane i: columns (x axis), rows (y axis, table offset included), line taps; weights of x / y / line axis
+        const uint32_t c0 = ui(i == 2 ? Q[0].z : Q[0].x) + p16, c1 = ui(i == 2 ? Q[0].w : Q[0].y) + p16;
+        const uint32_t r0 = ui(i == 0 ? Q[1].x : (i == 1 ? Q[1].z : Q[2].x)), r1 = ui(i == 0 ? Q[1].y : (i == 1 ? Q[1].w : Q[2].y));
+        const uint32_t l0 = ui(i == 0 ? Q[2].z : (i == 1 ? Q[3].x : Q[3].z)) + p16, l1 = ui(i == 0 ? Q[2].w : (i == 1 ? Q[3].y : Q[3].w)) + p16;
+        const float xw0 = i == 2 ? Q[4].z : Q[4].x, xw1 = i == 2 ? Q[4].w : Q[4].y;
+        const float yw0 = i == 0 ? Q[4].z : Q[5].x, yw1 = i == 0 ? Q[4].w : Q[5].y;
+        const float lw0 = i == 0 ? Q[5].x : (i == 1 ? Q[4].z : Q[4].x), lw1 = i == 0 ? Q[5].y : (i == 1 ? Q[4].w : Q[4].y);
+        r6[0] = *(const f32x4*)(F.base + (r0 + c0)); r6[1] = *(const f32x4*)(F.base + (r0 + c1));
+        r6[2] = *(const f32x4*)(F.base + (r1 + c0)); r6[3] = *(const f32x4*)(F.base + (r1 + c1));
+        r6[4] = *(const f32x4*)(F.base + l0); r6[5] = *(const f32x4*)(F.base + l1);
+        w6[0] = __fmul_rn(yw0, xw0); w6[1] = __fmul_rn(yw0, xw1); w6[2] = __fmul_rn(yw1, xw0); w6[3] = __fmul_rn(yw1, xw1);
+        w6[4] = lw0; w6[5] = lw1;
+        // every weight in a register of its own: a packed multiply then broadcasts the LOW half of its operand pair; the high-half
+        // broadcast form (op_sel without op_sel_hi) is the code-generation feature DESIGN.md 5.1 ties to non-reproducible results
+#pragma unroll
+        for (int k = 0; k < 6; ++k) asm volatile("" : "+v"(w6[k]));
+      };
+      auto finish = [&](const f32x4* r6, const float* w6) {
+        const f32x4 pv = r6[0] * w6[0] + r6[1] * w6[1] + r6[2] * w6[2] + r6[3] * w6[3];
+        const f32x4 lv = r6[4] * w6[4] + r6[5] * w6[5];
+        const f32x4 m = pv * lv;
+        float dot = (m.x + m.y) + (m.z + m.w);
+        // the team's four lanes are one DPP quad: two quad_perm adds (no LDS round trip, unlike __shfl_xor's ds_bpermute)
+        dot += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(dot), 0xB1 /* quad_perm [1,0,3,2] */, 0xf, 0xf, true));
+        dot += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(dot), 0x4E /* quad_perm [2,3,0,1] */, 0xf, 0xf, true));
+        feat += fmaxf(dot, 0.f);         // relu per plane (EgoNeRF.py:340,346)
+      };
+      fetch_setup(0, q);
+      issue(q, 0, raw[0], wgt6[0]);
+      bool masked = OCC && !(__float_as_int(q[5].z) & 1), masked_next = false;
+#pragma unroll
+      for (int st = 0; st < 12; ++st) {
+        const int rd = st / 3, i = st % 3;
+        if (st + 1 < 12) issue(q, (st + 1) % 3, raw[(st + 1) & 1], wgt6[(st + 1) & 1]);
+        if (i == 1 && rd + 1 < 4) {   // the set-up is dead once the round's last plane has been issued: fetch the next round's
+          fetch_setup(rd + 1, q);
+          masked_next = OCC && !(__float_as_int(q[5].z) & 1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        finish(raw[st & 1], wgt6[st & 1]);
+        if (i == 2) {
+          if (masked) feat = 0.f;   // sample masked out: sigma stays 0 (feature unused)
+          if (part == 0) fres[wv][16 * rd + team] = feat;
+          feat = 0.f;
+          masked = masked_next;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // ---- phase C: lane = sample ------------------------------------------------------------------------------------------
+    const float f = fres[wv][lane];
+    float sg = 0.f;
+    if (occupied) sg = softplus ? softplus_shift(f, shift) : fmaxf(f, 0.f);
     const float a = ok ? __fsub_rn(1.f, expf(-sg * __fmul_rn(dist, dscale))) : 0.f;
     const float t = ok ? __fadd_rn(__fsub_rn(1.f, a), 1e-10f) : 1.f;
     const float inc = wave_scan_mul(t, lane);
@@ -318,8 +466,8 @@ __global__ __launch_bounds__(256) void k_march_density(DevCoords c, DevField F, 
     carry *= __shfl(inc, 63, 64);
   }
   // with an environment map the reference appends a column of ones to alpha (EgoNeRF.py:587)
-  if (alpha && lane < alpha_stride - S) alpha[ray * alpha_stride + S + lane] = 1.f;
-  if (bg && lane == 0) bg[ray] = carry;
+  if (alpha && lane0 < alpha_stride - S) alpha[ray * alpha_stride + S + lane0] = 1.f;
+  if (bg && lane0 == 0) bg[ray] = carry;
 }
 
 // =============================================================================================
@@ -783,10 +931,17 @@ int ego_march_density(const ego_scene* sc, const float* rays, int64_t N, int32_t
   if (int e = check_field(f, "march_density")) return e;
   if (N == 0) return EGO_OK;
   if (f.n_comp != 16) return ego_fail(EGO_E_UNSUPPORTED, "march_density: n_comp %d (supported: 16)", f.n_comp);
-  k_march_density<16><<<nblk(N, 4), 256, 0, (hipStream_t)stream>>>(
-      make_coords(*sc, (coarse & 2) != 0), make_field(f), rays, N, S, z_in, r_sched, jitter, near_, sc->act_softplus, sc->density_shift,
-      sc->distance_scale, z_out, alpha, alpha_stride, weight, bg_weight, coords_out, sigma_out, make_occ(*sc, coarse & 1), sc->term_eps,
-      fmaxf(sc->weight_thres, 0.f), tile_active);
+  const DevOcc o = make_occ(*sc, coarse & 1);
+  if (o.vol)
+    k_march_density<16, true><<<nblk(N, 4), 256, 0, (hipStream_t)stream>>>(
+        make_coords(*sc, (coarse & 2) != 0), make_field(f), rays, N, S, z_in, r_sched, jitter, near_, sc->act_softplus, sc->density_shift,
+        sc->distance_scale, z_out, alpha, alpha_stride, weight, bg_weight, coords_out, sigma_out, o, sc->term_eps,
+        fmaxf(sc->weight_thres, 0.f), tile_active);
+  else
+    k_march_density<16, false><<<nblk(N, 4), 256, 0, (hipStream_t)stream>>>(
+        make_coords(*sc, (coarse & 2) != 0), make_field(f), rays, N, S, z_in, r_sched, jitter, near_, sc->act_softplus, sc->density_shift,
+        sc->distance_scale, z_out, alpha, alpha_stride, weight, bg_weight, coords_out, sigma_out, o, sc->term_eps,
+        fmaxf(sc->weight_thres, 0.f), tile_active);
   return ego_launch_status("k_march_density");
 }
 

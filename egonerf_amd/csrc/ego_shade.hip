@@ -814,13 +814,30 @@ __device__ __forceinline__ void dump24(float* dst, const float* v) {
 
 // whole gather + basis for one tile; ts[rd] = the sample this lane's team serves in round rd.  All 64 lanes must call
 // (cross-lane swaps).
-__device__ __forceinline__ void basis3(const u32x4* __restrict__ BASH, int lane, int step0, int gsel, bool keep, const float* v,
-                                       f32x16& fe) {
-  BasisFrag f0, f1, f2;
-  if (step0 == 0) { f0 = basis_frag<0>(BASH, lane, gsel); f1 = basis_frag<1>(BASH, lane, gsel); f2 = basis_frag<2>(BASH, lane, gsel); }
-  else if (step0 == 3) { f0 = basis_frag<3>(BASH, lane, gsel); f1 = basis_frag<4>(BASH, lane, gsel); f2 = basis_frag<5>(BASH, lane, gsel); }
-  else { f0 = basis_frag<6>(BASH, lane, gsel); f1 = basis_frag<7>(BASH, lane, gsel); f2 = basis_frag<8>(BASH, lane, gsel); }
-  basis_step(f0, v, keep, fe); basis_step(f1, v + 8, keep, fe); basis_step(f2, v + 16, keep, fe);
+// one basis k-step of 8 products: split once, three MFMAs with the wave's grid (g0) and - only in a wave that straddles the yin /
+// yang border - three more with the other grid's fragments into the second accumulator (the split is shared: re-splitting in the
+// rare branch made the compiler hoist 72 fp16 -> fp32 conversions per tile onto the common path)
+template <int STEP>
+__device__ __forceinline__ void basis_step2(const u32x4* __restrict__ BASH, int lane, const BasisFrag& a, bool mixed, const float x[8],
+                                            f32x16& fe, f32x16& fe2) {
+  const HL b = split8(x, true);
+  fe = MFMAH(a.hi, b.hi, fe);
+  fe = MFMAH(a.lo, b.hi, fe);
+  fe = MFMAH(a.hi, b.lo, fe);
+  if (mixed) {  // wave-uniform
+    const BasisFrag a1 = basis_frag<STEP>(BASH, lane, 1);
+    fe2 = MFMAH(a1.hi, b.hi, fe2);
+    fe2 = MFMAH(a1.lo, b.hi, fe2);
+    fe2 = MFMAH(a1.hi, b.lo, fe2);
+  }
+}
+
+template <int STEP0>
+__device__ __forceinline__ void basis3(const u32x4* __restrict__ BASH, int lane, int g0, bool mixed, const float* v, f32x16& fe, f32x16& fe2) {
+  const BasisFrag f0 = basis_frag<STEP0>(BASH, lane, g0), f1 = basis_frag<STEP0 + 1>(BASH, lane, g0), f2 = basis_frag<STEP0 + 2>(BASH, lane, g0);
+  basis_step2<STEP0>(BASH, lane, f0, mixed, v, fe, fe2);
+  basis_step2<STEP0 + 1>(BASH, lane, f1, mixed, v + 8, fe, fe2);
+  basis_step2<STEP0 + 2>(BASH, lane, f2, mixed, v + 16, fe, fe2);
 }
 
 // ROLL: the rolling form of the load buffer (tap_ptrs / line_load / line_finish above); it needs all 256 registers, so only the
@@ -864,8 +881,7 @@ __device__ __forceinline__ void gather_basis_team(const DevField& F, const TeamS
       }                                                                                                   \
       team_to_halves(ga, gb, v);                                                                          \
       dump24(DUMPPTR, v);                                                                                 \
-      basis3(BASH, lane, STEP0, g0, true, v, fe);                                                         \
-      if (mixed) basis3(BASH, lane, STEP0, 1, true, v, fe2);                                              \
+      basis3<STEP0>(BASH, lane, g0, mixed, v, fe, fe2);                                                   \
     }
     EGO_ROLL_PLANE(0, pa = tap_ptrs<1>(F, tA, ts[0].g, qa), 0, vdump)
     pb = tap_ptrs<1>(F, tB, ts[1].g, qb);
@@ -888,8 +904,7 @@ __device__ __forceinline__ void gather_basis_team(const DevField& F, const TeamS
   dump24(vdump, v);
   __builtin_amdgcn_sched_barrier(0);
   team_load<1>(F, tA, ts[0].g, qa, raw);
-  basis3(BASH, lane, 0, g0, true, v, fe);
-  if (mixed) basis3(BASH, lane, 0, 1, true, v, fe2);
+  basis3<0>(BASH, lane, g0, mixed, v, fe, fe2);
   team_finish<1>(tA, raw, ga);
   __builtin_amdgcn_sched_barrier(0);
   team_load<1>(F, tB, ts[1].g, qb, raw);
@@ -898,16 +913,14 @@ __device__ __forceinline__ void gather_basis_team(const DevField& F, const TeamS
   dump24(vdump ? vdump + 6 * 256 : nullptr, v);
   __builtin_amdgcn_sched_barrier(0);
   team_load<2>(F, tA, ts[0].g, qa, raw);
-  basis3(BASH, lane, 3, g0, true, v, fe);
-  if (mixed) basis3(BASH, lane, 3, 1, true, v, fe2);
+  basis3<3>(BASH, lane, g0, mixed, v, fe, fe2);
   team_finish<2>(tA, raw, ga);
   __builtin_amdgcn_sched_barrier(0);
   team_load<2>(F, tB, ts[1].g, qb, raw);
   team_finish<2>(tB, raw, gb);
   team_to_halves(ga, gb, v);
   dump24(vdump ? vdump + 12 * 256 : nullptr, v);
-  basis3(BASH, lane, 6, g0, true, v, fe);
-  if (mixed) basis3(BASH, lane, 6, 1, true, v, fe2);
+  basis3<6>(BASH, lane, g0, mixed, v, fe, fe2);
   if (mixed) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) fe[r] = g ? fe2[r] : fe[r];

@@ -504,6 +504,23 @@ class EgoNeRF(TensorBase):
         self._mlp_precision = value
         self._scene_cache = None
 
+    @torch.no_grad()
+    def check_mlp_precision(self, rays: torch.Tensor, **forward_kw) -> dict:
+        """Renders `rays` with the current arithmetic and with the fp32-grade "f16x3" one and returns the largest colour
+        difference.  "f16f8" is 2^-16-relative per product: its error scales with the magnitudes inside the MLP (1.4e-5 composited
+        on the bench scene, 2e-5 per sample at nn.Linear-default x 3 weights, 3e-3 per sample when the logits reach +-50), so a
+        trained checkpoint should be checked once on a few thousand rays and switched to "f16x3" if this exceeds its budget."""
+        keep = self._mlp_precision
+        try:
+            got = self.forward(rays, **forward_kw)[0]
+            self.mlp_precision = "f16x3"
+            ref = self.forward(rays, **forward_kw)[0]
+        finally:
+            self.mlp_precision = keep
+        d = (got - ref).abs()
+        return dict(mlp_precision=keep, max_abs_rgb_diff_vs_f16x3=float(d.max()) if d.numel() else 0.0,
+                    mean_abs_rgb_diff_vs_f16x3=float(d.mean()) if d.numel() else 0.0, rays=int(rays.shape[0]))
+
     @property
     def app_table_dtype(self) -> str:
         """Storage of the appearance tables the inference gather reads: "f32" (the parameters themselves) or "f16" (a

@@ -46,7 +46,7 @@ def precision(request, tiny, full):
 
 def test_native_library_is_the_path(tiny):
     from egonerf_amd import _lib
-    assert _lib.load().ego_abi_version() == 7
+    assert _lib.load().ego_abi_version() == _lib.EXPECTED_ABI_VERSION
     with pytest.raises(RuntimeError):  # CPU tensors never silently fall back
         tiny[3](torch.zeros(4, 6), n_coarse=8, exp_sampling=True)
 

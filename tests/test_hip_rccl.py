@@ -80,7 +80,7 @@ def test_one_rank_rccl_group_runs_the_sharded_render_and_evaluation():
     assert torch.equal(image, image1) and psnr == psnr1
     for a, c in zip(ev, ev1):
         assert a == c
-    assert len(ev) == 4 and 0 < ev[1][0] < 1 and np.isfinite(ev[2][0]) and 0 < ev[3][0] < 1
+    assert len(ev) == 4 and -1 < ev[1][0] < 1 and np.isfinite(ev[2][0]) and -1 < ev[3][0] < 1   # gt is noise: SSIM ~ 0
 
 
 def test_bench_erp_under_a_one_rank_rccl_launcher():
