@@ -1,15 +1,8 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-python -c "import __graft_entry__ as g; g.build()" > gpurun_out/r3_build.log 2>&1
-timeout 3000 python -m pytest tests -m gpu -q > gpurun_out/r3_gputest6.log 2>&1
-grep -E "passed|failed|FAILED" gpurun_out/r3_gputest6.log | tail -12
-python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/r3_bench2.json 2> gpurun_out/r3_bench2.err
-python -c "
-import json; d=json.load(open('gpurun_out/r3_bench2.json'))
-print('headline', d['value'], d['ms_per_step'], d['roofline']['ms'], d['roofline']['other_kernels_ms'], d['roofline']['frac'])
-s=d['secondary']
-print('train', s['train'].get('ms_per_step'), s['train'].get('cpu_baseline',{}).get('value'), s['train'].get('error'))
-print('erp', s['erp'].get('s_per_image'), s['erp'].get('cpu_baseline',{}).get('value'), s['erp'].get('parity'), s['erp'].get('error'))
-print('erp_opaque', s['erp_opaque_field'].get('s_per_image'), s['erp_opaque_field'].get('error'))
-print('ET', d['roofline']['alt_early_termination'])
-"
+for rep in 1 2 3; do for v in base f16src; do cp egonerf_amd/libvariant_$v.so egonerf_amd/libegonerf_hip.so
+EGO_ALLOW_STALE_LIB=1 python bench.py --no-cpu-baseline --no-secondary --cpu-rays 256 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$v', round(d['ms_per_step'], 4), 'shade', round(d['roofline']['ms'], 4))"
+done; done > gpurun_out/r3_f16src.log 2>&1
+cp egonerf_amd/libvariant_f16src.so egonerf_amd/libegonerf_hip.so
+EGO_ALLOW_STALE_LIB=1 python bench.py --no-secondary --cpu-rays 1024 --steps 20 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('f16src parity', d['parity'])" >> gpurun_out/r3_f16src.log 2>&1
+cat gpurun_out/r3_f16src.log
