@@ -21,10 +21,6 @@
 #include "ego_device.h"
 #include "ego_host.h"
 #include "variants.h"
-#include <stdlib.h>
-#ifndef EGO_F8_FROM_F16
-#define EGO_F8_FROM_F16 0
-#endif
 
 namespace {
 
@@ -639,18 +635,10 @@ __device__ __forceinline__ h8 split8_f8(const float x[8], v8i& b8, int odd) {
       // the low-half conversion keeps the other half of its destination, which the high-half conversion of the next value pair
       // overwrites: seed the destination with a value that is about to die (the operands themselves) rather than with a zero,
       // which costs a v_mov per operand register
-#if EGO_F8_FROM_F16
-      xh[q >> 1] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(__builtin_bit_cast(v2s, b), hp, 1.0f, false));
-#else
       xh[q >> 1] = (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(a, b, __builtin_bit_cast(int, b), false);
-#endif
       xl[q >> 1] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(__builtin_bit_cast(v2s, rb), ra, rb, 1.0f / 2048.0f, false));
     } else {
-#if EGO_F8_FROM_F16
-      xh[q >> 1] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(__builtin_bit_cast(v2s, xh[q >> 1]), hp, 1.0f, true));
-#else
       xh[q >> 1] = (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(a, b, (int)xh[q >> 1], true);
-#endif
       xl[q >> 1] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(__builtin_bit_cast(v2s, xl[q >> 1]), ra, rb,
                                                                                          1.0f / 2048.0f, true));
     }
@@ -1358,208 +1346,6 @@ __global__ __launch_bounds__(512) void k_shade_h(ShadeArgs A) {
   }
 }
 
-// =================================================================================================================
-// EXPERIMENT: one 512-register wave per SIMD whose instruction stream carries the MLP phase of tile k and the
-// gather phase of tile k + 1 side by side (the overlap two 256-register waves per SIMD produce dynamically, scheduled statically
-// by the compiler inside one basic block: no sched_barriers, no branches).  f16f8 arithmetic, fused SHADE mode, fp32 tables.
-// Border-straddling tiles take the first grid's basis for the whole tile (timing build: colours of those tiles are wrong).
-// =================================================================================================================
-struct PipeTile {
-  f32x16 fe;
-  float vd0, vd1, vd2;
-};
-
-__device__ __forceinline__ void pipe_gather(const ShadeArgs& A, int64_t tile, int lw, const u32x4* __restrict__ BASH, PipeTile& T) {
-  const int j = lw & 31;
-  const int64_t m_raw = tile * 32 + j;
-  const int64_t m = m_raw < A.M ? m_raw : A.M - 1;
-  const uint32_t ray = (uint32_t)m / (uint32_t)A.S;
-  const float* R = A.rays + (int64_t)ray * 6;
-  T.vd0 = R[3]; T.vd1 = R[4]; T.vd2 = R[5];
-  const f32x4 cc = ((const f32x4*)A.coords)[m];
-  const int g = cc.w != 0.f;
-  const int gu = __ballot(g == 0) != 0ull ? 0 : 1;
-  TeamSample ts[2];
-#pragma unroll
-  for (int rd = 0; rd < 2; ++rd) {
-    const int64_t mt_raw = tile * 32 + 2 * ((lw >> 1) & 15) + rd;
-    const int64_t mt = mt_raw < A.M ? mt_raw : A.M - 1;
-    const f32x4 c4 = ((const f32x4*)A.coords)[mt];
-    ts[rd].a_r = c4.x; ts[rd].a_th = c4.y; ts[rd].a_ph = c4.z; ts[rd].g = c4.w != 0.f;
-  }
-#pragma unroll
-  for (int r = 0; r < 16; ++r) T.fe[r] = 0.f;
-  const int qa = (lw >> 5) + 2 * (lw & 1), qb = (lw >> 5) + 2 * ((lw & 1) ^ 1);
-  const VMTaps tA = vm_setup(ts[0].a_r, ts[0].a_th, ts[0].a_ph, A.F.res), tB = vm_setup(ts[1].a_r, ts[1].a_th, ts[1].a_ph, A.F.res);
-  f32x4 rawA[18], rawB[18];
-  float ga[12], gb[12], v[24];
-  f32x16 unused;
-#define EGO_PIPE_PLANE(PL, STEP0)                              \
-  team_load<PL>(A.F, tA, ts[0].g, qa, rawA);                   \
-  team_load<PL>(A.F, tB, ts[1].g, qb, rawB);                   \
-  team_finish<PL>(tA, rawA, ga);                               \
-  team_finish<PL>(tB, rawB, gb);                               \
-  team_to_halves(ga, gb, v);                                   \
-  basis3<STEP0>(BASH, lw, gu, false, v, T.fe, unused);
-  EGO_PIPE_PLANE(0, 0)
-  EGO_PIPE_PLANE(1, 3)
-  EGO_PIPE_PLANE(2, 6)
-#undef EGO_PIPE_PLANE
-}
-
-__device__ __forceinline__ void pipe_mlp(const ShadeArgs& A, int64_t tile, int lw, const float* lds, const PipeTile& T) {
-  const int j = lw & 31, h = lw >> 5, hw = h;
-  const int64_t m_raw = tile * 32 + j;
-  const bool valid = m_raw < A.M;
-  const int64_t m = valid ? m_raw : A.M - 1;
-  const u32x4* W1 = (const u32x4*)(lds + OFF_W1);
-  const u32x4* W2 = (const u32x4*)(lds + OFF_W2);
-  const f32x4* B1 = (const f32x4*)(lds + OFF_B1);
-  const f32x4* B2 = (const f32x4*)(lds + OFF_B2);
-  const f32x4* W3 = (const f32x4*)(lds + OFF_W3);
-  float vw[8];
-  {
-    float sa0, ca0, sb0, cb0, sa1, ca1, sb1, cb1, sa2, ca2, sb2, cb2;
-    sincos_x_2x_hw(T.vd0, sa0, ca0, sb0, cb0);
-    sincos_x_2x_hw(T.vd1, sa1, ca1, sb1, cb1);
-    sincos_x_2x_hw(T.vd2, sa2, ca2, sb2, cb2);
-    vw[0] = h ? sb2 : T.vd0; vw[1] = h ? ca0 : T.vd1; vw[2] = h ? cb0 : T.vd2; vw[3] = h ? ca1 : sa0;
-    vw[4] = h ? cb1 : sb0; vw[5] = h ? ca2 : sa1; vw[6] = h ? cb2 : sb1; vw[7] = h ? 0.f : sa2;
-  }
-  f32x16 H[4];
-#pragma unroll
-  for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const f32x4 b = B1[(mt * 2 + hw) * 4 + q];
-      H[mt][q * 4 + 0] = b.x; H[mt][q * 4 + 1] = b.y; H[mt][q * 4 + 2] = b.z; H[mt][q * 4 + 3] = b.w;
-    }
-  {
-    float s1 = 0.f, c1 = 0.f, s2 = 0.f, c2 = 0.f;
-    float xs[8];
-    const u32x4* W1F = W1 + F8_HI1 / 4;
-    h8 ah[4];
-    v8i a8[4], b8;
-#pragma unroll
-    for (int kk = 0; kk < KS1; ++kk) {
-      float x;
-      if (kk < 5 * NSLOT) {
-        const int r = kk / 5, kind = kk % 5;
-        if (kind == 0) sincos_x_2x_hw(T.fe[r], s1, c1, s2, c2);
-        x = kind == 0 ? T.fe[r] : (kind == 1 ? s1 : (kind == 2 ? s2 : (kind == 3 ? c1 : c2)));
-      } else if (kk < 5 * NSLOT + 8) {
-        x = vw[kk - 5 * NSLOT];
-      } else {
-        x = 0.f;
-      }
-      xs[kk & 7] = x;
-      if ((kk & 7) == 7) {
-        const int step = kk >> 3;
-        const h8 bh = split8_f8(xs, b8, step & 1);
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) ah[mt] = __builtin_bit_cast(h8, W1[(step * 4 + mt) * 64 + lw]);
-        if ((step & 1) == 0) {
-#pragma unroll
-          for (int mt = 0; mt < 4; ++mt) a8[mt] = load_a8(W1F, step >> 1, mt, lw);
-        }
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) H[mt] = MFMAH(ah[mt], bh, H[mt]);
-        if (step & 1) {
-#pragma unroll
-          for (int mt = 0; mt < 4; ++mt) H[mt] = MFMA8(a8[mt], b8, H[mt]);
-        }
-      }
-    }
-  }
-#pragma unroll
-  for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) H[mt][r] = relu_f(H[mt][r]);
-  f32x16 G[4];
-#pragma unroll
-  for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const f32x4 b = B2[(mt * 2 + hw) * 4 + q];
-      G[mt][q * 4 + 0] = b.x; G[mt][q * 4 + 1] = b.y; G[mt][q * 4 + 2] = b.z; G[mt][q * 4 + 3] = b.w;
-    }
-  {
-    const u32x4* W2F = W2 + F8_HI2 / 4;
-    h8 ah[4];
-    v8i a8[4], b8;
-#pragma unroll
-    for (int step = 0; step < KH2; ++step) {
-      float xs[8];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) xs[e] = H[(step * 8 + e) >> 4][(step * 8 + e) & 15];
-      const h8 bh = split8_f8(xs, b8, step & 1);
-#pragma unroll
-      for (int mt = 0; mt < 4; ++mt) ah[mt] = __builtin_bit_cast(h8, W2[(step * 4 + mt) * 64 + lw]);
-      if ((step & 1) == 0) {
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) a8[mt] = load_a8(W2F, step >> 1, mt, lw);
-      }
-#pragma unroll
-      for (int mt = 0; mt < 4; ++mt) G[mt] = MFMAH(ah[mt], bh, G[mt]);
-      if (step & 1) {
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) G[mt] = MFMA8(a8[mt], b8, G[mt]);
-      }
-    }
-  }
-  float o0 = 0.f, o1 = 0.f, o2 = 0.f;
-#pragma unroll
-  for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const f32x4 w3 = W3[(mt * 2 + hw) * 16 + r];
-      const float hv = relu_f(G[mt][r]);
-      o0 = fmaf(hv, w3.x, o0); o1 = fmaf(hv, w3.y, o1); o2 = fmaf(hv, w3.z, o2);
-    }
-  o0 += __shfl_xor(o0, 32, 64);
-  o1 += __shfl_xor(o1, 32, 64);
-  o2 += __shfl_xor(o2, 32, 64);
-  if (valid && h == 0) {
-    const float* b3 = lds + OFF_B3;
-    float* o = A.out + m * 3;
-    o[0] = sigmoidf(o0 + b3[0]);
-    o[1] = sigmoidf(o1 + b3[1]);
-    o[2] = sigmoidf(o2 + b3[2]);
-  }
-}
-
-__global__ __launch_bounds__(256) void k_shade_pipe(ShadeArgs A) {
-  __shared__ __attribute__((aligned(16))) float lds[LDS_W_FLOATS + 4];
-  {
-    const float* blob = A.packed + PACKED_FLOATS;
-    const f32x4* src = (const f32x4*)blob;
-    const f32x4* src8 = (const f32x4*)(A.packed + 2 * PACKED_FLOATS + BASIS16_FLOATS_C);
-    f32x4* dst = (f32x4*)lds;
-    for (int i = threadIdx.x; i < LDS_W_FLOATS / 4; i += 256) dst[i] = (i < F8_FLOATS / 4) ? src8[i] : src[i];
-  }
-  __syncthreads();
-  __builtin_amdgcn_s_setreg(1 | (23 << 6) | (0 << 11), 1);   // MODE.FP16_OVFL (see k_shade_h)
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int64_t n_tiles = (A.M + 31) >> 5;
-  const u32x4* BASH = (const u32x4*)(A.packed + PACKED_FLOATS + OFF_BASIS);
-  const int64_t n_wv = (int64_t)gridDim.x * 4;
-  const int64_t per_wave = (n_tiles + n_wv - 1) / n_wv;
-  const int64_t tile0 = ((int64_t)blockIdx.x * 4 + wave) * per_wave;
-  const int64_t tile1 = tile0 + per_wave < n_tiles ? tile0 + per_wave : n_tiles;
-  if (tile0 >= tile1) return;
-  PipeTile cur;
-  pipe_gather(A, tile0, lane, BASH, cur);
-  for (int64_t tile = tile0; tile < tile1; ++tile) {
-    int lw = lane;
-    asm volatile("" : "+v"(lw));
-    PipeTile nxt;
-    const int64_t tn = tile + 1 < tile1 ? tile + 1 : tile;   // the last iteration gathers its own tile again (no branch in the body)
-    pipe_gather(A, tn, lw, BASH, nxt);
-    pipe_mlp(A, tile, lw, lds, cur);
-    cur = nxt;
-  }
-}
-
 #include "ego_train.inc"
 
 int check_shade_config(const ego_scene* sc, const char* who, bool need_tables, bool need_mlp) {
@@ -1693,11 +1479,7 @@ int ego_shade(const ego_scene* sc, const float* rays, const float* z, const floa
     a.F = make_field(sc->app16);
     if (sc->mlp_precision == EGO_PREC_F16F8) k_shade_h<MODE_SHADE, false, true, true><<<shade_grid(a.M), 512, 0, (hipStream_t)stream>>>(a);
     else k_shade_h<MODE_SHADE, false, true><<<shade_grid(a.M), 512, 0, (hipStream_t)stream>>>(a);
-  } else if (sc->mlp_precision == EGO_PREC_F16F8) {
-    static const bool pipe = getenv("EGO_SHADE_PIPE") != nullptr;   // EXPERIMENT switch (timing build)
-    if (pipe) k_shade_pipe<<<shade_grid(a.M), 256, 0, (hipStream_t)stream>>>(a);
-    else k_shade_h<MODE_SHADE, false, false, true><<<shade_grid(a.M), 512, 0, (hipStream_t)stream>>>(a);
-  }
+  } else if (sc->mlp_precision == EGO_PREC_F16F8) k_shade_h<MODE_SHADE, false, false, true><<<shade_grid(a.M), 512, 0, (hipStream_t)stream>>>(a);
   else k_shade_h<MODE_SHADE><<<shade_grid(a.M), 512, 0, (hipStream_t)stream>>>(a);
   return ego_launch_status("k_shade<SHADE>");
 }
