@@ -73,7 +73,7 @@ SP = C.POINTER(Scene)
 # The EGO_ABI_VERSION (include/egonerf_hip.h) the PROTOTYPES below were written against.  load() refuses a library that reports
 # another one: a stale libegonerf_hip.so can keep every struct size and still disagree on an argument list (ABI 5 -> 7 inserted
 # `normalize` before ego_erp_rays' output pointer), which ctypes would pass through as a wild pointer.
-EXPECTED_ABI_VERSION = 8
+EXPECTED_ABI_VERSION = 9
 
 # name -> (restype, argtypes); mirrors include/egonerf_hip.h one to one
 PROTOTYPES = {
@@ -81,6 +81,7 @@ PROTOTYPES = {
     "ego_last_error": (C.c_char_p, []),
     "ego_sizeof": (I64, [I32]),
     "ego_packed_floats": (I64, []),
+    "ego_packed_floats_scene": (I64, [SP]),
     "ego_sample_ray_exp": (C.c_int, [P, P, P, F32, I64, I32, P, P, P]),
     "ego_erp_rays": (C.c_int, [I32, I32, I32, I32, C.POINTER(C.c_float), I32, P, P]),
     "ego_from_cartesian": (C.c_int, [SP, P, I64, P, P]),

@@ -1,0 +1,448 @@
+// libegonerf_hip.so, part 7: the render path for model shapes OTHER than the one every shipped config resolves to
+// (opt.py:87-100 lets a user set n_lamb_sigma / n_lamb_sh, data_dim_color, featureC, view_pe, fea_pe).  The MFMA kernels of
+// ego_shade.hip bake 48 appearance components, app_dim 27, a 150 -> 128 -> 128 -> 3 MLP with two encoding frequencies and 16
+// density components into their register layouts; these kernels take the shape as runtime numbers (hidden width as a template
+// parameter) and compute in plain fp32 with the reference's operation order, so that any reference checkpoint renders on the
+// device.  They are a compatibility path, an order of magnitude slower than the tuned one and inference only; the host layer picks
+// them exactly when ego_shape_is_tuned() is false.
+//
+//   k_march_generic : rows A-E for C density components (multiple of 4, <= 48), lane = sample, wave per ray
+//   k_shade_generic : rows F, G (EgoNeRF.py:349-413, tensorBase.py:54-78): appearance gather + per-grid basis + positional
+//                     encoding + MLP_Fea for n_comp <= 48 (multiple of 4), app_dim <= 32, featureC in {64, 128}, view_pe, fea_pe <= 8
+#include "ego_device.h"
+#include "ego_host.h"
+#include "ego_generic.h"
+
+namespace {
+
+struct GenShadeArgs {
+  DevField F;
+  const float* gp;       // generic packed weights (ego_generic_pack)
+  const float* rays;     // SHADE: [N][6]
+  const float* coords;   // SHADE: [M][4]
+  const float* c7n;      // APP: [M][7]
+  const float* feat;     // MLP: [M][app_dim]
+  const float* dirs;     // MLP: [M][3]
+  float* out;
+  const uint8_t* tile_active;
+  int64_t M;
+  int32_t S, app_dim, n_comp, in_c, view_pe, fea_pe;
+};
+
+// packed layout (floats): W1T [in_c][HID] | b1 [HID] | W2T [HID][HID] | b2 [HID] | W3 [3][HID] | b3 [4] | basisT [2][3 C][32]
+struct GenLayout {
+  int64_t w1t, b1, w2t, b2, w3, b3, basis, total;
+};
+__host__ __device__ inline GenLayout gen_layout(int in_c, int hid, int n_comp) {
+  GenLayout L;
+  int64_t o = 0;
+  L.w1t = o; o += (int64_t)in_c * hid;
+  L.b1 = o; o += hid;
+  L.w2t = o; o += (int64_t)hid * hid;
+  L.b2 = o; o += hid;
+  L.w3 = o; o += 3 * hid;
+  L.b3 = o; o += 4;
+  L.basis = o; o += 2 * 3 * (int64_t)n_comp * 32;
+  L.total = o;
+  return L;
+}
+
+__global__ void k_generic_pack(const float* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ w2,
+                               const float* __restrict__ b2, const float* __restrict__ w3, const float* __restrict__ b3,
+                               const float* __restrict__ basis_yin, const float* __restrict__ basis_yang, int in_c, int hid, int n_comp,
+                               int app_dim, float* __restrict__ out) {
+  const GenLayout L = gen_layout(in_c, hid, n_comp);
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= L.total) return;
+  float v = 0.f;
+  if (idx < L.b1) { const int k = (int)(idx / hid), j = (int)(idx % hid); v = w1[(int64_t)j * in_c + k]; }
+  else if (idx < L.w2t) v = b1[idx - L.b1];
+  else if (idx < L.b2) { const int64_t e = idx - L.w2t; const int k = (int)(e / hid), j = (int)(e % hid); v = w2[(int64_t)j * hid + k]; }
+  else if (idx < L.w3) v = b2[idx - L.b2];
+  else if (idx < L.b3) v = w3[idx - L.w3];
+  else if (idx < L.basis) { const int c = (int)(idx - L.b3); v = c < 3 ? b3[c] : 0.f; }
+  else {
+    const int64_t e = idx - L.basis;
+    const int f = (int)(e & 31), col = (int)((e >> 5) % (3 * n_comp)), g = (int)((e >> 5) / (3 * n_comp));
+    if (f < app_dim) v = (g ? basis_yang : basis_yin)[(int64_t)f * (3 * n_comp) + col];
+  }
+  out[idx] = v;
+}
+
+enum { G_SHADE = 0, G_APP = 1, G_MLP = 2 };
+
+// one wave = 64 samples (lane = sample); 2 waves per workgroup; per wave an LDS slab [HID][64] that first stages chunks of the MLP
+// input and then holds relu(h1)
+template <int HID, int MODE>
+__global__ __launch_bounds__(128) void k_shade_generic(GenShadeArgs A) {
+  __shared__ float slab[2][HID][64];
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  float (*sl)[64] = slab[wv];
+  const GenLayout L = gen_layout(A.in_c, HID, A.n_comp);
+  const int64_t n_units = (A.M + 63) >> 6;
+  for (int64_t unit = (int64_t)blockIdx.x * 2 + wv; unit < n_units; unit += (int64_t)gridDim.x * 2) {
+    if (MODE == G_SHADE && A.tile_active && (A.M & 63) == 0) {   // two 32-sample tiles per unit: skip when neither is read
+      if (!A.tile_active[2 * unit] && !A.tile_active[2 * unit + 1]) continue;
+    }
+    const int64_t m_raw = unit * 64 + lane;
+    const bool valid = m_raw < A.M;
+    const int64_t m = valid ? m_raw : A.M - 1;
+    float feat[32];
+#pragma unroll
+    for (int f = 0; f < 32; ++f) feat[f] = 0.f;
+    float vd[3] = {0.f, 0.f, 0.f};
+    if (MODE == G_MLP) {
+#pragma unroll
+      for (int f = 0; f < 32; ++f)
+        if (f < A.app_dim) feat[f] = A.feat[m * A.app_dim + f];
+      vd[0] = A.dirs[m * 3]; vd[1] = A.dirs[m * 3 + 1]; vd[2] = A.dirs[m * 3 + 2];
+    } else {
+      // ---- rows F: appearance gather (EgoNeRF.py:349-413) + this sample's grid's basis (EgoNeRF.py:99-100) ----
+      float a[3];
+      int g;
+      if (MODE == G_APP) {
+        const float* p = A.c7n + m * 7;
+        g = (p[6] == 0.f) ? 0 : 1;
+        const int b = g ? 3 : 0;
+        a[0] = p[b]; a[1] = p[b + 1]; a[2] = p[b + 2];
+      } else {
+        const f32x4 cc = ((const f32x4*)A.coords)[m];
+        a[0] = cc.x; a[1] = cc.y; a[2] = cc.z; g = cc.w != 0.f;
+        const uint32_t ray = (uint32_t)(m / A.S);
+        const float* R = A.rays + (int64_t)ray * 6;
+        vd[0] = R[3]; vd[1] = R[4]; vd[2] = R[5];
+      }
+      const VMTaps t = vm_setup(a[0], a[1], a[2], A.F.res);
+      const int C = A.n_comp;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const Lin1 X = t.ax[vm_plane_x(i)], Y = t.ax[vm_plane_y(i)], Ln = t.ax[vm_line_ax(i)];
+        const int W = A.F.res[vm_plane_x(i)];
+        const float* P = g ? A.F.plane[1][i] : A.F.plane[0][i];
+        const float* Lp = g ? A.F.line[1][i] : A.F.line[0][i];
+        const float* p00 = P + ((int64_t)Y.i0 * W + X.i0) * C;
+        const float* p01 = P + ((int64_t)Y.i0 * W + X.i1) * C;
+        const float* p10 = P + ((int64_t)Y.i1 * W + X.i0) * C;
+        const float* p11 = P + ((int64_t)Y.i1 * W + X.i1) * C;
+        const float* l0 = Lp + (int64_t)Ln.i0 * C;
+        const float* l1 = Lp + (int64_t)Ln.i1 * C;
+        const float w00 = __fmul_rn(Y.w0, X.w0), w01 = __fmul_rn(Y.w0, X.w1), w10 = __fmul_rn(Y.w1, X.w0), w11 = __fmul_rn(Y.w1, X.w1);
+        for (int c4 = 0; c4 < C; c4 += 4) {
+          const f32x4 pv = *(const f32x4*)(p00 + c4) * w00 + *(const f32x4*)(p01 + c4) * w01 + *(const f32x4*)(p10 + c4) * w10 +
+                           *(const f32x4*)(p11 + c4) * w11;
+          const f32x4 lv = *(const f32x4*)(l0 + c4) * Ln.w0 + *(const f32x4*)(l1 + c4) * Ln.w1;
+          const f32x4 pr = pv * lv;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            // basisT [g][col][32]: uniform addresses -> scalar loads of both grids' rows, selected per lane
+            const float* b0 = A.gp + L.basis + (int64_t)(i * C + c4 + e) * 32;
+            const float* b1 = b0 + (int64_t)3 * C * 32;
+#pragma unroll
+            for (int f = 0; f < 32; ++f)
+              if (f < A.app_dim) feat[f] = fmaf(g ? b1[f] : b0[f], pr[e], feat[f]);
+          }
+        }
+      }
+    }
+    if (MODE == G_APP) {
+      if (valid) {
+#pragma unroll
+        for (int f = 0; f < 32; ++f)
+          if (f < A.app_dim) A.out[m * A.app_dim + f] = feat[f];
+      }
+      continue;
+    }
+    // ---- row G: mlp_in = [features, viewdirs, PE(features), PE(viewdirs)] (tensorBase.py:68-75) -> Linear relu Linear relu Linear ----
+    float h[HID];
+    {
+      const float* b1 = A.gp + L.b1;
+#pragma unroll
+      for (int j = 0; j < HID; ++j) h[j] = b1[j];
+    }
+    // consume n staged inputs: input t of the chunk sits in sl[t][lane] and multiplies row (row0 + t * stride) of W1^T
+    auto consume = [&](int n, int row0, int stride) {
+      for (int tt = 0; tt < n; ++tt) {
+        const float xk = sl[tt][lane];
+        const float* wrow = A.gp + L.w1t + (int64_t)(row0 + tt * stride) * HID;   // uniform: scalar loads
+#pragma unroll
+        for (int j = 0; j < HID; ++j) h[j] = fmaf(wrow[j], xk, h[j]);
+      }
+    };
+    const int D = A.app_dim;
+    // chunk 1: the raw features and the view direction (rows 0 .. D + 2)
+#pragma unroll
+    for (int f = 0; f < 32; ++f)
+      if (f < D) sl[f][lane] = feat[f];
+    sl[D][lane] = vd[0]; sl[D + 1][lane] = vd[1]; sl[D + 2][lane] = vd[2];
+    consume(D + 3, 0, 1);
+    // PE(features): element-major, frequency-minor; all sines (rows base + f * fea_pe + q), then all cosines
+    {
+      const int base_s = D + 3, base_c = base_s + D * A.fea_pe;
+      float fr = 1.f;
+      for (int q = 0; q < A.fea_pe; ++q, fr *= 2.f) {
+#pragma unroll
+        for (int f = 0; f < 32; ++f)
+          if (f < D) sl[f][lane] = sinf(__fmul_rn(feat[f], fr));
+        consume(D, base_s + q, A.fea_pe);
+#pragma unroll
+        for (int f = 0; f < 32; ++f)
+          if (f < D) sl[f][lane] = cosf(__fmul_rn(feat[f], fr));
+        consume(D, base_c + q, A.fea_pe);
+      }
+      const int vbase_s = base_c + D * A.fea_pe, vbase_c = vbase_s + 3 * A.view_pe;
+      fr = 1.f;
+      for (int q = 0; q < A.view_pe; ++q, fr *= 2.f) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) { sl[d][lane] = sinf(__fmul_rn(vd[d], fr)); sl[3 + d][lane] = cosf(__fmul_rn(vd[d], fr)); }
+        consume(3, vbase_s + q, A.view_pe);
+        for (int d = 0; d < 3; ++d) sl[d][lane] = sl[3 + d][lane];
+        consume(3, vbase_c + q, A.view_pe);
+      }
+    }
+    // relu(h1) -> LDS, layer 2 with the hidden index as the (runtime) loop
+#pragma unroll
+    for (int j = 0; j < HID; ++j) sl[j][lane] = fmaxf(h[j], 0.f);
+    {
+      const float* b2 = A.gp + L.b2;
+#pragma unroll
+      for (int j = 0; j < HID; ++j) h[j] = b2[j];
+      for (int k = 0; k < HID; ++k) {
+        const float xk = sl[k][lane];
+        const float* wrow = A.gp + L.w2t + (int64_t)k * HID;
+#pragma unroll
+        for (int j = 0; j < HID; ++j) h[j] = fmaf(wrow[j], xk, h[j]);
+      }
+    }
+    const float* w3 = A.gp + L.w3;
+    const float* b3 = A.gp + L.b3;
+    float o[3] = {b3[0], b3[1], b3[2]};
+#pragma unroll
+    for (int j = 0; j < HID; ++j) {
+      const float hv = fmaxf(h[j], 0.f);
+      o[0] = fmaf(w3[j], hv, o[0]); o[1] = fmaf(w3[HID + j], hv, o[1]); o[2] = fmaf(w3[2 * HID + j], hv, o[2]);
+    }
+    if (valid) {
+      float* op = A.out + m * 3;
+      op[0] = sigmoidf(o[0]); op[1] = sigmoidf(o[1]); op[2] = sigmoidf(o[2]);
+    }
+  }
+}
+
+// ---- generic march: the round-2 structure without teams (lane = sample gathers its own taps), any C % 4 == 0 -----------------
+struct GenMarchArgs {
+  DevCoords c;
+  DevField F;
+  const float* rays; const float* z_in; const float* r_sched; const float* jitter;
+  float* z_out; float* alpha; float* weight; float* bg; float* coords_out; float* sigma_out; uint8_t* tile_active;
+  const uint8_t* occ; int32_t occ_res[3];
+  int64_t N;
+  int32_t S, C, alpha_stride, softplus;
+  float near_, shift, dscale, term_eps, shade_above;
+};
+
+__device__ __forceinline__ float gen_occ(const GenMarchArgs& A, int g, float a_r, float a_th, float a_ph) {
+  const Lin1 X = lin_setup(a_r, A.occ_res[0]), Y = lin_setup(a_th, A.occ_res[1]), Z = lin_setup(a_ph, A.occ_res[2]);
+  const uint8_t* V = A.occ + (int64_t)g * A.occ_res[0] * A.occ_res[1] * A.occ_res[2];
+  float v = 0.f;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int ix = (k & 1) ? X.i1 : X.i0, iy = (k & 2) ? Y.i1 : Y.i0, iz = (k & 4) ? Z.i1 : Z.i0;
+    const float w = ((k & 1) ? X.w1 : X.w0) * ((k & 2) ? Y.w1 : Y.w0) * ((k & 4) ? Z.w1 : Z.w0);
+    v += w * (float)V[((int64_t)iz * A.occ_res[1] + iy) * A.occ_res[0] + ix];
+  }
+  return v;
+}
+
+__global__ __launch_bounds__(256) void k_march_generic(GenMarchArgs A) {
+  __shared__ float lut[1024];
+  for (int i = threadIdx.x; i < A.c.n_lut; i += blockDim.x) lut[i] = A.c.r_lut[i];
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int64_t ray = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (ray >= A.N) return;
+  const float* R = A.rays + ray * 6;
+  const float ox = R[0], oy = R[1], oz = R[2], dx = R[3], dy = R[4], dz = R[5];
+  const int S = A.S, C = A.C;
+  float carry = 1.f;
+  for (int s0 = 0; s0 < S; s0 += 64) {
+    const int s = min(s0 + lane, S - 1);
+    const bool ok = (s0 + lane) < S;
+    const int sn = (s < S - 1) ? s + 1 : s - 1;
+    float z, zn;
+    if (A.z_in) { z = A.z_in[ray * S + s]; zn = A.z_in[ray * S + sn]; }
+    else {
+      const auto zz = [&](int k) {
+        float r = A.r_sched[k];
+        if (A.jitter) {
+          const float step = (k < S - 1) ? __fsub_rn(A.r_sched[k + 1], r) : __fsub_rn(r, A.r_sched[S - 2]);
+          r = __fadd_rn(r, __fmul_rn(step, A.jitter[ray * S + k]));
+        }
+        return __fadd_rn(A.near_, r);
+      };
+      z = zz(s); zn = zz(sn);
+    }
+    const float dist = (s < S - 1) ? __fsub_rn(zn, z) : __fsub_rn(z, zn);
+    const float px = __fadd_rn(ox, __fmul_rn(dx, z)), py = __fadd_rn(oy, __fmul_rn(dy, z)), pz = __fadd_rn(oz, __fmul_rn(dz, z));
+    const YinYang y = yinyang_from_xyz(px, py, pz, A.c);
+    const float a_r = normalize_r(y.r, lut, A.c.n_lut, A.c.n_r);
+    const float a_th = normalize_ang(y.th, A.c.th_near, A.c.th_inv);
+    const float a_ph = normalize_ang(y.ph, A.c.ph_near, A.c.ph_inv);
+    const bool occupied = !A.occ || gen_occ(A, y.yang, a_r, a_th, a_ph) > 0.f;
+    float sg = 0.f;
+    if (occupied) {
+#pragma clang fp contract(fast)
+      const VMTaps t = vm_setup(a_r, a_th, a_ph, A.F.res);
+      const int g = y.yang;
+      float feat = 0.f;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const Lin1 X = t.ax[vm_plane_x(i)], Y = t.ax[vm_plane_y(i)], Ln = t.ax[vm_line_ax(i)];
+        const int W = A.F.res[vm_plane_x(i)];
+        const float* P = g ? A.F.plane[1][i] : A.F.plane[0][i];
+        const float* Lp = g ? A.F.line[1][i] : A.F.line[0][i];
+        const float* p00 = P + ((int64_t)Y.i0 * W + X.i0) * C;
+        const float* p01 = P + ((int64_t)Y.i0 * W + X.i1) * C;
+        const float* p10 = P + ((int64_t)Y.i1 * W + X.i0) * C;
+        const float* p11 = P + ((int64_t)Y.i1 * W + X.i1) * C;
+        const float* l0 = Lp + (int64_t)Ln.i0 * C;
+        const float* l1 = Lp + (int64_t)Ln.i1 * C;
+        const float w00 = __fmul_rn(Y.w0, X.w0), w01 = __fmul_rn(Y.w0, X.w1), w10 = __fmul_rn(Y.w1, X.w0), w11 = __fmul_rn(Y.w1, X.w1);
+        float dot = 0.f;
+        for (int c4 = 0; c4 < C; c4 += 4) {
+          const f32x4 pv = *(const f32x4*)(p00 + c4) * w00 + *(const f32x4*)(p01 + c4) * w01 + *(const f32x4*)(p10 + c4) * w10 +
+                           *(const f32x4*)(p11 + c4) * w11;
+          const f32x4 lv = *(const f32x4*)(l0 + c4) * Ln.w0 + *(const f32x4*)(l1 + c4) * Ln.w1;
+          const f32x4 mm = pv * lv;
+          dot += (mm.x + mm.y) + (mm.z + mm.w);
+        }
+        feat += fmaxf(dot, 0.f);
+      }
+      sg = A.softplus ? softplus_shift(feat, A.shift) : fmaxf(feat, 0.f);
+    }
+    const float a = ok ? __fsub_rn(1.f, expf(-sg * __fmul_rn(dist, A.dscale))) : 0.f;
+    const float tt = ok ? __fadd_rn(__fsub_rn(1.f, a), 1e-10f) : 1.f;
+    const float inc = wave_scan_mul(tt, lane);
+    float exc = __shfl_up(inc, 1, 64);
+    if (lane == 0) exc = 1.f;
+    const float T = carry * exc;
+    const float wgt = (A.term_eps > 0.f && T < A.term_eps) ? 0.f : a * T;
+    if (A.tile_active) {
+      const unsigned long long nz = __ballot(ok && wgt > A.shade_above);
+      const int64_t o = ray * S + s;
+      if ((S & 31) == 0) {
+        if (ok && (lane & 31) == 0) A.tile_active[o >> 5] = (nz >> (lane & 32) & 0xffffffffull) != 0ull ? 1 : 0;
+      } else if (ok && (nz >> (lane & 32) & 0xffffffffull) != 0ull && ((lane & 31) == 0 || (o & 31) == 0)) {
+        A.tile_active[o >> 5] = 1;
+      }
+    }
+    if (ok) {
+      const int64_t o = ray * S + s;
+      if (A.z_out) A.z_out[o] = z;
+      if (A.coords_out) ((f32x4*)A.coords_out)[o] = f32x4{a_r, a_th, a_ph, y.yang ? 1.f : 0.f};
+      if (A.sigma_out) A.sigma_out[o] = sg;
+      if (A.alpha) A.alpha[ray * A.alpha_stride + s] = a;
+      if (A.weight) A.weight[o] = wgt;
+    }
+    carry *= __shfl(inc, 63, 64);
+  }
+  if (A.alpha && lane < A.alpha_stride - S) A.alpha[ray * A.alpha_stride + S + lane] = 1.f;
+  if (A.bg && lane == 0) A.bg[ray] = carry;
+}
+
+int check_generic_shape(const ego_scene* sc, const char* who, bool need_tables, bool need_mlp, bool need_packed = true) {
+  if (!sc) return ego_fail(EGO_E_BADARG, "%s: null scene", who);
+  if (sc->app_dim < 1 || sc->app_dim > 32) return ego_fail(EGO_E_UNSUPPORTED, "%s: app_dim %d (supported: 1..32)", who, sc->app_dim);
+  const int C = sc->app.n_comp;
+  if (C < 4 || C > 48 || (C & 3)) return ego_fail(EGO_E_UNSUPPORTED, "%s: appearance n_comp %d (supported: multiples of 4 up to 48)", who, C);
+  if (sc->mlp_hidden != 64 && sc->mlp_hidden != 128) return ego_fail(EGO_E_UNSUPPORTED, "%s: featureC %d (supported: 64, 128)", who, sc->mlp_hidden);
+  if (need_tables) {
+    for (int g = 0; g < 2; ++g)
+      for (int i = 0; i < 3; ++i)
+        if (!sc->app.plane[g][i] || !sc->app.line[g][i]) return ego_fail(EGO_E_BADARG, "%s: null appearance table", who);
+    if (sc->app.res[0] < 2 || sc->app.res[1] < 2 || sc->app.res[2] < 2) return ego_fail(EGO_E_BADARG, "%s: appearance resolution < 2", who);
+  }
+  if (need_mlp) {
+    if (sc->view_pe < 0 || sc->view_pe > 8 || sc->fea_pe < 0 || sc->fea_pe > 8)
+      return ego_fail(EGO_E_UNSUPPORTED, "%s: view_pe %d / fea_pe %d (supported: 0..8)", who, sc->view_pe, sc->fea_pe);
+    const int in_c = 2 * sc->view_pe * 3 + 2 * sc->fea_pe * sc->app_dim + 3 + sc->app_dim;
+    if (sc->mlp_in != in_c) return ego_fail(EGO_E_BADARG, "%s: mlp_in %d does not match the encoding widths (%d)", who, sc->mlp_in, in_c);
+  }
+  if (need_packed && !sc->packed) return ego_fail(EGO_E_BADARG, "%s: scene.packed is null (call ego_pack_mlp first)", who);
+  return EGO_OK;
+}
+
+}  // namespace
+
+bool ego_shape_is_tuned(const ego_scene* sc) {
+  return sc->app_dim == 27 && sc->app.n_comp == 48 && sc->mlp_in == 150 && sc->mlp_hidden == 128 && sc->view_pe == 2 && sc->fea_pe == 2;
+}
+
+int64_t ego_generic_packed_floats(const ego_scene* sc) {
+  return gen_layout(sc->mlp_in, sc->mlp_hidden, sc->app.n_comp).total;
+}
+
+int ego_generic_pack(const ego_scene* sc, float* out, void* stream) {
+  if (int e = check_generic_shape(sc, "pack_mlp", false, true, false)) return e;
+  const int64_t n = ego_generic_packed_floats(sc);
+  k_generic_pack<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(sc->mlp_w[0], sc->mlp_b[0], sc->mlp_w[1], sc->mlp_b[1], sc->mlp_w[2],
+                                                                              sc->mlp_b[2], sc->basis[0], sc->basis[1], sc->mlp_in, sc->mlp_hidden,
+                                                                              sc->app.n_comp, sc->app_dim, out);
+  return ego_launch_status("k_generic_pack");
+}
+
+template <int MODE>
+static int launch_shade(const ego_scene* sc, GenShadeArgs& a, hipStream_t st) {
+  const int64_t units = (a.M + 63) >> 6;
+  const unsigned grid = (unsigned)((units + 1) / 2 < 2048 ? (units + 1) / 2 : 2048);
+  if (sc->mlp_hidden == 64) k_shade_generic<64, MODE><<<grid, 128, 0, st>>>(a);
+  else k_shade_generic<128, MODE><<<grid, 128, 0, st>>>(a);
+  return ego_launch_status("k_shade_generic");
+}
+
+static void fill_common(const ego_scene* sc, GenShadeArgs& a) {
+  a.F = make_field(sc->app);
+  a.gp = sc->packed;
+  a.app_dim = sc->app_dim; a.n_comp = sc->app.n_comp; a.in_c = sc->mlp_in; a.view_pe = sc->view_pe; a.fea_pe = sc->fea_pe;
+}
+
+int ego_generic_shade(const ego_scene* sc, const float* rays, const float* coords, int64_t N, int32_t S, float* rgb, const uint8_t* tile_active,
+                      void* stream) {
+  if (int e = check_generic_shape(sc, "shade", true, true)) return e;
+  if (!coords) return ego_fail(EGO_E_BADARG, "shade: coords (from ego_march_density) is required for this model shape");
+  GenShadeArgs a{};
+  fill_common(sc, a);
+  a.rays = rays; a.coords = coords; a.out = rgb; a.tile_active = tile_active; a.M = N * (int64_t)S; a.S = S;
+  return launch_shade<G_SHADE>(sc, a, (hipStream_t)stream);
+}
+
+int ego_generic_app_feature(const ego_scene* sc, const float* c7n, int64_t M, float* out, void* stream) {
+  if (int e = check_generic_shape(sc, "app_feature", true, false)) return e;
+  GenShadeArgs a{};
+  fill_common(sc, a);
+  a.c7n = c7n; a.out = out; a.M = M; a.S = 1;
+  return launch_shade<G_APP>(sc, a, (hipStream_t)stream);
+}
+
+int ego_generic_mlp_fea(const ego_scene* sc, const float* viewdirs, const float* feat, int64_t M, float* rgb, void* stream) {
+  if (int e = check_generic_shape(sc, "mlp_fea", false, true)) return e;
+  GenShadeArgs a{};
+  fill_common(sc, a);
+  a.feat = feat; a.dirs = viewdirs; a.out = rgb; a.M = M; a.S = 1;
+  return launch_shade<G_MLP>(sc, a, (hipStream_t)stream);
+}
+
+int ego_generic_march(const ego_scene* sc, const ego_vm_field& f, bool fine_lut, const float* rays, int64_t N, int32_t S, const float* z_in,
+                      const float* r_sched, const float* jitter, float near_, const uint8_t* occ, float* z_out, float* alpha, int32_t alpha_stride,
+                      float* weight, float* bg_weight, float* coords_out, float* sigma_out, uint8_t* tile_active, void* stream) {
+  const int C = f.n_comp;
+  if (C < 4 || C > 48 || (C & 3)) return ego_fail(EGO_E_UNSUPPORTED, "march_density: n_comp %d (supported: multiples of 4 up to 48)", C);
+  GenMarchArgs a{};
+  a.c = make_coords(*sc, fine_lut); a.F = make_field(f);
+  a.rays = rays; a.z_in = z_in; a.r_sched = r_sched; a.jitter = jitter; a.z_out = z_out; a.alpha = alpha; a.weight = weight; a.bg = bg_weight;
+  a.coords_out = coords_out; a.sigma_out = sigma_out; a.tile_active = tile_active; a.occ = occ;
+  a.occ_res[0] = sc->occ_res[0]; a.occ_res[1] = sc->occ_res[1]; a.occ_res[2] = sc->occ_res[2];
+  a.N = N; a.S = S; a.C = C; a.alpha_stride = alpha_stride; a.softplus = sc->act_softplus;
+  a.near_ = near_; a.shift = sc->density_shift; a.dscale = sc->distance_scale; a.term_eps = sc->term_eps; a.shade_above = fmaxf(sc->weight_thres, 0.f);
+  k_march_generic<<<(unsigned)((N + 3) / 4), 256, 0, (hipStream_t)stream>>>(a);
+  return ego_launch_status("k_march_generic");
+}

@@ -2,6 +2,7 @@
 // fused marching / compositing kernels.  gfx950 only.
 #include "ego_device.h"
 #include "ego_host.h"
+#include "ego_generic.h"
 
 // =============================================================================================
 // Row A  — sample schedule -> points      models/EgoNeRF.py:56-87
@@ -845,8 +846,18 @@ int ego_density_feature(const ego_scene* sc, const float* c7n, int64_t M, int32_
     k_density_feature<16><<<nblk(M, 256), 256, 0, (hipStream_t)stream>>>(make_field(f), c7n, M, out);
   else if (f.n_comp == 8)
     k_density_feature<8><<<nblk(M, 256), 256, 0, (hipStream_t)stream>>>(make_field(f), c7n, M, out);
+  else if (f.n_comp == 4)
+    k_density_feature<4><<<nblk(M, 256), 256, 0, (hipStream_t)stream>>>(make_field(f), c7n, M, out);
+  else if (f.n_comp == 12)
+    k_density_feature<12><<<nblk(M, 256), 256, 0, (hipStream_t)stream>>>(make_field(f), c7n, M, out);
+  else if (f.n_comp == 24)
+    k_density_feature<24><<<nblk(M, 256), 256, 0, (hipStream_t)stream>>>(make_field(f), c7n, M, out);
+  else if (f.n_comp == 32)
+    k_density_feature<32><<<nblk(M, 256), 256, 0, (hipStream_t)stream>>>(make_field(f), c7n, M, out);
+  else if (f.n_comp == 48)
+    k_density_feature<48><<<nblk(M, 256), 256, 0, (hipStream_t)stream>>>(make_field(f), c7n, M, out);
   else
-    return ego_fail(EGO_E_UNSUPPORTED, "density_feature: n_comp %d (supported: 8, 16)", f.n_comp);
+    return ego_fail(EGO_E_UNSUPPORTED, "density_feature: n_comp %d (supported: 4, 8, 12, 16, 24, 32, 48)", f.n_comp);
   return ego_launch_status("k_density_feature");
 }
 
@@ -930,8 +941,10 @@ int ego_march_density(const ego_scene* sc, const float* rays, int64_t N, int32_t
   const ego_vm_field& f = (coarse & 1) ? sc->density_coarse : sc->density;
   if (int e = check_field(f, "march_density")) return e;
   if (N == 0) return EGO_OK;
-  if (f.n_comp != 16) return ego_fail(EGO_E_UNSUPPORTED, "march_density: n_comp %d (supported: 16)", f.n_comp);
   const DevOcc o = make_occ(*sc, coarse & 1);
+  if (f.n_comp != 16)   // any other component count: the compatibility kernel (csrc/ego_generic.hip)
+    return ego_generic_march(sc, f, (coarse & 2) != 0, rays, N, S, z_in, r_sched, jitter, near_, o.vol, z_out, alpha, alpha_stride, weight, bg_weight,
+                             coords_out, sigma_out, tile_active, stream);
   if (o.vol)
     k_march_density<16, true><<<nblk(N, 4), 256, 0, (hipStream_t)stream>>>(
         make_coords(*sc, (coarse & 2) != 0), make_field(f), rays, N, S, z_in, r_sched, jitter, near_, sc->act_softplus, sc->density_shift,

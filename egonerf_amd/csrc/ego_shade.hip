@@ -21,6 +21,7 @@
 #include "ego_device.h"
 #include "ego_host.h"
 #include "variants.h"
+#include "ego_generic.h"
 
 namespace {
 
@@ -1389,13 +1390,16 @@ constexpr int BASIS16_FLOATS = 2 * KHB * 2 * 64 * 4;  // [2 g][9 steps][2 terms]
 
 int64_t ego_packed_floats(void) { return 2 * (int64_t)PACKED_FLOATS + BASIS16_FLOATS + F8_FLOATS; }
 
+int64_t ego_packed_floats_scene(const ego_scene* sc) {
+  if (!sc) return -1;
+  return ego_shape_is_tuned(sc) ? ego_packed_floats() : ego_generic_packed_floats(sc);
+}
+
 int ego_pack_mlp(const ego_scene* sc, float* packed_out, void* stream) {
   EGO_REQUIRE(sc && packed_out, "pack_mlp: null argument");
   for (int i = 0; i < 3; ++i) EGO_REQUIRE(sc->mlp_w[i] && sc->mlp_b[i], "pack_mlp: null MLP weight");
   EGO_REQUIRE(sc->basis[0] && sc->basis[1], "pack_mlp: null basis matrix");
-  if (sc->app_dim != APP_DIM || sc->app.n_comp != APP_C || sc->mlp_in != MLP_IN || sc->mlp_hidden != HID ||
-      sc->view_pe != 2 || sc->fea_pe != 2)
-    return ego_fail(EGO_E_UNSUPPORTED, "pack_mlp: only app_dim=27, n_comp=48, MLP_Fea 150/128 with view_pe=fea_pe=2 is supported");
+  if (!ego_shape_is_tuned(sc)) return ego_generic_pack(sc, packed_out, stream);   // any other shape: the fp32 compatibility kernels' layout
   k_pack_mlp<<<(PACKED_FLOATS + 255) / 256, 256, 0, (hipStream_t)stream>>>(sc->mlp_w[0], sc->mlp_b[0], sc->mlp_w[1], sc->mlp_b[1],
                                                                           sc->mlp_w[2], sc->mlp_b[2], sc->basis[0], sc->basis[1],
                                                                           packed_out);
@@ -1433,6 +1437,7 @@ int ego_app_feature(const ego_scene* sc, const float* c7n, int64_t M, float* out
   EGO_REQUIRE(M >= 0 && M < (1ll << 31), "app_feature: M out of range [0, 2^31)");
   if (M == 0) return EGO_OK;
   EGO_REQUIRE(c7n && out, "app_feature: null argument");
+  if (sc && !ego_shape_is_tuned(sc)) return ego_generic_app_feature(sc, c7n, M, out, stream);
   if (int e = check_shade_config(sc, "app_feature", true, false)) return e;
   ShadeArgs a{};
   a.c = make_coords(*sc); a.F = make_field(sc->app); a.packed = sc->packed; a.c7n = c7n; a.out = out; a.M = M; a.S = 1;
@@ -1449,6 +1454,7 @@ int ego_mlp_fea(const ego_scene* sc, const float* viewdirs, const float* feat, i
   EGO_REQUIRE(M >= 0 && M < (1ll << 31), "mlp_fea: M out of range [0, 2^31)");
   if (M == 0) return EGO_OK;
   EGO_REQUIRE(viewdirs && feat && rgb, "mlp_fea: null argument");
+  if (sc && !ego_shape_is_tuned(sc)) return ego_generic_mlp_fea(sc, viewdirs, feat, M, rgb, stream);
   if (int e = check_shade_config(sc, "mlp_fea", false, true)) return e;
   ShadeArgs a{};
   a.c = make_coords(*sc); a.packed = sc->packed; a.feat = feat; a.dirs = viewdirs; a.out = rgb; a.M = M; a.S = 1;
@@ -1461,6 +1467,12 @@ int ego_mlp_fea(const ego_scene* sc, const float* viewdirs, const float* feat, i
 int ego_shade(const ego_scene* sc, const float* rays, const float* z, const float* coords, int64_t N, int32_t S, float* rgb,
               const ego_shade_dump* dump, const uint8_t* tile_active, void* stream) {
   EGO_REQUIRE(rays && z && rgb && N >= 0 && S >= 1 && N * (int64_t)S < (1ll << 31), "shade: null argument or N*S >= 2^31");
+  if (sc && !ego_shape_is_tuned(sc)) {   // any other model shape: fp32 compatibility kernel (inference only)
+    if (dump) return ego_fail(EGO_E_UNSUPPORTED, "shade: activation dumps (training) exist for the tuned model shape only (app_dim 27, 48 components, "
+                                                  "MLP_Fea 150/128/128 with view_pe = fea_pe = 2)");
+    if (N == 0) return EGO_OK;
+    return ego_generic_shade(sc, rays, coords, N, S, rgb, tile_active, stream);
+  }
   if (int e = check_shade_config(sc, "shade", true, true)) return e;
   EGO_REQUIRE(sc->r_lut && sc->n_r_lut >= 2 && sc->n_r_lut <= LUT_MAX, "shade: r_lut missing or > 1024 entries");
   EGO_REQUIRE(coords || sc->mlp_precision == EGO_PREC_F32, "shade: coords (from ego_march_density) is required unless mlp_precision = EGO_PREC_F32");

@@ -488,6 +488,15 @@ class EgoNeRF(TensorBase):
         self._scene_cache = None
 
     @property
+    def is_tuned_shape(self) -> bool:
+        """True for the model shape every shipped config resolves to (app_dim 27, 48 appearance and 16 density components,
+        MLP_Fea 150 -> 128 -> 128 -> 3 with view_pe = fea_pe = 2): the MFMA kernels, forward and backward.  Any other shape
+        opt.py:87-100 can produce (n_lamb_sigma / n_lamb_sh multiples of 4 up to 48, data_dim_color <= 32, featureC 64 | 128,
+        view_pe / fea_pe <= 8) renders through the fp32 compatibility kernels: same results to fp32 rounding, roughly an order of
+        magnitude slower, inference only."""
+        return (self.app_dim, self.app_n_comp[0], self.density_n_comp[0], self.featureC, self.view_pe, self.fea_pe) == (27, 48, 16, 128, 2, 2)
+
+    @property
     def mlp_precision(self) -> str:
         """Arithmetic of the basis/MLP products:
         "f16f8" (default): layers 1 and 2 with the main term in fp16 and both correction terms in one block-scaled fp8 MFMA per
@@ -621,13 +630,16 @@ class EgoNeRF(TensorBase):
         sc.mlp_in, sc.mlp_hidden = self.renderModule.in_mlpC, self.featureC
         sc.view_pe, sc.fea_pe = self.view_pe, self.fea_pe
         sc.mlp_precision = {"f16x3": 0, "f32": 1, "f16f8": 2}[self._mlp_precision]
-        if (self.app_dim, self.app_n_comp[0], self.featureC, self.view_pe, self.fea_pe) == (27, 48, 128, 2, 2):
-            if self._packed is None or self._packed.device != dev:
-                self._packed = torch.empty(lib.ego_packed_floats(), device=dev)
-            _call("ego_pack_mlp", sc, self._packed.data_ptr(), _lib.stream_handle())
-            sc.packed = self._packed.data_ptr()
-        # any other head shape: sc.packed stays NULL; the density-side stage ops work, every shading entry point then fails with
-        # the library's "unsupported configuration" error instead of failing here for calls that never shade
+        # packed weights: the MFMA fragment layouts for the tuned shape (27 / 48 / 150 / 128 / 2 / 2, every shipped config), the fp32
+        # layout of the any-shape compatibility kernels otherwise (csrc/ego_generic.hip; the library reports the size for the shape)
+        sc.app.n_comp = self.app_n_comp[0]
+        need = lib.ego_packed_floats_scene(C.byref(sc))
+        if need <= 0:
+            raise RuntimeError("ego_packed_floats_scene rejected the scene")
+        if self._packed is None or self._packed.device != dev or self._packed.numel() != need:
+            self._packed = torch.empty(need, device=dev)
+        _call("ego_pack_mlp", sc, self._packed.data_ptr(), _lib.stream_handle())
+        sc.packed = self._packed.data_ptr()
         if self._app_table_dtype == "f16":
             self._fill_app16(sc)
         if self.use_alpha_mask and self.alphaMask is not None:
@@ -822,6 +834,9 @@ class EgoNeRF(TensorBase):
         else:
             jitter = u = None
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            if not self.is_tuned_shape:
+                raise NotImplementedError("the differentiable path (training) is built for the tuned model shape only (app_dim 27, 48 / 16 "
+                                          "components, MLP_Fea 150/128/128, view_pe = fea_pe = 2); other shapes render under torch.no_grad()")
             from .train import render_train  # differentiable path: keeps activations, backward in HIP (egonerf_amd/train.py)
             return render_train(self, rays, n_coarse, n_fine, resampling, use_coarse_sample, jitter, u, z_coarse)
         sc = self.scene()

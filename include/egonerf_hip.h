@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define EGO_ABI_VERSION 8
+#define EGO_ABI_VERSION 9
 
 enum { EGO_PREC_F16X3 = 0, EGO_PREC_F32 = 1, EGO_PREC_F16F8 = 2 };
 
@@ -131,6 +131,12 @@ typedef struct ego_scene {
 /* number of floats ego_pack_mlp writes: the packed weight blob used by ego_shade / ego_mlp_fea / ego_app_feature
  * (fp32 fragment layout, the fp16-split layout, then the basis fragments in the K order of the fp16-table gather) */
 int64_t ego_packed_floats(void);
+/* the same for the shape of `sc` (app_dim, app.n_comp, mlp_in, mlp_hidden, view_pe, fea_pe): ego_packed_floats() for the tuned shape
+ * every shipped config resolves to (27 / 48 / 150 / 128 / 2 / 2), the fp32 layout of the any-shape compatibility kernels otherwise
+ * (opt.py:87-100 lets a user choose n_lamb_sh, data_dim_color, featureC, view_pe, fea_pe; supported: n_comp a multiple of 4 up to
+ * 48, app_dim <= 32, featureC 64 or 128, view_pe / fea_pe <= 8; density n_comp a multiple of 4 up to 48).  Those kernels compute
+ * in plain fp32, are inference only (no activation dumps / backward) and about an order of magnitude slower than the tuned path. */
+int64_t ego_packed_floats_scene(const ego_scene* sc);
 
 int ego_abi_version(void);
 const char* ego_last_error(void);
@@ -180,7 +186,7 @@ int ego_avgpool_table(const float* src, int32_t H, int32_t W, int32_t C, float* 
 /* 8-tap occupancy lookup of YinYangAlphaGridMask.sample_alpha (models/EgoNeRF.py:19-24): c7n [M][7] -> out [M] (the
  * trilinear mask value; > 0 means occupied). */
 int ego_alpha_mask_sample(const ego_scene* sc, const float* c7n, int64_t M, float* out, void* stream);
-/* reference-layout basis/MLP weights in `sc` -> packed blob (dev, ego_packed_floats() floats) */
+/* reference-layout basis/MLP weights in `sc` -> packed blob (dev, ego_packed_floats_scene(sc) floats) */
 int ego_pack_mlp(const ego_scene* sc, float* packed_out, void* stream);
 
 /* ---- the fused hot path ------------------------------------------------------------------------ */

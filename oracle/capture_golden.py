@@ -643,9 +643,44 @@ def capture_uniform():
     np.savez_compressed(os.path.join(OUT, "tiny_uniform.npz"), **fx)
 
 
+SHAPES = {   # model shapes opt.py:87-100 can produce besides the one every shipped config resolves to (16 / 48 / 27 / 128 / 2 / 2)
+    "small_head": dict(density_n_comp=(8, 8, 8), app_n_comp=(24, 24, 24), app_dim=27, featureC=64, view_pe=2, fea_pe=2),
+    "ctor_defaults": dict(density_n_comp=(16, 16, 16), app_n_comp=(48, 48, 48), app_dim=12, featureC=128, view_pe=6, fea_pe=6),
+    "no_encoding": dict(density_n_comp=(24, 24, 24), app_n_comp=(8, 8, 8), app_dim=27, featureC=128, view_pe=0, fea_pe=0),
+    "tuned_head_other_density": dict(density_n_comp=(8, 8, 8), app_n_comp=(48, 48, 48), app_dim=27, featureC=128, view_pe=2, fea_pe=2),
+}
+
+
+def capture_shapes():
+    """The reference on a tiny grid with head / table shapes other than the shipped one (TensorBase ctor defaults: view_pe = fea_pe =
+    6, tensorBase.py:133-139; narrower tables and MLP; no positional encoding): stage ops on random coordinates and the end-to-end
+    render in both resampling modes, envmap on for one of them."""
+    fx = {}
+    for name, kw in SHAPES.items():
+        cfg = synth.SceneConfig(n_voxel=20 ** 3, use_envmap=(name == "small_head"), envmap_res_H=16, **kw)
+        weights = synth.make_weights(cfg, seed=4321)
+        model, coords = build_reference(cfg, weights)
+        rays = torch.from_numpy(synth.make_rays(48, seed=17))
+        M = 256
+        u = torch.from_numpy(synth.hash_uniform(98, 0, M * 7).reshape(M, 7).astype(np.float32))
+        q = u * 2.6 - 1.3
+        q[:, 6] = (u[:, 6] > 0.5).float()
+        af = model.compute_appfeature(q)
+        dirs = torch.nn.functional.normalize(torch.from_numpy(synth.hash_uniform(97, 0, M * 3).reshape(M, 3).astype(np.float32)) * 2 - 1, dim=-1)
+        fx.update({f"{name}/coords": np_(q), f"{name}/dirs": np_(dirs), f"{name}/density": np_(model.compute_densityfeature(q)),
+                   f"{name}/density_coarse": np_(model.compute_coarse_densityfeature(q)), f"{name}/app": np_(af),
+                   f"{name}/rgb_samples": np_(model.renderModule(q, dirs, af))})
+        o = run_forward(model, rays, n_coarse=24, n_fine=0, resampling=False)
+        fx.update({f"{name}/nr_rgb": np_(o[0]), f"{name}/nr_depth": np_(o[1]), f"{name}/nr_alpha": np_(o[4])})
+        o = run_forward(model, rays, n_coarse=16, n_fine=16, resampling=True, use_coarse_sample=True)
+        fx.update({f"{name}/rs_rgb": np_(o[0]), f"{name}/rs_depth": np_(o[1])})
+    fx["seed_weights"], fx["seed_rays"] = 4321, 17
+    np.savez_compressed(os.path.join(OUT, "shapes.npz"), **fx)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
-    which = sys.argv[1:] or ["tiny", "stages", "full", "alpha_mask", "checkpoint", "train_extras", "metrics", "plainexp", "sh", "uniform", "ricoh", "envmap_full", "ws", "skip", "omniblender"]
+    which = sys.argv[1:] or ["tiny", "stages", "full", "alpha_mask", "checkpoint", "train_extras", "metrics", "plainexp", "sh", "uniform", "ricoh", "envmap_full", "ws", "skip", "omniblender", "shapes"]
     for name in which:
         globals()["capture_" + name]()
         print("captured", name)
