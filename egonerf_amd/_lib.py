@@ -64,7 +64,7 @@ class AdamTensor(C.Structure):
 
 
 class ShadeDump(C.Structure):
-    _fields_ = [("x", C.c_void_p), ("h1", C.c_void_p), ("h2", C.c_void_p), ("v", C.c_void_p)]
+    _fields_ = [("x", C.c_void_p), ("h1", C.c_void_p), ("h2", C.c_void_p), ("v", C.c_void_p), ("relu_bits", C.c_void_p)]
 
 
 P, I32, I64, F32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
@@ -73,7 +73,7 @@ SP = C.POINTER(Scene)
 # The EGO_ABI_VERSION (include/egonerf_hip.h) the PROTOTYPES below were written against.  load() refuses a library that reports
 # another one: a stale libegonerf_hip.so can keep every struct size and still disagree on an argument list (ABI 5 -> 7 inserted
 # `normalize` before ego_erp_rays' output pointer), which ctypes would pass through as a wild pointer.
-EXPECTED_ABI_VERSION = 9
+EXPECTED_ABI_VERSION = 10
 
 # name -> (restype, argtypes); mirrors include/egonerf_hip.h one to one
 PROTOTYPES = {
@@ -107,9 +107,9 @@ PROTOTYPES = {
     "ego_scatter_density": (C.c_int, [SP, C.POINTER(VmGrad), P, P, I64, I32, P]),
     "ego_scatter_app": (C.c_int, [SP, C.POINTER(VmGrad), P, P, I64, I32, P]),
     "ego_envmap_backward": (C.c_int, [SP, P, I32, P, P, P, P, I64, P, P]),
-    "ego_shade_backward": (C.c_int, [SP, P, P, P, P, C.POINTER(ShadeDump), P, P, P, P, I64, I32, P]),
+    "ego_shade_backward": (C.c_int, [SP, P, P, P, P, C.POINTER(ShadeDump), P, P, P, P, P, I64, I32, P]),
     "ego_sh_render": (C.c_int, [P, P, I64, P, P]),
-    "ego_weight_grad": (C.c_int, [P, I32, I32, I32, P, I32, I32, I32, I32, I64, P, I32, P]),
+    "ego_weight_grad": (C.c_int, [P, I32, I32, I32, P, P, I32, I32, I32, I32, I64, P, I32, P]),
     "ego_tv_plane": (C.c_int, [P, I32, I32, I32, F32, P, P, P]),
     "ego_l1_table": (C.c_int, [P, I64, F32, P, P, P]),
     "ego_line_ortho": (C.c_int, [P, I32, I32, F32, P, P, P]),
@@ -150,7 +150,7 @@ def load() -> C.CDLL:
     if is_stale() and not os.environ.get("EGO_ALLOW_STALE_LIB"):
         raise RuntimeError(f"{LIB} was not built from the sources next to it (source hash differs from {LIB}.hash); rebuild it "
                            "(`python -m egonerf_amd.build`) or set EGO_ALLOW_STALE_LIB=1 for an experiment build")
-    for which, struct in ((0, Scene), (1, RenderArgs), (2, VmField), (3, AdamTensor)):
+    for which, struct in ((0, Scene), (1, RenderArgs), (2, VmField), (3, AdamTensor), (4, ShadeDump)):
         if lib.ego_sizeof(which) != C.sizeof(struct):
             raise RuntimeError(f"ABI mismatch: struct {struct.__name__} is {C.sizeof(struct)} B here, "
                                f"{lib.ego_sizeof(which)} B in {LIB}")

@@ -33,7 +33,7 @@ extern "C" {
 /* lets a binding verify its struct mirrors: which = 0 ego_scene, 1 ego_render_args, 2 ego_vm_field, 3 ego_adam_tensor */
 int64_t ego_sizeof(int32_t which) {
   return which == 0 ? (int64_t)sizeof(ego_scene) : which == 1 ? (int64_t)sizeof(ego_render_args) : which == 2 ? (int64_t)sizeof(ego_vm_field)
-       : which == 3 ? (int64_t)sizeof(ego_adam_tensor) : -1;
+       : which == 3 ? (int64_t)sizeof(ego_adam_tensor) : which == 4 ? (int64_t)sizeof(ego_shade_dump) : -1;
 }
 
 int64_t ego_render_workspace_bytes(int64_t N, const ego_render_args* args) {

@@ -300,6 +300,7 @@ struct ShadeArgs {
   float* dump_h1;     //   [M][160] X, [M][128] relu(H1), [M][128] relu(H2), [M][144] v   (see include/egonerf_hip.h)
   float* dump_h2;
   float* dump_v;
+  uint32_t* dump_bits;  // [tile][layer 0: h1, 1: h2][lane][2]: bit 16 (mt & 1) + r of word mt >> 1 <=> post-ReLU unit (mt, r) of the lane > 0
   const uint8_t* tile_active;  // optional [n_tiles]: 0 = every weight of the tile is zero, skip it
   int64_t M;
   int32_t S;
@@ -582,6 +583,18 @@ struct HL {
   h8 hi, lo;
 };
 
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+// bit 16 (mt & 1) + r of word mt >> 1 is set iff unit (mt, r) of this lane is > 0 (relu'(0) = 0 like torch's threshold backward)
+__device__ __forceinline__ u32x2 relu_bits(const f32x16 (&H)[4]) {
+  u32x2 b = {0u, 0u};
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) b[mt >> 1] |= (H[mt][r] > 0.f ? 1u : 0u) << (16 * (mt & 1) + r);
+  return b;
+}
+
 __device__ __forceinline__ void split_pair(float a, float b, bool keep, uint32_t& hi, uint32_t& lo) {
   a = keep ? a : 0.f;
   b = keep ? b : 0.f;
@@ -691,7 +704,6 @@ __device__ __forceinline__ void basis_step(const BasisFrag& a, const float x[8],
 // probes in tools/ reproduces it.  Builds of this file WITHOUT the SLP vectoriser (egonerf_amd/build.py) have been clean in every
 // soak (> 300 000 calls, all exchange forms tried); with it, only the __shfl_xor form happened to be.  tools/flaky_probe*.py,
 // tools/variant_test.sh and tests/test_hip_determinism.py are the guards: re-run them after ANY change to this file.
-typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 struct TeamSample {  // normalised coordinates of the sample this lane's team serves in one round
   float a_r, a_th, a_ph;
@@ -1241,6 +1253,8 @@ __global__ __launch_bounds__(512) void k_shade_h(ShadeArgs A) {
 #pragma unroll
         for (int q = 0; q < 4; ++q)
           *(f32x4*)(A.dump_h1 + dump_off(tile, 128, mt * 4 + q, hw, j)) = f32x4{H[mt][4 * q], H[mt][4 * q + 1], H[mt][4 * q + 2], H[mt][4 * q + 3]};
+      // the ReLU masks as bits: what the shade backward needs of h1 / h2 (it would otherwise re-read both dumps, 1 KB per sample)
+      ((u32x2*)A.dump_bits)[(tile * 2 + 0) * 64 + lane] = relu_bits(H);
     }
 
     // ---- layer 2 (8 steps), layer 3 on the VALU ----------------------------------------------------------------
@@ -1319,6 +1333,7 @@ __global__ __launch_bounds__(512) void k_shade_h(ShadeArgs A) {
         for (int q = 0; q < 4; ++q)
           *(f32x4*)(A.dump_h2 + dump_off(tile, 128, mt * 4 + q, hw, j)) =
               f32x4{relu_f(G[mt][4 * q]), relu_f(G[mt][4 * q + 1]), relu_f(G[mt][4 * q + 2]), relu_f(G[mt][4 * q + 3])};
+      ((u32x2*)A.dump_bits)[(tile * 2 + 1) * 64 + lane] = relu_bits(G);
     }
     float o0 = 0.f, o1 = 0.f, o2 = 0.f;
 #pragma unroll
@@ -1481,9 +1496,9 @@ int ego_shade(const ego_scene* sc, const float* rays, const float* z, const floa
   a.c = make_coords(*sc); a.F = make_field(sc->app); a.packed = sc->packed; a.rays = rays; a.z = z; a.coords = coords; a.out = rgb; a.tile_active = tile_active;
   a.M = N * (int64_t)S; a.S = S;
   if (dump) {
-    EGO_REQUIRE(sc->mlp_precision != EGO_PREC_F32 && dump->x && dump->h1 && dump->h2 && dump->v,
-                "shade: activation dumps need the fp16-split arithmetic (not EGO_PREC_F32) and four non-null buffers");
-    a.dump_x = dump->x; a.dump_h1 = dump->h1; a.dump_h2 = dump->h2; a.dump_v = dump->v;
+    EGO_REQUIRE(sc->mlp_precision != EGO_PREC_F32 && dump->x && dump->h1 && dump->h2 && dump->v && dump->relu_bits,
+                "shade: activation dumps need the fp16-split arithmetic (not EGO_PREC_F32) and five non-null buffers");
+    a.dump_x = dump->x; a.dump_h1 = dump->h1; a.dump_h2 = dump->h2; a.dump_v = dump->v; a.dump_bits = dump->relu_bits;
     k_shade_h<MODE_SHADE, true><<<shade_grid(a.M), 512, 0, (hipStream_t)stream>>>(a);
   } else if (sc->mlp_precision == EGO_PREC_F32) k_shade<MODE_SHADE><<<shade_grid(a.M), 512, 0, (hipStream_t)stream>>>(a);
   else if (sc->app_f16) {
@@ -1574,15 +1589,17 @@ int ego_march_backward(const ego_scene* sc, const float* z, const float* alpha, 
 }
 
 int ego_shade_backward(const ego_scene* sc, const float* train_packed, const float* coords, float* dc, const float* rgb,
-                       const ego_shade_dump* fwd, float* dh2, float* dh1, float* dfe, float* dv, int64_t N, int32_t S, void* stream) {
+                       const ego_shade_dump* fwd, uint16_t* dh2, uint16_t* dh1, float* dh_scale, float* dfe, float* dv, int64_t N, int32_t S,
+                       void* stream) {
   EGO_REQUIRE(N >= 0 && S >= 1 && N * (int64_t)S < (1ll << 31), "shade_backward: bad size");
   if (N == 0) return EGO_OK;
-  EGO_REQUIRE(sc && train_packed && coords && dc && rgb && fwd && fwd->x && fwd->h1 && fwd->h2 && dh2 && dh1 && dfe && dv,
+  EGO_REQUIRE(sc && train_packed && coords && dc && rgb && fwd && fwd->x && fwd->relu_bits && dh2 && dh1 && dh_scale && dfe && dv,
               "shade_backward: null argument");
+  EGO_REQUIRE((((uintptr_t)dh2 | (uintptr_t)dh1 | (uintptr_t)fwd->relu_bits) & 15) == 0, "shade_backward: dh2 / dh1 / relu_bits must be 16-byte aligned");
   if (int e = check_shade_config(sc, "shade_backward", true, true)) return e;
   ShadeBwdArgs a{};
   a.tpacked = train_packed; a.coords = coords; a.dc = dc; a.rgb = rgb;
-  a.x = fwd->x; a.h1 = fwd->h1; a.h2 = fwd->h2; a.dh2 = dh2; a.dh1 = dh1; a.dfe = dfe; a.dv = dv; a.M = N * (int64_t)S;
+  a.x = fwd->x; a.bits = fwd->relu_bits; a.dh2 = dh2; a.dh1 = dh1; a.dh_scale = dh_scale; a.dfe = dfe; a.dv = dv; a.M = N * (int64_t)S;
   k_shade_bwd<<<shade_grid(a.M), 512, 0, (hipStream_t)stream>>>(a);
   return ego_launch_status("k_shade_bwd");
 }

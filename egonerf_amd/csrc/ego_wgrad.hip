@@ -20,6 +20,7 @@ constexpr int WG_ROW = 72;  // bytes per LDS row: 32 bf16 samples (64 B) + 8 B p
 
 struct WgradArgs {
   const float* A;
+  const float* a_scale;  // A layout 2: per-row power of two
   const float* B;
   float* G;
   int64_t M;
@@ -44,11 +45,14 @@ __device__ __forceinline__ void split_bf16_pair(float v0, float v1, uint32_t& hi
 // One matrix tile = rows [row0, row0 + 32) x columns [0, 32 NB), staged to LDS as [term][column][32 samples].  A thread owns
 // (column quad, sample pair) items: two float4 global loads (fetch, issued a whole step ahead of their use), then eight
 // packed bf16-pair stores (commit).
-template <int NB, bool VEC, bool BLK>
+// BLK: 0 row-major fp32, 1 tile-blocked fp32, 2 tile-blocked scaled fp16 (ego_shade_backward's dh2 / dh1: [tile][k-step s][lane =
+// 32 h + sample][8 halves], element e = logical column 8 (2 s + e / 4) + 4 h + e % 4, value = half * scale[row]; NB == 4)
+template <int NB, bool VEC, int BLK>
 struct Tile {
   static constexpr int QUADS = NB * 8;                       // column quads per row
-  static constexpr int ITEMS = (16 * QUADS + 255) / 256;     // items per thread
+  static constexpr int ITEMS = BLK == 2 ? 1 : (16 * QUADS + 255) / 256;     // items per thread
   f32x4 v0[ITEMS], v1[ITEMS];
+  float s0, s1;  // BLK == 2: the two samples' scales
 
   // item -> (column quad, sample pair).  Row-major source: consecutive lanes take consecutive quads of one row (coalesced
   // rows); tile-blocked source (the shade kernels' dump layout, [tile][quad pair][32 h + j][4]): consecutive lanes take
@@ -57,7 +61,19 @@ struct Tile {
     if (BLK) { sp = idx & 15; cq = idx >> 4; } else { cq = idx % QUADS; sp = idx / QUADS; }
   }
 
-  __device__ __forceinline__ void fetch(const float* __restrict__ X, int ldx, int cx, int64_t row0, int64_t M) {
+  __device__ __forceinline__ void fetch(const float* __restrict__ X, const float* __restrict__ scale, int ldx, int cx, int64_t row0, int64_t M) {
+    if (BLK == 2) {  // item = (k-step, lane half, sample pair): 32 contiguous bytes = the 8 halves of two neighbouring lanes
+      static_assert(BLK != 2 || NB == 4, "the scaled-fp16 layout is the 128-column gradient dump");
+      const int s = threadIdx.x >> 5, hw = (threadIdx.x >> 4) & 1, sp = threadIdx.x & 15;
+      const int64_t r0 = row0 + 2 * sp;
+      const u32x4* p = (const u32x4*)X + ((row0 >> 5) * 8 + s) * 64 + hw * 32 + 2 * sp;
+      const u32x4 z = u32x4{0u, 0u, 0u, 0u};
+      v0[0] = __builtin_bit_cast(f32x4, r0 < M ? p[0] : z);
+      v1[0] = __builtin_bit_cast(f32x4, r0 + 1 < M ? p[1] : z);
+      s0 = r0 < M ? scale[r0] : 0.f;
+      s1 = r0 + 1 < M ? scale[r0 + 1] : 0.f;
+      return;
+    }
 #pragma unroll
     for (int it = 0; it < ITEMS; ++it) {
       const int idx = threadIdx.x + 256 * it;
@@ -88,6 +104,20 @@ struct Tile {
 
   __device__ __forceinline__ void commit(int ones_col, int64_t row0, int64_t M, uint8_t* __restrict__ lds) const {
     constexpr int COLS = NB * 32;
+    if (BLK == 2) {
+      typedef _Float16 h8v __attribute__((ext_vector_type(8)));
+      const int s = threadIdx.x >> 5, hw = (threadIdx.x >> 4) & 1, sp = threadIdx.x & 15;
+      const h8v a8 = __builtin_bit_cast(h8v, v0[0]), b8 = __builtin_bit_cast(h8v, v1[0]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int col = (2 * s + (e >> 2)) * 8 + hw * 4 + (e & 3);
+        uint32_t hi, lo;  // half * power of two is exact in fp32; its 11 significant bits split into 8 (hi) + 3 (lo) exactly
+        split_bf16_pair(__fmul_rn((float)a8[e], s0), __fmul_rn((float)b8[e], s1), hi, lo);
+        *(uint32_t*)(lds + col * WG_ROW + sp * 4) = hi;
+        *(uint32_t*)(lds + (COLS + col) * WG_ROW + sp * 4) = lo;
+      }
+      return;
+    }
 #pragma unroll
     for (int it = 0; it < ITEMS; ++it) {
       const int idx = threadIdx.x + 256 * it;
@@ -117,7 +147,7 @@ __device__ __forceinline__ bf8 frag(const uint8_t* row, int ks, int kb) {
 
 // 2-3 workgroups per CU hide the row fetches of one behind the multiplies of the others: cap the registers (left alone the
 // compiler takes 272 for the 4 x 5 shape, i.e. one workgroup per CU)
-template <int CAB, int CBB, bool AVEC, bool ABLK, bool BBLK>
+template <int CAB, int CBB, bool AVEC, int ABLK, bool BBLK>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CAB * CBB >= 20 ? 2 : 3, CAB * CBB >= 20 ? 2 : 3))) void k_wgrad(WgradArgs P) {
   __shared__ __attribute__((aligned(16))) uint8_t lds[(CAB + CBB) * 32 * 2 * WG_ROW];
   uint8_t* la = lds;
@@ -134,9 +164,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CAB * CBB >
     for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
   const int64_t step0 = (int64_t)blockIdx.x * P.steps_per_wg;
   Tile<CAB, AVEC, ABLK> ta;
-  Tile<CBB, true, BBLK> tb;
-  ta.fetch(P.A, P.lda, P.ca, step0 * 32, P.M);
-  tb.fetch(P.B, P.ldb, P.cb, step0 * 32, P.M);
+  Tile<CBB, true, BBLK ? 1 : 0> tb;
+  ta.fetch(P.A, P.a_scale, P.lda, P.ca, step0 * 32, P.M);
+  tb.fetch(P.B, nullptr, P.ldb, P.cb, step0 * 32, P.M);
   for (int st = 0; st < P.steps_per_wg; ++st) {
     const int64_t row0 = (step0 + st) * 32;
     if (row0 >= P.M) break;  // uniform over the workgroup
@@ -144,8 +174,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CAB * CBB >
     tb.commit(P.ones_col, row0, P.M, lb);
     __syncthreads();
     if (st + 1 < P.steps_per_wg) {  // next step's rows travel while this step multiplies
-      ta.fetch(P.A, P.lda, P.ca, row0 + 32, P.M);
-      tb.fetch(P.B, P.ldb, P.cb, row0 + 32, P.M);
+      ta.fetch(P.A, P.a_scale, P.lda, P.ca, row0 + 32, P.M);
+      tb.fetch(P.B, nullptr, P.ldb, P.cb, row0 + 32, P.M);
     }
 #pragma unroll
     for (int k = 0; k < MAXB; ++k) {
@@ -182,7 +212,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CAB * CBB >
   }
 }
 
-template <int CAB, int CBB, bool AVEC, bool ABLK, bool BBLK>
+template <int CAB, int CBB, bool AVEC, int ABLK, bool BBLK>
 int launch(const WgradArgs& a, hipStream_t st) {
   WgradArgs p = a;
   const int64_t steps = (a.M + 31) / 32;
@@ -196,34 +226,38 @@ int launch(const WgradArgs& a, hipStream_t st) {
 
 extern "C" {
 
-int ego_weight_grad(const float* A, int32_t lda, int32_t ca, int32_t a_blocked, const float* B, int32_t ldb, int32_t cb,
+int ego_weight_grad(const void* A, int32_t lda, int32_t ca, int32_t a_layout, const float* a_scale, const float* B, int32_t ldb, int32_t cb,
                     int32_t b_blocked, int32_t ones_col, int64_t M, float* G, int32_t ldg, void* stream) {
   EGO_REQUIRE(M >= 0 && ca >= 1 && ca <= 128 && cb >= 1 && cb <= 160 && lda >= ca && ldb >= cb && ones_col < 160,
               "weight_grad: bad size (ca <= 128, cb <= 160)");
+  EGO_REQUIRE(a_layout >= 0 && a_layout <= 2, "weight_grad: a_layout must be 0 (row-major), 1 (blocked fp32) or 2 (blocked scaled fp16)");
   if (M == 0) return EGO_OK;
   EGO_REQUIRE(A && B && G, "weight_grad: null argument");
+  EGO_REQUIRE(a_layout != 2 || (a_scale && ca == 128 && lda == 128 && ((uintptr_t)A & 15) == 0),
+              "weight_grad: the scaled-fp16 layout needs a_scale, 128 columns and a 16-byte aligned A");
   const int cab = (ca + 31) / 32;
   const int cbb = ((ones_col >= cb ? ones_col + 1 : cb) + 31) / 32;
   EGO_REQUIRE(ldg >= 32 * cbb, "weight_grad: ldg must cover the padded column blocks");
   EGO_REQUIRE((ldb & 3) == 0 && (cb & 3) == 0 && ((uintptr_t)B & 15) == 0, "weight_grad: B rows must be 16-byte aligned, cb a multiple of 4");
   const bool avec = (lda & 3) == 0 && (ca & 3) == 0 && ((uintptr_t)A & 15) == 0;
-  WgradArgs a{A, B, G, M, lda, ca, ldb, cb, ones_col, ldg, 0};
+  WgradArgs a{(const float*)A, a_scale, B, G, M, lda, ca, ldb, cb, ones_col, ldg, 0};
   const hipStream_t st = (hipStream_t)stream;
-  // instantiations: the training step's four products (dh2^T h1, dh1^T x: both blocked; do^T h2: ragged row-major A, blocked
-  // B; dfe^T v: row-major A, blocked B) and the all-row-major forms of the same shapes
-  const int key = (cab * 8 + cbb) * 4 + (a_blocked ? 2 : 0) + (b_blocked ? 1 : 0);
+  // instantiations: the training step's four products (dh2^T h1, dh1^T x: scaled-fp16 A, blocked B; do^T h2: ragged row-major
+  // A, blocked B; dfe^T v: row-major A, blocked B), their all-fp32 blocked forms and the all-row-major forms of the same shapes
+  const int key = (cab * 8 + cbb) * 8 + a_layout * 2 + (b_blocked ? 1 : 0);
   switch (key) {
-    case (1 * 8 + 5) * 4 + 0: return avec ? launch<1, 5, true, false, false>(a, st) : launch<1, 5, false, false, false>(a, st);
-    case (1 * 8 + 5) * 4 + 1: return avec ? launch<1, 5, true, false, true>(a, st) : launch<1, 5, false, false, true>(a, st);
-    case (2 * 8 + 5) * 4 + 0: if (avec) return launch<2, 5, true, false, false>(a, st); break;
-    case (2 * 8 + 5) * 4 + 1: if (avec) return launch<2, 5, true, false, true>(a, st); break;
-    case (4 * 8 + 5) * 4 + 0: if (avec) return launch<4, 5, true, false, false>(a, st); break;
-    case (4 * 8 + 5) * 4 + 3: if (avec) return launch<4, 5, true, true, true>(a, st); break;
-    case (4 * 8 + 4) * 4 + 0: if (avec) return launch<4, 4, true, false, false>(a, st); break;
+    case (1 * 8 + 5) * 8 + 0: return avec ? launch<1, 5, true, 0, false>(a, st) : launch<1, 5, false, 0, false>(a, st);
+    case (1 * 8 + 5) * 8 + 1: return avec ? launch<1, 5, true, 0, true>(a, st) : launch<1, 5, false, 0, true>(a, st);
+    case (2 * 8 + 5) * 8 + 0: if (avec) return launch<2, 5, true, 0, false>(a, st); break;
+    case (2 * 8 + 5) * 8 + 1: if (avec) return launch<2, 5, true, 0, true>(a, st); break;
+    case (4 * 8 + 5) * 8 + 0: if (avec) return launch<4, 5, true, 0, false>(a, st); break;
+    case (4 * 8 + 5) * 8 + 3: if (avec) return launch<4, 5, true, 1, true>(a, st); break;
+    case (4 * 8 + 5) * 8 + 5: return launch<4, 5, true, 2, true>(a, st);
+    case (4 * 8 + 4) * 8 + 0: if (avec) return launch<4, 4, true, 0, false>(a, st); break;
     default: break;
   }
-  return ego_fail(EGO_E_UNSUPPORTED, "weight_grad: no instantiation for %d x %d column blocks%s (blocked A %d, B %d)", cab, cbb,
-                  avec ? "" : " with unaligned A rows", a_blocked, b_blocked);
+  return ego_fail(EGO_E_UNSUPPORTED, "weight_grad: no instantiation for %d x %d column blocks%s (A layout %d, blocked B %d)", cab, cbb,
+                  avec ? "" : " with unaligned A rows", a_layout, b_blocked);
 }
 
 }  // extern "C"

@@ -171,8 +171,9 @@ class RenderFunction(torch.autograd.Function):
         M = N * S
         rgb = f(N, S, 3)
         Mp = (M + 31) // 32 * 32  # the dumps are tile-blocked ([tile][quad pair][lane][4], csrc/ego_shade.hip dump_off): whole tiles
-        dump = dict(x=f(Mp, 160), h1=f(Mp, 128), h2=f(Mp, 128), v=f(Mp, 144))
-        ds = _lib.ShadeDump(dump["x"].data_ptr(), dump["h1"].data_ptr(), dump["h2"].data_ptr(), dump["v"].data_ptr())
+        dump = dict(x=f(Mp, 160), h1=f(Mp, 128), h2=f(Mp, 128), v=f(Mp, 144),
+                    relu_bits=torch.empty(Mp // 32, 2, 64, 2, device=dev, dtype=torch.int32))
+        ds = _lib.ShadeDump(*(dump[k].data_ptr() for k in ("x", "h1", "h2", "v", "relu_bits")))
         _chk(lib.ego_shade(sc, rays.data_ptr(), z.data_ptr(), coords.data_ptr(), N, S, rgb.data_ptr(), C.byref(ds), None, st), "ego_shade")
         rgb_map, depth, raw = f(N, 3), f(N), f(N, 3)
         has_env = model.envmap is not None
@@ -245,10 +246,13 @@ class RenderFunction(torch.autograd.Function):
         tp = f(lib.ego_train_packed_floats())
         _chk(lib.ego_pack_train(sc, tp.data_ptr(), st), "ego_pack_train")
         Mp = (M + 31) // 32 * 32
-        dh2, dh1, dfe, dv = f(Mp, 128), f(Mp, 128), f(M, 64), f(Mp, 144)  # dh2 / dh1 / dv: tile-blocked like the dumps
-        ds = _lib.ShadeDump(sv["x"].data_ptr(), sv["h1"].data_ptr(), sv["h2"].data_ptr(), sv["v"].data_ptr())
+        # dh2 / dh1: scaled fp16 in the kernel's own operand order + one power of two per sample (include/egonerf_hip.h); dv: blocked fp32
+        half = lambda *shape: torch.empty(*shape, device=dev, dtype=torch.float16)
+        dh2, dh1, dh_scale, dfe, dv = half(Mp, 128), half(Mp, 128), f(2, Mp), f(M, 64), f(Mp, 144)
+        ds = _lib.ShadeDump(*(sv[k].data_ptr() for k in ("x", "h1", "h2", "v", "relu_bits")))
         _chk(lib.ego_shade_backward(sc, tp.data_ptr(), sv["coords"].data_ptr(), dc.data_ptr(), sv["rgb"].data_ptr(), C.byref(ds),
-                                          dh2.data_ptr(), dh1.data_ptr(), dfe.data_ptr(), dv.data_ptr(), N, S, st), "ego_shade_backward")
+                                          dh2.data_ptr(), dh1.data_ptr(), dh_scale.data_ptr(), dfe.data_ptr(), dv.data_ptr(), N, S, st),
+             "ego_shade_backward")
         ga = _grad_struct(g_app)
         on_side(lambda s_: _chk(lib.ego_scatter_app(sc, C.byref(ga), sv["coords"].data_ptr(), dv.data_ptr(), N, S, s_), "ego_scatter_app"))
         if side is None:
@@ -260,9 +264,9 @@ class RenderFunction(torch.autograd.Function):
         hid, vmap = ix["hid"], ix["vmap"]
         mlp = model.renderModule.mlp
 
-        def wgrad(A, ca, a_blocked, B, cb, ones_col):
+        def wgrad(A, ca, a_layout, B, cb, ones_col, a_scale=None):
             G = torch.zeros(32 * ((ca + 31) // 32), 160, device=dev)
-            _chk(lib.ego_weight_grad(A.data_ptr(), A.shape[1], ca, a_blocked, B.data_ptr(), B.shape[1], cb, 1, ones_col, M,
+            _chk(lib.ego_weight_grad(A.data_ptr(), A.shape[1], ca, a_layout, _lib.ptr(a_scale), B.data_ptr(), B.shape[1], cb, 1, ones_col, M,
                                            G.data_ptr(), 160, st), "ego_weight_grad")
             return G
 
@@ -270,13 +274,13 @@ class RenderFunction(torch.autograd.Function):
         gw3 = torch.zeros_like(mlp[4].weight)
         gw3[:, hid] = G3[:3, :128]
         gb3 = G3[:3, 128].clone()
-        G2 = wgrad(dh2, 128, 1, sv["h1"], 128, 128)
+        G2 = wgrad(dh2, 128, 2, sv["h1"], 128, 128, dh_scale[0])
         gw2 = torch.zeros_like(mlp[2].weight)
         gw2[hid[:, None], hid[None, :]] = G2[:, :128]
         gb2 = torch.zeros_like(mlp[2].bias)
         gb2[hid] = G2[:, 128]
         pad = ix["pad"]  # a padding column of the x dump (holds zeros) doubles as the ones column
-        G1 = wgrad(dh1, 128, 1, sv["x"], 160, pad)
+        G1 = wgrad(dh1, 128, 2, sv["x"], 160, pad, dh_scale[1])
         gw1 = torch.zeros_like(mlp[0].weight)
         gw1[hid[:, None], ix["x_cols"][None, :]] = G1[:, ix["x_sel"]]
         gb1 = torch.zeros_like(mlp[0].bias)

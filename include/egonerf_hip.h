@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define EGO_ABI_VERSION 9
+#define EGO_ABI_VERSION 10
 
 enum { EGO_PREC_F16X3 = 0, EGO_PREC_F32 = 1, EGO_PREC_F16F8 = 2 };
 
@@ -140,7 +140,7 @@ int64_t ego_packed_floats_scene(const ego_scene* sc);
 
 int ego_abi_version(void);
 const char* ego_last_error(void);
-/* sizeof the ABI structs as compiled (0 ego_scene, 1 ego_render_args, 2 ego_vm_field, 3 ego_adam_tensor): lets a foreign-
+/* sizeof the ABI structs as compiled (0 ego_scene, 1 ego_render_args, 2 ego_vm_field, 3 ego_adam_tensor, 4 ego_shade_dump): lets a foreign-
  * language binding verify its struct mirrors at load time */
 int64_t ego_sizeof(int32_t which);
 
@@ -210,12 +210,15 @@ int ego_march_density(const ego_scene* sc, const float* rays, int64_t N, int32_t
  * is logical column 8 (kk / 4) + 4 h + kk % 4 (ego_train_layout() maps columns to the reference's inputs / units).  Storage
  * is tile-blocked, lane-major: [tile = m / 32][quad pair q = column / 8][lane = 32 h + m % 32][4 floats], i.e. float offset
  * tile * 32 * width + q * 256 + (32 h + m % 32) * 4 + c, so each buffer needs ceil(M / 32) * 32 rows.  ego_weight_grad reads
- * this layout directly (a_blocked / b_blocked). */
+ * this layout directly (a_layout / b_blocked).  relu_bits [ceil(M / 32)][2 (h1, h2)][64 lanes][2] uint32 holds the ReLU masks of
+ * the two hidden layers (bit 16 (t & 1) + r of word t >> 1 of lane 32 h + m % 32 <=> unit 32 t + slot_row(r, h) of sample m is
+ * > 0): all the shade backward needs of h1 / h2 (autograd of torch.nn.ReLU, tensorBase.py:68-71), 32 B instead of 1 KB per sample. */
 typedef struct ego_shade_dump {
   float* x;
   float* h1;
   float* h2;
   float* v;
+  uint32_t* relu_bits;
 } ego_shade_dump;
 
 /* Static facts about the shade kernel that implements `precision` (EGO_PREC_*), for roofline accounting by a caller that times it
@@ -265,12 +268,16 @@ int ego_train_layout(int32_t which, int32_t* out, int32_t n);
 int ego_march_backward(const ego_scene* sc, const float* z, const float* alpha, int32_t alpha_stride, const float* weight,
                        const float* sigma, const float* bg_weight, const float* rgb, const float* g_rgb, const float* g_alpha,
                        const float* rgb_raw, const float* env_map, int64_t N, int32_t S, float* dc, float* dfeat, void* stream);
-/* shade backward: dc [N][S][3] in = dL/d rgb_sample, out = dL/d(pre-sigmoid).  Writes dh2, dh1 [M][128], dfe [M][64]
- * (grid g at [32g..)) and dv = dL/d(plane x line products).  dh2, dh1 use the tile-blocked layout of the forward's dumps
- * ([tile = m / 32][quad pair][lane = 32 h + m % 32][4]); dv is [tile][plane * 3 + line][sample][16 channels]; all three need
- * ceil(M / 32) * 32 rows. */
+/* shade backward: dc [N][S][3] in = dL/d rgb_sample, out = dL/d(pre-sigmoid).  Writes dh2, dh1 (logical [M][128]), dfe [M][64]
+ * (grid g at [32g..)) and dv = dL/d(plane x line products).  dh2 / dh1 are stored as SCALED fp16 in the order the kernel's own
+ * matrix products consume them: [tile = m / 32][k-step s = 0..7][lane = 32 h + m % 32][8 halves], element e = logical column
+ * 8 (2 s + e / 4) + 4 h + e % 4 (the column numbering of the forward's dumps), value = half * dh_scale[row][m] with dh_scale
+ * [2][ceil(M / 32) * 32] per-sample powers of two (row 0: dh2, row 1: dh1) chosen so that a sample's largest magnitude lies in
+ * [2^12, 2^13): 11 significant bits, rounded to nearest, half the bytes of fp32 (ego_weight_grad's a_layout 2 reads it).  dv is
+ * [tile][plane * 3 + line][sample][16 channels] fp32; all need ceil(M / 32) * 32 rows.  Reads fwd->x and fwd->relu_bits only. */
 int ego_shade_backward(const ego_scene* sc, const float* train_packed, const float* coords, float* dc, const float* rgb,
-                       const ego_shade_dump* fwd, float* dh2, float* dh1, float* dfe, float* dv, int64_t N, int32_t S, void* stream);
+                       const ego_shade_dump* fwd, uint16_t* dh2, uint16_t* dh1, float* dh_scale, float* dfe, float* dv, int64_t N,
+                       int32_t S, void* stream);
 /* backward of the VM lookups (autograd of F.grid_sample in EgoNeRF.py:291-347 / :349-413): accumulates into the gradient
  * tables (same channel-last layout as the parameters).  coords [N][S][4] = the forward's normalised (r, theta, phi, grid). */
 int ego_scatter_density(const ego_scene* sc, const ego_vm_grad* gdensity, const float* coords, const float* dfeat, int64_t N, int32_t S,
@@ -282,14 +289,15 @@ int ego_scatter_app(const ego_scene* sc, const ego_vm_grad* gapp, const float* c
  * env_map = the forward's radiance [N][3]; the clamp mask is taken from rgb_raw (pass values in [0,1] for none). */
 int ego_envmap_backward(const ego_scene* sc, const float* dirs, int32_t dir_stride, const float* g_rgb, const float* rgb_raw, const float* bg_weight,
                         const float* env_map, int64_t N, float* g_emission, void* stream);
-/* Weight gradients of nn.Linear layers over all samples: G [32 ceil(ca/32)][ldg] += A^T B for fp32 A (M rows, ca <= 128
- * columns used of lda) and B (M rows, cb <= 160 of ldb), G accumulated (zero it first).  a_blocked / b_blocked: the matrix is
- * stored in the shade kernels' dump layout [tile = m / 32][quad pair q][lane = 32 h + m % 32][4] with logical column
- * 8 q + 4 h + c (ceil(M / 32) * 32 rows allocated) instead of row-major.  ones_col >= 0 replaces that column of B by ones (it
- * may lie beyond cb, < 160), which yields the bias gradient = column sums of A in G[:, ones_col].  bf16 hi/lo split MFMA,
- * ~17 significand bits per operand. */
-int ego_weight_grad(const float* A, int32_t lda, int32_t ca, int32_t a_blocked, const float* B, int32_t ldb, int32_t cb,
-                    int32_t b_blocked, int32_t ones_col, int64_t M, float* G, int32_t ldg, void* stream);
+/* Weight gradients of nn.Linear layers over all samples: G [32 ceil(ca/32)][ldg] += A^T B for A (M rows, ca <= 128 columns
+ * used of lda) and fp32 B (M rows, cb <= 160 of ldb), G accumulated (zero it first).  a_layout 0: row-major fp32 | 1: fp32 in the
+ * shade kernels' dump layout [tile = m / 32][quad pair q][lane = 32 h + m % 32][4] with logical column 8 q + 4 h + c
+ * (ceil(M / 32) * 32 rows allocated) | 2: ego_shade_backward's scaled-fp16 layout (ca = lda = 128, a_scale [M] = that matrix's
+ * row of dh_scale; NULL otherwise).  b_blocked: B in the dump layout instead of row-major.  ones_col >= 0 replaces that column
+ * of B by ones (it may lie beyond cb, < 160), which yields the bias gradient = column sums of A in G[:, ones_col].  bf16 hi/lo
+ * split MFMA, ~17 significand bits per operand. */
+int ego_weight_grad(const void* A, int32_t lda, int32_t ca, int32_t a_layout, const float* a_scale, const float* B, int32_t ldb,
+                    int32_t cb, int32_t b_blocked, int32_t ones_col, int64_t M, float* G, int32_t ldg, void* stream);
 
 /* ---- training-step table ops (train.py:245-330).  Tables are channel-last [H][W][C].  `value` (device double, may be
  * NULL) and `grad` (device, same layout as the table, may be NULL) are ACCUMULATED into, so one buffer collects a whole

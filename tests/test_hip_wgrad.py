@@ -19,13 +19,32 @@ def _blocked(X):
     return P.view(Mp // 32, 32, W // 8, 2, 4).permute(0, 2, 3, 1, 4).contiguous().view(Mp, W)
 
 
-def _run(A, ca, B, cb, ones_col, G=None, a_blocked=0, b_blocked=0, M=None):
+def _scaled_half(X):
+    """Row-major fp32 [M, 128] -> ego_shade_backward's scaled-fp16 layout [tile][k-step s][lane = 32 h + j][8 halves] (element e =
+    logical column 8 (2 s + e / 4) + 4 h + e % 4) + the per-row power of two that puts the row's largest magnitude into
+    [2^12, 2^13), and the fp32 matrix those halves stand for."""
+    M, W = X.shape
+    assert W == 128
+    Mp = (M + 31) // 32 * 32
+    amax = X.abs().amax(1).clamp_min(1e-38)
+    k = 12 - torch.floor(torch.log2(amax))
+    scale, inv = torch.exp2(k), torch.exp2(-k)
+    H = (X * scale[:, None]).half()
+    exact = H.float() * inv[:, None]
+    P = torch.full((Mp, W), float("nan"), dtype=torch.float16)   # padding rows must never be read
+    P[:M] = H
+    # column = 8 (2 s + e4) + 4 h + c  ->  [tile][j][s][e4][h][c] -> [tile][s][h][j][e4][c]
+    P = P.view(Mp // 32, 32, 8, 2, 2, 4).permute(0, 2, 4, 1, 3, 5).contiguous().view(Mp, W)
+    return P, inv, exact
+
+
+def _run(A, ca, B, cb, ones_col, G=None, a_blocked=0, b_blocked=0, M=None, a_scale=None):
     lib, st = _lib.load(), _lib.stream_handle()
     M = A.shape[0] if M is None else M
     if G is None:
         G = torch.zeros(32 * ((ca + 31) // 32), 160, device=DEV)
-    _lib.check(lib.ego_weight_grad(A.data_ptr(), A.shape[1], ca, a_blocked, B.data_ptr(), B.shape[1], cb, b_blocked, ones_col, M,
-                                   G.data_ptr(), 160, st), "ego_weight_grad")
+    _lib.check(lib.ego_weight_grad(A.data_ptr(), A.shape[1], ca, a_blocked, _lib.ptr(a_scale), B.data_ptr(), B.shape[1], cb, b_blocked,
+                                   ones_col, M, G.data_ptr(), 160, st), "ego_weight_grad")
     return G
 
 
@@ -52,6 +71,18 @@ def test_weight_grad_matches_float64(ca, lda, cb, ones_col, M):
         Gb = _run((_blocked(A) if ab else A).to(DEV), ca, _blocked(B).to(DEV), cb, ones_col, a_blocked=int(ab), b_blocked=1, M=M).cpu().double()
         assert float((Gb[:ca, cols] - ref[:, cols]).abs().max()) <= 5e-5 * scale
         assert torch.isfinite(Gb).all()
+    # ... and with A as the shade backward writes it: scaled fp16 + one power of two per row.  Against the product of the values
+    # the halves stand for, the pass is as exact as the fp32 forms; against the unrounded A the fp16 rounding (2^-12 per element,
+    # unbiased) shows, averaged over the rows
+    if lda == 128 and cb in (128, 160):
+        Ah, inv, exact = _scaled_half(A)
+        Gh = _run(Ah.to(DEV), ca, _blocked(B).to(DEV), cb, ones_col, a_blocked=2, b_blocked=1, M=M, a_scale=inv.to(DEV)).cpu().double()
+        ref_h = exact.double().T @ B.double()
+        assert float((Gh[:ca, cols] - ref_h[:, cols]).abs().max()) <= 5e-5 * scale
+        assert float((Gh[:ca, cols] - ref[:, cols]).abs().max()) <= 3e-4 * scale
+        assert torch.isfinite(Gh).all()
+        if ones_col >= 0:
+            assert float((Gh[:ca, ones_col] - exact.double().sum(0)).abs().max()) <= 5e-5 * float(bias.abs().max())
 
 
 def test_weight_grad_accumulates_and_validates():
@@ -60,6 +91,7 @@ def test_weight_grad_accumulates_and_validates():
     G = _run(A, 128, B, 128, -1, G)
     assert float(G[:128, :128].min()) == 80.0 and float(G[:128, :128].max()) == 80.0
     lib = _lib.load()
-    assert lib.ego_weight_grad(A.data_ptr(), 128, 129, 0, B.data_ptr(), 128, 128, 0, -1, 40, G.data_ptr(), 160, None) == -1
+    assert lib.ego_weight_grad(A.data_ptr(), 128, 129, 0, None, B.data_ptr(), 128, 128, 0, -1, 40, G.data_ptr(), 160, None) == -1
     assert b"weight_grad" in lib.ego_last_error()
-    assert lib.ego_weight_grad(A.data_ptr(), 128, 96, 0, B.data_ptr(), 128, 128, 0, -1, 40, G.data_ptr(), 160, None) != 0  # no 3 x 4 instance
+    assert lib.ego_weight_grad(A.data_ptr(), 128, 96, 0, None, B.data_ptr(), 128, 128, 0, -1, 40, G.data_ptr(), 160, None) != 0  # no 3 x 4 instance
+    assert lib.ego_weight_grad(A.data_ptr(), 128, 128, 2, None, B.data_ptr(), 128, 128, 1, -1, 40, G.data_ptr(), 160, None) == -1  # no a_scale
