@@ -94,6 +94,7 @@ PROTOTYPES = {
     "ego_sample_pdf_merge": (C.c_int, [P, P, P, I64, I32, I32, I32, P, P, P]),
     "ego_envmap_radiance": (C.c_int, [SP, P, I64, P, P]),
     "ego_avgpool_table": (C.c_int, [P, I32, I32, I32, P, P]),
+    "ego_avgpool_field": (C.c_int, [C.POINTER(VmField), C.POINTER(VmField), P]),
     "ego_pack_mlp": (C.c_int, [SP, P, P]),
     "ego_march_density": (C.c_int, [SP, P, I64, I32, P, P, P, F32, I32, P, P, I32, P, P, P, P, P, P]),
     "ego_shade_kernel_info": (C.c_int, [I32, C.POINTER(C.c_int32), I32]),

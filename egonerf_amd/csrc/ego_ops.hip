@@ -749,6 +749,35 @@ __global__ void k_avgpool(const float* __restrict__ src, int H, int W, int C, fl
   }
 }
 
+// all tables of a field in one launch (update_coarse_sigma_grid runs after every training step: 12 launches of ~5 us otherwise)
+struct PoolJobs {
+  const float* src[12];
+  float* dst[12];
+  int32_t H[12], W[12];
+  int32_t C, n;
+};
+
+__global__ void k_avgpool_many(PoolJobs J) {
+  const int jb = blockIdx.y;
+  const int H = J.H[jb], W = J.W[jb], C = J.C;
+  const int Ho = H / 2, Wo = (W == 1) ? 1 : W / 2;
+  const float* __restrict__ src = J.src[jb];
+  float* __restrict__ dst = J.dst[jb];
+  const int64_t total = (int64_t)Ho * Wo * C;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int ch = (int)(idx % C);
+    const int x = (int)((idx / C) % Wo);
+    const int y = (int)(idx / ((int64_t)C * Wo));
+    if (W == 1) {
+      dst[idx] = (src[((int64_t)2 * y) * C + ch] + src[((int64_t)2 * y + 1) * C + ch]) * 0.5f;
+    } else {
+      const float* r0 = src + ((int64_t)(2 * y) * W + 2 * x) * C + ch;
+      const float* r1 = src + ((int64_t)(2 * y + 1) * W + 2 * x) * C + ch;
+      dst[idx] = (((r0[0] + r0[C]) + r1[0]) + r1[C]) * 0.25f;
+    }
+  }
+}
+
 // =============================================================================================
 // Equirectangular camera rays on the device   dataLoader/ray_utils.py:24-40 (directions), :85-113 (pose)
 // =============================================================================================
@@ -927,6 +956,29 @@ int ego_avgpool_table(const float* src, int32_t H, int32_t W, int32_t C, float* 
   const int64_t n = (int64_t)(H / 2) * (W == 1 ? 1 : W / 2) * C;
   k_avgpool<<<nblk(n, 256), 256, 0, (hipStream_t)stream>>>(src, H, W, C, dst);
   return ego_launch_status("k_avgpool");
+}
+
+int ego_avgpool_field(const ego_vm_field* src, const ego_vm_field* dst, void* stream) {
+  EGO_REQUIRE(src && dst && src->n_comp >= 1 && dst->n_comp == src->n_comp, "avgpool_field: null field or component counts differ");
+  PoolJobs J{};
+  J.C = src->n_comp; J.n = 12;
+  int64_t most = 0;
+  for (int g = 0; g < 2; ++g)
+    for (int i = 0; i < 3; ++i) {
+      // plane i: [res[y axis]][res[x axis]][C]; line i: [res[line axis]][C] (vm_plane_x / vm_plane_y / vm_line_ax of ego_device.h)
+      const int px = i == 2 ? 1 : 0, py = i == 0 ? 1 : 2, la = 2 - i;
+      EGO_REQUIRE(src->plane[g][i] && src->line[g][i] && dst->plane[g][i] && dst->line[g][i], "avgpool_field: null table");
+      EGO_REQUIRE(dst->res[0] == src->res[0] / 2 && dst->res[1] == src->res[1] / 2 && dst->res[2] == src->res[2] / 2 && dst->res[0] >= 1 &&
+                  dst->res[1] >= 1 && dst->res[2] >= 1, "avgpool_field: dst.res must be src.res / 2");
+      const int a = g * 6 + i, b = g * 6 + 3 + i;
+      J.src[a] = src->plane[g][i]; J.dst[a] = (float*)dst->plane[g][i]; J.H[a] = src->res[py]; J.W[a] = src->res[px];
+      J.src[b] = src->line[g][i]; J.dst[b] = (float*)dst->line[g][i]; J.H[b] = src->res[la]; J.W[b] = 1;
+      const int64_t n = (int64_t)(J.H[a] / 2) * (J.W[a] / 2) * J.C;
+      most = n > most ? n : most;
+    }
+  const unsigned bx = nblk(most, 256) < 1024u ? nblk(most, 256) : 1024u;
+  k_avgpool_many<<<dim3(bx ? bx : 1u, 12), 256, 0, (hipStream_t)stream>>>(J);
+  return ego_launch_status("k_avgpool_many");
 }
 
 int ego_march_density(const ego_scene* sc, const float* rays, int64_t N, int32_t S, const float* z_in,

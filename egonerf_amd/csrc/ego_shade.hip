@@ -1595,7 +1595,8 @@ int ego_shade_backward(const ego_scene* sc, const float* train_packed, const flo
   if (N == 0) return EGO_OK;
   EGO_REQUIRE(sc && train_packed && coords && dc && rgb && fwd && fwd->x && fwd->relu_bits && dh2 && dh1 && dh_scale && dfe && dv,
               "shade_backward: null argument");
-  EGO_REQUIRE((((uintptr_t)dh2 | (uintptr_t)dh1 | (uintptr_t)fwd->relu_bits) & 15) == 0, "shade_backward: dh2 / dh1 / relu_bits must be 16-byte aligned");
+  EGO_REQUIRE((((uintptr_t)dh2 | (uintptr_t)dh1 | (uintptr_t)fwd->relu_bits | (uintptr_t)dv) & 15) == 0,
+              "shade_backward: dh2 / dh1 / dv / relu_bits must be 16-byte aligned");
   if (int e = check_shade_config(sc, "shade_backward", true, true)) return e;
   ShadeBwdArgs a{};
   a.tpacked = train_packed; a.coords = coords; a.dc = dc; a.rgb = rgb;

@@ -482,9 +482,13 @@ class EgoNeRF(TensorBase):
         shapes = [(src.shape[1], src.shape[2] // 2, 1 if src.shape[3] == 1 else src.shape[3] // 2) for *_k, src in srcs]
         dsts = _carve_channel_last(shapes, srcs[0][3].device)   # one buffer: compact addressing like the full tables
         for (g, what, i, src), dst in zip(srcs, dsts):
-            _, C_, H, W = src.shape
-            _call("ego_avgpool_table", _table_ptr(src), H, W, C_, dst.data_ptr(), st)
             getattr(self, f"coarse_sigma_{what}_{g}")[i] = dst
+        # all 12 tables in one launch (this runs after every training step, train.py:356-357)
+        fs, fd = _lib.VmField(), _lib.VmField()
+        res = [int(v) for v in self.gridSize.tolist()]
+        self._fill_field(fs, "density", self.density_n_comp, res)
+        self._fill_field(fd, "density", self.density_n_comp, [r // 2 for r in res], coarse=True)
+        _call("ego_avgpool_field", C.byref(fs), C.byref(fd), st)
         self._scene_cache = None
 
     @property

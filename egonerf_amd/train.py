@@ -71,16 +71,40 @@ def mark(what: str) -> None:
         KERNEL_MARKS.append((what, ev))
 
 
-def _grad_indices(device):
-    """Index tensors that un-permute the lane-order columns of the weight-gradient products, derived once from the layouts
-    (boolean masks / nonzero() in the backward pass would cost a host synchronisation each, every step)."""
+# Weight-gradient products of one step land in ONE zero-filled buffer [352][160] (rows: do^T h2 | dh2^T h1 | dh1^T x | dfe^T v) and
+# ONE gather turns it into the eight reference-shaped gradients (basis yin / yang, w1, b1, w2, b2, w3, b3): two small kernels
+# instead of a zero fill per product and a fill + an index_put per gradient (22 launches of ~5 us each on the critical path).
+_G_ROWS = dict(G3=(0, 32), G2=(32, 160), G1=(160, 288), Gb=(288, 352))
+_G_LD = 160
+
+
+def _grad_plan(model, device):
+    """(flat gather index, split sizes, shapes, pad column) derived once from the layouts (no host synchronisation per step)."""
     key = str(device)
     if key not in _INDEX_CACHE:
         hid, xmap, fmap, vmap = (_layout(w, n, "cpu") for w, n in ((1, 128), (0, 160), (2, 32), (3, 144)))
         x_sel = (xmap >= 0).nonzero().flatten()
         f_sel = (fmap >= 0).nonzero().flatten()
-        d = dict(hid=hid, x_sel=x_sel, x_cols=xmap[x_sel], pad=int((xmap < 0).nonzero()[0]), f_sel=f_sel, f_rows=fmap[f_sel], vmap=vmap)
-        _INDEX_CACHE[key] = {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in d.items()}
+        x_cols, f_rows, pad = xmap[x_sel], fmap[f_sel], int((xmap < 0).nonzero()[0])
+        src = torch.arange(352 * _G_LD).view(352, _G_LD)   # every element of the product buffer, by flat position
+        G3, G2, G1, Gb = (src[a:b] for a, b in (_G_ROWS[k] for k in ("G3", "G2", "G1", "Gb")))
+        mlp = model.renderModule.mlp
+        neg = lambda *shape: torch.full(shape, -1, dtype=torch.int64)
+        gw3 = neg(*mlp[4].weight.shape); gw3[:, hid] = G3[:3, :128]
+        gb3 = G3[:3, 128].clone()
+        gw2 = neg(*mlp[2].weight.shape); gw2[hid[:, None], hid[None, :]] = G2[:, :128]
+        gb2 = neg(*mlp[2].bias.shape); gb2[hid] = G2[:, 128]
+        gw1 = neg(*mlp[0].weight.shape); gw1[hid[:, None], x_cols[None, :]] = G1[:, x_sel]
+        gb1 = neg(*mlp[0].bias.shape); gb1[hid] = G1[:, pad]
+        gbasis = []
+        for g in range(2):
+            gb = neg(model.app_dim, 144)
+            gb[f_rows[:, None], vmap[None, :]] = Gb[32 * g: 32 * g + 32, :144][f_sel]
+            gbasis.append(gb)
+        parts = gbasis + [gw1, gb1, gw2, gb2, gw3, gb3]
+        flat = torch.cat([p.reshape(-1) for p in parts])
+        assert int(flat.min()) >= 0, "every weight / bias gradient element has a source in the product buffer"
+        _INDEX_CACHE[key] = (flat.to(device), [p.numel() for p in parts], [tuple(p.shape) for p in parts], pad)
     return _INDEX_CACHE[key]
 
 
@@ -258,40 +282,23 @@ class RenderFunction(torch.autograd.Function):
         if side is None:
             del dv
         # ---- weight gradients: one pass of ego_weight_grad (bf16 hi/lo MFMA over transposed LDS tiles, bias gradients from a
-        # ones column) per layer over the dumped buffers, then un-permute the lane-order columns ----
+        # ones column) per layer over the dumped buffers into one product buffer, then one gather un-permutes the lane-order
+        # columns into the reference-shaped gradients ----
         do = dc.view(M, 3)  # now d(pre-sigmoid)
-        ix = _grad_indices(dev)
-        hid, vmap = ix["hid"], ix["vmap"]
-        mlp = model.renderModule.mlp
+        gidx, gsizes, gshapes, pad = _grad_plan(model, dev)  # pad: a padding column of the x dump (holds zeros) doubles as the ones column
+        Gall = torch.zeros(352, _G_LD, device=dev)
 
-        def wgrad(A, ca, a_layout, B, cb, ones_col, a_scale=None):
-            G = torch.zeros(32 * ((ca + 31) // 32), 160, device=dev)
+        def wgrad(which, A, ca, a_layout, B, cb, ones_col, a_scale=None):
+            G = Gall[_G_ROWS[which][0]:_G_ROWS[which][1]]
             _chk(lib.ego_weight_grad(A.data_ptr(), A.shape[1], ca, a_layout, _lib.ptr(a_scale), B.data_ptr(), B.shape[1], cb, 1, ones_col, M,
-                                           G.data_ptr(), 160, st), "ego_weight_grad")
-            return G
+                                           G.data_ptr(), _G_LD, st), "ego_weight_grad")
 
-        G3 = wgrad(do, 3, 0, sv["h2"], 128, 128)
-        gw3 = torch.zeros_like(mlp[4].weight)
-        gw3[:, hid] = G3[:3, :128]
-        gb3 = G3[:3, 128].clone()
-        G2 = wgrad(dh2, 128, 2, sv["h1"], 128, 128, dh_scale[0])
-        gw2 = torch.zeros_like(mlp[2].weight)
-        gw2[hid[:, None], hid[None, :]] = G2[:, :128]
-        gb2 = torch.zeros_like(mlp[2].bias)
-        gb2[hid] = G2[:, 128]
-        pad = ix["pad"]  # a padding column of the x dump (holds zeros) doubles as the ones column
-        G1 = wgrad(dh1, 128, 2, sv["x"], 160, pad, dh_scale[1])
-        gw1 = torch.zeros_like(mlp[0].weight)
-        gw1[hid[:, None], ix["x_cols"][None, :]] = G1[:, ix["x_sel"]]
-        gb1 = torch.zeros_like(mlp[0].bias)
-        gb1[hid] = G1[:, pad]
-        Gb = wgrad(dfe, 64, 0, sv["v"], 144, -1)
-        gbasis = []
-        for g in range(2):
-            gb = torch.zeros(model.app_dim, 144, device=dev)
-            gb[ix["f_rows"][:, None], vmap[None, :]] = Gb[32 * g: 32 * g + 32, :144][ix["f_sel"]]
-            gbasis.append(gb)
-        grads = g_dens + g_app + gbasis + [gw1, gb1, gw2, gb2, gw3, gb3]
+        wgrad("G3", do, 3, 0, sv["h2"], 128, 128)
+        wgrad("G2", dh2, 128, 2, sv["h1"], 128, 128, dh_scale[0])
+        wgrad("G1", dh1, 128, 2, sv["x"], 160, pad, dh_scale[1])
+        wgrad("Gb", dfe, 64, 0, sv["v"], 144, -1)
+        wg = [t.view(shp) for t, shp in zip(Gall.view(-1).index_select(0, gidx).split(gsizes), gshapes)]
+        grads = g_dens + g_app + wg  # wg: basis yin, basis yang, w1, b1, w2, b2, w3, b3 (differentiable_params order)
         if sv["env"] is not None:
             g_em = torch.zeros_like(model.envmap.emission)
             rays = sv["rays"]

@@ -183,6 +183,9 @@ int ego_sample_pdf_merge(const float* z, const float* weight, const float* u, in
 int ego_envmap_radiance(const ego_scene* sc, const float* dirs, int64_t N, float* out, void* stream);
 /* 2x average pooling of one channel-last plane [H][W][C] -> [H/2][W/2][C] (W==1: line [H][C] -> [H/2][C]) */
 int ego_avgpool_table(const float* src, int32_t H, int32_t W, int32_t C, float* dst, void* stream);
+/* the same for all 12 tables of a field in one launch (EgoNeRF.py:124-133 update_coarse_sigma_grid, called after every training
+ * step when resampling): dst->res must be src->res / 2 per axis, dst's tables allocated by the caller */
+int ego_avgpool_field(const ego_vm_field* src, const ego_vm_field* dst, void* stream);
 /* 8-tap occupancy lookup of YinYangAlphaGridMask.sample_alpha (models/EgoNeRF.py:19-24): c7n [M][7] -> out [M] (the
  * trilinear mask value; > 0 means occupied). */
 int ego_alpha_mask_sample(const ego_scene* sc, const float* c7n, int64_t M, float* out, void* stream);
@@ -274,7 +277,8 @@ int ego_march_backward(const ego_scene* sc, const float* z, const float* alpha, 
  * 8 (2 s + e / 4) + 4 h + e % 4 (the column numbering of the forward's dumps), value = half * dh_scale[row][m] with dh_scale
  * [2][ceil(M / 32) * 32] per-sample powers of two (row 0: dh2, row 1: dh1) chosen so that a sample's largest magnitude lies in
  * [2^12, 2^13): 11 significant bits, rounded to nearest, half the bytes of fp32 (ego_weight_grad's a_layout 2 reads it).  dv is
- * [tile][plane * 3 + line][sample][16 channels] fp32; all need ceil(M / 32) * 32 rows.  Reads fwd->x and fwd->relu_bits only. */
+ * [tile][plane * 3 + line][sample][16 channels] fp32 (it feeds single table texels, where fp16 rounding would show); all three
+ * need ceil(M / 32) * 32 rows.  Reads fwd->x and fwd->relu_bits only. */
 int ego_shade_backward(const ego_scene* sc, const float* train_packed, const float* coords, float* dc, const float* rgb,
                        const ego_shade_dump* fwd, uint16_t* dh2, uint16_t* dh1, float* dh_scale, float* dfe, float* dv, int64_t N,
                        int32_t S, void* stream);
