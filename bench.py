@@ -69,6 +69,7 @@ def parse():
     ap.add_argument("--no-secondary", action="store_true", help="render: skip the short train / erp runs that the default line carries as `secondary`")
     ap.add_argument("--cpu-rays", type=int, default=1024, help="rays in the single-process CPU-baseline sample")
     ap.add_argument("--train-reg", action="store_true", help="train: add the Ricoh configs' TV / L1 / ortho / entropy terms")
+    ap.add_argument("--train-eager", action="store_true", help="train: time the eager Python loop instead of the replayed hipGraph of the iteration")
     ap.add_argument("--views", type=int, default=None, help="erp: images per step sequence (default = --steps)")
     ap.add_argument("--erp-size", type=int, nargs=2, default=[1024, 2048], metavar=("H", "W"))
     ap.add_argument("--mask", action="store_true", help="erp: build the reference's alpha mask and apply it (TensorBase.forward semantics)")
@@ -593,7 +594,9 @@ def run_train(a, rk: Ranks):
     model.train()
     rays = torch.from_numpy(synth.make_rays(N, seed=1 + rk.rank)).to(dev)
     gt = torch.from_numpy(synth.hash_uniform(3 + rk.rank, 0, N * 3).reshape(N, 3).astype(np.float32)).to(dev)
-    opt = FusedAdam(model.get_optparam_groups(0.02, 1e-3), betas=(0.9, 0.99))  # train.py:176-186
+    # train.py:176-186; lr_factor = lr_decay_target_ratio ** (1 / n_iters) (train.py:171-174 with opt.py's 0.1 / 30000); the step count
+    # and the decay live on the device so that the whole iteration can be captured (egonerf_amd.train.GraphedTrainStep)
+    opt = FusedAdam(model.get_optparam_groups(0.02, 1e-3), betas=(0.9, 0.99), capturable=True, lr_factor=0.1 ** (1 / 30000))
     tv = TVLoss()
     kw = dict(is_train=True, n_coarse=TRAIN_NC, n_fine=TRAIN_NF, exp_sampling=True, resampling=True, use_coarse_sample=True)
     losses = []
@@ -614,7 +617,21 @@ def run_train(a, rk: Ranks):
         model.update_coarse_sigma_grid()  # every step when resampling (train.py:356-357)
         losses.append(loss.detach())
 
-    dt = timed(rk, step, a.steps, a.warmup)
+    # The measured step: the same iteration captured once as a hipGraph and replayed (eager Python queues ~150 launches per
+    # iteration and leaves the device ~0.5 ms of gaps between small kernels); the eager loop is timed next to it.  With the
+    # regularisers on (--train-reg) the eager loop is the measured one.
+    graphed = None
+    if not a.train_reg and not a.train_eager:
+        graphed = ego_train.GraphedTrainStep(model, opt, rays, gt, {k: v for k, v in kw.items() if k != "is_train"}, warmup=2)
+        # the step gets faster as the fit proceeds (the scatters skip zero gradients), so the eager loop is timed before AND after
+        # the replays and the two are averaged
+        losses.append(graphed(rays, gt).clone())
+        dt_eager = timed(rk, step, a.steps, 1)
+        dt = timed(rk, lambda: graphed(rays, gt), a.steps, a.warmup)
+        losses.append(graphed.loss.clone())
+        dt_eager = 0.5 * (dt_eager + timed(rk, step, a.steps, 1))
+    else:
+        dt = dt_eager = timed(rk, step, a.steps, a.warmup)
     if rk.rank != 0:
         return None
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
@@ -694,7 +711,9 @@ def run_train(a, rk: Ranks):
                                      " (BASELINE configs[3])",
                             rays_per_step_per_gpu=N, parallelism="independent replicas" if rk.world > 1 else "1 GPU"),
                 phases_ms=dict(forward=ev[0].elapsed_time(ev[1]), backward=ev[1].elapsed_time(ev[2]), adam_and_refresh=ev[2].elapsed_time(ev[3])),
-                loss_first=float(losses[a.warmup]), loss_last=float(losses[-1]), peak_mem_GB=torch.cuda.max_memory_allocated() / 2 ** 30,
+                step_mode="hipGraph replay of the captured iteration" if graphed is not None else "eager",
+                eager_ms_per_step=dt_eager / a.steps * 1e3,
+                loss_first=float(losses[0]), loss_last=float(losses[-1]), peak_mem_GB=torch.cuda.max_memory_allocated() / 2 ** 30,
                 roofline=roofline, cpu_baseline=cpu,
                 speedup_vs_cpu=None if not cpu or "value" not in cpu else rays_per_s / cpu["value"])
 

@@ -117,6 +117,7 @@ PROTOTYPES = {
     "ego_ray_entropy": (C.c_int, [P, I64, I32, I32, P, P, P]),
     "ego_resample_table": (C.c_int, [P, I32, I32, I32, P, P, I32, I32, P, P]),
     "ego_adam_step": (C.c_int, [C.POINTER(AdamTensor), I32, F32, F32, F32, I32, P]),
+    "ego_adam_step_graph": (C.c_int, [C.POINTER(AdamTensor), I32, F32, F32, F32, C.c_double, P, P]),
     "ego_rgb_ssim": (C.c_int, [P, P, I32, I32, C.c_double, I32, C.c_double, C.c_double, C.c_double, P, P, P]),
     "ego_render_workspace_bytes": (I64, [I64, C.POINTER(RenderArgs)]),
     "ego_render_forward": (C.c_int, [SP, C.POINTER(RenderArgs), P, I64, P, P, P, P, P, P, P]),

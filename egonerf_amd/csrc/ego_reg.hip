@@ -147,7 +147,18 @@ struct AdamBatch {
   float step_size[ADAM_MAX];     // lr / (1 - beta1^t)
   int32_t count;
   float beta1, beta2, eps, bc2_sqrt;
+  const double* clock;           // optional device clock (ego_adam_step_graph): [2] = lr scale / (1 - beta1^t), [3] = sqrt(1 - beta2^t)
 };
+
+// The step count and the learning-rate scale live on the device, so that a captured hipGraph of the training step advances them
+// by itself: clock = {t, lr scale, lr scale / (1 - beta1^t), sqrt(1 - beta2^t)}.  One thread, double precision like the host path.
+__global__ void k_adam_clock(double* clock, double beta1, double beta2, double lr_factor) {
+  const double t = clock[0] + 1.0;
+  clock[0] = t;
+  clock[2] = clock[1] / (1.0 - pow(beta1, t));
+  clock[3] = sqrt(1.0 - pow(beta2, t));
+  clock[1] *= lr_factor;   // train.py:328-329: the decay follows the step
+}
 
 __global__ __launch_bounds__(256) void k_adam(AdamBatch B) {
   int t = 0;
@@ -158,7 +169,8 @@ __global__ __launch_bounds__(256) void k_adam(AdamBatch B) {
   float* __restrict__ m = B.m[t];
   float* __restrict__ v = B.v[t];
   const int64_t n = B.n[t];
-  const float ss = B.step_size[t];
+  const float ss = B.clock ? (float)((double)B.step_size[t] * B.clock[2]) : B.step_size[t];
+  const float bc2_sqrt = B.clock ? (float)B.clock[3] : B.bc2_sqrt;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const int64_t i = base + k * 256 + threadIdx.x;
@@ -168,7 +180,7 @@ __global__ __launch_bounds__(256) void k_adam(AdamBatch B) {
     const float vi = v[i] * B.beta2 + (1.f - B.beta2) * gi * gi;     // exp_avg_sq.mul_(beta2).addcmul_(g, g, 1 - beta2)
     m[i] = mi;
     v[i] = vi;
-    const float denom = sqrtf(vi) / B.bc2_sqrt + B.eps;
+    const float denom = sqrtf(vi) / bc2_sqrt + B.eps;
     p[i] = p[i] - ss * (mi / denom);
   }
 }
@@ -222,15 +234,12 @@ int ego_resample_table(const float* src, int32_t C, int32_t H, int32_t W, const 
   return ego_launch_status("k_resample_table");
 }
 
-int ego_adam_step(const ego_adam_tensor* tensors, int32_t count, float beta1, float beta2, float eps, int32_t step, void* stream) {
-  EGO_REQUIRE(count >= 0 && step >= 1, "adam_step: bad count / step (steps count from 1)");
-  if (count == 0) return EGO_OK;
-  EGO_REQUIRE(tensors, "adam_step: null argument");
-  const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+static int adam_launch(const ego_adam_tensor* tensors, int32_t count, float beta1, float beta2, float eps, double bc1, double bc2,
+                       const double* clock, void* stream) {
   for (int first = 0; first < count; first += ADAM_MAX) {
     AdamBatch b{};
     b.count = count - first < ADAM_MAX ? count - first : ADAM_MAX;
-    b.beta1 = beta1; b.beta2 = beta2; b.eps = eps; b.bc2_sqrt = (float)sqrt(bc2);
+    b.beta1 = beta1; b.beta2 = beta2; b.eps = eps; b.bc2_sqrt = (float)sqrt(bc2); b.clock = clock;
     int blocks = 0;
     for (int i = 0; i < b.count; ++i) {
       const ego_adam_tensor& t = tensors[first + i];
@@ -246,6 +255,23 @@ int ego_adam_step(const ego_adam_tensor* tensors, int32_t count, float beta1, fl
     if (int e = ego_launch_status("k_adam")) return e;
   }
   return EGO_OK;
+}
+
+int ego_adam_step(const ego_adam_tensor* tensors, int32_t count, float beta1, float beta2, float eps, int32_t step, void* stream) {
+  EGO_REQUIRE(count >= 0 && step >= 1, "adam_step: bad count / step (steps count from 1)");
+  if (count == 0) return EGO_OK;
+  EGO_REQUIRE(tensors, "adam_step: null argument");
+  return adam_launch(tensors, count, beta1, beta2, eps, 1.0 - pow((double)beta1, (double)step), 1.0 - pow((double)beta2, (double)step), nullptr, stream);
+}
+
+int ego_adam_step_graph(const ego_adam_tensor* tensors, int32_t count, float beta1, float beta2, float eps, double lr_factor, double* clock,
+                        void* stream) {
+  EGO_REQUIRE(count >= 0 && lr_factor > 0.0, "adam_step_graph: bad count / lr_factor");
+  if (count == 0) return EGO_OK;
+  EGO_REQUIRE(tensors && clock, "adam_step_graph: null argument");
+  k_adam_clock<<<1, 1, 0, (hipStream_t)stream>>>(clock, (double)beta1, (double)beta2, lr_factor);
+  if (int e = ego_launch_status("k_adam_clock")) return e;
+  return adam_launch(tensors, count, beta1, beta2, eps, 1.0, 0.0, clock, stream);
 }
 
 }  // extern "C"

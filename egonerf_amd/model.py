@@ -480,16 +480,23 @@ class EgoNeRF(TensorBase):
         for *_k, src in srcs:
             _require_cuda(src, "update_coarse_sigma_grid")
         shapes = [(src.shape[1], src.shape[2] // 2, 1 if src.shape[3] == 1 else src.shape[3] // 2) for *_k, src in srcs]
-        dsts = _carve_channel_last(shapes, srcs[0][3].device)   # one buffer: compact addressing like the full tables
-        for (g, what, i, src), dst in zip(srcs, dsts):
-            getattr(self, f"coarse_sigma_{what}_{g}")[i] = dst
+        # The pooled tables are refreshed IN PLACE while their shapes stand (every training step, train.py:356-357): no allocation
+        # per step, the scene struct stays valid, and a captured hipGraph of the iteration reads on replay k + 1 what replay k wrote
+        # (freshly allocated tables would be invisible to the already captured forward).
+        cur = [getattr(self, f"coarse_sigma_{what}_{g}")[i] for (g, what, i, _src) in srcs]
+        same = all(c is not None and c.device == src.device and tuple(c.shape) == (1, C_, H, W)
+                   for c, (C_, H, W), (*_k, src) in zip(cur, shapes, srcs))
+        if not same:
+            dsts = _carve_channel_last(shapes, srcs[0][3].device)   # one buffer: compact addressing like the full tables
+            for (g, what, i, src), dst in zip(srcs, dsts):
+                getattr(self, f"coarse_sigma_{what}_{g}")[i] = dst
+            self._scene_cache = None
         # all 12 tables in one launch (this runs after every training step, train.py:356-357)
         fs, fd = _lib.VmField(), _lib.VmField()
         res = [int(v) for v in self.gridSize.tolist()]
         self._fill_field(fs, "density", self.density_n_comp, res)
         self._fill_field(fd, "density", self.density_n_comp, [r // 2 for r in res], coarse=True)
         _call("ego_avgpool_field", C.byref(fs), C.byref(fd), st)
-        self._scene_cache = None
 
     @property
     def is_tuned_shape(self) -> bool:

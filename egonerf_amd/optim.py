@@ -9,10 +9,20 @@ from . import _lib
 
 
 class FusedAdam(torch.optim.Optimizer):
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+    """`capturable=True` keeps the step count and the learning-rate schedule on the device (`ego_adam_step_graph`): every step()
+    then uses `group["lr"] * scale` with `scale *= lr_factor` afterwards — train.py:328-329's per-step decay done by the kernel
+    itself — so that a hipGraph capture of the whole training step (egonerf_amd.train.GraphedTrainStep) can be replayed.
+    `group["lr"]` are then the BASE rates; `lr_scale()` reads the current scale back (a device synchronisation: for logging)."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, capturable=False, lr_factor=1.0):
         if not 0.0 <= betas[0] < 1.0 or not 0.0 <= betas[1] < 1.0 or eps <= 0:
             raise ValueError("FusedAdam: bad betas / eps")
         super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps))
+        self.capturable, self.lr_factor = bool(capturable), float(lr_factor)
+        self._clock = None  # device double[4]: step count, lr scale, two derived coefficients
+
+    def lr_scale(self) -> float:
+        return 1.0 if self._clock is None else float(self._clock[1])
 
     @torch.no_grad()
     @_lib.device_guard
@@ -47,6 +57,17 @@ class FusedAdam(torch.optim.Optimizer):
                                     float(group["lr"]), 0)
                 batches.setdefault((float(b1), float(b2), float(group["eps"]), state["step"]), []).append(t)
                 torch.autograd.graph.increment_version(p)  # written through a raw pointer: keep autograd / caches honest
+        if self.capturable and batches:
+            if len({k[:3] for k in batches}) != 1:
+                raise NotImplementedError("FusedAdam(capturable=True): one (betas, eps) setting for all groups (true for train.py:176-186)")
+            ts = [t for group in batches.values() for t in group]
+            (b1, b2, eps, _step) = next(iter(batches))
+            if self._clock is None:
+                dev = next(p for g in self.param_groups for p in g["params"]).device
+                self._clock = torch.tensor([0.0, 1.0, 0.0, 0.0], dtype=torch.float64, device=dev)
+            arr = (_lib.AdamTensor * len(ts))(*ts)
+            _lib.check(lib.ego_adam_step_graph(arr, len(ts), b1, b2, eps, self.lr_factor, self._clock.data_ptr(), st), "ego_adam_step_graph")
+            return loss
         for (b1, b2, eps, step), ts in batches.items():
             arr = (_lib.AdamTensor * len(ts))(*ts)
             _lib.check(lib.ego_adam_step(arr, len(ts), b1, b2, eps, step, st), "ego_adam_step")

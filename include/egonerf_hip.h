@@ -332,6 +332,12 @@ typedef struct ego_adam_tensor {
   int32_t reserved;
 } ego_adam_tensor;
 int ego_adam_step(const ego_adam_tensor* tensors, int32_t count, float beta1, float beta2, float eps, int32_t step, void* stream);
+/* The same update with the step count and the learning-rate schedule ON THE DEVICE, so that a hipGraph capture of the whole
+ * training step (forward + backward + this + ego_avgpool_field) can be replayed: clock = device double[4] {t, lr scale, scratch,
+ * scratch}, initialised by the caller to {0, 1, 0, 0}.  Every call does t += 1, uses lr_i * scale / (1 - beta1^t) and
+ * sqrt(1 - beta2^t), then scale *= lr_factor (train.py:328-329 multiplies every group's lr by lr_factor after each step). */
+int ego_adam_step_graph(const ego_adam_tensor* tensors, int32_t count, float beta1, float beta2, float eps, double lr_factor,
+                        double* clock, void* stream);
 
 /* utils.py:104-152 rgb_ssim (renderer.py:160) on device images [H][W][3]: 'valid' separable Gaussian window in float64 over
  * float32 inputs.  sum (device double, may be NULL) accumulates the sum of the SSIM map — the caller divides by

@@ -1,0 +1,95 @@
+"""GPU: the training iteration as a replayed hipGraph (egonerf_amd.train.GraphedTrainStep) against the eager loop body of
+train.py:245-330, and the device-clock Adam (`FusedAdam(capturable=True)`, ego_adam_step_graph) against torch.optim.Adam with
+the reference's per-step learning-rate decay."""
+import numpy as np
+import pytest
+import torch
+
+from egonerf_amd import synth
+from egonerf_amd.optim import FusedAdam
+from egonerf_amd.train import GraphedTrainStep
+from tests.helpers import make_model
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+KW = dict(n_coarse=16, n_fine=16, exp_sampling=True, resampling=True, use_coarse_sample=True)
+
+
+def test_device_clock_adam_matches_torch_adam_with_lr_decay():
+    g = torch.Generator().manual_seed(5)
+    shapes = [(1, 16, 10, 12), (27, 144), (128,), (1025,)]
+    cpu = [torch.randn(*s, generator=g).requires_grad_(True) for s in shapes]
+    dev = [t.detach().to(DEV).requires_grad_(True) for t in cpu]
+    groups = lambda ps: [dict(params=ps[:1], lr=0.02), dict(params=ps[1:], lr=1e-3)]
+    factor = 0.977
+    o_ref = torch.optim.Adam(groups(cpu), betas=(0.9, 0.99))
+    o_dev = FusedAdam(groups(dev), betas=(0.9, 0.99), capturable=True, lr_factor=factor)
+    for it in range(8):
+        for a, b in zip(cpu, dev):
+            a.grad = torch.randn(a.shape, generator=g) * (10.0 ** -(it % 3))
+            b.grad = a.grad.to(DEV)
+        o_ref.step(), o_dev.step()
+        for grp in o_ref.param_groups:
+            grp["lr"] *= factor  # train.py:328-329; the capturable optimiser does this on the device
+        for a, b in zip(cpu, dev):
+            assert float((a.detach() - b.detach().cpu()).abs().max()) <= 2e-6, (it, a.shape)
+    assert abs(o_dev.lr_scale() - factor ** 8) <= 1e-12
+    assert [grp["lr"] for grp in o_dev.param_groups] == [0.02, 1e-3]  # base rates stay
+
+
+def _setup(seed):
+    cfg = synth.SceneConfig(n_voxel=20 ** 3)
+    model = make_model(cfg, synth.make_weights(cfg, seed=seed), DEV)
+    model.train()
+    model.update_coarse_sigma_grid()
+    return cfg, model
+
+
+def test_graphed_step_equals_eager_loop_body():
+    """Six iterations on changing ray batches with pinned is_train noise: replayed graph vs the eager loop (same kernels; the table
+    scatters use float atomics, so parameters agree to rounding, not bit for bit)."""
+    N, factor = 192, 0.9
+    batches = [(torch.from_numpy(synth.make_rays(N, seed=40 + i)).to(DEV),
+                torch.from_numpy(synth.hash_uniform(70 + i, 0, N * 3).reshape(N, 3).astype(np.float32)).to(DEV)) for i in range(6)]
+    jit = torch.from_numpy(synth.hash_uniform(9, 0, N * 16).reshape(N, 16).astype(np.float32)).to(DEV)
+    noise = lambda n, m, dev: jit
+    # eager reference
+    _, m_ref = _setup(3)
+    o_ref = FusedAdam(m_ref.get_optparam_groups(0.02, 1e-3), betas=(0.9, 0.99))
+    ref_losses = []
+    for rays, gt in batches:
+        rgb, *_ = m_ref(rays, is_train=True, jitter=jit, u=jit, **KW)
+        loss = torch.mean((rgb - gt) ** 2)
+        o_ref.zero_grad(set_to_none=True)
+        loss.backward()
+        o_ref.step()
+        for grp in o_ref.param_groups:
+            grp["lr"] *= factor
+        m_ref.update_coarse_sigma_grid()
+        ref_losses.append(float(loss))
+    # graphed: the constructor trains on batch 0 (warmup = 1), the replays take batches 1..5
+    _, m_g = _setup(3)
+    o_g = FusedAdam(m_g.get_optparam_groups(0.02, 1e-3), betas=(0.9, 0.99), capturable=True, lr_factor=factor)
+    step = GraphedTrainStep(m_g, o_g, batches[0][0], batches[0][1], KW, warmup=1, noise_fn=noise)
+    got = [float(step(rays, gt)) for rays, gt in batches[1:]]
+    assert step.iterations == 6
+    for a, b in zip(ref_losses[1:], got):
+        assert abs(a - b) <= 2e-5 * max(abs(a), 1e-3), (ref_losses, got)
+    pr, pg = dict(m_ref.named_parameters()), dict(m_g.named_parameters())
+    for k in pr:
+        d = float((pr[k].detach() - pg[k].detach()).abs().max())
+        assert d <= 2e-4 * max(float(pr[k].detach().abs().max()), 1e-3), (k, d)
+    # an eager render after the replays sees the CURRENT weights (the packed-weight cache follows the version bump)
+    m_ref.eval(); m_g.eval()
+    with torch.no_grad():
+        a = m_ref(batches[0][0], n_coarse=32, exp_sampling=True)[0]
+        b = m_g(batches[0][0], n_coarse=32, exp_sampling=True)[0]
+    assert float((a - b).abs().max()) <= 1e-4
+
+
+def test_graphed_step_needs_the_capturable_optimiser():
+    _, model = _setup(4)
+    opt = FusedAdam(model.get_optparam_groups(0.02, 1e-3), betas=(0.9, 0.99))
+    rays = torch.from_numpy(synth.make_rays(64, seed=1)).to(DEV)
+    with pytest.raises(ValueError, match="capturable"):
+        GraphedTrainStep(model, opt, rays, torch.zeros(64, 3, device=DEV), KW)

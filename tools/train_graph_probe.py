@@ -35,22 +35,16 @@ def timeit(fn, k=20, ramp=0.3):
     t_host = time.perf_counter() - t0
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / k, t_host / k * 1e3
-out = {}
-out["eager_ms"], out["eager_host_ms"] = timeit(step)
-s = torch.cuda.Stream()
-s.wait_stream(torch.cuda.current_stream())
-with torch.cuda.stream(s):
-    for _ in range(3): step()
-torch.cuda.current_stream().wait_stream(s)
-torch.cuda.synchronize()
-try:
-    g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
-        static_loss = step()
-    torch.cuda.synchronize()
-    out["graph_ms"], out["graph_host_ms"] = timeit(g.replay)
-    out["loss_after"] = float(static_loss)
-except Exception as e:
-    out["graph_error"] = repr(e)[:600]
-out["eager_again_ms"], _ = timeit(step)
+from egonerf_amd.train import GraphedTrainStep
+out = {"eager_ms": [], "graph_ms": [], "eager_host_ms": [], "graph_host_ms": []}
+a, b = timeit(step)
+out["eager_ms"].append(round(a, 4)); out["eager_host_ms"].append(round(b, 4))
+opt2 = FusedAdam(model.get_optparam_groups(0.02, 1e-3), betas=(0.9, 0.99), capturable=True, lr_factor=0.1 ** (1 / 30000))
+graphed = GraphedTrainStep(model, opt2, rays, gt, {k: v for k, v in kw.items() if k != "is_train"}, warmup=2)
+for rep in range(3):   # alternate on one box: graph replay / eager
+    a, b = timeit(lambda: graphed(rays, gt))
+    out["graph_ms"].append(round(a, 4)); out["graph_host_ms"].append(round(b, 4))
+    a, b = timeit(step)
+    out["eager_ms"].append(round(a, 4)); out["eager_host_ms"].append(round(b, 4))
+out["loss"] = float(graphed.loss)
 print(json.dumps(out))
