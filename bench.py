@@ -451,13 +451,16 @@ def run_render(a, rk: Ranks):
         with torch.no_grad():
             for _ in range(10):
                 model(rays, **kw)
-            s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            s0.record()
-            for _ in range(50):
-                model(rays, **kw)
-            s1.record()
-            torch.cuda.synchronize()
-        step_ms = s0.elapsed_time(s1) / 50
+            groups = []   # median of five groups of ten: one hiccup (a 1.7 ms outlier was seen once) must not become the figure
+            for _ in range(5):
+                s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s0.record()
+                for _ in range(10):
+                    model(rays, **kw)
+                s1.record()
+                torch.cuda.synchronize()
+                groups.append(s0.elapsed_time(s1) / 10)
+        step_ms = float(np.median(groups))
         return dict(shade_ms=shade_ms, ms_per_step=step_ms, rays_per_s=N_RAYS / (step_ms * 1e-3))
 
     variants = {"f16x3": ("f16x3", False), "f16f8": ("f16f8", False), "app_f16+f16f8": ("f16f8", True)}
