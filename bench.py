@@ -621,11 +621,21 @@ def run_train(a, rk: Ranks):
         losses.append(loss.detach())
 
     # The measured step: the same iteration captured once as a hipGraph and replayed (eager Python queues ~150 launches per
-    # iteration and leaves the device ~0.5 ms of gaps between small kernels); the eager loop is timed next to it.  With the
-    # regularisers on (--train-reg) the eager loop is the measured one.
-    graphed = None
-    if not a.train_reg and not a.train_eager:
-        graphed = ego_train.GraphedTrainStep(model, opt, rays, gt, {k: v for k, v in kw.items() if k != "is_train"}, warmup=2)
+    # iteration and leaves the device gaps between small kernels); the eager loop is timed next to it (--train-eager: only it).
+    graphed, graph_error = None, None
+    if not a.train_eager:
+        def loss_fn(rgb, tgt, alpha):
+            loss = torch.mean((rgb - tgt) ** 2)
+            if a.train_reg:
+                loss = loss + 1e-4 * model.vector_comp_diffs() + 8e-5 * model.density_L1() + 0.1 * model.TV_loss_density(tv) \
+                    + 0.01 * model.TV_loss_app(tv) + 1e-3 * ray_entropy_loss(alpha)
+            return loss
+        try:
+            graphed = ego_train.GraphedTrainStep(model, opt, rays, gt, {k: v for k, v in kw.items() if k != "is_train"}, loss_fn=loss_fn, warmup=2)
+        except Exception as e:  # a capture problem must not cost the configuration its number: fall back to the eager loop, say so
+            graphed, graph_error = None, repr(e)[:400]
+            torch.cuda.synchronize()
+    if graphed is not None:
         # the step gets faster as the fit proceeds (the scatters skip zero gradients), so the eager loop is timed before AND after
         # the replays and the two are averaged
         losses.append(graphed(rays, gt).clone())
@@ -714,7 +724,7 @@ def run_train(a, rk: Ranks):
                                      " (BASELINE configs[3])",
                             rays_per_step_per_gpu=N, parallelism="independent replicas" if rk.world > 1 else "1 GPU"),
                 phases_ms=dict(forward=ev[0].elapsed_time(ev[1]), backward=ev[1].elapsed_time(ev[2]), adam_and_refresh=ev[2].elapsed_time(ev[3])),
-                step_mode="hipGraph replay of the captured iteration" if graphed is not None else "eager",
+                step_mode="hipGraph replay of the captured iteration" if graphed is not None else ("eager" if graph_error is None else "eager (graph capture failed: " + graph_error + ")"),
                 eager_ms_per_step=dt_eager / a.steps * 1e3,
                 loss_first=float(losses[0]), loss_last=float(losses[-1]), peak_mem_GB=torch.cuda.max_memory_allocated() / 2 ** 30,
                 roofline=roofline, cpu_baseline=cpu,

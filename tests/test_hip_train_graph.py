@@ -37,8 +37,8 @@ def test_device_clock_adam_matches_torch_adam_with_lr_decay():
     assert [grp["lr"] for grp in o_dev.param_groups] == [0.02, 1e-3]  # base rates stay
 
 
-def _setup(seed):
-    cfg = synth.SceneConfig(n_voxel=20 ** 3)
+def _setup(seed, **cfg_kw):
+    cfg = synth.SceneConfig(n_voxel=20 ** 3, **cfg_kw)
     model = make_model(cfg, synth.make_weights(cfg, seed=seed), DEV)
     model.train()
     model.update_coarse_sigma_grid()
@@ -66,7 +66,7 @@ def test_graphed_step_equals_eager_loop_body():
         for grp in o_ref.param_groups:
             grp["lr"] *= factor
         m_ref.update_coarse_sigma_grid()
-        ref_losses.append(float(loss))
+        ref_losses.append(float(loss.detach()))
     # graphed: the constructor trains on batch 0 (warmup = 1), the replays take batches 1..5
     _, m_g = _setup(3)
     o_g = FusedAdam(m_g.get_optparam_groups(0.02, 1e-3), betas=(0.9, 0.99), capturable=True, lr_factor=factor)
@@ -85,6 +85,46 @@ def test_graphed_step_equals_eager_loop_body():
         a = m_ref(batches[0][0], n_coarse=32, exp_sampling=True)[0]
         b = m_g(batches[0][0], n_coarse=32, exp_sampling=True)[0]
     assert float((a - b).abs().max()) <= 1e-4
+
+
+def test_graphed_step_with_envmap_and_regularisers():
+    """The Ricoh-style iteration (configs/EgoNeRF/ricoh/common.txt:12-13 + opt.py defaults): envmap parameter, TV / L1 / ortho /
+    ray-entropy terms inside the captured loss - every one of those nodes is asynchronous, so the capture must take them."""
+    from egonerf_amd.losses import TVLoss, ray_entropy_loss
+    N, factor = 128, 0.95
+    tv = TVLoss()
+    batches = [(torch.from_numpy(synth.make_rays(N, seed=50 + i)).to(DEV),
+                torch.from_numpy(synth.hash_uniform(90 + i, 0, N * 3).reshape(N, 3).astype(np.float32)).to(DEV)) for i in range(4)]
+    jit = torch.from_numpy(synth.hash_uniform(19, 0, N * 16).reshape(N, 16).astype(np.float32)).to(DEV)
+
+    def make():
+        _, m = _setup(6, use_envmap=True, envmap_res_H=16)
+        loss_fn = lambda rgb, gt, alpha: (torch.mean((rgb - gt) ** 2) + 1e-4 * m.vector_comp_diffs() + 8e-5 * m.density_L1()
+                                          + 0.1 * m.TV_loss_density(tv) + 0.01 * m.TV_loss_app(tv) + 1e-3 * ray_entropy_loss(alpha))
+        return m, loss_fn
+
+    m_ref, loss_ref = make()
+    o_ref = FusedAdam(m_ref.get_optparam_groups(0.02, 1e-3, 0.01), betas=(0.9, 0.99))
+    ref_losses = []
+    for rays, gt in batches:
+        rgb, _d, _bg, _env, alpha = m_ref(rays, is_train=True, jitter=jit, u=jit, **KW)
+        loss = loss_ref(rgb, gt, alpha)
+        o_ref.zero_grad(set_to_none=True)
+        loss.backward()
+        o_ref.step()
+        for grp in o_ref.param_groups:
+            grp["lr"] *= factor
+        m_ref.update_coarse_sigma_grid()
+        ref_losses.append(float(loss.detach()))
+    m_g, loss_g = make()
+    o_g = FusedAdam(m_g.get_optparam_groups(0.02, 1e-3, 0.01), betas=(0.9, 0.99), capturable=True, lr_factor=factor)
+    step = GraphedTrainStep(m_g, o_g, batches[0][0], batches[0][1], KW, loss_fn=loss_g, warmup=1, noise_fn=lambda n, m, dev: jit)
+    got = [float(step(rays, gt)) for rays, gt in batches[1:]]
+    for a, b in zip(ref_losses[1:], got):
+        assert abs(a - b) <= 5e-5 * max(abs(a), 1e-3), (ref_losses, got)
+    d = float((m_ref.envmap.emission.detach() - m_g.envmap.emission.detach()).abs().max())
+    assert d <= 2e-4 * max(float(m_ref.envmap.emission.detach().abs().max()), 1e-3)
+    assert float((m_ref.envmap.emission.detach() - make()[0].envmap.emission.detach()).abs().max()) > 0  # the envmap did train
 
 
 def test_graphed_step_needs_the_capturable_optimiser():
