@@ -730,6 +730,136 @@ __global__ __launch_bounds__(256) void k_sample_pdf_merge(const float* __restric
   for (int i = tid; i < n_out; i += 256) z_out[ray * n_out + i] = keys[i];
 }
 
+// The same, one WAVE per ray (four rays per workgroup) for Sc, n_fine <= 256 - every shipped configuration (128 + 128): no
+// workgroup barriers (the workgroup form has ~15 on its path and leaves half of its 256 threads without an item at Sc = 128), four
+// times as many rays in flight per CU.  Same arithmetic in the same order wherever the order is observable: the cdf is the same
+// 64-wide double scan with carry, the inverse CDF and the rank merge are the loops above with a stride of 64.  The one difference is
+// the grouping of the double-precision sum of the pdf normaliser (per-lane partials + butterfly instead of 256 partials + tree):
+// it is rounded to float once, so the two agree unless the double sum lands within 2^-29 ulp of a float rounding boundary.  When the
+// fine samples come out unsorted (random u in training) only THEY are sorted (bitonic in LDS, wave-synchronous) and then merged
+// with the coarse run; equal keys are equal values, so the result is the sort's.
+constexpr int PDFW_MAX = 256;
+__global__ __launch_bounds__(256) void k_sample_pdf_merge_w(const float* __restrict__ z, const float* __restrict__ weight,
+                                                            const float* __restrict__ u_in, int64_t N, int Sc, int n_fine,
+                                                            int use_coarse, float* __restrict__ z_out,
+                                                            float* __restrict__ z_new_out) {
+  __shared__ float s_cdf[4][PDFW_MAX];
+  __shared__ float s_keys[4][2 * PDFW_MAX];
+  __shared__ float s_out[4][2 * PDFW_MAX];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t ray = (int64_t)blockIdx.x * 4 + wv;
+  if (ray >= N) return;
+  float* cdf = s_cdf[wv];
+  float* keys = s_keys[wv];
+  float* outk = s_out[wv];
+  const float* zr = z + ray * Sc;
+  const float* wr = weight + ray * Sc;
+  const int nb = Sc - 1, nw = Sc - 2;
+  const auto wsync = [] {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
+  double part = 0.0;
+  for (int i = lane; i < nw; i += 64) part += (double)__fadd_rn(wr[1 + i], 1e-5f);
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) part += __shfl_xor(part, d, 64);
+  const float total = (float)part;
+  double carry = 0.0;
+  for (int s0 = 0; s0 < nw; s0 += 64) {
+    const int i = s0 + lane;
+    double v = (i < nw) ? (double)__fdiv_rn(__fadd_rn(wr[1 + i], 1e-5f), total) : 0.0;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const double o = __shfl_up(v, d, 64);
+      if (lane >= d) v += o;
+    }
+    if (i < nw) cdf[i + 1] = (float)(carry + v);
+    carry += __shfl(v, 63, 64);
+  }
+  if (lane == 0) cdf[0] = 0.f;
+  wsync();
+  const int n_out = use_coarse ? Sc + n_fine : n_fine;
+  const int base_f = use_coarse ? Sc : 0;
+  for (int j = lane; j < n_fine; j += 64) {
+    float u;
+    if (u_in) u = u_in[ray * n_fine + j];
+    else {
+      const float step = __fdiv_rn(1.f, (float)(n_fine - 1));
+      u = (n_fine == 1) ? 0.f : (j < n_fine / 2 ? __fmul_rn(step, (float)j) : __fsub_rn(1.f, __fmul_rn(step, (float)(n_fine - 1 - j))));
+    }
+    int lo = 0, hi = nb;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (!(cdf[mid] > u)) lo = mid + 1; else hi = mid;
+    }
+    const int below = max(lo - 1, 0), above = min(lo, nb - 1);
+    const float c0 = cdf[below], c1 = cdf[above];
+    const float b0 = 0.5f * __fadd_rn(zr[below + 1], zr[below]);
+    const float b1 = 0.5f * __fadd_rn(zr[above + 1], zr[above]);
+    float den = __fsub_rn(c1, c0);
+    if (den < 1e-5f) den = 1.f;
+    const float t = __fdiv_rn(__fsub_rn(u, c0), den);
+    const float zs = __fadd_rn(b0, __fmul_rn(t, __fsub_rn(b1, b0)));
+    keys[base_f + j] = zs;
+    if (z_new_out) z_new_out[ray * n_fine + j] = zs;
+  }
+  if (use_coarse)
+    for (int i = lane; i < Sc; i += 64) keys[i] = zr[i];
+  wsync();
+  bool inv_f = false, inv_c = false;
+  for (int j = lane; j + 1 < n_fine; j += 64) inv_f |= keys[base_f + j] > keys[base_f + j + 1];
+  if (use_coarse)
+    for (int i = lane; i + 1 < Sc; i += 64) inv_c |= keys[i] > keys[i + 1];
+  const bool any_f = __ballot(inv_f) != 0ull, any_c = __ballot(inv_c) != 0ull;
+  // sort a run of n keys at keys[base ..) in place: bitonic network over the next power of two (padding +inf lives in outk)
+  const auto sort_run = [&](int base, int n) {
+    int P = 1;
+    while (P < n) P <<= 1;
+    float* buf = outk;   // scratch; P <= 2 * PDFW_MAX
+    for (int i = lane; i < P; i += 64) buf[i] = i < n ? keys[base + i] : __int_as_float(0x7f800000);
+    wsync();
+    for (int k = 2; k <= P; k <<= 1)
+      for (int j = k >> 1; j > 0; j >>= 1) {
+        for (int i = lane; i < P; i += 64) {
+          const int l = i ^ j;
+          if (l > i) {
+            const float a = buf[i], b = buf[l];
+            const bool up = (i & k) == 0;
+            if ((a > b) == up) { buf[i] = b; buf[l] = a; }
+          }
+        }
+        wsync();
+      }
+    for (int i = lane; i < n; i += 64) keys[base + i] = buf[i];
+    wsync();
+  };
+  if (any_c) {            // never seen (the coarse schedule is monotone); kept for safety: sort everything
+    sort_run(0, n_out);
+    for (int i = lane; i < n_out; i += 64) z_out[ray * n_out + i] = keys[i];
+    return;
+  }
+  if (any_f) sort_run(base_f, n_fine);
+  if (use_coarse) {
+    for (int i = lane; i < Sc; i += 64) {
+      const float v = keys[i];
+      int lo = 0, hi = n_fine;  // number of fine keys < v
+      while (lo < hi) { const int mid = (lo + hi) >> 1; if (keys[Sc + mid] < v) lo = mid + 1; else hi = mid; }
+      outk[i + lo] = v;
+    }
+    for (int j = lane; j < n_fine; j += 64) {
+      const float v = keys[Sc + j];
+      int lo = 0, hi = Sc;      // number of coarse keys <= v
+      while (lo < hi) { const int mid = (lo + hi) >> 1; if (keys[mid] <= v) lo = mid + 1; else hi = mid; }
+      outk[j + lo] = v;
+    }
+    wsync();
+    for (int i = lane; i < n_out; i += 64) z_out[ray * n_out + i] = outk[i];
+  } else {
+    for (int i = lane; i < n_out; i += 64) z_out[ray * n_out + i] = keys[i];
+  }
+}
+
 // =============================================================================================
 // update_coarse_sigma_grid — 2x average pooling of a channel-last table    models/EgoNeRF.py:124-131
 // =============================================================================================
@@ -912,7 +1042,10 @@ int ego_sample_pdf_merge(const float* z, const float* weight, const float* u, in
   EGO_REQUIRE(z && weight && z_out && N >= 0, "sample_pdf_merge: null argument");
   EGO_REQUIRE(Sc >= 3 && n_fine >= 1 && Sc + n_fine <= PDF_MAX, "sample_pdf_merge: need 3 <= Sc, Sc + n_fine <= 2048");
   if (N == 0) return EGO_OK;
-  k_sample_pdf_merge<<<(unsigned)N, 256, 0, (hipStream_t)stream>>>(z, weight, u, Sc, n_fine, use_coarse, z_out, z_new_out);
+  if (Sc <= PDFW_MAX && n_fine <= PDFW_MAX)   // every shipped configuration: one wave per ray
+    k_sample_pdf_merge_w<<<(unsigned)((N + 3) / 4), 256, 0, (hipStream_t)stream>>>(z, weight, u, N, Sc, n_fine, use_coarse, z_out, z_new_out);
+  else
+    k_sample_pdf_merge<<<(unsigned)N, 256, 0, (hipStream_t)stream>>>(z, weight, u, Sc, n_fine, use_coarse, z_out, z_new_out);
   return ego_launch_status("k_sample_pdf_merge");
 }
 
