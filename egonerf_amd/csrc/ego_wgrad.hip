@@ -46,7 +46,9 @@ __device__ __forceinline__ void split_bf16_pair(float v0, float v1, uint32_t& hi
 // (column quad, sample pair) items: two float4 global loads (fetch, issued a whole step ahead of their use), then eight
 // packed bf16-pair stores (commit).
 // BLK: 0 row-major fp32, 1 tile-blocked fp32, 2 tile-blocked scaled fp16 (ego_shade_backward's dh2 / dh1: [tile][k-step s][lane =
-// 32 h + sample][8 halves], element e = logical column 8 (2 s + e / 4) + 4 h + e % 4, value = half * scale[row]; NB == 4)
+// 32 h + sample][8 halves], element e = logical column 8 (2 s + e / 4) + 4 h + e % 4, value = half * scale[row]; NB == 4),
+// 3 row-major fp32 [M][32] standing for 64 logical columns: row m fills columns [32 g, 32 g + 32) with g = (scale[4 m + 3] != 0),
+// the other 32 are zero (ego_shade_backward's dfe with `scale` = the forward's coords [M][4]; NB == 2)
 template <int NB, bool VEC, int BLK>
 struct Tile {
   static constexpr int QUADS = NB * 8;                       // column quads per row
@@ -58,7 +60,7 @@ struct Tile {
   // rows); tile-blocked source (the shade kernels' dump layout, [tile][quad pair][32 h + j][4]): consecutive lanes take
   // consecutive sample pairs of one quad (512 contiguous bytes per 16 lanes, and conflict-free LDS stores)
   static __device__ __forceinline__ void item(int idx, int& cq, int& sp) {
-    if (BLK) { sp = idx & 15; cq = idx >> 4; } else { cq = idx % QUADS; sp = idx / QUADS; }
+    if (BLK == 1 || BLK == 2) { sp = idx & 15; cq = idx >> 4; } else { cq = idx % QUADS; sp = idx / QUADS; }
   }
 
   __device__ __forceinline__ void fetch(const float* __restrict__ X, const float* __restrict__ scale, int ldx, int cx, int64_t row0, int64_t M) {
@@ -83,7 +85,12 @@ struct Tile {
       const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
       v0[it] = z; v1[it] = z;
       if (idx < 16 * QUADS && 4 * cq < cx) {
-        if (BLK) {  // row0 is a multiple of 32: tile = row0 / 32; logical column quad cq = 2 q + h
+        if (BLK == 3) {
+          static_assert(BLK != 3 || NB == 2, "the grid-routed layout is the 2 x 32-column feature gradient");
+          const float* p = X + r0 * 32 + 4 * (cq & 7);
+          if (r0 < M && (scale[r0 * 4 + 3] != 0.f) == ((cq >> 3) != 0)) v0[it] = *(const f32x4*)p;
+          if (r0 + 1 < M && (scale[(r0 + 1) * 4 + 3] != 0.f) == ((cq >> 3) != 0)) v1[it] = *(const f32x4*)(p + 32);
+        } else if (BLK) {  // row0 is a multiple of 32: tile = row0 / 32; logical column quad cq = 2 q + h
           const float* p = X + row0 * ldx + (cq >> 1) * 256 + ((cq & 1) * 32 + 2 * sp) * 4;
           if (r0 < M) v0[it] = *(const f32x4*)p;
           if (r0 + 1 < M) v1[it] = *(const f32x4*)(p + 4);
@@ -228,13 +235,15 @@ extern "C" {
 
 int ego_weight_grad(const void* A, int32_t lda, int32_t ca, int32_t a_layout, const float* a_scale, const float* B, int32_t ldb, int32_t cb,
                     int32_t b_blocked, int32_t ones_col, int64_t M, float* G, int32_t ldg, void* stream) {
-  EGO_REQUIRE(M >= 0 && ca >= 1 && ca <= 128 && cb >= 1 && cb <= 160 && lda >= ca && ldb >= cb && ones_col < 160,
+  EGO_REQUIRE(a_layout >= 0 && a_layout <= 3, "weight_grad: a_layout must be 0 (row-major), 1 (blocked fp32), 2 (blocked scaled fp16) or 3 (grid-routed)");
+  EGO_REQUIRE(M >= 0 && ca >= 1 && ca <= 128 && cb >= 1 && cb <= 160 && (lda >= ca || a_layout == 3) && ldb >= cb && ones_col < 160,
               "weight_grad: bad size (ca <= 128, cb <= 160)");
-  EGO_REQUIRE(a_layout >= 0 && a_layout <= 2, "weight_grad: a_layout must be 0 (row-major), 1 (blocked fp32) or 2 (blocked scaled fp16)");
   if (M == 0) return EGO_OK;
   EGO_REQUIRE(A && B && G, "weight_grad: null argument");
   EGO_REQUIRE(a_layout != 2 || (a_scale && ca == 128 && lda == 128 && ((uintptr_t)A & 15) == 0),
               "weight_grad: the scaled-fp16 layout needs a_scale, 128 columns and a 16-byte aligned A");
+  EGO_REQUIRE(a_layout != 3 || (a_scale && ca == 64 && lda == 32 && ((uintptr_t)A & 15) == 0),
+              "weight_grad: the grid-routed layout needs a_scale (= coords [M][4]), ca = 64, lda = 32 and a 16-byte aligned A");
   const int cab = (ca + 31) / 32;
   const int cbb = ((ones_col >= cb ? ones_col + 1 : cb) + 31) / 32;
   EGO_REQUIRE(ldg >= 32 * cbb, "weight_grad: ldg must cover the padded column blocks");
@@ -243,13 +252,14 @@ int ego_weight_grad(const void* A, int32_t lda, int32_t ca, int32_t a_layout, co
   WgradArgs a{(const float*)A, a_scale, B, G, M, lda, ca, ldb, cb, ones_col, ldg, 0};
   const hipStream_t st = (hipStream_t)stream;
   // instantiations: the training step's four products (dh2^T h1, dh1^T x: scaled-fp16 A, blocked B; do^T h2: ragged row-major
-  // A, blocked B; dfe^T v: row-major A, blocked B), their all-fp32 blocked forms and the all-row-major forms of the same shapes
+  // A, blocked B; dfe^T v: grid-routed A, blocked B), their all-fp32 forms and the all-row-major forms of the same shapes
   const int key = (cab * 8 + cbb) * 8 + a_layout * 2 + (b_blocked ? 1 : 0);
   switch (key) {
     case (1 * 8 + 5) * 8 + 0: return avec ? launch<1, 5, true, 0, false>(a, st) : launch<1, 5, false, 0, false>(a, st);
     case (1 * 8 + 5) * 8 + 1: return avec ? launch<1, 5, true, 0, true>(a, st) : launch<1, 5, false, 0, true>(a, st);
     case (2 * 8 + 5) * 8 + 0: if (avec) return launch<2, 5, true, 0, false>(a, st); break;
     case (2 * 8 + 5) * 8 + 1: if (avec) return launch<2, 5, true, 0, true>(a, st); break;
+    case (2 * 8 + 5) * 8 + 7: return launch<2, 5, true, 3, true>(a, st);
     case (4 * 8 + 5) * 8 + 0: if (avec) return launch<4, 5, true, 0, false>(a, st); break;
     case (4 * 8 + 5) * 8 + 3: if (avec) return launch<4, 5, true, 1, true>(a, st); break;
     case (4 * 8 + 5) * 8 + 5: return launch<4, 5, true, 2, true>(a, st);

@@ -272,7 +272,7 @@ class RenderFunction(torch.autograd.Function):
         Mp = (M + 31) // 32 * 32
         # dh2 / dh1: scaled fp16 in the kernel's own operand order + one power of two per sample (include/egonerf_hip.h); dv: blocked fp32
         half = lambda *shape: torch.empty(*shape, device=dev, dtype=torch.float16)
-        dh2, dh1, dh_scale, dfe, dv = half(Mp, 128), half(Mp, 128), f(2, Mp), f(M, 64), f(Mp, 144)
+        dh2, dh1, dh_scale, dfe, dv = half(Mp, 128), half(Mp, 128), f(2, Mp), f(M, 32), f(Mp, 144)
         ds = _lib.ShadeDump(*(sv[k].data_ptr() for k in ("x", "h1", "h2", "v", "relu_bits")))
         _chk(lib.ego_shade_backward(sc, tp.data_ptr(), sv["coords"].data_ptr(), dc.data_ptr(), sv["rgb"].data_ptr(), C.byref(ds),
                                           dh2.data_ptr(), dh1.data_ptr(), dh_scale.data_ptr(), dfe.data_ptr(), dv.data_ptr(), N, S, st),
@@ -296,7 +296,7 @@ class RenderFunction(torch.autograd.Function):
         wgrad("G3", do, 3, 0, sv["h2"], 128, 128)
         wgrad("G2", dh2, 128, 2, sv["h1"], 128, 128, dh_scale[0])
         wgrad("G1", dh1, 128, 2, sv["x"], 160, pad, dh_scale[1])
-        wgrad("Gb", dfe, 64, 0, sv["v"], 144, -1)
+        wgrad("Gb", dfe, 64, 3, sv["v"], 144, -1, sv["coords"].view(M, 4))   # 32 stored columns, routed to the yin / yang block by coords.w
         wg = [t.view(shp) for t, shp in zip(Gall.view(-1).index_select(0, gidx).split(gsizes), gshapes)]
         grads = g_dens + g_app + wg  # wg: basis yin, basis yang, w1, b1, w2, b2, w3, b3 (differentiable_params order)
         if sv["env"] is not None:

@@ -271,8 +271,8 @@ int ego_train_layout(int32_t which, int32_t* out, int32_t n);
 int ego_march_backward(const ego_scene* sc, const float* z, const float* alpha, int32_t alpha_stride, const float* weight,
                        const float* sigma, const float* bg_weight, const float* rgb, const float* g_rgb, const float* g_alpha,
                        const float* rgb_raw, const float* env_map, int64_t N, int32_t S, float* dc, float* dfeat, void* stream);
-/* shade backward: dc [N][S][3] in = dL/d rgb_sample, out = dL/d(pre-sigmoid).  Writes dh2, dh1 (logical [M][128]), dfe [M][64]
- * (grid g at [32g..)) and dv = dL/d(plane x line products).  dh2 / dh1 are stored as SCALED fp16 in the order the kernel's own
+/* shade backward: dc [N][S][3] in = dL/d rgb_sample, out = dL/d(pre-sigmoid).  Writes dh2, dh1 (logical [M][128]), dfe [M][32]
+ * (the feature-slot gradients of the sample's OWN grid; ego_weight_grad's a_layout 3 routes them by coords.w) and dv = dL/d(plane x line products).  dh2 / dh1 are stored as SCALED fp16 in the order the kernel's own
  * matrix products consume them: [tile = m / 32][k-step s = 0..7][lane = 32 h + m % 32][8 halves], element e = logical column
  * 8 (2 s + e / 4) + 4 h + e % 4 (the column numbering of the forward's dumps), value = half * dh_scale[row][m] with dh_scale
  * [2][ceil(M / 32) * 32] per-sample powers of two (row 0: dh2, row 1: dh1) chosen so that a sample's largest magnitude lies in
@@ -297,7 +297,9 @@ int ego_envmap_backward(const ego_scene* sc, const float* dirs, int32_t dir_stri
  * used of lda) and fp32 B (M rows, cb <= 160 of ldb), G accumulated (zero it first).  a_layout 0: row-major fp32 | 1: fp32 in the
  * shade kernels' dump layout [tile = m / 32][quad pair q][lane = 32 h + m % 32][4] with logical column 8 q + 4 h + c
  * (ceil(M / 32) * 32 rows allocated) | 2: ego_shade_backward's scaled-fp16 layout (ca = lda = 128, a_scale [M] = that matrix's
- * row of dh_scale; NULL otherwise).  b_blocked: B in the dump layout instead of row-major.  ones_col >= 0 replaces that column
+ * row of dh_scale) | 3: row-major fp32 [M][32] standing for 64 logical columns, row m filling columns [32 g, 32 g + 32) with
+ * g = (a_scale[4 m + 3] != 0) (ego_shade_backward's dfe; ca = 64, lda = 32, a_scale = the forward's coords [M][4]); a_scale NULL for
+ * layouts 0 / 1.  b_blocked: B in the dump layout instead of row-major.  ones_col >= 0 replaces that column
  * of B by ones (it may lie beyond cb, < 160), which yields the bias gradient = column sums of A in G[:, ones_col].  bf16 hi/lo
  * split MFMA, ~17 significand bits per operand. */
 int ego_weight_grad(const void* A, int32_t lda, int32_t ca, int32_t a_layout, const float* a_scale, const float* B, int32_t ldb,

@@ -85,6 +85,27 @@ def test_weight_grad_matches_float64(ca, lda, cb, ones_col, M):
             assert float((Gh[:ca, ones_col] - exact.double().sum(0)).abs().max()) <= 5e-5 * float(bias.abs().max())
 
 
+@pytest.mark.parametrize("M", [1, 33, 4097, 70001])
+def test_weight_grad_grid_routed_layout(M):
+    """a_layout 3 (ego_shade_backward's dfe): A is [M][32], row m stands for 64 logical columns with its 32 values in the block
+    of the sample's grid (coords[m][3] != 0 -> columns 32..63) and zeros in the other."""
+    g = torch.Generator().manual_seed(M)
+    A32 = torch.randn(M, 32, generator=g) * torch.logspace(-9, -2, M).unsqueeze(1)
+    B = torch.randn(M, 144, generator=g)
+    grid = (torch.rand(M, generator=g) > 0.4)
+    coords = torch.rand(M, 4, generator=g)
+    coords[:, 3] = grid.float()
+    A64 = torch.zeros(M, 64)
+    A64[~grid, :32] = A32[~grid]
+    A64[grid, 32:] = A32[grid]
+    ref = A64.double().T @ B.double()
+    G = _run(A32.to(DEV), 64, _blocked(B).to(DEV), 144, -1, a_blocked=3, b_blocked=1, M=M, a_scale=coords.to(DEV)).cpu().double()
+    assert float((G[:64, :144] - ref).abs().max()) <= 5e-5 * float(ref.abs().max())
+    # ... and equals the plain row-major form on the expanded matrix
+    G0 = _run(A64.to(DEV), 64, _blocked(B).to(DEV), 144, -1, a_blocked=0, b_blocked=1, M=M).cpu().double()
+    assert float((G - G0).abs().max()) <= 1e-6 * float(ref.abs().max())
+
+
 def test_weight_grad_accumulates_and_validates():
     A, B = torch.ones(40, 128, device=DEV), torch.ones(40, 128, device=DEV)
     G = _run(A, 128, B, 128, -1)
