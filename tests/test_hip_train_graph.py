@@ -40,12 +40,13 @@ def test_device_clock_adam_matches_torch_adam_with_lr_decay():
 def _same_after_adam(name, a, b, n_steps, lr):
     """Two runs of the same iterations differ by the order of the table scatters' float atomics: gradients agree to rounding,
     but Adam's m / (sqrt(v) + eps) turns the rounding of a gradient element whose contributions nearly cancel into an O(lr)
-    difference of that one element (seen once in ten sessions: 5e-4 on one appearance texel).  So: the tensors agree closely on
-    average and in all but a handful of elements, and no element differs by more than the steps could have moved it."""
+    difference of that one element (seen in two of sixteen sessions: 5e-4 on one appearance texel).  So: the tensors agree closely
+    on average and in all but a handful of elements, and no element differs by more than the steps could have moved it."""
     scale = max(float(a.abs().max()), 1e-3)
     err = (a - b).abs()
     assert float(err.mean()) <= 2e-6 * scale, (name, float(err.mean()))
-    assert float((err > 2e-4 * scale).float().mean()) <= 1e-4, (name, float(err.max()))
+    n_off = int((err > 2e-4 * scale).sum())
+    assert n_off <= 2 + 1e-4 * err.numel(), (name, n_off, float(err.max()))
     assert float(err.max()) <= 2.0 * n_steps * lr, (name, float(err.max()))
 
 
@@ -95,7 +96,9 @@ def test_graphed_step_equals_eager_loop_body():
     with torch.no_grad():
         a = m_ref(batches[0][0], n_coarse=32, exp_sampling=True)[0]
         b = m_g(batches[0][0], n_coarse=32, exp_sampling=True)[0]
-    assert float((a - b).abs().max()) <= 1e-4
+    # (a stale packed blob would be one optimiser step behind: ~1e-2 in the image; an element-level Adam outlier as described in
+    # _same_after_adam moves a pixel by far less)
+    assert float((a - b).abs().max()) <= 1e-3
 
 
 def test_graphed_step_with_envmap_and_regularisers():
