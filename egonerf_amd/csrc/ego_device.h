@@ -196,6 +196,13 @@ __device__ __forceinline__ float relu_f(float x) {
 
 __device__ __forceinline__ float sigmoidf(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+// raw2alpha (tensorBase.py:22-27: alpha = 1 - exp(-sigma * dist)) evaluated as -expm1(-x): the correctly rounded value of the
+// reference's expression.  The literal float32 form loses ~6e-8 ABSOLUTE in the subtraction (6e-6 relative at alpha = 0.01), in the
+// reference as much as here but with a different exp and therefore a different error; the inverse CDF of the resampling pass
+// amplifies exactly those weight errors (steep tiny grids: 1e-4 in RGB from 6e-8 in the coarse weights).  With the accurate form
+// this side contributes nothing, so the distance to the reference is the reference's own rounding error instead of the sum of two.
+__device__ __forceinline__ float alpha_from(float x) { return -expm1f(-x); }
+
 // sin and cos of one argument: Cody-Waite reduction by pi/2 (two FMAs) + Cephes minimax polynomials on
 // [-pi/4, pi/4].  ~1 ulp for |x| < 1e4, branch-free (the libm versions drag a Payne-Hanek slow path
 // into every call site, which matters when 68 of them are inlined between MFMAs).

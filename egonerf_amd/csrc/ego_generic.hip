@@ -319,7 +319,7 @@ __global__ __launch_bounds__(256) void k_march_generic(GenMarchArgs A) {
       }
       sg = A.softplus ? softplus_shift(feat, A.shift) : fmaxf(feat, 0.f);
     }
-    const float a = ok ? __fsub_rn(1.f, expf(-sg * __fmul_rn(dist, A.dscale))) : 0.f;
+    const float a = ok ? alpha_from(sg * __fmul_rn(dist, A.dscale)) : 0.f;
     const float tt = ok ? __fadd_rn(__fsub_rn(1.f, a), 1e-10f) : 1.f;
     const float inc = wave_scan_mul(tt, lane);
     float exc = __shfl_up(inc, 1, 64);

@@ -127,7 +127,7 @@ __global__ void k_raw2alpha(const float* __restrict__ sigma, const float* __rest
   for (int s0 = 0; s0 < S; s0 += 64) {
     const int s = s0 + lane;
     const bool ok = s < S;
-    const float a = ok ? __fsub_rn(1.f, expf(-sigma[ray * S + s] * dist[ray * S + s])) : 0.f;
+    const float a = ok ? alpha_from(sigma[ray * S + s] * dist[ray * S + s]) : 0.f;
     const float t = ok ? __fadd_rn(__fsub_rn(1.f, a), 1e-10f) : 1.f;
     const float inc = wave_scan_mul(t, lane);
     float exc = __shfl_up(inc, 1, 64);
@@ -437,7 +437,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     const float f = fres[wv][lane];
     float sg = 0.f;
     if (occupied) sg = softplus ? softplus_shift(f, shift) : fmaxf(f, 0.f);
-    const float a = ok ? __fsub_rn(1.f, expf(-sg * __fmul_rn(dist, dscale))) : 0.f;
+    const float a = ok ? alpha_from(sg * __fmul_rn(dist, dscale)) : 0.f;
     const float t = ok ? __fadd_rn(__fsub_rn(1.f, a), 1e-10f) : 1.f;
     const float inc = wave_scan_mul(t, lane);
     float exc = __shfl_up(inc, 1, 64);

@@ -167,7 +167,9 @@ int ego_density_feature(const ego_scene* sc, const float* c7n, int64_t M, int32_
 int ego_app_feature(const ego_scene* sc, const float* c7n, int64_t M, float* out, void* stream);
 int ego_feature2density(const ego_scene* sc, const float* feat, int64_t M, float* sigma, void* stream);
 /* sigma, dist [N][S] (dist already multiplied by distance_scale, like the reference call site);
- * alpha, weight [N][S]; bg_weight [N] */
+ * alpha, weight [N][S]; bg_weight [N].  tensorBase.py:22-27.  alpha = 1 - exp(-sigma * dist) is evaluated as -expm1(-sigma * dist),
+ * the correctly rounded value of that expression (the literal float32 form loses ~6e-8 absolute in the subtraction; the fused
+ * march does the same) */
 int ego_raw2alpha(const float* sigma, const float* dist, int64_t N, int32_t S, float* alpha, float* weight,
                   float* bg_weight, void* stream);
 /* viewdirs [M][3], feat [M][app_dim] -> rgb [M][3] */

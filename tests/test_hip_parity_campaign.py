@@ -9,7 +9,10 @@ HIP result is more than 5e-5 from the float32 oracle, the float64 oracle is eval
 from that truth than K = 3 x the float32 oracle is (or within 5e-5 of it; two float32 evaluation orders of an ill-conditioned
 inverse CDF have errors of the same order, not of the same size: the worst ratio seen is 2.4, seed 13 case 6 ray 40).  A ray farther than 1e-4 from the float32 oracle is
 accepted only if the float32 oracle itself is that far from the float64 one (a discontinuity of the reference algorithm decided
-by one rounding: `denom < 1e-5 -> 1`, searchsorted ties, a sample within an ulp of a yin / yang border) and the same K bound holds.
+by one rounding: `denom < 1e-5 -> 1`, searchsorted ties, a sample within an ulp of a yin / yang border) and the same K bound holds,
+or if the HIP result equals the float64 one to a tenth of the tolerance.  (Since alpha is evaluated as -expm1(-sigma * dist) the
+coarse weights carry no cancellation error of their own and the HIP result tracks the float64 oracle to ~1e-6 on such rays: what
+is left against the float32 oracle is that oracle's own rounding.)
 """
 import numpy as np
 import pytest
@@ -48,7 +51,9 @@ def test_campaign_vs_float32_and_float64_oracle(seed, prec):
                 watched += 1
                 ratio = max(ratio, d_hip / max(d_f32, 1e-12)) if d_hip > WATCH else ratio
                 if per_ray[b] > TOL:
-                    assert d_f32 > TOL, f"{where}: |HIP - f32 oracle| = {float(per_ray[b]):.2e} on a well-conditioned ray"
+                    # ... unless this result IS the float64 one to a tenth of the tolerance: then |HIP - f32 oracle| <= the float32
+                    # oracle's own error + 1e-5 (seed 4 case 22 ray 243: |HIP - f64| 5e-7, |f32 oracle - f64| 9.95e-5)
+                    assert d_f32 > TOL or d_hip <= 0.1 * TOL, f"{where}: |HIP - f32 oracle| = {float(per_ray[b]):.2e} on a well-conditioned ray"
                     excused += 1
                     per_ray[b] = 0.0
         worst = max(worst, float(per_ray.max()))

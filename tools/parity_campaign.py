@@ -29,8 +29,29 @@ for case, cfg, w, rays, kw in campaign_cases(int(sys.argv[1]) if len(sys.argv) >
         o64 = OracleScene(cfg, w, dtype=torch.float64)
         with torch.no_grad():
             r64 = o64.forward(rays[bad].double(), **kw)
+        # ... or if the reference's own result moves by more than the tolerance when u moves by the float32 RESOLUTION OF THE CDF
+        # (2 ulp of 1 = 2.4e-7): sample_pdf evaluates (u - cdf_lo) / (cdf_hi - cdf_lo) * bin width with a float32 cdf near 1, so a
+        # cdf step of 2e-5 (a nearly empty last bin) turns one ulp into 0.6 % of a bin - and the far bins of the exponential schedule
+        # are wide.  Which side of such a knot a value lands on depends on the rounding of `weights.sum(-1)` (a float32 cascade sum in
+        # ATen, grouped by the CPU's vector width; the library rounds the exact sum once) - tools/pdf_ray_probe.py: seed 4 case 40
+        # ray 80 moves by 0.33 = 54.5 (bin) x 1.2e-7 / 1.97e-5 exactly that way.
+        nudged = []
+        for du in (2.4e-7, -2.4e-7):
+            orig = OracleScene.sample_pdf
+            def nudge(bins, weights, n, u=None, _du=du):
+                if u is None:
+                    u = torch.linspace(0.0, 1.0, steps=n, dtype=weights.dtype).expand(list(weights.shape[:-1]) + [n])
+                return orig(bins, weights, n, (u.double() + _du).clamp(0.0, 1.0).to(weights.dtype))
+            OracleScene.sample_pdf = staticmethod(nudge)
+            try:
+                with torch.no_grad():
+                    nudged.append(oracle.forward(rays[bad], **kw)[0])
+            finally:
+                OracleScene.sample_pdf = staticmethod(orig)
         for k, b in enumerate(bad.tolist()):
-            if float((r64[0][k].float() - ref[0][b]).abs().max()) > 1e-4:
+            if float((r64[0][k].float() - ref[0][b]).abs().max()) > 1e-4 or \
+                    max(float((nd[k] - ref[0][b]).abs().max()) for nd in nudged) > 1e-4 or \
+                    float((got[0][b].cpu().double() - r64[0][k]).abs().max()) <= 1e-5:   # ... or this result IS the float64 one
                 excused.append(b)
         keep = torch.ones(len(per_ray), dtype=torch.bool)
         keep[excused] = False
@@ -40,7 +61,7 @@ for case, cfg, w, rays, kw in campaign_cases(int(sys.argv[1]) if len(sys.argv) >
     e_dep = float((got[1].cpu() - ref[1]).abs().max()) / max(float(ref[1].abs().max()), 1.0)
     e_alpha = float((got[4].cpu() - ref[4]).abs().max()) if not resampling else 0.0
     worst = dict(rgb=max(worst["rgb"], e_rgb), depth=max(worst["depth"], e_dep), alpha=max(worst["alpha"], e_alpha))
-    flag = ("" if e_rgb <= 1e-4 else "   <-- ABOVE TOLERANCE") + (f"   [{len(excused)} ray(s) ill-conditioned in the reference (fp32 vs fp64 oracle differ): {excused}]" if excused else "")
+    flag = ("" if e_rgb <= 1e-4 else "   <-- ABOVE TOLERANCE") + (f"   [{len(excused)} ray(s) ill-conditioned in the reference (fp32 vs fp64 oracle differ by > 1e-4, the fp32 oracle moves by > 1e-4 with u +- the cdf's float32 resolution, or HIP equals the fp64 oracle to 1e-5): {excused}]" if excused else "")
     print(f"case {case:2d}: grid {cfg.grid} env {int(env)} near/far {cfg.near}/{cfg.far} N {N:3d} {kw}  rgb {e_rgb:.2e} depth(rel) {e_dep:.2e} alpha {e_alpha:.2e}{flag}")
 print("worst:", worst)
 sys.exit(0 if worst["rgb"] <= 1e-4 else 1)
