@@ -637,13 +637,15 @@ def run_train(a, rk: Ranks):
             torch.cuda.synchronize()
     if graphed is not None:
         # the step gets faster as the fit proceeds (the scatters skip zero gradients), so the eager loop is timed before AND after
-        # the replays; the smaller of the two is reported (the eager loop is host-driven: on a box whose CPUs are busy with another
-        # tenant's work one of the two has been seen at twice its usual time while the replays were unaffected)
+        # the replays and the two are averaged - unless one of them is a host hiccup (the eager loop is host-driven: on a box whose
+        # CPUs were busy with another tenant's work one of the two has been seen at twice its usual time while the replays were
+        # unaffected), in which case the other one stands
         losses.append(graphed(rays, gt).clone())
-        dt_eager = timed(rk, step, a.steps, 1)
+        e0 = timed(rk, step, a.steps, 1)
         dt = timed(rk, lambda: graphed(rays, gt), a.steps, a.warmup)
         losses.append(graphed.loss.clone())
-        dt_eager = min(dt_eager, timed(rk, step, a.steps, 1))
+        e1 = timed(rk, step, a.steps, 1)
+        dt_eager = min(e0, e1) if max(e0, e1) > 1.3 * min(e0, e1) else 0.5 * (e0 + e1)
     else:
         dt = dt_eager = timed(rk, step, a.steps, a.warmup)
     if rk.rank != 0:
