@@ -73,13 +73,15 @@ SP = C.POINTER(Scene)
 # The EGO_ABI_VERSION (include/egonerf_hip.h) the PROTOTYPES below were written against.  load() refuses a library that reports
 # another one: a stale libegonerf_hip.so can keep every struct size and still disagree on an argument list (ABI 5 -> 7 inserted
 # `normalize` before ego_erp_rays' output pointer), which ctypes would pass through as a wild pointer.
-EXPECTED_ABI_VERSION = 10
+EXPECTED_ABI_VERSION = 11
 
 # name -> (restype, argtypes); mirrors include/egonerf_hip.h one to one
 PROTOTYPES = {
     "ego_abi_version": (C.c_int, []),
     "ego_last_error": (C.c_char_p, []),
     "ego_sizeof": (I64, [I32]),
+    "ego_selftest_workspace_bytes": (I64, []),
+    "ego_selftest": (C.c_int, [P, I64, I32, C.POINTER(C.c_int32), P]),
     "ego_packed_floats": (I64, []),
     "ego_packed_floats_scene": (I64, [SP]),
     "ego_sample_ray_exp": (C.c_int, [P, P, P, F32, I64, I32, P, P, P]),
@@ -148,16 +150,54 @@ def load() -> C.CDLL:
     if got != EXPECTED_ABI_VERSION:
         raise RuntimeError(f"ABI mismatch: {LIB} reports EGO_ABI_VERSION {got}, this binding was written for {EXPECTED_ABI_VERSION}; "
                            "rebuild it (`python -m egonerf_amd.build`)")
-    from .build import is_stale
-    if is_stale() and not os.environ.get("EGO_ALLOW_STALE_LIB"):
-        raise RuntimeError(f"{LIB} was not built from the sources next to it (source hash differs from {LIB}.hash); rebuild it "
-                           "(`python -m egonerf_amd.build`) or set EGO_ALLOW_STALE_LIB=1 for an experiment build")
+    from .build import stale_reason
+    why = stale_reason()
+    if why and not os.environ.get("EGO_ALLOW_STALE_LIB"):
+        raise RuntimeError(f"{LIB} cannot be matched to the sources next to it: {why}; rebuild it (`python -m egonerf_amd.build`) "
+                           "or set EGO_ALLOW_STALE_LIB=1 for an experiment build")
     for which, struct in ((0, Scene), (1, RenderArgs), (2, VmField), (3, AdamTensor), (4, ShadeDump)):
         if lib.ego_sizeof(which) != C.sizeof(struct):
             raise RuntimeError(f"ABI mismatch: struct {struct.__name__} is {C.sizeof(struct)} B here, "
                                f"{lib.ego_sizeof(which)} B in {LIB}")
     _lib = lib
     return lib
+
+
+# ---- run-time self-test of the gather kernels, once per process and device -------------------------------
+_SELFTESTED: set = set()
+SELFTEST_REPS = int(os.environ.get("EGO_SELFTEST_REPS", "96"))
+
+
+def selftest(device_index: int, reps: int | None = None, lib: "C.CDLL | None" = None) -> int:
+    """Runs ego_selftest on `device_index` (the shipped ego_app_feature / ego_shade kernels, `reps` repetitions on a fixed
+    synthetic tile set, bit-compared) and returns the number of mismatching calls; raises on any other error.  `lib`: another
+    build of the library (tests hand in the known-faulty form)."""
+    lib = lib or load()
+    with torch.cuda.device(device_index):
+        n = int(lib.ego_selftest_workspace_bytes())
+        ws = torch.empty(n // 4 + 64, dtype=torch.float32, device=torch.device("cuda", device_index))  # torch blocks are 512-byte aligned
+        bad = C.c_int32(0)
+        code = lib.ego_selftest(ws.data_ptr(), n, int(reps or SELFTEST_REPS), C.byref(bad), stream_handle())
+        if code != 0 and bad.value == 0:
+            raise RuntimeError(f"ego_selftest failed (code {code}): {lib.ego_last_error().decode(errors='replace')}")
+    return int(bad.value)
+
+
+def ensure_selftest(device_index: int) -> None:
+    """First use of a device in this process: refuse a library whose gather kernels are not bit-reproducible on it.
+    EGO_SKIP_SELFTEST=1 opts out.  ~10 ms; skipped (and retried later) while the current stream is being captured."""
+    if device_index in _SELFTESTED:
+        return
+    if os.environ.get("EGO_SKIP_SELFTEST") == "1":
+        _SELFTESTED.add(device_index)
+        return
+    if torch.cuda.is_current_stream_capturing():
+        return
+    bad = selftest(device_index)
+    if bad:
+        raise RuntimeError(f"{LIB}: self-test FAILED on cuda:{device_index}: {bad} calls of the gather kernels returned different bits on identical "
+                           f"inputs ({load().ego_last_error().decode(errors='replace')}).  Set EGO_SKIP_SELFTEST=1 only to investigate.")
+    _SELFTESTED.add(device_index)
 
 
 def check(code: int, what: str) -> None:
@@ -195,7 +235,8 @@ def _device_of(args) -> "torch.device | None":
 
 
 def device_guard(fn):
-    """Decorator for every entry point that launches kernels: the C ABI takes raw pointers and a raw stream, so the launch
+    """Decorator for every entry point that launches kernels (it also runs the library's self-test on the first use of a
+    device, `ensure_selftest`): the C ABI takes raw pointers and a raw stream, so the launch
     must happen with the device that owns the pointers current (and on THAT device's current stream).  The owning device is
     the first HIP tensor among the positional arguments (or the first parameter of a module / optimiser argument); when it
     differs from torch's current device the call runs inside `torch.cuda.device(owner)`."""
@@ -203,6 +244,8 @@ def device_guard(fn):
     @functools.wraps(fn)
     def guarded(*args, **kw):
         dev = _device_of(args) or _device_of(kw.values())
+        if dev is not None and dev.index not in _SELFTESTED:
+            ensure_selftest(dev.index)
         if dev is None or dev.index == torch.cuda.current_device():
             return fn(*args, **kw)
         with torch.cuda.device(dev):

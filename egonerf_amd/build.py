@@ -9,7 +9,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libegonerf_hip.so")
-SOURCES = ["ego_ops.hip", "ego_shade.hip", "ego_render.hip", "ego_reg.hip", "ego_metrics.hip", "ego_wgrad.hip", "ego_generic.hip"]
+SOURCES = ["ego_ops.hip", "ego_shade.hip", "ego_render.hip", "ego_reg.hip", "ego_metrics.hip", "ego_wgrad.hip", "ego_generic.hip", "ego_selftest.hip"]
 HEADERS = ["ego_device.h", "ego_host.h", "ego_train.inc", "variants.h", "ego_generic.h", os.path.join("..", "..", "include", "egonerf_hip.h")]
 
 
@@ -31,23 +31,67 @@ def hipcc_version() -> str:
     return "unknown"
 
 
-def source_hash() -> str:
+def source_hash(extra: list | None = None, per_file: bool = True) -> str:
     """sha256 over the library's sources, headers and compile flags: what `libegonerf_hip.so.hash` records for the binary next
-    to it, and what profiles/r*/pmc_traffic.json records for the build its counters were taken from."""
+    to it, and what profiles/r*/pmc_traffic.json records for the build its counters were taken from.  `extra` / `per_file`:
+    an experiment build's additional flags / dropped per-file flags go into ITS hash, so it can never pass for the product build."""
     import hashlib
     h = hashlib.sha256()
     for f in SOURCES + HEADERS:
         h.update(f.encode())
         h.update(open(os.path.join(CSRC, f), "rb").read())
     h.update(repr((COMMON_FLAGS, sorted(EXTRA_FLAGS.items()))).encode())
+    if extra or not per_file:
+        h.update(repr((list(extra or []), per_file)).encode())
     return h.hexdigest()[:16]
 
 
+def stale_reason() -> str | None:
+    """None if the binary's recorded source hash equals the tree's (mtimes do not survive a snapshot copy), else why not."""
+    if not os.path.exists(LIB):
+        return "the library is missing"
+    if not os.path.exists(LIB + ".hash"):
+        return f"{LIB}.hash is missing (a binary without its recorded source hash cannot be matched to the sources next to it)"
+    got = open(LIB + ".hash").read().strip()
+    return None if got == source_hash() else f"source hash differs ({got} recorded, {source_hash()} in the tree: other sources, flags, or an experiment build)"
+
+
 def is_stale() -> bool:
-    """True unless the binary's recorded source hash equals the tree's (mtimes do not survive a snapshot copy)."""
-    if not os.path.exists(LIB) or not os.path.exists(LIB + ".hash"):
-        return True
-    return open(LIB + ".hash").read().strip() != source_hash()
+    return stale_reason() is not None
+
+
+def _code_objects(lib_path: str, workdir: str) -> tuple:
+    """The gfx950 code objects inside a built shared library (llvm-objdump --offloading extracts next to its input: work on a copy)."""
+    import glob
+    objdump = os.path.join(os.path.dirname(os.path.realpath(_hipcc())), "..", "lib", "llvm", "bin", "llvm-objdump")
+    if not os.path.exists(objdump):
+        objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    copy = os.path.join(workdir, "lib.so")
+    shutil.copy(lib_path, copy)
+    r = subprocess.run([objdump, "--offloading", copy], capture_output=True, text=True, cwd=workdir)
+    if r.returncode != 0:
+        raise RuntimeError("llvm-objdump --offloading failed: " + r.stderr[-500:])
+    return objdump, sorted(glob.glob(copy + ".*gfx950*"))
+
+
+def shipped_isa_report(lib_path: str | None = None) -> dict:
+    """Disassembles the device code INSIDE the built library (not a fresh compile) and reports the packed fp32 instructions that
+    broadcast the high dword of a register pair (`op_sel:[...]` without `op_sel_hi`): the trigger of the fault in DESIGN.md 5.1.
+    -> {"code_objects": n, "packed_fp32": n, "high_half_broadcast": [disassembly lines]}"""
+    import re
+    import tempfile
+    lib_path = lib_path or LIB
+    with tempfile.TemporaryDirectory() as tmp:
+        objdump, cos = _code_objects(lib_path, tmp)
+        n_packed, bad = 0, []
+        for co in cos:
+            dis = subprocess.run([objdump, "-d", co], capture_output=True, text=True).stdout
+            for line in dis.splitlines():
+                if re.search(r"v_pk_(fma|mul|add)_f32", line):
+                    n_packed += 1
+                    if "op_sel:" in line and "op_sel_hi" not in line:
+                        bad.append(line.strip())
+    return dict(code_objects=len(cos), packed_fp32=n_packed, high_half_broadcast=bad)
 
 
 # Per-source extra flags.  ego_shade.hip is built without the SLP vectoriser: it forms {w00, w01}-style pairs of the interpolation
@@ -93,8 +137,9 @@ def build_library(force: bool = False, verbose: bool = False, extra: list | None
     if r.returncode != 0:
         raise RuntimeError("hipcc (link) failed:\n" + r.stdout + r.stderr)
     os.replace(out + ".tmp", out)
-    if out == LIB and not extra:
-        open(LIB + ".hash", "w").write(source_hash() + "\n")
+    # every build records ITS hash next to the binary: an experiment build written over LIB (extra flags / no per-file flags) gets a
+    # hash that differs from the tree's, so _lib.load() refuses it unless EGO_ALLOW_STALE_LIB=1 (it used to keep the old .hash)
+    open(out + ".hash", "w").write(source_hash(extra, per_file=not os.environ.get("EGO_NO_PER_FILE_FLAGS")) + "\n")
     if out != LIB:
         shutil.rmtree(objdir, ignore_errors=True)
     return out

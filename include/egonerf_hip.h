@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define EGO_ABI_VERSION 10
+#define EGO_ABI_VERSION 11
 
 enum { EGO_PREC_F16X3 = 0, EGO_PREC_F32 = 1, EGO_PREC_F16F8 = 2 };
 
@@ -143,6 +143,15 @@ const char* ego_last_error(void);
 /* sizeof the ABI structs as compiled (0 ego_scene, 1 ego_render_args, 2 ego_vm_field, 3 ego_adam_tensor, 4 ego_shade_dump): lets a foreign-
  * language binding verify its struct mirrors at load time */
 int64_t ego_sizeof(int32_t which);
+
+/* Run-time self-test of the team-gather kernel family (no reference counterpart).  Builds of these kernels that contain
+ * packed fp32 instructions broadcasting the high dword of a register pair returned different bits call after call on MI355X; the build
+ * fences that off and this entry point checks the SHIPPED code on the device at hand: ego_app_feature and ego_shade (f16x3, f16f8) run
+ * `reps` times on a synthetic scene laid out in `workspace` (dev, ego_selftest_workspace_bytes() bytes, 256-byte aligned) and every
+ * result is bit-compared with the first.  Synchronises `stream`.  Returns EGO_OK and *mismatching_calls = 0, or EGO_E_UNSUPPORTED with
+ * the number of calls whose bits differed (host pointer).  The host layer calls it once per process and device (EGO_SKIP_SELFTEST=1 opts out). */
+int64_t ego_selftest_workspace_bytes(void);
+int ego_selftest(void* workspace, int64_t workspace_bytes, int32_t reps, int32_t* mismatching_calls, void* stream);
 
 /* ---- separately callable stages (back the reference's public methods; parity-tested one by one) ---- */
 

@@ -22,7 +22,7 @@ def test_library_exports_every_header_symbol():
     for n in names:
         assert hasattr(lib, n), n
     assert set(names) == set(_lib.PROTOTYPES)  # the binding covers the whole header, nothing extra
-    assert lib.ego_abi_version() == _lib.EXPECTED_ABI_VERSION == 10
+    assert lib.ego_abi_version() == _lib.EXPECTED_ABI_VERSION == 11
     assert [lib.ego_sizeof(i) for i in range(3)] == [ctypes.sizeof(_lib.Scene), ctypes.sizeof(_lib.RenderArgs),
                                                      ctypes.sizeof(_lib.VmField)]
     assert lib.ego_packed_floats() == 2 * 46852 + 9216 + 36864  # fp32 layout + fp16-split layout + fp16-table basis fragments + f16f8 W1/W2
@@ -275,27 +275,44 @@ def test_reference_opens_a_checkpoint_written_here(tmp_path):
     assert np.abs(out["env"] - ref[3].numpy()).max() <= 1e-6
 
 
-def test_kernels_have_no_high_half_broadcast_packed_fp32_ops(tmp_path):
+def test_shipped_binary_has_no_high_half_broadcast_packed_fp32_ops():
     """every build of ego_shade.hip whose kernels contained packed fp32 instructions broadcasting the HIGH dword of
     a register pair (`v_pk_fma_f32 ... op_sel:[1,0,0]` without op_sel_hi) returned wrong results in some calls on MI355X; builds
-    without them never did.  Compile every source to gfx950 assembly with the build's flags and check that none is there."""
-    import os, re, subprocess
+    without them never did.  The check reads the code objects INSIDE the built libegonerf_hip.so (the binary that ships), not a
+    fresh compile."""
     from egonerf_amd import build
-    procs = []
-    for f in build.SOURCES:
-        out = str(tmp_path / f.replace(".hip", ".s"))
-        cmd = [build._hipcc(), *[x for x in build.COMMON_FLAGS if x != "-fPIC"], *build.EXTRA_FLAGS.get(f, []), "-S", "--cuda-device-only",
-               "-o", out, os.path.join(build.CSRC, f)]
-        procs.append((f, out, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
-    n_packed = 0
-    for f, out, pr in procs:
-        log, _ = pr.communicate()
-        assert pr.returncode == 0, (f, log[-2000:])
-        lines = [l.strip() for l in open(out) if re.search(r"v_pk_(fma|mul|add)_f32", l)]
-        n_packed += len(lines)
-        bad = [l for l in lines if "op_sel:" in l and "op_sel_hi" not in l]
-        assert not bad, (f, bad[:5])
-    assert n_packed > 1000  # the check looked at real code
+    rep = build.shipped_isa_report()
+    assert rep["code_objects"] >= 6
+    assert rep["packed_fp32"] > 1000          # the check looked at real code
+    assert not rep["high_half_broadcast"], rep["high_half_broadcast"][:5]
+
+
+def build_faulty_variant(tmp_path):
+    """The known-faulty form of the gather kernels (csrc/variants.h: -DEGO_PAIRED_WEIGHTS, SLP vectoriser on) as a side library."""
+    import os
+    from egonerf_amd import build
+    out = str(tmp_path / "libegonerf_faulty.so")
+    old = os.environ.get("EGO_NO_PER_FILE_FLAGS")
+    os.environ["EGO_NO_PER_FILE_FLAGS"] = "1"
+    try:
+        build.build_library(force=True, extra=["-DEGO_PAIRED_WEIGHTS"], out=out)
+    finally:
+        if old is None:
+            del os.environ["EGO_NO_PER_FILE_FLAGS"]
+        else:
+            os.environ["EGO_NO_PER_FILE_FLAGS"] = old
+    return out
+
+
+def test_isa_guard_sees_the_faulty_form(tmp_path):
+    """The same check on a side build of the reproducer form finds the instructions, and that build's recorded hash can never pass
+    for the product build's (an experiment build written over LIB used to keep the old .hash)."""
+    from egonerf_amd import build
+    out = build_faulty_variant(tmp_path)
+    rep = build.shipped_isa_report(out)
+    assert len(rep["high_half_broadcast"]) >= 12, rep
+    assert open(out + ".hash").read().strip() != build.source_hash()
+    assert open(build.LIB + ".hash").read().strip() == build.source_hash()
 
 
 @pytest.mark.parametrize("flags", [["-DEGO_GATHER_TEAMS=0"], ["-DEGO_PAIRED_WEIGHTS"]])

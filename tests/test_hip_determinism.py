@@ -15,3 +15,41 @@ def test_forward_ops_are_bit_reproducible():
     res = determinism_check.run(reps=3000, full=False, verbose=False)
     bad = {k: v for k, v in res.items() if v[0]}
     assert not bad, bad
+
+
+def test_selftest_passes_on_the_shipped_library_and_ran_at_first_use():
+    """ego_selftest (the run-time fence of DESIGN.md 5.1) on the shipped binary: 0 mismatching calls in 400 repetitions, within the
+    50 ms budget at the default repetition count, and the host layer has run it for this device by the time a model has rendered."""
+    import time
+    import torch
+    from egonerf_amd import _lib, synth
+    from tests.helpers import make_model
+    cfg = synth.SceneConfig(n_voxel=20 ** 3)
+    model = make_model(cfg, synth.make_weights(cfg, seed=1234), "cuda:0")
+    with torch.no_grad():
+        model(torch.from_numpy(synth.make_rays(64, seed=3)).cuda(), n_coarse=32, exp_sampling=True)
+    assert 0 in _lib._SELFTESTED
+    assert _lib.selftest(0, reps=400) == 0
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    assert _lib.selftest(0) == 0
+    assert time.perf_counter() - t <= 0.05
+
+
+def test_selftest_rejects_the_known_faulty_build(tmp_path):
+    """the reproducer form of the gather kernels (csrc/variants.h: -DEGO_PAIRED_WEIGHTS with the SLP vectoriser
+    on) built into a side library; its code objects contain the high-half-broadcast packed instructions and the self-test must see
+    different bits among repeated calls (the fault hits 30-40 % of the calls of that form, profiles/r03/fault51_asm_experiments.txt)."""
+    import ctypes as C
+    from egonerf_amd import _lib, build
+    from tests.test_abi_and_host import build_faulty_variant
+    out = build_faulty_variant(tmp_path)
+    assert len(build.shipped_isa_report(out)["high_half_broadcast"]) >= 12
+    lib = C.CDLL(out)
+    for name in ("ego_selftest_workspace_bytes", "ego_selftest", "ego_last_error"):
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = _lib.PROTOTYPES[name]
+    bad = _lib.selftest(0, reps=600, lib=lib)
+    assert bad > 0, "the known-faulty build passed the self-test"
+    assert b"reproducibility fault" in lib.ego_last_error()
+    assert _lib.selftest(0, reps=100) == 0   # and the shipped library is still clean next to it

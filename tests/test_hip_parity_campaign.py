@@ -23,6 +23,7 @@ from tests.helpers import campaign_cases, make_model, make_oracle
 pytestmark = pytest.mark.gpu
 
 TOL, WATCH, K = 1e-4, 5e-5, 3.0
+MAX_EXCUSED = 2   # rays per (seed, arithmetic) that may exceed 1e-4 vs the float32 oracle under the float64 argument above; asserted, not printed
 
 
 @pytest.mark.parametrize("prec", ["f16f8", "f16x3"])
@@ -67,5 +68,6 @@ def test_campaign_vs_float32_and_float64_oracle(seed, prec):
             if not kw["resampling"]:
                 assert float((got[4].cpu()[keep] - ref[4][keep]).abs().max()) <= 1e-4, (seed, case)
     assert worst <= TOL
+    assert excused <= MAX_EXCUSED, f"seed {seed} {prec}: {excused} rays needed the float64 excuse (allowed: {MAX_EXCUSED})"
     print(f"campaign seed {seed} {prec}: worst |dRGB| {worst:.2e}, {watched} rays above {WATCH:g} checked against float64, {excused} ill-conditioned in the reference, "
           f"worst |HIP - f64| / |f32 oracle - f64| = {ratio:.2f}")
