@@ -73,9 +73,15 @@ def parse():
     ap.add_argument("--views", type=int, default=None, help="erp: images per step sequence (default = --steps)")
     ap.add_argument("--erp-size", type=int, nargs=2, default=[1024, 2048], metavar=("H", "W"))
     ap.add_argument("--mask", action="store_true", help="erp: build the reference's alpha mask and apply it (TensorBase.forward semantics)")
+    ap.add_argument("--carve", action="store_true", help="erp: give the synthetic field real empty space (synth.carve_empty_space: density exactly 0 "
+                    "outside two radial shells and inside a phi wedge); with --mask the line then carries mask-off AND mask-on timings")
     ap.add_argument("--term-eps", type=float, default=0.0, help="erp: early-termination threshold on the transmittance")
     ap.add_argument("--density-shift", type=float, default=None, help="render: override the scene's density_shift (-8) to make the synthetic "
                     "field more / less opaque: shows what the exact zero-weight tile skip does on surface-like scenes (not the headline workload)")
+    ap.add_argument("--n-voxel", type=float, default=None, help="render: grid size (default 27e6 -> [150,172,516], 94 MB of tables, cache resident); "
+                    "216e6 -> [300,346,1036], ~400 MB of tables > the 256 MiB Infinity Cache: the regime in which the gathers really read HBM")
+    ap.add_argument("--fresh-rays", type=int, default=0, metavar="B", help="render: B distinct ray batches used round-robin (a different batch every "
+                    "step) instead of re-rendering one batch; with --n-voxel / --fresh-rays the lean variant line is printed (no alt precisions)")
     ap.add_argument("--cpu-worker", nargs=2, type=int, metavar=("N_RAYS", "THREADS"), help=argparse.SUPPRESS)
     a = ap.parse_args()
     dflt = dict(render=(200, 10), train=(20, 3), erp=(4, 1))[a.config]  # render: 0.7 ms steps, amortise the barrier bracket
@@ -141,10 +147,33 @@ class Ranks:
         torch.cuda.synchronize()
 
     def max_over_ranks(self, seconds: float) -> float:
+        """MAX over ranks of one rank's wall time (the contract's figure); the per-rank spread of the same interval is kept in
+        `self.spread` (min / max / every rank's value), so that a straggler is visible in the line the day an 8-GPU node runs this."""
         t = torch.tensor([seconds], device="cpu" if self.shared else self.dev, dtype=torch.float64)
         if self.dist is not None:
-            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
-        return float(t.item())
+            every = [torch.zeros_like(t) for _ in range(self.world)]
+            self.dist.all_gather(every, t)
+            vals = [float(v.item()) for v in every]
+        else:
+            vals = [seconds]
+        self.spread = dict(min_s=min(vals), max_s=max(vals), per_rank_s=vals)
+        return max(vals)
+
+    def rank_step_ms(self, steps: int) -> dict:
+        sp = getattr(self, "spread", None)
+        if not sp:
+            return None
+        return dict(min=sp["min_s"] / steps * 1e3, max=sp["max_s"] / steps * 1e3, per_rank=[v / steps * 1e3 for v in sp["per_rank_s"]],
+                    note="wall time of the timed region on each rank / steps; `ms_per_step` is the max")
+
+    def same_on_all_ranks(self, values) -> bool:
+        """True iff `values` (floats) are bit-identical on every rank (all_gather of float64)."""
+        if self.dist is None:
+            return True
+        t = torch.tensor(list(values), device="cpu" if self.shared else self.dev, dtype=torch.float64)
+        every = [torch.zeros_like(t) for _ in range(self.world)]
+        self.dist.all_gather(every, t)
+        return all(bool(torch.equal(e, every[0])) for e in every)
 
     def finish(self):
         if self.dist is not None:
@@ -344,6 +373,7 @@ def run_render(a, rk: Ranks):
     kw = dict(n_coarse=N_SAMPLES, exp_sampling=True)
     with torch.no_grad():
         dt = timed(rk, lambda: model(rays, **kw), a.steps, a.warmup)
+    headline_spread = rk.rank_step_ms(a.steps)
     if rk.rank != 0:
         return None
     # ---- per-kernel durations, measured live with events on the launch stream (same work as a step) ----
@@ -511,6 +541,7 @@ def run_render(a, rk: Ranks):
     rays_per_s = rk.world * N_RAYS * a.steps / dt
     return dict(metric="rays/sec at 4096-ray batch, 512 samples (EgoNeRF volume-rendering forward)", value=rays_per_s,
                 unit="rays/s", samples_per_s=rays_per_s * N_SAMPLES, n_gpus=rk.world, steps=a.steps, warmup=a.warmup,
+                rank_step_ms=headline_spread,
                 clock_ramp_s=RAMP_SECONDS,  # untimed: the same step repeated before the W warm-up steps (see timed())
                 ms_per_step=dt / a.steps * 1e3, higher_is_better=True, scaling="weak", vs_baseline=None,
                 dtype={"f16x3": "f32 (tables, interpolation, compositing; matrix products as 3x fp16 MFMA with fp32 accumulate)",
@@ -523,6 +554,95 @@ def run_render(a, rk: Ranks):
                             rays_per_step_per_gpu=N_RAYS, samples_per_ray=N_SAMPLES, parallelism=f"ray-sharded x{rk.world}"),
                 roofline=roofline, cpu_baseline=cpu, cpu_baseline_single_process=cpu_single, parity=parity,
                 speedup_vs_cpu=None if cpu is None else rays_per_s / cpu["value"])
+
+
+
+# =====================================================================================================
+# render variants: fresh ray batches every step / a table set larger than the Infinity Cache
+# =====================================================================================================
+def run_render_variant(a, rk: Ranks):
+    """The headline step (4096 rays x 512 samples, eval, no resampling) with (a) `--fresh-rays B`: B distinct ray batches used
+    round-robin, so that no step re-reads the texels the previous one left in the caches, and / or (b) `--n-voxel V`: another grid
+    size - 216e6 gives ~400 MB of tables, more than the 256 MiB Infinity Cache, the only regime in which SURVEY 8(d)'s byte
+    roofline can bind physically.  The roofline object is the HBM one: achieved = ALGORITHMIC tap bytes of march + shade per step /
+    their event-timed duration; `traffic` = counter HBM bytes of the same two kernels when profiles/r*/pmc_traffic.json has a
+    section for this variant (tools/profile_r04.sh)."""
+    from egonerf_amd import _lib
+    dev = rk.dev
+    cfg = synth.SceneConfig() if not a.n_voxel else synth.SceneConfig(n_voxel=float(a.n_voxel))
+    weights = synth.make_weights(cfg, seed=1234)
+    model = synth.build_model(cfg, weights, dev)
+    B = max(int(a.fresh_rays), 1)
+    batches = [torch.from_numpy(synth.make_rays(N_RAYS, seed=1000 * rk.rank + 1 + b)).to(dev) for b in range(B)]
+    kw = dict(n_coarse=N_SAMPLES, exp_sampling=True)
+    state = dict(i=0)
+
+    def step():
+        model(batches[state["i"] % B], **kw)
+        state["i"] += 1
+    with torch.no_grad():
+        dt = timed(rk, step, a.steps, a.warmup)
+    spread = rk.rank_step_ms(a.steps)
+    if rk.rank != 0:
+        return None
+    lib, st = _lib.load(), _lib.stream_handle()
+    sc = model.scene()
+    M = N_RAYS * N_SAMPLES
+    sched = model._sched(N_SAMPLES, dev)
+    z = torch.empty(N_RAYS, N_SAMPLES, device=dev)
+    w = torch.empty_like(z)
+    bg = torch.empty(N_RAYS, device=dev)
+    rgb = torch.empty(N_RAYS, N_SAMPLES, 3, device=dev)
+    crd = torch.empty(N_RAYS, N_SAMPLES, 4, device=dev)
+    rgb_map, depth = torch.empty(N_RAYS, 3, device=dev), torch.empty(N_RAYS, device=dev)
+    reps = max(min(a.steps, 128), B, 8)
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(reps)]
+    for i in range(reps + 2):
+        e, rays = ev[max(i - 2, 0)], batches[i % B]
+        e[0].record()
+        _lib.check(lib.ego_march_density(sc, rays.data_ptr(), N_RAYS, N_SAMPLES, None, sched.data_ptr(), None, cfg.near, 0,
+                                         z.data_ptr(), None, 0, w.data_ptr(), bg.data_ptr(), crd.data_ptr(), None, None, st), "march")
+        e[1].record()
+        _lib.check(lib.ego_shade(sc, rays.data_ptr(), z.data_ptr(), crd.data_ptr(), N_RAYS, N_SAMPLES, rgb.data_ptr(), None, None, st), "shade")
+        e[2].record()
+        _lib.check(lib.ego_composite(sc, rays.data_ptr(), z.data_ptr(), w.data_ptr(), bg.data_ptr(), rgb.data_ptr(), N_RAYS,
+                                     N_SAMPLES, rgb_map.data_ptr(), depth.data_ptr(), None, None, None, st), "composite")
+        e[3].record()
+    torch.cuda.synchronize()
+    ms = np.array([[e[k].elapsed_time(e[k + 1]) for k in range(3)] for e in ev]).mean(0)
+    t_march, t_shade, t_comp = (float(x) * 1e-3 for x in ms)
+    info = kernel_info(model.mlp_precision)
+    table_bytes = sum(int(p.numel()) * 4 for n, p in model.named_parameters() if "plane" in n or "line" in n)
+    alg_shade = (info["app_tap_bytes_per_sample"] + 16 + 12) * M
+    alg_march = (B_DENSITY + 28) * M
+    key = "big_grid" if a.n_voxel else ("fresh_rays" if B > 1 else None)
+    pmc, src, stale = load_pmc_section(key) if key else (None, None, None)
+    t_gs = t_march + t_shade
+    roofline = dict(bound="hbm", kernel="k_march_density + k_shade_h (the two grid-sample kernels)", unit="GB/s", peak=HBM_PEAK_GBPS,
+                    achieved=(alg_shade + alg_march) / t_gs / 1e9, frac=(alg_shade + alg_march) / t_gs / 1e9 / HBM_PEAK_GBPS,
+                    algorithmic_bytes_per_step=alg_shade + alg_march, traffic=None, hbm_counter_GBps=None, hbm_counter_frac=None,
+                    kernels_ms=dict(k_march_density=t_march * 1e3, k_shade=t_shade * 1e3, k_composite=t_comp * 1e3),
+                    shade=dict(algorithmic_GBps=alg_shade / t_shade / 1e9, mfma_frac=info["flop_per_sample"] * M / t_shade / 1e12 / MFMA_F16_PEAK_TFLOPS),
+                    march=dict(algorithmic_GBps=alg_march / t_march / 1e9),
+                    table_bytes=table_bytes, infinity_cache_bytes=256 * 2 ** 20, tables_fit_infinity_cache=table_bytes < 256 * 2 ** 20,
+                    definition="achieved = SURVEY 8(d)'s algorithmic tap bytes (4 608 B per sample + coords / outputs) of the two grid-sample kernels "
+                               "per step / their event-timed duration; frac > 1 is possible and means the caches, not HBM, served the taps; "
+                               "traffic / hbm_counter_* = FETCH_SIZE x 2 + WRITE_SIZE of the same two kernels from separate rocprofv3 --pmc passes")
+    if pmc is not None and pmc.get("traffic_bytes"):
+        t_pmc = pmc.get("duration_s") or t_gs
+        roofline.update(traffic=pmc["traffic_bytes"], hbm_counter_GBps=pmc["traffic_bytes"] / t_gs / 1e9,
+                        hbm_counter_frac=pmc["traffic_bytes"] / t_gs / 1e9 / HBM_PEAK_GBPS,
+                        inputs=dict(source=src, stale_vs_current_sources=stale, per_kernel=pmc.get("per_kernel")))
+    rays_per_s = rk.world * N_RAYS * a.steps / dt
+    return dict(metric="rays/sec at 4096-ray batch, 512 samples (EgoNeRF volume-rendering forward)", value=rays_per_s, unit="rays/s",
+                samples_per_s=rays_per_s * N_SAMPLES, n_gpus=rk.world, steps=a.steps, warmup=a.warmup, clock_ramp_s=RAMP_SECONDS,
+                ms_per_step=dt / a.steps * 1e3, rank_step_ms=spread, higher_is_better=True, scaling="weak", vs_baseline=None,
+                dtype="f32 (tables, interpolation, compositing; matrix products: mlp_precision = " + model.mlp_precision + ")", data="synthetic",
+                config=dict(workload=f"grid {cfg.grid} ({table_bytes / 2 ** 20:.0f} MiB of VM tables), 4096 rays x 512 samples, eval, no resampling; "
+                                     f"{B} distinct ray batch(es) used round-robin (a different batch every step)" if B > 1 else
+                                     f"grid {cfg.grid} ({table_bytes / 2 ** 20:.0f} MiB of VM tables), 4096 rays x 512 samples, eval, no resampling",
+                            ray_batches=B, rays_per_step_per_gpu=N_RAYS, samples_per_ray=N_SAMPLES, parallelism=f"ray-sharded x{rk.world}"),
+                roofline=roofline, cpu_baseline=None)
 
 
 # =====================================================================================================
@@ -643,11 +763,13 @@ def run_train(a, rk: Ranks):
         losses.append(graphed(rays, gt).clone())
         e0 = timed(rk, step, a.steps, 1)
         dt = timed(rk, lambda: graphed(rays, gt), a.steps, a.warmup)
+        spread = rk.rank_step_ms(a.steps)
         losses.append(graphed.loss.clone())
         e1 = timed(rk, step, a.steps, 1)
         dt_eager = min(e0, e1) if max(e0, e1) > 1.3 * min(e0, e1) else 0.5 * (e0 + e1)
     else:
         dt = dt_eager = timed(rk, step, a.steps, a.warmup)
+        spread = rk.rank_step_ms(a.steps)
     if rk.rank != 0:
         return None
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
@@ -719,7 +841,7 @@ def run_train(a, rk: Ranks):
             cpu = dict(error=repr(e))
     return dict(metric="rays/sec, training step (forward + backward + FusedAdam + coarse-table refresh)", value=rays_per_s, unit="rays/s",
                 samples_per_s=rays_per_s * 384, n_gpus=rk.world, steps=a.steps, warmup=a.warmup, clock_ramp_s=RAMP_SECONDS,
-                ms_per_step=t_step * 1e3, higher_is_better=True, scaling="weak", vs_baseline=None,
+                ms_per_step=t_step * 1e3, rank_step_ms=spread, higher_is_better=True, scaling="weak", vs_baseline=None,
                 dtype="f32 (tables, gradients, optimiser state; matrix products as fp16 / bf16 hi+lo MFMA with fp32 accumulate)",
                 data="synthetic",
                 config=dict(workload="OmniBlender barbershop shape: grid [150,172,516]; 8192 rays x (128 coarse + 128 fine) per step, "
@@ -746,13 +868,16 @@ def erp_pose(k: int, K: int) -> np.ndarray:
     return np.array([[c, 0, s, 0.3 * c], [0, 1, 0, 0.05 * (k % 5)], [-s, 0, c, 0.3 * s]], np.float32)
 
 
-def cpu_baseline_erp(cfg, weights, H: int, W: int, n_rays: int):
-    """The oracle's 128+128 render (resampling, envmap on) of `n_rays` rays of the first view, spread evenly over the image."""
+def cpu_baseline_erp(cfg, weights, H: int, W: int, n_rays: int, alpha_mask=None):
+    """The oracle's 128+128 render (resampling, envmap on) of `n_rays` rays of the first view, spread evenly over the image.
+    `alpha_mask` = (yin, yang) volumes: applied with TensorBase.forward's semantics (tensorBase.py:464-478), as the HIP path does."""
     from oracle.egonerf_oracle import OracleScene, erp_rays_reference
     logical = os.cpu_count() or 1
     threads = min(32, logical)
     torch.set_num_threads(threads)
     sc = OracleScene(cfg, weights)
+    if alpha_mask is not None:
+        sc.alpha_mask = alpha_mask
     pose = torch.from_numpy(erp_pose(0, 1))
     allr = erp_rays_reference(H, W, pose)
     pick = torch.linspace(0, allr.shape[0] - 1, n_rays).long()
@@ -766,63 +891,18 @@ def cpu_baseline_erp(cfg, weights, H: int, W: int, n_rays: int):
             best = min(best, time.perf_counter() - t)
     return dict(value=n_rays / best, unit="rays/s", cores=threads, kind="port",
                 sample=f"oracle render of {n_rays} rays (evenly spaced pixels of view 0 of the {H}x{W} image) x ({ERP_NC}+{ERP_NF}) samples, envmap on, "
+                       + ("the same alpha mask applied, " if alpha_mask is not None else "") +
                        f"best of 2 ({best:.2f} s) with {threads} ATen threads (survey container, 8 threads, 4096 x (128+128): 1 208 rays/s)"), out, rays, pick
 
 
-def run_erp(a, rk: Ranks):
+def erp_chunk_split(model, rays_c, reps: int = 12):
+    """The five launches of one ERP chunk (what ego_render_forward queues), event-timed through the stage entry points with the
+    model's CURRENT scene (mask / thresholds included) -> ({kernel: ms}, fraction of 32-sample tiles the shade skips)."""
     from egonerf_amd import _lib
-    from egonerf_amd.renderer import erp_rays, psnr_from_sse, shard_bounds, volume_renderer
-    dev = rk.dev
-    H, W = a.erp_size
-    over = {} if a.density_shift is None else dict(density_shift=a.density_shift)
-    cfg = synth.SceneConfig(**dict(synth.RICOH, **over))
-    weights = synth.make_weights(cfg, seed=1234)
-    model = synth.build_model(cfg, weights, dev)
-    # 16384-ray chunks: the per-chunk workspace (coords, colours, weights: 150 MB at 256 samples) then stays inside the 256 MB Infinity
-    # Cache between the march that writes it and the shade / composite that read it (65536: 0.168-0.171 s per image, 16384: 0.165)
-    chunk = int(os.environ.get("EGO_ERP_CHUNK", "16384"))
-    kw = dict(chunk=chunk, n_coarse=ERP_NC, n_fine=ERP_NF, exp_sampling=True, resampling=True, use_coarse_sample=True, device=dev,
-              keep_alpha=False)  # an image render reads rgb only (renderer.py:125-157)
-    row0, row1 = shard_bounds(H, rk.world, rk.rank)  # contiguous block of rows per rank
-    K = a.views or max(a.steps, 1)
-    state = dict(k=0)
-
-    def render(k):
-        rays = erp_rays(H, W, erp_pose(k, K), dev, row0, row1 - row0)
-        return volume_renderer(rays, model, **kw)[0]
-
-    def step():
-        state["last"] = render(state["k"] % K)
-        state["k"] += 1
-
-    # reference images for the PSNR column: the same views with the fp32-MFMA arithmetic and no skipping
-    with torch.no_grad():
-        default_prec = model.mlp_precision
-        model.mlp_precision = "f32"
-        refs = [render(k) for k in range(min(K, 2))]
-        model.mlp_precision = default_prec
-        occupied = None
-        if a.mask:
-            occupied = model.updateAlphaMask()
-            model.use_alpha_mask = True
-        model.early_termination_eps = a.term_eps
-        dt = timed(rk, step, a.steps, a.warmup)
-        psnrs = []
-        for k, ref in enumerate(refs):
-            d = render(k).double() - ref.double()
-            stat = torch.stack([(d * d).sum(), torch.tensor(float(d.numel()), device=dev, dtype=torch.float64)])
-            if rk.dist is not None:
-                stat = stat.cpu() if rk.shared else stat
-                rk.dist.all_reduce(stat)
-            psnrs.append(psnr_from_sse(max(stat[0].item(), 1e-300), stat[1].item()))
-    if rk.rank != 0:
-        return None
-    # ---- per-chunk kernel split, event-timed through the stage entry points (the same five launches ego_render_forward queues) ----
+    dev = rays_c.device
     lib, st = _lib.load(), _lib.stream_handle()
     sc = model.scene()
-    N, S = chunk, ERP_NC + ERP_NF
-    rays_c = erp_rays(H, W, erp_pose(0, K), dev, H // 3, max(1, -(-N // W)))[:N].contiguous()   # a chunk from the image's middle third
-    N = rays_c.shape[0]
+    N, S = rays_c.shape[0], ERP_NC + ERP_NF
     f = lambda *shape: torch.empty(*shape, device=dev, dtype=torch.float32)
     sched = model._sched(ERP_NC, dev)
     zc, wc, z, w, bg, crd, rgb = f(N, ERP_NC), f(N, ERP_NC), f(N, S), f(N, S), f(N), f(N, S, 4), f(N, S, 3)
@@ -830,7 +910,6 @@ def run_erp(a, rk: Ranks):
     rgb_map, depth, bgm, envm = f(N, 3), f(N), f(N, 3), f(N, 3)
     near = float(model.near_far[0])
     names = ("k_march_density(coarse)", "k_sample_pdf_merge", "k_march_density(fine)", "k_shade", "k_composite")
-    reps = 12
     evs = [[torch.cuda.Event(enable_timing=True) for _ in range(6)] for _ in range(reps)]
     for i in range(reps + 2):
         e = evs[max(i - 2, 0)]
@@ -850,47 +929,148 @@ def run_erp(a, rk: Ranks):
         e[5].record()
     torch.cuda.synchronize()
     ms = np.array([[e[k].elapsed_time(e[k + 1]) for k in range(5)] for e in evs]).mean(0)
-    split = {n: float(v) for n, v in zip(names, ms)}
-    tiles_skipped = float((act[: N * S // 32] == 0).float().mean())
-    roofline = shade_roofline(model.mlp_precision, float(ms[3]) * 1e-3, N * S)
+    return {n: float(v) for n, v in zip(names, ms)}, float((act[: N * S // 32] == 0).float().mean())
+
+
+def run_erp(a, rk: Ranks):
+    from egonerf_amd.renderer import erp_rays, psnr_from_sse, shard_bounds, volume_renderer
+    dev = rk.dev
+    H, W = a.erp_size
+    over = {} if a.density_shift is None else dict(density_shift=a.density_shift)
+    cfg = synth.SceneConfig(**dict(synth.RICOH, **over))
+    weights = synth.make_weights(cfg, seed=1234)
+    carve = bool(getattr(a, "carve", False))
+    if carve:   # real empty space: what the reference's occupancy mask is for (BASELINE configs[2] "empty-space skipping on")
+        weights = synth.carve_empty_space(weights, cfg)
+    mask_ab = carve and a.mask
+    model = synth.build_model(cfg, weights, dev)
+    # 16384-ray chunks: the per-chunk workspace (coords, colours, weights: 150 MB at 256 samples) then stays inside the 256 MB Infinity
+    # Cache between the march that writes it and the shade / composite that read it (65536: 0.168-0.171 s per image, 16384: 0.165)
+    chunk = int(os.environ.get("EGO_ERP_CHUNK", "16384"))
+    kw = dict(chunk=chunk, n_coarse=ERP_NC, n_fine=ERP_NF, exp_sampling=True, resampling=True, use_coarse_sample=True, device=dev,
+              keep_alpha=False)  # an image render reads rgb only (renderer.py:125-157)
+    row0, row1 = shard_bounds(H, rk.world, rk.rank)  # contiguous block of rows per rank
+    K = a.views or max(a.steps, 1)
+    state = dict(k=0)
+
+    def render(k):
+        rays = erp_rays(H, W, erp_pose(k, K), dev, row0, row1 - row0)
+        return volume_renderer(rays, model, **kw)[0]
+
+    def step():
+        state["last"] = render(state["k"] % K)
+        state["k"] += 1
+
+    def all_max(v: float) -> float:
+        t = torch.tensor([v], dtype=torch.float64, device="cpu" if rk.shared else dev)
+        if rk.dist is not None:
+            rk.dist.all_reduce(t, op=rk.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    rays_c = erp_rays(H, W, erp_pose(0, K), dev, H // 3, max(1, -(-chunk // W)))[:chunk].contiguous()   # a chunk from the image's middle third
+    mask_info = None
+    with torch.no_grad():
+        occupied = None
+        if a.mask:   # the reference's mask construction (EgoNeRF.py:437-489) on this field; applied as TensorBase.forward does (tensorBase.py:464-478)
+            occupied = model.updateAlphaMask()
+            model.use_alpha_mask = True
+        # reference images for the PSNR column: the same views with the fp32-MFMA arithmetic (and the same mask) and no lossy skipping
+        default_prec = model.mlp_precision
+        model.mlp_precision = "f32"
+        refs = [render(k) for k in range(min(K, 2))]
+        model.mlp_precision = default_prec
+        if mask_ab:   # the same field and views with the mask OFF first (EgoNeRF.forward as written: every sample evaluated)
+            model.use_alpha_mask = False
+            dt_off = timed(rk, step, a.steps, a.warmup)
+            imgs_off = [render(k) for k in range(min(K, 2))]
+            split_off, skipped_off = erp_chunk_split(model, rays_c) if rk.rank == 0 else (None, None)
+            state["k"] = 0
+            model.use_alpha_mask = True
+        model.early_termination_eps = a.term_eps
+        dt = timed(rk, step, a.steps, a.warmup)
+        spread = rk.rank_step_ms(a.steps)
+        psnrs = []
+        imgs_on = []
+        for k, ref in enumerate(refs):
+            img = render(k)
+            imgs_on.append(img)
+            d = img.double() - ref.double()
+            stat = torch.stack([(d * d).sum(), torch.tensor(float(d.numel()), device=dev, dtype=torch.float64)])
+            if rk.dist is not None:
+                stat = stat.cpu() if rk.shared else stat
+                rk.dist.all_reduce(stat)
+            psnrs.append(psnr_from_sse(max(stat[0].item(), 1e-300), stat[1].item()))
+        psnr_same = rk.same_on_all_ranks(psnrs)   # the all-reduced statistics must give every rank the same PSNR (renderer.py:156-157)
+        if mask_ab:
+            diff = [float((on - off).abs().max()) for on, off in zip(imgs_on, imgs_off)]
+            mean = [float((on - off).abs().mean()) for on, off in zip(imgs_on, imgs_off)]
+            mask_info = dict(occupied_fraction=occupied, s_per_image_mask_off=dt_off / a.steps, s_per_image_mask_on=dt / a.steps,
+                             speedup=dt_off / dt, max_abs_rgb_masked_vs_unmasked=all_max(max(diff)), mean_abs_rgb_masked_vs_unmasked=max(mean),
+                             note="mask built by updateAlphaMask (EgoNeRF.py:437-489) from this field's own density, applied with TensorBase.forward's "
+                                  "semantics (sigma = 0 where the trilinear mask value is <= 0, tensorBase.py:464-478); the march skips the gather "
+                                  "of 64-sample passes that are masked out entirely and the shade skips 32-sample tiles whose weights are all 0; "
+                                  "masked vs unmasked differs because 'empty' space still has sigma = softplus(density_shift) in the unmasked render "
+                                  "(the reference's rule drops it); parity (below) is against the oracle WITH THE SAME MASK")
+        del imgs_on
+    if rk.rank != 0:
+        return None
+    # ---- per-chunk kernel split, event-timed through the stage entry points (the same five launches ego_render_forward queues) ----
+    split, tiles_skipped = erp_chunk_split(model, rays_c)
+    ms_sum = float(sum(split.values()))
+    N, S = rays_c.shape[0], ERP_NC + ERP_NF
+    roofline = shade_roofline(model.mlp_precision, split["k_shade"] * 1e-3, N * S)
     pmc, src, stale = load_pmc_section("erp_image")
     t_img = dt / a.steps
-    if pmc is not None and pmc.get("traffic_bytes") is not None:   # whole-image counters replace the headline kernel's per-launch ones
+    if pmc is not None and pmc.get("traffic_bytes") is not None and not carve:   # whole-image counters replace the headline kernel's per-launch ones
         roofline.update(traffic=pmc["traffic_bytes"], hbm_counter_frac=pmc["traffic_bytes"] / t_img / (HBM_PEAK_GBPS * 1e9),
                         traffic_scope="one whole image (every kernel of every chunk), " + str(src), traffic_stale_vs_current_sources=stale)
     else:
         roofline.update(traffic=None, hbm_counter_frac=None)
     for k in ("issue", "l1", "inputs", "matrix_pipe_busy", "executed_TFLOPs"):   # those are derived from the 4096 x 512 launch's counters
         roofline.pop(k, None)
-    roofline.update(chunk_rays=N, chunk_samples_per_ray=S, chunk_kernels_ms=split, chunk_kernels_ms_sum=float(ms.sum()),
+    roofline.update(chunk_rays=N, chunk_samples_per_ray=S, chunk_kernels_ms=split, chunk_kernels_ms_sum=ms_sum,
                     chunks_per_image=-(-(row1 - row0) * W // chunk), exact_zero_weight_tiles_skipped_frac_in_chunk=tiles_skipped,
-                    note="dominant kernel = k_shade on one chunk (flops as in the headline); chunk_kernels_ms = the five launches of a chunk, event "
-                         "timed through the stage entry points; traffic = counter HBM bytes of one whole image")
+                    note="dominant kernel = k_shade on one chunk (flops as in the headline; with tiles skipped `frac` counts the flops of ALL "
+                         "samples of the chunk against the time of the tiles that ran, i.e. it is an effective rate); chunk_kernels_ms = the five "
+                         "launches of a chunk, event timed through the stage entry points; traffic = counter HBM bytes of one whole image")
+    if mask_ab:
+        roofline.update(chunk_kernels_ms_mask_off=split_off, exact_zero_weight_tiles_skipped_frac_in_chunk_mask_off=skipped_off)
     cpu = parity = None
     if not a.no_cpu_baseline and rk.world == 1:
         try:
-            cpu, ref_out, cpu_rays, pick = cpu_baseline_erp(cfg, weights, H, W, 4096)
+            am = None
+            if a.mask and model.alphaMask is not None:
+                am = (model.alphaMask.alpha_volume_yin.cpu(), model.alphaMask.alpha_volume_yang.cpu())
+            cpu, ref_out, cpu_rays, pick = cpu_baseline_erp(cfg, weights, H, W, 4096, alpha_mask=am)
             with torch.no_grad():
                 got = volume_renderer(cpu_rays.to(dev), model, **kw)   # the oracle's own rays: the ray generators are compared in tests/test_hip_ricoh.py
             err = float((got[0].cpu() - ref_out[0]).abs().max())
             mse = float(((got[0].cpu() - ref_out[0]) ** 2).mean())
             parity = dict(max_abs_rgb_err=err, psnr_vs_oracle_db=float(-10 * np.log10(max(mse, 1e-30))), rays=int(pick.numel()),
+                          alpha_mask_applied_in_both=am is not None,
                           note="a sample within an ulp of a yin/yang border may land on the other grid with another libm (DESIGN.md 2); "
                                "tests/test_hip_ricoh.py handles that case explicitly", tolerance=dict(rgb=1e-4))
         except Exception as e:
             cpu = dict(error=repr(e))
     rays_per_s = H * W / t_img
-    return dict(metric="rays/sec, full equirectangular image render (128 coarse + 128 fine samples, envmap on)", value=rays_per_s,
+    line = dict(metric="rays/sec, full equirectangular image render (128 coarse + 128 fine samples, envmap on)", value=rays_per_s,
                 unit="rays/s", samples_per_s=rays_per_s * 384, n_gpus=rk.world, steps=a.steps, warmup=a.warmup, clock_ramp_s=RAMP_SECONDS,
-                ms_per_step=t_img * 1e3, s_per_image=t_img, higher_is_better=True, scaling="strong", vs_baseline=None,
+                ms_per_step=t_img * 1e3, s_per_image=t_img, rank_step_ms=spread, psnr_identical_on_all_ranks=psnr_same,
+                row_shards=[list(shard_bounds(H, rk.world, r)) for r in range(rk.world)],
+                higher_is_better=True, scaling="strong", vs_baseline=None,
                 dtype=f"f32 (matrix products: mlp_precision = {model.mlp_precision}, fp32 accumulate)", data="synthetic",
-                config=dict(workload=f"Ricoh360-like scene (near_far [0.1,300], r0 0.05, shift {cfg.density_shift:g}, envmap 3x3840x1920, grid [150,172,516]); "
+                config=dict(workload=f"Ricoh360-like scene (near_far [0.1,300], r0 0.05, shift {cfg.density_shift:g}, envmap 3x3840x1920, grid [150,172,516]"
+                                     + (", density carved to two radial shells minus a phi wedge: real empty space" if carve else "") + "); "
                                      f"a step = one {H}x{W} ERP image, rays generated on the device, rows sharded over the ranks, exact zero-weight "
-                                     f"tile skip on (BASELINE configs[2]; configs[4] at --gpus 8)",
+                                     f"tile skip on" + (", occupancy-grid empty-space skipping ON" if a.mask else "") +
+                                     " (BASELINE configs[2]; configs[4] at --gpus 8)",
                             alpha_mask=bool(a.mask), alpha_mask_occupied_fraction=occupied, term_eps=a.term_eps,
                             parallelism=f"row-sharded x{rk.world}"),
                 psnr_vs_f32_unskipped_db=psnrs, roofline=roofline, cpu_baseline=cpu, parity=parity,
                 speedup_vs_cpu=None if not cpu or "value" not in cpu else rays_per_s / cpu["value"])
+    if mask_info is not None:
+        line["mask"] = mask_info
+    return line
 
 
 def run_secondary(a, rk: Ranks):
@@ -906,10 +1086,14 @@ def run_secondary(a, rk: Ranks):
             setattr(b, k, v)
         return b
 
-    jobs = (("train", run_train, sub(config="train", steps=5, warmup=2, train_reg=False)),
-            ("erp", run_erp, sub(config="erp", steps=2, warmup=1, views=2, erp_size=[1024, 2048], mask=False, term_eps=0.0, density_shift=None)),
+    jobs = (("render_fresh_rays", run_render_variant, sub(config="render", steps=128, warmup=8, fresh_rays=64, n_voxel=None)),
+            ("render_big_grid", run_render_variant, sub(config="render", steps=64, warmup=8, fresh_rays=64, n_voxel=216e6)),
+            ("train", run_train, sub(config="train", steps=5, warmup=2, train_reg=False)),
+            ("erp", run_erp, sub(config="erp", steps=2, warmup=1, views=2, erp_size=[1024, 2048], mask=False, carve=False, term_eps=0.0, density_shift=None)),
+            ("erp_masked", run_erp, sub(config="erp", steps=2, warmup=1, views=2, erp_size=[1024, 2048], mask=True, carve=True, term_eps=0.0,
+                                        density_shift=None)),
             ("erp_opaque_field", run_erp, sub(config="erp", steps=2, warmup=1, views=2, erp_size=[1024, 2048], mask=False, term_eps=0.0,
-                                              density_shift=0.0, no_cpu_baseline=True)))
+                                              density_shift=0.0, carve=False, no_cpu_baseline=True)))
     for name, fn, args in jobs:
         t0 = time.perf_counter()
         try:
@@ -929,8 +1113,9 @@ def main():
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return self_launch(a)
     rk = Ranks(a)
-    line = dict(render=run_render, train=run_train, erp=run_erp)[a.config](a, rk)
-    if a.config == "render" and rk.world == 1 and not a.no_secondary and a.density_shift is None:
+    variant = a.config == "render" and (a.n_voxel or a.fresh_rays)
+    line = (run_render_variant if variant else dict(render=run_render, train=run_train, erp=run_erp)[a.config])(a, rk)
+    if a.config == "render" and not variant and rk.world == 1 and not a.no_secondary and a.density_shift is None:
         line["secondary"] = run_secondary(a, rk)
     if rk.rank == 0:
         line["process_group"] = None if rk.dist is None else rk.dist.get_backend()   # "nccl" = RCCL on ROCm

@@ -342,8 +342,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     const float a_r = normalize_r_fast(y.r, lut, c.n_lut, c.n_r, H);
     const float a_th = normalize_ang(y.th, c.th_near, c.th_inv);
     const float a_ph = normalize_ang(y.ph, c.ph_near, c.ph_inv);
-    // occupancy mask (opt-in): unoccupied samples keep sigma = 0 and skip the 18-tap gather
+    // occupancy mask (opt-in): unoccupied samples keep sigma = 0
     const bool occupied = !OCC || !occ.vol || occ_sample(occ, y.yang, a_r, a_th, a_ph) > 0.f;
+    // a pass whose 64 samples are ALL masked out skips the set-up hand-over and the whole gather (wave-uniform: the software
+    // pipeline of phase B is either run completely or not at all, so its wait counts stay exact); sigma is 0 for every lane then
+    const bool pass_occupied = !OCC || __ballot(occupied) != 0ull;
+    if (pass_occupied) {
     {
       // byte offsets of every tap row / line of the sample's grid (the grid's table offsets folded in here, once per sample, so
       // that phase B needs no per-lane table select) + column offsets + the six axis weights
@@ -433,8 +437,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }  // pass_occupied
     // ---- phase C: lane = sample ------------------------------------------------------------------------------------------
-    const float f = fres[wv][lane];
+    const float f = pass_occupied ? fres[wv][lane] : 0.f;
     float sg = 0.f;
     if (occupied) sg = softplus ? softplus_shift(f, shift) : fmaxf(f, 0.f);
     const float a = ok ? alpha_from(sg * __fmul_rn(dist, dscale)) : 0.f;

@@ -167,6 +167,39 @@ def make_weights(cfg: SceneConfig, seed: int = 1234, mlp_gain: float = 3.0) -> D
     return out
 
 
+def carve_empty_space(weights: Dict[str, np.ndarray], cfg: SceneConfig, r_keep=((0.14, 0.30), (0.54, 0.68)), phi_cut=(0.0, 0.28),
+                       density_gain: float = 1.0) -> Dict[str, np.ndarray]:
+    """A copy of `weights` whose DENSITY field has real empty space, like a trained scene: the density feature is exactly 0 outside
+    the radial shells `r_keep` and inside the phi wedge `phi_cut` (fractions of the r / phi index ranges; both grids alike), so that
+    sigma = softplus(density_shift) there and the reference's alpha-mask rule (EgoNeRF.py:437-489: lattice alpha >= 1e-4 after a 3^3
+    max-pool) marks those voxels empty.  Zeroing the factors of every VM term does it exactly: for r outside the shells planes 0, 1
+    (x = r) and line 2 (r); inside the wedge planes 1, 2 (y = phi) and line 0 (phi).  Bilinear taps make the transition one texel
+    wide.  The appearance field is untouched (the reference's mask acts on sigma only)."""
+    n_r, _n_th, n_ph = cfg.grid
+    r_idx = np.arange(n_r) / max(n_r - 1, 1)
+    keep_r = np.zeros(n_r, bool)
+    for lo, hi in r_keep:
+        keep_r |= (r_idx >= lo) & (r_idx < hi)
+    ph_idx = np.arange(n_ph) / max(n_ph - 1, 1)
+    keep_ph = ~((ph_idx >= phi_cut[0]) & (ph_idx < phi_cut[1]))
+    out = dict(weights)
+    for g in ("yin", "yang"):
+        p0 = weights[f"density_plane_{g}.0"].copy() * density_gain   # (1, C, N_theta, N_r)
+        p1 = weights[f"density_plane_{g}.1"].copy() * density_gain   # (1, C, N_phi, N_r)
+        p2 = weights[f"density_plane_{g}.2"].copy() * density_gain   # (1, C, N_phi, N_theta)
+        l0 = weights[f"density_line_{g}.0"].copy()                   # (1, C, N_phi, 1)
+        l2 = weights[f"density_line_{g}.2"].copy()                   # (1, C, N_r, 1)
+        p0[..., ~keep_r] = 0
+        p1[..., ~keep_r] = 0
+        l2[:, :, ~keep_r, :] = 0
+        p1[:, :, ~keep_ph, :] = 0
+        p2[:, :, ~keep_ph, :] = 0
+        l0[:, :, ~keep_ph, :] = 0
+        out.update({f"density_plane_{g}.0": p0, f"density_plane_{g}.1": p1, f"density_plane_{g}.2": p2,
+                    f"density_line_{g}.0": l0, f"density_line_{g}.2": l2})
+    return out
+
+
 def white_envmap(seed: int, h: int) -> np.ndarray:
     """[3, 2h, h] fp32 emission map of independent uniforms in [-3, 3) (pre-sigmoid), for index-exact envmap tests."""
     return ((hash_uniform(seed, 7, 3 * 2 * h * h) * 6 - 3).reshape(3, 2 * h, h)).astype(np.float32)

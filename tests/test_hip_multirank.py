@@ -156,6 +156,23 @@ def test_bench_default_line_contract():
     assert erp["cpu_baseline"]["value"] > 0 and erp["speedup_vs_cpu"] > 10
     assert opaque["roofline"]["exact_zero_weight_tiles_skipped_frac_in_chunk"] > erp["roofline"]["exact_zero_weight_tiles_skipped_frac_in_chunk"]
     assert opaque["value"] > erp["value"]   # the exact skip pays on a surface-like field
+    # memory-system evidence: a different ray batch every step, and a table set larger than the Infinity Cache
+    fresh, big = d["secondary"]["render_fresh_rays"], d["secondary"]["render_big_grid"]
+    assert "error" not in fresh and "error" not in big, (fresh.get("error"), big.get("error"))
+    assert fresh["config"]["ray_batches"] == 64 and fresh["roofline"]["bound"] == "hbm" and fresh["roofline"]["tables_fit_infinity_cache"] is True
+    assert 0.8 * d["value"] < fresh["value"] < 1.1 * d["value"]        # fresh rays cost at most a few per cent on the cache-resident grid
+    assert big["roofline"]["tables_fit_infinity_cache"] is False and big["roofline"]["table_bytes"] > 256 * 2 ** 20
+    assert big["roofline"]["frac"] > 0 and big["value"] > 0
+    # BASELINE configs[2] as written: occupancy-grid empty-space skipping ON (mask-off and mask-on on the same carved field)
+    masked = d["secondary"]["erp_masked"]
+    assert "error" not in masked, masked.get("error")
+    mk = masked["mask"]
+    assert masked["config"]["alpha_mask"] is True and 0.05 < mk["occupied_fraction"] <= 0.5
+    assert mk["s_per_image_mask_on"] < mk["s_per_image_mask_off"] and mk["speedup"] > 1.2
+    assert masked["parity"]["alpha_mask_applied_in_both"] is True and masked["parity"]["max_abs_rgb_err"] <= 1e-4
+    assert masked["roofline"]["exact_zero_weight_tiles_skipped_frac_in_chunk"] > masked["roofline"]["exact_zero_weight_tiles_skipped_frac_in_chunk_mask_off"]
+    assert masked["roofline"]["chunk_kernels_ms"]["k_march_density(fine)"] < masked["roofline"]["chunk_kernels_ms_mask_off"]["k_march_density(fine)"]
+    assert masked["cpu_baseline"]["value"] > 0
 
 
 def test_bench_train_and_erp_configs_run():
@@ -166,3 +183,26 @@ def test_bench_train_and_erp_configs_run():
     env = {"EGO_BENCH_TEST_SHARED_GPU": "1"}
     d = _bench("--config", "erp", "--gpus", "2", "--steps", "1", "--warmup", "1", "--erp-size", "128", "256", env_extra=env)
     assert d["n_gpus"] == 2 and d["psnr_vs_f32_unskipped_db"][0] > 80
+
+
+def test_bench_erp_eight_ranks_dry_run_on_one_gpu():
+    """BASELINE configs[4] without an 8-GPU node: `bench.py --gpus 8 --config erp --steps 1` with all eight ranks
+    on this box's one GPU over gloo (EGO_BENCH_TEST_SHARED_GPU=1) - the launcher, the row shards of 8 ranks, the all-reduced PSNR
+    (identical on every rank, equal to the 1-rank value to 1e-9) and a JSON line with n_gpus = 8 that carries every rank's step time.
+    Matches SURVEY 8(e); renderer.py:156-157,185-193."""
+    args = ("--config", "erp", "--steps", "1", "--warmup", "1", "--views", "1", "--erp-size", "512", "1024", "--no-cpu-baseline")
+    one = _bench(*args)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["EGO_BENCH_TEST_SHARED_GPU"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "8", *args], capture_output=True, text=True, timeout=1500, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["scaling"] == "strong" and d["process_group"] == "gloo"
+    assert d["row_shards"] == [[64 * k, 64 * (k + 1)] for k in range(8)]     # 512 rows over 8 ranks, contiguous blocks
+    assert d["psnr_identical_on_all_ranks"] is True
+    assert abs(d["psnr_vs_f32_unskipped_db"][0] - one["psnr_vs_f32_unskipped_db"][0]) <= 1e-9
+    sp = d["rank_step_ms"]
+    assert len(sp["per_rank"]) == 8 and sp["min"] <= sp["max"] and abs(sp["max"] - d["ms_per_step"]) < 1e-9
+    assert one["rank_step_ms"]["per_rank"] == [one["ms_per_step"]] and one["row_shards"] == [[0, 512]]

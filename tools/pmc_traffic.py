@@ -76,7 +76,18 @@ for key, prefix, unit_like, what in (("train_step", "pmctrain", "k_adam", "one t
     sec = whole_step(prefix, unit_like, what)
     if sec is not None:
         out[key] = sec
-out["_source"] = f"gpurun_out/prof_{tag} (tools/profile_r03.sh {tag}; separate rocprofv3 --pmc passes of `bench.py --steps 10 --warmup 2`, `--config train`, `--config erp`)"
+# render variants (bench.py --fresh-rays / --n-voxel): HBM bytes of the two grid-sample kernels per step
+for key, prefix, what in (("big_grid", "pmcbig", "one step of bench.py --n-voxel 216e6 --fresh-rays 64 (grid [300,346,1036], ~400 MB of tables): k_march_density + k_shade_h"),
+                          ("fresh_rays", "pmcfresh", "one step of bench.py --fresh-rays 64 (headline grid, a different ray batch every step): k_march_density + k_shade_h")):
+    sec = whole_step(prefix, "k_composite", what)
+    if sec is not None:
+        pk = {k: v for k, v in sec["per_kernel"].items() if "k_march_density" in k or "k_shade" in k}
+        sec["per_kernel"] = pk
+        sec["hbm_read_bytes_corrected"] = sum(v["read_bytes"] for v in pk.values())
+        sec["hbm_write_bytes"] = sum(v["write_bytes"] for v in pk.values())
+        sec["traffic_bytes"] = sec["hbm_read_bytes_corrected"] + sec["hbm_write_bytes"]
+        out[key] = sec
+out["_source"] = f"gpurun_out/prof_{tag} (tools/profile_r03.sh / profile_r04.sh {tag}; separate rocprofv3 --pmc passes of `bench.py --steps 10 --warmup 2`, `--config train`, `--config erp`)"
 out["_source_hash"] = source_hash()
 dst = out_path or os.path.join(root, "profiles", rnd, "pmc_traffic.json")
 os.makedirs(os.path.dirname(dst), exist_ok=True)
