@@ -37,7 +37,7 @@ class Scene(C.Structure):
         ("packed", C.c_void_p), ("envmap", C.c_void_p), ("envmap_h", C.c_int32), ("mlp_precision", C.c_int32),
         ("occ", C.c_void_p), ("occ_res", C.c_int32 * 3), ("term_eps", C.c_float),
         ("app16", VmField), ("app_f16", C.c_int32), ("n_r_lut_fine", C.c_int32), ("r_lut_fine", C.c_void_p), ("n_r_fine", C.c_int32),
-        ("weight_thres", C.c_float),
+        ("weight_thres", C.c_float), ("occ_cell", C.c_void_p),
     ]
 
 

@@ -81,8 +81,9 @@ __global__ __launch_bounds__(128) void k_shade_generic(GenShadeArgs A) {
   const GenLayout L = gen_layout(A.in_c, HID, A.n_comp);
   const int64_t n_units = (A.M + 63) >> 6;
   for (int64_t unit = (int64_t)blockIdx.x * 2 + wv; unit < n_units; unit += (int64_t)gridDim.x * 2) {
-    if (MODE == G_SHADE && A.tile_active && (A.M & 63) == 0) {   // two 32-sample tiles per unit: skip when neither is read
-      if (!A.tile_active[2 * unit] && !A.tile_active[2 * unit + 1]) continue;
+    if (MODE == G_SHADE && A.tile_active) {   // two 32-sample tiles per unit (the last unit of a ragged M may hold one): skip when neither is read
+      const int64_t n_tiles = (A.M + 31) >> 5, t1 = 2 * unit + 1;
+      if (!A.tile_active[2 * unit] && !(t1 < n_tiles && A.tile_active[t1])) continue;
     }
     const int64_t m_raw = unit * 64 + lane;
     const bool valid = m_raw < A.M;

@@ -149,6 +149,7 @@ __global__ void k_raw2alpha(const float* __restrict__ sigma, const float* __rest
 struct DevOcc {
   const uint8_t* vol;  // [2][res2][res1][res0] or null
   int32_t res[3];
+  const uint8_t* cell; // optional [2][res2-1][res1-1][res0-1]: OR of the 8 corner voxels of every cell (ego_scene.occ_cell)
 };
 
 __device__ __forceinline__ float occ_sample(const DevOcc& O, int g, float a_r, float a_th, float a_ph) {
@@ -162,6 +163,21 @@ __device__ __forceinline__ float occ_sample(const DevOcc& O, int g, float a_r, f
     v += w * (float)V[((int64_t)iz * O.res[1] + iy) * O.res[0] + ix];
   }
   return v;
+}
+
+// "mask value > 0" (tensorBase.py:464-478) for the march: a sample strictly inside a cell (all six axis weights > 0, all taps in
+// range) has a positive trilinear value iff any of the cell's eight corner voxels is set - one byte of the per-cell OR volume instead
+// of eight dependent byte loads and the interpolation; samples on a lattice plane / outside the volume take the exact evaluation
+__device__ __forceinline__ bool occ_occupied(const DevOcc& O, int g, float a_r, float a_th, float a_ph) {
+  if (O.cell) {
+    const Lin1 X = lin_setup(a_r, O.res[0]), Y = lin_setup(a_th, O.res[1]), Z = lin_setup(a_ph, O.res[2]);
+    const bool interior = fminf(fminf(fminf(X.w0, X.w1), fminf(Y.w0, Y.w1)), fminf(Z.w0, Z.w1)) > 0.f;
+    if (interior) {
+      const int64_t c0 = O.res[0] - 1, c1 = O.res[1] - 1, c2 = O.res[2] - 1;
+      return O.cell[(((int64_t)g * c2 + Z.i0) * c1 + Y.i0) * c0 + X.i0] != 0;
+    }
+  }
+  return occ_sample(O, g, a_r, a_th, a_ph) > 0.f;
 }
 
 __global__ void k_alpha_mask_sample(DevOcc O, const float* __restrict__ c7n, int64_t M, float* __restrict__ out) {
@@ -343,7 +359,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     const float a_th = normalize_ang(y.th, c.th_near, c.th_inv);
     const float a_ph = normalize_ang(y.ph, c.ph_near, c.ph_inv);
     // occupancy mask (opt-in): unoccupied samples keep sigma = 0
-    const bool occupied = !OCC || !occ.vol || occ_sample(occ, y.yang, a_r, a_th, a_ph) > 0.f;
+    const bool occupied = !OCC || !occ.vol || occ_occupied(occ, y.yang, a_r, a_th, a_ph);
     // a pass whose 64 samples are ALL masked out skips the set-up hand-over and the whole gather (wave-uniform: the software
     // pipeline of phase B is either run completely or not at all, so its wait counts stay exact); sigma is 0 for every lane then
     const bool pass_occupied = !OCC || __ballot(occupied) != 0ull;
@@ -986,6 +1002,7 @@ static DevOcc make_occ(const ego_scene& sc, int coarse) {
   DevOcc o;
   o.vol = coarse ? nullptr : sc.occ;  // the coarse (proposal) pass always sees the full field
   o.res[0] = sc.occ_res[0]; o.res[1] = sc.occ_res[1]; o.res[2] = sc.occ_res[2];
+  o.cell = (o.vol && o.res[0] >= 2 && o.res[1] >= 2 && o.res[2] >= 2) ? sc.occ_cell : nullptr;
   return o;
 }
 

@@ -251,7 +251,7 @@ class YinYangAlphaGridMask(torch.nn.Module):
         self.device = device
         self.alpha_volume_yin = alpha_volume_yin.view(1, 1, *alpha_volume_yin.shape[-3:])
         self.alpha_volume_yang = alpha_volume_yang.view(1, 1, *alpha_volume_yang.shape[-3:])
-        self._bytes = None
+        self._bytes = self._cells = None
 
     def packed(self) -> torch.Tensor:
         """[2][N_phi][N_theta][N_r] uint8 (what the kernels read)."""
@@ -259,10 +259,22 @@ class YinYangAlphaGridMask(torch.nn.Module):
             self._bytes = torch.stack([self.alpha_volume_yin[0, 0], self.alpha_volume_yang[0, 0]]).gt(0).to(torch.uint8).contiguous()
         return self._bytes
 
+    def cell_or(self) -> Optional[torch.Tensor]:
+        """[2][N_phi-1][N_theta-1][N_r-1] uint8: OR of every cell's eight corner voxels (ego_scene.occ_cell: the march's one-byte
+        answer to "trilinear mask value > 0" for samples strictly inside a cell)."""
+        vol = self.packed()
+        if min(vol.shape[1:]) < 2:
+            return None
+        if self._cells is None:
+            self._cells = torch.nn.functional.max_pool3d(vol.float()[None], kernel_size=2, stride=1)[0].to(torch.uint8).contiguous()
+        return self._cells
+
     def fill_scene(self, sc):
         vol = self.packed()
         sc.occ = vol.data_ptr()
         sc.occ_res[:] = [vol.shape[3], vol.shape[2], vol.shape[1]]
+        cells = self.cell_or()
+        sc.occ_cell = None if cells is None else cells.data_ptr()
 
     @_lib.device_guard
     def sample_alpha(self, norm_samples):
@@ -486,6 +498,12 @@ class EgoNeRF(TensorBase):
         cur = [getattr(self, f"coarse_sigma_{what}_{g}")[i] for (g, what, i, _src) in srcs]
         same = all(c is not None and c.device == src.device and tuple(c.shape) == (1, C_, H, W)
                    for c, (C_, H, W), (*_k, src) in zip(cur, shapes, srcs))
+        if same:
+            # ... and only while they still form ONE carved buffer: a caller may have assigned coarse_sigma_* one by one (separate
+            # allocations have no bounded distance, and the march addresses a tap as base + 32-bit offset: ADVICE r03)
+            lo = min(c.data_ptr() for c in cur)
+            hi = max(c.data_ptr() + c.numel() * c.element_size() for c in cur)
+            same = hi - lo < (1 << 32) and all(c.dtype == torch.float32 and c.permute(0, 2, 3, 1).is_contiguous() for c in cur)
         if not same:
             dsts = _carve_channel_last(shapes, srcs[0][3].device)   # one buffer: compact addressing like the full tables
             for (g, what, i, src), dst in zip(srcs, dsts):
@@ -602,7 +620,13 @@ class EgoNeRF(TensorBase):
 
     @_lib.device_guard
     def scene(self) -> "_lib.Scene":
-        """The ego_scene struct for the current parameters (re-packs the MFMA weights when they changed)."""
+        """The ego_scene struct for the current parameters (re-packs the MFMA weights when they changed).
+
+        The struct holds raw device pointers: to the parameter tables (optimiser steps write them in place), and to the pooled density
+        tables, which `update_coarse_sigma_grid()` also refreshes IN PLACE while their shapes stand - so a struct returned earlier, or a
+        captured hipGraph that embeds it, reads the refreshed values (what GraphedTrainStep relies on).  A holder that needs a frozen
+        snapshot must copy the tables; re-allocation (another shape / device, tables assigned one by one) invalidates the cached
+        struct and the next scene() call builds a new one."""
         dev = self.density_plane_yin[0].device
         if dev.type != "cuda":
             raise RuntimeError(f"model parameters are on {dev}; the EgoNeRF hot path runs only on the HIP device")
@@ -827,8 +851,10 @@ class EgoNeRF(TensorBase):
             z_coarse = self.sample_ray_z(rays, n_coarse, jitter.to(dev) if is_train else None)
             if not is_train:
                 if N and not bool((z_coarse[:, 0] == z_coarse[0, 0]).all()):
-                    raise NotImplementedError("exp_sampling=False in eval mode with rays that enter the aabb at different distances: "
-                                              "the reference then measures every ray with ray 0's distances (EgoNeRF.py:515-516)")
+                    # rays that enter the aabb at different distances: the reference places the first-pass samples per ray but
+                    # measures every ray with ray 0's distances (EgoNeRF.py:515-516) - evaluated the same way, stage by stage
+                    return self._forward_eval_ray0_distances(rays, z_coarse, int(n_coarse), int(n_fine), bool(resampling),
+                                                             bool(use_coarse_sample), need_alpha)
             jitter = None
         if is_train and exp_sampling and not self.coordinates.interval_th:
             if jitter is None:
@@ -876,6 +902,45 @@ class EgoNeRF(TensorBase):
         env_map = torch.empty(N, 3, device=dev) if has_env else None
         _call("ego_render_forward", sc, C.byref(args), rays.data_ptr(), N, ws.data_ptr(), rgb_map.data_ptr(), depth.data_ptr(),
               _lib.ptr(alpha), _lib.ptr(bg_map), _lib.ptr(env_map), _lib.stream_handle())
+        return rgb_map, depth, bg_map, env_map, alpha
+
+    def _forward_eval_ray0_distances(self, rays, z_pos, n_coarse, n_fine, resampling, use_coarse_sample, need_alpha):
+        """Eval with exp_sampling=False and rays whose aabb entry distances differ (rays starting outside the box).  The reference
+        (EgoNeRF.py:506-518) samples every ray at its OWN distances `t_min_i + k * stepSize` but then overwrites the distances of all
+        rays with ray 0's: the first-pass intervals, the depth integral and - with resampling - the proposal bins and therefore the
+        fine sample positions `o + d * z_fine` all come from ray 0's schedule.  Reproduced here with the stage entry points: a
+        first-pass sample of ray i sits at o_i + d_i * (z_0[k] + (t_min_i - t_min_0)), i.e. on the ray with the origin moved by
+        d_i * (t_min_i - t_min_0) and measured with z_0; the fine pass runs on the ORIGINAL origins with the merged distances."""
+        lib, st, sc = _lib.load(), _lib.stream_handle(), self.scene()
+        N, dev = rays.shape[0], rays.device
+        f = lambda *shape: torch.empty(*shape, device=dev, dtype=torch.float32)
+        z0 = z_pos[0:1].expand(N, n_coarse).contiguous()
+        shifted = rays.clone()
+        shifted[:, :3] = rays[:, :3] + rays[:, 3:6] * (z_pos[:, :1] - z_pos[0:1, :1])
+        S = (n_coarse + n_fine if use_coarse_sample else n_fine) if resampling else n_coarse
+        has_env = self.envmap is not None
+        astride = S + int(has_env)
+        alpha = f(N, astride) if need_alpha else None
+        w, bg, crd, rgb = f(N, S), f(N), f(N, S, 4), f(N, S, 3)
+        use_flags = bool(sc.occ) or sc.term_eps > 0 or sc.weight_thres >= 0
+        act = torch.zeros(N * S // 32 + 1, device=dev, dtype=torch.uint8) if use_flags else None
+        near = float(self.near_far[0])
+        if resampling:
+            wc, z = f(N, n_coarse), f(N, S)
+            _call("ego_march_density", sc, shifted.data_ptr(), N, n_coarse, z0.data_ptr(), None, None, near, 1, None, None, 0, wc.data_ptr(),
+                  None, None, None, None, st)
+            _call("ego_sample_pdf_merge", z0.data_ptr(), wc.data_ptr(), None, N, n_coarse, n_fine, int(use_coarse_sample), z.data_ptr(), None, st)
+            _call("ego_march_density", sc, rays.data_ptr(), N, S, z.data_ptr(), None, None, near, 2, None, _lib.ptr(alpha), astride, w.data_ptr(),
+                  bg.data_ptr(), crd.data_ptr(), None, _lib.ptr(act), st)
+        else:
+            z = z0
+            _call("ego_march_density", sc, shifted.data_ptr(), N, S, z0.data_ptr(), None, None, near, 0, None, _lib.ptr(alpha), astride, w.data_ptr(),
+                  bg.data_ptr(), crd.data_ptr(), None, _lib.ptr(act), st)
+        _call("ego_shade", sc, rays.data_ptr(), z.data_ptr(), crd.data_ptr(), N, S, rgb.data_ptr(), None, _lib.ptr(act), st)
+        rgb_map, depth = f(N, 3), f(N)
+        bg_map, env_map = (f(N, 3), f(N, 3)) if has_env else (None, None)
+        _call("ego_composite", sc, rays.data_ptr(), z.data_ptr(), w.data_ptr(), bg.data_ptr(), rgb.data_ptr(), N, S, rgb_map.data_ptr(),
+              depth.data_ptr(), _lib.ptr(bg_map), _lib.ptr(env_map), None, st)
         return rgb_map, depth, bg_map, env_map, alpha
 
     # -- checkpoints (EgoNeRF.py:158-187) -----------------------------------------------------------------------------

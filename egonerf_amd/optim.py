@@ -24,6 +24,46 @@ class FusedAdam(torch.optim.Optimizer):
     def lr_scale(self) -> float:
         return 1.0 if self._clock is None else float(self._clock[1])
 
+    def current_lrs(self) -> list:
+        """The learning rates the NEXT step() applies, per group (train.py logs `param_group['lr']`; in capturable mode
+        `group["lr"]` holds the base rate and the decay lives on the device).  A device synchronisation: for logging."""
+        s = self.lr_scale() if self.capturable else 1.0
+        return [float(g["lr"]) * s for g in self.param_groups]
+
+    def steps_taken(self) -> int:
+        """Optimiser steps executed so far, graph replays included (the host-side state['step'] does not advance during replays)."""
+        if self.capturable and self._clock is not None:
+            return int(self._clock[0])
+        return max((int(st.get("step", 0)) for st in self.state.values()), default=0)
+
+    def state_dict(self):
+        """torch's state dict + the device clock of capturable mode (step count, lr scale): without it a reloaded optimiser would
+        restart the bias correction and the learning-rate decay at t = 0.  state['step'] is synchronised from the clock."""
+        if self.capturable and self._clock is not None:
+            t = int(self._clock[0])
+            for st in self.state.values():
+                if "step" in st:
+                    st["step"] = t
+        sd = super().state_dict()
+        if self.capturable and self._clock is not None:
+            sd["ego_clock"] = [float(v) for v in self._clock.cpu()]
+            sd["ego_lr_factor"] = self.lr_factor
+        return sd
+
+    def load_state_dict(self, state_dict):
+        state_dict = dict(state_dict)
+        clock = state_dict.pop("ego_clock", None)
+        factor = state_dict.pop("ego_lr_factor", None)
+        super().load_state_dict(state_dict)
+        if clock is not None:
+            dev = next(p for g in self.param_groups for p in g["params"]).device
+            if self._clock is None:
+                self._clock = torch.tensor(clock, dtype=torch.float64, device=dev)
+            else:
+                self._clock.copy_(torch.tensor(clock, dtype=torch.float64))   # in place: a captured graph keeps reading this buffer
+            if factor is not None:
+                self.lr_factor = float(factor)
+
     @torch.no_grad()
     @_lib.device_guard
     def step(self, closure=None):
@@ -58,6 +98,13 @@ class FusedAdam(torch.optim.Optimizer):
                 batches.setdefault((float(b1), float(b2), float(group["eps"]), state["step"]), []).append(t)
                 torch.autograd.graph.increment_version(p)  # written through a raw pointer: keep autograd / caches honest
         if self.capturable and batches:
+            base = tuple(float(g["lr"]) for g in self.param_groups)
+            if getattr(self, "_base_lrs", base) != base:
+                import warnings
+                warnings.warn("FusedAdam(capturable=True): param_groups[i]['lr'] changed between steps; in this mode it is the BASE rate and the "
+                              "per-step decay (lr_factor) is applied on the device - a caller that also multiplies group['lr'] decays twice, and a "
+                              "captured graph keeps the rates of its capture", RuntimeWarning, stacklevel=2)
+            self._base_lrs = base
             if len({k[:3] for k in batches}) != 1:
                 raise NotImplementedError("FusedAdam(capturable=True): one (betas, eps) setting for all groups (true for train.py:176-186)")
             ts = [t for group in batches.values() for t in group]

@@ -356,6 +356,35 @@ def render_train(model, rays, n_coarse, n_fine=0, resampling=False, use_coarse_s
     return rgb_map, depth, None, None, alpha
 
 
+class TrainSchedule:
+    """Device-side iteration clock for loss terms whose weights change from iteration to iteration.  train.py:295-309 multiplies
+    TV_weight_density / TV_weight_app (while `iteration < iter_ignore_TV`) and entropy_weight (once `iteration > iter_ignore_entropy`)
+    by lr_factor in every iteration in which the term is active; a Python float captured into a hipGraph would freeze at its value
+    of the capture.  `it` is a float64 device scalar holding the index of the CURRENT iteration (GraphedTrainStep advances it inside
+    the graph), and `decayed()` evaluates the reference's running product as a device expression."""
+
+    def __init__(self, device, start_iteration: int = 0):
+        self.first = int(start_iteration)
+        self.it = torch.full((), float(start_iteration), dtype=torch.float64, device=device)
+
+    def decayed(self, w0: float, factor: float, active_before: Optional[int] = None, active_after: Optional[int] = None) -> torch.Tensor:
+        """The weight the reference's loop holds in the current iteration (float32 device scalar; 0 when the term is gated off):
+        `active_before=K`: term active while iteration < K, `w *= factor` in every active iteration before use (the TV terms,
+        train.py:295-304); `active_after=K`: active once iteration > K (the ray-entropy term, train.py:306-309)."""
+        it = self.it
+        if (active_before is None) == (active_after is None):
+            raise ValueError("TrainSchedule.decayed: exactly one of active_before / active_after")
+        if active_before is not None:
+            n, gate = it - (self.first - 1), it < float(active_before)
+        else:
+            n, gate = it - float(max(int(active_after), self.first - 1)), it > float(active_after)
+        w = float(w0) * torch.pow(torch.full_like(it, float(factor)), n)
+        return torch.where(gate, w, torch.zeros_like(w)).float()
+
+    def iteration(self) -> int:
+        return int(self.it.item())
+
+
 class GraphedTrainStep:
     """One training iteration of train.py:245-330 — differentiable render of a ray batch, loss, backward, optimiser step with
     the per-step learning-rate decay, coarse-table refresh — captured once as a hipGraph and replayed.
@@ -369,13 +398,27 @@ class GraphedTrainStep:
     captures one; `__call__(rays, target)` copies the batch into the graph's static inputs, replays, and returns the loss tensor
     of that iteration (overwritten by the next call).  Shapes are fixed: re-create the object after `upsample_volume_grid`
     (train.py:377-392 re-creates the optimiser there as well).  `loss_fn(rgb_map, target, alpha)` defaults to the MSE of
-    train.py:250; regularisers go in there (egonerf_amd.losses).  `noise_fn` replaces torch.rand for the is_train jitter."""
+    train.py:250; regularisers go in there (egonerf_amd.losses).  `noise_fn` replaces torch.rand for the is_train jitter.
 
-    def __init__(self, model, optimizer, rays, target, render_kwargs, loss_fn=None, warmup=3, noise_fn=None):
+    Loss terms whose WEIGHTS change per iteration (train.py:295-309: the TV and ray-entropy weights decay by lr_factor per active
+    iteration and are gated on iter_ignore_TV / iter_ignore_entropy) must not be Python floats - a float is frozen into the graph at
+    capture.  A `loss_fn` with a fourth parameter receives `self.schedule` (a TrainSchedule: device-side iteration counter advanced
+    inside the graph) and writes e.g. `sched.decayed(TV_weight_density, lr_factor, active_before=iter_ignore_TV) * model.TV_loss_density(tv)`;
+    tests/test_hip_train_graph.py::test_graphed_step_with_decaying_regulariser_weights pins that against the eager loop."""
+
+    def __init__(self, model, optimizer, rays, target, render_kwargs, loss_fn=None, warmup=3, noise_fn=None, start_iteration=0):
         if not getattr(optimizer, "capturable", False):
             raise ValueError("GraphedTrainStep needs FusedAdam(capturable=True): the step count and lr schedule must live on the device")
         self.model, self.opt, self.kw = model, optimizer, dict(render_kwargs)
         self.loss_fn = loss_fn or (lambda rgb, tgt, alpha: torch.mean((rgb - tgt) ** 2))
+        import inspect
+        try:
+            n_par = len([q for q in inspect.signature(self.loss_fn).parameters.values()
+                         if q.kind in (q.POSITIONAL_ONLY, q.POSITIONAL_OR_KEYWORD)])
+        except (TypeError, ValueError):
+            n_par = 3
+        self._loss_takes_schedule = n_par >= 4
+        self.schedule = TrainSchedule(rays.device, start_iteration)
         # noise_fn(n_rays, n_samples, device) -> [n_rays, n_samples] in [0, 1): torch.rand by default; tests pin it
         self.noise_fn = noise_fn or (lambda n, m, dev: torch.rand(n, m, device=dev))
         self.rays, self.target = rays.detach().clone().float().contiguous(), target.detach().clone().float().contiguous()
@@ -401,12 +444,13 @@ class GraphedTrainStep:
         jitter = self.noise_fn(N, kw["n_coarse"], dev)
         u = self.noise_fn(N, kw["n_fine"], dev) if kw.get("resampling") else None
         rgb, _depth, _bg, _env, alpha = self.model(self.rays, is_train=True, jitter=jitter, u=u, **kw)
-        loss = self.loss_fn(rgb, self.target, alpha)
+        loss = self.loss_fn(rgb, self.target, alpha, self.schedule) if self._loss_takes_schedule else self.loss_fn(rgb, self.target, alpha)
         self.opt.zero_grad(set_to_none=True)
         loss.backward()
         self.opt.step()
         if kw.get("resampling"):
             self.model.update_coarse_sigma_grid()  # train.py:356-357
+        self.schedule.it.add_(1.0)   # inside the graph: the next replay sees the next iteration index
         return loss.detach()
 
     def __call__(self, rays, target):

@@ -126,6 +126,10 @@ typedef struct ego_scene {
    * 32-sample tiles without any sample above the threshold are not shaded.  weight_thres = 0 is EXACT (EgoNeRF.forward adds
    * w * rgb = 0 for those samples, models/EgoNeRF.py:583) and is what the host layer sets by default. */
   float weight_thres;
+  /* Optional accelerator for `occ` (NULL = off): [grid][N_phi - 1][N_theta - 1][N_r - 1] bytes, 1 iff any of the cell's eight corner
+   * voxels is set.  The march then decides "mask value > 0" for a sample strictly inside a cell from this one byte (identical result:
+   * all eight trilinear weights are positive there) and keeps the eight-tap evaluation for samples on lattice planes / outside. */
+  const uint8_t* occ_cell;
 } ego_scene;
 
 /* number of floats ego_pack_mlp writes: the packed weight blob used by ego_shade / ego_mlp_fea / ego_app_feature

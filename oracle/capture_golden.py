@@ -641,6 +641,19 @@ def capture_uniform():
         o = fwd(n_coarse=16, n_fine=16, resampling=True, use_coarse_sample=True, is_train=True)
     fx.update(tr_jitter=np_(jit), tr_u=np_(uu), tr_rgb=np_(o[0]), tr_depth=np_(o[1]))
     np.savez_compressed(os.path.join(OUT, "tiny_uniform.npz"), **fx)
+    # rays that start OUTSIDE the aabb enter it at different distances t_min (clamped to [near, far]): in eval the reference then places
+    # the first-pass samples per ray but measures every ray with ray 0's distances (EgoNeRF.py:515-516)
+    far = synth.make_rays(64, seed=9)
+    far[1::2, :3] = -far[1::2, 3:6] * (19.0 + 6.0 * synth.hash_uniform(14, 0, 32).reshape(32, 1).astype(np.float32)) + 0.5 * far[1::2, :3]
+    rays = torch.from_numpy(far)
+    xyz, z, _ = model.sample_ray(rays[:, :3], rays[:, 3:6], is_train=False, N_samples=24)
+    assert len(torch.unique(z[:, 0])) > 20
+    fm = dict(seed_weights=1234, rays=rays.numpy(), z_eval=np_(z))
+    o = fwd(n_coarse=24, n_fine=0, resampling=False)
+    fm.update(nr_rgb=np_(o[0]), nr_depth=np_(o[1]), nr_alpha=np_(o[4]))
+    o = fwd(n_coarse=16, n_fine=16, resampling=True, use_coarse_sample=True)
+    fm.update(rs_rgb=np_(o[0]), rs_depth=np_(o[1]), rs_alpha=np_(o[4]))
+    np.savez_compressed(os.path.join(OUT, "tiny_uniform_mixed.npz"), **fm)
 
 
 SHAPES = {   # model shapes opt.py:87-100 can produce besides the one every shipped config resolves to (16 / 48 / 27 / 128 / 2 / 2)

@@ -149,3 +149,100 @@ def test_graphed_step_needs_the_capturable_optimiser():
     rays = torch.from_numpy(synth.make_rays(64, seed=1)).to(DEV)
     with pytest.raises(ValueError, match="capturable"):
         GraphedTrainStep(model, opt, rays, torch.zeros(64, 3, device=DEV), KW)
+
+
+def test_graphed_step_with_decaying_regulariser_weights():
+    """train.py:295-309 multiplies the TV weights (while iteration < iter_ignore_TV) and the ray-entropy weight
+    (once iteration > iter_ignore_entropy) by lr_factor in every active iteration.  A Python float would be frozen into the graph at
+    capture; the graphed loop takes them from the device-side schedule (GraphedTrainStep.schedule.decayed).  Seven iterations with
+    both gates switching inside the run, eager loop with the reference's own Python-side bookkeeping vs replays."""
+    from egonerf_amd.losses import TVLoss, ray_entropy_loss
+    N, factor, n_it = 128, 0.8, 7          # a strong decay so that a frozen weight would be far off
+    ignore_tv, ignore_entropy = 4, 2        # TV active in iterations 0..3, entropy in iterations 3..6
+    tv = TVLoss()
+    batches = [(torch.from_numpy(synth.make_rays(N, seed=60 + i)).to(DEV),
+                torch.from_numpy(synth.hash_uniform(110 + i, 0, N * 3).reshape(N, 3).astype(np.float32)).to(DEV)) for i in range(n_it)]
+    jit = torch.from_numpy(synth.hash_uniform(29, 0, N * 16).reshape(N, 16).astype(np.float32)).to(DEV)
+    W_TVD, W_TVA, W_ENT = 1.0, 0.1, 0.05
+    # eager loop, the reference's bookkeeping verbatim (train.py:295-309)
+    _, m_ref = _setup(8)
+    o_ref = FusedAdam(m_ref.get_optparam_groups(0.02, 1e-3), betas=(0.9, 0.99))
+    w_tvd, w_tva, w_ent = W_TVD, W_TVA, W_ENT
+    ref_losses, ref_weights = [], []
+    for it, (rays, gt) in enumerate(batches):
+        rgb, _d, _bg, _env, alpha = m_ref(rays, is_train=True, jitter=jit, u=jit, **KW)
+        loss = torch.mean((rgb - gt) ** 2)
+        if it < ignore_tv:
+            w_tvd *= factor
+            loss = loss + m_ref.TV_loss_density(tv) * w_tvd
+            w_tva *= factor
+            loss = loss + m_ref.TV_loss_app(tv) * w_tva
+        if it > ignore_entropy:
+            w_ent *= factor
+            loss = loss + ray_entropy_loss(alpha) * w_ent
+        ref_weights.append((w_tvd if it < ignore_tv else 0.0, w_ent if it > ignore_entropy else 0.0))
+        o_ref.zero_grad(set_to_none=True)
+        loss.backward()
+        o_ref.step()
+        for grp in o_ref.param_groups:
+            grp["lr"] *= factor
+        m_ref.update_coarse_sigma_grid()
+        ref_losses.append(float(loss.detach()))
+    # graphed loop: weights from the device-side schedule
+    _, m_g = _setup(8)
+    o_g = FusedAdam(m_g.get_optparam_groups(0.02, 1e-3), betas=(0.9, 0.99), capturable=True, lr_factor=factor)
+    seen = []
+
+    def loss_fn(rgb, gt, alpha, sched):
+        wd = sched.decayed(W_TVD, factor, active_before=ignore_tv)
+        wa = sched.decayed(W_TVA, factor, active_before=ignore_tv)
+        we = sched.decayed(W_ENT, factor, active_after=ignore_entropy)
+        seen.append((wd, we))
+        return torch.mean((rgb - gt) ** 2) + m_g.TV_loss_density(tv) * wd + m_g.TV_loss_app(tv) * wa + ray_entropy_loss(alpha) * we
+
+    step = GraphedTrainStep(m_g, o_g, batches[0][0], batches[0][1], KW, loss_fn=loss_fn, warmup=1, noise_fn=lambda n, m, dev: jit)
+    got = []
+    for it, (rays, gt) in enumerate(batches[1:], start=1):
+        got.append(float(step(rays, gt)))
+        wd, we = (float(t) for t in seen[-1])    # the captured weight tensors hold this replay's values
+        assert abs(wd - ref_weights[it][0]) <= 1e-6 and abs(we - ref_weights[it][1]) <= 1e-7, (it, wd, we, ref_weights[it])
+    assert step.schedule.iteration() == n_it
+    for a, b in zip(ref_losses[1:], got):
+        assert abs(a - b) <= 5e-5 * max(abs(a), 1e-3), (ref_losses, got)
+    pr, pg = dict(m_ref.named_parameters()), dict(m_g.named_parameters())
+    for k in pr:
+        _same_after_adam(k, pr[k].detach(), pg[k].detach(), n_steps=n_it, lr=0.02)
+
+
+def test_capturable_adam_state_dict_carries_the_device_clock():
+    """the step count and lr scale of capturable mode live in a device buffer; state_dict() / load_state_dict()
+    must carry them, or a resumed run restarts bias correction and decay at t = 0."""
+    g = torch.Generator().manual_seed(7)
+    mk = lambda: [torch.randn(33, 5, generator=g).to(DEV).requires_grad_(True), torch.randn(64, generator=g).to(DEV).requires_grad_(True)]
+    g.manual_seed(7); a = mk()
+    g.manual_seed(7); b = mk()
+    grads = [[torch.randn(p.shape, generator=g).to(DEV) for p in a] for _ in range(6)]
+    oa = FusedAdam([dict(params=a, lr=0.01)], betas=(0.9, 0.99), capturable=True, lr_factor=0.9)
+    ob = FusedAdam([dict(params=b, lr=0.01)], betas=(0.9, 0.99), capturable=True, lr_factor=0.9)
+    for k in range(3):
+        for p, q, gr in zip(a, b, grads[k]):
+            p.grad, q.grad = gr, gr.clone()
+        oa.step(), ob.step()
+    sd = ob.state_dict()
+    assert sd["ego_clock"][0] == 3.0 and abs(sd["ego_clock"][1] - 0.9 ** 3) < 1e-12
+    assert all(st["step"] == 3 for st in sd["state"].values())
+    oc = FusedAdam([dict(params=b, lr=0.01)], betas=(0.9, 0.99), capturable=True, lr_factor=0.5)   # a fresh optimiser on the same tensors
+    oc.load_state_dict(sd)
+    assert oc.steps_taken() == 3 and abs(oc.lr_scale() - 0.9 ** 3) < 1e-12 and oc.lr_factor == 0.9
+    assert abs(oc.current_lrs()[0] - 0.01 * 0.9 ** 3) < 1e-12
+    for k in range(3, 6):
+        for p, q, gr in zip(a, b, grads[k]):
+            p.grad, q.grad = gr, gr.clone()
+        oa.step(), oc.step()
+    for p, q in zip(a, b):
+        assert float((p.detach() - q.detach()).abs().max()) <= 1e-7
+    with pytest.warns(RuntimeWarning, match="BASE rate"):
+        oc.param_groups[0]["lr"] *= 0.5
+        for q, gr in zip(b, grads[0]):
+            q.grad = gr
+        oc.step()

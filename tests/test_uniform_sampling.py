@@ -66,13 +66,51 @@ def test_hip_uniform_sampling(golden):
                                jitter=T(fx["tr_jitter"]).cuda(), u=T(fx["tr_u"]).cuda())
         assert float((rgb.cpu() - T(fx["tr_rgb"])).abs().max()) <= 1e-4
         assert float((depth.cpu() - T(fx["tr_depth"])).abs().max()) <= 1e-3
-        # rays that enter the aabb at different distances: the reference measures all of them with ray 0's distances in eval
-        far_rays = rays.clone()
-        far_rays[1, :3] = torch.tensor([0.0, 0.0, -40.0])
-        far_rays[1, 3:6] = torch.tensor([0.0, 0.0, 1.0])
-        if not bool((model.sample_ray_z(far_rays, 8)[:, 0] == model.sample_ray_z(far_rays, 8)[0, 0]).all()):
-            with pytest.raises(NotImplementedError):
-                model(far_rays, n_coarse=24, exp_sampling=False)
+
+
+def test_oracle_uniform_sampling_mixed_entry_distances(golden):
+    """Rays starting outside the aabb enter it at different distances; in eval the reference samples per ray but measures every ray
+    with ray 0's distances (EgoNeRF.py:515-516).  Captured from the reference (tiny_uniform_mixed.npz); the oracle restates it."""
+    fx = golden("tiny_uniform_mixed")
+    cfg = _cfg()
+    sc = make_oracle(cfg, synth.make_weights(cfg, seed=int(fx["seed_weights"])))
+    rays = T(fx["rays"])
+    _xyz, z = sc.sample_ray(rays[:, :3], rays[:, 3:6], 24)
+    assert np.array_equal(z.numpy(), fx["z_eval"]) and len(np.unique(fx["z_eval"][:, 0])) > 20
+    rgb, depth, _, _, alpha = sc.forward(rays, n_coarse=24, exp_sampling=False)
+    assert float((rgb - T(fx["nr_rgb"])).abs().max()) <= 2e-6 and float((alpha - T(fx["nr_alpha"])).abs().max()) <= 5e-6
+    assert float((depth - T(fx["nr_depth"])).abs().max()) <= 2e-5
+    rgb, depth, *_ = sc.forward(rays, n_coarse=16, n_fine=16, resampling=True, exp_sampling=False)
+    assert float((rgb - T(fx["rs_rgb"])).abs().max()) <= 2e-6 and float((depth - T(fx["rs_depth"])).abs().max()) <= 2e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("envmap", [False, True])
+def test_hip_uniform_sampling_mixed_entry_distances(golden, envmap):
+    """the same case on the GPU (it used to raise NotImplementedError): reference goldens without an envmap,
+    the oracle with one (alpha gets its extra column, bg / env maps appear)."""
+    fx = golden("tiny_uniform_mixed")
+    cfg = synth.SceneConfig(n_voxel=20 ** 3, use_envmap=envmap, envmap_res_H=16)
+    w = synth.make_weights(cfg, seed=int(fx["seed_weights"]))
+    model = make_model(cfg, w, "cuda")
+    rays = T(fx["rays"])
+    z = model.sample_ray_z(rays.cuda(), 24)
+    assert np.array_equal(z.cpu().numpy(), fx["z_eval"])
+    with torch.no_grad():
+        for kw in (dict(n_coarse=24), dict(n_coarse=16, n_fine=16, resampling=True)):
+            got = model(rays.cuda(), exp_sampling=False, **kw)
+            if envmap:
+                ref = make_oracle(cfg, w).forward(rays, exp_sampling=False, **kw)
+                assert got[4].shape == ref[4].shape and float((got[3].cpu() - ref[3]).abs().max()) <= 1e-5
+                assert float((got[2].cpu() - ref[2]).abs().max()) <= 1e-4
+            else:
+                tag = "rs" if kw.get("resampling") else "nr"
+                ref = (T(fx[f"{tag}_rgb"]), T(fx[f"{tag}_depth"]), None, None, T(fx[f"{tag}_alpha"]))
+            assert float((got[0].cpu() - ref[0]).abs().max()) <= 1e-4
+            assert float((got[1].cpu() - ref[1]).abs().max()) <= 1e-3 * 15.0
+            assert float((got[4].cpu() - ref[4]).abs().max()) <= 1e-4
+            none = model(rays.cuda(), exp_sampling=False, need_alpha=False, **kw)
+            assert none[4] is None and torch.equal(none[0], got[0])
 
 
 @pytest.mark.gpu
