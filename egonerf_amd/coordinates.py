@@ -147,10 +147,11 @@ class YinYangSphericalCoords:
         if axis != 0:
             return torch.linspace(-1, 1, n)
         self._require_supported()
-        if not self.interval_th:
-            raise NotImplementedError("up_sampling_VM of the plain exponential r grid (coordinates.py:260-262) is not built")
         ratio = pow(self.far[0] / self.r0, 1 / (n - 1))  # coordinates.py:238 (0-dim tensor pow)
-        new = linearised_exp_grid(self.r0, ratio, n)
+        if self.interval_th:
+            new = linearised_exp_grid(self.r0, ratio, n)
+        else:   # plain exponential grid (coordinates.py:260-262): 0, r0, r0 ratio, ..., r0 ratio^(n-2)
+            new = torch.cat([torch.zeros(1), self.r0 * torch.pow(torch.as_tensor(ratio, dtype=torch.float32).cpu(), torch.arange(n - 1))]).float()
         G = self.reference_r_grid()
         k_out = torch.clamp(torch.searchsorted(G, new, right=True), 1, G.shape[0] - 1)
         k_in = k_out - 1

