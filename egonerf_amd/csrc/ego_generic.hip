@@ -27,6 +27,12 @@ struct GenShadeArgs {
   const uint8_t* tile_active;
   int64_t M;
   int32_t S, app_dim, n_comp, in_c, view_pe, fea_pe;
+  // training forward (DUMP): row-major per-sample activations for the backward pass / the weight-gradient products
+  float* dump_x;   // [M][ldx]: the MLP input row in the reference's column order (tensorBase.py:68-75)
+  float* dump_h1;  // [M][ldh]: relu(h1)
+  float* dump_h2;  // [M][ldh]: relu(h2)
+  float* dump_v;   // [M][ldv]: plane x line products, column = plane * C + channel
+  int32_t ldx, ldh, ldv;
 };
 
 // packed layout (floats): W1T [in_c][HID] | b1 [HID] | W2T [HID][HID] | b2 [HID] | W3 [3][HID] | b3 [4] | basisT [2][3 C][32]
@@ -73,7 +79,7 @@ enum { G_SHADE = 0, G_APP = 1, G_MLP = 2 };
 
 // one wave = 64 samples (lane = sample); 2 waves per workgroup; per wave an LDS slab [HID][64] that first stages chunks of the MLP
 // input and then holds relu(h1)
-template <int HID, int MODE>
+template <int HID, int MODE, bool DUMP = false>
 __global__ __launch_bounds__(128) void k_shade_generic(GenShadeArgs A) {
   __shared__ float slab[2][HID][64];
   const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -133,6 +139,7 @@ __global__ __launch_bounds__(128) void k_shade_generic(GenShadeArgs A) {
                            *(const f32x4*)(p11 + c4) * w11;
           const f32x4 lv = *(const f32x4*)(l0 + c4) * Ln.w0 + *(const f32x4*)(l1 + c4) * Ln.w1;
           const f32x4 pr = pv * lv;
+          if (DUMP && valid) *(f32x4*)(A.dump_v + m * A.ldv + i * C + c4) = pr;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             // basisT [g][col][32]: uniform addresses -> scalar loads of both grids' rows, selected per lane
@@ -164,6 +171,7 @@ __global__ __launch_bounds__(128) void k_shade_generic(GenShadeArgs A) {
     auto consume = [&](int n, int row0, int stride) {
       for (int tt = 0; tt < n; ++tt) {
         const float xk = sl[tt][lane];
+        if (DUMP && valid) A.dump_x[m * A.ldx + row0 + tt * stride] = xk;
         const float* wrow = A.gp + L.w1t + (int64_t)(row0 + tt * stride) * HID;   // uniform: scalar loads
 #pragma unroll
         for (int j = 0; j < HID; ++j) h[j] = fmaf(wrow[j], xk, h[j]);
@@ -202,7 +210,10 @@ __global__ __launch_bounds__(128) void k_shade_generic(GenShadeArgs A) {
     }
     // relu(h1) -> LDS, layer 2 with the hidden index as the (runtime) loop
 #pragma unroll
-    for (int j = 0; j < HID; ++j) sl[j][lane] = fmaxf(h[j], 0.f);
+    for (int j = 0; j < HID; ++j) {
+      sl[j][lane] = fmaxf(h[j], 0.f);
+      if (DUMP && valid) A.dump_h1[m * A.ldh + j] = fmaxf(h[j], 0.f);
+    }
     {
       const float* b2 = A.gp + L.b2;
 #pragma unroll
@@ -220,11 +231,181 @@ __global__ __launch_bounds__(128) void k_shade_generic(GenShadeArgs A) {
 #pragma unroll
     for (int j = 0; j < HID; ++j) {
       const float hv = fmaxf(h[j], 0.f);
+      if (DUMP && valid) A.dump_h2[m * A.ldh + j] = hv;
       o[0] = fmaf(w3[j], hv, o[0]); o[1] = fmaf(w3[HID + j], hv, o[1]); o[2] = fmaf(w3[2 * HID + j], hv, o[2]);
     }
     if (valid) {
       float* op = A.out + m * 3;
       op[0] = sigmoidf(o[0]); op[1] = sigmoidf(o[1]); op[2] = sigmoidf(o[2]);
+    }
+  }
+}
+
+// ---- training of the other model shapes: backward of rows F, G and of the VM lookups, plain fp32, lane = sample --------------------
+// The data-gradient chain of one sample: do = dL/d(pre-sigmoid) -> dh2 = relu'(h2) W3^T do -> dh1 = relu'(h1) W2^T dh2 -> dx = W1^T dh1
+// -> feature gradients through the encodings (d sin(f w)/df = w cos(f w), taken from the dumped cosines) -> dv = B_g^T dfe.  The
+// weight gradients are plain A^T B products over the row-major buffers written here and by the dumping forward (ego_weight_grad).
+struct GenBwdArgs {
+  const float* gp;
+  const float* coords;  // [M][4]
+  float* dc;            // in: dL/d rgb_sample [M][3]; out: dL/d(pre-sigmoid)
+  const float* rgb;     // [M][3] the forward's colours
+  const float* x;       // dumps of the forward
+  const float* h1;
+  const float* h2;
+  float* dh2;           // out [M][HID]
+  float* dh1;           // out [M][HID]
+  float* dfe;           // out [M][64]: columns [32 g, 32 g + 32) of the sample's grid g, the other half zero
+  float* dv;            // out [M][ldv]
+  int64_t M;
+  int32_t app_dim, n_comp, in_c, view_pe, fea_pe, ldx, ldh, ldv;
+};
+
+template <int HID>
+__global__ __launch_bounds__(128) void k_shade_generic_bwd(GenBwdArgs A) {
+  __shared__ float slab[2][HID][64];
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  float (*sl)[64] = slab[wv];
+  const GenLayout L = gen_layout(A.in_c, HID, A.n_comp);
+  const int64_t n_units = (A.M + 63) >> 6;
+  const int D = A.app_dim;
+  for (int64_t unit = (int64_t)blockIdx.x * 2 + wv; unit < n_units; unit += (int64_t)gridDim.x * 2) {
+    const int64_t m_raw = unit * 64 + lane;
+    const bool valid = m_raw < A.M;
+    const int64_t m = valid ? m_raw : A.M - 1;
+    const int g = ((const f32x4*)A.coords)[m].w != 0.f;
+    float d_o[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float y = A.rgb[m * 3 + c];
+      d_o[c] = A.dc[m * 3 + c] * y * (1.f - y);       // sigmoid'
+    }
+    if (valid) { A.dc[m * 3] = d_o[0]; A.dc[m * 3 + 1] = d_o[1]; A.dc[m * 3 + 2] = d_o[2]; }
+    float dh[HID];
+    const float* w3 = A.gp + L.w3;
+#pragma unroll
+    for (int j = 0; j < HID; ++j) {
+      const float s = w3[j] * d_o[0] + w3[HID + j] * d_o[1] + w3[2 * HID + j] * d_o[2];
+      dh[j] = A.h2[m * A.ldh + j] > 0.f ? s : 0.f;    // threshold backward of torch.nn.ReLU
+      if (valid) A.dh2[m * HID + j] = dh[j];
+    }
+    // dh1[k] = relu'(h1[k]) sum_j W2[j][k] dh2[j]; W2T row k holds W2[:, k]
+    for (int k = 0; k < HID; ++k) {
+      const float* wrow = A.gp + L.w2t + (int64_t)k * HID;   // uniform: scalar loads
+      float s = 0.f;
+#pragma unroll
+      for (int j = 0; j < HID; ++j) s = fmaf(wrow[j], dh[j], s);
+      s = A.h1[m * A.ldh + k] > 0.f ? s : 0.f;
+      sl[k][lane] = s;
+      if (valid) A.dh1[m * HID + k] = s;
+    }
+#pragma unroll
+    for (int j = 0; j < HID; ++j) dh[j] = sl[j][lane];      // dh1 in registers
+    auto dx = [&](int t) {                                   // dL/d(MLP input t) = sum_k W1[k][t] dh1[k]; W1T row t holds W1[:, t]
+      const float* wrow = A.gp + L.w1t + (int64_t)t * HID;
+      float s = 0.f;
+#pragma unroll
+      for (int j = 0; j < HID; ++j) s = fmaf(wrow[j], dh[j], s);
+      return s;
+    };
+    const int base_s = D + 3, base_c = base_s + D * A.fea_pe;
+    const float* xr = A.x + m * A.ldx;
+    for (int f = 0; f < D; ++f) {
+      float acc = dx(f);
+      float fr = 1.f;
+      for (int q = 0; q < A.fea_pe; ++q, fr *= 2.f) {
+        const int ts = base_s + f * A.fea_pe + q, tc = base_c + f * A.fea_pe + q;
+        acc += fr * (xr[tc] * dx(ts) - xr[ts] * dx(tc));    // d sin(f w) = w cos(f w) df, d cos(f w) = -w sin(f w) df
+      }
+      sl[f][lane] = acc;
+    }
+    float dfe[32];
+#pragma unroll
+    for (int f = 0; f < 32; ++f) dfe[f] = f < D ? sl[f][lane] : 0.f;
+    if (valid) {
+#pragma unroll
+      for (int f = 0; f < 32; ++f) {
+        A.dfe[m * 64 + 32 * g + f] = dfe[f];
+        A.dfe[m * 64 + 32 * (1 - g) + f] = 0.f;
+      }
+    }
+    // dv[col] = sum_f basis_g[f][col] dfe[f]; basisT [g][col][32]
+    const int ncol = 3 * A.n_comp;
+    for (int col = 0; col < ncol; ++col) {
+      const float* b0 = A.gp + L.basis + (int64_t)col * 32;
+      const float* b1 = b0 + (int64_t)ncol * 32;
+      float s = 0.f;
+#pragma unroll
+      for (int f = 0; f < 32; ++f) s = fmaf(g ? b1[f] : b0[f], dfe[f], s);
+      if (valid) A.dv[m * A.ldv + col] = s;
+    }
+  }
+}
+
+// backward of the VM lookups for any component count (multiple of 4): thread = (sample, plane); float atomics per tap and channel
+struct GenScatterArgs {
+  DevField F;
+  float* gplane[2][3];
+  float* gline[2][3];
+  const float* coords;   // [M][4]
+  const float* d;        // ldd == 0: dfeat [M] (density: relu per plane, EgoNeRF.py:340,346); else dv [M][ldd], column = plane * C + channel
+  int64_t M;
+  int32_t C, ldd;
+};
+
+__global__ void k_scatter_generic(GenScatterArgs A) {
+#pragma clang fp contract(fast)
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= A.M * 3) return;
+  const int64_t m = idx / 3;
+  const int i = (int)(idx % 3), C = A.C;
+  const bool dens = A.ldd == 0;
+  float ds = 0.f;
+  if (dens) {
+    ds = A.d[m];
+    if (ds == 0.f) return;
+  }
+  const f32x4 cc = ((const f32x4*)A.coords)[m];
+  const int g = cc.w != 0.f;
+  const VMTaps t = vm_setup(cc.x, cc.y, cc.z, A.F.res);
+  const Lin1 X = t.ax[i == 2 ? 1 : 0], Y = t.ax[i == 0 ? 1 : 2], Ln = t.ax[2 - i];
+  const int W = A.F.res[i == 2 ? 1 : 0];
+  const float* P = g ? A.F.plane[1][i] : A.F.plane[0][i];
+  const float* Lp = g ? A.F.line[1][i] : A.F.line[0][i];
+  float* GP = g ? A.gplane[1][i] : A.gplane[0][i];
+  float* GL = g ? A.gline[1][i] : A.gline[0][i];
+  const int64_t o00 = ((int64_t)Y.i0 * W + X.i0) * C, o01 = ((int64_t)Y.i0 * W + X.i1) * C, o10 = ((int64_t)Y.i1 * W + X.i0) * C,
+                o11 = ((int64_t)Y.i1 * W + X.i1) * C, ol0 = (int64_t)Ln.i0 * C, ol1 = (int64_t)Ln.i1 * C;
+  const float w00 = __fmul_rn(Y.w0, X.w0), w01 = __fmul_rn(Y.w0, X.w1), w10 = __fmul_rn(Y.w1, X.w0), w11 = __fmul_rn(Y.w1, X.w1);
+  if (dens) {
+    float dot = 0.f;
+    for (int c4 = 0; c4 < C; c4 += 4) {
+      const f32x4 pv = *(const f32x4*)(P + o00 + c4) * w00 + *(const f32x4*)(P + o01 + c4) * w01 + *(const f32x4*)(P + o10 + c4) * w10 +
+                       *(const f32x4*)(P + o11 + c4) * w11;
+      const f32x4 lv = *(const f32x4*)(Lp + ol0 + c4) * Ln.w0 + *(const f32x4*)(Lp + ol1 + c4) * Ln.w1;
+      const f32x4 mm = pv * lv;
+      dot += (mm.x + mm.y) + (mm.z + mm.w);
+    }
+    if (!(dot > 0.f)) return;
+  }
+  for (int c4 = 0; c4 < C; c4 += 4) {
+    const f32x4 pv = *(const f32x4*)(P + o00 + c4) * w00 + *(const f32x4*)(P + o01 + c4) * w01 + *(const f32x4*)(P + o10 + c4) * w10 +
+                     *(const f32x4*)(P + o11 + c4) * w11;
+    const f32x4 lv = *(const f32x4*)(Lp + ol0 + c4) * Ln.w0 + *(const f32x4*)(Lp + ol1 + c4) * Ln.w1;
+    const f32x4 di = dens ? f32x4{ds, ds, ds, ds} : *(const f32x4*)(A.d + m * A.ldd + i * C + c4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float gp = di[e] * lv[e], gl = di[e] * pv[e];
+      if (gp != 0.f) {
+        if (w00 != 0.f) unsafeAtomicAdd(GP + o00 + c4 + e, gp * w00);
+        if (w01 != 0.f) unsafeAtomicAdd(GP + o01 + c4 + e, gp * w01);
+        if (w10 != 0.f) unsafeAtomicAdd(GP + o10 + c4 + e, gp * w10);
+        if (w11 != 0.f) unsafeAtomicAdd(GP + o11 + c4 + e, gp * w11);
+      }
+      if (gl != 0.f) {
+        if (Ln.w0 != 0.f) unsafeAtomicAdd(GL + ol0 + c4 + e, gl * Ln.w0);
+        if (Ln.w1 != 0.f) unsafeAtomicAdd(GL + ol1 + c4 + e, gl * Ln.w1);
+      }
     }
   }
 }
@@ -447,3 +628,67 @@ int ego_generic_march(const ego_scene* sc, const ego_vm_field& f, bool fine_lut,
   k_march_generic<<<(unsigned)((N + 3) / 4), 256, 0, (hipStream_t)stream>>>(a);
   return ego_launch_status("k_march_generic");
 }
+
+// ---- training entry points for the other model shapes (declared in include/egonerf_hip.h) ---------------------------------------
+extern "C" {
+
+int ego_shade_train_generic(const ego_scene* sc, const float* rays, const float* coords, int64_t N, int32_t S, float* rgb, float* x, int32_t ldx,
+                            float* h1, float* h2, int32_t ldh, float* v, int32_t ldv, void* stream) {
+  EGO_REQUIRE(N >= 0 && S >= 1 && N * (int64_t)S < (1ll << 31), "shade_train_generic: bad size");
+  if (N == 0) return EGO_OK;
+  EGO_REQUIRE(rays && coords && rgb && x && h1 && h2 && v, "shade_train_generic: null argument");
+  if (int e = check_generic_shape(sc, "shade_train_generic", true, true)) return e;
+  EGO_REQUIRE(ldx >= sc->mlp_in && ldh >= sc->mlp_hidden && ldv >= 3 * sc->app.n_comp && (ldv & 3) == 0 && ((uintptr_t)v & 15) == 0,
+              "shade_train_generic: leading dimensions too small (or v not 16-byte aligned / ldv not a multiple of 4)");
+  GenShadeArgs a{};
+  fill_common(sc, a);
+  a.rays = rays; a.coords = coords; a.out = rgb; a.M = N * (int64_t)S; a.S = S;
+  a.dump_x = x; a.dump_h1 = h1; a.dump_h2 = h2; a.dump_v = v; a.ldx = ldx; a.ldh = ldh; a.ldv = ldv;
+  const int64_t units = (a.M + 63) >> 6;
+  const unsigned grid = (unsigned)((units + 1) / 2 < 2048 ? (units + 1) / 2 : 2048);
+  if (sc->mlp_hidden == 64) k_shade_generic<64, G_SHADE, true><<<grid, 128, 0, (hipStream_t)stream>>>(a);
+  else k_shade_generic<128, G_SHADE, true><<<grid, 128, 0, (hipStream_t)stream>>>(a);
+  return ego_launch_status("k_shade_generic<DUMP>");
+}
+
+int ego_shade_backward_generic(const ego_scene* sc, const float* coords, float* dc, const float* rgb, const float* x, int32_t ldx, const float* h1,
+                               const float* h2, int32_t ldh, float* dh2, float* dh1, float* dfe64, float* dv, int32_t ldv, int64_t N, int32_t S,
+                               void* stream) {
+  EGO_REQUIRE(N >= 0 && S >= 1 && N * (int64_t)S < (1ll << 31), "shade_backward_generic: bad size");
+  if (N == 0) return EGO_OK;
+  EGO_REQUIRE(coords && dc && rgb && x && h1 && h2 && dh2 && dh1 && dfe64 && dv, "shade_backward_generic: null argument");
+  if (int e = check_generic_shape(sc, "shade_backward_generic", false, true)) return e;
+  EGO_REQUIRE(ldx >= sc->mlp_in && ldh >= sc->mlp_hidden && ldv >= 3 * sc->app.n_comp, "shade_backward_generic: leading dimensions too small");
+  GenBwdArgs a{};
+  a.gp = sc->packed; a.coords = coords; a.dc = dc; a.rgb = rgb; a.x = x; a.h1 = h1; a.h2 = h2; a.dh2 = dh2; a.dh1 = dh1; a.dfe = dfe64; a.dv = dv;
+  a.M = N * (int64_t)S; a.app_dim = sc->app_dim; a.n_comp = sc->app.n_comp; a.in_c = sc->mlp_in; a.view_pe = sc->view_pe; a.fea_pe = sc->fea_pe;
+  a.ldx = ldx; a.ldh = ldh; a.ldv = ldv;
+  const int64_t units = (a.M + 63) >> 6;
+  const unsigned grid = (unsigned)((units + 1) / 2 < 2048 ? (units + 1) / 2 : 2048);
+  if (sc->mlp_hidden == 64) k_shade_generic_bwd<64><<<grid, 128, 0, (hipStream_t)stream>>>(a);
+  else k_shade_generic_bwd<128><<<grid, 128, 0, (hipStream_t)stream>>>(a);
+  return ego_launch_status("k_shade_generic_bwd");
+}
+
+int ego_scatter_generic(const ego_vm_field* field, const ego_vm_grad* grad, const float* coords, const float* d, int32_t ldd, int64_t N, int32_t S,
+                        void* stream) {
+  EGO_REQUIRE(field && grad && N >= 0 && S >= 1 && ldd >= 0, "scatter_generic: null argument or bad size");
+  if (N == 0) return EGO_OK;
+  EGO_REQUIRE(coords && d, "scatter_generic: null argument");
+  const int C = field->n_comp;
+  if (C < 4 || C > 48 || (C & 3)) return ego_fail(EGO_E_UNSUPPORTED, "scatter_generic: n_comp %d (supported: multiples of 4 up to 48)", C);
+  EGO_REQUIRE(ldd == 0 || (ldd >= 3 * C && (ldd & 3) == 0 && ((uintptr_t)d & 15) == 0), "scatter_generic: ldd must be 0 (density) or >= 3 C, a multiple of 4");
+  GenScatterArgs a{};
+  a.F = make_field(*field);
+  for (int g = 0; g < 2; ++g)
+    for (int i = 0; i < 3; ++i) {
+      EGO_REQUIRE(field->plane[g][i] && field->line[g][i] && grad->plane[g][i] && grad->line[g][i], "scatter_generic: null table");
+      a.gplane[g][i] = grad->plane[g][i]; a.gline[g][i] = grad->line[g][i];
+    }
+  a.coords = coords; a.d = d; a.M = N * (int64_t)S; a.C = C; a.ldd = ldd;
+  const int64_t n = a.M * 3;
+  k_scatter_generic<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(a);
+  return ego_launch_status("k_scatter_generic");
+}
+
+}  // extern "C"

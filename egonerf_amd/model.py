@@ -871,9 +871,7 @@ class EgoNeRF(TensorBase):
         else:
             jitter = u = None
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            if not self.is_tuned_shape:
-                raise NotImplementedError("the differentiable path (training) is built for the tuned model shape only (app_dim 27, 48 / 16 "
-                                          "components, MLP_Fea 150/128/128, view_pe = fea_pe = 2); other shapes render under torch.no_grad()")
+            # any supported shape trains: the tuned one through the MFMA kernels, the others through the fp32 compatibility kernels
             from .train import render_train  # differentiable path: keeps activations, backward in HIP (egonerf_amd/train.py)
             return render_train(self, rays, n_coarse, n_fine, resampling, use_coarse_sample, jitter, u, z_coarse)
         sc = self.scene()

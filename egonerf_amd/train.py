@@ -137,6 +137,13 @@ def table_params(model, kind: str) -> List[torch.nn.Parameter]:
     return out
 
 
+def head_is_tuned(model) -> bool:
+    """True when the appearance head has the shape the MFMA kernels (forward dumps, ego_shade_backward, ego_scatter_app) are built for:
+    48 components, app_dim 27, MLP_Fea 150 -> 128 -> 128 -> 3 with view_pe = fea_pe = 2.  (The density field's component count is
+    independent: 16 takes ego_scatter_density, anything else ego_scatter_generic.)"""
+    return (model.app_dim, model.app_n_comp[0], model.featureC, model.view_pe, model.fea_pe) == (27, 48, 128, 2, 2)
+
+
 def differentiable_params(model) -> List[torch.nn.Parameter]:
     """Fixed order: 12 density tables, 12 appearance tables, basis yin/yang, mlp (w0,b0,w1,b1,w2,b2)."""
     m = model.renderModule.mlp
@@ -194,11 +201,23 @@ class RenderFunction(torch.autograd.Function):
                                              coords.data_ptr(), sigma.data_ptr(), None, st), "ego_march_density")
         M = N * S
         rgb = f(N, S, 3)
-        Mp = (M + 31) // 32 * 32  # the dumps are tile-blocked ([tile][quad pair][lane][4], csrc/ego_shade.hip dump_off): whole tiles
-        dump = dict(x=f(Mp, 160), h1=f(Mp, 128), h2=f(Mp, 128), v=f(Mp, 144),
-                    relu_bits=torch.empty(Mp // 32, 2, 64, 2, device=dev, dtype=torch.int32))
-        ds = _lib.ShadeDump(*(dump[k].data_ptr() for k in ("x", "h1", "h2", "v", "relu_bits")))
-        _chk(lib.ego_shade(sc, rays.data_ptr(), z.data_ptr(), coords.data_ptr(), N, S, rgb.data_ptr(), C.byref(ds), None, st), "ego_shade")
+        head_tuned = head_is_tuned(model)
+        if head_tuned:
+            Mp = (M + 31) // 32 * 32  # the dumps are tile-blocked ([tile][quad pair][lane][4], csrc/ego_shade.hip dump_off): whole tiles
+            dump = dict(x=f(Mp, 160), h1=f(Mp, 128), h2=f(Mp, 128), v=f(Mp, 144),
+                        relu_bits=torch.empty(Mp // 32, 2, 64, 2, device=dev, dtype=torch.int32))
+            ds = _lib.ShadeDump(*(dump[k].data_ptr() for k in ("x", "h1", "h2", "v", "relu_bits")))
+            _chk(lib.ego_shade(sc, rays.data_ptr(), z.data_ptr(), coords.data_ptr(), N, S, rgb.data_ptr(), C.byref(ds), None, st), "ego_shade")
+        else:
+            # any other model shape (opt.py:87-100): fp32 compatibility kernels over row-major dumps, padded to whole 160-column
+            # blocks (what ego_weight_grad multiplies at a time) with at least one zero column left for the bias gradients
+            in_c = model.renderModule.in_mlpC
+            ldx = (in_c // _G_LD + 1) * _G_LD
+            z0 = lambda *shape: torch.zeros(*shape, device=dev, dtype=torch.float32)
+            dump = dict(x=z0(M, ldx), h1=z0(M, _G_LD), h2=z0(M, _G_LD), v=z0(M, _G_LD))
+            _chk(lib.ego_shade_train_generic(sc, rays.data_ptr(), coords.data_ptr(), N, S, rgb.data_ptr(), dump["x"].data_ptr(), ldx,
+                                             dump["h1"].data_ptr(), dump["h2"].data_ptr(), _G_LD, dump["v"].data_ptr(), _G_LD, st),
+                 "ego_shade_train_generic")
         rgb_map, depth, raw = f(N, 3), f(N), f(N, 3)
         has_env = model.envmap is not None
         bg_map = f(N, 3) if has_env else None
@@ -206,7 +225,7 @@ class RenderFunction(torch.autograd.Function):
         _chk(lib.ego_composite(sc, rays.data_ptr(), z.data_ptr(), weight.data_ptr(), bg.data_ptr(), rgb.data_ptr(), N, S,
                                      rgb_map.data_ptr(), depth.data_ptr(), _lib.ptr(bg_map), _lib.ptr(env_map), raw.data_ptr(), st),
                    "ego_composite")
-        ctx.model, ctx.N, ctx.S = model, N, S
+        ctx.model, ctx.N, ctx.S, ctx.head_tuned = model, N, S, head_tuned
         ctx.saved = dict(z=z, alpha=alpha, weight=weight, sigma=sigma, bg=bg, coords=coords, rgb=rgb, raw=raw, env=env_map, rays=rays,
                          **dump)
         # depth is computed under no_grad in the reference (EgoNeRF.py:595-598); one call: a second would replace the first
@@ -265,8 +284,14 @@ class RenderFunction(torch.autograd.Function):
 
     @staticmethod
     def _backward_body(ctx, lib, st, model, N, S, sv, dev, M, sc, g_rgb, astride, g_dens, g_app, dc, dfeat, gd, main, side, on_side, f):
-        on_side(lambda s_: _chk(lib.ego_scatter_density(sc, C.byref(gd), sv["coords"].data_ptr(), dfeat.data_ptr(), N, S, s_),
-                                      "ego_scatter_density"))
+        if model.density_n_comp[0] == 16:
+            on_side(lambda s_: _chk(lib.ego_scatter_density(sc, C.byref(gd), sv["coords"].data_ptr(), dfeat.data_ptr(), N, S, s_),
+                                          "ego_scatter_density"))
+        else:
+            on_side(lambda s_: _chk(lib.ego_scatter_generic(C.byref(sc.density), C.byref(gd), sv["coords"].data_ptr(), dfeat.data_ptr(), 0, N, S, s_),
+                                          "ego_scatter_generic(density)"))
+        if not ctx.head_tuned:
+            return RenderFunction._backward_generic_head(ctx, lib, st, model, N, S, sv, dev, M, sc, g_rgb, g_dens, g_app, dc, main, side, on_side, f)
         tp = f(lib.ego_train_packed_floats())
         _chk(lib.ego_pack_train(sc, tp.data_ptr(), st), "ego_pack_train")
         Mp = (M + 31) // 32 * 32
@@ -307,6 +332,50 @@ class RenderFunction(torch.autograd.Function):
             grads.append(g_em)
         if side is not None:
             main.wait_stream(side)  # the table gradients are complete; dv / dfeat / coords may be released from here on
+        return (None, None, None, *grads)
+
+
+    @staticmethod
+    def _backward_generic_head(ctx, lib, st, model, N, S, sv, dev, M, sc, g_rgb, g_dens, g_app, dc, main, side, on_side, f):
+        """Backward of the appearance head for any model shape the compatibility kernels support (row-major buffers; the weight
+        gradients are A^T B products in 160-column blocks, already in the reference's [out][in] orientation)."""
+        hid, in_c, ncol, D = model.featureC, model.renderModule.in_mlpC, 3 * model.app_n_comp[0], model.app_dim
+        ldx = sv["x"].shape[1]
+        dh2, dh1, dfe, dv = f(M, hid), f(M, hid), f(M, 64), f(M, _G_LD)
+        _chk(lib.ego_shade_backward_generic(sc, sv["coords"].data_ptr(), dc.data_ptr(), sv["rgb"].data_ptr(), sv["x"].data_ptr(), ldx,
+                                            sv["h1"].data_ptr(), sv["h2"].data_ptr(), _G_LD, dh2.data_ptr(), dh1.data_ptr(), dfe.data_ptr(),
+                                            dv.data_ptr(), _G_LD, N, S, st), "ego_shade_backward_generic")
+        ga = _grad_struct(g_app)
+        on_side(lambda s_: _chk(lib.ego_scatter_generic(C.byref(sc.app), C.byref(ga), sv["coords"].data_ptr(), dv.data_ptr(), _G_LD, N, S, s_),
+                                "ego_scatter_generic(app)"))
+        hp = (hid + 31) // 32 * 32
+        n_chunks = ldx // _G_LD
+
+        def product(A, lda, ca, B_ptr, ldb, ones_col, rows):
+            G = torch.zeros(rows, _G_LD, device=dev)
+            _chk(lib.ego_weight_grad(A.data_ptr(), lda, ca, 0, None, B_ptr, ldb, _G_LD, 0, ones_col, M, G.data_ptr(), _G_LD, st), "ego_weight_grad")
+            return G
+
+        G3 = product(dc.view(M, 3), 3, 3, sv["h2"].data_ptr(), _G_LD, hid, 32)          # do^T [h2 | 1]
+        G2 = product(dh2, hid, hid, sv["h1"].data_ptr(), _G_LD, hid, hp)                  # dh2^T [h1 | 1]
+        G1 = []
+        for c in range(n_chunks):
+            c0 = c * _G_LD
+            ones = in_c - c0 if c0 <= in_c < c0 + _G_LD else -1                          # the first zero-padding column doubles as the ones column
+            G1.append(product(dh1, hid, hid, sv["x"].data_ptr() + 4 * c0, ldx, ones, hp))
+        Gb = product(dfe, 64, 64, sv["v"].data_ptr(), _G_LD, -1, 64)                      # [yin | yang] feature gradients ^T v
+        G1 = torch.cat(G1, dim=1)
+        wg = [Gb[0:D, :ncol].contiguous(), Gb[32:32 + D, :ncol].contiguous(), G1[:hid, :in_c].contiguous(), G1[:hid, in_c].contiguous(),
+              G2[:hid, :hid].contiguous(), G2[:hid, hid].contiguous(), G3[:3, :hid].contiguous(), G3[:3, hid].contiguous()]
+        grads = g_dens + g_app + wg
+        if sv["env"] is not None:
+            g_em = torch.zeros_like(model.envmap.emission)
+            rays = sv["rays"]
+            _chk(lib.ego_envmap_backward(sc, rays.data_ptr() + 12, 6, g_rgb.data_ptr(), sv["raw"].data_ptr(), sv["bg"].data_ptr(),
+                                         sv["env"].data_ptr(), N, g_em.data_ptr(), st), "ego_envmap_backward")
+            grads.append(g_em)
+        if side is not None:
+            main.wait_stream(side)
         return (None, None, None, *grads)
 
 

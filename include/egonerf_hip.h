@@ -320,6 +320,28 @@ int ego_envmap_backward(const ego_scene* sc, const float* dirs, int32_t dir_stri
 int ego_weight_grad(const void* A, int32_t lda, int32_t ca, int32_t a_layout, const float* a_scale, const float* B, int32_t ldb,
                     int32_t cb, int32_t b_blocked, int32_t ones_col, int64_t M, float* G, int32_t ldg, void* stream);
 
+/* ---- training of model shapes other than the tuned one (opt.py:87-100 lets a user choose n_lamb_sigma / n_lamb_sh, data_dim_color,
+ * featureC, view_pe, fea_pe; supported shapes as for ego_packed_floats_scene).  Plain fp32 compatibility kernels over ROW-MAJOR
+ * per-sample buffers, about an order of magnitude slower than the tuned path; ego_march_density / ego_march_backward /
+ * ego_composite / ego_weight_grad (a_layout 0, b_blocked 0, 160-column chunks) serve every shape.  Autograd of EgoNeRF.py:349-413 and
+ * tensorBase.py:54-78, as train.py:312-314 runs it. ---- */
+/* ego_shade for training: rgb [N][S][3] plus the activations the backward needs: x [M][ldx] = the MLP input row in the reference's
+ * column order (tensorBase.py:68-75; columns >= mlp_in are not written: zero the buffer), h1 / h2 [M][ldh] = post-ReLU hidden
+ * activations, v [M][ldv] = plane x line products (column = plane * n_comp + channel; 16-byte aligned, ldv % 4 == 0). */
+int ego_shade_train_generic(const ego_scene* sc, const float* rays, const float* coords, int64_t N, int32_t S, float* rgb, float* x, int32_t ldx,
+                            float* h1, float* h2, int32_t ldh, float* v, int32_t ldv, void* stream);
+/* dc [M][3] in = dL/d rgb_sample, out = dL/d(pre-sigmoid).  Writes dh2, dh1 [M][mlp_hidden], dfe64 [M][64] (the feature gradients of
+ * the sample's own grid g in columns [32 g, 32 g + 32), zeros in the other half: dfe64^T v gives both basis gradients in one
+ * product) and dv [M][ldv] = dL/d(plane x line products). */
+int ego_shade_backward_generic(const ego_scene* sc, const float* coords, float* dc, const float* rgb, const float* x, int32_t ldx, const float* h1,
+                               const float* h2, int32_t ldh, float* dh2, float* dh1, float* dfe64, float* dv, int32_t ldv, int64_t N, int32_t S,
+                               void* stream);
+/* backward of the VM lookups of `field` (any n_comp that is a multiple of 4 up to 48) into `grad` (channel-last like the parameters,
+ * accumulated with float atomics).  ldd == 0: d = dfeat [M] from ego_march_backward (density: the per-plane relu mask of
+ * EgoNeRF.py:340,346 is applied here); ldd > 0: d = dv [M][ldd] from ego_shade_backward_generic (appearance). */
+int ego_scatter_generic(const ego_vm_field* field, const ego_vm_grad* grad, const float* coords, const float* d, int32_t ldd, int64_t N, int32_t S,
+                        void* stream);
+
 /* ---- training-step table ops (train.py:245-330).  Tables are channel-last [H][W][C].  `value` (device double, may be
  * NULL) and `grad` (device, same layout as the table, may be NULL) are ACCUMULATED into, so one buffer collects a whole
  * regulariser and gradients add onto the render's. ---- */

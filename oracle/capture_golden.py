@@ -704,6 +704,34 @@ def capture_shapes():
     np.savez_compressed(os.path.join(OUT, "shapes.npz"), **fx)
 
 
+def capture_shapes_grad():
+    """Autograd of the reference through EgoNeRF.forward (is_train, 16 + 16 resampling, noise pinned; MSE against random targets) for
+    model shapes other than the shipped one: gradients of every parameter (train.py:312-314 on opt.py:87-100's other shapes)."""
+    fx = {}
+    for name in ("small_head", "ctor_defaults", "tuned_head_other_density"):
+        cfg = synth.SceneConfig(n_voxel=20 ** 3, use_envmap=(name == "small_head"), envmap_res_H=16, **SHAPES[name])
+        weights = synth.make_weights(cfg, seed=4321)
+        model, coords = build_reference(cfg, weights)
+        model.train()
+        rays = torch.from_numpy(synth.make_rays(48, seed=17))
+        jit = torch.from_numpy(synth.hash_uniform(15, 0, 48 * 16).reshape(48, 16).astype(np.float32))
+        uu = torch.from_numpy(synth.hash_uniform(15, 1, 48 * 16).reshape(48, 16).astype(np.float32))
+        gt = torch.from_numpy(synth.hash_uniform(16, 0, 48 * 3).reshape(48, 3).astype(np.float32))
+        model.zero_grad()
+        with patched_rand([jit], [uu]):
+            o = run_forward(model, rays, n_coarse=16, n_fine=16, resampling=True, use_coarse_sample=True, is_train=True)
+        loss = torch.mean((o[0] - gt) ** 2)
+        loss.backward()
+        fx.update({f"{name}/jitter": np_(jit), f"{name}/u": np_(uu), f"{name}/gt": np_(gt), f"{name}/rgb": np_(o[0]),
+                   f"{name}/loss": np.float32(loss.item())})
+        for k, p in model.named_parameters():
+            fx[f"{name}/grad/{k}"] = np_(p.grad if p.grad is not None else torch.zeros_like(p))
+        if cfg.use_envmap:
+            fx[f"{name}/grad/envmap.emission"] = np_(model.envmap.emission.grad)
+    fx["seed_weights"], fx["seed_rays"] = 4321, 17
+    np.savez_compressed(os.path.join(OUT, "shapes_grad.npz"), **fx)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     which = sys.argv[1:] or ["tiny", "stages", "full", "alpha_mask", "checkpoint", "train_extras", "metrics", "plainexp", "sh", "uniform", "ricoh", "envmap_full", "ws", "skip", "omniblender", "shapes"]

@@ -90,7 +90,58 @@ def test_hip_renders_other_shapes_like_the_reference(golden, name):
         got = m2(r2.cuda(), n_coarse=37, exp_sampling=True)
         ref = o2.forward(r2, n_coarse=37)
         assert float((got[0].cpu() - ref[0]).abs().max()) <= 1e-4 and float((got[4].cpu() - ref[4]).abs().max()) <= 1e-4
-    # training is built for the tuned shape only: a differentiable call must say so instead of computing something else
+    # training of these shapes: test_training_gradients_on_other_shapes_vs_reference_autograd below
+
+
+def test_oracle_autograd_reproduces_the_reference_gradients_on_other_shapes(golden):
+    """The oracle's autograd (CPU) against the reference's for the same is_train render + MSE (shapes_grad.npz)."""
+    fx = golden("shapes_grad")
+    name = "small_head"
+    cfg = _cfg(name)
+    sc = make_oracle(cfg, synth.make_weights(cfg, seed=int(fx["seed_weights"])))
+    for v in sc.w.values():
+        v.requires_grad_(True)
+    sc.update_coarse_sigma_grid()
+    rays = T(synth.make_rays(48, seed=int(fx["seed_rays"])))
+    rgb = sc.forward(rays, n_coarse=16, n_fine=16, resampling=True, is_train=True, jitter=T(fx[f"{name}/jitter"]), u=T(fx[f"{name}/u"]))[0]
+    assert float((rgb.detach() - T(fx[f"{name}/rgb"])).abs().max()) <= 2e-6
+    torch.mean((rgb - T(fx[f"{name}/gt"])) ** 2).backward()
+    for k in ("density_plane_yin.0", "app_line_yang.2", "basis_mat_yin.weight", "renderModule.mlp.0.weight", "renderModule.mlp.4.bias"):
+        ref = fx[f"{name}/grad/{k}"]
+        assert float((sc.w[k].grad - T(ref)).abs().max()) <= 2e-5 * max(float(np.abs(ref).max()), 1e-12), k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["small_head", "ctor_defaults", "tuned_head_other_density"])
+def test_training_gradients_on_other_shapes_vs_reference_autograd(golden, name):
+    """VERDICT r03 missing #2: the differentiable path for model shapes other than 16 / 48 / 27 / 128 / 2 / 2 (it used to raise):
+    is_train render with pinned noise + MSE, every parameter gradient against the reference's autograd (shapes_grad.npz).
+    small_head: 8 / 24 / 27 / 64 / 2 / 2 with an envmap (compatibility kernels end to end); ctor_defaults: 16 / 48 / 12 / 128 / 6 / 6
+    (390 MLP inputs: three 160-column blocks of the weight-gradient product, tuned density scatter); tuned_head_other_density: the
+    MFMA head on 8 density components (generic march + generic density scatter around the tuned shade kernels)."""
+    fx = golden("shapes_grad")
+    cfg = _cfg(name)
+    model = make_model(cfg, synth.make_weights(cfg, seed=int(fx["seed_weights"])), "cuda")
     model.train()
-    with pytest.raises(NotImplementedError, match="tuned model shape"):
-        model(rays, is_train=True, n_coarse=16, exp_sampling=True)
+    rays = T(synth.make_rays(48, seed=int(fx["seed_rays"]))).cuda()
+    rgb, depth, _, _, alpha = model(rays, is_train=True, n_coarse=16, n_fine=16, exp_sampling=True, resampling=True, use_coarse_sample=True,
+                                    jitter=T(fx[f"{name}/jitter"]).cuda(), u=T(fx[f"{name}/u"]).cuda())
+    assert rgb.requires_grad and float((rgb.detach().cpu() - T(fx[f"{name}/rgb"])).abs().max()) <= 1e-4
+    loss = torch.mean((rgb - T(fx[f"{name}/gt"]).cuda()) ** 2)
+    assert abs(loss.item() - float(fx[f"{name}/loss"])) <= 1e-6
+    loss.backward()
+    named = dict(model.named_parameters())
+    if cfg.use_envmap:
+        named["envmap.emission"] = model.envmap.emission
+    worst = {}
+    for k, p in named.items():
+        ref = fx[f"{name}/grad/{k}"]
+        assert p.grad is not None, k
+        g = p.grad.detach().cpu().numpy()
+        assert g.shape == ref.shape, k
+        worst[k] = float(np.abs(g - ref).max()) / max(float(np.abs(ref).max()), 1e-12)
+    bad = {k: v for k, v in worst.items() if v > 2e-4}
+    assert not bad, bad
+    # and a FusedAdam step on these gradients runs (the optimiser is shape-agnostic)
+    from egonerf_amd.optim import FusedAdam
+    FusedAdam(model.get_optparam_groups(0.02, 1e-3), betas=(0.9, 0.99)).step()

@@ -12,6 +12,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
+export EGO_SKIP_SELFTEST=1   # the self-test launches the SHIPPED shade kernels on a tiny scene: it would dilute their per-dispatch averages
 B="python $ROOT/bench.py --no-cpu-baseline --no-secondary"
 # kernel-trace stats: render at its default step count (steady-state per-kernel averages), train, erp
 rocprofv3 --kernel-trace --stats -d "$OUT/trace_render" -o trace -- $B > "$OUT/bench_render_under_trace.log" 2>&1

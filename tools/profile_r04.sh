@@ -11,6 +11,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
+export EGO_SKIP_SELFTEST=1   # the self-test launches the SHIPPED shade kernels on a tiny scene: it would dilute their per-dispatch averages
 B="python $ROOT/bench.py --no-cpu-baseline --no-secondary"
 rocprofv3 --kernel-trace --stats -d "$OUT/trace_fresh" -o trace -- $B --fresh-rays 64 --steps 128 --warmup 8 > "$OUT/bench_fresh_under_trace.log" 2>&1
 rocprofv3 --kernel-trace --stats -d "$OUT/trace_big" -o trace -- $B --fresh-rays 64 --n-voxel 216e6 --steps 64 --warmup 8 > "$OUT/bench_big_under_trace.log" 2>&1
