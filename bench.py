@@ -1093,7 +1093,7 @@ def run_secondary(a, rk: Ranks):
             ("erp_masked", run_erp, sub(config="erp", steps=2, warmup=1, views=2, erp_size=[1024, 2048], mask=True, carve=True, term_eps=0.0,
                                         density_shift=None)),
             ("erp_opaque_field", run_erp, sub(config="erp", steps=2, warmup=1, views=2, erp_size=[1024, 2048], mask=False, term_eps=0.0,
-                                              density_shift=0.0, carve=False, no_cpu_baseline=True)))
+                                              density_shift=0.0, carve=False)))   # with its own parity leg + cpu_baseline
     for name, fn, args in jobs:
         t0 = time.perf_counter()
         try:

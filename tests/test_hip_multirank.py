@@ -156,6 +156,7 @@ def test_bench_default_line_contract():
     assert erp["cpu_baseline"]["value"] > 0 and erp["speedup_vs_cpu"] > 10
     assert opaque["roofline"]["exact_zero_weight_tiles_skipped_frac_in_chunk"] > erp["roofline"]["exact_zero_weight_tiles_skipped_frac_in_chunk"]
     assert opaque["value"] > erp["value"]   # the exact skip pays on a surface-like field
+    assert opaque["parity"]["max_abs_rgb_err"] <= 1e-4 and opaque["cpu_baseline"]["value"] > 0
     # memory-system evidence: a different ray batch every step, and a table set larger than the Infinity Cache
     fresh, big = d["secondary"]["render_fresh_rays"], d["secondary"]["render_big_grid"]
     assert "error" not in fresh and "error" not in big, (fresh.get("error"), big.get("error"))
