@@ -3,8 +3,8 @@
 // ego_shade.hip bake 48 appearance components, app_dim 27, a 150 -> 128 -> 128 -> 3 MLP with two encoding frequencies and 16
 // density components into their register layouts; these kernels take the shape as runtime numbers (hidden width as a template
 // parameter) and compute in plain fp32 with the reference's operation order, so that any reference checkpoint renders on the
-// device.  They are a compatibility path, an order of magnitude slower than the tuned one and inference only; the host layer picks
-// them exactly when ego_shape_is_tuned() is false.
+// device.  They are a compatibility path, an order of magnitude slower than the tuned one (forward AND, since round 4, backward); the
+// host layer picks them exactly when ego_shape_is_tuned() is false.
 //
 //   k_march_generic : rows A-E for C density components (multiple of 4, <= 48), lane = sample, wave per ray
 //   k_shade_generic : rows F, G (EgoNeRF.py:349-413, tensorBase.py:54-78): appearance gather + per-grid basis + positional

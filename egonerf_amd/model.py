@@ -521,8 +521,8 @@ class EgoNeRF(TensorBase):
         """True for the model shape every shipped config resolves to (app_dim 27, 48 appearance and 16 density components,
         MLP_Fea 150 -> 128 -> 128 -> 3 with view_pe = fea_pe = 2): the MFMA kernels, forward and backward.  Any other shape
         opt.py:87-100 can produce (n_lamb_sigma / n_lamb_sh multiples of 4 up to 48, data_dim_color <= 32, featureC 64 | 128,
-        view_pe / fea_pe <= 8) renders through the fp32 compatibility kernels: same results to fp32 rounding, roughly an order of
-        magnitude slower, inference only."""
+        view_pe / fea_pe <= 8) renders and trains through the fp32 compatibility kernels: same results to fp32 rounding, roughly an
+        order of magnitude slower."""
         return (self.app_dim, self.app_n_comp[0], self.density_n_comp[0], self.featureC, self.view_pe, self.fea_pe) == (27, 48, 16, 128, 2, 2)
 
     @property

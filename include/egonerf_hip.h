@@ -139,7 +139,8 @@ int64_t ego_packed_floats(void);
  * every shipped config resolves to (27 / 48 / 150 / 128 / 2 / 2), the fp32 layout of the any-shape compatibility kernels otherwise
  * (opt.py:87-100 lets a user choose n_lamb_sh, data_dim_color, featureC, view_pe, fea_pe; supported: n_comp a multiple of 4 up to
  * 48, app_dim <= 32, featureC 64 or 128, view_pe / fea_pe <= 8; density n_comp a multiple of 4 up to 48).  Those kernels compute
- * in plain fp32, are inference only (no activation dumps / backward) and about an order of magnitude slower than the tuned path. */
+ * in plain fp32 and are about an order of magnitude slower than the tuned path; they train through ego_shade_train_generic /
+ * ego_shade_backward_generic / ego_scatter_generic (row-major buffers; ego_shade's `dump` argument is for the tuned shape only). */
 int64_t ego_packed_floats_scene(const ego_scene* sc);
 
 int ego_abi_version(void);
