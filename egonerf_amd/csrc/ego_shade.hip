@@ -283,6 +283,122 @@ __global__ void k_pack_mlp_f8(const float* __restrict__ w1, const float* __restr
   out[idx] = __builtin_bit_cast(float, word);
 }
 
+// ---- fp16 main term + fp6 correction terms ("f16f6") weight layout ------------------------------------------------------------
+// Same split as f16f8, with the two correction terms on the fp6 (e2m3) path of v_mfma_scale_f32_32x32x64_f8f6f4, which runs at
+// 1.18x the time of one fp16 32x32x16 instruction where the fp8 path takes 2.0x, and whose operands one conversion instruction
+// produces for 32 values at a time (v_cvt_scalef32_pk32_fp6_f16 / v_cvt_scalef32_2xpk16_fp6_f32: 64 clk per 32 values against
+// 16 x ~10 clk on the fp8 path; tools/fp6_probe.hip, profiles/r04/fp6_probe.txt).  e2m3 spans 6 binades only, so every block of 32
+// K values of a lane carries its own power-of-two scale (the instruction's E8M0 block scale is per lane): static for the weights
+// (from the block's largest magnitude), dynamic for the activations (exponent of the largest |x| of the lane's 32 values).
+// A GROUP is 4 k-steps = 32 values of a lane half; per group and m-tile two fp6 MFMAs: term 0 = w_lo * x_hi, term 1 = w_hi * x_lo.
+// Element e of a lane's 192-bit operand sits at bits [6e, 6e + 6); it carries the lane's K value f6_value(layer, group, term, e):
+//   term 0 (B from pk32_fp6_f16 of the four steps' packed halves): value 32 g + e
+//   term 1 (B from 2xpk16_fp6_f32 of the residuals, which interleaves its two 16-value sources): even e -> 32 g + e / 2, odd e -> 32 g + 16 + e / 2
+//   layer 1's last group holds only steps 8, 9: both terms come from 2xpk16(values, zeros): even e -> 64 + e / 2, odd e -> none
+// Scale bytes: with eb = biased exponent of the block's largest |x| (clamped to >= 14) the conversions divide by 2^(eb - 129) (x) and
+// 2^(eb - 140) (residual, i.e. 2^-11 further down) and the MFMAs pass eb itself as B's block scale; the 2^-2 / 2^-13 that this
+// overstates is folded into A's static scale byte, which is biased(weight block scale) - 2 (term 0) / - 13 (term 1).
+// Region layout (32-bit slots, inside the same OFF_W1 / OFF_W2 extents): per layer the fp16 hi fragments [step][m-tile][lane][8 halves]
+// (as f16f8), then per group: four m-tile blocks of 12 x 64 slots (term 0 dwords 0-3 [lane][4], dwords 4-5 [lane][2] | the same for
+// term 1) followed by the scale bytes [lane][2 dwords]: byte mt of dword t = block scale of (term t, m-tile mt) - the MFMA's op_sel
+// picks the byte.
+constexpr int G6_1 = 3, G6_2 = 2;                 // groups per layer
+constexpr int F6_BLK = 12 * 64;                   // slots per (group, m-tile)
+constexpr int F6_GRP = 4 * F6_BLK + 2 * 64;       // slots per group
+constexpr int F6_HI1 = F8_HI1, F6_HI2 = F8_HI2;
+constexpr int F6_FLOATS = OFF_B1;
+static_assert(F6_HI1 + G6_1 * F6_GRP <= OFF_W2 - OFF_W1 && F6_HI2 + G6_2 * F6_GRP <= OFF_B1 - OFF_W2, "f16f6 regions must fit the LDS image");
+
+__host__ __device__ constexpr int f6_value(int layer2, int grp, int term, int e) {
+  if (!layer2 && grp == G6_1 - 1) return (e & 1) ? -1 : 64 + (e >> 1);
+  if (term == 0) return 32 * grp + e;
+  return 32 * grp + ((e & 1) ? 16 + (e >> 1) : (e >> 1));
+}
+
+// e2m3 code of v (already divided by its block scale): round to nearest even, saturating at 7.5
+__device__ inline uint32_t e2m3_code(float v) {
+  const uint32_t s = v < 0.f ? 32u : 0u;
+  const float a = fminf(fabsf(v), 7.5f);
+  if (a < 1.0f) return s | (uint32_t)rintf(a * 8.0f);     // subnormal step 1/8; 8 = the code of 1.0
+  const int e = a < 2.0f ? 0 : (a < 4.0f ? 1 : 2);
+  int m = (int)rintf(ldexpf(a, 3 - e));                    // 8..16
+  int ee = e;
+  if (m == 16) { m = 8; ee = e + 1; }
+  if (ee > 2) return s | 31u;
+  return s | (uint32_t)(((ee + 1) << 3) | (m - 8));
+}
+
+__device__ inline float mlp_weight_k(const float* __restrict__ w1, const float* __restrict__ w2, bool l2, int k, int lane, int mt) {
+  if (!l2) {
+    const int ch = k < KS1 ? x_channel(k, lane >> 5) : -1;
+    return ch >= 0 ? w1[(mt * 32 + (lane & 31)) * MLP_IN + ch] : 0.f;
+  }
+  return w2[(mt * 32 + (lane & 31)) * HID + (k >> 4) * 32 + slot_row(k & 15, lane >> 5)];
+}
+
+// one thread per 32-bit slot of the hi parts / per (layer, group, m-tile, lane) of the fp6 blocks
+__global__ void k_pack_mlp_f6(const float* __restrict__ w1, const float* __restrict__ w2, float* __restrict__ out) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t* o = (uint32_t*)out;
+  const int n_hi = F6_HI1 + F6_HI2;
+  if (idx < n_hi) {  // [step][mt][lane][8 halves]
+    const bool l2 = idx >= F6_HI1;
+    const int e0 = l2 ? idx - F6_HI1 : idx;
+    _Float16 pr[2];
+    for (int p = 0; p < 2; ++p) {
+      const int hidx = e0 * 2 + p;
+      const int e = hidx & 7, lane = (hidx >> 3) & 63, mt = (hidx >> 9) & 3, step = hidx >> 11;
+      _Float16 hi, lo;
+      split_weight(mlp_weight_k(w1, w2, l2, step * 8 + e, lane, mt), hi, lo);
+      pr[p] = hi;
+    }
+    typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+    h2v v = {pr[0], pr[1]};
+    o[(l2 ? OFF_W2 : OFF_W1) + e0] = __builtin_bit_cast(uint32_t, v);
+    return;
+  }
+  const int t = idx - n_hi;
+  if (t >= (G6_1 + G6_2) * 4 * 64) return;
+  const int lane = t & 63, mt = (t >> 6) & 3, gg = t >> 8;
+  const bool l2 = gg >= G6_1;
+  const int grp = l2 ? gg - G6_1 : gg;
+  uint32_t* gbase = o + (l2 ? OFF_W2 + F6_HI2 : OFF_W1 + F6_HI1) + grp * F6_GRP;
+  uint32_t* blk = gbase + mt * F6_BLK;
+  uint8_t* scales = (uint8_t*)(gbase + 4 * F6_BLK);   // [lane][term][mt]
+  for (int term = 0; term < 2; ++term) {
+    float v[32];
+    float amax = 0.f;
+    for (int e = 0; e < 32; ++e) {
+      const int k = f6_value(l2, grp, term, e);
+      float w = 0.f;
+      if (k >= 0) {
+        _Float16 hi, lo;
+        const float wf = mlp_weight_k(w1, w2, l2, k, lane, mt);
+        split_weight(wf, hi, lo);
+        w = term == 0 ? wf - (float)hi : (float)hi;   // term 0 carries the exact fp32 residual of the weight, term 1 a copy of its fp16 part
+      }
+      v[e] = w;
+      amax = fmaxf(amax, fabsf(w));
+    }
+    int E = amax > 0.f ? ilogbf(amax) : -100;
+    if (E < -100) E = -100;
+    if (ldexpf(amax, 2 - E) > 7.75f) E += 1;          // the largest element would saturate: one binade up
+    const float inv = ldexpf(1.0f, 2 - E);            // 1 / block scale, block scale = 2^(E - 2)
+    uint32_t wd[6] = {0, 0, 0, 0, 0, 0};
+    for (int e = 0; e < 32; ++e) {
+      const uint32_t c = e2m3_code(v[e] * inv);
+      const int bit = 6 * e, wi = bit >> 5, sh = bit & 31;
+      wd[wi] |= c << sh;
+      if (sh > 26) wd[wi + 1] |= c >> (32 - sh);
+    }
+    for (int d = 0; d < 4; ++d) blk[term * 384 + lane * 4 + d] = wd[d];
+    blk[term * 384 + 256 + lane * 2] = wd[4];
+    blk[term * 384 + 256 + lane * 2 + 1] = wd[5];
+    const int byte = (E - 2) + 127 - (term == 0 ? 2 : 13);
+    scales[lane * 8 + term * 4 + mt] = (uint8_t)(byte < 0 ? 0 : (byte > 254 ? 254 : byte));
+  }
+}
+
 enum { MODE_SHADE = 0, MODE_APP = 1, MODE_MLP = 2 };
 
 struct ShadeArgs {
@@ -667,6 +783,124 @@ __device__ __forceinline__ v8i load_a8(const u32x4* __restrict__ WF, int pair, i
   return v8i{(int)p0.x, (int)p0.y, (int)p0.z, (int)p0.w, (int)p1.x, (int)p1.y, (int)p1.z, (int)p1.w};
 }
 
+// ---- f16f6 arithmetic (layout: k_pack_mlp_f6) ------------------------------------------------------------------------------------------
+typedef int v16i __attribute__((ext_vector_type(16)));
+typedef _Float16 h32 __attribute__((ext_vector_type(32)));
+#define MFMA6(a, b, c, sa, opa, sb) __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4((a), (b), (c), 2, 2, (opa), (sa), 0, (sb))
+
+// one k-step's 8 values -> packed fp16 main operand (also written to dwords 4 s .. 4 s + 3 of the group's hp), the 8 exact residuals
+// x - fp16(x), and the running maximum of |x| over the group
+// mmask (a constant after unrolling): bit e set = value e takes part in the maximum (layer 1 knows that its sines and cosines are bounded by 1)
+__device__ __forceinline__ h8 split8_f6(const float x[8], uint32_t* hp, float* res, float& amax, int mmask = 0xff) {
+  u32x4 hi;
+  float neg1 = -1.0f;
+  asm("" : "+v"(neg1));
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float a = x[2 * q], b = x[2 * q + 1];
+    typedef float f2v __attribute__((ext_vector_type(2)));
+    typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+    const h2v hpv = __builtin_convertvector(f2v{a, b}, h2v);
+    hi[q] = __builtin_bit_cast(uint32_t, hpv);
+    hp[q] = hi[q];
+    res[2 * q] = __builtin_fmaf((float)hpv[0], neg1, a);
+    res[2 * q + 1] = __builtin_fmaf((float)hpv[1], neg1, b);
+    const bool ma = (mmask >> (2 * q)) & 1, mb = (mmask >> (2 * q + 1)) & 1;
+    if (ma && mb) amax = fmaxf(fmaxf(fabsf(a), fabsf(b)), amax);
+    else if (ma) amax = fmaxf(fabsf(a), amax);
+    else if (mb) amax = fmaxf(fabsf(b), amax);
+  }
+  return __builtin_bit_cast(h8, hi);
+}
+
+// The 32-value conversions run in passes and write their destination registers while later passes still read the scale and the
+// sources: with the scale, or any but the first registers of a source tuple, in a destination register the result is wrong
+// (tools/fp6_overlap_probe.hip, profiles/r04/fp6_overlap_probe.txt) - and this compiler's register allocator produces exactly such
+// overlaps for the builtins (their definitions carry no early-clobber; keeping the operands live past the builtin does not help,
+// the allocator copies tuples).  So the two conversions are issued through inline asm with an early-clobber destination.  What the
+// compiler's hazard recogniser cannot see into is covered inside the block: one wait state before (a VALU result feeding the
+// conversion) and two after it (conversion result -> MFMA operand needs one: tools/fp6_raw_probe.hip).
+typedef uint32_t u32x6 __attribute__((ext_vector_type(6)));
+__device__ __forceinline__ u32x6 cvt_pk32_fp6_f16(const v16i& halves, float scale) {
+  u32x6 r;
+  asm("s_nop 0\n\tv_cvt_scalef32_pk32_fp6_f16 %0, %1, %2\n\ts_nop 1" : "=&v"(r) : "v"(halves), "v"(scale));
+  return r;
+}
+__device__ __forceinline__ u32x6 cvt_2xpk16_fp6_f32(const f32x16& a, const f32x16& b, float scale) {
+  u32x6 r;
+  asm("s_nop 0\n\tv_cvt_scalef32_2xpk16_fp6_f32 %0, %1, %2, %3\n\ts_nop 1" : "=&v"(r) : "v"(a), "v"(b), "v"(scale));
+  return r;
+}
+
+struct B6 {
+  v8i x, r;   // fp6 operands of the two correction terms (dwords 6, 7 unused)
+  int sb;     // B's block scale byte (biased exponent of the group's largest |x|)
+};
+
+__device__ __forceinline__ void f6_scales(float amax, int& eb, float& sx, float& sr) {
+  uint32_t e = __float_as_uint(amax) >> 23;
+  e = e < 14u ? 14u : e;
+  eb = (int)e;
+  sx = __uint_as_float((e - 2u) << 23);
+  sr = __uint_as_float((e - 13u) << 23);
+}
+
+// full group: hp = the 16 packed-half dwords of its 32 values, res = their 32 residuals in value order
+__device__ __forceinline__ B6 group6(const uint32_t hp[16], const float res[32], float amax) {
+  B6 o;
+  float sx, sr;
+  f6_scales(amax, o.sb, sx, sr);
+  v16i hv;
+  f32x16 ra, rb;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { hv[i] = (int)hp[i]; ra[i] = res[i]; rb[i] = res[16 + i]; }
+  const u32x6 x6 = cvt_pk32_fp6_f16(hv, sx);
+  const u32x6 r6 = cvt_2xpk16_fp6_f32(ra, rb, sr);
+  o.x = v8i{(int)x6[0], (int)x6[1], (int)x6[2], (int)x6[3], (int)x6[4], (int)x6[5], 0, 0};
+  o.r = v8i{(int)r6[0], (int)r6[1], (int)r6[2], (int)r6[3], (int)r6[4], (int)r6[5], 0, 0};
+  return o;
+}
+
+// half group (layer 1's last: 16 values): both operands through the interleaving conversion with a zero second source
+__device__ __forceinline__ B6 group6_half(const float xv[16], const float res[16], float amax) {
+  B6 o;
+  float sx, sr;
+  f6_scales(amax, o.sb, sx, sr);
+  f32x16 xa, ra, z;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { xa[i] = xv[i]; ra[i] = res[i]; z[i] = 0.f; }
+  const u32x6 x6 = cvt_2xpk16_fp6_f32(xa, z, sx);
+  const u32x6 r6 = cvt_2xpk16_fp6_f32(ra, z, sr);
+  o.x = v8i{(int)x6[0], (int)x6[1], (int)x6[2], (int)x6[3], (int)x6[4], (int)x6[5], 0, 0};
+  o.r = v8i{(int)r6[0], (int)r6[1], (int)r6[2], (int)r6[3], (int)r6[4], (int)r6[5], 0, 0};
+  return o;
+}
+
+// blk: LDS dwords of one layer's fp6 groups; one term's fragment of (group, m-tile)
+__device__ __forceinline__ v8i load_a6(const uint32_t* __restrict__ blk, int grp, int mt, int term, int lane) {
+  const uint32_t* b = blk + grp * F6_GRP + mt * F6_BLK + term * 384;
+  const u32x4 h = ((const u32x4*)b)[lane];
+  const u32x2 t = ((const u32x2*)(b + 256))[lane];
+  return v8i{(int)h.x, (int)h.y, (int)h.z, (int)h.w, (int)t.x, (int)t.y, 0, 0};
+}
+
+__device__ __forceinline__ void group_mfma6(const uint32_t* __restrict__ blk, int grp, int lane, const B6& b, f32x16 (&H)[4]) {
+  v8i a[4];
+  const u32x2 sa = ((const u32x2*)(blk + grp * F6_GRP + 4 * F6_BLK))[lane];   // byte mt of .x: term 0's block scales, of .y: term 1's
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) a[mt] = load_a6(blk, grp, mt, 0, lane);
+  H[0] = MFMA6(a[0], b.x, H[0], (int)sa.x, 0, b.sb);
+  H[1] = MFMA6(a[1], b.x, H[1], (int)sa.x, 1, b.sb);
+  H[2] = MFMA6(a[2], b.x, H[2], (int)sa.x, 2, b.sb);
+  H[3] = MFMA6(a[3], b.x, H[3], (int)sa.x, 3, b.sb);
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) a[mt] = load_a6(blk, grp, mt, 1, lane);
+  H[0] = MFMA6(a[0], b.r, H[0], (int)sa.y, 0, b.sb);
+  H[1] = MFMA6(a[1], b.r, H[1], (int)sa.y, 1, b.sb);
+  H[2] = MFMA6(a[2], b.r, H[2], (int)sa.y, 2, b.sb);
+  H[3] = MFMA6(a[3], b.r, H[3], (int)sa.y, 3, b.sb);
+}
+
 struct BasisFrag {
 
   h8 hi, lo;
@@ -997,19 +1231,21 @@ __device__ __forceinline__ void gather_basis_f16(const DevField& F, const VMTaps
   basis_step(f0, v2, keep, fe); basis_step(f1, v2 + 8, keep, fe); basis_step(f2, v2 + 16, keep, fe);
 }
 
-template <int MODE, bool DUMP = false, bool TAB16 = false, bool P8 = false>
+// PX: arithmetic of the MLP's correction terms: 0 = fp16 (f16x3), 1 = fp8 (f16f8), 2 = fp6 (f16f6)
+template <int MODE, bool DUMP = false, bool TAB16 = false, int PX = 0>
 __global__ __launch_bounds__(512) void k_shade_h(ShadeArgs A) {
-  static_assert(!P8 || (!DUMP && MODE != MODE_APP), "the fp8-correction arithmetic exists for the inference MLP only");
+  constexpr bool P8 = PX == 1, P6 = PX == 2;
+  static_assert(!PX || (!DUMP && MODE != MODE_APP), "the fp8 / fp6 correction arithmetic exists for the inference MLP only");
   __shared__ __attribute__((aligned(16))) float lds[(MODE == MODE_APP ? 0 : LDS_W_FLOATS) + 4];
   const float* blob = A.packed + PACKED_FLOATS;  // the f16x3 half of the packed blob
   if (MODE != MODE_APP) {
     const f32x4* src = (const f32x4*)blob;
-    const f32x4* src8 = (const f32x4*)(A.packed + 2 * PACKED_FLOATS + BASIS16_FLOATS_C);  // f16f8 layout of W1 / W2
+    const f32x4* src8 = (const f32x4*)(A.packed + 2 * PACKED_FLOATS + BASIS16_FLOATS_C + (P6 ? F8_FLOATS : 0));  // f16f8 / f16f6 layout of W1 / W2
     f32x4* dst = (f32x4*)lds;
-    for (int i = threadIdx.x; i < LDS_W_FLOATS / 4; i += 512) dst[i] = (P8 && i < F8_FLOATS / 4) ? src8[i] : src[i];
+    for (int i = threadIdx.x; i < LDS_W_FLOATS / 4; i += 512) dst[i] = (PX && i < F8_FLOATS / 4) ? src8[i] : src[i];
   }
   __syncthreads();
-  if (P8) {
+  if (PX) {
     // MODE.FP16_OVFL = 1: an out-of-range f32 -> fp8 / f16 conversion saturates to the largest finite value instead of producing
     // NaN / inf (v_cvt_pk_fp8_f32 returns NaN above 448, tools/fp8_layout_probe.hip); a saturated correction operand costs accuracy
     // of one low-order term, a NaN would poison the pixel
@@ -1195,6 +1431,63 @@ __global__ __launch_bounds__(512) void k_shade_h(ShadeArgs A) {
           }
         }
       }
+    } else if (P6) {
+      float s1 = 0.f, c1 = 0.f, s2 = 0.f, c2 = 0.f;
+      const uint32_t* W1F = (const uint32_t*)W1 + F6_HI1;
+      h8 ah[4], nh[4];
+      uint32_t hp[16];
+      float res[32], xl[16];
+      float amax = 1.f;
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) nh[mt] = __builtin_bit_cast(h8, W1[mt * 64 + lw]);
+      // step-outer / value-inner: the flat 80-iteration form of the other arithmetics exceeds the unroller's size limit with the group
+      // code in its body, and a rolled loop indexes the register arrays through scratch
+#pragma unroll
+      for (int step = 0; step < KH1; ++step) {
+        float xs[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int kk = step * 8 + e;
+          float x;
+          if (kk < 5 * NSLOT) {
+            const int r = kk / 5, kind = kk % 5;
+            if (kind == 0) sincos_x_2x_hw(fe[r], s1, c1, s2, c2);
+            x = kind == 0 ? fe[r] : (kind == 1 ? s1 : (kind == 2 ? s2 : (kind == 3 ? c1 : c2)));
+          } else if (kk < 5 * NSLOT + 8) {
+            x = vw[kk - 5 * NSLOT];
+          } else {
+            x = 0.f;
+          }
+          xs[e] = x;
+          if (kk >= 64) xl[kk - 64] = x;
+        }
+        const int sg = step & 3;
+        // the block maximum only has to look at the unbounded values (features, raw view direction): every group holds cosines of
+        // magnitude ~1 and nothing else above 1, so the running maximum starts at 1
+        int mmask = 0;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int kk = step * 8 + e;
+          if ((kk < 5 * NSLOT && kk % 5 == 0) || (kk >= 5 * NSLOT && kk < 5 * NSLOT + 3)) mmask |= 1 << e;
+        }
+        const h8 bh = split8_f6(xs, hp + 4 * sg, res + 8 * sg, amax, mmask);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) ah[mt] = nh[mt];
+        if (step + 1 < KH1) {
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt) nh[mt] = __builtin_bit_cast(h8, W1[((step + 1) * 4 + mt) * 64 + lw]);
+        }
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) H[mt] = MFMAH(ah[mt], bh, H[mt]);
+        if (sg == 3) {
+          const B6 b6 = group6(hp, res, amax);
+          group_mfma6(W1F, step >> 2, lw, b6, H);
+          amax = 1.f;
+        } else if (step == KH1 - 1) {
+          const B6 b6 = group6_half(xl, res, amax);
+          group_mfma6(W1F, G6_1 - 1, lw, b6, H);
+        }
+      }
     } else
     {
       float s1 = 0.f, c1 = 0.f, s2 = 0.f, c2 = 0.f;
@@ -1293,6 +1586,35 @@ __global__ __launch_bounds__(512) void k_shade_h(ShadeArgs A) {
         if (step & 1) {
 #pragma unroll
           for (int mt = 0; mt < 4; ++mt) G[mt] = MFMA8(a8[mt], b8, G[mt]);
+        }
+      }
+    } else if (P6) {
+      const uint32_t* W2F = (const uint32_t*)W2 + F6_HI2;
+      h8 ah[4], nh[4];
+      uint32_t hp[16];
+      float res[32];
+      float amax = 0.f;
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) nh[mt] = __builtin_bit_cast(h8, W2[mt * 64 + lw]);
+#pragma unroll
+      for (int step = 0; step < KH2; ++step) {
+        float xs[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) xs[e] = H[(step * 8 + e) >> 4][(step * 8 + e) & 15];
+        const int sg = step & 3;
+        const h8 bh = split8_f6(xs, hp + 4 * sg, res + 8 * sg, amax);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) ah[mt] = nh[mt];
+        if (step + 1 < KH2) {
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt) nh[mt] = __builtin_bit_cast(h8, W2[((step + 1) * 4 + mt) * 64 + lw]);
+        }
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) G[mt] = MFMAH(ah[mt], bh, G[mt]);
+        if (sg == 3) {
+          const B6 b6 = group6(hp, res, amax);
+          group_mfma6(W2F, step >> 2, lw, b6, G);
+          amax = 0.f;
         }
       }
     } else
@@ -1403,7 +1725,7 @@ extern "C" {
 
 constexpr int BASIS16_FLOATS = 2 * KHB * 2 * 64 * 4;  // [2 g][9 steps][2 terms][64 lanes][8 halves]
 
-int64_t ego_packed_floats(void) { return 2 * (int64_t)PACKED_FLOATS + BASIS16_FLOATS + F8_FLOATS; }
+int64_t ego_packed_floats(void) { return 2 * (int64_t)PACKED_FLOATS + BASIS16_FLOATS + F8_FLOATS + F6_FLOATS; }
 
 int64_t ego_packed_floats_scene(const ego_scene* sc) {
   if (!sc) return -1;
@@ -1428,17 +1750,26 @@ int ego_pack_mlp(const ego_scene* sc, float* packed_out, void* stream) {
   static_assert(BASIS16_FLOATS == BASIS16_FLOATS_C, "blob region sizes");
   k_pack_mlp_f8<<<(F8_FLOATS + 255) / 256, 256, 0, (hipStream_t)stream>>>(sc->mlp_w[0], sc->mlp_w[1],
                                                                           packed_out + 2 * PACKED_FLOATS + BASIS16_FLOATS);
-  return ego_launch_status("k_pack_mlp_f8");
+  if (int e = ego_launch_status("k_pack_mlp_f8")) return e;
+  float* f6 = packed_out + 2 * PACKED_FLOATS + BASIS16_FLOATS + F8_FLOATS;
+  if (const hipError_t err = hipMemsetAsync(f6, 0, sizeof(float) * F6_FLOATS, (hipStream_t)stream)) return (int)err;  // the gaps behind the blocks
+  constexpr int F6_THREADS = F6_HI1 + F6_HI2 + (G6_1 + G6_2) * 4 * 64;
+  k_pack_mlp_f6<<<(F6_THREADS + 255) / 256, 256, 0, (hipStream_t)stream>>>(sc->mlp_w[0], sc->mlp_w[1], f6);
+  return ego_launch_status("k_pack_mlp_f6");
 }
 
 int ego_shade_kernel_info(int32_t precision, int32_t* out, int32_t n) {
   EGO_REQUIRE(out && n == 8, "shade_kernel_info: out must hold 8 values");
-  EGO_REQUIRE(precision == EGO_PREC_F16X3 || precision == EGO_PREC_F32 || precision == EGO_PREC_F16F8, "shade_kernel_info: unknown precision");
+  EGO_REQUIRE(precision == EGO_PREC_F16X3 || precision == EGO_PREC_F32 || precision == EGO_PREC_F16F8 || precision == EGO_PREC_F16F6,
+              "shade_kernel_info: unknown precision");
   out[0] = 32;
   if (precision == EGO_PREC_F32) {          // k_shade: one v_mfma_f32_32x32x2_f32 per k (basis) / per k and m-tile (layers 1, 2)
     out[1] = KS_BASIS + 4 * (KS1 + KS2); out[2] = 0; out[3] = 2 * 32 * 32 * 2; out[4] = 0; out[5] = 0;
   } else if (precision == EGO_PREC_F16X3) {  // three v_mfma_f32_32x32x16_f16 per 8-k step (and m-tile)
     out[1] = 3 * (KHB + 4 * (KH1 + KH2)); out[2] = 0; out[3] = 2 * 32 * 32 * 16; out[4] = 0; out[5] = 0;
+  } else if (precision == EGO_PREC_F16F6) {  // basis as f16x3; layers 1, 2: one fp16 MFMA per step + two fp6 MFMAs per group of four steps
+    out[1] = 3 * KHB + 4 * (KH1 + KH2); out[2] = 4 * 2 * (G6_1 + G6_2); out[3] = 2 * 32 * 32 * 16; out[4] = 2 * 32 * 32 * 64;
+    out[5] = 2 * (G6_1 + G6_2);              // 32-value conversions (v_cvt_scalef32_pk32_fp6_f16 / _2xpk16_fp6_f32)
   } else {                                   // basis as f16x3; layers 1, 2: one fp16 MFMA per step + one fp8 MFMA per pair of steps
     out[1] = 3 * KHB + 4 * (KH1 + KH2); out[2] = 4 * (KH1 / 2 + KH2 / 2); out[3] = 2 * 32 * 32 * 16; out[4] = 2 * 32 * 32 * 64;
     out[5] = (KS1 + KS2) / 2 * 2;            // per pair of values: one v_cvt_pk_fp8_f32 (x) and one v_cvt_scalef32_pk_fp8_f32 (residual)
@@ -1474,7 +1805,8 @@ int ego_mlp_fea(const ego_scene* sc, const float* viewdirs, const float* feat, i
   ShadeArgs a{};
   a.c = make_coords(*sc); a.packed = sc->packed; a.feat = feat; a.dirs = viewdirs; a.out = rgb; a.M = M; a.S = 1;
   if (sc->mlp_precision == EGO_PREC_F32) k_shade<MODE_MLP><<<shade_grid(M), 512, 0, (hipStream_t)stream>>>(a);
-  else if (sc->mlp_precision == EGO_PREC_F16F8) k_shade_h<MODE_MLP, false, false, true><<<shade_grid(M), 512, 0, (hipStream_t)stream>>>(a);
+  else if (sc->mlp_precision == EGO_PREC_F16F8) k_shade_h<MODE_MLP, false, false, 1><<<shade_grid(M), 512, 0, (hipStream_t)stream>>>(a);
+  else if (sc->mlp_precision == EGO_PREC_F16F6) k_shade_h<MODE_MLP, false, false, 2><<<shade_grid(M), 512, 0, (hipStream_t)stream>>>(a);
   else k_shade_h<MODE_MLP><<<shade_grid(M), 512, 0, (hipStream_t)stream>>>(a);
   return ego_launch_status("k_shade<MLP>");
 }
@@ -1504,9 +1836,11 @@ int ego_shade(const ego_scene* sc, const float* rays, const float* z, const floa
   else if (sc->app_f16) {
     if (int e = check_app16(sc, "shade")) return e;
     a.F = make_field(sc->app16);
-    if (sc->mlp_precision == EGO_PREC_F16F8) k_shade_h<MODE_SHADE, false, true, true><<<shade_grid(a.M), 512, 0, (hipStream_t)stream>>>(a);
+    if (sc->mlp_precision == EGO_PREC_F16F8) k_shade_h<MODE_SHADE, false, true, 1><<<shade_grid(a.M), 512, 0, (hipStream_t)stream>>>(a);
+    else if (sc->mlp_precision == EGO_PREC_F16F6) k_shade_h<MODE_SHADE, false, true, 2><<<shade_grid(a.M), 512, 0, (hipStream_t)stream>>>(a);
     else k_shade_h<MODE_SHADE, false, true><<<shade_grid(a.M), 512, 0, (hipStream_t)stream>>>(a);
-  } else if (sc->mlp_precision == EGO_PREC_F16F8) k_shade_h<MODE_SHADE, false, false, true><<<shade_grid(a.M), 512, 0, (hipStream_t)stream>>>(a);
+  } else if (sc->mlp_precision == EGO_PREC_F16F8) k_shade_h<MODE_SHADE, false, false, 1><<<shade_grid(a.M), 512, 0, (hipStream_t)stream>>>(a);
+  else if (sc->mlp_precision == EGO_PREC_F16F6) k_shade_h<MODE_SHADE, false, false, 2><<<shade_grid(a.M), 512, 0, (hipStream_t)stream>>>(a);
   else k_shade_h<MODE_SHADE><<<shade_grid(a.M), 512, 0, (hipStream_t)stream>>>(a);
   return ego_launch_status("k_shade<SHADE>");
 }

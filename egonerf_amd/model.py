@@ -537,8 +537,8 @@ class EgoNeRF(TensorBase):
 
     @mlp_precision.setter
     def mlp_precision(self, value: str):
-        if value not in ("f16x3", "f16f8", "f32"):
-            raise ValueError("mlp_precision must be 'f16x3', 'f16f8' or 'f32'")
+        if value not in ("f16x3", "f16f8", "f16f6", "f32"):
+            raise ValueError("mlp_precision must be 'f16x3', 'f16f8', 'f16f6' or 'f32'")
         self._mlp_precision = value
         self._scene_cache = None
 
@@ -664,7 +664,7 @@ class EgoNeRF(TensorBase):
         sc.app_dim = self.app_dim
         sc.mlp_in, sc.mlp_hidden = self.renderModule.in_mlpC, self.featureC
         sc.view_pe, sc.fea_pe = self.view_pe, self.fea_pe
-        sc.mlp_precision = {"f16x3": 0, "f32": 1, "f16f8": 2}[self._mlp_precision]
+        sc.mlp_precision = {"f16x3": 0, "f32": 1, "f16f8": 2, "f16f6": 3}[self._mlp_precision]
         # packed weights: the MFMA fragment layouts for the tuned shape (27 / 48 / 150 / 128 / 2 / 2, every shipped config), the fp32
         # layout of the any-shape compatibility kernels otherwise (csrc/ego_generic.hip; the library reports the size for the shape)
         sc.app.n_comp = self.app_n_comp[0]

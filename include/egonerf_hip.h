@@ -44,7 +44,7 @@ extern "C" {
 
 #define EGO_ABI_VERSION 11
 
-enum { EGO_PREC_F16X3 = 0, EGO_PREC_F32 = 1, EGO_PREC_F16F8 = 2 };
+enum { EGO_PREC_F16X3 = 0, EGO_PREC_F32 = 1, EGO_PREC_F16F8 = 2, EGO_PREC_F16F6 = 3 };
 
 enum {
   EGO_OK = 0,

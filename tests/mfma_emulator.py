@@ -239,3 +239,156 @@ def pack_mlp_f8(w):
     out[OFF_W1:OFF_W2] = region(f32[OFF_W1:OFF_W2], KS1 // 8)
     out[OFF_W2:OFF_B1] = region(f32[OFF_W2:OFF_B1], KS2 // 8)
     return out
+
+
+# ---- f16f6: fp16 main term + fp6 (e2m3) correction terms with per-lane block scales (k_pack_mlp_f6) ----------------------------------
+G6_1, G6_2, F6_BLK = 3, 2, 12 * 64
+F6_GRP = 4 * F6_BLK + 2 * 64
+F6_FLOATS = OFF_B1
+F6_HI1, F6_HI2 = (KS1 // 8) * 4 * 64 * 4, (KS2 // 8) * 4 * 64 * 4
+
+
+def f6_value(layer2, grp, term, e):
+    """K value (index into the lane half's K order) carried by element e of a lane's 32-element fp6 operand, -1 = none."""
+    if not layer2 and grp == G6_1 - 1:
+        return -1 if e & 1 else 64 + (e >> 1)
+    if term == 0:
+        return 32 * grp + e
+    return 32 * grp + (16 + (e >> 1) if e & 1 else (e >> 1))
+
+
+def e2m3_codes(v):
+    """v (already divided by the block scale) -> 6-bit e2m3 codes, round to nearest even, saturating at 7.5"""
+    v = np.asarray(v, np.float64)
+    s = np.where(v < 0, 32, 0)
+    a = np.minimum(np.abs(v), 7.5)
+    sub = np.rint(a * 8.0)
+    e = np.where(a < 2.0, 0, np.where(a < 4.0, 1, 2))
+    m = np.rint(a * 2.0 ** (3 - e))
+    carry = m == 16
+    ee = np.where(carry, e + 1, e)
+    m = np.where(carry, 8, m)
+    norm = np.where(ee > 2, 31, ((ee + 1) << 3) | (m.astype(np.int64) - 8))
+    return (s | np.where(a < 1.0, sub.astype(np.int64), norm)).astype(np.uint32)
+
+
+def e2m3_decode(c):
+    c = np.asarray(c, np.int64)
+    e, m = (c >> 3) & 3, c & 7
+    f = np.where(e == 0, m / 8.0, (1.0 + m / 8.0) * 2.0 ** (e - 1))
+    return np.where(c & 32, -f, f)
+
+
+def f6_block(v, term):
+    """v [..., 32] float32 values of one lane's operand -> (6 dwords [..., 6], scale byte [...]) as k_pack_mlp_f6 writes them"""
+    v = np.asarray(v, np.float32)
+    amax = np.abs(v).max(-1)
+    E = np.where(amax > 0, np.frexp(np.where(amax > 0, amax, 1.0))[1] - 1, -100)
+    E = np.maximum(E, -100)
+    E = np.where(np.ldexp(amax.astype(np.float64), 2 - E) > 7.75, E + 1, E)
+    codes = e2m3_codes(v.astype(np.float64) * np.ldexp(1.0, 2 - E)[..., None]).astype(np.uint64)
+    bits = np.zeros(v.shape[:-1] + (3,), np.uint64)            # 192 bits as three 64-bit words
+    for e in range(32):
+        bit = 6 * e
+        wi, sh = bit >> 6, bit & 63
+        bits[..., wi] |= (codes[..., e] << np.uint64(sh)) & np.uint64(0xFFFFFFFFFFFFFFFF)
+        if sh > 58:
+            bits[..., wi + 1] |= codes[..., e] >> np.uint64(64 - sh)
+    dw = np.zeros(v.shape[:-1] + (6,), np.uint32)
+    for i in range(6):
+        dw[..., i] = ((bits[..., i >> 1] >> np.uint64(32 * (i & 1))) & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+    byte = np.clip((E - 2) + 127 - (2 if term == 0 else 13), 0, 254).astype(np.uint32)
+    return dw, byte
+
+
+def mlp_k_matrix(w, layer2):
+    """[m-tile][lane][K] weights in the lane halves' K order (K = 96 for layer 1: the 80 values + one padding group's worth of zeros)"""
+    f32 = pack_mlp(w)
+    if layer2:
+        frag, steps = f32[OFF_W2:OFF_B1], KS2 // 8
+    else:
+        frag, steps = f32[OFF_W1:OFF_W2], KS1 // 8
+    kk = frag.reshape(steps * 2, 4, 64, 4).transpose(1, 2, 0, 3).reshape(4, 64, steps * 8)
+    if not layer2:
+        kk = np.concatenate([kk, np.zeros((4, 64, 16), np.float32)], -1)
+    return kk
+
+
+def pack_mlp_f6(w):
+    """Fifth region of the packed blob: per layer the fp16 hi fragments, then per group four m-tile blocks of 12 x 64 slots
+    (term t dwords 0-3 at t * 384 + [lane][4], dwords 4-5 at t * 384 + 256 + [lane][2]) and the scale bytes [lane][term][m-tile]."""
+    out = np.zeros(F6_FLOATS, np.uint32)
+    for layer2, base, hi_slots, groups in ((False, OFF_W1, F6_HI1, G6_1), (True, OFF_W2, F6_HI2, G6_2)):
+        kk = mlp_k_matrix(w, layer2)
+        steps = (KS2 if layer2 else KS1) // 8
+        hi = kk.astype(np.float16)
+        lo = kk - hi.astype(np.float32)
+        hi_part = np.zeros((steps, 4, 64, 8), np.float16)
+        for st in range(steps):
+            hi_part[st] = hi[:, :, st * 8:st * 8 + 8]
+        out[base:base + hi_slots] = hi_part.reshape(-1).view(np.uint32)
+        for grp in range(groups):
+            for term in range(2):
+                src = lo if term == 0 else hi.astype(np.float32)
+                v = np.zeros((4, 64, 32), np.float32)
+                for e in range(32):
+                    k = f6_value(layer2, grp, term, e)
+                    if k >= 0:
+                        v[:, :, e] = src[:, :, k]
+                dw, byte = f6_block(v, term)
+                g0 = base + hi_slots + grp * F6_GRP
+                for mt in range(4):
+                    b0 = g0 + mt * F6_BLK
+                    out[b0 + term * 384: b0 + term * 384 + 256] = dw[mt, :, :4].reshape(-1)
+                    out[b0 + term * 384 + 256: b0 + term * 384 + 384] = dw[mt, :, 4:].reshape(-1)
+                    out[g0 + 4 * F6_BLK + term: g0 + F6_GRP: 2] |= byte[mt] << np.uint32(8 * mt)
+    return out.view(np.float32)
+
+
+def f6_layer_reference(w, layer2, X):
+    """What the f16f6 arithmetic computes for one layer before the bias, in float64, from the PACKED operands: X [n][K] activations in
+    the lane halves' K order for both halves: X[h] [n][K].  Returns [n][128] (unit m * 32 + i).  Test infrastructure: checks that the
+    packed blocks, the element orders and the scale bytes mean what the kernel assumes."""
+    blob = pack_mlp_f6(w).view(np.uint32)
+    base, hi_slots, groups = (OFF_W2, F6_HI2, G6_2) if layer2 else (OFF_W1, F6_HI1, G6_1)
+    steps = (KS2 if layer2 else KS1) // 8
+    n = X[0].shape[0]
+    out = np.zeros((n, 128))
+    hi_frag = blob[base:base + hi_slots].view(np.float16).reshape(steps, 4, 64, 8).astype(np.float64)
+    for h in range(2):
+        x = np.asarray(X[h], np.float32)
+        kpad = 32 * groups
+        xp = np.concatenate([x, np.zeros((n, kpad - x.shape[1]), np.float32)], 1) if x.shape[1] < kpad else x
+        xh = xp.astype(np.float16)
+        xr = (xp - xh.astype(np.float32)).astype(np.float64)
+        for mt in range(4):
+            for i in range(32):
+                lane = i + 32 * h
+                wrow = np.concatenate([hi_frag[st, mt, lane] for st in range(steps)])
+                acc = xh[:, :steps * 8].astype(np.float64) @ wrow
+                for grp in range(groups):
+                    g0 = base + hi_slots + grp * F6_GRP
+                    blk = blob[g0 + mt * F6_BLK:][:F6_BLK]
+                    half = (not layer2) and grp == G6_1 - 1
+                    xg = xp[:, 32 * grp:32 * grp + (16 if half else 32)]
+                    if layer2:
+                        amax = np.abs(xg).max(1)
+                    else:   # the kernel's rule for layer 1: 1 and the unbounded values (features, raw view direction)
+                        ks = [k for k in range(32 * grp, 32 * grp + xg.shape[1]) if (k < 70 and k % 5 == 0) or 70 <= k < 73]
+                        amax = np.maximum(np.abs(xp[:, ks]).max(1), np.float32(1.0))
+                    eb = np.maximum(amax.view(np.uint32) >> 23, 14).astype(np.int64)
+                    for term in range(2):
+                        sword = int(blob[g0 + 4 * F6_BLK + lane * 2 + term]) >> (8 * mt)
+                        dw = np.concatenate([blk[term * 384 + lane * 4: term * 384 + lane * 4 + 4], blk[term * 384 + 256 + lane * 2: term * 384 + 256 + lane * 2 + 2]])
+                        big = sum(int(dw[j]) << (32 * j) for j in range(6))
+                        a = e2m3_decode(np.array([(big >> (6 * e)) & 63 for e in range(32)])) * 2.0 ** ((sword & 255) - 127)
+                        src = xh.astype(np.float64) if term == 0 else xr
+                        scale = 2.0 ** (eb - 127 - (2 if term == 0 else 13))
+                        bvals = np.zeros((n, 32))
+                        for e in range(32):
+                            k = f6_value(layer2, grp, term, e)
+                            if k >= 0:
+                                bvals[:, e] = e2m3_decode(e2m3_codes(src[:, k] / scale)) * 2.0 ** (eb - 127)
+                        acc = acc + bvals @ a
+                out[:, mt * 32 + i] += acc
+    return out
