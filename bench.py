@@ -40,11 +40,13 @@ MFMA_F16_PEAK_TFLOPS = 2500.0  # dense fp16/bf16 MFMA peak
 MFMA_F8_PEAK_TFLOPS = 5000.0   # dense MX-fp8 peak
 N_CU = 256
 N_SIMD = N_CU * 4
-CLK_PER_MFMA = {"f16x3": 32, "f16f8": 32, "f32": 64}   # issue-to-issue cycles of a dependent-free MFMA stream (tools/coissue_probe.hip)
+CLK_PER_MFMA = {"f16x3": 32, "f16f8": 32, "f16f6": 32, "f32": 64}   # issue-to-issue cycles of a dependent-free MFMA stream (tools/coissue_probe.hip)
 CLK_PER_FP8_MFMA = 61          # 1.9x an fp16 instruction (tools/fp8_mfma_probe.hip)
+CLK_PER_FP6_MFMA = 38          # 1.18x an fp16 instruction (tools/fp6_probe.hip)
+MFMA_F6_PEAK_TFLOPS = 10000.0  # dense MX-fp6 / fp4 peak
 CLK_PER_VALU = 4               # a wave64 VALU instruction occupies its SIMD for 4 cycles (16 lanes x 4)
 B_DENSITY = 1152               # algorithmic density tap bytes per sample: 3 * (4 + 2) taps * 16 channels * 4 B
-PREC_CODE = {"f16x3": 0, "f32": 1, "f16f8": 2}
+PREC_CODE = {"f16x3": 0, "f32": 1, "f16f8": 2, "f16f6": 3}
 
 
 def kernel_info(prec: str) -> dict:
@@ -307,7 +309,7 @@ def shade_roofline(prec: str, t_shade: float, M: int, kname_tag: str = "SHADE"):
     it, clearly labelled: `matrix_pipe_busy` (EXECUTED MFMA work incl. the precision-split overhead, each instruction kind against
     its own dense peak), `traffic` (counter-measured HBM bytes per launch) and `hbm_counter_frac` (traffic / time / 8 TB/s)."""
     info = kernel_info(prec)
-    kname = {"f16x3": "k_shade_h<SHADE>", "f16f8": "k_shade_h<SHADE,f16f8>", "f32": "k_shade<SHADE>"}[prec]
+    kname = {"f16x3": "k_shade_h<SHADE>", "f16f8": "k_shade_h<SHADE,f16f8>", "f16f6": "k_shade_h<SHADE,f16f6>", "f32": "k_shade<SHADE>"}[prec]
     pmc, src, stale = load_pmc(kname)
     peak = MFMA_F32_PEAK_TFLOPS if prec == "f32" else MFMA_F16_PEAK_TFLOPS
     alg_flop = info["flop_per_sample"] * M
@@ -325,10 +327,12 @@ def shade_roofline(prec: str, t_shade: float, M: int, kname_tag: str = "SHADE"):
         n8 = info["fp8_mfma_per_tile"] * tiles
         n16 = mfma - n8
         flops16, flops8 = n16 * info["flop_per_mfma"], n8 * info["flop_per_fp8_mfma"]
-        busy = (flops16 / (peak * 1e12) + flops8 / (MFMA_F8_PEAK_TFLOPS * 1e12)) / t_shade
+        busy = (flops16 / (peak * 1e12) + flops8 / ((MFMA_F6_PEAK_TFLOPS if prec == "f16f6" else MFMA_F8_PEAK_TFLOPS) * 1e12)) / t_shade
         clock_ghz = pmc["GRBM_GUI_ACTIVE"] / (pmc["duration_us"] * 1e3) if "duration_us" in pmc else None
         cvt8 = info["fp8_cvt_per_tile"] * tiles
-        bound_clk = (n16 * CLK_PER_MFMA[prec] + n8 * CLK_PER_FP8_MFMA + (valu + cvt8) * CLK_PER_VALU) / N_SIMD
+        clk8 = CLK_PER_FP6_MFMA if prec == "f16f6" else CLK_PER_FP8_MFMA
+        cvt_extra = 15 if prec == "f16f6" else 1   # issue slots beyond the first: a 32-value fp6 conversion holds the VALU for 64 clk, an fp8 pair conversion for 8
+        bound_clk = (n16 * CLK_PER_MFMA[prec] + n8 * clk8 + (valu + cvt8 * cvt_extra) * CLK_PER_VALU) / N_SIMD
         traffic = pmc.get("traffic_bytes")
         out.update(traffic=traffic,
                    hbm_counter_frac=None if traffic is None else traffic / t_shade / (HBM_PEAK_GBPS * 1e9),
@@ -340,7 +344,7 @@ def shade_roofline(prec: str, t_shade: float, M: int, kname_tag: str = "SHADE"):
                                effective_clock_GHz=clock_ghz),
                    issue=None if clock_ghz is None else dict(
                        note="VALU + MFMA issue time per SIMD summed (an upper estimate of the issue time, not a hard bound: conversion-class VALU runs beside the matrix pipe, fp32-FMA-class VALU competes with it, tools/agpr_coissue_probe.hip)",
-                       clk_per_mfma=CLK_PER_MFMA[prec], clk_per_fp8_mfma=CLK_PER_FP8_MFMA if n8 else None, clk_per_valu=CLK_PER_VALU,
+                       clk_per_mfma=CLK_PER_MFMA[prec], clk_per_fp8_mfma=clk8 if n8 else None, clk_per_valu=CLK_PER_VALU,
                        bound_ms=bound_clk / (clock_ghz * 1e6), frac=bound_clk / (clock_ghz * 1e6) / (t_shade * 1e3)))
         if clock_ghz is not None and "TA_BUSY_avr" in pmc and "SQ_INSTS_VMEM_RD_per_SE" in pmc:
             # third resource: the vector L1's address / data path.  A wave64 global_load_dwordx4 occupies it for 16 clk whatever its
@@ -493,7 +497,7 @@ def run_render(a, rk: Ranks):
         step_ms = float(np.median(groups))
         return dict(shade_ms=shade_ms, ms_per_step=step_ms, rays_per_s=N_RAYS / (step_ms * 1e-3))
 
-    variants = {"f16x3": ("f16x3", False), "f16f8": ("f16f8", False), "app_f16+f16f8": ("f16f8", True)}
+    variants = {"f16x3": ("f16x3", False), "f16f8": ("f16f8", False), "f16f6": ("f16f6", False), "app_f16+f16f8": ("f16f8", True)}
     for name, (prec, app16) in variants.items():
         if name == main_prec:
             continue
@@ -546,7 +550,10 @@ def run_render(a, rk: Ranks):
                 ms_per_step=dt / a.steps * 1e3, higher_is_better=True, scaling="weak", vs_baseline=None,
                 dtype={"f16x3": "f32 (tables, interpolation, compositing; matrix products as 3x fp16 MFMA with fp32 accumulate)",
                        "f16f8": "f32 (tables, interpolation, compositing; matrix products: fp16 MFMA main term + block-scaled fp8 MFMA "
-                                "correction terms in the MLP, 3x fp16 MFMA in the basis, fp32 accumulate)", "f32": "f32"}[model.mlp_precision],
+                                "correction terms in the MLP, 3x fp16 MFMA in the basis, fp32 accumulate)",
+                       "f16f6": "f32 (tables, interpolation, compositing; matrix products: fp16 MFMA main term + block-scaled fp6 MFMA "
+                                "correction terms with per-lane dynamic block scales in the MLP, 3x fp16 MFMA in the basis, fp32 accumulate)",
+                       "f32": "f32"}[model.mlp_precision],
                 data="synthetic",
                 config=dict(workload="OmniBlender barbershop shape: grid [150,172,516], 16x3/48x3 comps, MLP_Fea; "
                                      "4096 rays x 512 samples, eval, no resampling (BASELINE configs[1])"

@@ -159,8 +159,8 @@ int ego_selftest(void* workspace, int64_t workspace_bytes, int32_t reps, int32_t
   if (int e = soak([&](float* o) { return ego_app_feature(&sc, ws + L.c7_sc, M_APP, o, stream); }, (int64_t)M_APP * APP_DIM, reps)) return e;
   if (int e = soak([&](float* o) { return ego_app_feature(&sc, ws + L.c7_big, M_APP2, o, stream); }, (int64_t)M_APP2 * APP_DIM, (reps + 7) / 8)) return e;
   // the fused kernels (rolling load buffer) in both fp16 arithmetics
-  const int precs[2] = {EGO_PREC_F16X3, EGO_PREC_F16F8};
-  for (int p = 0; p < 2; ++p) {
+  const int precs[3] = {EGO_PREC_F16X3, EGO_PREC_F16F8, EGO_PREC_F16F6};
+  for (int p = 0; p < 3; ++p) {
     sc.mlp_precision = precs[p];
     if (int e = soak([&](float* o) { return ego_shade(&sc, ws + L.rays, ws + L.z, ws + L.coords, N_RAYS, S, o, nullptr, nullptr, stream); },
                      (int64_t)N_RAYS * S * 3, (reps + 1) / 2)) return e;
@@ -173,8 +173,8 @@ int ego_selftest(void* workspace, int64_t workspace_bytes, int32_t reps, int32_t
   *mismatching_calls = total;
   if (total)
     return ego_fail(EGO_E_UNSUPPORTED, "selftest: the gather kernels returned different bits on identical inputs (stage in-range %u, scattered %u, "
-                    "24 workgroups %u, fused f16x3 %u, fused f16f8 %u mismatching calls): this build has the reproducibility fault of "
-                    "DESIGN.md 5.1 on this device - rebuild with the pinned compiler / flags (egonerf_amd/build.py)", host[0], host[1], host[2], host[3], host[4]);
+                    "24 workgroups %u, fused f16x3 %u, fused f16f8 %u, fused f16f6 %u mismatching calls): this build has the reproducibility fault of "
+                    "DESIGN.md 5.1 on this device - rebuild with the pinned compiler / flags (egonerf_amd/build.py)", host[0], host[1], host[2], host[3], host[4], host[5]);
   return EGO_OK;
 }
 

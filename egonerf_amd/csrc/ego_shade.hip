@@ -298,16 +298,24 @@ __global__ void k_pack_mlp_f8(const float* __restrict__ w1, const float* __restr
 // Scale bytes: with eb = biased exponent of the block's largest |x| (clamped to >= 14) the conversions divide by 2^(eb - 129) (x) and
 // 2^(eb - 140) (residual, i.e. 2^-11 further down) and the MFMAs pass eb itself as B's block scale; the 2^-2 / 2^-13 that this
 // overstates is folded into A's static scale byte, which is biased(weight block scale) - 2 (term 0) / - 13 (term 1).
-// Region layout (32-bit slots, inside the same OFF_W1 / OFF_W2 extents): per layer the fp16 hi fragments [step][m-tile][lane][8 halves]
-// (as f16f8), then per group: four m-tile blocks of 12 x 64 slots (term 0 dwords 0-3 [lane][4], dwords 4-5 [lane][2] | the same for
-// term 1) followed by the scale bytes [lane][2 dwords]: byte mt of dword t = block scale of (term t, m-tile mt) - the MFMA's op_sel
-// picks the byte.
+// Image layout (32-bit slots; it replaces the first OFF_B1 slots of the LDS image, biases / W3 behind it stay where they are):
+//   F6I_HI1 / F6I_HI2: fp16 hi fragments [step][m-tile][lane][8 halves] of layers 1 / 2 (as f16f8)
+//   F6I_Q1 / F6I_Q2:   the fp6 operands [group][m-tile][quad 0..2][lane][4]: the two terms' 6 + 6 dwords of a lane as three 16-byte
+//                      pieces: term 0 dwords 0-3 | term 1 dwords 0-3 | term 0 dwords 4-5, term 1 dwords 4-5.  (Separate 16 + 8 byte
+//                      pieces per term made the compiler pair the 8-byte reads of neighbouring fragments and copy the halves apart,
+//                      +42 v_mov per tile; term 0's six dwords followed by term 1's, +81: it does not coalesce a 12-register tuple.)
+//   F6I_SC:            scale bytes [group (layer 1's three, then layer 2's two)][lane][2 dwords]: byte mt of dword t = block scale of
+//                      (term t, m-tile mt) - the MFMA's op_sel picks the byte
+// The kernel addresses LDS as `per-lane base + 16-bit immediate` with one opaque base per 64 KB window (f6_bases): left to itself
+// the compiler spends a v_add on every read beyond 64 KB (62 more per tile than f16f8).
 constexpr int G6_1 = 3, G6_2 = 2;                 // groups per layer
-constexpr int F6_BLK = 12 * 64;                   // slots per (group, m-tile)
-constexpr int F6_GRP = 4 * F6_BLK + 2 * 64;       // slots per group
-constexpr int F6_HI1 = F8_HI1, F6_HI2 = F8_HI2;
+constexpr int F6I_HI1 = 0, F6I_HI2 = F6I_HI1 + F8_HI1;
+constexpr int F6I_Q1 = F6I_HI2 + F8_HI2, F6I_Q2 = F6I_Q1 + G6_1 * 4 * 3 * 256;
+constexpr int F6I_SC = F6I_Q2 + G6_2 * 4 * 3 * 256;
+constexpr int F6I_END = F6I_SC + (G6_1 + G6_2) * 128;
 constexpr int F6_FLOATS = OFF_B1;
-static_assert(F6_HI1 + G6_1 * F6_GRP <= OFF_W2 - OFF_W1 && F6_HI2 + G6_2 * F6_GRP <= OFF_B1 - OFF_W2, "f16f6 regions must fit the LDS image");
+static_assert(F6I_END <= F6_FLOATS, "f16f6 image must fit the W1 / W2 part of the LDS image");
+static_assert(F6I_SC * 4 < 3 * 65536, "16-byte-stride part of the f16f6 image: three 64 KB windows");
 
 __host__ __device__ constexpr int f6_value(int layer2, int grp, int term, int e) {
   if (!layer2 && grp == G6_1 - 1) return (e & 1) ? -1 : 64 + (e >> 1);
@@ -340,10 +348,10 @@ __device__ inline float mlp_weight_k(const float* __restrict__ w1, const float* 
 __global__ void k_pack_mlp_f6(const float* __restrict__ w1, const float* __restrict__ w2, float* __restrict__ out) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   uint32_t* o = (uint32_t*)out;
-  const int n_hi = F6_HI1 + F6_HI2;
+  const int n_hi = F8_HI1 + F8_HI2;
   if (idx < n_hi) {  // [step][mt][lane][8 halves]
-    const bool l2 = idx >= F6_HI1;
-    const int e0 = l2 ? idx - F6_HI1 : idx;
+    const bool l2 = idx >= F8_HI1;
+    const int e0 = l2 ? idx - F8_HI1 : idx;
     _Float16 pr[2];
     for (int p = 0; p < 2; ++p) {
       const int hidx = e0 * 2 + p;
@@ -354,7 +362,7 @@ __global__ void k_pack_mlp_f6(const float* __restrict__ w1, const float* __restr
     }
     typedef _Float16 h2v __attribute__((ext_vector_type(2)));
     h2v v = {pr[0], pr[1]};
-    o[(l2 ? OFF_W2 : OFF_W1) + e0] = __builtin_bit_cast(uint32_t, v);
+    o[(l2 ? F6I_HI2 : F6I_HI1) + e0] = __builtin_bit_cast(uint32_t, v);
     return;
   }
   const int t = idx - n_hi;
@@ -362,9 +370,7 @@ __global__ void k_pack_mlp_f6(const float* __restrict__ w1, const float* __restr
   const int lane = t & 63, mt = (t >> 6) & 3, gg = t >> 8;
   const bool l2 = gg >= G6_1;
   const int grp = l2 ? gg - G6_1 : gg;
-  uint32_t* gbase = o + (l2 ? OFF_W2 + F6_HI2 : OFF_W1 + F6_HI1) + grp * F6_GRP;
-  uint32_t* blk = gbase + mt * F6_BLK;
-  uint8_t* scales = (uint8_t*)(gbase + 4 * F6_BLK);   // [lane][term][mt]
+  uint8_t* scales = (uint8_t*)(o + F6I_SC + gg * 128);   // [lane][term][mt]
   for (int term = 0; term < 2; ++term) {
     float v[32];
     float amax = 0.f;
@@ -391,9 +397,10 @@ __global__ void k_pack_mlp_f6(const float* __restrict__ w1, const float* __restr
       wd[wi] |= c << sh;
       if (sh > 26) wd[wi + 1] |= c >> (32 - sh);
     }
-    for (int d = 0; d < 4; ++d) blk[term * 384 + lane * 4 + d] = wd[d];
-    blk[term * 384 + 256 + lane * 2] = wd[4];
-    blk[term * 384 + 256 + lane * 2 + 1] = wd[5];
+    uint32_t* q = o + (l2 ? F6I_Q2 : F6I_Q1) + (grp * 4 + mt) * 768 + lane * 4;
+    for (int d = 0; d < 4; ++d) q[term * 256 + d] = wd[d];
+    q[512 + 2 * term] = wd[4];
+    q[512 + 2 * term + 1] = wd[5];
     const int byte = (E - 2) + 127 - (term == 0 ? 2 : 13);
     scales[lane * 8 + term * 4 + mt] = (uint8_t)(byte < 0 ? 0 : (byte > 254 ? 254 : byte));
   }
@@ -826,6 +833,11 @@ __device__ __forceinline__ u32x6 cvt_pk32_fp6_f16(const v16i& halves, float scal
   asm("s_nop 0\n\tv_cvt_scalef32_pk32_fp6_f16 %0, %1, %2\n\ts_nop 1" : "=&v"(r) : "v"(halves), "v"(scale));
   return r;
 }
+__device__ __forceinline__ u32x6 cvt_2xpk16_fp6_f32_dup(const f32x16& a, float scale) {   // both sources = a
+  u32x6 r;
+  asm("s_nop 0\n\tv_cvt_scalef32_2xpk16_fp6_f32 %0, %1, %1, %2\n\ts_nop 1" : "=&v"(r) : "v"(a), "v"(scale));
+  return r;
+}
 __device__ __forceinline__ u32x6 cvt_2xpk16_fp6_f32(const f32x16& a, const f32x16& b, float scale) {
   u32x6 r;
   asm("s_nop 0\n\tv_cvt_scalef32_2xpk16_fp6_f32 %0, %1, %2, %3\n\ts_nop 1" : "=&v"(r) : "v"(a), "v"(b), "v"(scale));
@@ -856,49 +868,70 @@ __device__ __forceinline__ B6 group6(const uint32_t hp[16], const float res[32],
   for (int i = 0; i < 16; ++i) { hv[i] = (int)hp[i]; ra[i] = res[i]; rb[i] = res[16 + i]; }
   const u32x6 x6 = cvt_pk32_fp6_f16(hv, sx);
   const u32x6 r6 = cvt_2xpk16_fp6_f32(ra, rb, sr);
-  o.x = v8i{(int)x6[0], (int)x6[1], (int)x6[2], (int)x6[3], (int)x6[4], (int)x6[5], 0, 0};
-  o.r = v8i{(int)r6[0], (int)r6[1], (int)r6[2], (int)r6[3], (int)r6[4], (int)r6[5], 0, 0};
+  o.x = __builtin_bit_cast(v8i, __builtin_shufflevector(x6, x6, 0, 1, 2, 3, 4, 5, -1, -1));
+  o.r = __builtin_bit_cast(v8i, __builtin_shufflevector(r6, r6, 0, 1, 2, 3, 4, 5, -1, -1));
   return o;
 }
 
-// half group (layer 1's last: 16 values): both operands through the interleaving conversion with a zero second source
+// half group (layer 1's last: 16 values): both operands through the interleaving conversion with the values as BOTH sources - the odd
+// elements meet zero weights (f6_value), and no tuple of zeros has to be materialised
 __device__ __forceinline__ B6 group6_half(const float xv[16], const float res[16], float amax) {
   B6 o;
   float sx, sr;
   f6_scales(amax, o.sb, sx, sr);
-  f32x16 xa, ra, z;
+  f32x16 xa, ra;
 #pragma unroll
-  for (int i = 0; i < 16; ++i) { xa[i] = xv[i]; ra[i] = res[i]; z[i] = 0.f; }
-  const u32x6 x6 = cvt_2xpk16_fp6_f32(xa, z, sx);
-  const u32x6 r6 = cvt_2xpk16_fp6_f32(ra, z, sr);
-  o.x = v8i{(int)x6[0], (int)x6[1], (int)x6[2], (int)x6[3], (int)x6[4], (int)x6[5], 0, 0};
-  o.r = v8i{(int)r6[0], (int)r6[1], (int)r6[2], (int)r6[3], (int)r6[4], (int)r6[5], 0, 0};
+  for (int i = 0; i < 16; ++i) { xa[i] = xv[i]; ra[i] = res[i]; }
+  const u32x6 x6 = cvt_2xpk16_fp6_f32_dup(xa, sx);
+  const u32x6 r6 = cvt_2xpk16_fp6_f32_dup(ra, sr);
+  o.x = __builtin_bit_cast(v8i, __builtin_shufflevector(x6, x6, 0, 1, 2, 3, 4, 5, -1, -1));
+  o.r = __builtin_bit_cast(v8i, __builtin_shufflevector(r6, r6, 0, 1, 2, 3, 4, 5, -1, -1));
   return o;
 }
 
-// blk: LDS dwords of one layer's fp6 groups; one term's fragment of (group, m-tile)
-__device__ __forceinline__ v8i load_a6(const uint32_t* __restrict__ blk, int grp, int mt, int term, int lane) {
-  const uint32_t* b = blk + grp * F6_GRP + mt * F6_BLK + term * 384;
-  const u32x4 h = ((const u32x4*)b)[lane];
-  const u32x2 t = ((const u32x2*)(b + 256))[lane];
-  return v8i{(int)h.x, (int)h.y, (int)h.z, (int)h.w, (int)t.x, (int)t.y, 0, 0};
+// Per-lane LDS byte offsets into the f16f6 image (opaque to the compiler, so that a read is `base + 16-bit immediate` and not an
+// address computation of its own): one base per 64 KB window of the 16-byte-stride part, one for the scale bytes
+struct F6Bases {
+  uint32_t o16[3], o8s;   // lane * 16 + 64 KB * w, lane * 8 + 4 F6I_SC
+};
+__device__ __forceinline__ F6Bases f6_bases(int lane) {
+  F6Bases b;
+  b.o16[0] = (uint32_t)lane * 16u; b.o16[1] = (uint32_t)lane * 16u + 65536u; b.o16[2] = (uint32_t)lane * 16u + 131072u;
+  b.o8s = (uint32_t)lane * 8u + 4u * F6I_SC;
+  asm volatile("" : "+v"(b.o16[0]), "+v"(b.o16[1]), "+v"(b.o16[2]), "+v"(b.o8s));
+  return b;
+}
+// slot: 32-bit slot index of lane 0's element (a constant after unrolling)
+__device__ __forceinline__ u32x4 f6_ld128(const float* lds, const F6Bases& b, int slot) {
+  const int w = (slot * 4) >> 16;
+  return *(const u32x4*)((const char*)lds + (slot * 4 - 65536 * w) + b.o16[w]);
+}
+__device__ __forceinline__ h8 f6_hi(const float* lds, const F6Bases& b, bool l2, int step, int mt) {
+  return __builtin_bit_cast(h8, f6_ld128(lds, b, (l2 ? F6I_HI2 : F6I_HI1) + (step * 4 + mt) * 256));
 }
 
-__device__ __forceinline__ void group_mfma6(const uint32_t* __restrict__ blk, int grp, int lane, const B6& b, f32x16 (&H)[4]) {
-  v8i a[4];
-  const u32x2 sa = ((const u32x2*)(blk + grp * F6_GRP + 4 * F6_BLK))[lane];   // byte mt of .x: term 0's block scales, of .y: term 1's
+// dwords 6, 7 of the builtin's operand type are not read by the fp6 form of the instruction and stay undefined
+__device__ __forceinline__ v8i a6_operand(const u32x4& head, const u32x4& tails, int term) {
+  return term == 0 ? __builtin_bit_cast(v8i, __builtin_shufflevector(head, tails, 0, 1, 2, 3, 4, 5, -1, -1))
+                   : __builtin_bit_cast(v8i, __builtin_shufflevector(head, tails, 0, 1, 2, 3, 6, 7, -1, -1));
+}
+
+__device__ __forceinline__ void group_mfma6(const float* lds, const F6Bases& fb, bool l2, int grp, const B6& b, f32x16 (&H)[4]) {
+  const u32x2 sa = *(const u32x2*)((const char*)lds + ((l2 ? G6_1 : 0) + grp) * 512 + fb.o8s);   // byte mt of .x: term 0's block scales, of .y: term 1's
+  const int q = (l2 ? F6I_Q2 : F6I_Q1) + grp * 4 * 768;
+  u32x4 hd[4], tl[4];
 #pragma unroll
-  for (int mt = 0; mt < 4; ++mt) a[mt] = load_a6(blk, grp, mt, 0, lane);
-  H[0] = MFMA6(a[0], b.x, H[0], (int)sa.x, 0, b.sb);
-  H[1] = MFMA6(a[1], b.x, H[1], (int)sa.x, 1, b.sb);
-  H[2] = MFMA6(a[2], b.x, H[2], (int)sa.x, 2, b.sb);
-  H[3] = MFMA6(a[3], b.x, H[3], (int)sa.x, 3, b.sb);
+  for (int mt = 0; mt < 4; ++mt) { hd[mt] = f6_ld128(lds, fb, q + mt * 768); tl[mt] = f6_ld128(lds, fb, q + mt * 768 + 512); }
+  H[0] = MFMA6(a6_operand(hd[0], tl[0], 0), b.x, H[0], (int)sa.x, 0, b.sb);
+  H[1] = MFMA6(a6_operand(hd[1], tl[1], 0), b.x, H[1], (int)sa.x, 1, b.sb);
+  H[2] = MFMA6(a6_operand(hd[2], tl[2], 0), b.x, H[2], (int)sa.x, 2, b.sb);
+  H[3] = MFMA6(a6_operand(hd[3], tl[3], 0), b.x, H[3], (int)sa.x, 3, b.sb);
 #pragma unroll
-  for (int mt = 0; mt < 4; ++mt) a[mt] = load_a6(blk, grp, mt, 1, lane);
-  H[0] = MFMA6(a[0], b.r, H[0], (int)sa.y, 0, b.sb);
-  H[1] = MFMA6(a[1], b.r, H[1], (int)sa.y, 1, b.sb);
-  H[2] = MFMA6(a[2], b.r, H[2], (int)sa.y, 2, b.sb);
-  H[3] = MFMA6(a[3], b.r, H[3], (int)sa.y, 3, b.sb);
+  for (int mt = 0; mt < 4; ++mt) hd[mt] = f6_ld128(lds, fb, q + mt * 768 + 256);
+  H[0] = MFMA6(a6_operand(hd[0], tl[0], 1), b.r, H[0], (int)sa.y, 0, b.sb);
+  H[1] = MFMA6(a6_operand(hd[1], tl[1], 1), b.r, H[1], (int)sa.y, 1, b.sb);
+  H[2] = MFMA6(a6_operand(hd[2], tl[2], 1), b.r, H[2], (int)sa.y, 2, b.sb);
+  H[3] = MFMA6(a6_operand(hd[3], tl[3], 1), b.r, H[3], (int)sa.y, 3, b.sb);
 }
 
 struct BasisFrag {
@@ -1433,13 +1466,13 @@ __global__ __launch_bounds__(512) void k_shade_h(ShadeArgs A) {
       }
     } else if (P6) {
       float s1 = 0.f, c1 = 0.f, s2 = 0.f, c2 = 0.f;
-      const uint32_t* W1F = (const uint32_t*)W1 + F6_HI1;
+      const F6Bases fb = f6_bases(lw);
       h8 ah[4], nh[4];
       uint32_t hp[16];
       float res[32], xl[16];
       float amax = 1.f;
 #pragma unroll
-      for (int mt = 0; mt < 4; ++mt) nh[mt] = __builtin_bit_cast(h8, W1[mt * 64 + lw]);
+      for (int mt = 0; mt < 4; ++mt) nh[mt] = f6_hi(lds, fb, false, 0, mt);
       // step-outer / value-inner: the flat 80-iteration form of the other arithmetics exceeds the unroller's size limit with the group
       // code in its body, and a rolled loop indexes the register arrays through scratch
 #pragma unroll
@@ -1475,17 +1508,17 @@ __global__ __launch_bounds__(512) void k_shade_h(ShadeArgs A) {
         for (int mt = 0; mt < 4; ++mt) ah[mt] = nh[mt];
         if (step + 1 < KH1) {
 #pragma unroll
-          for (int mt = 0; mt < 4; ++mt) nh[mt] = __builtin_bit_cast(h8, W1[((step + 1) * 4 + mt) * 64 + lw]);
+          for (int mt = 0; mt < 4; ++mt) nh[mt] = f6_hi(lds, fb, false, step + 1, mt);
         }
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) H[mt] = MFMAH(ah[mt], bh, H[mt]);
         if (sg == 3) {
           const B6 b6 = group6(hp, res, amax);
-          group_mfma6(W1F, step >> 2, lw, b6, H);
+          group_mfma6(lds, fb, false, step >> 2, b6, H);
           amax = 1.f;
         } else if (step == KH1 - 1) {
           const B6 b6 = group6_half(xl, res, amax);
-          group_mfma6(W1F, G6_1 - 1, lw, b6, H);
+          group_mfma6(lds, fb, false, G6_1 - 1, b6, H);
         }
       }
     } else
@@ -1589,13 +1622,13 @@ __global__ __launch_bounds__(512) void k_shade_h(ShadeArgs A) {
         }
       }
     } else if (P6) {
-      const uint32_t* W2F = (const uint32_t*)W2 + F6_HI2;
+      const F6Bases fb = f6_bases(lw);
       h8 ah[4], nh[4];
       uint32_t hp[16];
       float res[32];
       float amax = 0.f;
 #pragma unroll
-      for (int mt = 0; mt < 4; ++mt) nh[mt] = __builtin_bit_cast(h8, W2[mt * 64 + lw]);
+      for (int mt = 0; mt < 4; ++mt) nh[mt] = f6_hi(lds, fb, true, 0, mt);
 #pragma unroll
       for (int step = 0; step < KH2; ++step) {
         float xs[8];
@@ -1607,13 +1640,13 @@ __global__ __launch_bounds__(512) void k_shade_h(ShadeArgs A) {
         for (int mt = 0; mt < 4; ++mt) ah[mt] = nh[mt];
         if (step + 1 < KH2) {
 #pragma unroll
-          for (int mt = 0; mt < 4; ++mt) nh[mt] = __builtin_bit_cast(h8, W2[((step + 1) * 4 + mt) * 64 + lw]);
+          for (int mt = 0; mt < 4; ++mt) nh[mt] = f6_hi(lds, fb, true, step + 1, mt);
         }
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) G[mt] = MFMAH(ah[mt], bh, G[mt]);
         if (sg == 3) {
           const B6 b6 = group6(hp, res, amax);
-          group_mfma6(W2F, step >> 2, lw, b6, G);
+          group_mfma6(lds, fb, true, step >> 2, b6, G);
           amax = 0.f;
         }
       }
@@ -1753,7 +1786,7 @@ int ego_pack_mlp(const ego_scene* sc, float* packed_out, void* stream) {
   if (int e = ego_launch_status("k_pack_mlp_f8")) return e;
   float* f6 = packed_out + 2 * PACKED_FLOATS + BASIS16_FLOATS + F8_FLOATS;
   if (const hipError_t err = hipMemsetAsync(f6, 0, sizeof(float) * F6_FLOATS, (hipStream_t)stream)) return (int)err;  // the gaps behind the blocks
-  constexpr int F6_THREADS = F6_HI1 + F6_HI2 + (G6_1 + G6_2) * 4 * 64;
+  constexpr int F6_THREADS = F8_HI1 + F8_HI2 + (G6_1 + G6_2) * 4 * 64;
   k_pack_mlp_f6<<<(F6_THREADS + 255) / 256, 256, 0, (hipStream_t)stream>>>(sc->mlp_w[0], sc->mlp_w[1], f6);
   return ego_launch_status("k_pack_mlp_f6");
 }

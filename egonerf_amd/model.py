@@ -301,7 +301,7 @@ class EgoNeRF(TensorBase):
         self._packed = None
         self._packed_versions = None
         self._sched_cache = {}
-        self._mlp_precision = "f16f8"   # inference default; differentiable calls always use the three-term fp16 split
+        self._mlp_precision = "f16f6"   # inference default; differentiable calls always use the three-term fp16 split
         self._app_table_dtype = "f32"   # "f16": inference gathers appearance taps from a half-precision copy of the tables
         self._app16 = None              # (versions, [12 half tensors])
         # opt-in skipping (EgoNeRF.forward itself evaluates every sample; TensorBase.forward's semantics, tensorBase.py:464-487,
@@ -528,9 +528,11 @@ class EgoNeRF(TensorBase):
     @property
     def mlp_precision(self) -> str:
         """Arithmetic of the basis/MLP products:
-        "f16f8" (default): layers 1 and 2 with the main term in fp16 and both correction terms in one block-scaled fp8 MFMA per
-                 pair of k-steps; composited max |d RGB| ~1e-5 (bar: 1e-4), 8-9 % faster shade kernel; inference only — a
-                 differentiable call uses "f16x3";
+        "f16f6" (default): layers 1 and 2 with the main term in fp16 and the two correction terms on the fp6 (e2m3) path of the
+                 block-scaled MFMA, per-lane block scales taken from the activations at run time; composited max |d RGB| ~1.7e-5
+                 (bar: 1e-4); inference only — a differentiable call uses "f16x3";
+        "f16f8": the same split with both correction terms in one block-scaled fp8 (e4m3, fixed scales) MFMA per pair of k-steps
+                 (round 2's default; 3-4 % slower shade kernel, saturates above 448);
         "f16x3": three fp16 MFMAs per product, fp32-grade (2e-7);
         "f32":   fp32-input MFMA, bit-for-bit fp32 FMA chains (2.8x slower)."""
         return self._mlp_precision

@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define EGO_ABI_VERSION 11
+#define EGO_ABI_VERSION 12
 
 enum { EGO_PREC_F16X3 = 0, EGO_PREC_F32 = 1, EGO_PREC_F16F8 = 2, EGO_PREC_F16F6 = 3 };
 
@@ -99,7 +99,10 @@ typedef struct ego_scene {
    * fp32 accumulate, ~2^-21 relative: fp32-grade); EGO_PREC_F32 = fp32-input MFMA; EGO_PREC_F16F8 = layers 1 and 2 of the MLP
    * with the main term in fp16 and both correction terms in one block-scaled fp8 (e4m3) MFMA per pair of k-steps (~2^-16
    * relative per product; composited max |d RGB| ~8e-6, i.e. > 10x inside the 1e-4 bar; inference only, the training forward
-   * keeps the fp16 split) */
+   * keeps the fp16 split); EGO_PREC_F16F6 = the same split with the correction terms on the fp6 (e2m3) path of the block-scaled
+   * MFMA, two instructions per group of four k-steps, one power-of-two block scale per lane and 32 K values - static for the
+   * weights, taken from the largest activation of the block at run time (so no fixed range to saturate); per-sample error 1.1x
+   * F16F8's, shade kernel 3-4 % faster */
   int32_t mlp_precision;
   /* Opt-in skipping (EgoNeRF.forward itself evaluates every sample; these follow TensorBase.forward's mask semantics,
    * models/tensorBase.py:464-478, and YinYangAlphaGridMask, models/EgoNeRF.py:11-24):
@@ -151,7 +154,7 @@ int64_t ego_sizeof(int32_t which);
 
 /* Run-time self-test of the team-gather kernel family (no reference counterpart).  Builds of these kernels that contain
  * packed fp32 instructions broadcasting the high dword of a register pair returned different bits call after call on MI355X; the build
- * fences that off and this entry point checks the SHIPPED code on the device at hand: ego_app_feature and ego_shade (f16x3, f16f8) run
+ * fences that off and this entry point checks the SHIPPED code on the device at hand: ego_app_feature and ego_shade (f16x3, f16f8, f16f6) run
  * `reps` times on a synthetic scene laid out in `workspace` (dev, ego_selftest_workspace_bytes() bytes, 256-byte aligned) and every
  * result is bit-compared with the first.  Synchronises `stream`.  Returns EGO_OK and *mismatching_calls = 0, or EGO_E_UNSUPPORTED with
  * the number of calls whose bits differed (host pointer).  The host layer calls it once per process and device (EGO_SKIP_SELFTEST=1 opts out). */
@@ -242,8 +245,8 @@ typedef struct ego_shade_dump {
 
 /* Static facts about the shade kernel that implements `precision` (EGO_PREC_*), for roofline accounting by a caller that times it
  * (bench.py): out[0] samples per tile (one wave-level unit of work), [1] fp16 / fp32-input MFMA instructions per tile of samples
- * that lie in one grid, [2] block-scaled fp8 MFMA instructions per tile, [3] flop per instruction of [1], [4] flop per
- * instruction of [2], [5] f32 -> fp8 conversion instructions per lane and tile, [6] algorithmic flop per sample (basis +
+ * that lie in one grid, [2] block-scaled fp8 / fp6 MFMA instructions per tile, [3] flop per instruction of [1], [4] flop per
+ * instruction of [2], [5] f32 -> fp8 conversion instructions (F16F6: 32-value fp6 conversions) per lane and tile, [6] algorithmic flop per sample (basis +
  * MLP_Fea of tensorBase.py:54-78: 2 (144 x 27 + 150 x 128 + 128 x 128 + 128 x 3)), [7] gathered appearance tap bytes per
  * sample (EgoNeRF.py:349-413: 3 x (4 + 2) taps x 48 channels x 4 B).  n must be 8.  The counts are computed from the same
  * constants the kernel's loops run over. */

@@ -242,10 +242,13 @@ def pack_mlp_f8(w):
 
 
 # ---- f16f6: fp16 main term + fp6 (e2m3) correction terms with per-lane block scales (k_pack_mlp_f6) ----------------------------------
-G6_1, G6_2, F6_BLK = 3, 2, 12 * 64
-F6_GRP = 4 * F6_BLK + 2 * 64
+G6_1, G6_2 = 3, 2
 F6_FLOATS = OFF_B1
 F6_HI1, F6_HI2 = (KS1 // 8) * 4 * 64 * 4, (KS2 // 8) * 4 * 64 * 4
+F6I_HI1, F6I_HI2 = 0, F6_HI1
+F6I_Q1 = F6I_HI2 + F6_HI2
+F6I_Q2 = F6I_Q1 + G6_1 * 4 * 3 * 256
+F6I_SC = F6I_Q2 + G6_2 * 4 * 3 * 256
 
 
 def f6_value(layer2, grp, term, e):
@@ -315,10 +318,10 @@ def mlp_k_matrix(w, layer2):
 
 
 def pack_mlp_f6(w):
-    """Fifth region of the packed blob: per layer the fp16 hi fragments, then per group four m-tile blocks of 12 x 64 slots
-    (term t dwords 0-3 at t * 384 + [lane][4], dwords 4-5 at t * 384 + 256 + [lane][2]) and the scale bytes [lane][term][m-tile]."""
+    """Fifth region of the packed blob (the f16f6 LDS image, csrc/ego_shade.hip): hi fragments of both layers, the fp6 operands
+    [group][m-tile][quad][lane][4] (quad t: term t's dwords 0-3; quad 2: term 0's dwords 4-5, term 1's dwords 4-5), scale bytes [group][lane][term][m-tile]."""
     out = np.zeros(F6_FLOATS, np.uint32)
-    for layer2, base, hi_slots, groups in ((False, OFF_W1, F6_HI1, G6_1), (True, OFF_W2, F6_HI2, G6_2)):
+    for layer2, hi0, q0, groups in ((False, F6I_HI1, F6I_Q1, G6_1), (True, F6I_HI2, F6I_Q2, G6_2)):
         kk = mlp_k_matrix(w, layer2)
         steps = (KS2 if layer2 else KS1) // 8
         hi = kk.astype(np.float16)
@@ -326,8 +329,9 @@ def pack_mlp_f6(w):
         hi_part = np.zeros((steps, 4, 64, 8), np.float16)
         for st in range(steps):
             hi_part[st] = hi[:, :, st * 8:st * 8 + 8]
-        out[base:base + hi_slots] = hi_part.reshape(-1).view(np.uint32)
+        out[hi0:hi0 + steps * 4 * 64 * 4] = hi_part.reshape(-1).view(np.uint32)
         for grp in range(groups):
+            sc0 = F6I_SC + ((G6_1 if layer2 else 0) + grp) * 128
             for term in range(2):
                 src = lo if term == 0 else hi.astype(np.float32)
                 v = np.zeros((4, 64, 32), np.float32)
@@ -336,12 +340,11 @@ def pack_mlp_f6(w):
                     if k >= 0:
                         v[:, :, e] = src[:, :, k]
                 dw, byte = f6_block(v, term)
-                g0 = base + hi_slots + grp * F6_GRP
                 for mt in range(4):
-                    b0 = g0 + mt * F6_BLK
-                    out[b0 + term * 384: b0 + term * 384 + 256] = dw[mt, :, :4].reshape(-1)
-                    out[b0 + term * 384 + 256: b0 + term * 384 + 384] = dw[mt, :, 4:].reshape(-1)
-                    out[g0 + 4 * F6_BLK + term: g0 + F6_GRP: 2] |= byte[mt] << np.uint32(8 * mt)
+                    blk = out[q0 + (grp * 4 + mt) * 768: q0 + (grp * 4 + mt + 1) * 768].reshape(3, 64, 4)
+                    blk[term, :, :] = dw[mt, :, :4]
+                    blk[2, :, 2 * term:2 * term + 2] = dw[mt, :, 4:]
+                    out[sc0 + term: sc0 + 128: 2] |= byte[mt] << np.uint32(8 * mt)
     return out.view(np.float32)
 
 
@@ -350,11 +353,11 @@ def f6_layer_reference(w, layer2, X):
     the lane halves' K order for both halves: X[h] [n][K].  Returns [n][128] (unit m * 32 + i).  Test infrastructure: checks that the
     packed blocks, the element orders and the scale bytes mean what the kernel assumes."""
     blob = pack_mlp_f6(w).view(np.uint32)
-    base, hi_slots, groups = (OFF_W2, F6_HI2, G6_2) if layer2 else (OFF_W1, F6_HI1, G6_1)
+    hi0, q0, groups = (F6I_HI2, F6I_Q2, G6_2) if layer2 else (F6I_HI1, F6I_Q1, G6_1)
     steps = (KS2 if layer2 else KS1) // 8
     n = X[0].shape[0]
     out = np.zeros((n, 128))
-    hi_frag = blob[base:base + hi_slots].view(np.float16).reshape(steps, 4, 64, 8).astype(np.float64)
+    hi_frag = blob[hi0:hi0 + steps * 1024].view(np.float16).reshape(steps, 4, 64, 8).astype(np.float64)
     for h in range(2):
         x = np.asarray(X[h], np.float32)
         kpad = 32 * groups
@@ -367,8 +370,7 @@ def f6_layer_reference(w, layer2, X):
                 wrow = np.concatenate([hi_frag[st, mt, lane] for st in range(steps)])
                 acc = xh[:, :steps * 8].astype(np.float64) @ wrow
                 for grp in range(groups):
-                    g0 = base + hi_slots + grp * F6_GRP
-                    blk = blob[g0 + mt * F6_BLK:][:F6_BLK]
+                    sc0 = F6I_SC + ((G6_1 if layer2 else 0) + grp) * 128
                     half = (not layer2) and grp == G6_1 - 1
                     xg = xp[:, 32 * grp:32 * grp + (16 if half else 32)]
                     if layer2:
@@ -378,8 +380,9 @@ def f6_layer_reference(w, layer2, X):
                         amax = np.maximum(np.abs(xp[:, ks]).max(1), np.float32(1.0))
                     eb = np.maximum(amax.view(np.uint32) >> 23, 14).astype(np.int64)
                     for term in range(2):
-                        sword = int(blob[g0 + 4 * F6_BLK + lane * 2 + term]) >> (8 * mt)
-                        dw = np.concatenate([blk[term * 384 + lane * 4: term * 384 + lane * 4 + 4], blk[term * 384 + 256 + lane * 2: term * 384 + 256 + lane * 2 + 2]])
+                        sword = int(blob[sc0 + lane * 2 + term]) >> (8 * mt)
+                        blk = blob[q0 + (grp * 4 + mt) * 768: q0 + (grp * 4 + mt + 1) * 768].reshape(3, 64, 4)
+                        dw = np.concatenate([blk[term, lane], blk[2, lane, 2 * term:2 * term + 2]])
                         big = sum(int(dw[j]) << (32 * j) for j in range(6))
                         a = e2m3_decode(np.array([(big >> (6 * e)) & 63 for e in range(32)])) * 2.0 ** ((sword & 255) - 127)
                         src = xh.astype(np.float64) if term == 0 else xr

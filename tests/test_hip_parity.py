@@ -36,7 +36,7 @@ def full(golden):
     return fx, cfg, w, make_model(cfg, w, DEV)
 
 
-@pytest.fixture(params=["f16x3", "f16f8", "f32"], autouse=True)
+@pytest.fixture(params=["f16x3", "f16f8", "f16f6", "f32"], autouse=True)
 def precision(request, tiny, full):
     """Every test runs with all three matrix-product arithmetics (fp16-split MFMA, fp16 + fp8 corrections, fp32 MFMA)."""
     tiny[3].mlp_precision = request.param
@@ -58,8 +58,10 @@ def test_device_packer_is_bit_exact(tiny):
     blob = model._packed.cpu().numpy()
     assert np.array_equal(blob[:em.PACKED_FLOATS], em.pack_mlp(w))
     assert np.array_equal(blob[em.PACKED_FLOATS:2 * em.PACKED_FLOATS].view(np.uint32), em.pack_mlp_f16(w).view(np.uint32))
-    assert blob.shape[0] == 2 * em.PACKED_FLOATS + 9216 + em.F8_FLOATS  # + basis fragments in the fp16-table K order + f16f8 region
-    assert np.array_equal(blob[2 * em.PACKED_FLOATS + 9216:].view(np.uint32), em.pack_mlp_f8(w).view(np.uint32))
+    assert blob.shape[0] == 2 * em.PACKED_FLOATS + 9216 + em.F8_FLOATS + em.F6_FLOATS  # + basis fragments in the fp16-table K order + f16f8 + f16f6 images
+    f8 = 2 * em.PACKED_FLOATS + 9216
+    assert np.array_equal(blob[f8:f8 + em.F8_FLOATS].view(np.uint32), em.pack_mlp_f8(w).view(np.uint32))
+    assert np.array_equal(blob[f8 + em.F8_FLOATS:].view(np.uint32), em.pack_mlp_f6(w).view(np.uint32))
 
 
 def test_stage_sample_and_coords(tiny):
@@ -129,7 +131,7 @@ def test_stage_density_alpha_mlp(tiny, precision):
     rgb = model.renderModule(None, vd, T(fx["st_app_feat"]))
     # per-sample colour: fp32-grade for the three-term arithmetics; with fp8 correction terms a single sample may be off by
     # a few 1e-5 (the composited colour, which is what the 1e-4 bar applies to, by < 1e-5: see the end-to-end tests)
-    assert maxerr(rgb, fx["st_rgb_samples"]) <= (5e-5 if precision == "f16f8" else 5e-6)
+    assert maxerr(rgb, fx["st_rgb_samples"]) <= (5e-5 if precision in ("f16f8", "f16f6") else 5e-6)
 
 
 def test_stage_sample_pdf(golden):

@@ -65,11 +65,11 @@ def assert_matches_reference(model, rays, got, want_rgb, want_depth, kw):
     return int(bad.numel())
 
 
-@pytest.fixture(params=["f16x3", "f16f8", "f32"])
+@pytest.fixture(params=["f16x3", "f16f8", "f16f6", "f32"])
 def precision(request, ricoh):
     ricoh[2].mlp_precision = request.param
     yield request.param
-    ricoh[2].mlp_precision = "f16f8"
+    ricoh[2].mlp_precision = "f16f6"
 
 
 def test_erp_rays_vs_reference_generator(ricoh):
@@ -157,7 +157,7 @@ def test_alpha_mask_rule_on_the_ricoh_scene(ricoh):
     poles, seam and region borders included.  Rays holding a weight within rounding of the threshold (a flip moves a colour by
     up to the threshold) or a sample on a yin/yang border (libm-dependent grid choice) are compared for depth only."""
     fx, cfg, model = ricoh
-    model.mlp_precision = "f16f8"
+    model.mlp_precision = "f16f6"
     orc = model.oracle
     rays = T(fx["rays/0"])
     kw = {k: v for k, v in KW.items() if k != "device"}

@@ -1,5 +1,5 @@
 """GPU: parity of the inference arithmetics on TRAINED weights.  Every other parity test uses synthetic weights (smooth tables,
-uniform-init linears); the default `f16f8` arithmetic carries the correction terms of the MLP products in e4m3 (saturating above
+uniform-init linears); the `f16f8` arithmetic carries the correction terms of the MLP products in e4m3 (saturating above
 448, flushing below 2^-9 of the block scale), so it is also checked on a model whose tables and MLP came out of the optimiser:
 a freshly initialised student (0.1 * randn tables, default nn.Linear init, like train.py) fitted to a synthetic teacher scene
 with the graphed training iteration, then rendered against the CPU oracle built from the student's state dict."""
@@ -64,7 +64,7 @@ def test_inference_arithmetics_on_trained_weights():
     rays = rays_all[held][:256]
     ref = oracle.forward(rays.cpu(), **KW)
     errs = {}
-    for prec in ("f16f8", "f16x3", "f32"):
+    for prec in ("f16f6", "f16f8", "f16x3", "f32"):
         student.mlp_precision = prec
         with torch.no_grad():
             got = student(rays, **KW)

@@ -41,3 +41,38 @@ def test_every_mlp_input_column_is_used_exactly_once():
         assert cols == list(range(em.MLP_IN))
     rows = sorted(em.slot_row(r, h) for r in range(16) for h in (0, 1))
     assert rows == list(range(32))
+
+
+def test_f16f6_packed_operands_mean_what_the_kernel_assumes():
+    """The f16f6 image (k_pack_mlp_f6 == em.pack_mlp_f6 bit for bit, checked on the GPU): decoding the packed fp6 blocks, their element
+    orders (f6_value) and scale bytes the way the MFMA reads them, with the activations quantised by the kernel's rule (block scale
+    from the largest |x| of a lane's 32 values; layer 1: from 1 and the unbounded inputs only), must give both layers' products to
+    ~2^-16 relative - >= 10x closer to float64 than the fp16 main term alone."""
+    cfg = synth.SceneConfig(n_voxel=20 ** 3)
+    w = synth.make_weights(cfg, seed=1234)
+    n = 24
+    h1 = np.maximum(synth.hash_normal(3, 0, n * 128).reshape(n, 128), 0).astype(np.float32)
+    W2 = np.asarray(w["renderModule.mlp.2.weight"], np.float64)
+    X = [np.stack([h1[:, (kk >> 4) * 32 + em.slot_row(kk & 15, h)] for kk in range(em.KS2)], 1) for h in range(2)]
+    ref = h1.astype(np.float64) @ W2.T
+    e6 = np.abs(em.f6_layer_reference(w, True, X) - ref).max()
+    e16 = np.abs(h1.astype(np.float16).astype(np.float64) @ W2.astype(np.float32).astype(np.float16).astype(np.float64).T - ref).max()
+    assert e6 < 0.1 * e16 and e6 < 1.5e-4, (e6, e16)
+    feat = (synth.hash_normal(3, 1, n * 27).reshape(n, 27) * 0.7).astype(np.float32)
+    d = synth.make_rays(n, seed=3)[:, 3:6].astype(np.float32)
+    pe = lambda x: np.concatenate([np.sin((x[..., None] * [1, 2]).reshape(x.shape[0], -1)), np.cos((x[..., None] * [1, 2]).reshape(x.shape[0], -1))], 1)
+    x = np.concatenate([feat, d, pe(feat), pe(d)], 1).astype(np.float32)
+    W1 = np.asarray(w["renderModule.mlp.0.weight"], np.float64)
+    X = []
+    for h in range(2):
+        cols = [em.x_channel(kk, h) for kk in range(em.KS1)]
+        X.append(np.stack([x[:, c] if c >= 0 else np.zeros(n, np.float32) for c in cols], 1))
+    ref = x.astype(np.float64) @ W1.T
+    e6 = np.abs(em.f6_layer_reference(w, False, X) - ref).max()
+    e16 = np.abs(x.astype(np.float16).astype(np.float64) @ W1.astype(np.float32).astype(np.float16).astype(np.float64).T - ref).max()
+    assert e6 < 0.1 * e16 and e6 < 1.5e-4, (e6, e16)
+    # every K value of a lane half appears exactly once per term across a layer's groups
+    for layer2, groups, nk in ((False, em.G6_1, em.KS1), (True, em.G6_2, em.KS2)):
+        for term in range(2):
+            ks = sorted(k for g in range(groups) for e in range(32) if (k := em.f6_value(layer2, g, term, e)) >= 0 and k < nk)
+            assert ks == list(range(nk)), (layer2, term)
