@@ -255,7 +255,17 @@ __device__ __forceinline__ float normalize_r_fast(float r, const float* lut, int
   return __fsub_rn(__fmul_rn(v, 2.0f), 1.0f);
 }
 
-template <int C, bool OCC>
+// NSPLIT (1, 2): a ray's passes are dealt to NSPLIT waves of the workgroup (segments of consecutive passes).  One wave per ray
+// leaves the launch quantised by wave slots: 3 waves per SIMD = 3 072 slots, so 4 096 rays take a full round and a third of one, 106 us
+// where 3 072 rays take 76 and the sustained rate (19.6 us per 1 024 rays) would give 80 (tools/march_timing.py sweep).  Shorter waves
+// pack the slots better: 4 096 x 512 with two waves per ray 98 us.  Each wave pays the workgroup prologue (LUT, hints) and the hand-over,
+// so it only pays with few rounds of slots and long rays (four waves per ray: 109 us; 16 384 x 128 split in two: 101 -> 118 us); wave
+// priorities by phase (+7 %) and a staggered start of the waves of a SIMD (+-0) were measured and are not in the kernel.  Segment 0 streams as before (it knows the transmittance in front of it); a later segment evaluates its
+// passes with the transmittance unknown, parks (alpha, in-pass exclusive product) per sample and the pass totals in LDS, and turns
+// them into weights once its predecessor has published the carry - with the same multiplications in the same order as the
+// one-wave form, so the outputs are bit-identical for every NSPLIT.
+constexpr int MARCH_MAXP = 4;   // passes per deferred segment (LDS parking space)
+template <int C, bool OCC, int NSPLIT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_march_density(DevCoords c, DevField F, const float* __restrict__ rays,
                                                        int64_t N, int S, const float* __restrict__ z_in,
                                                        const float* __restrict__ r_sched,
@@ -270,6 +280,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   __shared__ float lut[1024];
   __shared__ __attribute__((aligned(16))) f32x4 stage[4][6][64];   // per wave: the pass's tap set-ups
   __shared__ float fres[4][64];                                      // per wave: the pass's density features
+  __shared__ float park[NSPLIT > 1 ? 4 : 1][NSPLIT > 1 ? MARCH_MAXP : 1][2][64];   // deferred segments: alpha, exclusive product
+  __shared__ float park_tot[4][MARCH_MAXP];
+  __shared__ float carry_slot[4];
   __shared__ int s_nlin;
   __shared__ LutHints s_hints;
   for (int i = threadIdx.x; i < c.n_lut; i += blockDim.x) lut[i] = c.r_lut[i];
@@ -312,8 +325,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   }
   // the wave index is wave-uniform: readfirstlane puts it - and with it the ray index and every per-ray base address - into SGPRs
   const int lane0 = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int64_t ray = (int64_t)blockIdx.x * 4 + wv;
-  if (ray >= N) return;
+  const int seg = NSPLIT > 1 ? (wv & (NSPLIT - 1)) : 0;
+  const int64_t ray_raw = (int64_t)blockIdx.x * (4 / NSPLIT) + wv / NSPLIT;
+  const bool live = ray_raw < N;
+  if (NSPLIT == 1 && !live) return;            // split launches meet at workgroup barriers below: nobody leaves early
+  const int64_t ray = live ? ray_raw : N - 1;
+  const int n_pass = (S + 63) >> 6, per_seg = (n_pass + NSPLIT - 1) / NSPLIT;
+  const int pass0 = seg * per_seg, pass1 = live ? min(n_pass, pass0 + per_seg) : pass0;
+  const bool defer = NSPLIT > 1 && seg > 0;    // wave-uniform
   const float* R = rays + ray * 6;
   const float ox = R[0], oy = R[1], oz = R[2], dx = R[3], dy = R[4], dz = R[5];
   const int nr64 = F.res[0] * (C * 4), nth64 = F.res[1] * (C * 4);
@@ -321,8 +340,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   // Exact early termination: once the transmittance in front of a pass is exactly 0 (fp32 underflow behind opaque samples), every
   // remaining weight is a * 0 = 0 and bg stays 0, so the rest of the ray only needs its distances and zero weights - unless the
   // caller wants per-sample alpha / sigma, which are independent of what lies in front.
-  const bool may_stop = !alpha && !sigma_out;
-  for (int s0 = 0; s0 < S; s0 += 64) {
+  const bool may_stop = !alpha && !sigma_out && !defer;
+  // weights, tile flags and the carry of one pass from (alpha, in-pass exclusive product, pass total) and the carry in front of it
+  auto emit = [&](int s0, int lane, float a, float exc, float tot) {
+    const int s = min(s0 + lane, S - 1);
+    const bool ok = (s0 + lane) < S;
+    const float T = carry * exc;
+    const float wgt = (term_eps > 0.f && T < term_eps) ? 0.f : a * T;  // early termination (opt-in)
+    if (tile_active) {
+      // 32-sample shade tiles are cut from the flat [N*S] order: lanes 0-31 / 32-63 of this pass are (parts of) tiles
+      // a tile is shaded iff it holds a sample whose colour is read: weight > shade_above (0, or rayMarch_weight_thres)
+      const unsigned long long nz = __ballot(ok && wgt > shade_above);
+      const int64_t o = ray * S + s;
+      if ((S & 31) == 0) {
+        // whole tiles per pass half: written unconditionally (0 or 1), so the caller need not clear the flags first
+        if (ok && (lane & 31) == 0) tile_active[o >> 5] = (nz >> (lane & 32) & 0xffffffffull) != 0ull ? 1 : 0;
+      } else if (ok && (nz >> (lane & 32) & 0xffffffffull) != 0ull && ((lane & 31) == 0 || (o & 31) == 0)) {
+        tile_active[o >> 5] = 1;  // tiles straddle rays: flags are pre-zeroed by the caller and only set here
+      }
+    }
+    if (ok && weight) weight[ray * S + s] = wgt;
+    carry *= tot;
+  };
+  for (int s0 = pass0 * 64; s0 < pass1 * 64; s0 += 64) {
     // lane-derived values (team, part, LDS slab addresses, ...) are recomputed per pass from an opaque copy of the lane index:
     // hoisted out of the loop they cost a dozen VGPRs for the whole kernel, which then spill around the 48-register load buffers
     int lane = lane0;
@@ -463,29 +503,42 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     const float inc = wave_scan_mul(t, lane);
     float exc = __shfl_up(inc, 1, 64);
     if (lane == 0) exc = 1.f;
-    const float T = carry * exc;
-    const float wgt = (term_eps > 0.f && T < term_eps) ? 0.f : a * T;  // early termination (opt-in)
-    if (tile_active) {
-      // 32-sample shade tiles are cut from the flat [N*S] order: lanes 0-31 / 32-63 of this pass are (parts of) tiles
-      // a tile is shaded iff it holds a sample whose colour is read: weight > shade_above (0, or rayMarch_weight_thres)
-      const unsigned long long nz = __ballot(ok && wgt > shade_above);
-      const int64_t o = ray * S + s;
-      if ((S & 31) == 0) {
-        // whole tiles per pass half: written unconditionally (0 or 1), so the caller need not clear the flags first
-        if (ok && (lane & 31) == 0) tile_active[o >> 5] = (nz >> (lane & 32) & 0xffffffffull) != 0ull ? 1 : 0;
-      } else if (ok && (nz >> (lane & 32) & 0xffffffffull) != 0ull && ((lane & 31) == 0 || (o & 31) == 0)) {
-        tile_active[o >> 5] = 1;  // tiles straddle rays: flags are pre-zeroed by the caller and only set here
-      }
-    }
+    const float tot = __shfl(inc, 63, 64);
     if (ok) {
       const int64_t o = ray * S + s;
       if (z_out) z_out[o] = z;
       if (coords_out) ((f32x4*)coords_out)[o] = f32x4{a_r, a_th, a_ph, y.yang ? 1.f : 0.f};
       if (sigma_out) sigma_out[o] = sg;
       if (alpha) alpha[ray * alpha_stride + s] = a;
-      if (weight) weight[o] = wgt;
     }
-    carry *= __shfl(inc, 63, 64);
+    if (!defer) {
+      emit(s0, lane, a, exc, tot);
+    } else {
+      const int kp = (s0 >> 6) - pass0;
+      park[NSPLIT > 1 ? wv : 0][NSPLIT > 1 ? kp : 0][0][lane] = a;
+      park[NSPLIT > 1 ? wv : 0][NSPLIT > 1 ? kp : 0][1][lane] = exc;
+      if (lane == 0) park_tot[wv][kp] = tot;
+    }
+  }
+  if (NSPLIT > 1) {
+    // the carry travels down the ray's segments: segment k turns its parked passes into weights once segment k - 1 has published
+    if (!defer && lane0 == 0) carry_slot[wv] = carry;
+#pragma unroll
+    for (int k = 1; k < NSPLIT; ++k) {
+      __syncthreads();
+      if (seg == k && live) {
+        carry = carry_slot[wv - 1];
+        for (int kp = 0; kp < pass1 - pass0; ++kp) {
+          int lane = lane0;
+          asm volatile("" : "+v"(lane));
+          emit((pass0 + kp) * 64, lane, park[NSPLIT > 1 ? wv : 0][NSPLIT > 1 ? kp : 0][0][lane], park[NSPLIT > 1 ? wv : 0][NSPLIT > 1 ? kp : 0][1][lane], park_tot[wv][kp]);
+        }
+        if (lane0 == 0) carry_slot[wv] = carry;
+      }
+    }
+    if (live && seg == 0 && alpha && lane0 < alpha_stride - S) alpha[ray * alpha_stride + S + lane0] = 1.f;
+    if (live && seg == NSPLIT - 1 && bg && lane0 == 0) bg[ray] = carry;
+    return;
   }
   // with an environment map the reference appends a column of ones to alpha (EgoNeRF.py:587)
   if (alpha && lane0 < alpha_stride - S) alpha[ray * alpha_stride + S + lane0] = 1.f;
@@ -1152,16 +1205,34 @@ int ego_march_density(const ego_scene* sc, const float* rays, int64_t N, int32_t
   if (f.n_comp != 16)   // any other component count: the compatibility kernel (csrc/ego_generic.hip)
     return ego_generic_march(sc, f, (coarse & 2) != 0, rays, N, S, z_in, r_sched, jitter, near_, o.vol, z_out, alpha, alpha_stride, weight, bg_weight,
                              coords_out, sigma_out, tile_active, stream);
-  if (o.vol)
-    k_march_density<16, true><<<nblk(N, 4), 256, 0, (hipStream_t)stream>>>(
-        make_coords(*sc, (coarse & 2) != 0), make_field(f), rays, N, S, z_in, r_sched, jitter, near_, sc->act_softplus, sc->density_shift,
-        sc->distance_scale, z_out, alpha, alpha_stride, weight, bg_weight, coords_out, sigma_out, o, sc->term_eps,
-        fmaxf(sc->weight_thres, 0.f), tile_active);
-  else
-    k_march_density<16, false><<<nblk(N, 4), 256, 0, (hipStream_t)stream>>>(
-        make_coords(*sc, (coarse & 2) != 0), make_field(f), rays, N, S, z_in, r_sched, jitter, near_, sc->act_softplus, sc->density_shift,
-        sc->distance_scale, z_out, alpha, alpha_stride, weight, bg_weight, coords_out, sigma_out, o, sc->term_eps,
-        fmaxf(sc->weight_thres, 0.f), tile_active);
+  // Rays split over two waves when one wave per ray would leave the launch quantised by wave slots (see k_march_density): fewer than
+  // two rounds of slots and at least two passes per half (at most MARCH_MAXP in the deferred half).
+  const int n_pass = (S + 63) / 64;
+  int nsplit = 1;
+  {
+    static int slots = 0;   // wave slots of the device (3 per SIMD), queried once
+    if (!slots) {
+      int dev = 0, cus = 0;
+      if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) slots = cus * 12;
+      else slots = 3072;
+    }
+    if ((double)N / slots < 2.0 && n_pass >= 4 && (n_pass + 1) / 2 <= MARCH_MAXP) nsplit = 2;
+    if (const char* e = getenv("EGO_MARCH_SPLIT")) {   // experiments (tools/march_timing.py): force 1 or 2 where the shape allows it
+      const int want = atoi(e);
+      if (want == 1 || (want == 2 && n_pass >= 2 && (n_pass + 1) / 2 <= MARCH_MAXP)) nsplit = want;
+    }
+  }
+#define EGO_LAUNCH_MARCH(OCC, NS)                                                                                                       \
+  k_march_density<16, OCC, NS><<<nblk(N, 4 / NS), 256, 0, (hipStream_t)stream>>>(                                                      \
+      make_coords(*sc, (coarse & 2) != 0), make_field(f), rays, N, S, z_in, r_sched, jitter, near_, sc->act_softplus, sc->density_shift, \
+      sc->distance_scale, z_out, alpha, alpha_stride, weight, bg_weight, coords_out, sigma_out, o, sc->term_eps,                          \
+      fmaxf(sc->weight_thres, 0.f), tile_active)
+  if (o.vol) {
+    if (nsplit == 2) EGO_LAUNCH_MARCH(true, 2); else EGO_LAUNCH_MARCH(true, 1);
+  } else {
+    if (nsplit == 2) EGO_LAUNCH_MARCH(false, 2); else EGO_LAUNCH_MARCH(false, 1);
+  }
+#undef EGO_LAUNCH_MARCH
   return ego_launch_status("k_march_density");
 }
 

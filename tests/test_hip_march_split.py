@@ -1,0 +1,53 @@
+"""ego_march_density with a ray's passes dealt to two waves (few rounds of wave slots, long rays: the 4096 x 512 headline) must return
+the bits of the one-wave-per-ray form: weights, background weight, alpha, distances, tile flags (the coordinates of samples behind an
+exactly opaque prefix are the one documented difference: the one-wave form never evaluates them and writes zeros)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from egonerf_amd import _lib, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def march(model, cfg, rays, S, with_alpha, term_eps=0.0):
+    lib, st = _lib.load(), _lib.stream_handle()
+    model.early_termination_eps = term_eps
+    sc = model.scene()
+    N = rays.shape[0]
+    dev = rays.device
+    sched = model._sched(S, dev)
+    z, w, bg = torch.zeros(N, S, device=dev), torch.zeros(N, S, device=dev), torch.zeros(N, device=dev)
+    crd = torch.zeros(N, S, 4, device=dev)
+    alpha = torch.zeros(N, S + 1, device=dev) if with_alpha else None
+    act = torch.zeros((N * S + 31) // 32, device=dev, dtype=torch.uint8)
+    _lib.check(lib.ego_march_density(sc, rays.data_ptr(), N, S, None, sched.data_ptr(), None, cfg.near, 0, z.data_ptr(), _lib.ptr(alpha), S + 1 if with_alpha else 0,
+                                     w.data_ptr(), bg.data_ptr(), crd.data_ptr(), None, act.data_ptr(), st), "march")
+    torch.cuda.synchronize()
+    return z, w, bg, alpha, act, crd
+
+
+@pytest.mark.parametrize("S,n_rays,density_shift", [(512, 4096, None), (300, 1001, None), (256, 130, 0.0), (449, 67, 0.0)])
+@pytest.mark.parametrize("with_alpha", [False, True])
+def test_two_waves_per_ray_return_the_same_bits(S, n_rays, density_shift, with_alpha):
+    cfg = synth.SceneConfig(n_voxel=40 ** 3) if density_shift is None else synth.SceneConfig(n_voxel=40 ** 3, density_shift=density_shift)
+    model = synth.build_model(cfg, synth.make_weights(cfg, seed=7), "cuda")
+    rays = torch.from_numpy(synth.make_rays(n_rays, seed=5)).cuda()
+    out = {}
+    try:
+        for split in ("1", "2"):
+            os.environ["EGO_MARCH_SPLIT"] = split
+            out[split] = march(model, cfg, rays, S, with_alpha, term_eps=1e-4 if S == 449 else 0.0)
+    finally:
+        os.environ.pop("EGO_MARCH_SPLIT", None)
+    a, b = out["1"], out["2"]
+    for k, name in enumerate(("z", "weight", "bg", "alpha", "tile flags")):
+        if a[k] is not None:
+            assert torch.equal(a[k], b[k]), (name, S, n_rays)
+    assert float(a[1].sum()) > 0.0
+    shaded = a[1] > 0
+    assert torch.equal(a[5][shaded], b[5][shaded])   # coordinates wherever a colour is read
+    if density_shift is not None and not with_alpha:   # opaque field: the one-wave form stops behind exact zero transmittance
+        assert bool((a[1] == 0).any())

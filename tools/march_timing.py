@@ -32,3 +32,6 @@ b = run(16384, 128, 1)
 zf = torch.sort(torch.cat([b[3], b[3] + 0.004], 1), 1).values.contiguous()
 c = run(16384, 256, 2, z_in=zf)
 print(f"march 4096x512 {a[0]*1e3:.1f} us | 16384x128 coarse {b[0]*1e3:.1f} us | 16384x256 fine {c[0]*1e3:.1f} us | checksums {a[1]:.6f} {a[2]:.3f} {b[1]:.6f} {c[1]:.6f}")
+if len(sys.argv) > 1 and sys.argv[1] == "sweep":   # wave-slot quantisation: time against the number of rays (one wave per ray, 3 waves per SIMD = 3072 slots)
+    for n in (1024, 2048, 3072, 3584, 4096, 5120, 6144, 8192, 9216, 12288):
+        print(f"  N = {n:6d} x 512: {run(n, 512, 0, reps=50)[0] * 1e3:7.1f} us   ({n / 3072:.2f} rounds of wave slots)")

@@ -10,6 +10,6 @@ for v in $VALUES; do
 done
 wait
 for v in $VALUES; do test -f egonerf_amd/libvariant_$v.so || { echo "variant $v failed to build"; exit 1; }; done
-/usr/local/graft/bin/gpurun --timeout 900 -- "for v in $VALUES; do cp egonerf_amd/libvariant_\$v.so egonerf_amd/libegonerf_hip.so; echo \"== $MACRO=\$v\"; EGO_ALLOW_STALE_LIB=1 python $SCRIPT 2>&1 | tail -4; done" 2>&1 | tail -40
+/usr/local/graft/bin/gpurun --timeout 900 -- "for v in $VALUES; do cp egonerf_amd/libvariant_\$v.so egonerf_amd/libegonerf_hip.so; echo \"== $MACRO=\$v\"; EGO_ALLOW_STALE_LIB=1 $SCRIPT 2>&1 | tail -4; done" 2>&1 | tail -40
 rm -f egonerf_amd/libvariant_*.so
 python -c "import __graft_entry__ as g; g.build()" | tail -1
