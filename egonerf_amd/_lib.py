@@ -103,6 +103,7 @@ PROTOTYPES = {
     "ego_shade": (C.c_int, [SP, P, P, P, I64, I32, P, P, P, P]),
     "ego_alpha_mask_sample": (C.c_int, [SP, P, I64, P, P]),
     "ego_composite": (C.c_int, [SP, P, P, P, P, P, I64, I32, P, P, P, P, P, P]),
+    "ego_shade_composite": (C.c_int, [SP, P, P, P, P, P, I64, I32, P, P, P, P, P, P]),
     "ego_train_packed_floats": (I64, []),
     "ego_pack_train": (C.c_int, [SP, P, P]),
     "ego_train_layout": (C.c_int, [I32, C.POINTER(C.c_int32), I32]),

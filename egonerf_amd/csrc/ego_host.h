@@ -23,6 +23,9 @@ inline int ego_fail(int code, const char* fmt, ...) {
     if (!(cond)) return ego_fail(EGO_E_BADARG, "%s", msg); \
   } while (0)
 
+// csrc/ego_shade.hip: can ego_shade_composite serve this scene and sample count? (asked by ego_render_forward)
+bool ego_can_fold_composite(const ego_scene* sc, int32_t S);
+
 inline int ego_launch_status(const char* kernel) {
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return ego_fail((int)e, "%s: launch failed: %s", kernel, hipGetErrorString(e));

@@ -548,25 +548,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 // =============================================================================================
 // Row J — environment map     models/envmap.py:6-14, 26-34
 // =============================================================================================
-__device__ __forceinline__ void envmap_lookup(const float* __restrict__ em, int h, float dx, float dy, float dz,
-                                              float out[3]) {
-  const float nrm = fmaxf(__fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz))), 1e-12f);
-  const float nx = __fdiv_rn(dx, nrm), ny = __fdiv_rn(dy, nrm), nz = __fdiv_rn(dz, nrm);
-  const float u = __fmul_rn(__fadd_rn(nz, 1.f), 0.5f);
-  const float v = __fdiv_rn(__fadd_rn(atan2f(ny, nx), 3.14159265358979323846f), 6.28318530717958647692f);
-  const Lin1 X = lin_setup(__fsub_rn(__fmul_rn(u, 2.f), 1.f), h);       // u indexes the h-wide axis
-  const Lin1 Y = lin_setup(__fsub_rn(__fmul_rn(v, 2.f), 1.f), 2 * h);   // v indexes the 2h axis
-  const float w00 = __fmul_rn(Y.w0, X.w0), w01 = __fmul_rn(Y.w0, X.w1), w10 = __fmul_rn(Y.w1, X.w0),
-              w11 = __fmul_rn(Y.w1, X.w1);
-#pragma unroll
-  for (int ch = 0; ch < 3; ++ch) {
-    const float* E = em + (int64_t)ch * 2 * h * h;
-    const float s = E[(int64_t)Y.i0 * h + X.i0] * w00 + E[(int64_t)Y.i0 * h + X.i1] * w01 +
-                    E[(int64_t)Y.i1 * h + X.i0] * w10 + E[(int64_t)Y.i1 * h + X.i1] * w11;
-    out[ch] = sigmoidf(s);
-  }
-}
-
 __global__ void k_envmap(const float* __restrict__ em, int h, const float* __restrict__ dirs, int64_t N,
                          float* __restrict__ out) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

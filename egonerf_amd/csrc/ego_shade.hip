@@ -425,6 +425,15 @@ struct ShadeArgs {
   float* dump_v;
   uint32_t* dump_bits;  // [tile][layer 0: h1, 1: h2][lane][2]: bit 16 (mt & 1) + r of word mt >> 1 <=> post-ReLU unit (mt, r) of the lane > 0
   const uint8_t* tile_active;  // optional [n_tiles]: 0 = every weight of the tile is zero, skip it
+  // FOLD (ego_shade_composite): compositing in the kernel's epilogue instead of per-sample colours
+  const float* comp_w;    // [N][S] weights
+  const float* comp_bg;   // [N] background weight (with an envmap)
+  const float* envmap;    // emission or null
+  int32_t envmap_h;
+  float* rgb_map;         // [N][3]
+  float* depth;           // [N] or null
+  float* bg_map;          // [N][3] or null
+  float* env_map;         // [N][3] or null
   int64_t M;
   int32_t S;
 };
@@ -1265,9 +1274,14 @@ __device__ __forceinline__ void gather_basis_f16(const DevField& F, const VMTaps
 }
 
 // PX: arithmetic of the MLP's correction terms: 0 = fp16 (f16x3), 1 = fp8 (f16f8), 2 = fp6 (f16f6)
-template <int MODE, bool DUMP = false, bool TAB16 = false, int PX = 0>
+// FOLD: rows H / J in the epilogue (models/EgoNeRF.py:579-598): a wave owns whole rays (S a multiple of 32, a ray = S / 32 consecutive
+// tiles), keeps sum w rgb / sum w (lane half 0) and sum w z (lane half 1) per lane across the ray's tiles and finishes the pixel -
+// background, clamp, depth - itself; no per-sample colours are written and k_composite (12 us per 4096 x 512 launch: 25 MB of colours
+// written here, 42 MB read there) is not launched.
+template <int MODE, bool DUMP = false, bool TAB16 = false, int PX = 0, bool FOLD = false>
 __global__ __launch_bounds__(512) void k_shade_h(ShadeArgs A) {
   constexpr bool P8 = PX == 1, P6 = PX == 2;
+  static_assert(!FOLD || (MODE == MODE_SHADE && !DUMP), "compositing folds into the fused inference kernel only");
   static_assert(!PX || (!DUMP && MODE != MODE_APP), "the fp8 / fp6 correction arithmetic exists for the inference MLP only");
   __shared__ __attribute__((aligned(16))) float lds[(MODE == MODE_APP ? 0 : LDS_W_FLOATS) + 4];
   const float* blob = A.packed + PACKED_FLOATS;  // the f16x3 half of the packed blob
@@ -1303,17 +1317,22 @@ __global__ __launch_bounds__(512) void k_shade_h(ShadeArgs A) {
   // (tile mask) are the tails of rays and every wave owns whole rays; sharing the ACTIVE tiles evenly instead (prefix sums over the
   // mask in the prologue, or chunks dealt through an atomic counter) was built and measured: DESIGN.md 4.3.
   const int64_t n_wv = (int64_t)gridDim.x * 8;
-  const int64_t per_wave = (n_tiles + n_wv - 1) / n_wv;
+  const int64_t tpr = FOLD ? (int64_t)(A.S >> 5) : 0;   // tiles per ray
+  const int64_t per_wave = FOLD ? ((A.M / A.S + n_wv - 1) / n_wv) * tpr : (n_tiles + n_wv - 1) / n_wv;
   const int64_t tile0 = ((int64_t)blockIdx.x * 8 + wave) * per_wave;
   const int64_t tile1 = tile0 + per_wave < n_tiles ? tile0 + per_wave : n_tiles;
+  const int64_t seg_len = FOLD ? tpr : per_wave;   // FOLD: one ray per segment
+  for (int64_t seg0 = tile0; seg0 < tile1; seg0 += seg_len) {
+  const int64_t seg1 = seg0 + seg_len < tile1 ? seg0 + seg_len : tile1;
+  float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f;   // FOLD, lane half 0: sum w r, w g, w b, w; half 1: sum w z in c0
   // the tile mask is read 64 tiles at a time (one byte per lane + ballot) and walked with find-first-set: a skipped tile costs no
   // memory round trip (a per-tile flag load sat on the critical path of every skipped tile)
-  for (int64_t wbase = tile0; wbase < tile1; wbase += 64) {
+  for (int64_t wbase = seg0; wbase < seg1; wbase += 64) {
     unsigned long long wmask;
     {
       const int64_t t = wbase + (int64_t)lane;
-      const bool in = t < tile1;
-      wmask = (MODE == MODE_SHADE && A.tile_active) ? __ballot(in && A.tile_active[in ? t : tile0] != 0) : __ballot(in);
+      const bool in = t < seg1;
+      wmask = (MODE == MODE_SHADE && A.tile_active) ? __ballot(in && A.tile_active[in ? t : seg0] != 0) : __ballot(in);
     }
   while (wmask != 0ull) {
     const int64_t tile = wbase + (int64_t)__builtin_ctzll(wmask);
@@ -1325,6 +1344,9 @@ __global__ __launch_bounds__(512) void k_shade_h(ShadeArgs A) {
     const int64_t m_raw = tile * 32 + j;
     const bool valid = m_raw < A.M;
     const int64_t m = valid ? m_raw : A.M - 1;
+    // FOLD: the sample's weight and distance travel while the tile is computed (fetched where they are used, their latency is exposed once per tile)
+    float fold_w = 0.f, fold_z = 0.f;
+    if (FOLD) { fold_w = A.comp_w[m]; fold_z = A.z[m]; }
 
     f32x16 fe;
     float vd0 = 0.f, vd1 = 0.f, vd2 = 0.f;
@@ -1706,12 +1728,47 @@ __global__ __launch_bounds__(512) void k_shade_h(ShadeArgs A) {
     o0 += __shfl_xor(o0, 32, 64);
     o1 += __shfl_xor(o1, 32, 64);
     o2 += __shfl_xor(o2, 32, 64);
-    if (valid && h == 0) {
+    if (FOLD) {
+      // weights are >= 0 and a tile skipped above holds only zeros (the fold is used with shade_above = 0), so nothing is conditional
+      const float* b3 = lds + OFF_B3;
+      const float wgt = valid ? fold_w : 0.f;
+      const float x0 = h ? fold_z : sigmoidf(o0 + b3[0]);
+      c0 += wgt * x0;
+      c1 += wgt * sigmoidf(o1 + b3[1]);
+      c2 += wgt * sigmoidf(o2 + b3[2]);
+      c3 += wgt;
+    } else if (valid && h == 0) {
       const float* b3 = lds + OFF_B3;
       float* o = A.out + m * 3;
       o[0] = sigmoidf(o0 + b3[0]);
       o[1] = sigmoidf(o1 + b3[1]);
       o[2] = sigmoidf(o2 + b3[2]);
+    }
+  }
+  }
+  if (FOLD) {   // the pixel of ray seg0 / tpr (rows H, J: k_composite's arithmetic on the per-lane sums)
+#pragma unroll
+    for (int sh = 1; sh < 32; sh <<= 1) {
+      c0 += __shfl_xor(c0, sh, 64); c1 += __shfl_xor(c1, sh, 64); c2 += __shfl_xor(c2, sh, 64); c3 += __shfl_xor(c3, sh, 64);
+    }
+    const float dp = __shfl(c0, 32, 64);
+    if (lane == 0) {
+      const int64_t ray = seg0 / tpr;
+      const float* R = A.rays + ray * 6;
+      float cr = c0, cg = c1, cb = c2;
+      if (A.envmap) {
+        float e[3];
+        envmap_lookup(A.envmap, A.envmap_h, R[3], R[4], R[5], e);
+        const float b = A.comp_bg[ray];
+        const float bx = b * e[0], by = b * e[1], bz = b * e[2];
+        cr += bx; cg += by; cb += bz;
+        if (A.bg_map) { A.bg_map[ray * 3] = bx; A.bg_map[ray * 3 + 1] = by; A.bg_map[ray * 3 + 2] = bz; }
+        if (A.env_map) { A.env_map[ray * 3] = e[0]; A.env_map[ray * 3 + 1] = e[1]; A.env_map[ray * 3 + 2] = e[2]; }
+      }
+      A.rgb_map[ray * 3] = fminf(fmaxf(cr, 0.f), 1.f);
+      A.rgb_map[ray * 3 + 1] = fminf(fmaxf(cg, 0.f), 1.f);
+      A.rgb_map[ray * 3 + 2] = fminf(fmaxf(cb, 0.f), 1.f);
+      if (A.depth) A.depth[ray] = dp + (1.f - c3) * R[5];  // (1-acc) * d_z: reference quirk, EgoNeRF.py:598
     }
   }
   }
@@ -1753,6 +1810,11 @@ unsigned shade_grid(int64_t M) {
 }
 
 }  // namespace
+
+// ego_render_forward's question (csrc/ego_render.hip): can shading and compositing run as one launch for this scene and sample count?
+bool ego_can_fold_composite(const ego_scene* sc, int32_t S) {
+  return sc && ego_shape_is_tuned(sc) && !sc->app_f16 && sc->mlp_precision != EGO_PREC_F32 && sc->weight_thres <= 0.f && S >= 32 && (S & 31) == 0;
+}
 
 extern "C" {
 
@@ -1876,6 +1938,25 @@ int ego_shade(const ego_scene* sc, const float* rays, const float* z, const floa
   else if (sc->mlp_precision == EGO_PREC_F16F6) k_shade_h<MODE_SHADE, false, false, 2><<<shade_grid(a.M), 512, 0, (hipStream_t)stream>>>(a);
   else k_shade_h<MODE_SHADE><<<shade_grid(a.M), 512, 0, (hipStream_t)stream>>>(a);
   return ego_launch_status("k_shade<SHADE>");
+}
+
+int ego_shade_composite(const ego_scene* sc, const float* rays, const float* z, const float* coords, const float* weight, const float* bg_weight,
+                        int64_t N, int32_t S, const uint8_t* tile_active, float* rgb_map, float* depth, float* bg_map, float* env_map, void* stream) {
+  EGO_REQUIRE(rays && z && coords && weight && rgb_map && N >= 0 && S >= 32 && (S & 31) == 0 && N * (int64_t)S < (1ll << 31),
+              "shade_composite: null argument, S not a multiple of 32, or N*S >= 2^31");
+  if (!ego_can_fold_composite(sc, S)) return ego_fail(EGO_E_UNSUPPORTED, "shade_composite: tuned model shape, fp32 tables, a split-precision arithmetic and weight_thres <= 0 only");
+  if (int e = check_shade_config(sc, "shade_composite", true, true)) return e;
+  EGO_REQUIRE(!sc->envmap || bg_weight, "shade_composite: envmap needs bg_weight");
+  if (N == 0) return EGO_OK;
+  ShadeArgs a{};
+  a.c = make_coords(*sc); a.F = make_field(sc->app); a.packed = sc->packed; a.rays = rays; a.z = z; a.coords = coords; a.tile_active = tile_active;
+  a.comp_w = weight; a.comp_bg = bg_weight; a.envmap = sc->envmap; a.envmap_h = sc->envmap_h;
+  a.rgb_map = rgb_map; a.depth = depth; a.bg_map = bg_map; a.env_map = env_map;
+  a.M = N * (int64_t)S; a.S = S;
+  if (sc->mlp_precision == EGO_PREC_F16F6) k_shade_h<MODE_SHADE, false, false, 2, true><<<shade_grid(a.M), 512, 0, (hipStream_t)stream>>>(a);
+  else if (sc->mlp_precision == EGO_PREC_F16F8) k_shade_h<MODE_SHADE, false, false, 1, true><<<shade_grid(a.M), 512, 0, (hipStream_t)stream>>>(a);
+  else k_shade_h<MODE_SHADE, false, false, 0, true><<<shade_grid(a.M), 512, 0, (hipStream_t)stream>>>(a);
+  return ego_launch_status("k_shade<SHADE, composite>");
 }
 
 // ---- training step (backward) --------------------------------------------------------------------------------------

@@ -259,6 +259,17 @@ int ego_shade(const ego_scene* sc, const float* rays, const float* z, const floa
               const ego_shade_dump* dump /* NULL for inference */, const uint8_t* tile_active /* NULL = shade every tile */,
               void* stream);
 
+/* ego_shade + ego_composite as ONE launch (rows F, G, H, J; EgoNeRF.py:555-598): the shade kernel's waves own whole rays and finish the
+ * pixel in their epilogue, no per-sample colours are written.  For the tuned model shape with fp32 tables, a split-precision arithmetic
+ * (not EGO_PREC_F32), weight_thres <= 0 and S a multiple of 32 (EGO_E_UNSUPPORTED otherwise: call ego_shade + ego_composite); coords
+ * is required.  Sums run in a different order than ego_composite's (per lane over the ray's tiles, then across 32 lanes): equal to it
+ * within fp32 rounding of the sums, not bit for bit.  ego_render_forward takes this path whenever it applies (EGO_RENDER_NO_FOLD=1 in
+ * the environment keeps the two-launch form, for A/B measurements). */
+int ego_shade_composite(const ego_scene* sc, const float* rays, const float* z, const float* coords, const float* weight,
+                        const float* bg_weight /* NULL without an envmap */, int64_t N, int32_t S,
+                        const uint8_t* tile_active /* NULL = shade every tile */, float* rgb_map, float* depth /* may be NULL */,
+                        float* bg_map /* may be NULL */, float* env_map /* may be NULL */, void* stream);
+
 /* acc, rgb_map (+ envmap background), clamp, depth (+ (1-acc)*d_z quirk, EgoNeRF.py:598).
  * Outputs rgb_map [N][3], depth [N]; bg_map/env_map [N][3] written only when sc->envmap != NULL (may be NULL);
  * rgb_raw [N][3] optional = rgb_map before the clamp (the backward pass needs the clamp mask). */

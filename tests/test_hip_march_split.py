@@ -51,3 +51,32 @@ def test_two_waves_per_ray_return_the_same_bits(S, n_rays, density_shift, with_a
     assert torch.equal(a[5][shaded], b[5][shaded])   # coordinates wherever a colour is read
     if density_shift is not None and not with_alpha:   # opaque field: the one-wave form stops behind exact zero transmittance
         assert bool((a[1] == 0).any())
+
+
+@pytest.mark.parametrize("kw", [dict(n_coarse=512), dict(n_coarse=64, n_fine=64, resampling=True), dict(n_coarse=96)])
+@pytest.mark.parametrize("prec", ["f16f6", "f16f8", "f16x3"])
+@pytest.mark.parametrize("envmap", [False, True])
+def test_folded_compositing_equals_the_two_launch_form(kw, prec, envmap):
+    """ego_render_forward shades and composites in one launch (ego_shade_composite) wherever it applies; EGO_RENDER_NO_FOLD=1 keeps
+    ego_shade + ego_composite.  Same products, sums in another order: equal within fp32 rounding of the sums (2e-6), all five outputs."""
+    cfg = synth.SceneConfig(n_voxel=40 ** 3, use_envmap=envmap, envmap_res_H=64) if envmap else synth.SceneConfig(n_voxel=40 ** 3)
+    model = synth.build_model(cfg, synth.make_weights(cfg, seed=11), "cuda")
+    model.mlp_precision = prec
+    rays = torch.from_numpy(synth.make_rays(333, seed=9)).cuda()
+    out = {}
+    try:
+        for fold in (True, False):
+            if fold:
+                os.environ.pop("EGO_RENDER_NO_FOLD", None)
+            else:
+                os.environ["EGO_RENDER_NO_FOLD"] = "1"
+            with torch.no_grad():
+                out[fold] = model(rays, exp_sampling=True, **kw)
+    finally:
+        os.environ.pop("EGO_RENDER_NO_FOLD", None)
+    for k in range(5):
+        a, b = out[True][k], out[False][k]
+        assert (a is None) == (b is None), k
+        if a is not None:
+            assert float((a - b).abs().max()) <= (2e-6 if k != 1 else 2e-5), (k, float((a - b).abs().max()))
+    assert float(out[True][0].max()) > 0.05
