@@ -1288,10 +1288,20 @@ __global__ __launch_bounds__(512) void k_shade_h(ShadeArgs A) {
   if (MODE != MODE_APP) {
     const f32x4* src = (const f32x4*)blob;
     const f32x4* src8 = (const f32x4*)(A.packed + 2 * PACKED_FLOATS + BASIS16_FLOATS_C + (P6 ? F8_FLOATS : 0));  // f16f8 / f16f6 layout of W1 / W2
-    f32x4* dst = (f32x4*)lds;
-    for (int i = threadIdx.x; i < LDS_W_FLOATS / 4; i += 512) dst[i] = (PX && i < F8_FLOATS / 4) ? src8[i] : src[i];
+    // The 150 KB image goes to LDS by the loads themselves (global_load_lds_dwordx4: a wave instruction moves 1 KB, no VGPRs), and
+    // nobody waits for it here: the first tile's gather + basis phase reads no LDS, so the workgroup meets at a barrier in front of
+    // its first MLP phase instead (`need_sync` below).  A launch has ~32 us of fixed cost at 4096 x 512 (tools/shade_scaling.py), of
+    // which the fill - every CU pulling the same 150 KB through its L1 with all waves parked - was the largest piece.
+    constexpr int NQ = LDS_W_FLOATS / 4, NCH = NQ / 64;   // float4 quads; whole 1 KB chunks (the image ends 1 quad behind them)
+    static_assert(F8_FLOATS % 256 == 0 && NQ - NCH * 64 < 64, "chunking of the LDS image");
+    const int wv_u = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    for (int c = wv_u; c < NCH; c += 8) {
+      const f32x4* from = ((PX && c < F8_FLOATS / 256) ? src8 : src) + c * 64 + (threadIdx.x & 63);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)from, (__attribute__((address_space(3))) void*)(lds + c * 256), 16, 0, 0);
+    }
+    for (int i = NCH * 64 + threadIdx.x; i < NQ; i += 512) ((f32x4*)lds)[i] = src[i];
   }
-  __syncthreads();
+  bool need_sync = MODE != MODE_APP;   // wave-uniform: the barrier that publishes the LDS image is still ahead
   if (PX) {
     // MODE.FP16_OVFL = 1: an out-of-range f32 -> fp8 / f16 conversion saturates to the largest finite value instead of producing
     // NaN / inf (v_cvt_pk_fp8_f32 returns NaN above 448, tools/fp8_layout_probe.hip); a saturated correction operand costs accuracy
@@ -1425,6 +1435,7 @@ __global__ __launch_bounds__(512) void k_shade_h(ShadeArgs A) {
     }
 
     __builtin_amdgcn_s_setprio(0);
+    if (need_sync) { __syncthreads(); need_sync = false; }
     float vw[8];
     {
       float sa0, ca0, sb0, cb0, sa1, ca1, sb1, cb1, sa2, ca2, sb2, cb2;
@@ -1772,6 +1783,7 @@ __global__ __launch_bounds__(512) void k_shade_h(ShadeArgs A) {
     }
   }
   }
+  if (need_sync) __syncthreads();   // a wave without a tile still owes the workgroup its arrival
 }
 
 #include "ego_train.inc"
