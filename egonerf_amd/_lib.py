@@ -64,7 +64,7 @@ class AdamTensor(C.Structure):
 
 
 class ShadeDump(C.Structure):
-    _fields_ = [("x", C.c_void_p), ("h1", C.c_void_p), ("h2", C.c_void_p), ("v", C.c_void_p), ("relu_bits", C.c_void_p)]
+    _fields_ = [("x", C.c_void_p), ("h1", C.c_void_p), ("h2", C.c_void_p), ("v", C.c_void_p), ("relu_bits", C.c_void_p), ("fe", C.c_void_p)]
 
 
 P, I32, I64, F32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float

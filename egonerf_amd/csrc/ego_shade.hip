@@ -419,10 +419,11 @@ struct ShadeArgs {
   const float* feat;  // MODE_MLP: [M][27]
   const float* dirs;  // MODE_MLP: [M][3]
   float* out;         // rgb [M][3] or feat [M][27]
-  float* dump_x;      // training forward (MODE_SHADE, f16x3): activations kept for the backward pass, lane-contiguous
-  float* dump_h1;     //   [M][160] X, [M][128] relu(H1), [M][128] relu(H2), [M][144] v   (see include/egonerf_hip.h)
-  float* dump_h2;
+  uint16_t* dump_x;   // training forward (MODE_SHADE, f16x3): activations kept for the backward pass, lane-contiguous
+  uint16_t* dump_h1;  //   [M][160] X, [M][128] relu(H1), [M][128] relu(H2) as halves [tile][k-step][lane][8]; [M][144] v fp32 (include/egonerf_hip.h)
+  uint16_t* dump_h2;
   float* dump_v;
+  float* dump_fe;       // [tile][quad 0..3][lane][4]: the lane's 16 feature slots (basis output), fp32: the backward re-derives the encodings from them
   uint32_t* dump_bits;  // [tile][layer 0: h1, 1: h2][lane][2]: bit 16 (mt & 1) + r of word mt >> 1 <=> post-ReLU unit (mt, r) of the lane > 0
   const uint8_t* tile_active;  // optional [n_tiles]: 0 = every weight of the tile is zero, skip it
   // FOLD (ego_shade_composite): compositing in the kernel's epilogue instead of per-sample colours
@@ -851,6 +852,18 @@ __device__ __forceinline__ u32x6 cvt_2xpk16_fp6_f32(const f32x16& a, const f32x1
   u32x6 r;
   asm("s_nop 0\n\tv_cvt_scalef32_2xpk16_fp6_f32 %0, %1, %2, %3\n\ts_nop 1" : "=&v"(r) : "v"(a), "v"(b), "v"(scale));
   return r;
+}
+
+// 8 fp32 values -> 8 halves, round to nearest: one k-step of an activation dump (ego_shade_dump's x / h1 / h2)
+__device__ __forceinline__ u32x4 pack8_rn(const float x[8]) {
+  u32x4 o;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    typedef float f2v __attribute__((ext_vector_type(2)));
+    typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+    o[q] = __builtin_bit_cast(uint32_t, __builtin_convertvector(f2v{x[2 * q], x[2 * q + 1]}, h2v));
+  }
+  return o;
 }
 
 struct B6 {
@@ -1436,6 +1449,10 @@ __global__ __launch_bounds__(512) void k_shade_h(ShadeArgs A) {
 
     __builtin_amdgcn_s_setprio(0);
     if (need_sync) { __syncthreads(); need_sync = false; }
+    if (DUMP && valid) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) ((f32x4*)A.dump_fe)[(tile * 4 + q) * 64 + lane] = f32x4{fe[4 * q], fe[4 * q + 1], fe[4 * q + 2], fe[4 * q + 3]};
+    }
     float vw[8];
     {
       float sa0, ca0, sb0, cb0, sa1, ca1, sb1, cb1, sa2, ca2, sb2, cb2;
@@ -1580,10 +1597,7 @@ __global__ __launch_bounds__(512) void k_shade_h(ShadeArgs A) {
         if ((kk & 7) == 7) {
           const int step = kk >> 3;
           const HL b = split8(xs, true);
-          if (DUMP && valid) {
-            f32x4* d = (f32x4*)(A.dump_x + dump_off(tile, 160, 2 * step, hw, j));
-            d[0] = f32x4{xs[0], xs[1], xs[2], xs[3]}; d[64] = f32x4{xs[4], xs[5], xs[6], xs[7]};  // quad pairs 2 step, 2 step + 1
-          }
+          if (DUMP && valid) ((u32x4*)A.dump_x)[(tile * KH1 + step) * 64 + lane] = pack8_rn(xs);   // [tile][k-step][lane][8 halves]
 #pragma unroll
           for (int mt = 0; mt < 4; ++mt) { ah[mt] = nh[mt]; al[mt] = nl[mt]; }
           if (step + 1 < KH1) {
@@ -1608,10 +1622,12 @@ __global__ __launch_bounds__(512) void k_shade_h(ShadeArgs A) {
       for (int r = 0; r < 16; ++r) H[mt][r] = relu_f(H[mt][r]);
     if (DUMP && valid) {
 #pragma unroll
-      for (int mt = 0; mt < 4; ++mt)
+      for (int st = 0; st < KH2; ++st) {   // k-step st of the next layer = registers 8 (st & 1) .. + 7 of m-tile st >> 1
+        float v8[8];
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-          *(f32x4*)(A.dump_h1 + dump_off(tile, 128, mt * 4 + q, hw, j)) = f32x4{H[mt][4 * q], H[mt][4 * q + 1], H[mt][4 * q + 2], H[mt][4 * q + 3]};
+        for (int e = 0; e < 8; ++e) v8[e] = H[st >> 1][8 * (st & 1) + e];
+        ((u32x4*)A.dump_h1)[(tile * KH2 + st) * 64 + lane] = pack8_rn(v8);
+      }
       // the ReLU masks as bits: what the shade backward needs of h1 / h2 (it would otherwise re-read both dumps, 1 KB per sample)
       ((u32x2*)A.dump_bits)[(tile * 2 + 0) * 64 + lane] = relu_bits(H);
     }
@@ -1716,11 +1732,12 @@ __global__ __launch_bounds__(512) void k_shade_h(ShadeArgs A) {
     }
     if (DUMP && valid) {
 #pragma unroll
-      for (int mt = 0; mt < 4; ++mt)
+      for (int st = 0; st < KH2; ++st) {
+        float v8[8];
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-          *(f32x4*)(A.dump_h2 + dump_off(tile, 128, mt * 4 + q, hw, j)) =
-              f32x4{relu_f(G[mt][4 * q]), relu_f(G[mt][4 * q + 1]), relu_f(G[mt][4 * q + 2]), relu_f(G[mt][4 * q + 3])};
+        for (int e = 0; e < 8; ++e) v8[e] = relu_f(G[st >> 1][8 * (st & 1) + e]);
+        ((u32x4*)A.dump_h2)[(tile * KH2 + st) * 64 + lane] = pack8_rn(v8);
+      }
       ((u32x2*)A.dump_bits)[(tile * 2 + 1) * 64 + lane] = relu_bits(G);
     }
     float o0 = 0.f, o1 = 0.f, o2 = 0.f;
@@ -1935,9 +1952,9 @@ int ego_shade(const ego_scene* sc, const float* rays, const float* z, const floa
   a.c = make_coords(*sc); a.F = make_field(sc->app); a.packed = sc->packed; a.rays = rays; a.z = z; a.coords = coords; a.out = rgb; a.tile_active = tile_active;
   a.M = N * (int64_t)S; a.S = S;
   if (dump) {
-    EGO_REQUIRE(sc->mlp_precision != EGO_PREC_F32 && dump->x && dump->h1 && dump->h2 && dump->v && dump->relu_bits,
-                "shade: activation dumps need the fp16-split arithmetic (not EGO_PREC_F32) and five non-null buffers");
-    a.dump_x = dump->x; a.dump_h1 = dump->h1; a.dump_h2 = dump->h2; a.dump_v = dump->v; a.dump_bits = dump->relu_bits;
+    EGO_REQUIRE(sc->mlp_precision != EGO_PREC_F32 && dump->x && dump->h1 && dump->h2 && dump->v && dump->relu_bits && dump->fe,
+                "shade: activation dumps need the fp16-split arithmetic (not EGO_PREC_F32) and six non-null buffers");
+    a.dump_x = dump->x; a.dump_h1 = dump->h1; a.dump_h2 = dump->h2; a.dump_v = dump->v; a.dump_bits = dump->relu_bits; a.dump_fe = dump->fe;
     k_shade_h<MODE_SHADE, true><<<shade_grid(a.M), 512, 0, (hipStream_t)stream>>>(a);
   } else if (sc->mlp_precision == EGO_PREC_F32) k_shade<MODE_SHADE><<<shade_grid(a.M), 512, 0, (hipStream_t)stream>>>(a);
   else if (sc->app_f16) {
@@ -2060,7 +2077,7 @@ int ego_shade_backward(const ego_scene* sc, const float* train_packed, const flo
   if (int e = check_shade_config(sc, "shade_backward", true, true)) return e;
   ShadeBwdArgs a{};
   a.tpacked = train_packed; a.coords = coords; a.dc = dc; a.rgb = rgb;
-  a.x = fwd->x; a.bits = fwd->relu_bits; a.dh2 = dh2; a.dh1 = dh1; a.dh_scale = dh_scale; a.dfe = dfe; a.dv = dv; a.M = N * (int64_t)S;
+  a.fe = fwd->fe; a.bits = fwd->relu_bits; a.dh2 = dh2; a.dh1 = dh1; a.dh_scale = dh_scale; a.dfe = dfe; a.dv = dv; a.M = N * (int64_t)S;
   k_shade_bwd<<<shade_grid(a.M), 512, 0, (hipStream_t)stream>>>(a);
   return ego_launch_status("k_shade_bwd");
 }

@@ -45,14 +45,16 @@ __device__ __forceinline__ void split_bf16_pair(float v0, float v1, uint32_t& hi
 // One matrix tile = rows [row0, row0 + 32) x columns [0, 32 NB), staged to LDS as [term][column][32 samples].  A thread owns
 // (column quad, sample pair) items: two float4 global loads (fetch, issued a whole step ahead of their use), then eight
 // packed bf16-pair stores (commit).
-// BLK: 0 row-major fp32, 1 tile-blocked fp32, 2 tile-blocked scaled fp16 (ego_shade_backward's dh2 / dh1: [tile][k-step s][lane =
-// 32 h + sample][8 halves], element e = logical column 8 (2 s + e / 4) + 4 h + e % 4, value = half * scale[row]; NB == 4),
+// BLK: 0 row-major fp32, 1 tile-blocked fp32, 2 tile-blocked fp16 in the shade kernels' operand order ([tile][k-step s][lane =
+// 32 h + sample][8 halves], element e = logical column 8 (2 s + e / 4) + 4 h + e % 4; cx / 16 k-steps in memory, the tile's further
+// column blocks are zero): ego_shade_backward's dh2 / dh1 with value = half * scale[row], the forward's x / h1 / h2 dumps with scale
+// = NULL (the halves are the values),
 // 3 row-major fp32 [M][32] standing for 64 logical columns: row m fills columns [32 g, 32 g + 32) with g = (scale[4 m + 3] != 0),
 // the other 32 are zero (ego_shade_backward's dfe with `scale` = the forward's coords [M][4]; NB == 2)
 template <int NB, bool VEC, int BLK>
 struct Tile {
   static constexpr int QUADS = NB * 8;                       // column quads per row
-  static constexpr int ITEMS = BLK == 2 ? 1 : (16 * QUADS + 255) / 256;     // items per thread
+  static constexpr int ITEMS = BLK == 2 ? (NB + 3) / 4 : (16 * QUADS + 255) / 256;     // items per thread
   f32x4 v0[ITEMS], v1[ITEMS];
   float s0, s1;  // BLK == 2: the two samples' scales
 
@@ -65,15 +67,19 @@ struct Tile {
 
   __device__ __forceinline__ void fetch(const float* __restrict__ X, const float* __restrict__ scale, int ldx, int cx, int64_t row0, int64_t M) {
     if (BLK == 2) {  // item = (k-step, lane half, sample pair): 32 contiguous bytes = the 8 halves of two neighbouring lanes
-      static_assert(BLK != 2 || NB == 4, "the scaled-fp16 layout is the 128-column gradient dump");
-      const int s = threadIdx.x >> 5, hw = (threadIdx.x >> 4) & 1, sp = threadIdx.x & 15;
+      static_assert(BLK != 2 || NB == 4 || NB == 5, "the fp16 layouts are the 128-column dumps (+ a block for the ones column) and the 160-column x dump");
+      const int hw = (threadIdx.x >> 4) & 1, sp = threadIdx.x & 15, steps_mem = cx >> 4;
       const int64_t r0 = row0 + 2 * sp;
-      const u32x4* p = (const u32x4*)X + ((row0 >> 5) * 8 + s) * 64 + hw * 32 + 2 * sp;
       const u32x4 z = u32x4{0u, 0u, 0u, 0u};
-      v0[0] = __builtin_bit_cast(f32x4, r0 < M ? p[0] : z);
-      v1[0] = __builtin_bit_cast(f32x4, r0 + 1 < M ? p[1] : z);
-      s0 = r0 < M ? scale[r0] : 0.f;
-      s1 = r0 + 1 < M ? scale[r0 + 1] : 0.f;
+#pragma unroll
+      for (int it = 0; it < ITEMS; ++it) {
+        const int s = (threadIdx.x >> 5) + 8 * it;
+        const u32x4* p = (const u32x4*)X + ((row0 >> 5) * steps_mem + (s < steps_mem ? s : 0)) * 64 + hw * 32 + 2 * sp;
+        v0[it] = __builtin_bit_cast(f32x4, (r0 < M && s < steps_mem) ? p[0] : z);
+        v1[it] = __builtin_bit_cast(f32x4, (r0 + 1 < M && s < steps_mem) ? p[1] : z);
+      }
+      s0 = r0 < M ? (scale ? scale[r0] : 1.f) : 0.f;
+      s1 = r0 + 1 < M ? (scale ? scale[r0 + 1] : 1.f) : 0.f;
       return;
     }
 #pragma unroll
@@ -113,15 +119,23 @@ struct Tile {
     constexpr int COLS = NB * 32;
     if (BLK == 2) {
       typedef _Float16 h8v __attribute__((ext_vector_type(8)));
-      const int s = threadIdx.x >> 5, hw = (threadIdx.x >> 4) & 1, sp = threadIdx.x & 15;
-      const h8v a8 = __builtin_bit_cast(h8v, v0[0]), b8 = __builtin_bit_cast(h8v, v1[0]);
+      const int hw = (threadIdx.x >> 4) & 1, sp = threadIdx.x & 15;
+      const int64_t r0 = row0 + 2 * sp;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const int col = (2 * s + (e >> 2)) * 8 + hw * 4 + (e & 3);
-        uint32_t hi, lo;  // half * power of two is exact in fp32; its 11 significant bits split into 8 (hi) + 3 (lo) exactly
-        split_bf16_pair(__fmul_rn((float)a8[e], s0), __fmul_rn((float)b8[e], s1), hi, lo);
-        *(uint32_t*)(lds + col * WG_ROW + sp * 4) = hi;
-        *(uint32_t*)(lds + (COLS + col) * WG_ROW + sp * 4) = lo;
+      for (int it = 0; it < ITEMS; ++it) {
+        const int s = (threadIdx.x >> 5) + 8 * it;
+        if (s >= 2 * NB) break;   // k-steps of the tile (memory holds the first cx / 16 of them, fetch left the others zero)
+        const h8v a8 = __builtin_bit_cast(h8v, v0[it]), b8 = __builtin_bit_cast(h8v, v1[it]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int col = (2 * s + (e >> 2)) * 8 + hw * 4 + (e & 3);
+          float a = __fmul_rn((float)a8[e], s0), b = __fmul_rn((float)b8[e], s1);
+          if (col == ones_col) { a = r0 < M ? 1.f : 0.f; b = r0 + 1 < M ? 1.f : 0.f; }
+          uint32_t hi, lo;  // half * power of two is exact in fp32; its 11 significant bits split into 8 (hi) + 3 (lo) exactly
+          split_bf16_pair(a, b, hi, lo);
+          *(uint32_t*)(lds + col * WG_ROW + sp * 4) = hi;
+          *(uint32_t*)(lds + (COLS + col) * WG_ROW + sp * 4) = lo;
+        }
       }
       return;
     }
@@ -154,7 +168,7 @@ __device__ __forceinline__ bf8 frag(const uint8_t* row, int ks, int kb) {
 
 // 2-3 workgroups per CU hide the row fetches of one behind the multiplies of the others: cap the registers (left alone the
 // compiler takes 272 for the 4 x 5 shape, i.e. one workgroup per CU)
-template <int CAB, int CBB, bool AVEC, int ABLK, bool BBLK>
+template <int CAB, int CBB, bool AVEC, int ABLK, int BBLK>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CAB * CBB >= 20 ? 2 : 3, CAB * CBB >= 20 ? 2 : 3))) void k_wgrad(WgradArgs P) {
   __shared__ __attribute__((aligned(16))) uint8_t lds[(CAB + CBB) * 32 * 2 * WG_ROW];
   uint8_t* la = lds;
@@ -171,7 +185,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CAB * CBB >
     for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
   const int64_t step0 = (int64_t)blockIdx.x * P.steps_per_wg;
   Tile<CAB, AVEC, ABLK> ta;
-  Tile<CBB, true, BBLK ? 1 : 0> tb;
+  Tile<CBB, true, BBLK> tb;
   ta.fetch(P.A, P.a_scale, P.lda, P.ca, step0 * 32, P.M);
   tb.fetch(P.B, nullptr, P.ldb, P.cb, step0 * 32, P.M);
   for (int st = 0; st < P.steps_per_wg; ++st) {
@@ -219,7 +233,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CAB * CBB >
   }
 }
 
-template <int CAB, int CBB, bool AVEC, int ABLK, bool BBLK>
+template <int CAB, int CBB, bool AVEC, int ABLK, int BBLK>
 int launch(const WgradArgs& a, hipStream_t st) {
   WgradArgs p = a;
   const int64_t steps = (a.M + 31) / 32;
@@ -233,9 +247,11 @@ int launch(const WgradArgs& a, hipStream_t st) {
 
 extern "C" {
 
-int ego_weight_grad(const void* A, int32_t lda, int32_t ca, int32_t a_layout, const float* a_scale, const float* B, int32_t ldb, int32_t cb,
-                    int32_t b_blocked, int32_t ones_col, int64_t M, float* G, int32_t ldg, void* stream) {
+int ego_weight_grad(const void* A, int32_t lda, int32_t ca, int32_t a_layout, const float* a_scale, const void* B, int32_t ldb, int32_t cb,
+                    int32_t b_layout, int32_t ones_col, int64_t M, float* G, int32_t ldg, void* stream) {
   EGO_REQUIRE(a_layout >= 0 && a_layout <= 3, "weight_grad: a_layout must be 0 (row-major), 1 (blocked fp32), 2 (blocked scaled fp16) or 3 (grid-routed)");
+  EGO_REQUIRE(b_layout >= 0 && b_layout <= 2, "weight_grad: b_layout must be 0 (row-major), 1 (blocked fp32) or 2 (blocked fp16)");
+  EGO_REQUIRE(b_layout != 2 || ((cb & 15) == 0 && ldb == cb), "weight_grad: the fp16 B layout holds whole k-steps (cb a multiple of 16, ldb = cb)");
   EGO_REQUIRE(M >= 0 && ca >= 1 && ca <= 128 && cb >= 1 && cb <= 160 && (lda >= ca || a_layout == 3) && ldb >= cb && ones_col < 160,
               "weight_grad: bad size (ca <= 128, cb <= 160)");
   if (M == 0) return EGO_OK;
@@ -249,25 +265,28 @@ int ego_weight_grad(const void* A, int32_t lda, int32_t ca, int32_t a_layout, co
   EGO_REQUIRE(ldg >= 32 * cbb, "weight_grad: ldg must cover the padded column blocks");
   EGO_REQUIRE((ldb & 3) == 0 && (cb & 3) == 0 && ((uintptr_t)B & 15) == 0, "weight_grad: B rows must be 16-byte aligned, cb a multiple of 4");
   const bool avec = (lda & 3) == 0 && (ca & 3) == 0 && ((uintptr_t)A & 15) == 0;
-  WgradArgs a{(const float*)A, a_scale, B, G, M, lda, ca, ldb, cb, ones_col, ldg, 0};
+  WgradArgs a{(const float*)A, a_scale, (const float*)B, G, M, lda, ca, ldb, cb, ones_col, ldg, 0};
   const hipStream_t st = (hipStream_t)stream;
-  // instantiations: the training step's four products (dh2^T h1, dh1^T x: scaled-fp16 A, blocked B; do^T h2: ragged row-major
-  // A, blocked B; dfe^T v: grid-routed A, blocked B), their all-fp32 forms and the all-row-major forms of the same shapes
-  const int key = (cab * 8 + cbb) * 8 + a_layout * 2 + (b_blocked ? 1 : 0);
+  // instantiations: the training step's four products, their all-fp32 forms and the all-row-major forms of the same shapes
+  // (the training step's four products: dh2^T h1, dh1^T x: scaled-fp16 A, fp16 B; do^T h2: ragged row-major A, fp16 B; dfe^T v: grid-routed A,
+  // blocked fp32 B)
+  const int key = (cab * 8 + cbb) * 16 + a_layout * 4 + b_layout;
   switch (key) {
-    case (1 * 8 + 5) * 8 + 0: return avec ? launch<1, 5, true, 0, false>(a, st) : launch<1, 5, false, 0, false>(a, st);
-    case (1 * 8 + 5) * 8 + 1: return avec ? launch<1, 5, true, 0, true>(a, st) : launch<1, 5, false, 0, true>(a, st);
-    case (2 * 8 + 5) * 8 + 0: if (avec) return launch<2, 5, true, 0, false>(a, st); break;
-    case (2 * 8 + 5) * 8 + 1: if (avec) return launch<2, 5, true, 0, true>(a, st); break;
-    case (2 * 8 + 5) * 8 + 7: return launch<2, 5, true, 3, true>(a, st);
-    case (4 * 8 + 5) * 8 + 0: if (avec) return launch<4, 5, true, 0, false>(a, st); break;
-    case (4 * 8 + 5) * 8 + 3: if (avec) return launch<4, 5, true, 1, true>(a, st); break;
-    case (4 * 8 + 5) * 8 + 5: return launch<4, 5, true, 2, true>(a, st);
-    case (4 * 8 + 4) * 8 + 0: if (avec) return launch<4, 4, true, 0, false>(a, st); break;
+    case (1 * 8 + 5) * 16 + 0: return avec ? launch<1, 5, true, 0, 0>(a, st) : launch<1, 5, false, 0, 0>(a, st);
+    case (1 * 8 + 5) * 16 + 1: return avec ? launch<1, 5, true, 0, 1>(a, st) : launch<1, 5, false, 0, 1>(a, st);
+    case (1 * 8 + 5) * 16 + 2: return avec ? launch<1, 5, true, 0, 2>(a, st) : launch<1, 5, false, 0, 2>(a, st);
+    case (2 * 8 + 5) * 16 + 0: if (avec) return launch<2, 5, true, 0, 0>(a, st); break;
+    case (2 * 8 + 5) * 16 + 1: if (avec) return launch<2, 5, true, 0, 1>(a, st); break;
+    case (2 * 8 + 5) * 16 + 13: return launch<2, 5, true, 3, 1>(a, st);
+    case (4 * 8 + 5) * 16 + 0: if (avec) return launch<4, 5, true, 0, 0>(a, st); break;
+    case (4 * 8 + 5) * 16 + 5: if (avec) return launch<4, 5, true, 1, 1>(a, st); break;
+    case (4 * 8 + 5) * 16 + 9: return launch<4, 5, true, 2, 1>(a, st);
+    case (4 * 8 + 5) * 16 + 10: return launch<4, 5, true, 2, 2>(a, st);
+    case (4 * 8 + 4) * 16 + 0: if (avec) return launch<4, 4, true, 0, 0>(a, st); break;
     default: break;
   }
-  return ego_fail(EGO_E_UNSUPPORTED, "weight_grad: no instantiation for %d x %d column blocks%s (A layout %d, blocked B %d)", cab, cbb,
-                  avec ? "" : " with unaligned A rows", a_layout, b_blocked);
+  return ego_fail(EGO_E_UNSUPPORTED, "weight_grad: no instantiation for %d x %d column blocks%s (A layout %d, B layout %d)", cab, cbb,
+                  avec ? "" : " with unaligned A rows", a_layout, b_layout);
 }
 
 }  // extern "C"

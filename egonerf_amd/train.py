@@ -203,10 +203,11 @@ class RenderFunction(torch.autograd.Function):
         rgb = f(N, S, 3)
         head_tuned = head_is_tuned(model)
         if head_tuned:
-            Mp = (M + 31) // 32 * 32  # the dumps are tile-blocked ([tile][quad pair][lane][4], csrc/ego_shade.hip dump_off): whole tiles
-            dump = dict(x=f(Mp, 160), h1=f(Mp, 128), h2=f(Mp, 128), v=f(Mp, 144),
-                        relu_bits=torch.empty(Mp // 32, 2, 64, 2, device=dev, dtype=torch.int32))
-            ds = _lib.ShadeDump(*(dump[k].data_ptr() for k in ("x", "h1", "h2", "v", "relu_bits")))
+            Mp = (M + 31) // 32 * 32  # the dumps are tile-blocked (include/egonerf_hip.h, ego_shade_dump): whole tiles
+            f16 = lambda *shape: torch.empty(*shape, device=dev, dtype=torch.float16)   # x / h1 / h2: halves in the kernels' operand order
+            dump = dict(x=f16(Mp, 160), h1=f16(Mp, 128), h2=f16(Mp, 128), v=f(Mp, 144),
+                        relu_bits=torch.empty(Mp // 32, 2, 64, 2, device=dev, dtype=torch.int32), fe=f(Mp // 32, 4, 64, 4))
+            ds = _lib.ShadeDump(*(dump[k].data_ptr() for k in ("x", "h1", "h2", "v", "relu_bits", "fe")))
             _chk(lib.ego_shade(sc, rays.data_ptr(), z.data_ptr(), coords.data_ptr(), N, S, rgb.data_ptr(), C.byref(ds), None, st), "ego_shade")
         else:
             # any other model shape (opt.py:87-100): fp32 compatibility kernels over row-major dumps, padded to whole 160-column
@@ -298,7 +299,7 @@ class RenderFunction(torch.autograd.Function):
         # dh2 / dh1: scaled fp16 in the kernel's own operand order + one power of two per sample (include/egonerf_hip.h); dv: blocked fp32
         half = lambda *shape: torch.empty(*shape, device=dev, dtype=torch.float16)
         dh2, dh1, dh_scale, dfe, dv = half(Mp, 128), half(Mp, 128), f(2, Mp), f(M, 32), f(Mp, 144)
-        ds = _lib.ShadeDump(*(sv[k].data_ptr() for k in ("x", "h1", "h2", "v", "relu_bits")))
+        ds = _lib.ShadeDump(*(sv[k].data_ptr() for k in ("x", "h1", "h2", "v", "relu_bits", "fe")))
         _chk(lib.ego_shade_backward(sc, tp.data_ptr(), sv["coords"].data_ptr(), dc.data_ptr(), sv["rgb"].data_ptr(), C.byref(ds),
                                           dh2.data_ptr(), dh1.data_ptr(), dh_scale.data_ptr(), dfe.data_ptr(), dv.data_ptr(), N, S, st),
              "ego_shade_backward")
@@ -315,7 +316,8 @@ class RenderFunction(torch.autograd.Function):
 
         def wgrad(which, A, ca, a_layout, B, cb, ones_col, a_scale=None):
             G = Gall[_G_ROWS[which][0]:_G_ROWS[which][1]]
-            _chk(lib.ego_weight_grad(A.data_ptr(), A.shape[1], ca, a_layout, _lib.ptr(a_scale), B.data_ptr(), B.shape[1], cb, 1, ones_col, M,
+            b_layout = 2 if B.dtype == torch.float16 else 1
+            _chk(lib.ego_weight_grad(A.data_ptr(), A.shape[1], ca, a_layout, _lib.ptr(a_scale), B.data_ptr(), B.shape[1], cb, b_layout, ones_col, M,
                                            G.data_ptr(), _G_LD, st), "ego_weight_grad")
 
         wgrad("G3", do, 3, 0, sv["h2"], 128, 128)

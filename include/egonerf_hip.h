@@ -230,17 +230,25 @@ int ego_march_density(const ego_scene* sc, const float* rays, int64_t N, int32_t
 /* Per-sample activations the training forward keeps for the backward pass (all dev).  Logical matrices x [M][160] (layer-1
  * inputs), h1, h2 [M][128] (post-ReLU hidden activations), v [M][144] (plane x line products); element kk of lane half h
  * is logical column 8 (kk / 4) + 4 h + kk % 4 (ego_train_layout() maps columns to the reference's inputs / units).  Storage
- * is tile-blocked, lane-major: [tile = m / 32][quad pair q = column / 8][lane = 32 h + m % 32][4 floats], i.e. float offset
- * tile * 32 * width + q * 256 + (32 h + m % 32) * 4 + c, so each buffer needs ceil(M / 32) * 32 rows.  ego_weight_grad reads
- * this layout directly (a_layout / b_blocked).  relu_bits [ceil(M / 32)][2 (h1, h2)][64 lanes][2] uint32 holds the ReLU masks of
+ * is tile-blocked, lane-major, whole tiles (each buffer needs ceil(M / 32) * 32 rows):
+ *   v: fp32 [tile = m / 32][quad pair q = column / 8][lane = 32 h + m % 32][4 floats] (float offset tile * 32 * width + q * 256 +
+ *      (32 h + m % 32) * 4 + c);
+ *   x, h1, h2: IEEE halves, rounded to nearest, in the MFMA operand order of the kernels themselves: [tile][k-step s][lane][8], element
+ *      e = logical column 8 (2 s + e / 4) + 4 h + e % 4 - they only feed the weight-gradient sums (sum over samples of dh * x: the
+ *      2^-12 rounding is unbiased and averages out; pinned by the gradient goldens), at half the bytes of fp32 (round 4: the training
+ *      step is bound by its dump traffic).  What the DATA gradients need of the forward stays exact: the ReLU masks (relu_bits) and
+ *      the feature slots in fp32 (fe).
+ * ego_weight_grad reads these layouts directly (a_layout / b_layout).  relu_bits [ceil(M / 32)][2 (h1, h2)][64 lanes][2] uint32 holds the ReLU masks of
  * the two hidden layers (bit 16 (t & 1) + r of word t >> 1 of lane 32 h + m % 32 <=> unit 32 t + slot_row(r, h) of sample m is
  * > 0): all the shade backward needs of h1 / h2 (autograd of torch.nn.ReLU, tensorBase.py:68-71), 32 B instead of 1 KB per sample. */
 typedef struct ego_shade_dump {
-  float* x;
-  float* h1;
-  float* h2;
+  uint16_t* x;
+  uint16_t* h1;
+  uint16_t* h2;
   float* v;
   uint32_t* relu_bits;
+  float* fe;   /* [ceil(M / 32)][4][64 lanes][4] fp32: the 16 feature slots of lane 32 h + m % 32 (basis output, slot r = feature 2 r + h);
+                * the backward re-derives the encodings' sines and cosines from them with the forward's own instructions */
 } ego_shade_dump;
 
 /* Static facts about the shade kernel that implements `precision` (EGO_PREC_*), for roofline accounting by a caller that times it
@@ -324,16 +332,17 @@ int ego_scatter_app(const ego_scene* sc, const ego_vm_grad* gapp, const float* c
 int ego_envmap_backward(const ego_scene* sc, const float* dirs, int32_t dir_stride, const float* g_rgb, const float* rgb_raw, const float* bg_weight,
                         const float* env_map, int64_t N, float* g_emission, void* stream);
 /* Weight gradients of nn.Linear layers over all samples: G [32 ceil(ca/32)][ldg] += A^T B for A (M rows, ca <= 128 columns
- * used of lda) and fp32 B (M rows, cb <= 160 of ldb), G accumulated (zero it first).  a_layout 0: row-major fp32 | 1: fp32 in the
+ * used of lda) and B (M rows, cb <= 160 of ldb), G accumulated (zero it first).  a_layout 0: row-major fp32 | 1: fp32 in the
  * shade kernels' dump layout [tile = m / 32][quad pair q][lane = 32 h + m % 32][4] with logical column 8 q + 4 h + c
  * (ceil(M / 32) * 32 rows allocated) | 2: ego_shade_backward's scaled-fp16 layout (ca = lda = 128, a_scale [M] = that matrix's
  * row of dh_scale) | 3: row-major fp32 [M][32] standing for 64 logical columns, row m filling columns [32 g, 32 g + 32) with
  * g = (a_scale[4 m + 3] != 0) (ego_shade_backward's dfe; ca = 64, lda = 32, a_scale = the forward's coords [M][4]); a_scale NULL for
- * layouts 0 / 1.  b_blocked: B in the dump layout instead of row-major.  ones_col >= 0 replaces that column
+ * layouts 0 / 1.  b_layout 0: row-major fp32 | 1: fp32 in the dump layout (ego_shade_dump.v) | 2: halves in the dump layout of
+ * ego_shade_dump's x / h1 / h2 ([tile][k-step][lane][8]; cb a multiple of 16, ldb = cb).  ones_col >= 0 replaces that column
  * of B by ones (it may lie beyond cb, < 160), which yields the bias gradient = column sums of A in G[:, ones_col].  bf16 hi/lo
  * split MFMA, ~17 significand bits per operand. */
-int ego_weight_grad(const void* A, int32_t lda, int32_t ca, int32_t a_layout, const float* a_scale, const float* B, int32_t ldb,
-                    int32_t cb, int32_t b_blocked, int32_t ones_col, int64_t M, float* G, int32_t ldg, void* stream);
+int ego_weight_grad(const void* A, int32_t lda, int32_t ca, int32_t a_layout, const float* a_scale, const void* B, int32_t ldb,
+                    int32_t cb, int32_t b_layout, int32_t ones_col, int64_t M, float* G, int32_t ldg, void* stream);
 
 /* ---- training of model shapes other than the tuned one (opt.py:87-100 lets a user choose n_lamb_sigma / n_lamb_sh, data_dim_color,
  * featureC, view_pe, fea_pe; supported shapes as for ego_packed_floats_scene).  Plain fp32 compatibility kernels over ROW-MAJOR

@@ -38,6 +38,18 @@ def _scaled_half(X):
     return P, inv, exact
 
 
+def _half_blocked(X):
+    """Row-major fp32 [M, W] (W = 128 or 160) -> the forward's x / h1 / h2 dump layout: halves [tile][k-step s][lane = 32 h + j][8]
+    (element e = logical column 8 (2 s + e / 4) + 4 h + e % 4), and the fp32 matrix those halves stand for."""
+    M, W = X.shape
+    Mp = (M + 31) // 32 * 32
+    H = X.half()
+    P = torch.full((Mp, W), float("nan"), dtype=torch.float16)   # padding rows must never be read
+    P[:M] = H
+    P = P.view(Mp // 32, 32, W // 16, 2, 2, 4).permute(0, 2, 4, 1, 3, 5).contiguous().view(Mp, W)
+    return P, H.float()
+
+
 def _run(A, ca, B, cb, ones_col, G=None, a_blocked=0, b_blocked=0, M=None, a_scale=None):
     lib, st = _lib.load(), _lib.stream_handle()
     M = A.shape[0] if M is None else M
@@ -83,6 +95,20 @@ def test_weight_grad_matches_float64(ca, lda, cb, ones_col, M):
         assert torch.isfinite(Gh).all()
         if ones_col >= 0:
             assert float((Gh[:ca, ones_col] - exact.double().sum(0)).abs().max()) <= 5e-5 * float(bias.abs().max())
+        # ... and with B as the training forward writes x / h1 / h2: halves in the same operand order (b_layout 2)
+        Bh, Bexact = _half_blocked(B)
+        Ghh = _run(Ah.to(DEV), ca, Bh.to(DEV), cb, ones_col, a_blocked=2, b_blocked=2, M=M, a_scale=inv.to(DEV)).cpu().double()
+        ref_hh = exact.double().T @ Bexact.double()
+        assert float((Ghh[:ca, cols] - ref_hh[:, cols]).abs().max()) <= 5e-5 * scale
+        assert float((Ghh[:ca, cols] - ref[:, cols]).abs().max()) <= (4e-4 if M > 1000 else 1e-3) * scale   # two operands of 2^-12 each, averaged over the rows
+        assert torch.isfinite(Ghh).all()
+        if ones_col >= 0:
+            assert float((Ghh[:ca, ones_col] - exact.double().sum(0)).abs().max()) <= 5e-5 * float(bias.abs().max())
+    if ca == 3 and cb == 128:   # d(W3) = do^T h2: ragged row-major A, halves B
+        Bh, Bexact = _half_blocked(B)
+        G3 = _run(A.to(DEV), ca, Bh.to(DEV), cb, ones_col, a_blocked=0, b_blocked=2, M=M).cpu().double()
+        assert float((G3[:ca, cols] - A[:, :ca].double().T @ Bexact.double()[:, cols]).abs().max()) <= 5e-5 * scale
+        assert float((G3[:ca, ones_col] - bias).abs().max()) <= 5e-5 * float(bias.abs().max())
 
 
 @pytest.mark.parametrize("M", [1, 33, 4097, 70001])

@@ -60,9 +60,9 @@ Mtot = N * S
 Mp = (Mtot + 31) // 32 * 32
 def shade_dump():
     rgb = f(N, S, 3)
-    d = dict(x=torch.zeros(Mp, 160, device=dev), h1=torch.zeros(Mp, 128, device=dev), h2=torch.zeros(Mp, 128, device=dev), v=torch.zeros(Mp, 144, device=dev),
-             relu_bits=torch.zeros(Mp // 32, 2, 64, 2, device=dev, dtype=torch.int32))
-    ds = _lib.ShadeDump(*(d[k].data_ptr() for k in ("x", "h1", "h2", "v", "relu_bits")))
+    d = dict(x=torch.zeros(Mp, 160, device=dev, dtype=torch.float16), h1=torch.zeros(Mp, 128, device=dev, dtype=torch.float16), h2=torch.zeros(Mp, 128, device=dev, dtype=torch.float16), v=torch.zeros(Mp, 144, device=dev),
+             relu_bits=torch.zeros(Mp // 32, 2, 64, 2, device=dev, dtype=torch.int32), fe=torch.zeros(Mp // 32, 4, 64, 4, device=dev))
+    ds = _lib.ShadeDump(*(d[k].data_ptr() for k in ("x", "h1", "h2", "v", "relu_bits", "fe")))
     _lib.check(lib.ego_shade(sc, rays.data_ptr(), z.data_ptr(), crd.data_ptr(), N, S, rgb.data_ptr(), C.byref(ds), None, st), "shade")
     return rgb, d["x"], d["h1"], d["h2"], d["v"]
 r0 = shade_dump(); bad = [0] * 5
