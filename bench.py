@@ -392,6 +392,9 @@ def run_render(a, rk: Ranks):
     crd = torch.empty(N_RAYS, N_SAMPLES, 4, device=dev)
     rgb_map, depth = torch.empty(N_RAYS, 3, device=dev), torch.empty(N_RAYS, device=dev)
     reps = max(min(a.steps, 200), 5)
+    # ego_render_forward folds the compositing into the shade kernel where it can (tuned shape, fp32 tables, split-precision arithmetic,
+    # S a multiple of 32): then the step is two launches and the shade figure below is that kernel's
+    folded = model.mlp_precision != "f32" and N_SAMPLES % 32 == 0 and not os.environ.get("EGO_RENDER_NO_FOLD")
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(reps)]
     for i in range(reps + 2):
         e = ev[max(i - 2, 0)]
@@ -399,10 +402,15 @@ def run_render(a, rk: Ranks):
         _lib.check(lib.ego_march_density(sc, rays.data_ptr(), N_RAYS, N_SAMPLES, None, sched.data_ptr(), None, cfg.near, 0,
                                          z.data_ptr(), alpha.data_ptr(), 0, w.data_ptr(), bg.data_ptr(), crd.data_ptr(), None, None, st), "march")
         e[1].record()
-        _lib.check(lib.ego_shade(sc, rays.data_ptr(), z.data_ptr(), crd.data_ptr(), N_RAYS, N_SAMPLES, rgb.data_ptr(), None, None, st), "shade")
-        e[2].record()
-        _lib.check(lib.ego_composite(sc, rays.data_ptr(), z.data_ptr(), w.data_ptr(), bg.data_ptr(), rgb.data_ptr(), N_RAYS,
-                                     N_SAMPLES, rgb_map.data_ptr(), depth.data_ptr(), None, None, None, st), "composite")
+        if folded:   # what ego_render_forward launches for this scene: shading with the compositing in its epilogue, no k_composite
+            _lib.check(lib.ego_shade_composite(sc, rays.data_ptr(), z.data_ptr(), crd.data_ptr(), w.data_ptr(), bg.data_ptr(), N_RAYS, N_SAMPLES,
+                                               None, rgb_map.data_ptr(), depth.data_ptr(), None, None, st), "shade_composite")
+            e[2].record()
+        else:
+            _lib.check(lib.ego_shade(sc, rays.data_ptr(), z.data_ptr(), crd.data_ptr(), N_RAYS, N_SAMPLES, rgb.data_ptr(), None, None, st), "shade")
+            e[2].record()
+            _lib.check(lib.ego_composite(sc, rays.data_ptr(), z.data_ptr(), w.data_ptr(), bg.data_ptr(), rgb.data_ptr(), N_RAYS,
+                                         N_SAMPLES, rgb_map.data_ptr(), depth.data_ptr(), None, None, None, st), "composite")
         e[3].record()
     torch.cuda.synchronize()
     ms = np.array([[e[k].elapsed_time(e[k + 1]) for k in range(3)] for e in ev]).mean(0)
@@ -422,6 +430,7 @@ def run_render(a, rk: Ranks):
     # the per-kernel timings above shade every tile): how much of THIS synthetic batch it skips
     zero_tiles = float((w.view(-1, 32).max(dim=1).values == 0).float().mean()) if M % 32 == 0 else None
     roofline.update(other_kernels_ms=dict(k_march_density=t_march * 1e3, k_composite=t_comp * 1e3),
+                    compositing_folded_into_shade=folded,
                     exact_zero_weight_tile_skip=dict(enabled=os.environ.get("EGO_EXACT_SKIP", "1") != "0", tiles_skipped_frac=zero_tiles,
                                                      note="bit-identical outputs (the reference adds w * rgb = 0 for those samples); the synthetic "
                                                           "field is semi-transparent, so almost nothing is skipped here"),
@@ -469,7 +478,11 @@ def run_render(a, rk: Ranks):
         model.mlp_precision = prec
         model.app_table_dtype = "f16" if app16 else "f32"
         sc2 = model.scene()
-        shade = lambda: _lib.check(lib.ego_shade(sc2, rays.data_ptr(), z.data_ptr(), crd.data_ptr(), N_RAYS, N_SAMPLES, rgb.data_ptr(), None, None, st), "shade")
+        if folded and not app16 and prec != "f32":
+            shade = lambda: _lib.check(lib.ego_shade_composite(sc2, rays.data_ptr(), z.data_ptr(), crd.data_ptr(), w.data_ptr(), bg.data_ptr(), N_RAYS, N_SAMPLES,
+                                                               None, rgb_map.data_ptr(), depth.data_ptr(), None, None, st), "shade_composite")
+        else:
+            shade = lambda: _lib.check(lib.ego_shade(sc2, rays.data_ptr(), z.data_ptr(), crd.data_ptr(), N_RAYS, N_SAMPLES, rgb.data_ptr(), None, None, st), "shade")
         t_end = time.perf_counter() + 0.1   # untimed ramp, as for the headline: the host-side work above let the clocks drop
         while time.perf_counter() < t_end:
             for _ in range(8):
@@ -603,6 +616,9 @@ def run_render_variant(a, rk: Ranks):
     crd = torch.empty(N_RAYS, N_SAMPLES, 4, device=dev)
     rgb_map, depth = torch.empty(N_RAYS, 3, device=dev), torch.empty(N_RAYS, device=dev)
     reps = max(min(a.steps, 128), B, 8)
+    # ego_render_forward folds the compositing into the shade kernel where it can (tuned shape, fp32 tables, split-precision arithmetic,
+    # S a multiple of 32): then the step is two launches and the shade figure below is that kernel's
+    folded = model.mlp_precision != "f32" and N_SAMPLES % 32 == 0 and not os.environ.get("EGO_RENDER_NO_FOLD")
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(reps)]
     for i in range(reps + 2):
         e, rays = ev[max(i - 2, 0)], batches[i % B]
@@ -610,10 +626,15 @@ def run_render_variant(a, rk: Ranks):
         _lib.check(lib.ego_march_density(sc, rays.data_ptr(), N_RAYS, N_SAMPLES, None, sched.data_ptr(), None, cfg.near, 0,
                                          z.data_ptr(), None, 0, w.data_ptr(), bg.data_ptr(), crd.data_ptr(), None, None, st), "march")
         e[1].record()
-        _lib.check(lib.ego_shade(sc, rays.data_ptr(), z.data_ptr(), crd.data_ptr(), N_RAYS, N_SAMPLES, rgb.data_ptr(), None, None, st), "shade")
-        e[2].record()
-        _lib.check(lib.ego_composite(sc, rays.data_ptr(), z.data_ptr(), w.data_ptr(), bg.data_ptr(), rgb.data_ptr(), N_RAYS,
-                                     N_SAMPLES, rgb_map.data_ptr(), depth.data_ptr(), None, None, None, st), "composite")
+        if folded:   # what ego_render_forward launches for this scene: shading with the compositing in its epilogue, no k_composite
+            _lib.check(lib.ego_shade_composite(sc, rays.data_ptr(), z.data_ptr(), crd.data_ptr(), w.data_ptr(), bg.data_ptr(), N_RAYS, N_SAMPLES,
+                                               None, rgb_map.data_ptr(), depth.data_ptr(), None, None, st), "shade_composite")
+            e[2].record()
+        else:
+            _lib.check(lib.ego_shade(sc, rays.data_ptr(), z.data_ptr(), crd.data_ptr(), N_RAYS, N_SAMPLES, rgb.data_ptr(), None, None, st), "shade")
+            e[2].record()
+            _lib.check(lib.ego_composite(sc, rays.data_ptr(), z.data_ptr(), w.data_ptr(), bg.data_ptr(), rgb.data_ptr(), N_RAYS,
+                                         N_SAMPLES, rgb_map.data_ptr(), depth.data_ptr(), None, None, None, st), "composite")
         e[3].record()
     torch.cuda.synchronize()
     ms = np.array([[e[k].elapsed_time(e[k + 1]) for k in range(3)] for e in ev]).mean(0)

@@ -17,7 +17,7 @@ out_path = next((a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--out
 tag = argv[0] if len(argv) > 0 else "v1"
 rnd = argv[1] if len(argv) > 1 else "r02"
 src = os.path.join(root, "gpurun_out", f"prof_{tag}")
-names = {"k_shade_h<SHADE>": "%k_shade_h<0, false, false, 0>%", "k_shade_h<SHADE,f16f8>": "%k_shade_h<0, false, false, 1>%", "k_shade_h<SHADE,f16f6>": "%k_shade_h<0, false, false, 2>%",
+names = {"k_shade_h<SHADE>": "%k_shade_h<0, false, false, 0, %", "k_shade_h<SHADE,f16f8>": "%k_shade_h<0, false, false, 1, %", "k_shade_h<SHADE,f16f6>": "%k_shade_h<0, false, false, 2, %",
          "k_shade<SHADE>": "%k_shade<0%", "k_march_density<16>": "%k_march_density%",
          "k_composite": "%k_composite%"}
 keys = {"FETCH_SIZE": "FETCH_SIZE_KB", "WRITE_SIZE": "WRITE_SIZE_KB", "TCC_HIT_sum": "TCC_HIT", "TCC_MISS_sum": "TCC_MISS",
