@@ -233,6 +233,134 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CAB * CBB >
   }
 }
 
+// ---- both operands as halves (the training step's two large products: d(W2) = dh2^T h1, d(W1) = dh1^T x) ------------------------------
+// A = ego_shade_backward's dh (fp16 payload x one power of two per sample), B = the forward's h1 / x dump (halves).  A product of two
+// halves is exact in fp32, so ONE v_mfma_f32_32x32x16_f16 does what the bf16 hi/lo form needs three instructions and a split of both
+// operands for (~240 VALU instructions per thread and 32-row step: those passes were bound by their commit -> barrier -> MFMA -> barrier
+// chain, 11 k clocks per step against 1 k of matrix work, not by bytes).  The per-sample scale runs along K, so it cannot be applied
+// to the accumulator; within a step (32 samples = one tile) the largest scale `ref` is taken out instead: B's row m is multiplied by
+// inv_m / ref <= 1 (a power of two: exact in fp16 down to 2^-14, gradually flushed below - a sample whose gradient is 2^-14 of its
+// tile's largest contributes that little), the step's product lands in a scratch accumulator and acc += ref * scratch.
+typedef _Float16 h8w __attribute__((ext_vector_type(8)));
+typedef _Float16 h2w __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ h8w frag_h(const uint8_t* row, int ks, int kb) {
+  const u32x2* p = (const u32x2*)(row + ks * 32 + kb * 16);
+  const u32x2 a = p[0], b = p[1];
+  return __builtin_bit_cast(h8w, u32x4{a.x, a.y, b.x, b.y});
+}
+
+struct HTile {   // one operand's rows [row0, row0 + 32): up to two (k-step, lane half, sample pair) items per thread
+  u32x4 v0[2], v1[2];
+  __device__ __forceinline__ void fetch(const void* __restrict__ X, int steps_mem, int items, int64_t row0, int64_t M) {
+    const int hw = (threadIdx.x >> 4) & 1, sp = threadIdx.x & 15;
+    const int64_t r0 = row0 + 2 * sp;
+    const u32x4 z = u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      if (it >= items) break;
+      const int s = (threadIdx.x >> 5) + 8 * it;
+      const u32x4* p = (const u32x4*)X + ((row0 >> 5) * steps_mem + (s < steps_mem ? s : 0)) * 64 + hw * 32 + 2 * sp;
+      v0[it] = (r0 < M && s < steps_mem) ? p[0] : z;
+      v1[it] = (r0 + 1 < M && s < steps_mem) ? p[1] : z;
+    }
+  }
+  // [column][32 samples] halves; ratio2 = the two samples' inv / ref as packed halves (B only), ones_col as in the bf16 form
+  template <bool IS_B>
+  __device__ __forceinline__ void commit(int steps, int items, int ones_col, uint32_t ratio2, uint8_t* __restrict__ lds) const {
+    const int hw = (threadIdx.x >> 4) & 1, sp = threadIdx.x & 15;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      if (it >= items) break;
+      const int s = (threadIdx.x >> 5) + 8 * it;
+      if (s >= steps) break;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int col = (2 * s + (e >> 2)) * 8 + hw * 4 + (e & 3);
+        const uint32_t a = v0[it][e >> 1], b = v1[it][e >> 1];
+        uint32_t word = (e & 1) ? ((a >> 16) | (b & 0xffff0000u)) : ((a & 0xffffu) | (b << 16));   // (sample 2 sp, sample 2 sp + 1)
+        if (IS_B) {
+          if (col == ones_col) word = 0x3c003c00u;   // (1.0, 1.0)
+          word = __builtin_bit_cast(uint32_t, __builtin_bit_cast(h2w, word) * __builtin_bit_cast(h2w, ratio2));
+        }
+        *(uint32_t*)(lds + col * WG_ROW + sp * 4) = word;
+      }
+    }
+  }
+};
+
+template <int CBB>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_wgrad_h(WgradArgs P) {
+  __shared__ __attribute__((aligned(16))) uint8_t lds[(4 + CBB) * 32 * WG_ROW];
+  uint8_t* la = lds;
+  uint8_t* lb = lds + 4 * 32 * WG_ROW;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 31, kb = lane >> 5;
+  f32x16 acc[CBB];
+#pragma unroll
+  for (int k = 0; k < CBB; ++k)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
+  const int64_t step0 = (int64_t)blockIdx.x * P.steps_per_wg;
+  const int steps_b = P.cb >> 4;   // k-steps of B in memory; the tile's further steps (ones / padding columns) are fetched as zeros
+  HTile ta, tb;
+  float inv0, inv1;   // the thread's two samples' scales (rows row0 + 2 sp, + 1)
+  auto fetch = [&](int64_t row0) {
+    ta.fetch(P.A, 8, 1, row0, P.M);
+    tb.fetch(P.B, steps_b, 2, row0, P.M);
+    const int64_t r0 = row0 + 2 * (threadIdx.x & 15);
+    inv0 = r0 < P.M ? P.a_scale[r0] : 0.f;
+    inv1 = r0 + 1 < P.M ? P.a_scale[r0 + 1] : 0.f;
+  };
+  fetch(step0 * 32);
+  for (int st = 0; st < P.steps_per_wg; ++st) {
+    const int64_t row0 = (step0 + st) * 32;
+    if (row0 >= P.M) break;  // uniform over the workgroup
+    // the step's largest scale: 16 consecutive lanes hold the 32 rows
+    float ref = fmaxf(inv0, inv1);
+#pragma unroll
+    for (int sh = 1; sh < 16; sh <<= 1) ref = fmaxf(ref, __shfl_xor(ref, sh, 16));
+    const float rinv = ref > 0.f ? 1.f / ref : 0.f;   // powers of two: exact
+    const h2w ratio = h2w{(_Float16)(inv0 * rinv), (_Float16)(inv1 * rinv)};
+    ta.commit<false>(8, 1, -1, 0u, la);
+    tb.commit<true>(2 * CBB, 2, P.ones_col, __builtin_bit_cast(uint32_t, ratio), lb);
+    __syncthreads();
+    if (st + 1 < P.steps_per_wg) fetch(row0 + 32);   // next step's rows travel while this step multiplies
+    const uint8_t* ra = la + (32 * wave + i) * WG_ROW;
+    const h8w a0 = frag_h(ra, 0, kb), a1 = frag_h(ra, 1, kb);
+#pragma unroll
+    for (int nt = 0; nt < CBB; ++nt) {
+      const uint8_t* rb = lb + (32 * nt + i) * WG_ROW;
+      f32x16 t;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) t[r] = 0.f;
+      t = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, frag_h(rb, 0, kb), t, 0, 0, 0);
+      t = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, frag_h(rb, 1, kb), t, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[nt][r] = fmaf(ref, t[r], acc[nt][r]);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int nt = 0; nt < CBB; ++nt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * kb, col = 32 * nt + i;
+      const float v = acc[nt][r];
+      if (v != 0.f) unsafeAtomicAdd(P.G + (int64_t)row * P.ldg + col, v);
+    }
+}
+
+template <int CBB>
+int launch_h(const WgradArgs& a, hipStream_t st) {
+  WgradArgs p = a;
+  const int64_t steps = (a.M + 31) / 32;
+  const int64_t wgs = steps < 1024 ? steps : 1024;
+  p.steps_per_wg = (int32_t)((steps + wgs - 1) / wgs);
+  k_wgrad_h<CBB><<<(unsigned)((steps + p.steps_per_wg - 1) / p.steps_per_wg), 256, 0, st>>>(p);
+  return ego_launch_status("k_wgrad_h");
+}
+
 template <int CAB, int CBB, bool AVEC, int ABLK, int BBLK>
 int launch(const WgradArgs& a, hipStream_t st) {
   WgradArgs p = a;
@@ -281,7 +409,7 @@ int ego_weight_grad(const void* A, int32_t lda, int32_t ca, int32_t a_layout, co
     case (4 * 8 + 5) * 16 + 0: if (avec) return launch<4, 5, true, 0, 0>(a, st); break;
     case (4 * 8 + 5) * 16 + 5: if (avec) return launch<4, 5, true, 1, 1>(a, st); break;
     case (4 * 8 + 5) * 16 + 9: return launch<4, 5, true, 2, 1>(a, st);
-    case (4 * 8 + 5) * 16 + 10: return launch<4, 5, true, 2, 2>(a, st);
+    case (4 * 8 + 5) * 16 + 10: return getenv("EGO_WGRAD_BF16") ? launch<4, 5, true, 2, 2>(a, st) : launch_h<5>(a, st);   // both operands halves: the fp16 MFMA form
     case (4 * 8 + 4) * 16 + 0: if (avec) return launch<4, 4, true, 0, 0>(a, st); break;
     default: break;
   }
