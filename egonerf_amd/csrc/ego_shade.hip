@@ -1107,6 +1107,8 @@ __device__ __forceinline__ void team_to_halves(const float ga[12], const float g
   }
 }
 
+// (v as halves - 0.6 GB less per step each way, forward -0.12 ms - puts the basis gradient of the 1.5 k-sample golden at 2.3e-4 of its
+// largest element against the 2e-4 it is held to: v stays fp32)
 __device__ __forceinline__ void dump24(float* dst, const float* v) {
   if (dst) {
 #pragma unroll

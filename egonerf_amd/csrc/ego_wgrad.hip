@@ -406,6 +406,7 @@ int ego_weight_grad(const void* A, int32_t lda, int32_t ca, int32_t a_layout, co
     case (2 * 8 + 5) * 16 + 0: if (avec) return launch<2, 5, true, 0, 0>(a, st); break;
     case (2 * 8 + 5) * 16 + 1: if (avec) return launch<2, 5, true, 0, 1>(a, st); break;
     case (2 * 8 + 5) * 16 + 13: return launch<2, 5, true, 3, 1>(a, st);
+    case (2 * 8 + 5) * 16 + 14: return launch<2, 5, true, 3, 2>(a, st);
     case (4 * 8 + 5) * 16 + 0: if (avec) return launch<4, 5, true, 0, 0>(a, st); break;
     case (4 * 8 + 5) * 16 + 5: if (avec) return launch<4, 5, true, 1, 1>(a, st); break;
     case (4 * 8 + 5) * 16 + 9: return launch<4, 5, true, 2, 1>(a, st);

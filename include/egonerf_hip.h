@@ -316,7 +316,7 @@ int ego_march_backward(const ego_scene* sc, const float* z, const float* alpha, 
  * [2][ceil(M / 32) * 32] per-sample powers of two (row 0: dh2, row 1: dh1) chosen so that a sample's largest magnitude lies in
  * [2^12, 2^13): 11 significant bits, rounded to nearest, half the bytes of fp32 (ego_weight_grad's a_layout 2 reads it).  dv is
  * [tile][plane * 3 + line][sample][16 channels] fp32 (it feeds single table texels, where fp16 rounding would show); all three
- * need ceil(M / 32) * 32 rows.  Reads fwd->x and fwd->relu_bits only. */
+ * need ceil(M / 32) * 32 rows.  Reads fwd->fe and fwd->relu_bits only. */
 int ego_shade_backward(const ego_scene* sc, const float* train_packed, const float* coords, float* dc, const float* rgb,
                        const ego_shade_dump* fwd, uint16_t* dh2, uint16_t* dh1, float* dh_scale, float* dfe, float* dv, int64_t N,
                        int32_t S, void* stream);
