@@ -344,7 +344,7 @@ __device__ inline float mlp_weight_k(const float* __restrict__ w1, const float* 
   return w2[(mt * 32 + (lane & 31)) * HID + (k >> 4) * 32 + slot_row(k & 15, lane >> 5)];
 }
 
-// one thread per 32-bit slot of the hi parts / per (layer, group, m-tile, lane) of the fp6 blocks
+// the fp16 hi fragments of both layers: one thread per 32-bit slot
 __global__ void k_pack_mlp_f6(const float* __restrict__ w1, const float* __restrict__ w2, float* __restrict__ out) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   uint32_t* o = (uint32_t*)out;
@@ -363,46 +363,49 @@ __global__ void k_pack_mlp_f6(const float* __restrict__ w1, const float* __restr
     typedef _Float16 h2v __attribute__((ext_vector_type(2)));
     h2v v = {pr[0], pr[1]};
     o[(l2 ? F6I_HI2 : F6I_HI1) + e0] = __builtin_bit_cast(uint32_t, v);
-    return;
   }
-  const int t = idx - n_hi;
-  if (t >= (G6_1 + G6_2) * 4 * 64) return;
-  const int lane = t & 63, mt = (t >> 6) & 3, gg = t >> 8;
+}
+
+// the fp6 operands: one 32-lane group per (layer / group, m-tile, lane, term), lane e = element e (the one-thread-per-operand form took
+// 29 us - two dependent chains of 32 scattered weight reads per thread - on every training iteration, whose weights change every step)
+__global__ void k_pack_mlp_f6_frag(const float* __restrict__ w1, const float* __restrict__ w2, float* __restrict__ out) {
+  uint32_t* o = (uint32_t*)out;
+  const int item = blockIdx.x * (blockDim.x >> 5) + (threadIdx.x >> 5), e = threadIdx.x & 31;
+  if (item >= (G6_1 + G6_2) * 4 * 64 * 2) return;
+  const int term = item & 1, lane = (item >> 1) & 63, mt = (item >> 7) & 3, gg = item >> 9;
   const bool l2 = gg >= G6_1;
   const int grp = l2 ? gg - G6_1 : gg;
-  uint8_t* scales = (uint8_t*)(o + F6I_SC + gg * 128);   // [lane][term][mt]
-  for (int term = 0; term < 2; ++term) {
-    float v[32];
-    float amax = 0.f;
-    for (int e = 0; e < 32; ++e) {
-      const int k = f6_value(l2, grp, term, e);
-      float w = 0.f;
-      if (k >= 0) {
-        _Float16 hi, lo;
-        const float wf = mlp_weight_k(w1, w2, l2, k, lane, mt);
-        split_weight(wf, hi, lo);
-        w = term == 0 ? wf - (float)hi : (float)hi;   // term 0 carries the exact fp32 residual of the weight, term 1 a copy of its fp16 part
-      }
-      v[e] = w;
-      amax = fmaxf(amax, fabsf(w));
-    }
-    int E = amax > 0.f ? ilogbf(amax) : -100;
-    if (E < -100) E = -100;
-    if (ldexpf(amax, 2 - E) > 7.75f) E += 1;          // the largest element would saturate: one binade up
-    const float inv = ldexpf(1.0f, 2 - E);            // 1 / block scale, block scale = 2^(E - 2)
-    uint32_t wd[6] = {0, 0, 0, 0, 0, 0};
-    for (int e = 0; e < 32; ++e) {
-      const uint32_t c = e2m3_code(v[e] * inv);
-      const int bit = 6 * e, wi = bit >> 5, sh = bit & 31;
-      wd[wi] |= c << sh;
-      if (sh > 26) wd[wi + 1] |= c >> (32 - sh);
-    }
-    uint32_t* q = o + (l2 ? F6I_Q2 : F6I_Q1) + (grp * 4 + mt) * 768 + lane * 4;
-    for (int d = 0; d < 4; ++d) q[term * 256 + d] = wd[d];
-    q[512 + 2 * term] = wd[4];
-    q[512 + 2 * term + 1] = wd[5];
+  const int k = f6_value(l2, grp, term, e);
+  float w = 0.f;
+  if (k >= 0) {
+    _Float16 hi, lo;
+    const float wf = mlp_weight_k(w1, w2, l2, k, lane, mt);
+    split_weight(wf, hi, lo);
+    w = term == 0 ? wf - (float)hi : (float)hi;   // term 0 carries the exact fp32 residual of the weight, term 1 a copy of its fp16 part
+  }
+  float amax = fabsf(w);
+#pragma unroll
+  for (int sh = 1; sh < 32; sh <<= 1) amax = fmaxf(amax, __shfl_xor(amax, sh, 32));
+  int E = amax > 0.f ? ilogbf(amax) : -100;
+  if (E < -100) E = -100;
+  if (ldexpf(amax, 2 - E) > 7.75f) E += 1;          // the largest element would saturate: one binade up
+  const float inv = ldexpf(1.0f, 2 - E);            // 1 / block scale, block scale = 2^(E - 2)
+  const uint32_t c = e2m3_code(w * inv);
+  const int bit = 6 * e, wi = bit >> 5, sh = bit & 31;
+  uint32_t mine = 0;                                // after the reduction lane d < 6 holds dword d of the 192-bit operand
+#pragma unroll
+  for (int d = 0; d < 6; ++d) {
+    uint32_t v = (d == wi ? c << sh : 0u) | ((d == wi + 1 && sh > 26) ? c >> (32 - sh) : 0u);
+#pragma unroll
+    for (int x = 1; x < 32; x <<= 1) v |= __shfl_xor(v, x, 32);
+    if (e == d) mine = v;
+  }
+  uint32_t* q = o + (l2 ? F6I_Q2 : F6I_Q1) + (grp * 4 + mt) * 768 + lane * 4;
+  if (e < 4) q[term * 256 + e] = mine;
+  else if (e < 6) q[512 + 2 * term + (e - 4)] = mine;
+  if (e == 0) {
     const int byte = (E - 2) + 127 - (term == 0 ? 2 : 13);
-    scales[lane * 8 + term * 4 + mt] = (uint8_t)(byte < 0 ? 0 : (byte > 254 ? 254 : byte));
+    ((uint8_t*)(o + F6I_SC + gg * 128))[lane * 8 + term * 4 + mt] = (uint8_t)(byte < 0 ? 0 : (byte > 254 ? 254 : byte));
   }
 }
 
@@ -1879,9 +1882,10 @@ int ego_pack_mlp(const ego_scene* sc, float* packed_out, void* stream) {
   if (int e = ego_launch_status("k_pack_mlp_f8")) return e;
   float* f6 = packed_out + 2 * PACKED_FLOATS + BASIS16_FLOATS + F8_FLOATS;
   if (const hipError_t err = hipMemsetAsync(f6, 0, sizeof(float) * F6_FLOATS, (hipStream_t)stream)) return (int)err;  // the gaps behind the blocks
-  constexpr int F6_THREADS = F8_HI1 + F8_HI2 + (G6_1 + G6_2) * 4 * 64;
-  k_pack_mlp_f6<<<(F6_THREADS + 255) / 256, 256, 0, (hipStream_t)stream>>>(sc->mlp_w[0], sc->mlp_w[1], f6);
-  return ego_launch_status("k_pack_mlp_f6");
+  k_pack_mlp_f6<<<(F8_HI1 + F8_HI2 + 255) / 256, 256, 0, (hipStream_t)stream>>>(sc->mlp_w[0], sc->mlp_w[1], f6);
+  if (int e = ego_launch_status("k_pack_mlp_f6")) return e;
+  k_pack_mlp_f6_frag<<<((G6_1 + G6_2) * 4 * 64 * 2 + 7) / 8, 256, 0, (hipStream_t)stream>>>(sc->mlp_w[0], sc->mlp_w[1], f6);
+  return ego_launch_status("k_pack_mlp_f6_frag");
 }
 
 int ego_shade_kernel_info(int32_t precision, int32_t* out, int32_t n) {

@@ -238,9 +238,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CAB * CBB >
 // halves is exact in fp32, so ONE v_mfma_f32_32x32x16_f16 does what the bf16 hi/lo form needs three instructions and a split of both
 // operands for (~240 VALU instructions per thread and 32-row step: those passes were bound by their commit -> barrier -> MFMA -> barrier
 // chain, 11 k clocks per step against 1 k of matrix work, not by bytes).  The per-sample scale runs along K, so it cannot be applied
-// to the accumulator; within a step (32 samples = one tile) the largest scale `ref` is taken out instead: B's row m is multiplied by
-// inv_m / ref <= 1 (a power of two: exact in fp16 down to 2^-14, gradually flushed below - a sample whose gradient is 2^-14 of its
-// tile's largest contributes that little), the step's product lands in a scratch accumulator and acc += ref * scratch.
+// to the accumulator; within a step (32 samples = one tile) the largest scale `ref` is taken out instead: A's row m (the payload, whose
+// largest entry lies in [2^12, 2^13)) is multiplied by inv_m / ref <= 1, a power of two - exact until an entry drops below 2^-14, i.e.
+// 26 binades of head room for a sample's largest entries (consecutive samples of a ray differ by many orders of magnitude in their
+// gradients; scaling B's O(1) activations instead flushed them after ~10 binades and cost 4 % of a small batch's dW1) -, the step's
+// product lands in a scratch accumulator and acc += ref * scratch.
 typedef _Float16 h8w __attribute__((ext_vector_type(8)));
 typedef _Float16 h2w __attribute__((ext_vector_type(2)));
 
@@ -265,8 +267,8 @@ struct HTile {   // one operand's rows [row0, row0 + 32): up to two (k-step, lan
       v1[it] = (r0 + 1 < M && s < steps_mem) ? p[1] : z;
     }
   }
-  // [column][32 samples] halves; ratio2 = the two samples' inv / ref as packed halves (B only), ones_col as in the bf16 form
-  template <bool IS_B>
+  // [column][32 samples] halves; ratio2 = the two samples' inv / ref as packed halves (SCALE: A), ones_col as in the bf16 form (B)
+  template <bool SCALE>
   __device__ __forceinline__ void commit(int steps, int items, int ones_col, uint32_t ratio2, uint8_t* __restrict__ lds) const {
     const int hw = (threadIdx.x >> 4) & 1, sp = threadIdx.x & 15;
 #pragma unroll
@@ -279,10 +281,8 @@ struct HTile {   // one operand's rows [row0, row0 + 32): up to two (k-step, lan
         const int col = (2 * s + (e >> 2)) * 8 + hw * 4 + (e & 3);
         const uint32_t a = v0[it][e >> 1], b = v1[it][e >> 1];
         uint32_t word = (e & 1) ? ((a >> 16) | (b & 0xffff0000u)) : ((a & 0xffffu) | (b << 16));   // (sample 2 sp, sample 2 sp + 1)
-        if (IS_B) {
-          if (col == ones_col) word = 0x3c003c00u;   // (1.0, 1.0)
-          word = __builtin_bit_cast(uint32_t, __builtin_bit_cast(h2w, word) * __builtin_bit_cast(h2w, ratio2));
-        }
+        if (col == ones_col) word = 0x3c003c00u;   // (1.0, 1.0); rows beyond M meet zero rows of A
+        if (SCALE) word = __builtin_bit_cast(uint32_t, __builtin_bit_cast(h2w, word) * __builtin_bit_cast(h2w, ratio2));
         *(uint32_t*)(lds + col * WG_ROW + sp * 4) = word;
       }
     }
@@ -322,8 +322,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     for (int sh = 1; sh < 16; sh <<= 1) ref = fmaxf(ref, __shfl_xor(ref, sh, 16));
     const float rinv = ref > 0.f ? 1.f / ref : 0.f;   // powers of two: exact
     const h2w ratio = h2w{(_Float16)(inv0 * rinv), (_Float16)(inv1 * rinv)};
-    ta.commit<false>(8, 1, -1, 0u, la);
-    tb.commit<true>(2 * CBB, 2, P.ones_col, __builtin_bit_cast(uint32_t, ratio), lb);
+    ta.commit<true>(8, 1, -1, __builtin_bit_cast(uint32_t, ratio), la);
+    tb.commit<false>(2 * CBB, 2, P.ones_col, 0u, lb);
     __syncthreads();
     if (st + 1 < P.steps_per_wg) fetch(row0 + 32);   // next step's rows travel while this step multiplies
     const uint8_t* ra = la + (32 * wave + i) * WG_ROW;

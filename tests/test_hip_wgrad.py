@@ -146,3 +146,36 @@ def test_weight_grad_accumulates_and_validates():
     assert b"weight_grad" in lib.ego_last_error()
     assert lib.ego_weight_grad(A.data_ptr(), 128, 96, 0, None, B.data_ptr(), 128, 128, 0, -1, 40, G.data_ptr(), 160, None) != 0  # no 3 x 4 instance
     assert lib.ego_weight_grad(A.data_ptr(), 128, 128, 2, None, B.data_ptr(), 128, 128, 1, -1, 40, G.data_ptr(), 160, None) == -1  # no a_scale
+
+
+@pytest.mark.parametrize("M", [2048, 70001])
+def test_both_halves_form_with_wild_scales_and_zero_rows(M):
+    """k_wgrad_h takes the largest per-row scale of a 32-row step as its reference: neighbouring rows whose gradients differ by seven
+    orders of magnitude (consecutive samples of a ray do) and rows that are all zero (ego_shade_backward writes scale 0 for them - a 1.0
+    standing for "nothing" would flush the step) must still give the product of the values the halves stand for."""
+    g = torch.Generator().manual_seed(M)
+    A = torch.randn(M, 128, generator=g) * torch.pow(10.0, -9 + 7 * torch.rand(M, generator=g)).unsqueeze(1)
+    dead = torch.rand(M, generator=g) < 0.15
+    A[dead] = 0
+    B = torch.randn(M, 160, generator=g)
+    B[:, 154] = 0
+    Ah, inv, exact = _scaled_half(torch.where(dead[:, None], torch.ones_like(A), A))
+    Mp = Ah.shape[0]
+    # zero rows: payload 0, scale 0 (the layout permutes rows inside a tile: rebuild the payload from the masked matrix)
+    Az = torch.where(dead[:, None], torch.zeros_like(A), A)
+    amax = Az.abs().amax(1).clamp_min(1e-38)
+    k = 12 - torch.floor(torch.log2(amax))
+    scale, inv = torch.exp2(k), torch.exp2(-k)
+    scale[dead], inv[dead] = 0.0, 0.0
+    H = (Az * scale[:, None]).half()
+    exact = H.float() * inv[:, None]
+    P = torch.zeros(Mp, 128, dtype=torch.float16)
+    P[:M] = H
+    Ah = P.view(Mp // 32, 32, 8, 2, 2, 4).permute(0, 2, 4, 1, 3, 5).contiguous().view(Mp, 128)
+    Bh, Bexact = _half_blocked(B)
+    G = _run(Ah.to(DEV), 128, Bh.to(DEV), 160, 154, a_blocked=2, b_blocked=2, M=M, a_scale=inv.to(DEV)).cpu().double()
+    ref = exact.double().T @ Bexact.double()
+    cols = [c for c in range(160) if c != 154]
+    scale_ref = float(ref.abs().max())
+    assert float((G[:128, cols] - ref[:, cols]).abs().max()) <= 5e-5 * scale_ref
+    assert float((G[:128, 154] - exact.double().sum(0)).abs().max()) <= 5e-5 * float(exact.double().sum(0).abs().max())
