@@ -47,6 +47,10 @@ def run(reps=200, full=False, verbose=True):
              ("appfeature f16 tables", appf("f16x3", "f16", q)), ("densityfeature", lambda: model.compute_densityfeature(q)),
              ("renderModule f16x3", withprec("f16x3", lambda: model.renderModule(q_in, vd, feat))),
              ("renderModule f16f8", withprec("f16f8", lambda: model.renderModule(q_in, vd, feat))),
+             ("renderModule f16f6", withprec("f16f6", lambda: model.renderModule(q_in, vd, feat))),
+             ("forward 24 f16f6", withprec("f16f6", lambda: model(rays, n_coarse=24, exp_sampling=True)[0])),
+             ("forward 32 f16f6 (folded compositing)", withprec("f16f6", lambda: model(rays, n_coarse=32, exp_sampling=True)[0])),
+             ("forward 16+16 f16f6", withprec("f16f6", lambda: model(rays, n_coarse=16, n_fine=16, exp_sampling=True, resampling=True)[0])),
              ("forward 24 f16x3", withprec("f16x3", lambda: model(rays, n_coarse=24, exp_sampling=True)[0])),
              ("forward 24 f16f8", withprec("f16f8", lambda: model(rays, n_coarse=24, exp_sampling=True)[0])),
              ("forward 16+16 f16x3", withprec("f16x3", lambda: model(rays, n_coarse=16, n_fine=16, exp_sampling=True, resampling=True)[0])),
@@ -55,7 +59,7 @@ def run(reps=200, full=False, verbose=True):
         cfg2 = synth.SceneConfig()
         big = build_model(cfg2, synth.make_weights(cfg2, seed=1234), dev)
         rays2 = torch.from_numpy(synth.make_rays(4096, seed=1)).to(dev)
-        for prec in ("f16x3", "f16f8"):
+        for prec in ("f16x3", "f16f8", "f16f6"):
             def big_fn(kw, prec=prec):
                 def f():
                     big.mlp_precision = prec
