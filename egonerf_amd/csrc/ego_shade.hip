@@ -1353,6 +1353,8 @@ __global__ __launch_bounds__(512) void k_shade_h(ShadeArgs A) {
   for (int64_t seg0 = tile0; seg0 < tile1; seg0 += seg_len) {
   const int64_t seg1 = seg0 + seg_len < tile1 ? seg0 + seg_len : tile1;
   float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f;   // FOLD, lane half 0: sum w r, w g, w b, w; half 1: sum w z in c0
+  // the ray's d_z for the depth quirk: wave-uniform address, fetched (scalar) at the top of the ray instead of in its epilogue
+  const float fold_dz = FOLD ? A.rays[(seg0 / tpr) * 6 + 5] : 0.f;
   // the tile mask is read 64 tiles at a time (one byte per lane + ballot) and walked with find-first-set: a skipped tile costs no
   // memory round trip (a per-tile flag load sat on the critical path of every skipped tile)
   for (int64_t wbase = seg0; wbase < seg1; wbase += 64) {
@@ -1780,12 +1782,15 @@ __global__ __launch_bounds__(512) void k_shade_h(ShadeArgs A) {
   }
   }
   if (FOLD) {   // the pixel of ray seg0 / tpr (rows H, J: k_composite's arithmetic on the per-lane sums)
-#pragma unroll
-    for (int sh = 1; sh < 32; sh <<= 1) {
-      c0 += __shfl_xor(c0, sh, 64); c1 += __shfl_xor(c1, sh, 64); c2 += __shfl_xor(c2, sh, 64); c3 += __shfl_xor(c3, sh, 64);
-    }
-    const float dp = __shfl(c0, 32, 64);
-    if (lane == 0) {
+    // sums over the 32 lanes of each half on the DPP path (no LDS round trips: the wave is alone with this chain at the end of a ray):
+    // row_shr 1, 2, 4, 8 inside the 16-lane rows, then row_bcast:15 into rows 1 / 3: lane 31 holds half 0's sums, lane 63 half 1's
+#define EGO_SUM_STEP(v, ctrl, rmask) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, rmask, 0xf, false))
+#define EGO_HALF_SUM(v) EGO_SUM_STEP(v, 0x111, 0xf); EGO_SUM_STEP(v, 0x112, 0xf); EGO_SUM_STEP(v, 0x114, 0xf); EGO_SUM_STEP(v, 0x118, 0xf); EGO_SUM_STEP(v, 0x142, 0xa)
+    EGO_HALF_SUM(c0); EGO_HALF_SUM(c1); EGO_HALF_SUM(c2); EGO_HALF_SUM(c3);
+#undef EGO_HALF_SUM
+#undef EGO_SUM_STEP
+    const float dp = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c0), 63));
+    if (lane == 31) {
       const int64_t ray = seg0 / tpr;
       const float* R = A.rays + ray * 6;
       float cr = c0, cg = c1, cb = c2;
@@ -1801,7 +1806,7 @@ __global__ __launch_bounds__(512) void k_shade_h(ShadeArgs A) {
       A.rgb_map[ray * 3] = fminf(fmaxf(cr, 0.f), 1.f);
       A.rgb_map[ray * 3 + 1] = fminf(fmaxf(cg, 0.f), 1.f);
       A.rgb_map[ray * 3 + 2] = fminf(fmaxf(cb, 0.f), 1.f);
-      if (A.depth) A.depth[ray] = dp + (1.f - c3) * R[5];  // (1-acc) * d_z: reference quirk, EgoNeRF.py:598
+      if (A.depth) A.depth[ray] = dp + (1.f - c3) * fold_dz;  // (1-acc) * d_z: reference quirk, EgoNeRF.py:598
     }
   }
   }

@@ -271,8 +271,9 @@ int ego_shade(const ego_scene* sc, const float* rays, const float* z, const floa
  * pixel in their epilogue, no per-sample colours are written.  For the tuned model shape with fp32 tables, a split-precision arithmetic
  * (not EGO_PREC_F32), weight_thres <= 0 and S a multiple of 32 (EGO_E_UNSUPPORTED otherwise: call ego_shade + ego_composite); coords
  * is required.  Sums run in a different order than ego_composite's (per lane over the ray's tiles, then across 32 lanes): equal to it
- * within fp32 rounding of the sums, not bit for bit.  ego_render_forward takes this path whenever it applies (EGO_RENDER_NO_FOLD=1 in
- * the environment keeps the two-launch form, for A/B measurements). */
+ * within fp32 rounding of the sums, not bit for bit.  Measured 0.25 % slower than ego_shade + ego_composite on the 4096 x 512 and the
+ * ERP configurations (the epilogue costs the shade kernel what the small second launch costs), so ego_render_forward takes it only
+ * with EGO_RENDER_FOLD=1 in the environment; what it saves is the [N][S][3] colour buffer's traffic. */
 int ego_shade_composite(const ego_scene* sc, const float* rays, const float* z, const float* coords, const float* weight,
                         const float* bg_weight /* NULL without an envmap */, int64_t N, int32_t S,
                         const uint8_t* tile_active /* NULL = shade every tile */, float* rgb_map, float* depth /* may be NULL */,

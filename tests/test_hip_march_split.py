@@ -57,8 +57,8 @@ def test_two_waves_per_ray_return_the_same_bits(S, n_rays, density_shift, with_a
 @pytest.mark.parametrize("prec", ["f16f6", "f16f8", "f16x3"])
 @pytest.mark.parametrize("envmap", [False, True])
 def test_folded_compositing_equals_the_two_launch_form(kw, prec, envmap):
-    """ego_render_forward shades and composites in one launch (ego_shade_composite) wherever it applies; EGO_RENDER_NO_FOLD=1 keeps
-    ego_shade + ego_composite.  Same products, sums in another order: equal within fp32 rounding of the sums (2e-6), all five outputs."""
+    """EGO_RENDER_FOLD=1: ego_render_forward shades and composites in one launch (ego_shade_composite) wherever it applies; the default
+    is ego_shade + ego_composite.  Same products, sums in another order: equal within fp32 rounding of the sums (2e-6), all five outputs."""
     cfg = synth.SceneConfig(n_voxel=40 ** 3, use_envmap=envmap, envmap_res_H=64) if envmap else synth.SceneConfig(n_voxel=40 ** 3)
     model = synth.build_model(cfg, synth.make_weights(cfg, seed=11), "cuda")
     model.mlp_precision = prec
@@ -67,13 +67,13 @@ def test_folded_compositing_equals_the_two_launch_form(kw, prec, envmap):
     try:
         for fold in (True, False):
             if fold:
-                os.environ.pop("EGO_RENDER_NO_FOLD", None)
+                os.environ["EGO_RENDER_FOLD"] = "1"
             else:
-                os.environ["EGO_RENDER_NO_FOLD"] = "1"
+                os.environ.pop("EGO_RENDER_FOLD", None)
             with torch.no_grad():
                 out[fold] = model(rays, exp_sampling=True, **kw)
     finally:
-        os.environ.pop("EGO_RENDER_NO_FOLD", None)
+        os.environ.pop("EGO_RENDER_FOLD", None)
     for k in range(5):
         a, b = out[True][k], out[False][k]
         assert (a is None) == (b is None), k

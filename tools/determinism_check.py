@@ -49,7 +49,7 @@ def run(reps=200, full=False, verbose=True):
              ("renderModule f16f8", withprec("f16f8", lambda: model.renderModule(q_in, vd, feat))),
              ("renderModule f16f6", withprec("f16f6", lambda: model.renderModule(q_in, vd, feat))),
              ("forward 24 f16f6", withprec("f16f6", lambda: model(rays, n_coarse=24, exp_sampling=True)[0])),
-             ("forward 32 f16f6 (folded compositing)", withprec("f16f6", lambda: model(rays, n_coarse=32, exp_sampling=True)[0])),
+             ("forward 32 f16f6", withprec("f16f6", lambda: model(rays, n_coarse=32, exp_sampling=True)[0])),
              ("forward 16+16 f16f6", withprec("f16f6", lambda: model(rays, n_coarse=16, n_fine=16, exp_sampling=True, resampling=True)[0])),
              ("forward 24 f16x3", withprec("f16x3", lambda: model(rays, n_coarse=24, exp_sampling=True)[0])),
              ("forward 24 f16f8", withprec("f16f8", lambda: model(rays, n_coarse=24, exp_sampling=True)[0])),

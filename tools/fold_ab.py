@@ -1,5 +1,5 @@
-"""A/B inside one process: EgoNeRF.forward at the headline shape with compositing folded into the shade kernel (default) and with the
-two-launch form (EGO_RENDER_NO_FOLD=1, read by the library on every call), alternated."""
+"""A/B inside one process: EgoNeRF.forward at the headline shape with compositing folded into the shade kernel (EGO_RENDER_FOLD=1, read by the
+library on every call) and with the two-launch form (default), alternated."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -18,8 +18,8 @@ def run(steps=200):
     return (time.perf_counter() - t0) / steps * 1e3
 run(400)
 for rnd in range(4):
-    os.environ.pop("EGO_RENDER_NO_FOLD", None); a = run()
-    os.environ["EGO_RENDER_NO_FOLD"] = "1"; b = run()
+    os.environ["EGO_RENDER_FOLD"] = "1"; a = run()
+    os.environ.pop("EGO_RENDER_FOLD", None); b = run()
     print(f"round {rnd}: folded {a:.4f} ms/step, two launches {b:.4f} ms/step")
 # the two shade kernels alone
 from egonerf_amd import _lib
