@@ -37,7 +37,7 @@ class Scene(C.Structure):
         ("packed", C.c_void_p), ("envmap", C.c_void_p), ("envmap_h", C.c_int32), ("mlp_precision", C.c_int32),
         ("occ", C.c_void_p), ("occ_res", C.c_int32 * 3), ("term_eps", C.c_float),
         ("app16", VmField), ("app_f16", C.c_int32), ("n_r_lut_fine", C.c_int32), ("r_lut_fine", C.c_void_p), ("n_r_fine", C.c_int32),
-        ("weight_thres", C.c_float), ("occ_cell", C.c_void_p),
+        ("weight_thres", C.c_float), ("occ_cell", C.c_void_p), ("head", C.c_int32),
     ]
 
 
@@ -73,7 +73,7 @@ SP = C.POINTER(Scene)
 # The EGO_ABI_VERSION (include/egonerf_hip.h) the PROTOTYPES below were written against.  load() refuses a library that reports
 # another one: a stale libegonerf_hip.so can keep every struct size and still disagree on an argument list (ABI 5 -> 7 inserted
 # `normalize` before ego_erp_rays' output pointer), which ctypes would pass through as a wild pointer.
-EXPECTED_ABI_VERSION = 12
+EXPECTED_ABI_VERSION = 13
 
 # name -> (restype, argtypes); mirrors include/egonerf_hip.h one to one
 PROTOTYPES = {

@@ -27,6 +27,7 @@ struct GenShadeArgs {
   const uint8_t* tile_active;
   int64_t M;
   int32_t S, app_dim, n_comp, in_c, view_pe, fea_pe;
+  int32_t head;          // EGO_HEAD_MLP_FEA: features -> MLP -> sigmoid; EGO_HEAD_RGB: colour = features 0..2 (RGBRender, tensorBase.py:37-39)
   // training forward (DUMP): row-major per-sample activations for the backward pass / the weight-gradient products
   float* dump_x;   // [M][ldx]: the MLP input row in the reference's column order (tensorBase.py:68-75)
   float* dump_h1;  // [M][ldh]: relu(h1)
@@ -66,7 +67,7 @@ __global__ void k_generic_pack(const float* __restrict__ w1, const float* __rest
   else if (idx < L.b2) { const int64_t e = idx - L.w2t; const int k = (int)(e / hid), j = (int)(e % hid); v = w2[(int64_t)j * hid + k]; }
   else if (idx < L.w3) v = b2[idx - L.b2];
   else if (idx < L.b3) v = w3[idx - L.w3];
-  else if (idx < L.basis) { const int c = (int)(idx - L.b3); v = c < 3 ? b3[c] : 0.f; }
+  else if (idx < L.basis) { const int c = (int)(idx - L.b3); v = (c < 3 && b3) ? b3[c] : 0.f; }   // b3 == null: EGO_HEAD_RGB (hid = in_c = 0)
   else {
     const int64_t e = idx - L.basis;
     const int f = (int)(e & 31), col = (int)((e >> 5) % (3 * n_comp)), g = (int)((e >> 5) / (3 * n_comp));
@@ -84,7 +85,7 @@ __global__ __launch_bounds__(128) void k_shade_generic(GenShadeArgs A) {
   __shared__ float slab[2][HID][64];
   const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   float (*sl)[64] = slab[wv];
-  const GenLayout L = gen_layout(A.in_c, HID, A.n_comp);
+  const GenLayout L = gen_layout(A.in_c, A.head == EGO_HEAD_RGB ? 0 : HID, A.n_comp);   // no MLP block in the RGB head's blob
   const int64_t n_units = (A.M + 63) >> 6;
   for (int64_t unit = (int64_t)blockIdx.x * 2 + wv; unit < n_units; unit += (int64_t)gridDim.x * 2) {
     if (MODE == G_SHADE && A.tile_active) {   // two 32-sample tiles per unit (the last unit of a ragged M may hold one): skip when neither is read
@@ -157,6 +158,13 @@ __global__ __launch_bounds__(128) void k_shade_generic(GenShadeArgs A) {
 #pragma unroll
         for (int f = 0; f < 32; ++f)
           if (f < A.app_dim) A.out[m * A.app_dim + f] = feat[f];
+      }
+      continue;
+    }
+    if (A.head == EGO_HEAD_RGB) {   // RGBRender (tensorBase.py:37-39): the colour IS the (3-channel) appearance feature; no sigmoid, no clamp
+      if (valid) {
+        float* op = A.out + m * 3;
+        op[0] = feat[0]; op[1] = feat[1]; op[2] = feat[2];
       }
       continue;
     }
@@ -259,6 +267,7 @@ struct GenBwdArgs {
   float* dv;            // out [M][ldv]
   int64_t M;
   int32_t app_dim, n_comp, in_c, view_pe, fea_pe, ldx, ldh, ldv;
+  int32_t head;
 };
 
 template <int HID>
@@ -266,7 +275,7 @@ __global__ __launch_bounds__(128) void k_shade_generic_bwd(GenBwdArgs A) {
   __shared__ float slab[2][HID][64];
   const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   float (*sl)[64] = slab[wv];
-  const GenLayout L = gen_layout(A.in_c, HID, A.n_comp);
+  const GenLayout L = gen_layout(A.in_c, A.head == EGO_HEAD_RGB ? 0 : HID, A.n_comp);
   const int64_t n_units = (A.M + 63) >> 6;
   const int D = A.app_dim;
   for (int64_t unit = (int64_t)blockIdx.x * 2 + wv; unit < n_units; unit += (int64_t)gridDim.x * 2) {
@@ -274,6 +283,26 @@ __global__ __launch_bounds__(128) void k_shade_generic_bwd(GenBwdArgs A) {
     const bool valid = m_raw < A.M;
     const int64_t m = valid ? m_raw : A.M - 1;
     const int g = ((const f32x4*)A.coords)[m].w != 0.f;
+    if (A.head == EGO_HEAD_RGB) {   // colour = features: dfe = dL/d rgb_sample, then dv = B_g^T dfe as below (basisT [g][col][32])
+      float dfe[3] = {A.dc[m * 3], A.dc[m * 3 + 1], A.dc[m * 3 + 2]};
+      if (valid) {
+#pragma unroll
+        for (int f = 0; f < 32; ++f) {
+          A.dfe[m * 64 + 32 * g + f] = f < 3 ? dfe[f] : 0.f;
+          A.dfe[m * 64 + 32 * (1 - g) + f] = 0.f;
+        }
+      }
+      const int ncol = 3 * A.n_comp;
+      for (int col = 0; col < ncol; ++col) {
+        const float* b0 = A.gp + L.basis + (int64_t)col * 32;
+        const float* b1 = b0 + (int64_t)ncol * 32;
+        float s = 0.f;
+#pragma unroll
+        for (int f = 0; f < 3; ++f) s = fmaf(g ? b1[f] : b0[f], dfe[f], s);
+        if (valid) A.dv[m * A.ldv + col] = s;
+      }
+      continue;
+    }
     float d_o[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
@@ -536,7 +565,12 @@ int check_generic_shape(const ego_scene* sc, const char* who, bool need_tables, 
   if (sc->app_dim < 1 || sc->app_dim > 32) return ego_fail(EGO_E_UNSUPPORTED, "%s: app_dim %d (supported: 1..32)", who, sc->app_dim);
   const int C = sc->app.n_comp;
   if (C < 4 || C > 48 || (C & 3)) return ego_fail(EGO_E_UNSUPPORTED, "%s: appearance n_comp %d (supported: multiples of 4 up to 48)", who, C);
-  if (sc->mlp_hidden != 64 && sc->mlp_hidden != 128) return ego_fail(EGO_E_UNSUPPORTED, "%s: featureC %d (supported: 64, 128)", who, sc->mlp_hidden);
+  if (sc->head != EGO_HEAD_MLP_FEA && sc->head != EGO_HEAD_RGB) return ego_fail(EGO_E_BADARG, "%s: scene.head %d (EGO_HEAD_MLP_FEA or EGO_HEAD_RGB)", who, sc->head);
+  if (sc->head == EGO_HEAD_RGB) {   // tensorBase.py:194-196: `assert self.app_dim == 3`; no MLP
+    if (sc->app_dim != 3) return ego_fail(EGO_E_BADARG, "%s: the RGB head needs app_dim == 3 (got %d)", who, sc->app_dim);
+    if (sc->mlp_in != 0 || sc->mlp_hidden != 0) return ego_fail(EGO_E_BADARG, "%s: the RGB head has no MLP (mlp_in / mlp_hidden must be 0)", who);
+    need_mlp = false;
+  } else if (sc->mlp_hidden != 64 && sc->mlp_hidden != 128) return ego_fail(EGO_E_UNSUPPORTED, "%s: featureC %d (supported: 64, 128)", who, sc->mlp_hidden);
   if (need_tables) {
     for (int g = 0; g < 2; ++g)
       for (int i = 0; i < 3; ++i)
@@ -556,7 +590,8 @@ int check_generic_shape(const ego_scene* sc, const char* who, bool need_tables, 
 }  // namespace
 
 bool ego_shape_is_tuned(const ego_scene* sc) {
-  return sc->app_dim == 27 && sc->app.n_comp == 48 && sc->mlp_in == 150 && sc->mlp_hidden == 128 && sc->view_pe == 2 && sc->fea_pe == 2;
+  return sc->head == EGO_HEAD_MLP_FEA && sc->app_dim == 27 && sc->app.n_comp == 48 && sc->mlp_in == 150 && sc->mlp_hidden == 128 && sc->view_pe == 2 &&
+         sc->fea_pe == 2;
 }
 
 int64_t ego_generic_packed_floats(const ego_scene* sc) {
@@ -566,8 +601,9 @@ int64_t ego_generic_packed_floats(const ego_scene* sc) {
 int ego_generic_pack(const ego_scene* sc, float* out, void* stream) {
   if (int e = check_generic_shape(sc, "pack_mlp", false, true, false)) return e;
   const int64_t n = ego_generic_packed_floats(sc);
+  const bool mlp = sc->head != EGO_HEAD_RGB;   // the RGB head's blob is [4 zeros | basisT]
   k_generic_pack<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(sc->mlp_w[0], sc->mlp_b[0], sc->mlp_w[1], sc->mlp_b[1], sc->mlp_w[2],
-                                                                              sc->mlp_b[2], sc->basis[0], sc->basis[1], sc->mlp_in, sc->mlp_hidden,
+                                                                              mlp ? sc->mlp_b[2] : nullptr, sc->basis[0], sc->basis[1], sc->mlp_in, sc->mlp_hidden,
                                                                               sc->app.n_comp, sc->app_dim, out);
   return ego_launch_status("k_generic_pack");
 }
@@ -576,7 +612,7 @@ template <int MODE>
 static int launch_shade(const ego_scene* sc, GenShadeArgs& a, hipStream_t st) {
   const int64_t units = (a.M + 63) >> 6;
   const unsigned grid = (unsigned)((units + 1) / 2 < 2048 ? (units + 1) / 2 : 2048);
-  if (sc->mlp_hidden == 64) k_shade_generic<64, MODE><<<grid, 128, 0, st>>>(a);
+  if (sc->mlp_hidden != 128) k_shade_generic<64, MODE><<<grid, 128, 0, st>>>(a);   // 64, or 0 = the RGB head (leaves before the MLP)
   else k_shade_generic<128, MODE><<<grid, 128, 0, st>>>(a);
   return ego_launch_status("k_shade_generic");
 }
@@ -584,7 +620,7 @@ static int launch_shade(const ego_scene* sc, GenShadeArgs& a, hipStream_t st) {
 static void fill_common(const ego_scene* sc, GenShadeArgs& a) {
   a.F = make_field(sc->app);
   a.gp = sc->packed;
-  a.app_dim = sc->app_dim; a.n_comp = sc->app.n_comp; a.in_c = sc->mlp_in; a.view_pe = sc->view_pe; a.fea_pe = sc->fea_pe;
+  a.app_dim = sc->app_dim; a.n_comp = sc->app.n_comp; a.in_c = sc->mlp_in; a.view_pe = sc->view_pe; a.fea_pe = sc->fea_pe; a.head = sc->head;
 }
 
 int ego_generic_shade(const ego_scene* sc, const float* rays, const float* coords, int64_t N, int32_t S, float* rgb, const uint8_t* tile_active,
@@ -607,6 +643,7 @@ int ego_generic_app_feature(const ego_scene* sc, const float* c7n, int64_t M, fl
 
 int ego_generic_mlp_fea(const ego_scene* sc, const float* viewdirs, const float* feat, int64_t M, float* rgb, void* stream) {
   if (int e = check_generic_shape(sc, "mlp_fea", false, true)) return e;
+  if (sc->head == EGO_HEAD_RGB) return ego_fail(EGO_E_UNSUPPORTED, "mlp_fea: the RGB head has no MLP (RGBRender returns the features)");
   GenShadeArgs a{};
   fill_common(sc, a);
   a.feat = feat; a.dirs = viewdirs; a.out = rgb; a.M = M; a.S = 1;
@@ -636,8 +673,9 @@ int ego_shade_train_generic(const ego_scene* sc, const float* rays, const float*
                             float* h1, float* h2, int32_t ldh, float* v, int32_t ldv, void* stream) {
   EGO_REQUIRE(N >= 0 && S >= 1 && N * (int64_t)S < (1ll << 31), "shade_train_generic: bad size");
   if (N == 0) return EGO_OK;
-  EGO_REQUIRE(rays && coords && rgb && x && h1 && h2 && v, "shade_train_generic: null argument");
   if (int e = check_generic_shape(sc, "shade_train_generic", true, true)) return e;
+  const bool rgb_head = sc->head == EGO_HEAD_RGB;   // no MLP: x / h1 / h2 are not written and may be null
+  EGO_REQUIRE(rays && coords && rgb && v && (rgb_head || (x && h1 && h2)), "shade_train_generic: null argument");
   EGO_REQUIRE(ldx >= sc->mlp_in && ldh >= sc->mlp_hidden && ldv >= 3 * sc->app.n_comp && (ldv & 3) == 0 && ((uintptr_t)v & 15) == 0,
               "shade_train_generic: leading dimensions too small (or v not 16-byte aligned / ldv not a multiple of 4)");
   GenShadeArgs a{};
@@ -646,7 +684,7 @@ int ego_shade_train_generic(const ego_scene* sc, const float* rays, const float*
   a.dump_x = x; a.dump_h1 = h1; a.dump_h2 = h2; a.dump_v = v; a.ldx = ldx; a.ldh = ldh; a.ldv = ldv;
   const int64_t units = (a.M + 63) >> 6;
   const unsigned grid = (unsigned)((units + 1) / 2 < 2048 ? (units + 1) / 2 : 2048);
-  if (sc->mlp_hidden == 64) k_shade_generic<64, G_SHADE, true><<<grid, 128, 0, (hipStream_t)stream>>>(a);
+  if (sc->mlp_hidden != 128) k_shade_generic<64, G_SHADE, true><<<grid, 128, 0, (hipStream_t)stream>>>(a);
   else k_shade_generic<128, G_SHADE, true><<<grid, 128, 0, (hipStream_t)stream>>>(a);
   return ego_launch_status("k_shade_generic<DUMP>");
 }
@@ -656,16 +694,16 @@ int ego_shade_backward_generic(const ego_scene* sc, const float* coords, float* 
                                void* stream) {
   EGO_REQUIRE(N >= 0 && S >= 1 && N * (int64_t)S < (1ll << 31), "shade_backward_generic: bad size");
   if (N == 0) return EGO_OK;
-  EGO_REQUIRE(coords && dc && rgb && x && h1 && h2 && dh2 && dh1 && dfe64 && dv, "shade_backward_generic: null argument");
   if (int e = check_generic_shape(sc, "shade_backward_generic", false, true)) return e;
+  EGO_REQUIRE(coords && dc && dfe64 && dv && (sc->head == EGO_HEAD_RGB || (rgb && x && h1 && h2 && dh2 && dh1)), "shade_backward_generic: null argument");
   EGO_REQUIRE(ldx >= sc->mlp_in && ldh >= sc->mlp_hidden && ldv >= 3 * sc->app.n_comp, "shade_backward_generic: leading dimensions too small");
   GenBwdArgs a{};
   a.gp = sc->packed; a.coords = coords; a.dc = dc; a.rgb = rgb; a.x = x; a.h1 = h1; a.h2 = h2; a.dh2 = dh2; a.dh1 = dh1; a.dfe = dfe64; a.dv = dv;
   a.M = N * (int64_t)S; a.app_dim = sc->app_dim; a.n_comp = sc->app.n_comp; a.in_c = sc->mlp_in; a.view_pe = sc->view_pe; a.fea_pe = sc->fea_pe;
-  a.ldx = ldx; a.ldh = ldh; a.ldv = ldv;
+  a.ldx = ldx; a.ldh = ldh; a.ldv = ldv; a.head = sc->head;
   const int64_t units = (a.M + 63) >> 6;
   const unsigned grid = (unsigned)((units + 1) / 2 < 2048 ? (units + 1) / 2 : 2048);
-  if (sc->mlp_hidden == 64) k_shade_generic_bwd<64><<<grid, 128, 0, (hipStream_t)stream>>>(a);
+  if (sc->mlp_hidden != 128) k_shade_generic_bwd<64><<<grid, 128, 0, (hipStream_t)stream>>>(a);
   else k_shade_generic_bwd<128><<<grid, 128, 0, (hipStream_t)stream>>>(a);
   return ego_launch_status("k_shade_generic_bwd");
 }

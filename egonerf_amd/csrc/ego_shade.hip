@@ -1455,7 +1455,13 @@ __global__ __launch_bounds__(512) void k_shade_h(ShadeArgs A) {
     }
 
     __builtin_amdgcn_s_setprio(0);
-    if (need_sync) { __syncthreads(); need_sync = false; }
+    if (need_sync) {
+      // the LDS image was written by global_load_lds: its completion is counted by vmcnt, which the barrier's own release fence
+      // (lgkmcnt) does not wait for.  Here the gather has already drained the counter, so the wait is free.
+      __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0) (gfx9 encoding: vmcnt = bits 3:0 + 15:14, expcnt 7, lgkmcnt 15 = no wait)
+      __syncthreads();
+      need_sync = false;
+    }
     if (DUMP && valid) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) ((f32x4*)A.dump_fe)[(tile * 4 + q) * 64 + lane] = f32x4{fe[4 * q], fe[4 * q + 1], fe[4 * q + 2], fe[4 * q + 3]};
@@ -1810,7 +1816,10 @@ __global__ __launch_bounds__(512) void k_shade_h(ShadeArgs A) {
     }
   }
   }
-  if (need_sync) __syncthreads();   // a wave without a tile still owes the workgroup its arrival
+  if (need_sync) {   // a wave without a tile still owes the workgroup its arrival - and its DMA chunks, which must have LANDED first
+    __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0): global_load_lds completion is tracked by vmcnt, not by the barrier's lgkmcnt fence
+    __syncthreads();
+  }
 }
 
 #include "ego_train.inc"
@@ -1868,7 +1877,8 @@ int64_t ego_packed_floats_scene(const ego_scene* sc) {
 
 int ego_pack_mlp(const ego_scene* sc, float* packed_out, void* stream) {
   EGO_REQUIRE(sc && packed_out, "pack_mlp: null argument");
-  for (int i = 0; i < 3; ++i) EGO_REQUIRE(sc->mlp_w[i] && sc->mlp_b[i], "pack_mlp: null MLP weight");
+  if (sc->head != EGO_HEAD_RGB)   // RGBRender has no MLP (tensorBase.py:37-39): only the basis matrices are packed
+    for (int i = 0; i < 3; ++i) EGO_REQUIRE(sc->mlp_w[i] && sc->mlp_b[i], "pack_mlp: null MLP weight");
   EGO_REQUIRE(sc->basis[0] && sc->basis[1], "pack_mlp: null basis matrix");
   if (!ego_shape_is_tuned(sc)) return ego_generic_pack(sc, packed_out, stream);   // any other shape: the fp32 compatibility kernels' layout
   k_pack_mlp<<<(PACKED_FLOATS + 255) / 256, 256, 0, (hipStream_t)stream>>>(sc->mlp_w[0], sc->mlp_b[0], sc->mlp_w[1], sc->mlp_b[1],

@@ -172,6 +172,21 @@ class MLPRender_Fea(torch.nn.Module):
         return out.view(*features.shape[:-1], 3)
 
 
+class MLPRender(MLPRender_Fea):
+    """tensorBase.py:107-129 (shadingMode 'MLP'): mlp_in = [features, viewdirs, PE(viewdirs)] - MLPRender_Fea without the feature
+    encoding, same state-dict keys `mlp.{0,2,4}.*`; runs the any-shape kernels (csrc/ego_generic.hip) with fea_pe = 0."""
+
+    def __init__(self, inChannel, viewpe=6, featureC=128):
+        super().__init__(inChannel, viewpe, 0, featureC)
+        del self.feape   # the reference class has no such attribute
+
+
+def RGBRender(xyz_sampled, viewdirs, features):
+    """tensorBase.py:37-39 (shadingMode 'RGB', app_dim == 3): the colour is the appearance feature.  A plain function like the
+    reference's (no parameters: `isinstance(renderModule, torch.nn.Module)` is False, EgoNeRF.py:152)."""
+    return features
+
+
 class TensorBase(torch.nn.Module):
     """Constructor surface and shared helpers of tensorBase.py:132-186, 206-217, 241-295, 415-419."""
 
@@ -198,12 +213,39 @@ class TensorBase(torch.nn.Module):
                 self.envmap = EnvironmentMap(h=envmap.emission.shape[2], init_strategy="zero", device=device)
                 self.envmap.load_envmap(envmap.emission, device=device)
         self.shadingMode, self.pos_pe, self.view_pe, self.fea_pe, self.featureC = shadingMode, pos_pe, view_pe, fea_pe, featureC
-        if shadingMode != "MLP_Fea":
-            raise NotImplementedError(f"shadingMode {shadingMode!r}: the HIP path implements MLP_Fea (every shipped config, "
-                                      "configs/EgoNeRF/common.txt:34)")
-        self.renderModule = MLPRender_Fea(self.app_dim, view_pe, fea_pe, featureC).to(device)
+        self.init_render_func(shadingMode, pos_pe, view_pe, fea_pe, featureC, device)
         self.coordinates = coordinates
         self.coarse_sigma_grid_update_rule = coarse_sigma_grid_update_rule
+
+    def init_render_func(self, shadingMode, pos_pe, view_pe, fea_pe, featureC, device):
+        """tensorBase.py:186-200, for the heads the reference's EgoNeRF.forward can run with: 'MLP_Fea' (every shipped config,
+        configs/EgoNeRF/common.txt:34), 'MLP' and 'RGB'.  'MLP_PE' (the ctor default) and 'SH' raise inside the reference's
+        EgoNeRF.forward - MLPRender_PE is handed 7-column yin-yang coordinates for a 3-column position encoding (shape error in its
+        first Linear), SHRender [N,S,3] directions against [N*S,3,9] features - so they are refused here at construction
+        (SHRender exists as a stage function)."""
+        if shadingMode == "MLP_Fea":
+            self.renderModule = MLPRender_Fea(self.app_dim, view_pe, fea_pe, featureC).to(device)
+        elif shadingMode == "MLP":
+            self.renderModule = MLPRender(self.app_dim, view_pe, featureC).to(device)
+        elif shadingMode == "RGB":
+            assert self.app_dim == 3   # tensorBase.py:198
+            self.renderModule = RGBRender
+        else:
+            raise NotImplementedError(f"shadingMode {shadingMode!r}: EgoNeRF.forward runs with 'MLP_Fea', 'MLP' or 'RGB' (the reference's own "
+                                      "forward raises with 'MLP_PE' and 'SH')")
+
+    @property
+    def head_fea_pe(self) -> int:
+        """Feature-encoding frequencies of the head as built (MLPRender ignores the `fea_pe` argument, RGBRender has no network)."""
+        return self.fea_pe if self.shadingMode == "MLP_Fea" else 0
+
+    @property
+    def head_in_mlpC(self) -> int:
+        return self.renderModule.in_mlpC if self.shadingMode != "RGB" else 0
+
+    @property
+    def head_hidden(self) -> int:
+        return self.featureC if self.shadingMode != "RGB" else 0
 
     def init_envmap(self, envmap_res_H, init_strategy="zero", device="cuda"):
         self.envmap = EnvironmentMap(h=envmap_res_H, init_strategy=init_strategy, device=device)
@@ -296,7 +338,8 @@ class EgoNeRF(TensorBase):
         self.matMode_yin = self.matMode_yang = MAT_MODE
         self.vecMode_yin = self.vecMode_yang = VEC_MODE
         self.init_svd_volume(gridSize[0], device)
-        self.renderModule._owner = _WeakOwner(self)
+        if isinstance(self.renderModule, torch.nn.Module):
+            self.renderModule._owner = _WeakOwner(self)
         self._scene_cache = None
         self._packed = None
         self._packed_versions = None
@@ -419,7 +462,8 @@ class EgoNeRF(TensorBase):
                    {"params": getattr(self, f"app_line_{g}"), "lr": lr_init_spatialxyz},
                    {"params": getattr(self, f"app_plane_{g}"), "lr": lr_init_spatialxyz},
                    {"params": getattr(self, f"basis_mat_{g}").parameters(), "lr": lr_init_network}]
-        gv += [{"params": self.renderModule.parameters(), "lr": lr_init_network}]
+        if isinstance(self.renderModule, torch.nn.Module):   # EgoNeRF.py:152 (RGBRender is a function)
+            gv += [{"params": self.renderModule.parameters(), "lr": lr_init_network}]
         if self.envmap is not None:
             gv += [{"params": self.envmap.emission, "lr": lr_init_envmap}]
         return gv
@@ -518,12 +562,18 @@ class EgoNeRF(TensorBase):
 
     @property
     def is_tuned_shape(self) -> bool:
-        """True for the model shape every shipped config resolves to (app_dim 27, 48 appearance and 16 density components,
-        MLP_Fea 150 -> 128 -> 128 -> 3 with view_pe = fea_pe = 2): the MFMA kernels, forward and backward.  Any other shape
-        opt.py:87-100 can produce (n_lamb_sigma / n_lamb_sh multiples of 4 up to 48, data_dim_color <= 32, featureC 64 | 128,
-        view_pe / fea_pe <= 8) renders and trains through the fp32 compatibility kernels: same results to fp32 rounding, roughly an
-        order of magnitude slower."""
-        return (self.app_dim, self.app_n_comp[0], self.density_n_comp[0], self.featureC, self.view_pe, self.fea_pe) == (27, 48, 16, 128, 2, 2)
+        """True for the model shape every shipped config resolves to (head_is_tuned AND 16 density components): the MFMA / team-gather
+        kernels end to end, forward and backward.  Any other shape opt.py:87-100 can produce (n_lamb_sigma / n_lamb_sh multiples of 4
+        up to 48, data_dim_color <= 32, featureC 64 | 128, view_pe / fea_pe <= 8, shadingMode 'MLP' / 'RGB') renders and trains through
+        the fp32 compatibility kernels for the part that differs: same results to fp32 rounding, roughly an order of magnitude slower."""
+        return self.head_is_tuned and self.density_n_comp[0] == 16
+
+    @property
+    def head_is_tuned(self) -> bool:
+        """The appearance head alone (= the C library's ego_shape_is_tuned): MLP_Fea 150 -> 128 -> 128 -> 3 on 48 components / app_dim 27
+        with view_pe = fea_pe = 2 shades, and trains, through the MFMA kernels whatever the density field's component count (16 takes the
+        tuned march / density scatter, any other multiple of 4 the compatibility march around the same shade kernels)."""
+        return (self.shadingMode, self.app_dim, self.app_n_comp[0], self.featureC, self.view_pe, self.fea_pe) == ("MLP_Fea", 27, 48, 128, 2, 2)
 
     @property
     def mlp_precision(self) -> str:
@@ -602,6 +652,8 @@ class EgoNeRF(TensorBase):
 
     # -- C-ABI scene ----------------------------------------------------------------------------------------
     def _mlp_tensors(self) -> List[torch.Tensor]:
+        if self.shadingMode == "RGB":   # no network: the packed blob holds the two basis matrices only
+            return [self.basis_mat_yin.weight, self.basis_mat_yang.weight]
         m = self.renderModule.mlp
         return [m[0].weight, m[0].bias, m[2].weight, m[2].bias, m[4].weight, m[4].bias, self.basis_mat_yin.weight,
                 self.basis_mat_yang.weight]
@@ -660,12 +712,15 @@ class EgoNeRF(TensorBase):
         if self.coarse_sigma_plane_yin[0] is not None:
             self._fill_field(sc.density_coarse, "density", self.density_n_comp, [v // 2 for v in g], coarse=True)
         holds = [t.detach().contiguous() for t in mlp]
-        sc.mlp_w[:] = [holds[0].data_ptr(), holds[2].data_ptr(), holds[4].data_ptr()]
-        sc.mlp_b[:] = [holds[1].data_ptr(), holds[3].data_ptr(), holds[5].data_ptr()]
-        sc.basis[:] = [holds[6].data_ptr(), holds[7].data_ptr()]
+        if self.shadingMode == "RGB":
+            sc.head = 1   # EGO_HEAD_RGB: mlp_w / mlp_b stay null, mlp_in = mlp_hidden = 0
+        else:
+            sc.mlp_w[:] = [holds[0].data_ptr(), holds[2].data_ptr(), holds[4].data_ptr()]
+            sc.mlp_b[:] = [holds[1].data_ptr(), holds[3].data_ptr(), holds[5].data_ptr()]
+        sc.basis[:] = [holds[-2].data_ptr(), holds[-1].data_ptr()]
         sc.app_dim = self.app_dim
-        sc.mlp_in, sc.mlp_hidden = self.renderModule.in_mlpC, self.featureC
-        sc.view_pe, sc.fea_pe = self.view_pe, self.fea_pe
+        sc.mlp_in, sc.mlp_hidden = self.head_in_mlpC, self.head_hidden
+        sc.view_pe, sc.fea_pe = (self.view_pe, self.head_fea_pe) if self.shadingMode != "RGB" else (0, 0)
         sc.mlp_precision = {"f16x3": 0, "f32": 1, "f16f8": 2, "f16f6": 3}[self._mlp_precision]
         # packed weights: the MFMA fragment layouts for the tuned shape (27 / 48 / 150 / 128 / 2 / 2, every shipped config), the fp32
         # layout of the any-shape compatibility kernels otherwise (csrc/ego_generic.hip; the library reports the size for the shape)

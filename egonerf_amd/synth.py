@@ -104,6 +104,9 @@ class SceneConfig:
     use_envmap: bool = False
     envmap_res_H: int = 1000
     interval_th: bool = True  # configs/EgoNeRF/common.txt:19; False = the plain exponential r grid / sample schedule
+    # appearance head (tensorBase.py:186-200): "MLP_Fea" (every shipped config), "MLP" (MLPRender: no feature encoding, `fea_pe` is
+    # ignored) or "RGB" (RGBRender: colour = the 3 appearance features, no MLP; needs app_dim == 3)
+    shadingMode: str = "MLP_Fea"
     grid: List[int] = field(default_factory=list)
 
     def __post_init__(self):
@@ -116,8 +119,15 @@ class SceneConfig:
         return np.array([[-e, -e, -e], [e, e, e]], dtype=np.float32)
 
     @property
+    def head_fea_pe(self) -> int:
+        """Feature-encoding frequencies the head really uses: MLPRender (tensorBase.py:107-129) has none whatever `fea_pe` says."""
+        return self.fea_pe if self.shadingMode == "MLP_Fea" else 0
+
+    @property
     def in_mlpC(self) -> int:
-        return 2 * self.view_pe * 3 + 2 * self.fea_pe * self.app_dim + 3 + self.app_dim
+        if self.shadingMode == "RGB":
+            return 0
+        return 2 * self.view_pe * 3 + 2 * self.head_fea_pe * self.app_dim + 3 + self.app_dim
 
 
 RICOH = dict(near=0.1, far=300.0, r0=0.05, density_shift=-10.0, use_envmap=True, envmap_res_H=1920)
@@ -158,9 +168,10 @@ def make_weights(cfg: SceneConfig, seed: int = 1234, mlp_gain: float = 3.0) -> D
 
     linear("basis_mat_yin", cfg.app_dim, sum(cfg.app_n_comp), False, 9000)
     linear("basis_mat_yang", cfg.app_dim, sum(cfg.app_n_comp), False, 9010)
-    linear("renderModule.mlp.0", cfg.featureC, cfg.in_mlpC, True, 9020)
-    linear("renderModule.mlp.2", cfg.featureC, cfg.featureC, True, 9030)
-    linear("renderModule.mlp.4", 3, cfg.featureC, True, 9040, zero_bias=True)  # tensorBase.py:66
+    if cfg.shadingMode != "RGB":   # RGBRender is a plain function: no parameters (tensorBase.py:37-39)
+        linear("renderModule.mlp.0", cfg.featureC, cfg.in_mlpC, True, 9020)
+        linear("renderModule.mlp.2", cfg.featureC, cfg.featureC, True, 9030)
+        linear("renderModule.mlp.4", 3, cfg.featureC, True, 9040, zero_bias=True)  # tensorBase.py:66
     if cfg.use_envmap:
         h = cfg.envmap_res_H
         out["envmap.emission"] = (smooth_field(seed, 9100, 3, 2 * h, h, lattice=24) * 1.5).astype(np.float32)
@@ -205,6 +216,24 @@ def white_envmap(seed: int, h: int) -> np.ndarray:
     return ((hash_uniform(seed, 7, 3 * 2 * h * h) * 6 - 3).reshape(3, 2 * h, h)).astype(np.float32)
 
 
+def psnr_target(ref_rgb: np.ndarray, seed: int = 77, target_db: float = 30.0) -> np.ndarray:
+    """A synthetic ground truth at ~`target_db` PSNR from a rendered image: clamp(ref + sigma * N(0,1), 0, 1), integer-hash noise.
+    Lets a test state the north_star's PSNR clause directly: PSNR(candidate, gt) - PSNR(reference, gt) on a realistic ~30 dB target."""
+    ref = np.asarray(ref_rgb, np.float64)
+    sigma = 10.0 ** (-target_db / 20.0)
+    return np.clip(ref + sigma * hash_normal(seed, 11, ref.size).reshape(ref.shape), 0.0, 1.0)
+
+
+def delta_psnr(candidate_rgb, reference_rgb, seed: int = 77, target_db: float = 30.0) -> Tuple[float, float, float]:
+    """(PSNR(candidate, gt) - PSNR(reference, gt), PSNR(candidate, gt), PSNR(reference, gt)) in dB, float64, with
+    gt = psnr_target(reference) and PSNR = -10 log10(mean((img - gt)^2)) as renderer.py:156-157 computes it."""
+    cand, ref = np.asarray(candidate_rgb, np.float64), np.asarray(reference_rgb, np.float64)
+    gt = psnr_target(ref, seed, target_db)
+    p_c = -10.0 * np.log10(np.mean((cand - gt) ** 2))
+    p_r = -10.0 * np.log10(np.mean((ref - gt) ** 2))
+    return float(p_c - p_r), float(p_c), float(p_r)
+
+
 def make_rays(n: int, seed: int = 1, origin_extent: float = 0.25) -> np.ndarray:
     """[n,6] fp32: o ~ U(-e,e)^3, d = normalised approx-normal vector (sqrt is IEEE-exact)."""
     o = (hash_uniform(seed, 1, n * 3).reshape(n, 3) * 2 - 1) * origin_extent
@@ -246,7 +275,7 @@ def build_model(cfg: "SceneConfig", weights, device="cuda"):
     assert coords.resolution == cfg.grid
     model = EgoNeRF(torch.from_numpy(cfg.aabb), cfg.grid, device, coords, density_n_comp=list(cfg.density_n_comp),
                     appearance_n_comp=list(cfg.app_n_comp), app_dim=cfg.app_dim, near_far=[cfg.near, cfg.far],
-                    shadingMode="MLP_Fea", alphaMask_thres=1e-4, density_shift=cfg.density_shift,
+                    shadingMode=cfg.shadingMode, alphaMask_thres=1e-4, density_shift=cfg.density_shift,
                     distance_scale=cfg.distance_scale, pos_pe=6, view_pe=cfg.view_pe, fea_pe=cfg.fea_pe, featureC=cfg.featureC,
                     step_ratio=0.5, fea2denseAct="softplus", use_envmap=cfg.use_envmap, envmap_res_H=cfg.envmap_res_H,
                     coarse_sigma_grid_update_rule="conv", coarse_sigma_grid_reso=None, interval_th=cfg.interval_th)

@@ -141,15 +141,16 @@ def head_is_tuned(model) -> bool:
     """True when the appearance head has the shape the MFMA kernels (forward dumps, ego_shade_backward, ego_scatter_app) are built for:
     48 components, app_dim 27, MLP_Fea 150 -> 128 -> 128 -> 3 with view_pe = fea_pe = 2.  (The density field's component count is
     independent: 16 takes ego_scatter_density, anything else ego_scatter_generic.)"""
-    return (model.app_dim, model.app_n_comp[0], model.featureC, model.view_pe, model.fea_pe) == (27, 48, 128, 2, 2)
+    return model.head_is_tuned
 
 
 def differentiable_params(model) -> List[torch.nn.Parameter]:
     """Fixed order: 12 density tables, 12 appearance tables, basis yin/yang, mlp (w0,b0,w1,b1,w2,b2)."""
-    m = model.renderModule.mlp
-    return (table_params(model, "density") + table_params(model, "app") +
-            [model.basis_mat_yin.weight, model.basis_mat_yang.weight, m[0].weight, m[0].bias, m[2].weight, m[2].bias,
-             m[4].weight, m[4].bias])
+    head = [model.basis_mat_yin.weight, model.basis_mat_yang.weight]
+    if model.shadingMode != "RGB":   # RGBRender has no parameters (tensorBase.py:37-39)
+        m = model.renderModule.mlp
+        head += [m[0].weight, m[0].bias, m[2].weight, m[2].bias, m[4].weight, m[4].bias]
+    return table_params(model, "density") + table_params(model, "app") + head
 
 
 class RenderFunction(torch.autograd.Function):
@@ -212,12 +213,15 @@ class RenderFunction(torch.autograd.Function):
         else:
             # any other model shape (opt.py:87-100): fp32 compatibility kernels over row-major dumps, padded to whole 160-column
             # blocks (what ego_weight_grad multiplies at a time) with at least one zero column left for the bias gradients
-            in_c = model.renderModule.in_mlpC
+            in_c = model.head_in_mlpC
             ldx = (in_c // _G_LD + 1) * _G_LD
             z0 = lambda *shape: torch.zeros(*shape, device=dev, dtype=torch.float32)
-            dump = dict(x=z0(M, ldx), h1=z0(M, _G_LD), h2=z0(M, _G_LD), v=z0(M, _G_LD))
-            _chk(lib.ego_shade_train_generic(sc, rays.data_ptr(), coords.data_ptr(), N, S, rgb.data_ptr(), dump["x"].data_ptr(), ldx,
-                                             dump["h1"].data_ptr(), dump["h2"].data_ptr(), _G_LD, dump["v"].data_ptr(), _G_LD, st),
+            if model.shadingMode == "RGB":   # no network: only the plane x line products are kept (they feed the basis gradient)
+                dump = dict(x=None, h1=None, h2=None, v=z0(M, _G_LD))
+            else:
+                dump = dict(x=z0(M, ldx), h1=z0(M, _G_LD), h2=z0(M, _G_LD), v=z0(M, _G_LD))
+            _chk(lib.ego_shade_train_generic(sc, rays.data_ptr(), coords.data_ptr(), N, S, rgb.data_ptr(), _lib.ptr(dump["x"]), ldx,
+                                             _lib.ptr(dump["h1"]), _lib.ptr(dump["h2"]), _G_LD, dump["v"].data_ptr(), _G_LD, st),
                  "ego_shade_train_generic")
         rgb_map, depth, raw = f(N, 3), f(N), f(N, 3)
         has_env = model.envmap is not None
@@ -341,11 +345,12 @@ class RenderFunction(torch.autograd.Function):
     def _backward_generic_head(ctx, lib, st, model, N, S, sv, dev, M, sc, g_rgb, g_dens, g_app, dc, main, side, on_side, f):
         """Backward of the appearance head for any model shape the compatibility kernels support (row-major buffers; the weight
         gradients are A^T B products in 160-column blocks, already in the reference's [out][in] orientation)."""
-        hid, in_c, ncol, D = model.featureC, model.renderModule.in_mlpC, 3 * model.app_n_comp[0], model.app_dim
-        ldx = sv["x"].shape[1]
-        dh2, dh1, dfe, dv = f(M, hid), f(M, hid), f(M, 64), f(M, _G_LD)
-        _chk(lib.ego_shade_backward_generic(sc, sv["coords"].data_ptr(), dc.data_ptr(), sv["rgb"].data_ptr(), sv["x"].data_ptr(), ldx,
-                                            sv["h1"].data_ptr(), sv["h2"].data_ptr(), _G_LD, dh2.data_ptr(), dh1.data_ptr(), dfe.data_ptr(),
+        hid, in_c, ncol, D = model.head_hidden, model.head_in_mlpC, 3 * model.app_n_comp[0], model.app_dim
+        rgb_head = model.shadingMode == "RGB"
+        ldx = _G_LD if rgb_head else sv["x"].shape[1]
+        dh2, dh1, dfe, dv = (None if rgb_head else f(M, hid)), (None if rgb_head else f(M, hid)), f(M, 64), f(M, _G_LD)
+        _chk(lib.ego_shade_backward_generic(sc, sv["coords"].data_ptr(), dc.data_ptr(), sv["rgb"].data_ptr(), _lib.ptr(sv["x"]), ldx,
+                                            _lib.ptr(sv["h1"]), _lib.ptr(sv["h2"]), _G_LD, _lib.ptr(dh2), _lib.ptr(dh1), dfe.data_ptr(),
                                             dv.data_ptr(), _G_LD, N, S, st), "ego_shade_backward_generic")
         ga = _grad_struct(g_app)
         on_side(lambda s_: _chk(lib.ego_scatter_generic(C.byref(sc.app), C.byref(ga), sv["coords"].data_ptr(), dv.data_ptr(), _G_LD, N, S, s_),
@@ -358,17 +363,19 @@ class RenderFunction(torch.autograd.Function):
             _chk(lib.ego_weight_grad(A.data_ptr(), lda, ca, 0, None, B_ptr, ldb, _G_LD, 0, ones_col, M, G.data_ptr(), _G_LD, st), "ego_weight_grad")
             return G
 
-        G3 = product(dc.view(M, 3), 3, 3, sv["h2"].data_ptr(), _G_LD, hid, 32)          # do^T [h2 | 1]
-        G2 = product(dh2, hid, hid, sv["h1"].data_ptr(), _G_LD, hid, hp)                  # dh2^T [h1 | 1]
-        G1 = []
-        for c in range(n_chunks):
-            c0 = c * _G_LD
-            ones = in_c - c0 if c0 <= in_c < c0 + _G_LD else -1                          # the first zero-padding column doubles as the ones column
-            G1.append(product(dh1, hid, hid, sv["x"].data_ptr() + 4 * c0, ldx, ones, hp))
         Gb = product(dfe, 64, 64, sv["v"].data_ptr(), _G_LD, -1, 64)                      # [yin | yang] feature gradients ^T v
-        G1 = torch.cat(G1, dim=1)
-        wg = [Gb[0:D, :ncol].contiguous(), Gb[32:32 + D, :ncol].contiguous(), G1[:hid, :in_c].contiguous(), G1[:hid, in_c].contiguous(),
-              G2[:hid, :hid].contiguous(), G2[:hid, hid].contiguous(), G3[:3, :hid].contiguous(), G3[:3, hid].contiguous()]
+        wg = [Gb[0:D, :ncol].contiguous(), Gb[32:32 + D, :ncol].contiguous()]
+        if not rgb_head:
+            G3 = product(dc.view(M, 3), 3, 3, sv["h2"].data_ptr(), _G_LD, hid, 32)          # do^T [h2 | 1]
+            G2 = product(dh2, hid, hid, sv["h1"].data_ptr(), _G_LD, hid, hp)                  # dh2^T [h1 | 1]
+            G1 = []
+            for c in range(n_chunks):
+                c0 = c * _G_LD
+                ones = in_c - c0 if c0 <= in_c < c0 + _G_LD else -1                          # the first zero-padding column doubles as the ones column
+                G1.append(product(dh1, hid, hid, sv["x"].data_ptr() + 4 * c0, ldx, ones, hp))
+            G1 = torch.cat(G1, dim=1)
+            wg += [G1[:hid, :in_c].contiguous(), G1[:hid, in_c].contiguous(), G2[:hid, :hid].contiguous(), G2[:hid, hid].contiguous(),
+                   G3[:3, :hid].contiguous(), G3[:3, hid].contiguous()]
         grads = g_dens + g_app + wg
         if sv["env"] is not None:
             g_em = torch.zeros_like(model.envmap.emission)

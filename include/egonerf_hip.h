@@ -42,9 +42,11 @@
 extern "C" {
 #endif
 
-#define EGO_ABI_VERSION 12
+#define EGO_ABI_VERSION 13
 
 enum { EGO_PREC_F16X3 = 0, EGO_PREC_F32 = 1, EGO_PREC_F16F8 = 2, EGO_PREC_F16F6 = 3 };
+/* ego_scene.head: the appearance head TensorBase.init_render_func selected (models/tensorBase.py:186-200) */
+enum { EGO_HEAD_MLP_FEA = 0, EGO_HEAD_RGB = 1 };
 
 enum {
   EGO_OK = 0,
@@ -133,6 +135,12 @@ typedef struct ego_scene {
    * voxels is set.  The march then decides "mask value > 0" for a sample strictly inside a cell from this one byte (identical result:
    * all eight trilinear weights are positive there) and keeps the eight-tap evaluation for samples on lattice planes / outside. */
   const uint8_t* occ_cell;
+  /* Appearance head (models/tensorBase.py:186-200).  EGO_HEAD_MLP_FEA (0): MLPRender_Fea (tensorBase.py:54-78); shadingMode 'MLP'
+   * (MLPRender, tensorBase.py:107-129) is the same network with fea_pe = 0, i.e. mlp_in = 3 + 6 view_pe + app_dim.  EGO_HEAD_RGB (1):
+   * RGBRender (tensorBase.py:37-39): the per-sample colour is the 3-channel appearance feature itself (no MLP, no sigmoid; app_dim must be
+   * 3, mlp_in = mlp_hidden = 0, mlp_w / mlp_b unused).  'MLP_PE' cannot run in EgoNeRF.forward (it is handed 7-column coordinates for a
+   * 3-column encoding), 'SH' crashes there too (its stage op is ego_sh_render). */
+  int32_t head;
 } ego_scene;
 
 /* number of floats ego_pack_mlp writes: the packed weight blob used by ego_shade / ego_mlp_fea / ego_app_feature

@@ -65,7 +65,7 @@ def build_reference(cfg: synth.SceneConfig, weights):
         assert reso == cfg.grid, (reso, cfg.grid)
         model = EgoNeRF(aabb, reso, "cpu", coords, density_n_comp=list(cfg.density_n_comp),
                         appearance_n_comp=list(cfg.app_n_comp), app_dim=cfg.app_dim, near_far=[cfg.near, cfg.far],
-                        shadingMode="MLP_Fea", alphaMask_thres=1e-4, density_shift=cfg.density_shift,
+                        shadingMode=cfg.shadingMode, alphaMask_thres=1e-4, density_shift=cfg.density_shift,
                         distance_scale=cfg.distance_scale, pos_pe=6, view_pe=cfg.view_pe, fea_pe=cfg.fea_pe,
                         featureC=cfg.featureC, step_ratio=0.5, fea2denseAct="softplus", use_envmap=cfg.use_envmap,
                         envmap_res_H=cfg.envmap_res_H, coarse_sigma_grid_update_rule="conv",
@@ -732,9 +732,58 @@ def capture_shapes_grad():
     np.savez_compressed(os.path.join(OUT, "shapes_grad.npz"), **fx)
 
 
+HEADS = {   # the other appearance heads EgoNeRF.forward runs with (tensorBase.py:186-200); `fea_pe` is what opt.py passes, MLPRender ignores it
+    "mlp_head": dict(shadingMode="MLP", app_dim=27, view_pe=2, fea_pe=2, featureC=128),
+    "mlp_head_small": dict(shadingMode="MLP", density_n_comp=(8, 8, 8), app_n_comp=(24, 24, 24), app_dim=12, view_pe=6, fea_pe=6, featureC=64),
+    "rgb_head": dict(shadingMode="RGB", app_dim=3),
+}
+
+
+def capture_heads():
+    """shadingMode 'MLP' (MLPRender, tensorBase.py:107-129) and 'RGB' (RGBRender, :37-39) through the reference's EgoNeRF.forward on the
+    tiny grid: per-sample colours, the end-to-end render in both resampling modes (envmap on for the RGB head), and the autograd
+    gradients of every parameter for the is_train render with pinned noise + MSE (train.py:312-314)."""
+    fx = {}
+    for name, kw in HEADS.items():
+        cfg = synth.SceneConfig(n_voxel=20 ** 3, use_envmap=(name == "rgb_head"), envmap_res_H=16, **kw)
+        weights = synth.make_weights(cfg, seed=2468)
+        model, coords = build_reference(cfg, weights)
+        rays = torch.from_numpy(synth.make_rays(48, seed=19))
+        M = 256
+        u = torch.from_numpy(synth.hash_uniform(96, 0, M * 7).reshape(M, 7).astype(np.float32))
+        q = u * 2.6 - 1.3
+        q[:, 6] = (u[:, 6] > 0.5).float()
+        af = model.compute_appfeature(q)
+        dirs = torch.nn.functional.normalize(torch.from_numpy(synth.hash_uniform(95, 0, M * 3).reshape(M, 3).astype(np.float32)) * 2 - 1, dim=-1)
+        fx.update({f"{name}/coords": np_(q), f"{name}/dirs": np_(dirs), f"{name}/app": np_(af),
+                   f"{name}/rgb_samples": np_(model.renderModule(q, dirs, af))})
+        o = run_forward(model, rays, n_coarse=24, n_fine=0, resampling=False)
+        fx.update({f"{name}/nr_rgb": np_(o[0]), f"{name}/nr_depth": np_(o[1]), f"{name}/nr_alpha": np_(o[4])})
+        o = run_forward(model, rays, n_coarse=16, n_fine=16, resampling=True, use_coarse_sample=True)
+        fx.update({f"{name}/rs_rgb": np_(o[0]), f"{name}/rs_depth": np_(o[1])})
+        # autograd
+        model.train()
+        jit = torch.from_numpy(synth.hash_uniform(25, 0, 48 * 16).reshape(48, 16).astype(np.float32))
+        uu = torch.from_numpy(synth.hash_uniform(25, 1, 48 * 16).reshape(48, 16).astype(np.float32))
+        gt = torch.from_numpy(synth.hash_uniform(26, 0, 48 * 3).reshape(48, 3).astype(np.float32))
+        model.zero_grad()
+        with patched_rand([jit], [uu]):
+            o = run_forward(model, rays, n_coarse=16, n_fine=16, resampling=True, use_coarse_sample=True, is_train=True)
+        loss = torch.mean((o[0] - gt) ** 2)
+        loss.backward()
+        fx.update({f"{name}/jitter": np_(jit), f"{name}/u": np_(uu), f"{name}/gt": np_(gt), f"{name}/train_rgb": np_(o[0]),
+                   f"{name}/loss": np.float32(loss.item())})
+        for k, p in model.named_parameters():
+            fx[f"{name}/grad/{k}"] = np_(p.grad if p.grad is not None else torch.zeros_like(p))
+        if cfg.use_envmap:
+            fx[f"{name}/grad/envmap.emission"] = np_(model.envmap.emission.grad)
+    fx["seed_weights"], fx["seed_rays"] = 2468, 19
+    np.savez_compressed(os.path.join(OUT, "heads.npz"), **fx)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
-    which = sys.argv[1:] or ["tiny", "stages", "full", "alpha_mask", "checkpoint", "train_extras", "metrics", "plainexp", "sh", "uniform", "ricoh", "envmap_full", "ws", "skip", "omniblender", "shapes"]
+    which = sys.argv[1:] or ["tiny", "stages", "full", "alpha_mask", "checkpoint", "train_extras", "metrics", "plainexp", "sh", "uniform", "ricoh", "envmap_full", "ws", "skip", "omniblender", "shapes", "shapes_grad", "heads"]
     for name in which:
         globals()["capture_" + name]()
         print("captured", name)

@@ -283,9 +283,12 @@ class OracleScene:
         return torch.cat([torch.sin(p), torch.cos(p)], -1)
 
     def mlp_fea(self, viewdirs: torch.Tensor, feat: torch.Tensor) -> torch.Tensor:
-        """MLPRender_Fea.forward (tensorBase.py:68-78); 150 -> 128 -> 128 -> 3, sigmoid."""
+        """MLPRender_Fea.forward (tensorBase.py:68-78); 150 -> 128 -> 128 -> 3, sigmoid.  shadingMode "MLP" = MLPRender.forward
+        (tensorBase.py:121-129): the same network without the feature encoding; "RGB" = RGBRender (tensorBase.py:37-39): the features."""
         c = self.cfg
-        x = torch.cat([feat, viewdirs, self.positional_encoding(feat, c.fea_pe),
+        if getattr(c, "shadingMode", "MLP_Fea") == "RGB":
+            return feat
+        x = torch.cat([feat, viewdirs, self.positional_encoding(feat, getattr(c, "head_fea_pe", c.fea_pe)),
                        self.positional_encoding(viewdirs, c.view_pe)], -1)
         h = F.relu(F.linear(x, self.w["renderModule.mlp.0.weight"], self.w["renderModule.mlp.0.bias"]))
         h = F.relu(F.linear(h, self.w["renderModule.mlp.2.weight"], self.w["renderModule.mlp.2.bias"]))

@@ -1,0 +1,125 @@
+"""The other appearance heads EgoNeRF.forward runs with (tensorBase.py:186-200): shadingMode 'MLP' (MLPRender,
+tensorBase.py:107-129: MLPRender_Fea without the feature encoding, same state-dict keys) and 'RGB' (RGBRender, :37-39: colour = the three
+appearance features, no sigmoid, no parameters), against tests/golden/heads.npz captured from the real reference
+(oracle/capture_golden.py::capture_heads): the oracle's restatement on CPU, the HIP path on the GPU through the same Python surface."""
+import numpy as np
+import pytest
+import torch
+
+from egonerf_amd import synth
+from tests.helpers import make_model, make_oracle
+
+T = torch.from_numpy
+HEADS = {   # keep in step with oracle/capture_golden.py::HEADS
+    "mlp_head": dict(shadingMode="MLP", app_dim=27, view_pe=2, fea_pe=2, featureC=128),
+    "mlp_head_small": dict(shadingMode="MLP", density_n_comp=(8, 8, 8), app_n_comp=(24, 24, 24), app_dim=12, view_pe=6, fea_pe=6, featureC=64),
+    "rgb_head": dict(shadingMode="RGB", app_dim=3),
+}
+TRAIN_KW = dict(n_coarse=16, n_fine=16, resampling=True)
+
+
+def _cfg(name):
+    return synth.SceneConfig(n_voxel=20 ** 3, use_envmap=(name == "rgb_head"), envmap_res_H=16, **HEADS[name])
+
+
+def _grad_keys(fx, name):
+    pre = f"{name}/grad/"
+    return [k[len(pre):] for k in fx.files if k.startswith(pre)]
+
+
+@pytest.mark.parametrize("name", list(HEADS))
+def test_oracle_reproduces_the_reference_heads(golden, name):
+    fx = golden("heads")
+    cfg = _cfg(name)
+    sc = make_oracle(cfg, synth.make_weights(cfg, seed=int(fx["seed_weights"])))
+    rays = T(synth.make_rays(48, seed=int(fx["seed_rays"])))
+    q, dirs = T(fx[f"{name}/coords"]), T(fx[f"{name}/dirs"])
+    af = sc.app_feature(q)
+    assert af.shape[-1] == cfg.app_dim and float((af - T(fx[f"{name}/app"])).abs().max()) <= 2e-5
+    assert float((sc.mlp_fea(dirs, T(fx[f"{name}/app"])) - T(fx[f"{name}/rgb_samples"])).abs().max()) <= 2e-6
+    rgb, depth, _, _, alpha = sc.forward(rays, n_coarse=24)
+    assert float((rgb - T(fx[f"{name}/nr_rgb"])).abs().max()) <= 2e-6 and float((alpha - T(fx[f"{name}/nr_alpha"])).abs().max()) <= 1e-5
+    rgb, depth, *_ = sc.forward(rays, n_coarse=16, n_fine=16, resampling=True)
+    assert float((rgb - T(fx[f"{name}/rs_rgb"])).abs().max()) <= 5e-6 and float((depth - T(fx[f"{name}/rs_depth"])).abs().max()) <= 5e-5
+
+
+@pytest.mark.parametrize("name", list(HEADS))
+def test_oracle_autograd_reproduces_the_reference_gradients_of_the_heads(golden, name):
+    fx = golden("heads")
+    cfg = _cfg(name)
+    sc = make_oracle(cfg, synth.make_weights(cfg, seed=int(fx["seed_weights"])))
+    for v in sc.w.values():
+        v.requires_grad_(True)
+    sc.update_coarse_sigma_grid()
+    rays = T(synth.make_rays(48, seed=int(fx["seed_rays"])))
+    rgb = sc.forward(rays, is_train=True, jitter=T(fx[f"{name}/jitter"]), u=T(fx[f"{name}/u"]), **TRAIN_KW)[0]
+    assert float((rgb.detach() - T(fx[f"{name}/train_rgb"])).abs().max()) <= 2e-6
+    torch.mean((rgb - T(fx[f"{name}/gt"])) ** 2).backward()
+    keys = _grad_keys(fx, name)
+    assert ("renderModule.mlp.0.weight" in keys) == (name != "rgb_head")     # RGBRender has no parameters
+    for k in keys:
+        ref = fx[f"{name}/grad/{k}"]
+        assert float((sc.w[k].grad - T(ref)).abs().max()) <= 5e-5 * max(float(np.abs(ref).max()), 1e-12), k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", list(HEADS))
+def test_hip_renders_the_other_heads_like_the_reference(golden, name):
+    fx = golden("heads")
+    cfg = _cfg(name)
+    model = make_model(cfg, synth.make_weights(cfg, seed=int(fx["seed_weights"])), "cuda")
+    assert model.shadingMode == HEADS[name]["shadingMode"] and model.get_kwargs()["shadingMode"] == model.shadingMode
+    assert type(model.renderModule).__name__ == {"MLP": "MLPRender", "RGB": "RGBRender"}[model.shadingMode]
+    sd = model.state_dict()
+    assert ("renderModule.mlp.0.weight" in sd) == (name != "rgb_head")
+    rays = T(synth.make_rays(48, seed=int(fx["seed_rays"]))).cuda()
+    q, dirs = T(fx[f"{name}/coords"]).cuda(), T(fx[f"{name}/dirs"]).cuda()
+    with torch.no_grad():
+        af = model.compute_appfeature(q)
+        assert float((af.cpu() - T(fx[f"{name}/app"])).abs().max()) <= 2e-5
+        rgb_s = model.renderModule(None, dirs, T(fx[f"{name}/app"]).cuda())
+        assert float((rgb_s.cpu() - T(fx[f"{name}/rgb_samples"])).abs().max()) <= 1e-5
+        rgb, depth, bg, env, alpha = model(rays, n_coarse=24, exp_sampling=True)
+        assert float((rgb.cpu() - T(fx[f"{name}/nr_rgb"])).abs().max()) <= 1e-4      # north_star tolerance; measured ~1e-6
+        assert float((alpha.cpu() - T(fx[f"{name}/nr_alpha"])).abs().max()) <= 1e-4
+        assert float((depth.cpu() - T(fx[f"{name}/nr_depth"])).abs().max()) <= 1e-3
+        rgb, depth, *_ = model(rays, n_coarse=16, n_fine=16, exp_sampling=True, resampling=True)
+        assert float((rgb.cpu() - T(fx[f"{name}/rs_rgb"])).abs().max()) <= 1e-4
+        assert float((depth.cpu() - T(fx[f"{name}/rs_depth"])).abs().max()) <= 1e-3
+        # ragged sizes + tile skip on an opaque field, against the oracle
+        cfg2 = synth.SceneConfig(n_voxel=20 ** 3, density_shift=0.0, **HEADS[name])
+        w2 = synth.make_weights(cfg2, seed=5)
+        m2, o2 = make_model(cfg2, w2, "cuda"), make_oracle(cfg2, w2)
+        r2 = T(synth.make_rays(333, seed=3))
+        got = m2(r2.cuda(), n_coarse=37, exp_sampling=True)
+        ref = o2.forward(r2, n_coarse=37)
+        assert float((got[0].cpu() - ref[0]).abs().max()) <= 1e-4 and float((got[4].cpu() - ref[4]).abs().max()) <= 1e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", list(HEADS))
+def test_training_gradients_of_the_other_heads_vs_reference_autograd(golden, name):
+    fx = golden("heads")
+    cfg = _cfg(name)
+    model = make_model(cfg, synth.make_weights(cfg, seed=int(fx["seed_weights"])), "cuda")
+    model.train()
+    rays = T(synth.make_rays(48, seed=int(fx["seed_rays"]))).cuda()
+    rgb, depth, _, _, alpha = model(rays, is_train=True, exp_sampling=True, use_coarse_sample=True, jitter=T(fx[f"{name}/jitter"]).cuda(),
+                                    u=T(fx[f"{name}/u"]).cuda(), **TRAIN_KW)
+    assert rgb.requires_grad and float((rgb.detach().cpu() - T(fx[f"{name}/train_rgb"])).abs().max()) <= 1e-4
+    loss = torch.mean((rgb - T(fx[f"{name}/gt"]).cuda()) ** 2)
+    assert abs(loss.item() - float(fx[f"{name}/loss"])) <= 1e-6
+    loss.backward()
+    named = dict(model.named_parameters())
+    if cfg.use_envmap:
+        named["envmap.emission"] = model.envmap.emission
+    assert sorted(named) == sorted(_grad_keys(fx, name))
+    for k, p in named.items():
+        ref = fx[f"{name}/grad/{k}"]
+        assert p.grad is not None, k
+        g = p.grad.detach().cpu().numpy()
+        assert g.shape == ref.shape, k
+        # 2e-4 of the tensor's largest gradient against the reference's float32 autograd (as tests/test_model_shapes.py)
+        assert float(np.abs(g - ref).max()) <= 2e-4 * max(float(np.abs(ref).max()), 1e-12), k
+    from egonerf_amd.optim import FusedAdam
+    FusedAdam(model.get_optparam_groups(0.02, 1e-3), betas=(0.9, 0.99)).step()

@@ -100,25 +100,40 @@ def test_row_sharded_ssim_and_ws_metrics_equal_single_process(world):
             assert abs(got[0] - ref[0]) <= 1e-9, (ev, single)
 
 
-def _bench(*args, env_extra=None):
-    env = dict(os.environ, **(env_extra or {}))
-    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), *args], capture_output=True, text=True, timeout=1500, env=env)
-    assert r.returncode == 0, r.stderr[-3000:]
-    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, r.stdout[-2000:]  # rank 0 prints ONE JSON line
-    return json.loads(lines[0])
+def _check_compact(line: str, full: dict) -> dict:
+    """The stdout line is what the driver parses out of an 8 KB tail: compact, strict JSON, the contract's keys, agreeing with the full record."""
+    assert len(line.encode()) < 6000, len(line)
+    d = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+              "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert "workload" in d["config"] and d["steps"] == full["steps"] and d["n_gpus"] == full["n_gpus"]
+    assert abs(d["value"] - full["value"]) <= 1e-5 * full["value"] and abs(d["ms_per_step"] - full["ms_per_step"]) <= 1e-5 * full["ms_per_step"]
+    return d
+
+
+def _bench(*args, env_extra=None, launcher=None, env=None):
+    """Runs bench.py; returns the FULL record (--full-out) after checking the compact stdout line against it."""
+    import tempfile
+    env = dict(os.environ if env is None else env, **(env_extra or {}))
+    with tempfile.TemporaryDirectory() as tmp:
+        full_path = os.path.join(tmp, "full.json")
+        cmd = (launcher or [sys.executable]) + [os.path.join(REPO, "bench.py"), *args, "--full-out", full_path]
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, env=env)
+        assert r.returncode == 0, r.stderr[-3000:]
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1, r.stdout[-2000:]  # rank 0 prints ONE JSON line
+        assert r.stdout.rstrip().splitlines()[-1] == lines[0]   # and it is the LAST line of stdout
+        full = json.load(open(full_path))
+    full["_compact"] = _check_compact(lines[0], full)
+    return full
 
 
 def test_bench_self_launches_two_ranks():
     """`python bench.py --gpus 2` with no launcher environment re-executes itself through torch.distributed.run."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env["EGO_BENCH_TEST_SHARED_GPU"] = "1"
-    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2"],
-                       capture_output=True, text=True, timeout=1500, env=env)
-    assert r.returncode == 0, r.stderr[-3000:]
-    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1
-    d = json.loads(lines[0])
+    d = _bench("--gpus", "2", "--steps", "5", "--warmup", "2", env=env)
     assert d["n_gpus"] == 2 and d["steps"] == 5 and d["scaling"] == "weak" and d["cpu_baseline"] is None
     assert d["value"] > 0 and abs(d["value"] - 2 * 4096 * 5 / (d["ms_per_step"] * 5e-3)) / d["value"] < 1e-9
     assert d["roofline"]["frac"] <= 1.0 and d["roofline"]["bound"] == "mfma" and "secondary" not in d and d["process_group"] == "gloo"
@@ -197,11 +212,7 @@ def test_bench_erp_eight_ranks_dry_run_on_one_gpu():
     one = _bench(*args)
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env["EGO_BENCH_TEST_SHARED_GPU"] = "1"
-    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "8", *args], capture_output=True, text=True, timeout=1500, env=env)
-    assert r.returncode == 0, r.stderr[-3000:]
-    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1
-    d = json.loads(lines[0])
+    d = _bench("--gpus", "8", *args, env=env)
     assert d["n_gpus"] == 8 and d["scaling"] == "strong" and d["process_group"] == "gloo"
     assert d["row_shards"] == [[64 * k, 64 * (k + 1)] for k in range(8)]     # 512 rows over 8 ranks, contiguous blocks
     assert d["psnr_identical_on_all_ranks"] is True

@@ -91,10 +91,10 @@ def test_bench_erp_under_a_one_rank_rccl_launcher():
         env.pop(k, None)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(REPO, "bench.py"), "--gpus", "1", "--config", "erp", "--erp-size", "128", "256",
-           "--steps", "1", "--warmup", "1", "--no-cpu-baseline"]
+           "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--full-out", os.devnull]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, r.stdout[-2000:]
+    assert len(lines) == 1 and len(lines[0]) < 6000, r.stdout[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["value"] > 0 and d["psnr_vs_f32_unskipped_db"][0] > 80 and d["process_group"] == "nccl"
