@@ -86,6 +86,9 @@ def parse():
                     "step) instead of re-rendering one batch; with --n-voxel / --fresh-rays the lean variant line is printed (no alt precisions)")
     ap.add_argument("--full-out", default=None, metavar="PATH", help="where the FULL record goes (default: bench_full.json next to bench.py, and "
                     "gpurun_out/bench_full.json when that directory exists); stdout carries only the compact line (< 6 KB)")
+    ap.add_argument("--shape", type=int, nargs=3, default=None, metavar=("RAYS", "N_COARSE", "N_FINE"), help="render: another batch shape on the "
+                    "headline scene, e.g. 256 64 0 (BASELINE configs[0]) or 4096 256 256 (SURVEY 8(d) Config 2's resampling secondary: the path "
+                    "every shipped config uses, configs/EgoNeRF/common.txt:15-23); N_FINE > 0 = inverse-CDF resampling, coarse samples kept")
     ap.add_argument("--cpu-worker", nargs=2, type=int, metavar=("N_RAYS", "THREADS"), help=argparse.SUPPRESS)
     a = ap.parse_args()
     dflt = dict(render=(200, 10), train=(20, 3), erp=(4, 1))[a.config]  # render: 0.7 ms steps, amortise the barrier bracket
@@ -677,6 +680,89 @@ def run_render_variant(a, rk: Ranks):
                 roofline=roofline, cpu_baseline=None)
 
 
+def run_render_shape(a, rk: Ranks):
+    """`--shape RAYS N_COARSE N_FINE` on the headline scene: BASELINE configs[0] (256 x 64, the reference's own CPU-runnable case) and
+    SURVEY 8(d) Config 2's secondary (4096 x (256 + 256), resampling on - what every shipped config runs, configs/EgoNeRF/common.txt:15-23).
+    A step = one EgoNeRF.forward over one resident batch; per-kernel split through the stage entry points; parity and cpu_baseline
+    against the oracle on the same rays."""
+    from egonerf_amd import _lib
+    dev = rk.dev
+    N, nc, nf = (int(v) for v in a.shape)
+    cfg = synth.SceneConfig()
+    weights = synth.make_weights(cfg, seed=1234)
+    model = synth.build_model(cfg, weights, dev)
+    rays = torch.from_numpy(synth.make_rays(N, seed=1 + rk.rank)).to(dev)
+    kw = dict(n_coarse=nc, exp_sampling=True) if nf == 0 else dict(n_coarse=nc, n_fine=nf, resampling=True, use_coarse_sample=True, exp_sampling=True)
+    with torch.no_grad():
+        dt = timed(rk, lambda: model(rays, **kw), a.steps, a.warmup)
+    spread = rk.rank_step_ms(a.steps)
+    if rk.rank != 0:
+        return None
+    S = nc + nf
+    if nf:
+        split, skipped = erp_chunk_split(model, rays, reps=24, ERP_NC=nc, ERP_NF=nf)
+    else:
+        lib, st, sc = _lib.load(), _lib.stream_handle(), model.scene()
+        f = lambda *shape: torch.empty(*shape, device=dev, dtype=torch.float32)
+        sched = model._sched(nc, dev)
+        z, w, bg, crd, rgb, rgb_map, depth = f(N, S), f(N, S), f(N), f(N, S, 4), f(N, S, 3), f(N, 3), f(N)
+        act = torch.empty(N * S // 32 + 1, device=dev, dtype=torch.uint8)
+        evs = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(24)]
+        for i in range(26):
+            e = evs[max(i - 2, 0)]
+            e[0].record()
+            _lib.check(lib.ego_march_density(sc, rays.data_ptr(), N, S, None, sched.data_ptr(), None, cfg.near, 0, z.data_ptr(), None, 0, w.data_ptr(),
+                                             bg.data_ptr(), crd.data_ptr(), None, act.data_ptr(), st), "march")
+            e[1].record()
+            _lib.check(lib.ego_shade(sc, rays.data_ptr(), z.data_ptr(), crd.data_ptr(), N, S, rgb.data_ptr(), None, act.data_ptr(), st), "shade")
+            e[2].record()
+            _lib.check(lib.ego_composite(sc, rays.data_ptr(), z.data_ptr(), w.data_ptr(), bg.data_ptr(), rgb.data_ptr(), N, S, rgb_map.data_ptr(),
+                                         depth.data_ptr(), None, None, None, st), "composite")
+            e[3].record()
+        torch.cuda.synchronize()
+        ms = np.array([[e[k].elapsed_time(e[k + 1]) for k in range(3)] for e in evs]).mean(0)
+        split = {n: float(v) for n, v in zip(("k_march_density", "k_shade", "k_composite"), ms)}
+        skipped = float((act[: N * S // 32] == 0).float().mean()) if N * S >= 32 else 0.0
+    roofline = shade_roofline(model.mlp_precision, split["k_shade"] * 1e-3, N * S)
+    for k in ("issue", "l1", "inputs", "matrix_pipe_busy", "executed_TFLOPs"):   # derived from the 4096 x 512 launch's counters
+        roofline.pop(k, None)
+    roofline.update(traffic=None, hbm_counter_frac=None, kernels_ms=split, kernels_ms_sum=float(sum(split.values())),
+                    exact_zero_weight_tiles_skipped_frac=skipped,
+                    note="dominant kernel = k_shade; kernels_ms = the launches of one step, event timed through the stage entry points; a step of "
+                         "this size is partly launch-bound (ms_per_step vs kernels_ms_sum)")
+    cpu = parity = None
+    if not a.no_cpu_baseline and rk.world == 1:
+        from oracle.egonerf_oracle import OracleScene
+        threads = min(32, os.cpu_count() or 1)
+        torch.set_num_threads(threads)
+        n_cpu = min(N, 1024)
+        orc, r_cpu = OracleScene(cfg, weights), rays[:n_cpu].cpu()
+        okw = {k: v for k, v in kw.items() if k != "exp_sampling"}
+        best = float("inf")
+        with torch.no_grad():
+            for _ in range(2):
+                t0 = time.perf_counter()
+                ref = orc.forward(r_cpu, **okw)
+                best = min(best, time.perf_counter() - t0)
+            got = model(rays[:n_cpu], **kw)
+        err = float((got[0].cpu() - ref[0]).abs().max())
+        dp, p_hip, p_ref = synth.delta_psnr(got[0].cpu().clamp(0, 1).numpy(), ref[0].clamp(0, 1).numpy())
+        parity = dict(max_abs_rgb_err=err, delta_psnr_db=dp, psnr_hip_vs_gt_db=p_hip, psnr_ref_vs_gt_db=p_ref,
+                      max_abs_depth_err=float((got[1].cpu() - ref[1]).abs().max()), rays=n_cpu, tolerance=dict(rgb=1e-4, delta_psnr_db=1e-3))
+        cpu = dict(value=n_cpu / best, unit="rays/s", cores=threads, kind="port",
+                   sample=f"oracle render of {n_cpu} rays x ({nc}+{nf}) samples, best of 2 ({best:.2f} s) with {threads} ATen threads")
+    rays_per_s = rk.world * N * a.steps / dt
+    return dict(metric=f"rays/sec at {N}-ray batch, {nc}+{nf} samples (EgoNeRF volume-rendering forward)", value=rays_per_s, unit="rays/s",
+                samples_per_s=rays_per_s * S, n_gpus=rk.world, steps=a.steps, warmup=a.warmup, clock_ramp_s=RAMP_SECONDS,
+                ms_per_step=dt / a.steps * 1e3, rank_step_ms=spread, higher_is_better=True, scaling="weak", vs_baseline=None,
+                dtype="f32 (tables, interpolation, compositing; matrix products: mlp_precision = " + model.mlp_precision + ")", data="synthetic",
+                config=dict(workload=f"OmniBlender barbershop shape: grid {cfg.grid}, {N} rays x ({nc}+{nf}) samples, eval, "
+                                     + ("inverse-CDF resampling on (coarse samples kept)" if nf else "no resampling")
+                                     + (" (BASELINE configs[0] on the GPU)" if (N, nc, nf) == (256, 64, 0) else ""),
+                            rays_per_step_per_gpu=N, samples_per_ray=S, parallelism=f"ray-sharded x{rk.world}"),
+                roofline=roofline, cpu_baseline=cpu, parity=parity, speedup_vs_cpu=None if cpu is None else rays_per_s / cpu["value"])
+
+
 # =====================================================================================================
 # --config train (BASELINE configs[3])
 # =====================================================================================================
@@ -927,10 +1013,12 @@ def cpu_baseline_erp(cfg, weights, H: int, W: int, n_rays: int, alpha_mask=None)
                        f"best of 2 ({best:.2f} s) with {threads} ATen threads (survey container, 8 threads, 4096 x (128+128): 1 208 rays/s)"), out, rays, pick
 
 
-def erp_chunk_split(model, rays_c, reps: int = 12):
+def erp_chunk_split(model, rays_c, reps: int = 12, ERP_NC: int = None, ERP_NF: int = None):
     """The five launches of one ERP chunk (what ego_render_forward queues), event-timed through the stage entry points with the
     model's CURRENT scene (mask / thresholds included) -> ({kernel: ms}, fraction of 32-sample tiles the shade skips)."""
     from egonerf_amd import _lib
+    ERP_NC = globals()["ERP_NC"] if ERP_NC is None else ERP_NC
+    ERP_NF = globals()["ERP_NF"] if ERP_NF is None else ERP_NF
     dev = rays_c.device
     lib, st = _lib.load(), _lib.stream_handle()
     sc = model.scene()
@@ -1120,7 +1208,9 @@ def run_secondary(a, rk: Ranks):
             setattr(b, k, v)
         return b
 
-    jobs = (("render_fresh_rays", run_render_variant, sub(config="render", steps=128, warmup=8, fresh_rays=64, n_voxel=None)),
+    jobs = (("render_config1_256x64", run_render_shape, sub(config="render", steps=200, warmup=10, shape=[256, 64, 0])),
+            ("render_resampling_4096x256+256", run_render_shape, sub(config="render", steps=100, warmup=10, shape=[4096, 256, 256])),
+            ("render_fresh_rays", run_render_variant, sub(config="render", steps=128, warmup=8, fresh_rays=64, n_voxel=None)),
             ("render_big_grid", run_render_variant, sub(config="render", steps=64, warmup=8, fresh_rays=64, n_voxel=216e6)),
             ("train", run_train, sub(config="train", steps=5, warmup=2, train_reg=False)),
             ("erp", run_erp, sub(config="erp", steps=2, warmup=1, views=2, erp_size=[1024, 2048], mask=False, carve=False, term_eps=0.0, density_shift=None)),
@@ -1258,8 +1348,9 @@ def main():
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return self_launch(a)
     rk = Ranks(a)
-    variant = a.config == "render" and (a.n_voxel or a.fresh_rays)
-    line = (run_render_variant if variant else dict(render=run_render, train=run_train, erp=run_erp)[a.config])(a, rk)
+    variant = a.config == "render" and (a.n_voxel or a.fresh_rays or a.shape)
+    line = (run_render_shape if (a.config == "render" and a.shape) else run_render_variant if variant
+            else dict(render=run_render, train=run_train, erp=run_erp)[a.config])(a, rk)
     if a.config == "render" and not variant and rk.world == 1 and not a.no_secondary and a.density_shift is None:
         line["secondary"] = run_secondary(a, rk)
     if rk.rank == 0:

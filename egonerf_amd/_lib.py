@@ -98,6 +98,9 @@ PROTOTYPES = {
     "ego_avgpool_table": (C.c_int, [P, I32, I32, I32, P, P]),
     "ego_avgpool_field": (C.c_int, [C.POINTER(VmField), C.POINTER(VmField), P]),
     "ego_pack_mlp": (C.c_int, [SP, P, P]),
+    "ego_pack_mlp_for": (C.c_int, [SP, P, C.c_int32, P]),
+    "ego_packed_floats_compat": (C.c_int64, [SP]),
+    "ego_pack_mlp_compat": (C.c_int, [SP, P, P]),
     "ego_march_density": (C.c_int, [SP, P, I64, I32, P, P, P, F32, I32, P, P, I32, P, P, P, P, P, P]),
     "ego_shade_kernel_info": (C.c_int, [I32, C.POINTER(C.c_int32), I32]),
     "ego_shade": (C.c_int, [SP, P, P, P, I64, I32, P, P, P, P]),

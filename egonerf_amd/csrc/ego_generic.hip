@@ -671,6 +671,7 @@ extern "C" {
 
 int ego_shade_train_generic(const ego_scene* sc, const float* rays, const float* coords, int64_t N, int32_t S, float* rgb, float* x, int32_t ldx,
                             float* h1, float* h2, int32_t ldh, float* v, int32_t ldv, void* stream) {
+  EGO_TRACE("ego_shade_train_generic");
   EGO_REQUIRE(N >= 0 && S >= 1 && N * (int64_t)S < (1ll << 31), "shade_train_generic: bad size");
   if (N == 0) return EGO_OK;
   if (int e = check_generic_shape(sc, "shade_train_generic", true, true)) return e;
@@ -692,6 +693,7 @@ int ego_shade_train_generic(const ego_scene* sc, const float* rays, const float*
 int ego_shade_backward_generic(const ego_scene* sc, const float* coords, float* dc, const float* rgb, const float* x, int32_t ldx, const float* h1,
                                const float* h2, int32_t ldh, float* dh2, float* dh1, float* dfe64, float* dv, int32_t ldv, int64_t N, int32_t S,
                                void* stream) {
+  EGO_TRACE("ego_shade_backward_generic");
   EGO_REQUIRE(N >= 0 && S >= 1 && N * (int64_t)S < (1ll << 31), "shade_backward_generic: bad size");
   if (N == 0) return EGO_OK;
   if (int e = check_generic_shape(sc, "shade_backward_generic", false, true)) return e;
@@ -710,6 +712,7 @@ int ego_shade_backward_generic(const ego_scene* sc, const float* coords, float* 
 
 int ego_scatter_generic(const ego_vm_field* field, const ego_vm_grad* grad, const float* coords, const float* d, int32_t ldd, int64_t N, int32_t S,
                         void* stream) {
+  EGO_TRACE("ego_scatter_generic");
   EGO_REQUIRE(field && grad && N >= 0 && S >= 1 && ldd >= 0, "scatter_generic: null argument or bad size");
   if (N == 0) return EGO_OK;
   EGO_REQUIRE(coords && d, "scatter_generic: null argument");

@@ -31,3 +31,23 @@ inline int ego_launch_status(const char* kernel) {
   if (e != hipSuccess) return ego_fail((int)e, "%s: launch failed: %s", kernel, hipGetErrorString(e));
   return EGO_OK;
 }
+
+// ---- tracing ("tracing" row) ---------------------------------------------------------------------------
+// EGO_ROCTX=1 in the environment: every entry point of the library that queues device work opens a roctx range named after itself
+// (roctxRangePushA / roctxRangePop of librocprofiler-sdk-roctx.so, dlopen'ed on first use - no link-time dependency, nothing loaded
+// and one predictable branch per call when the switch is off).  `rocprofv3 --marker-trace --kernel-trace -- python bench.py ...`
+// then shows which library call (= which row of SURVEY 8(a)) every kernel of every config belongs to, without the stage probes.
+struct EgoRoctx {
+  int (*push)(const char*);
+  int (*pop)();
+};
+const EgoRoctx* ego_roctx();   // csrc/ego_ops.hip; nullptr when tracing is off or the roctx library is absent
+
+struct EgoRange {
+  const EgoRoctx* r;
+  explicit EgoRange(const char* name) : r(ego_roctx()) { if (r) r->push(name); }
+  ~EgoRange() { if (r) r->pop(); }
+  EgoRange(const EgoRange&) = delete;
+  EgoRange& operator=(const EgoRange&) = delete;
+};
+#define EGO_TRACE(name) EgoRange ego_trace_range_(name)

@@ -77,6 +77,7 @@ extern "C" {
 
 int ego_rgb_ssim(const float* img0, const float* img1, int32_t H, int32_t W, double max_val, int32_t filter_size, double filter_sigma,
                  double k1, double k2, double* sum, float* ssim_map, void* stream) {
+  EGO_TRACE("ego_rgb_ssim");
   EGO_REQUIRE(filter_size >= 1 && filter_size <= SSIM_MAX_FS && H >= filter_size && W >= filter_size && filter_sigma > 0.0,
               "rgb_ssim: bad size (image must cover the filter, filter_size <= 15)");
   EGO_REQUIRE(img0 && img1 && (sum || ssim_map), "rgb_ssim: null argument");

@@ -1,5 +1,8 @@
 // libegonerf_hip.so, part 1: the separately callable stages (rows A-E, I, J of SURVEY 8a) and the
 // fused marching / compositing kernels.  gfx950 only.
+#include <atomic>
+#include <dlfcn.h>
+#include <stdlib.h>
 #include "ego_device.h"
 #include "ego_host.h"
 #include "ego_generic.h"
@@ -263,7 +266,10 @@ __device__ __forceinline__ float normalize_r_fast(float r, const float* lut, int
 // priorities by phase (+7 %) and a staggered start of the waves of a SIMD (+-0) were measured and are not in the kernel.  Segment 0 streams as before (it knows the transmittance in front of it); a later segment evaluates its
 // passes with the transmittance unknown, parks (alpha, in-pass exclusive product) per sample and the pass totals in LDS, and turns
 // them into weights once its predecessor has published the carry - with the same multiplications in the same order as the
-// one-wave form, so the outputs are bit-identical for every NSPLIT.
+// one-wave form, so z / alpha / weight / bg / tile flags are bit-identical for every NSPLIT.  One documented difference:
+// `coords_out` of passes that the one-wave form stops evaluating (transmittance exactly 0 in front of them, no per-sample alpha asked
+// for) holds zeros there and the real coordinates in a deferred segment, which cannot know yet; those samples have weight 0, their
+// tiles are never shaded, and tests/test_hip_march_split.py compares coordinates where a colour is read.
 constexpr int MARCH_MAXP = 4;   // passes per deferred segment (LDS parking space)
 template <int C, bool OCC, int NSPLIT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_march_density(DevCoords c, DevField F, const float* __restrict__ rays,
@@ -992,6 +998,25 @@ __global__ void k_erp_rays(int H, int W, int row0, int n_rows, Pose34 c2w, int n
 // =============================================================================================
 static inline unsigned nblk(int64_t n, int b) { return (unsigned)((n + b - 1) / b); }
 
+// roctx hooks of EGO_TRACE (ego_host.h): resolved once, on the first traced call
+const EgoRoctx* ego_roctx() {
+  static const EgoRoctx* const hooks = []() -> const EgoRoctx* {
+    const char* e = getenv("EGO_ROCTX");
+    if (!e || !*e || *e == '0') return nullptr;
+    static EgoRoctx h{};
+    for (const char* lib : {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so", "libroctx64.so.4"}) {
+      void* so = dlopen(lib, RTLD_NOW | RTLD_GLOBAL);
+      if (!so) continue;
+      h.push = (int (*)(const char*))dlsym(so, "roctxRangePushA");
+      h.pop = (int (*)())dlsym(so, "roctxRangePop");
+      if (h.push && h.pop) return &h;
+    }
+    fprintf(stderr, "libegonerf_hip: EGO_ROCTX is set but no roctx library could be loaded; tracing ranges are off\n");
+    return nullptr;
+  }();
+  return hooks;
+}
+
 extern "C" {
 
 int ego_abi_version(void) { return EGO_ABI_VERSION; }
@@ -999,6 +1024,7 @@ const char* ego_last_error(void) { return ego_err_buf(); }
 
 int ego_sample_ray_exp(const float* rays, const float* r_sched, const float* jitter, float near_, int64_t N, int32_t S,
                        float* xyz, float* z, void* stream) {
+  EGO_TRACE("ego_sample_ray_exp");
   EGO_REQUIRE(rays && r_sched && N >= 0 && S >= 2, "sample_ray_exp: null input or S < 2");
   if (N == 0) return EGO_OK;
   k_sample_ray_exp<<<nblk(N * S, 256), 256, 0, (hipStream_t)stream>>>(rays, r_sched, jitter, near_, N, S, xyz, z);
@@ -1007,6 +1033,7 @@ int ego_sample_ray_exp(const float* rays, const float* r_sched, const float* jit
 
 int ego_erp_rays(int32_t H, int32_t W, int32_t row0, int32_t n_rows, const float* c2w, int32_t normalize, float* rays,
                  void* stream) {
+  EGO_TRACE("ego_erp_rays");
   EGO_REQUIRE(H >= 1 && W >= 1 && row0 >= 0 && n_rows >= 0 && row0 + n_rows <= H, "erp_rays: bad image window");
   if (n_rows == 0) return EGO_OK;
   EGO_REQUIRE(c2w && rays, "erp_rays: null argument");
@@ -1017,6 +1044,7 @@ int ego_erp_rays(int32_t H, int32_t W, int32_t row0, int32_t n_rows, const float
 }
 
 int ego_from_cartesian(const ego_scene* sc, const float* xyz, int64_t M, float* c7, void* stream) {
+  EGO_TRACE("ego_from_cartesian");
   EGO_REQUIRE(M >= 0, "from_cartesian: M < 0");
   if (M == 0) return EGO_OK;
   EGO_REQUIRE(sc && xyz && c7, "from_cartesian: null argument");
@@ -1025,6 +1053,7 @@ int ego_from_cartesian(const ego_scene* sc, const float* xyz, int64_t M, float* 
 }
 
 int ego_normalize_coord(const ego_scene* sc, const float* c7, int64_t M, float* c7n, void* stream) {
+  EGO_TRACE("ego_normalize_coord");
   EGO_REQUIRE(M >= 0, "normalize_coord: M < 0");
   if (M == 0) return EGO_OK;
   EGO_REQUIRE(sc && c7 && c7n && sc->r_lut, "normalize_coord: null argument");
@@ -1052,6 +1081,7 @@ static int check_field(const ego_vm_field& f, const char* what) {
 }
 
 int ego_density_feature(const ego_scene* sc, const float* c7n, int64_t M, int32_t coarse, float* out, void* stream) {
+  EGO_TRACE("ego_density_feature");
   EGO_REQUIRE(M >= 0, "density_feature: M < 0");
   if (M == 0) return EGO_OK;
   EGO_REQUIRE(sc && c7n && out, "density_feature: null argument");
@@ -1077,6 +1107,7 @@ int ego_density_feature(const ego_scene* sc, const float* c7n, int64_t M, int32_
 }
 
 int ego_feature2density(const ego_scene* sc, const float* feat, int64_t M, float* sigma, void* stream) {
+  EGO_TRACE("ego_feature2density");
   EGO_REQUIRE(M >= 0, "feature2density: M < 0");
   if (M == 0) return EGO_OK;
   EGO_REQUIRE(sc && feat && sigma, "feature2density: null argument");
@@ -1086,6 +1117,7 @@ int ego_feature2density(const ego_scene* sc, const float* feat, int64_t M, float
 
 int ego_raw2alpha(const float* sigma, const float* dist, int64_t N, int32_t S, float* alpha, float* weight,
                   float* bg_weight, void* stream) {
+  EGO_TRACE("ego_raw2alpha");
   EGO_REQUIRE(N >= 0 && S >= 1, "raw2alpha: bad size");
   if (N == 0) return EGO_OK;
   EGO_REQUIRE(sigma && dist, "raw2alpha: null argument");
@@ -1095,6 +1127,7 @@ int ego_raw2alpha(const float* sigma, const float* dist, int64_t N, int32_t S, f
 
 int ego_sample_pdf_merge(const float* z, const float* weight, const float* u, int64_t N, int32_t Sc, int32_t n_fine,
                          int32_t use_coarse, float* z_out, float* z_new_out, void* stream) {
+  EGO_TRACE("ego_sample_pdf_merge");
   EGO_REQUIRE(z && weight && z_out && N >= 0, "sample_pdf_merge: null argument");
   EGO_REQUIRE(Sc >= 3 && n_fine >= 1 && Sc + n_fine <= PDF_MAX, "sample_pdf_merge: need 3 <= Sc, Sc + n_fine <= 2048");
   if (N == 0) return EGO_OK;
@@ -1106,6 +1139,7 @@ int ego_sample_pdf_merge(const float* z, const float* weight, const float* u, in
 }
 
 int ego_envmap_radiance(const ego_scene* sc, const float* dirs, int64_t N, float* out, void* stream) {
+  EGO_TRACE("ego_envmap_radiance");
   EGO_REQUIRE(N >= 0, "envmap_radiance: N < 0");
   if (N == 0) return EGO_OK;
   EGO_REQUIRE(sc && dirs && out && sc->envmap && sc->envmap_h >= 2, "envmap_radiance: no envmap / null argument");
@@ -1115,6 +1149,7 @@ int ego_envmap_radiance(const ego_scene* sc, const float* dirs, int64_t N, float
 
 int ego_envmap_backward(const ego_scene* sc, const float* dirs, int32_t dir_stride, const float* g_rgb, const float* rgb_raw, const float* bg_weight,
                         const float* env_map, int64_t N, float* g_emission, void* stream) {
+  EGO_TRACE("ego_envmap_backward");
   EGO_REQUIRE(N >= 0, "envmap_backward: N < 0");
   if (N == 0) return EGO_OK;
   EGO_REQUIRE(sc && dirs && dir_stride >= 3 && g_rgb && rgb_raw && bg_weight && env_map && g_emission && sc->envmap_h >= 2,
@@ -1124,6 +1159,7 @@ int ego_envmap_backward(const ego_scene* sc, const float* dirs, int32_t dir_stri
 }
 
 int ego_sh_render(const float* viewdirs, const float* features, int64_t M, float* rgb, void* stream) {
+  EGO_TRACE("ego_sh_render");
   EGO_REQUIRE(M >= 0, "sh_render: M < 0");
   if (M == 0) return EGO_OK;
   EGO_REQUIRE(viewdirs && features && rgb, "sh_render: null argument");
@@ -1132,6 +1168,7 @@ int ego_sh_render(const float* viewdirs, const float* features, int64_t M, float
 }
 
 int ego_alpha_mask_sample(const ego_scene* sc, const float* c7n, int64_t M, float* out, void* stream) {
+  EGO_TRACE("ego_alpha_mask_sample");
   EGO_REQUIRE(M >= 0, "alpha_mask_sample: M < 0");
   if (M == 0) return EGO_OK;
   EGO_REQUIRE(sc && c7n && out && sc->occ && sc->occ_res[0] >= 2 && sc->occ_res[1] >= 2 && sc->occ_res[2] >= 2,
@@ -1141,6 +1178,7 @@ int ego_alpha_mask_sample(const ego_scene* sc, const float* c7n, int64_t M, floa
 }
 
 int ego_avgpool_table(const float* src, int32_t H, int32_t W, int32_t C, float* dst, void* stream) {
+  EGO_TRACE("ego_avgpool_table");
   EGO_REQUIRE(src && dst && H >= 2 && W >= 1 && C >= 1, "avgpool_table: bad argument");
   const int64_t n = (int64_t)(H / 2) * (W == 1 ? 1 : W / 2) * C;
   k_avgpool<<<nblk(n, 256), 256, 0, (hipStream_t)stream>>>(src, H, W, C, dst);
@@ -1148,6 +1186,7 @@ int ego_avgpool_table(const float* src, int32_t H, int32_t W, int32_t C, float* 
 }
 
 int ego_avgpool_field(const ego_vm_field* src, const ego_vm_field* dst, void* stream) {
+  EGO_TRACE("ego_avgpool_field");
   EGO_REQUIRE(src && dst && src->n_comp >= 1 && dst->n_comp == src->n_comp, "avgpool_field: null field or component counts differ");
   PoolJobs J{};
   J.C = src->n_comp; J.n = 12;
@@ -1174,6 +1213,7 @@ int ego_march_density(const ego_scene* sc, const float* rays, int64_t N, int32_t
                       const float* r_sched, const float* jitter, float near_, int32_t coarse, float* z_out,
                       float* alpha, int32_t alpha_stride, float* weight, float* bg_weight, float* coords_out, float* sigma_out,
                       uint8_t* tile_active, void* stream) {
+  EGO_TRACE("ego_march_density");
   EGO_REQUIRE(sc && rays && N >= 0 && S >= 2, "march_density: null argument or S < 2");
   if (alpha_stride == 0) alpha_stride = S;
   EGO_REQUIRE(alpha_stride >= S && alpha_stride <= S + 64, "march_density: alpha_stride must be in [S, S+64]");
@@ -1191,16 +1231,22 @@ int ego_march_density(const ego_scene* sc, const float* rays, int64_t N, int32_t
   const int n_pass = (S + 63) / 64;
   int nsplit = 1;
   {
-    static int slots = 0;   // wave slots of the device (3 per SIMD), queried once
+    // wave slots (3 per SIMD) of the CURRENT device, queried once per device; racing first calls store the same value
+    static std::atomic<int> slots_of[16];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
+    int slots = slots_of[dev].load(std::memory_order_relaxed);
     if (!slots) {
-      int dev = 0, cus = 0;
-      if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) slots = cus * 12;
-      else slots = 3072;
+      int cus = 0;
+      slots = (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) ? cus * 12 : 3072;
+      slots_of[dev].store(slots, std::memory_order_relaxed);
     }
     if ((double)N / slots < 2.0 && n_pass >= 4 && (n_pass + 1) / 2 <= MARCH_MAXP) nsplit = 2;
-    if (const char* e = getenv("EGO_MARCH_SPLIT")) {   // experiments (tools/march_timing.py): force 1 or 2 where the shape allows it
-      const int want = atoi(e);
-      if (want == 1 || (want == 2 && n_pass >= 2 && (n_pass + 1) / 2 <= MARCH_MAXP)) nsplit = want;
+    // experiments and tests/test_hip_march_split.py (which flips it between calls of one process, hence read per launch: a getenv is
+    // ~50 ns against a 5 us launch): EGO_MARCH_SPLIT forces 1 or 2 where the shape allows it
+    if (const char* e = getenv("EGO_MARCH_SPLIT")) {
+      const int forced = atoi(e);
+      if (forced == 1 || (forced == 2 && n_pass >= 2 && (n_pass + 1) / 2 <= MARCH_MAXP)) nsplit = forced;
     }
   }
 #define EGO_LAUNCH_MARCH(OCC, NS)                                                                                                       \
@@ -1220,6 +1266,7 @@ int ego_march_density(const ego_scene* sc, const float* rays, int64_t N, int32_t
 int ego_composite(const ego_scene* sc, const float* rays, const float* z, const float* weight, const float* bg_weight,
                   const float* rgb, int64_t N, int32_t S, float* rgb_map, float* depth, float* bg_map, float* env_map,
                   float* rgb_raw, void* stream) {
+  EGO_TRACE("ego_composite");
   EGO_REQUIRE(sc && rays && z && weight && rgb && rgb_map && N >= 0 && S >= 1, "composite: null argument");
   EGO_REQUIRE(!sc->envmap || bg_weight, "composite: envmap needs bg_weight");
   if (N == 0) return EGO_OK;

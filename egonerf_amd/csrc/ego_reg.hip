@@ -195,6 +195,7 @@ inline unsigned stream_blocks(int64_t n) {
 extern "C" {
 
 int ego_tv_plane(const float* table, int32_t C, int32_t H, int32_t W, float scale, double* value, float* grad, void* stream) {
+  EGO_TRACE("ego_tv_plane");
   EGO_REQUIRE(C >= 1 && H >= 2 && W >= 2, "tv_plane: bad size");
   EGO_REQUIRE(table && (value || grad), "tv_plane: null argument");
   const float ah = scale * 2.f / ((float)C * (float)(H - 1) * (float)W);
@@ -204,6 +205,7 @@ int ego_tv_plane(const float* table, int32_t C, int32_t H, int32_t W, float scal
 }
 
 int ego_l1_table(const float* table, int64_t n, float scale, double* value, float* grad, void* stream) {
+  EGO_TRACE("ego_l1_table");
   EGO_REQUIRE(n >= 1, "l1_table: bad size");
   EGO_REQUIRE(table && (value || grad), "l1_table: null argument");
   k_l1<<<stream_blocks(n), 256, 0, (hipStream_t)stream>>>(table, n, scale / (float)n, value, grad);
@@ -211,6 +213,7 @@ int ego_l1_table(const float* table, int64_t n, float scale, double* value, floa
 }
 
 int ego_line_ortho(const float* line, int32_t C, int32_t n, float scale, double* value, float* grad, void* stream) {
+  EGO_TRACE("ego_line_ortho");
   EGO_REQUIRE(C >= 2 && C <= 64 && n >= 1, "line_ortho: bad size (2 <= n_comp <= 64)");
   EGO_REQUIRE(line && (value || grad), "line_ortho: null argument");
   k_line_ortho<<<1, 256, 0, (hipStream_t)stream>>>(line, C, n, scale, value, grad);
@@ -218,6 +221,7 @@ int ego_line_ortho(const float* line, int32_t C, int32_t n, float scale, double*
 }
 
 int ego_ray_entropy(const float* alpha, int64_t N, int32_t S, int32_t stride, double* value, float* g_alpha, void* stream) {
+  EGO_TRACE("ego_ray_entropy");
   EGO_REQUIRE(N >= 0 && S >= 1 && stride >= S, "ray_entropy: bad size");
   if (N == 0) return EGO_OK;
   EGO_REQUIRE(alpha && (value || g_alpha), "ray_entropy: null argument");
@@ -227,6 +231,7 @@ int ego_ray_entropy(const float* alpha, int64_t N, int32_t S, int32_t stride, do
 
 int ego_resample_table(const float* src, int32_t C, int32_t H, int32_t W, const float* xs, const float* ys, int32_t H2, int32_t W2,
                        float* dst, void* stream) {
+  EGO_TRACE("ego_resample_table");
   EGO_REQUIRE(C >= 1 && H >= 1 && W >= 1 && H2 >= 1 && W2 >= 1, "resample_table: bad size");
   EGO_REQUIRE(src && xs && ys && dst, "resample_table: null argument");
   const int64_t n = (int64_t)H2 * W2 * C;
@@ -258,6 +263,7 @@ static int adam_launch(const ego_adam_tensor* tensors, int32_t count, float beta
 }
 
 int ego_adam_step(const ego_adam_tensor* tensors, int32_t count, float beta1, float beta2, float eps, int32_t step, void* stream) {
+  EGO_TRACE("ego_adam_step");
   EGO_REQUIRE(count >= 0 && step >= 1, "adam_step: bad count / step (steps count from 1)");
   if (count == 0) return EGO_OK;
   EGO_REQUIRE(tensors, "adam_step: null argument");
@@ -266,6 +272,7 @@ int ego_adam_step(const ego_adam_tensor* tensors, int32_t count, float beta1, fl
 
 int ego_adam_step_graph(const ego_adam_tensor* tensors, int32_t count, float beta1, float beta2, float eps, double lr_factor, double* clock,
                         void* stream) {
+  EGO_TRACE("ego_adam_step_graph");
   EGO_REQUIRE(count >= 0 && lr_factor > 0.0, "adam_step_graph: bad count / lr_factor");
   if (count == 0) return EGO_OK;
   EGO_REQUIRE(tensors && clock, "adam_step_graph: null argument");

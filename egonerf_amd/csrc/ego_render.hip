@@ -43,6 +43,7 @@ int64_t ego_render_workspace_bytes(int64_t N, const ego_render_args* args) {
 
 int ego_render_forward(const ego_scene* sc, const ego_render_args* a, const float* rays, int64_t N, void* workspace,
                        float* rgb_map, float* depth, float* alpha, float* bg_map, float* env_map, void* stream) {
+  EGO_TRACE("ego_render_forward");
   EGO_REQUIRE(N >= 0, "render_forward: N < 0");
   if (N == 0) return EGO_OK;
   EGO_REQUIRE(sc && a && rays && workspace && rgb_map, "render_forward: null argument");

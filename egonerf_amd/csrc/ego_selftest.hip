@@ -101,6 +101,7 @@ extern "C" {
 int64_t ego_selftest_workspace_bytes(void) { return make_layout().total * 4; }
 
 int ego_selftest(void* workspace, int64_t workspace_bytes, int32_t reps, int32_t* mismatching_calls, void* stream_) {
+  EGO_TRACE("ego_selftest");
   EGO_REQUIRE(workspace && mismatching_calls && reps >= 1, "selftest: null argument or reps < 1");
   const Layout L = make_layout();
   EGO_REQUIRE(workspace_bytes >= L.total * 4 && ((uintptr_t)workspace & 255) == 0, "selftest: workspace too small (ego_selftest_workspace_bytes) or not 256-byte aligned");

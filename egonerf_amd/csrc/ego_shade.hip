@@ -1875,7 +1875,21 @@ int64_t ego_packed_floats_scene(const ego_scene* sc) {
   return ego_shape_is_tuned(sc) ? ego_packed_floats() : ego_generic_packed_floats(sc);
 }
 
-int ego_pack_mlp(const ego_scene* sc, float* packed_out, void* stream) {
+int ego_pack_mlp(const ego_scene* sc, float* packed_out, void* stream) { return ego_pack_mlp_for(sc, packed_out, 0, stream); }
+
+int64_t ego_packed_floats_compat(const ego_scene* sc) { return sc ? ego_generic_packed_floats(sc) : -1; }
+
+int ego_pack_mlp_compat(const ego_scene* sc, float* packed_out, void* stream) {
+  EGO_TRACE("ego_pack_mlp_compat");
+  EGO_REQUIRE(sc && packed_out, "pack_mlp_compat: null argument");
+  if (sc->head != EGO_HEAD_RGB)
+    for (int i = 0; i < 3; ++i) EGO_REQUIRE(sc->mlp_w[i] && sc->mlp_b[i], "pack_mlp_compat: null MLP weight");
+  EGO_REQUIRE(sc->basis[0] && sc->basis[1], "pack_mlp_compat: null basis matrix");
+  return ego_generic_pack(sc, packed_out, stream);
+}
+
+int ego_pack_mlp_for(const ego_scene* sc, float* packed_out, int32_t for_training, void* stream) {
+  EGO_TRACE("ego_pack_mlp_for");
   EGO_REQUIRE(sc && packed_out, "pack_mlp: null argument");
   if (sc->head != EGO_HEAD_RGB)   // RGBRender has no MLP (tensorBase.py:37-39): only the basis matrices are packed
     for (int i = 0; i < 3; ++i) EGO_REQUIRE(sc->mlp_w[i] && sc->mlp_b[i], "pack_mlp: null MLP weight");
@@ -1892,6 +1906,7 @@ int ego_pack_mlp(const ego_scene* sc, float* packed_out, void* stream) {
   k_pack_basis16<<<(BASIS16_FLOATS + 255) / 256, 256, 0, (hipStream_t)stream>>>(sc->basis[0], sc->basis[1], packed_out + 2 * PACKED_FLOATS);
   if (int e = ego_launch_status("k_pack_basis16")) return e;
   static_assert(BASIS16_FLOATS == BASIS16_FLOATS_C, "blob region sizes");
+  if (for_training) return EGO_OK;   // the f16f8 / f16f6 images below are read by the inference arithmetics only
   k_pack_mlp_f8<<<(F8_FLOATS + 255) / 256, 256, 0, (hipStream_t)stream>>>(sc->mlp_w[0], sc->mlp_w[1],
                                                                           packed_out + 2 * PACKED_FLOATS + BASIS16_FLOATS);
   if (int e = ego_launch_status("k_pack_mlp_f8")) return e;
@@ -1925,6 +1940,7 @@ int ego_shade_kernel_info(int32_t precision, int32_t* out, int32_t n) {
 }
 
 int ego_app_feature(const ego_scene* sc, const float* c7n, int64_t M, float* out, void* stream) {
+  EGO_TRACE("ego_app_feature");
   EGO_REQUIRE(M >= 0 && M < (1ll << 31), "app_feature: M out of range [0, 2^31)");
   if (M == 0) return EGO_OK;
   EGO_REQUIRE(c7n && out, "app_feature: null argument");
@@ -1942,6 +1958,7 @@ int ego_app_feature(const ego_scene* sc, const float* c7n, int64_t M, float* out
 }
 
 int ego_mlp_fea(const ego_scene* sc, const float* viewdirs, const float* feat, int64_t M, float* rgb, void* stream) {
+  EGO_TRACE("ego_mlp_fea");
   EGO_REQUIRE(M >= 0 && M < (1ll << 31), "mlp_fea: M out of range [0, 2^31)");
   if (M == 0) return EGO_OK;
   EGO_REQUIRE(viewdirs && feat && rgb, "mlp_fea: null argument");
@@ -1958,6 +1975,7 @@ int ego_mlp_fea(const ego_scene* sc, const float* viewdirs, const float* feat, i
 
 int ego_shade(const ego_scene* sc, const float* rays, const float* z, const float* coords, int64_t N, int32_t S, float* rgb,
               const ego_shade_dump* dump, const uint8_t* tile_active, void* stream) {
+  EGO_TRACE("ego_shade");
   EGO_REQUIRE(rays && z && rgb && N >= 0 && S >= 1 && N * (int64_t)S < (1ll << 31), "shade: null argument or N*S >= 2^31");
   if (sc && !ego_shape_is_tuned(sc)) {   // any other model shape: fp32 compatibility kernel (inference only)
     if (dump) return ego_fail(EGO_E_UNSUPPORTED, "shade: activation dumps (training) exist for the tuned model shape only (app_dim 27, 48 components, "
@@ -1992,6 +2010,7 @@ int ego_shade(const ego_scene* sc, const float* rays, const float* z, const floa
 
 int ego_shade_composite(const ego_scene* sc, const float* rays, const float* z, const float* coords, const float* weight, const float* bg_weight,
                         int64_t N, int32_t S, const uint8_t* tile_active, float* rgb_map, float* depth, float* bg_map, float* env_map, void* stream) {
+  EGO_TRACE("ego_shade_composite");
   EGO_REQUIRE(rays && z && coords && weight && rgb_map && N >= 0 && S >= 32 && (S & 31) == 0 && N * (int64_t)S < (1ll << 31),
               "shade_composite: null argument, S not a multiple of 32, or N*S >= 2^31");
   if (!ego_can_fold_composite(sc, S)) return ego_fail(EGO_E_UNSUPPORTED, "shade_composite: tuned model shape, fp32 tables, a split-precision arithmetic and weight_thres <= 0 only");
@@ -2013,6 +2032,7 @@ int ego_shade_composite(const ego_scene* sc, const float* rays, const float* z, 
 int64_t ego_train_packed_floats(void) { return TRAIN_FLOATS; }
 
 int ego_pack_train(const ego_scene* sc, float* out, void* stream) {
+  EGO_TRACE("ego_pack_train");
   EGO_REQUIRE(sc && out, "pack_train: null argument");
   if (int e = check_shade_config(sc, "pack_train", true, true)) return e;
   EGO_REQUIRE(sc->mlp_w[0] && sc->mlp_w[1] && sc->mlp_w[2] && sc->basis[0] && sc->basis[1], "pack_train: null weight");
@@ -2074,6 +2094,7 @@ static int check_grad(const ego_vm_grad* g, const char* who) {
 int ego_march_backward(const ego_scene* sc, const float* z, const float* alpha, int32_t alpha_stride, const float* weight,
                        const float* sigma, const float* bg_weight, const float* rgb, const float* g_rgb, const float* g_alpha,
                        const float* rgb_raw, const float* env_map, int64_t N, int32_t S, float* dc, float* dfeat, void* stream) {
+  EGO_TRACE("ego_march_backward");
   EGO_REQUIRE(N >= 0 && S >= 2 && alpha_stride >= S, "march_backward: bad size");
   if (N == 0) return EGO_OK;
   EGO_REQUIRE(sc && z && alpha && weight && sigma && bg_weight && rgb && g_rgb && rgb_raw && dc && dfeat, "march_backward: null argument");
@@ -2089,6 +2110,7 @@ int ego_march_backward(const ego_scene* sc, const float* z, const float* alpha, 
 int ego_shade_backward(const ego_scene* sc, const float* train_packed, const float* coords, float* dc, const float* rgb,
                        const ego_shade_dump* fwd, uint16_t* dh2, uint16_t* dh1, float* dh_scale, float* dfe, float* dv, int64_t N, int32_t S,
                        void* stream) {
+  EGO_TRACE("ego_shade_backward");
   EGO_REQUIRE(N >= 0 && S >= 1 && N * (int64_t)S < (1ll << 31), "shade_backward: bad size");
   if (N == 0) return EGO_OK;
   EGO_REQUIRE(sc && train_packed && coords && dc && rgb && fwd && fwd->x && fwd->relu_bits && dh2 && dh1 && dh_scale && dfe && dv,
@@ -2122,6 +2144,7 @@ static dim3 scatter_blocks(const ScatterArgs& a) {
 
 int ego_scatter_density(const ego_scene* sc, const ego_vm_grad* gdensity, const float* coords, const float* dfeat, int64_t N, int32_t S,
                         void* stream) {
+  EGO_TRACE("ego_scatter_density");
   EGO_REQUIRE(sc, "scatter_density: null scene");
   if (sc->density.n_comp != 16) return ego_fail(EGO_E_UNSUPPORTED, "scatter_density: n_comp %d (supported: 16)", sc->density.n_comp);
   ScatterArgs a{};
@@ -2133,6 +2156,7 @@ int ego_scatter_density(const ego_scene* sc, const ego_vm_grad* gdensity, const 
 
 int ego_scatter_app(const ego_scene* sc, const ego_vm_grad* gapp, const float* coords, const float* dv, int64_t N, int32_t S,
                     void* stream) {
+  EGO_TRACE("ego_scatter_app");
   EGO_REQUIRE(sc, "scatter_app: null scene");
   if (sc->app.n_comp != APP_C) return ego_fail(EGO_E_UNSUPPORTED, "scatter_app: n_comp %d (supported: 48)", sc->app.n_comp);
   ScatterArgs a{};

@@ -377,6 +377,7 @@ extern "C" {
 
 int ego_weight_grad(const void* A, int32_t lda, int32_t ca, int32_t a_layout, const float* a_scale, const void* B, int32_t ldb, int32_t cb,
                     int32_t b_layout, int32_t ones_col, int64_t M, float* G, int32_t ldg, void* stream) {
+  EGO_TRACE("ego_weight_grad");
   EGO_REQUIRE(a_layout >= 0 && a_layout <= 3, "weight_grad: a_layout must be 0 (row-major), 1 (blocked fp32), 2 (blocked scaled fp16) or 3 (grid-routed)");
   EGO_REQUIRE(b_layout >= 0 && b_layout <= 2, "weight_grad: b_layout must be 0 (row-major), 1 (blocked fp32) or 2 (blocked fp16)");
   EGO_REQUIRE(b_layout != 2 || ((cb & 15) == 0 && ldb == cb), "weight_grad: the fp16 B layout holds whole k-steps (cb a multiple of 16, ldb = cb)");

@@ -345,6 +345,11 @@ class EgoNeRF(TensorBase):
         self._packed_versions = None
         self._sched_cache = {}
         self._mlp_precision = "f16f6"   # inference default; differentiable calls always use the three-term fp16 split
+        # Differentiable calls of the tuned head keep the activations that only feed the weight-gradient products (x, h1, h2, dh1, dh2)
+        # as halves (~2^-12 relative per operand against the reference's fp32 autograd, nothing above 65504).  True (or
+        # EGO_TRAIN_FP32=1 in the environment at construction) trains it through the fp32 compatibility kernels instead: the parity
+        # mode, several times slower.
+        self.train_fp32_head = os.environ.get("EGO_TRAIN_FP32", "0") not in ("", "0")
         self._app_table_dtype = "f32"   # "f16": inference gathers appearance taps from a half-precision copy of the tables
         self._app16 = None              # (versions, [12 half tensors])
         # opt-in skipping (EgoNeRF.forward itself evaluates every sample; TensorBase.forward's semantics, tensorBase.py:464-487,
@@ -673,8 +678,12 @@ class EgoNeRF(TensorBase):
                 f.line[gi][i] = _table_ptr(lines[i])
 
     @_lib.device_guard
-    def scene(self) -> "_lib.Scene":
+    def scene(self, training: bool = False) -> "_lib.Scene":
         """The ego_scene struct for the current parameters (re-packs the MFMA weights when they changed).
+
+        training=True is what the differentiable path asks for (train.RenderFunction, forward and backward): the fp32 tables, every
+        sample shaded like EgoNeRF.forward (the appearance skip is an inference option), all three fp16 terms of every product
+        (mlp_precision "f16x3"), and only the regions of the packed blob that arithmetic reads (ego_pack_mlp_for).
 
         The struct holds raw device pointers: to the parameter tables (optimiser steps write them in place), and to the pooled density
         tables, which `update_coarse_sigma_grid()` also refreshes IN PLACE while their shapes stand - so a struct returned earlier, or a
@@ -698,7 +707,7 @@ class EgoNeRF(TensorBase):
                                                                   float(self.rayMarch_weight_thres) if self.use_weight_thres else None,
                                                                   bool(self.skip_zero_weight_tiles), co.N_r, float(co.r0), float(co.far[0]), tuple(co.center.tolist()),
                                                                   tuple(t.data_ptr() for t in luts), float(self.distance_scale),
-                                                                  float(self.density_shift), self.fea2denseAct)
+                                                                  float(self.density_shift), self.fea2denseAct, bool(training))
         if self._scene_cache is not None and self._scene_cache[0] == keys and self._packed_versions == versions:
             return self._scene_cache[1]
         lib = _lib.load()
@@ -721,7 +730,7 @@ class EgoNeRF(TensorBase):
         sc.app_dim = self.app_dim
         sc.mlp_in, sc.mlp_hidden = self.head_in_mlpC, self.head_hidden
         sc.view_pe, sc.fea_pe = (self.view_pe, self.head_fea_pe) if self.shadingMode != "RGB" else (0, 0)
-        sc.mlp_precision = {"f16x3": 0, "f32": 1, "f16f8": 2, "f16f6": 3}[self._mlp_precision]
+        sc.mlp_precision = 0 if training else {"f16x3": 0, "f32": 1, "f16f8": 2, "f16f6": 3}[self._mlp_precision]
         # packed weights: the MFMA fragment layouts for the tuned shape (27 / 48 / 150 / 128 / 2 / 2, every shipped config), the fp32
         # layout of the any-shape compatibility kernels otherwise (csrc/ego_generic.hip; the library reports the size for the shape)
         sc.app.n_comp = self.app_n_comp[0]
@@ -730,14 +739,16 @@ class EgoNeRF(TensorBase):
             raise RuntimeError("ego_packed_floats_scene rejected the scene")
         if self._packed is None or self._packed.device != dev or self._packed.numel() != need:
             self._packed = torch.empty(need, device=dev)
-        _call("ego_pack_mlp", sc, self._packed.data_ptr(), _lib.stream_handle())
+        _call("ego_pack_mlp_for", sc, self._packed.data_ptr(), int(training), _lib.stream_handle())
         sc.packed = self._packed.data_ptr()
-        if self._app_table_dtype == "f16":
+        if self._app_table_dtype == "f16" and not training:
             self._fill_app16(sc)
         if self.use_alpha_mask and self.alphaMask is not None:
             self.alphaMask.fill_scene(sc)
         sc.term_eps = float(self.early_termination_eps)
         sc.weight_thres = float(self.rayMarch_weight_thres) if self.use_weight_thres else (0.0 if self.skip_zero_weight_tiles else -1.0)
+        if training:
+            sc.weight_thres = -1.0
         if self.envmap is not None:
             em = self.envmap.emission.detach()
             if not em.is_contiguous():

@@ -63,6 +63,18 @@ class FusedAdam(torch.optim.Optimizer):
                 self._clock.copy_(torch.tensor(clock, dtype=torch.float64))   # in place: a captured graph keeps reading this buffer
             if factor is not None:
                 self.lr_factor = float(factor)
+        elif self.capturable:
+            # a checkpoint written in non-capturable mode (no device clock): seed the clock from its step count, or the bias correction
+            # and the decay would silently restart at t = 0.  Its param_groups[i]["lr"] are the rates the caller had already
+            # decayed to (train.py:328-329), so they become the base rates and the device-side scale starts at 1.
+            t = max((int(st.get("step", 0)) for st in self.state.values()), default=0)
+            dev = next(p for g in self.param_groups for p in g["params"]).device
+            seed = torch.tensor([float(t), 1.0, 0.0, 0.0], dtype=torch.float64, device=dev)
+            if self._clock is None:
+                self._clock = seed
+            else:
+                self._clock.copy_(seed)
+            self._base_lrs = tuple(float(g["lr"]) for g in self.param_groups)
 
     @torch.no_grad()
     @_lib.device_guard

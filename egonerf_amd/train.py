@@ -161,16 +161,9 @@ class RenderFunction(torch.autograd.Function):
         lib, st = _lib.load(), _lib.stream_handle()
         ctx.set_materialize_grads(False)
         dev = rays.device
-        sc = model.scene()
-        if sc.mlp_precision == 1:
-            raise NotImplementedError("training uses the fp16-split matrix path (model.mlp_precision = 'f16x3' or 'f16f8')")
-        if sc.app_f16 or sc.weight_thres >= 0 or sc.mlp_precision != 0:
-            # training gathers from the fp32 parameters (the backward re-gathers from them), shades every sample like
-            # EgoNeRF.forward (the appearance skip is an inference option) and keeps all three fp16 terms of every product
-            sc = _lib.Scene.from_buffer_copy(sc)
-            sc.app_f16 = 0
-            sc.weight_thres = -1.0
-            sc.mlp_precision = 0
+        # training gathers from the fp32 parameters (the backward re-gathers from them), shades every sample like EgoNeRF.forward (the
+        # appearance skip is an inference option) and keeps all three fp16 terms of every product, whatever model.mlp_precision says
+        sc = model.scene(training=True)
         N = rays.shape[0]
         n_coarse, n_fine = opts["n_coarse"], opts["n_fine"]
         resampling, use_coarse = opts["resampling"], opts["use_coarse_sample"]
@@ -202,7 +195,16 @@ class RenderFunction(torch.autograd.Function):
                                              coords.data_ptr(), sigma.data_ptr(), None, st), "ego_march_density")
         M = N * S
         rgb = f(N, S, 3)
-        head_tuned = head_is_tuned(model)
+        head_tuned = head_is_tuned(model) and not model.train_fp32_head
+        compat = None
+        if head_is_tuned(model) and not head_tuned:
+            # parity mode (model.train_fp32_head / EGO_TRAIN_FP32=1): the tuned head trained through the fp32 compatibility kernels -
+            # fp32 activations, fp32 dumps, fp32 weight-gradient operands like the reference's autograd - on a copy of the scene whose
+            # packed blob is the compatibility layout (the tuned path keeps x / h1 / h2 / dh1 / dh2 as halves: DESIGN.md 4.2)
+            sc = _lib.Scene.from_buffer_copy(sc)
+            compat = f(lib.ego_packed_floats_compat(sc))
+            _chk(lib.ego_pack_mlp_compat(sc, compat.data_ptr(), st), "ego_pack_mlp_compat")
+            sc.packed = compat.data_ptr()
         if head_tuned:
             Mp = (M + 31) // 32 * 32  # the dumps are tile-blocked (include/egonerf_hip.h, ego_shade_dump): whole tiles
             f16 = lambda *shape: torch.empty(*shape, device=dev, dtype=torch.float16)   # x / h1 / h2: halves in the kernels' operand order
@@ -230,7 +232,7 @@ class RenderFunction(torch.autograd.Function):
         _chk(lib.ego_composite(sc, rays.data_ptr(), z.data_ptr(), weight.data_ptr(), bg.data_ptr(), rgb.data_ptr(), N, S,
                                      rgb_map.data_ptr(), depth.data_ptr(), _lib.ptr(bg_map), _lib.ptr(env_map), raw.data_ptr(), st),
                    "ego_composite")
-        ctx.model, ctx.N, ctx.S, ctx.head_tuned = model, N, S, head_tuned
+        ctx.model, ctx.N, ctx.S, ctx.head_tuned, ctx.compat = model, N, S, head_tuned, compat
         ctx.saved = dict(z=z, alpha=alpha, weight=weight, sigma=sigma, bg=bg, coords=coords, rgb=rgb, raw=raw, env=env_map, rays=rays,
                          **dump)
         # depth is computed under no_grad in the reference (EgoNeRF.py:595-598); one call: a second would replace the first
@@ -247,7 +249,10 @@ class RenderFunction(torch.autograd.Function):
         model, N, S, sv = ctx.model, ctx.N, ctx.S, ctx.saved
         dev = sv["z"].device
         M = N * S
-        sc = model.scene()
+        sc = model.scene(training=True)
+        if ctx.compat is not None:   # the forward's compatibility blob (fp32 parity mode of the tuned head)
+            sc = _lib.Scene.from_buffer_copy(sc)
+            sc.packed = ctx.compat.data_ptr()
         g_rgb = torch.zeros(N, 3, device=dev) if g_rgb is None else g_rgb.contiguous().float()
         astride = sv["alpha"].shape[1]
         if g_alpha is not None:  # ray_entropy_loss (train.py:306-309); the envmap's ones column takes no gradient
@@ -480,22 +485,25 @@ class GraphedTrainStep:
 
     Loss terms whose WEIGHTS change per iteration (train.py:295-309: the TV and ray-entropy weights decay by lr_factor per active
     iteration and are gated on iter_ignore_TV / iter_ignore_entropy) must not be Python floats - a float is frozen into the graph at
-    capture.  A `loss_fn` with a fourth parameter receives `self.schedule` (a TrainSchedule: device-side iteration counter advanced
+    capture.  A `loss_fn` whose fourth parameter is named `sched` / `schedule` (or any loss_fn with `schedule_aware=True`) receives `self.schedule` (a TrainSchedule: device-side iteration counter advanced
     inside the graph) and writes e.g. `sched.decayed(TV_weight_density, lr_factor, active_before=iter_ignore_TV) * model.TV_loss_density(tv)`;
     tests/test_hip_train_graph.py::test_graphed_step_with_decaying_regulariser_weights pins that against the eager loop."""
 
-    def __init__(self, model, optimizer, rays, target, render_kwargs, loss_fn=None, warmup=3, noise_fn=None, start_iteration=0):
+    def __init__(self, model, optimizer, rays, target, render_kwargs, loss_fn=None, warmup=3, noise_fn=None, start_iteration=0,
+                 schedule_aware=None):
         if not getattr(optimizer, "capturable", False):
             raise ValueError("GraphedTrainStep needs FusedAdam(capturable=True): the step count and lr schedule must live on the device")
         self.model, self.opt, self.kw = model, optimizer, dict(render_kwargs)
         self.loss_fn = loss_fn or (lambda rgb, tgt, alpha: torch.mean((rgb - tgt) ** 2))
-        import inspect
-        try:
-            n_par = len([q for q in inspect.signature(self.loss_fn).parameters.values()
-                         if q.kind in (q.POSITIONAL_ONLY, q.POSITIONAL_OR_KEYWORD)])
-        except (TypeError, ValueError):
-            n_par = 3
-        self._loss_takes_schedule = n_par >= 4
+        # Explicit opt-in, not arity sniffing (ADVICE r04: a fourth parameter like reduction="mean" must not receive the schedule, a
+        # *args loss must be able to): `schedule_aware=True`, or - when left None - a loss_fn parameter NAMED `sched` or `schedule`.
+        if schedule_aware is None:
+            import inspect
+            try:
+                schedule_aware = any(n in ("sched", "schedule") for n in inspect.signature(self.loss_fn).parameters)
+            except (TypeError, ValueError):
+                schedule_aware = False
+        self._loss_takes_schedule = bool(schedule_aware)
         self.schedule = TrainSchedule(rays.device, start_iteration)
         # noise_fn(n_rays, n_samples, device) -> [n_rays, n_samples] in [0, 1): torch.rand by default; tests pin it
         self.noise_fn = noise_fn or (lambda n, m, dev: torch.rand(n, m, device=dev))

@@ -218,6 +218,18 @@ int ego_avgpool_field(const ego_vm_field* src, const ego_vm_field* dst, void* st
 int ego_alpha_mask_sample(const ego_scene* sc, const float* c7n, int64_t M, float* out, void* stream);
 /* reference-layout basis/MLP weights in `sc` -> packed blob (dev, ego_packed_floats_scene(sc) floats) */
 int ego_pack_mlp(const ego_scene* sc, float* packed_out, void* stream);
+/* the same with a choice of what is written: for_training != 0 writes only the regions the differentiable path reads (the fp32 and
+ * fp16-split fragment layouts and the basis fragments) and leaves the f16f8 / f16f6 inference images of the blob untouched - a training
+ * step re-packs after every optimiser step and never reads them (a memset and three kernels saved per step).  A scene packed this way
+ * must be shaded with EGO_PREC_F16X3 or EGO_PREC_F32.  ego_pack_mlp(sc, out, st) == ego_pack_mlp_for(sc, out, 0, st). */
+int ego_pack_mlp_for(const ego_scene* sc, float* packed_out, int32_t for_training, void* stream);
+/* The fp32 compatibility layout (what ego_packed_floats_scene / ego_pack_mlp produce for a non-tuned shape) for ANY supported shape,
+ * the tuned one included: a scene whose `packed` points at this blob can be trained through ego_shade_train_generic /
+ * ego_shade_backward_generic / ego_scatter_generic, i.e. with fp32 activations, fp32 dumps and fp32 weight-gradient operands like the
+ * reference's autograd (train.py:312-314) - the parity mode beside the tuned training path, whose x / h1 / h2 dumps and dh1 / dh2 are
+ * halves (weight gradients carry ~2^-12 relative error per operand, activations above 65504 are not representable). */
+int64_t ego_packed_floats_compat(const ego_scene* sc);
+int ego_pack_mlp_compat(const ego_scene* sc, float* packed_out, void* stream);
 
 /* ---- the fused hot path ------------------------------------------------------------------------ */
 

@@ -14,6 +14,8 @@ from egonerf_amd.renderer import psnr_from_sse, shard_bounds
 from egonerf_amd.sampler import SimpleSampler, ThetaImportanceSampler
 from tests.helpers import make_model
 
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
 
 def test_library_exports_every_header_symbol():
     lib = _lib.load()
@@ -332,3 +334,20 @@ def test_kept_variants_compile(tmp_path, flags):
         text = open(os.path.join(build.CSRC, f)).read()
         stray = set(re.findall(r"#\s*if(?:n?def)?\s+(?:!?\s*defined\s*\(?\s*)?(EGO_[A-Z0-9_]+)", text)) - macros
         assert not stray, (f, stray)
+
+
+def test_roctx_switch_loads_and_is_off_by_default():
+    """EGO_ROCTX=1 (SURVEY 5 tracing row): the entry points open roctx ranges through a dlopen'ed roctx library - the library must load,
+    the hooks must resolve (no stderr complaint) and a traced call must still return its normal status, with or without the switch."""
+    import subprocess
+    import sys
+    code = ("from egonerf_amd import _lib; lib = _lib.load(); "
+            "print(lib.ego_raw2alpha(None, None, 0, 4, None, None, None, None), lib.ego_sh_render(None, None, 5, None, None))")
+    for switch in ("1", "0", None):
+        env = {k: v for k, v in os.environ.items() if k != "EGO_ROCTX"}
+        if switch is not None:
+            env["EGO_ROCTX"] = switch
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=REPO, env=env, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert r.stdout.split() == ["0", "-1"], r.stdout        # N = 0 is a no-op; a null argument is still refused inside a range
+        assert "roctx" not in r.stderr, r.stderr

@@ -69,7 +69,9 @@ def test_hip_renders_the_other_heads_like_the_reference(golden, name):
     cfg = _cfg(name)
     model = make_model(cfg, synth.make_weights(cfg, seed=int(fx["seed_weights"])), "cuda")
     assert model.shadingMode == HEADS[name]["shadingMode"] and model.get_kwargs()["shadingMode"] == model.shadingMode
-    assert type(model.renderModule).__name__ == {"MLP": "MLPRender", "RGB": "RGBRender"}[model.shadingMode]
+    # MLPRender is a module, RGBRender a plain function - as in the reference (tensorBase.py:37-39, EgoNeRF.py:152)
+    assert getattr(model.renderModule, "__name__", type(model.renderModule).__name__) == {"MLP": "MLPRender", "RGB": "RGBRender"}[model.shadingMode]
+    assert isinstance(model.renderModule, torch.nn.Module) == (name != "rgb_head")
     sd = model.state_dict()
     assert ("renderModule.mlp.0.weight" in sd) == (name != "rgb_head")
     rays = T(synth.make_rays(48, seed=int(fx["seed_rays"]))).cuda()

@@ -18,6 +18,7 @@ import numpy as np
 import pytest
 import torch
 
+from egonerf_amd import synth
 from tests.helpers import campaign_cases, make_model, make_oracle
 
 pytestmark = pytest.mark.gpu
@@ -26,11 +27,11 @@ TOL, WATCH, K = 1e-4, 5e-5, 3.0
 MAX_EXCUSED = 2   # rays per (seed, arithmetic) that may exceed 1e-4 vs the float32 oracle under the float64 argument above; asserted, not printed
 
 
-@pytest.mark.parametrize("prec", ["f16f6", "f16x3"])
+@pytest.mark.parametrize("prec", ["f16f6", "f16f8", "f16x3"])   # every shipped split arithmetic (f16f8 had lost its campaign)
 @pytest.mark.parametrize("seed", [13, 23])
 def test_campaign_vs_float32_and_float64_oracle(seed, prec):
     torch.set_num_threads(16)
-    worst, watched, excused, ratio = 0.0, 0, 0, 0.0
+    worst, watched, excused, ratio, worst_dpsnr = 0.0, 0, 0, 0.0, 0.0
     for case, cfg, w, rays, kw in campaign_cases(seed, 20):
         model, oracle = make_model(cfg, w, "cuda"), make_oracle(cfg, w)
         model.mlp_precision = prec
@@ -38,6 +39,10 @@ def test_campaign_vs_float32_and_float64_oracle(seed, prec):
             got = model(rays.cuda(), exp_sampling=True, **kw)
             ref = oracle.forward(rays, **kw)
         rgb = got[0].cpu()
+        if rays.shape[0] >= 64:   # north_star's PSNR clause on a ~30 dB target (a handful of rays is not an image: one ray moves its PSNR)
+            d_psnr = synth.delta_psnr(rgb.numpy(), ref[0].numpy(), seed=seed * 100 + case)[0]
+            assert abs(d_psnr) <= 1e-3, (seed, case, prec, d_psnr)
+            worst_dpsnr = max(worst_dpsnr, abs(d_psnr))
         per_ray = (rgb - ref[0]).abs().max(dim=1).values
         look = torch.nonzero(per_ray > WATCH).flatten()
         if len(look):
@@ -70,4 +75,4 @@ def test_campaign_vs_float32_and_float64_oracle(seed, prec):
     assert worst <= TOL
     assert excused <= MAX_EXCUSED, f"seed {seed} {prec}: {excused} rays needed the float64 excuse (allowed: {MAX_EXCUSED})"
     print(f"campaign seed {seed} {prec}: worst |dRGB| {worst:.2e}, {watched} rays above {WATCH:g} checked against float64, {excused} ill-conditioned in the reference, "
-          f"worst |HIP - f64| / |f32 oracle - f64| = {ratio:.2f}")
+          f"worst |HIP - f64| / |f32 oracle - f64| = {ratio:.2f}, worst |delta PSNR| on a 30 dB target {worst_dpsnr:.1e} dB")

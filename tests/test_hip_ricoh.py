@@ -44,6 +44,13 @@ def assert_matches_reference(model, rays, got, want_rgb, want_depth, kw):
     e_rgb = (got[0].cpu() - torch.from_numpy(want_rgb)).abs().amax(1)
     e_d = (got[1].cpu() - torch.from_numpy(want_depth)).abs()
     bad = ((e_rgb > RGB_TOL) | (e_d > DEPTH_TOL)).nonzero().flatten()
+    # north_star's PSNR clause, stated directly (renderer.py:156-157): gt = the reference's image + integer-hash noise at ~30 dB;
+    # PSNR(HIP, gt) and PSNR(reference, gt) agree to 1e-3 dB over the rays both evaluate on the same grid (the border rays below
+    # are a property of the reference's float32 comparisons and are checked against the oracle with the grid choice forced)
+    ok = torch.ones(e_rgb.shape[0], dtype=torch.bool)
+    ok[bad] = False
+    d_psnr, _p_hip, p_ref = synth.delta_psnr(got[0].cpu()[ok].numpy(), want_rgb[ok.numpy()])
+    assert 28.0 < p_ref < 36.0 and abs(d_psnr) <= 1e-3, (d_psnr, p_ref)
     if bad.numel() == 0:
         return 0
     assert bad.numel() <= max(2, rays.shape[0] // 200), f"{bad.numel()} rays off: not a border effect"

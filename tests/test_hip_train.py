@@ -40,6 +40,32 @@ def test_gradients_match_reference_autograd(golden):
     assert not bad, bad
 
 
+def test_fp32_parity_mode_of_the_tuned_head(golden):
+    """the tuned training path keeps x / h1 / h2 / dh1 / dh2 as halves; `model.train_fp32_head = True` (EGO_TRAIN_FP32=1)
+    trains the same head through the fp32 compatibility kernels - fp32 dumps and fp32 weight-gradient operands like the reference's
+    autograd - and must meet the reference's gradients at least as closely (bounds 4x tighter on the MLP weights than the default's)."""
+    fx = golden("tiny")
+    cfg = synth.SceneConfig(n_voxel=int(fx["n_voxel"]))
+    worst = {}
+    for fp32 in (False, True):
+        model = make_model(cfg, synth.make_weights(cfg, seed=int(fx["seed_weights"])), DEV)
+        model.train()
+        model.train_fp32_head = fp32
+        rgb, *_ = model(T(fx["rays"]), is_train=True, n_coarse=16, n_fine=16, exp_sampling=True, resampling=True, use_coarse_sample=True,
+                        jitter=T(fx["tr_jitter"]), u=T(fx["tr_u"]))
+        assert float((rgb.detach().cpu() - torch.from_numpy(fx["tr_rgb"])).abs().max()) <= 1e-4
+        torch.mean((rgb - T(fx["bw_gt"])) ** 2).backward()
+        worst[fp32] = {}
+        for k, p in model.named_parameters():
+            ref = fx["bw_grad/" + k]
+            worst[fp32][k] = float(np.abs(p.grad.detach().cpu().numpy() - ref).max()) / max(float(np.abs(ref).max()), 1e-12)
+    mlp = [k for k in worst[True] if k.startswith("renderModule") or k.startswith("basis_mat")]
+    assert max(worst[True].values()) <= 2e-4, worst[True]
+    assert max(worst[True][k] for k in mlp) <= 5e-5, {k: worst[True][k] for k in mlp}
+    print("max relative gradient error vs the reference's autograd, MLP / basis tensors: halves", max(worst[False][k] for k in mlp),
+          "fp32 parity mode", max(worst[True][k] for k in mlp))
+
+
 def test_gradients_full_grid_vs_float64_truth():
     """Barbershop-size grid, 128 rays x (32+32) with resampling (opaque samples make the transmittance backward
     ill-conditioned: t = 1 - alpha + 1e-10 ~ 1e-10).  Truth = the oracle evaluated in float64; the HIP gradients must be

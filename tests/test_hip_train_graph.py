@@ -246,3 +246,74 @@ def test_capturable_adam_state_dict_carries_the_device_clock():
         for q, gr in zip(b, grads[0]):
             q.grad = gr
         oc.step()
+
+
+def test_capturable_adam_loads_a_checkpoint_written_without_the_device_clock():
+    """a state dict saved in non-capturable mode (the caller decays group['lr'] itself, train.py:328-329) loaded into
+    a capturable optimiser must continue at the saved step count with the saved (already decayed) rates as base rates - not restart
+    the bias correction at t = 0."""
+    g = torch.Generator().manual_seed(11)
+    mk = lambda: [torch.randn(17, 9, generator=g).to(DEV).requires_grad_(True), torch.randn(40, generator=g).to(DEV).requires_grad_(True)]
+    g.manual_seed(11); a = mk()
+    g.manual_seed(11); b = mk()
+    grads = [[torch.randn(p.shape, generator=g).to(DEV) for p in a] for _ in range(6)]
+    factor = 0.9
+    oa = FusedAdam([dict(params=a, lr=0.01)], betas=(0.9, 0.99))     # eager reference: six steps, host-side decay
+    ob = FusedAdam([dict(params=b, lr=0.01)], betas=(0.9, 0.99))
+    for k in range(3):
+        for p, q, gr in zip(a, b, grads[k]):
+            p.grad, q.grad = gr, gr.clone()
+        oa.step(), ob.step()
+        for o in (oa, ob):
+            o.param_groups[0]["lr"] *= factor
+    sd = ob.state_dict()
+    assert "ego_clock" not in sd
+    oc = FusedAdam([dict(params=b, lr=0.01)], betas=(0.9, 0.99), capturable=True, lr_factor=factor)
+    oc.load_state_dict(sd)
+    assert oc.steps_taken() == 3 and oc.lr_scale() == 1.0 and abs(oc.current_lrs()[0] - 0.01 * factor ** 3) < 1e-12
+    for k in range(3, 6):
+        for p, q, gr in zip(a, b, grads[k]):
+            p.grad, q.grad = gr, gr.clone()
+        oa.step(), oc.step()
+        oa.param_groups[0]["lr"] *= factor
+    for p, q in zip(a, b):
+        assert float((p.detach() - q.detach()).abs().max()) <= 1e-7
+
+
+def test_graphed_step_passes_the_schedule_only_on_opt_in():
+    """no arity sniffing - a fourth parameter with an unrelated default keeps its default, a *args loss gets the
+    schedule with schedule_aware=True, a parameter named `sched` opts in by itself."""
+    from egonerf_amd.train import TrainSchedule
+    cfg = synth.SceneConfig(n_voxel=20 ** 3)
+    rays = torch.from_numpy(synth.make_rays(64, seed=2)).to(DEV)
+    gt = torch.rand(64, 3, device=DEV)
+    kw = dict(n_coarse=16, exp_sampling=True)
+    seen = {}
+
+    def make(loss_fn, **extra):
+        m = make_model(cfg, synth.make_weights(cfg, seed=9), DEV)
+        m.train()
+        o = FusedAdam(m.get_optparam_groups(0.02, 1e-3), betas=(0.9, 0.99), capturable=True)
+        return GraphedTrainStep(m, o, rays, gt, kw, loss_fn=loss_fn, warmup=1, **extra)
+
+    def with_default(rgb, tgt, alpha, reduction="mean"):
+        seen["reduction"] = reduction
+        return torch.mean((rgb - tgt) ** 2)
+
+    def star(*args):
+        seen["n_args"] = len(args)
+        seen["last"] = args[-1]
+        return torch.mean((args[0] - args[1]) ** 2)
+
+    def named(rgb, tgt, alpha, sched):
+        seen["named"] = sched
+        return torch.mean((rgb - tgt) ** 2)
+
+    make(with_default)
+    assert seen["reduction"] == "mean"
+    make(star)
+    assert seen["n_args"] == 3
+    make(star, schedule_aware=True)
+    assert seen["n_args"] == 4 and isinstance(seen["last"], TrainSchedule)
+    make(named)
+    assert isinstance(seen["named"], TrainSchedule)
