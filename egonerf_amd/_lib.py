@@ -113,6 +113,10 @@ PROTOTYPES = {
     "ego_march_backward": (C.c_int, [SP, P, P, I32, P, P, P, P, P, P, P, P, I64, I32, P, P, P]),
     "ego_scatter_density": (C.c_int, [SP, C.POINTER(VmGrad), P, P, I64, I32, P]),
     "ego_scatter_app": (C.c_int, [SP, C.POINTER(VmGrad), P, P, I64, I32, P]),
+    "ego_scatter_sorted_workspace_bytes": (C.c_int64, [SP, I64, I32]),
+    "ego_scatter_sort": (C.c_int, [SP, P, I64, I32, P, I64, P]),
+    "ego_scatter_density_sorted": (C.c_int, [SP, C.POINTER(VmGrad), P, P, I64, I32, P, I64, P]),
+    "ego_scatter_app_sorted": (C.c_int, [SP, C.POINTER(VmGrad), P, P, I64, I32, P, I64, P]),
     "ego_envmap_backward": (C.c_int, [SP, P, I32, P, P, P, P, I64, P, P]),
     "ego_shade_backward": (C.c_int, [SP, P, P, P, P, C.POINTER(ShadeDump), P, P, P, P, P, I64, I32, P]),
     "ego_sh_render": (C.c_int, [P, P, I64, P, P]),
@@ -120,6 +124,8 @@ PROTOTYPES = {
     "ego_shade_backward_generic": (C.c_int, [SP, P, P, P, P, I32, P, P, I32, P, P, P, P, I32, I64, I32, P]),
     "ego_scatter_generic": (C.c_int, [C.POINTER(VmField), C.POINTER(VmGrad), P, P, I32, I64, I32, P]),
     "ego_weight_grad": (C.c_int, [P, I32, I32, I32, P, P, I32, I32, I32, I32, I64, P, I32, P]),
+    "ego_weight_grad_partial_floats": (C.c_int64, []),
+    "ego_weight_grad_det": (C.c_int, [P, I32, I32, I32, P, P, I32, I32, I32, I32, I64, P, I32, P, I64, P]),
     "ego_tv_plane": (C.c_int, [P, I32, I32, I32, F32, P, P, P]),
     "ego_l1_table": (C.c_int, [P, I64, F32, P, P, P]),
     "ego_line_ortho": (C.c_int, [P, I32, I32, F32, P, P, P]),

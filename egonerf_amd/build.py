@@ -9,7 +9,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libegonerf_hip.so")
-SOURCES = ["ego_ops.hip", "ego_shade.hip", "ego_render.hip", "ego_reg.hip", "ego_metrics.hip", "ego_wgrad.hip", "ego_generic.hip", "ego_selftest.hip"]
+SOURCES = ["ego_ops.hip", "ego_shade.hip", "ego_render.hip", "ego_reg.hip", "ego_metrics.hip", "ego_wgrad.hip", "ego_generic.hip", "ego_selftest.hip", "ego_scatter_sorted.hip"]
 HEADERS = ["ego_device.h", "ego_host.h", "ego_train.inc", "variants.h", "ego_generic.h", os.path.join("..", "..", "include", "egonerf_hip.h")]
 
 

@@ -1,0 +1,509 @@
+// libegonerf_hip.so, part 9: the table-gradient scatter without atomics - bit-reproducible (SURVEY 5 "sorted-segment mode", VERDICT r04
+// item 3).  Backward of F.grid_sample in compute_densityfeature / compute_appfeature (models/EgoNeRF.py:291-347, :349-413) under
+// train.py:312-314, for the tuned table shapes (16 density / 48 appearance components).
+//
+// k_vm_scatter (ego_train.inc) walks rays and sends one float-atomic line per (cell run, tap): ~16 M atomic line requests per 8192 x 256
+// step at the L2's ~21 G/s plus ~0.95 ms of cell bookkeeping, and a sum whose order changes from run to run.  Here the step's samples are
+// binned by texel CELL once (three stable radix sorts of 18-bit keys: rocPRIM's device radix sort, the one library primitive of this
+// file - the sort is plumbing, the reductions are the kernels), and every gradient texel is then written exactly once from sums taken in a
+// fixed order:
+//
+//   ego_scatter_sort      : coords -> three permutations + cell start offsets (needs only the forward's coordinates: it runs on the side
+//                           stream next to the dumping shade forward, and both fields share it)
+//       sort 0: key (grid, phi cell, r cell)     -> cells of plane 1 (x = r, y = phi), ranges of line 0 (phi)
+//       sort 1: key (grid, r cell, theta cell)   -> cells of plane 0 (x = r, y = theta), ranges of line 2 (r)
+//       sort 2: key (grid, theta cell, phi cell) -> cells of plane 2 (x = theta, y = phi), ranges of line 1 (theta)
+//     a cell = the unclamped west tap index + 1 (0 .. n); a sample whose two taps of an axis are both out of range has no gradient
+//     through that axis and sorts behind everything else
+//   k_sorted_plane        : one wave per cell: its samples (contiguous, in ascending sample order: the sort is stable) are dealt to the four
+//                           16-lane groups (lane = channel of a 64-byte line, as in k_vm_scatter), each keeps the four corner sums in
+//                           registers, the groups are folded in a fixed tree and the cell's four corner sums go to a cell buffer
+//   k_sorted_plane_final  : texel = the four corner sums of its four neighbouring cells, added in a fixed order, one store
+//   k_sorted_line         : a line cell holds thousands of samples: fixed 256-sample sub-blocks of its range, one wave each -> partial sums
+//   k_sorted_line_final   : texel = its two cells' partials, added in sub-block order
+//
+// No zero fill of the gradient tables is needed (every texel is written), no atomics, and two runs return the same bits.
+#include <rocprim/device/device_radix_sort.hpp>
+
+#include "ego_device.h"
+#include "ego_host.h"
+
+namespace {
+
+constexpr int SUB = 256;       // samples per line sub-block
+constexpr int CMAX = 48;       // channels of the widest field (appearance)
+
+// sort s: major / minor axis of its key (0 r, 1 theta, 2 phi), the plane whose cells it bins and the line whose ranges it bins
+__host__ __device__ constexpr int sort_major(int s) { return s == 0 ? 2 : s == 1 ? 0 : 1; }
+__host__ __device__ constexpr int sort_minor(int s) { return s == 0 ? 0 : s == 1 ? 1 : 2; }
+__host__ __device__ constexpr int sort_plane(int s) { return s == 0 ? 1 : s == 1 ? 0 : 2; }
+__host__ __device__ constexpr int sort_line(int s) { return s == 0 ? 0 : s == 1 ? 2 : 1; }
+
+struct SortGeom {
+  int32_t res[3];      // N_r, N_theta, N_phi
+  int64_t M;
+  uint32_t K[3];       // keys per sort = 2 (n_major + 1) (n_minor + 1); key K = "no gradient through this pair of axes"
+  uint32_t LC[3];      // line cells per sort = 2 (n_major + 1)
+  uint32_t nsub_max;   // upper bound of the line sub-blocks of one sort
+  int bits;            // key bits (covers max K)
+  // byte offsets into the workspace
+  int64_t perm[3], start[3], suboff[3], scratch, total;
+  // sort-phase view of the scratch region
+  int64_t keys_in[3], keys_out, idx_in, rp_temp;
+  size_t rp_bytes;
+  // scatter-phase view of the scratch region
+  int64_t cellbuf[3], linepart[3];
+};
+
+inline int64_t align256(int64_t v) { return (v + 255) & ~(int64_t)255; }
+
+SortGeom make_geom(const int32_t res[3], int64_t M) {
+  SortGeom G{};
+  G.M = M;
+  uint32_t kmax = 0, lcmax = 0;
+  for (int a = 0; a < 3; ++a) G.res[a] = res[a];
+  for (int s = 0; s < 3; ++s) {
+    const uint32_t nmaj = (uint32_t)res[sort_major(s)] + 1, nmin = (uint32_t)res[sort_minor(s)] + 1;
+    G.K[s] = 2u * nmaj * nmin;
+    G.LC[s] = 2u * nmaj;
+    kmax = G.K[s] > kmax ? G.K[s] : kmax;
+    lcmax = G.LC[s] > lcmax ? G.LC[s] : lcmax;
+  }
+  G.bits = 1;
+  while ((1ull << G.bits) <= kmax) ++G.bits;      // keys 0 .. K inclusive
+  G.nsub_max = (uint32_t)(M / SUB) + lcmax + 1;
+  int64_t o = 0;
+  for (int s = 0; s < 3; ++s) { G.perm[s] = o; o = align256(o + 4 * M); }
+  for (int s = 0; s < 3; ++s) { G.start[s] = o; o = align256(o + 4 * ((int64_t)G.K[s] + 2)); }
+  for (int s = 0; s < 3; ++s) { G.suboff[s] = o; o = align256(o + 4 * ((int64_t)G.LC[s] + 1)); }
+  G.scratch = o;
+  // sort phase
+  int64_t a = o;
+  for (int s = 0; s < 3; ++s) { G.keys_in[s] = a; a = align256(a + 4 * M); }
+  G.keys_out = a; a = align256(a + 4 * M);
+  G.idx_in = a; a = align256(a + 4 * M);
+  G.rp_temp = a;
+  G.rp_bytes = 0;
+  (void)rocprim::radix_sort_pairs(nullptr, G.rp_bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr,
+                                  (size_t)M, 0u, (unsigned)G.bits, (hipStream_t)0);
+  a = align256(a + (int64_t)G.rp_bytes);
+  // scatter phase
+  int64_t b = o;
+  for (int s = 0; s < 3; ++s) { G.cellbuf[s] = b; b = align256(b + 4 * (int64_t)G.K[s] * 4 * CMAX); }
+  for (int s = 0; s < 3; ++s) { G.linepart[s] = b; b = align256(b + 4 * (int64_t)G.nsub_max * 2 * CMAX); }
+  G.total = a > b ? a : b;
+  return G;
+}
+
+// the unclamped west tap index + 1 (0 .. n) with lin_setup's arithmetic, or -1 when both taps are out of range
+__device__ __forceinline__ int cell_of(float xhat, int n) {
+  const float ix = __fmul_rn(__fadd_rn(xhat, 1.0f), 0.5f * (float)(n - 1));
+  const float flc = fminf(fmaxf(floorf(ix), -2.0f), (float)n);
+  const int i0 = (int)flc;
+  return (i0 < -1 || i0 > n - 1) ? -1 : i0 + 1;
+}
+
+__global__ void k_sort_keys(const float* __restrict__ coords, int64_t M, int nr, int nth, int nph, uint32_t K0, uint32_t K1, uint32_t K2,
+                            uint32_t* __restrict__ k0, uint32_t* __restrict__ k1, uint32_t* __restrict__ k2, uint32_t* __restrict__ idx) {
+  const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= M) return;
+  const f32x4 cc = ((const f32x4*)coords)[m];
+  const uint32_t g = cc.w != 0.f ? 1u : 0u;
+  const int cr = cell_of(cc.x, nr), cth = cell_of(cc.y, nth), cph = cell_of(cc.z, nph);
+  k0[m] = (cph < 0 || cr < 0) ? K0 : (g * (uint32_t)(nph + 1) + (uint32_t)cph) * (uint32_t)(nr + 1) + (uint32_t)cr;
+  k1[m] = (cr < 0 || cth < 0) ? K1 : (g * (uint32_t)(nr + 1) + (uint32_t)cr) * (uint32_t)(nth + 1) + (uint32_t)cth;
+  k2[m] = (cth < 0 || cph < 0) ? K2 : (g * (uint32_t)(nth + 1) + (uint32_t)cth) * (uint32_t)(nph + 1) + (uint32_t)cph;
+  idx[m] = (uint32_t)m;
+}
+
+// start[k] = first sorted position whose key is >= k, k = 0 .. K + 1 (start[K] = the number of samples with a gradient)
+__global__ void k_cell_starts(const uint32_t* __restrict__ sorted, int64_t M, uint32_t K, uint32_t* __restrict__ start) {
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k > K + 1) return;
+  int64_t lo = 0, hi = M;
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (sorted[mid] < k) lo = mid + 1; else hi = mid;
+  }
+  start[k] = (uint32_t)lo;
+}
+
+// suboff[lc] = number of 256-sample sub-blocks of the line cells before lc (exclusive scan; suboff[LC] = total); one workgroup
+__global__ __launch_bounds__(1024) void k_line_suboff(const uint32_t* __restrict__ start, uint32_t LC, uint32_t nmin1, uint32_t* __restrict__ suboff) {
+  __shared__ uint32_t wsum[16];
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  uint32_t carry = 0;
+  for (uint32_t base = 0; base < LC; base += 1024) {
+    const uint32_t lc = base + t;
+    uint32_t n = 0;
+    if (lc < LC) n = (start[(lc + 1) * nmin1] - start[lc * nmin1] + SUB - 1) / SUB;
+    uint32_t inc = n;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t v = __shfl_up(inc, d, 64);
+      if (lane >= d) inc += v;
+    }
+    if (lane == 63) wsum[wv] = inc;
+    __syncthreads();
+    uint32_t before = 0;
+    for (int w = 0; w < wv; ++w) before += wsum[w];
+    uint32_t all = 0;
+    for (int w = 0; w < 16; ++w) all += wsum[w];
+    if (lc < LC) suboff[lc] = carry + before + inc - n;
+    carry += all;
+    __syncthreads();
+  }
+  if (t == 0) suboff[LC] = carry;
+}
+
+struct GradTables {
+  float* plane[2][3];
+  float* line[2][3];
+};
+
+struct SortedArgs {
+  DevField F;
+  GradTables G;
+  const float* coords;   // [M][4]
+  const float* d;        // DENS: dfeat [M]; else k_shade_bwd's blocked dv
+  const uint32_t* perm[3];
+  const uint32_t* start[3];
+  const uint32_t* suboff[3];
+  float* cellbuf[3];
+  float* linepart[3];
+  uint32_t K[3], LC[3];
+};
+
+// fold the four 16-lane groups of a wave: lanes 0..15 end up with (g0 + g1) + (g2 + g3)
+__device__ __forceinline__ float fold_groups(float v) {
+  v += __shfl_down(v, 16, 64);
+  v += __shfl_down(v, 32, 64);
+  return v;
+}
+
+// ---- planes: one wave per cell ----------------------------------------------------------------------------------------------------
+template <int C, bool DENS, int S_>
+__device__ __forceinline__ void sorted_plane(const SortedArgs& A) {
+#pragma clang fp contract(fast)
+  constexpr int NL = C / 16, I = sort_plane(S_);
+  constexpr int AX = vm_plane_x(I), AY = vm_plane_y(I), AL = vm_line_ax(I);
+  const int lane = threadIdx.x & 63, c16 = lane & 15, q = lane >> 4;
+  const uint32_t k = blockIdx.x * 4u + (threadIdx.x >> 6);
+  if (k >= A.K[S_]) return;
+  const uint32_t a = A.start[S_][k], b = A.start[S_][k + 1];
+  if (a == b) return;   // empty cell: nothing written, k_sorted_plane_final does not read it
+  const int nmin1 = A.F.res[sort_minor(S_)] + 1, nmaj1 = A.F.res[sort_major(S_)] + 1;
+  const int cmin = (int)(k % (uint32_t)nmin1), t_ = (int)(k / (uint32_t)nmin1);
+  const int cmaj = t_ % nmaj1, g = t_ / nmaj1;
+  const int cX = sort_major(S_) == AX ? cmaj : cmin, cY = sort_major(S_) == AY ? cmaj : cmin;
+  const int W = A.F.res[AX], H = A.F.res[AY];
+  const int x0 = max(cX - 1, 0), x1 = min(cX, W - 1), y0 = max(cY - 1, 0), y1 = min(cY, H - 1);   // the clamped tap indices of lin_setup
+  const int oP[4] = {(y0 * W + x0) * C, (y0 * W + x1) * C, (y1 * W + x0) * C, (y1 * W + x1) * C};
+  const float* P = (g ? A.F.plane[1][I] : A.F.plane[0][I]) + c16;
+  const float* L = (g ? A.F.line[1][I] : A.F.line[0][I]) + c16;
+  float acc[NL][4];
+#pragma unroll
+  for (int i = 0; i < NL; ++i) acc[i][0] = acc[i][1] = acc[i][2] = acc[i][3] = 0.f;
+  for (uint32_t p = a + (uint32_t)q; p < b; p += 4) {
+    const int64_t m = A.perm[S_][p];
+    float dsample = 0.f;
+    if (DENS) {
+      dsample = A.d[m];
+      if (dsample == 0.f) continue;   // uniform over the 16-lane group
+    }
+    const f32x4 cc = ((const f32x4*)A.coords)[m];
+    const float ax[3] = {cc.x, cc.y, cc.z};
+    const Lin1 X = lin_setup(ax[AX], W), Y = lin_setup(ax[AY], H), Ln = lin_setup(ax[AL], A.F.res[AL]);
+    const float w00 = __fmul_rn(Y.w0, X.w0), w01 = __fmul_rn(Y.w0, X.w1), w10 = __fmul_rn(Y.w1, X.w0), w11 = __fmul_rn(Y.w1, X.w1);
+    const int oL0 = Ln.i0 * C, oL1 = Ln.i1 * C;
+    float lv[NL], di[NL];
+#pragma unroll
+    for (int i = 0; i < NL; ++i) lv[i] = L[oL0 + 16 * i] * Ln.w0 + L[oL1 + 16 * i] * Ln.w1;
+    if (DENS) {
+      // relu per plane (EgoNeRF.py:340,346): the gradient passes where this plane's sum over channels is positive
+      float dot = (P[oP[0]] * w00 + P[oP[1]] * w01 + P[oP[2]] * w10 + P[oP[3]] * w11) * lv[0];
+#pragma unroll
+      for (int sh = 8; sh >= 1; sh >>= 1) dot += __shfl_xor(dot, sh, 16);
+      di[0] = dot > 0.f ? dsample : 0.f;
+    } else {
+#pragma unroll
+      for (int i = 0; i < NL; ++i) di[i] = A.d[(m >> 5) * (32 * 3 * C) + (I * NL + i) * 512 + (m & 31) * 16 + c16];   // k_shade_bwd's blocked dv
+    }
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      const float gp = di[i] * lv[i];
+      acc[i][0] += gp * w00; acc[i][1] += gp * w01; acc[i][2] += gp * w10; acc[i][3] += gp * w11;
+    }
+  }
+  float* out = A.cellbuf[S_] + (int64_t)k * 4 * C + c16;
+#pragma unroll
+  for (int i = 0; i < NL; ++i)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const float v = fold_groups(acc[i][t]);
+      if (q == 0) out[t * C + 16 * i] = v;
+    }
+}
+
+template <int C, bool DENS>
+__global__ __launch_bounds__(256) void k_sorted_plane(SortedArgs A) {
+  if (blockIdx.y == 0) sorted_plane<C, DENS, 0>(A);
+  else if (blockIdx.y == 1) sorted_plane<C, DENS, 1>(A);
+  else sorted_plane<C, DENS, 2>(A);
+}
+
+// texel (g, ty, tx) of plane sort_plane(s): corner 0 (y0, x0) of cell (ty + 1, tx + 1), corner 1 (y0, x1) of cell (ty + 1, tx), corner 2
+// (y1, x0) of cell (ty, tx + 1), corner 3 (y1, x1) of cell (ty, tx); thread = (texel, 4 channels)
+template <int C, int S_>
+__device__ __forceinline__ void sorted_plane_final(const SortedArgs& A) {
+  constexpr int I = sort_plane(S_), AX = vm_plane_x(I), AY = vm_plane_y(I), Q = C / 4;
+  const int W = A.F.res[AX], H = A.F.res[AY];
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)2 * H * W * Q) return;
+  const int c4 = (int)(idx % Q);
+  const int64_t tex = idx / Q;
+  const int tx = (int)(tex % W), ty = (int)((tex / W) % H), g = (int)(tex / ((int64_t)W * H));
+  const int nmin1 = A.F.res[sort_minor(S_)] + 1, nmaj1 = A.F.res[sort_major(S_)] + 1;
+  f32x4 sum[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int cy = ty + (t < 2 ? 1 : 0), cx = tx + ((t & 1) ? 0 : 1);
+    const int cmaj = sort_major(S_) == AX ? cx : cy, cmin = sort_major(S_) == AX ? cy : cx;
+    const uint32_t k = ((uint32_t)g * (uint32_t)nmaj1 + (uint32_t)cmaj) * (uint32_t)nmin1 + (uint32_t)cmin;
+    sum[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (A.start[S_][k + 1] != A.start[S_][k]) sum[t] = *(const f32x4*)(A.cellbuf[S_] + ((int64_t)k * 4 + t) * C + 4 * c4);
+  }
+  const f32x4 r = (sum[0] + sum[1]) + (sum[2] + sum[3]);
+  *(f32x4*)((g ? A.G.plane[1][I] : A.G.plane[0][I]) + ((int64_t)ty * W + tx) * C + 4 * c4) = r;
+}
+
+template <int C>
+__global__ void k_sorted_plane_final(SortedArgs A) {
+  if (blockIdx.y == 0) sorted_plane_final<C, 0>(A);
+  else if (blockIdx.y == 1) sorted_plane_final<C, 1>(A);
+  else sorted_plane_final<C, 2>(A);
+}
+
+// ---- lines: one wave per 256-sample sub-block of a line cell's range ------------------------------------------------------------------
+template <int C, bool DENS, int S_>
+__device__ __forceinline__ void sorted_line(const SortedArgs& A) {
+#pragma clang fp contract(fast)
+  constexpr int NL = C / 16, J = sort_line(S_);                      // line J, its co-plane J
+  constexpr int AX = vm_plane_x(J), AY = vm_plane_y(J), AL = vm_line_ax(J);
+  static_assert(AL == sort_major(S_), "the line's axis is the major key of its sort");
+  const int lane = threadIdx.x & 63, c16 = lane & 15, q = lane >> 4;
+  const uint32_t w = blockIdx.x * 4u + (threadIdx.x >> 6);
+  const uint32_t LC = A.LC[S_];
+  if (w >= A.suboff[S_][LC]) return;
+  // line cell of sub-block w: the last lc with suboff[lc] <= w (empty cells have suboff[lc] == suboff[lc + 1] and are never selected)
+  uint32_t lo = 0, hi = LC;
+  while (hi - lo > 1) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (A.suboff[S_][mid] <= w) lo = mid; else hi = mid;
+  }
+  const uint32_t lc = lo, j = w - A.suboff[S_][lc];
+  const uint32_t nmin1 = (uint32_t)A.F.res[sort_minor(S_)] + 1;
+  const uint32_t r0 = A.start[S_][lc * nmin1] + j * SUB, rend = A.start[S_][(lc + 1) * nmin1];
+  const uint32_t r1 = r0 + SUB < rend ? r0 + SUB : rend;
+  const int g = (int)(lc / ((uint32_t)A.F.res[AL] + 1));
+  const int W = A.F.res[AX], H = A.F.res[AY];
+  const float* P = (g ? A.F.plane[1][J] : A.F.plane[0][J]) + c16;
+  const float* L = (g ? A.F.line[1][J] : A.F.line[0][J]) + c16;
+  float acc[NL][2];
+#pragma unroll
+  for (int i = 0; i < NL; ++i) acc[i][0] = acc[i][1] = 0.f;
+  for (uint32_t p = r0 + (uint32_t)q; p < r1; p += 4) {
+    const int64_t m = A.perm[S_][p];
+    float dsample = 0.f;
+    if (DENS) {
+      dsample = A.d[m];
+      if (dsample == 0.f) continue;
+    }
+    const f32x4 cc = ((const f32x4*)A.coords)[m];
+    const float ax[3] = {cc.x, cc.y, cc.z};
+    const Lin1 X = lin_setup(ax[AX], W), Y = lin_setup(ax[AY], H), Ln = lin_setup(ax[AL], A.F.res[AL]);
+    const float w00 = __fmul_rn(Y.w0, X.w0), w01 = __fmul_rn(Y.w0, X.w1), w10 = __fmul_rn(Y.w1, X.w0), w11 = __fmul_rn(Y.w1, X.w1);
+    const int o00 = (Y.i0 * W + X.i0) * C, o01 = (Y.i0 * W + X.i1) * C, o10 = (Y.i1 * W + X.i0) * C, o11 = (Y.i1 * W + X.i1) * C;
+    float pv[NL], di[NL];
+#pragma unroll
+    for (int i = 0; i < NL; ++i) pv[i] = P[o00 + 16 * i] * w00 + P[o01 + 16 * i] * w01 + P[o10 + 16 * i] * w10 + P[o11 + 16 * i] * w11;
+    if (DENS) {
+      float dot = pv[0] * (L[Ln.i0 * C] * Ln.w0 + L[Ln.i1 * C] * Ln.w1);
+#pragma unroll
+      for (int sh = 8; sh >= 1; sh >>= 1) dot += __shfl_xor(dot, sh, 16);
+      di[0] = dot > 0.f ? dsample : 0.f;
+    } else {
+#pragma unroll
+      for (int i = 0; i < NL; ++i) di[i] = A.d[(m >> 5) * (32 * 3 * C) + (J * NL + i) * 512 + (m & 31) * 16 + c16];
+    }
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      const float gl = di[i] * pv[i];
+      acc[i][0] += gl * Ln.w0; acc[i][1] += gl * Ln.w1;
+    }
+  }
+  float* out = A.linepart[S_] + (int64_t)w * 2 * C + c16;
+#pragma unroll
+  for (int i = 0; i < NL; ++i)
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const float v = fold_groups(acc[i][t]);
+      if (q == 0) out[t * C + 16 * i] = v;
+    }
+}
+
+template <int C, bool DENS>
+__global__ __launch_bounds__(256) void k_sorted_line(SortedArgs A) {
+  if (blockIdx.y == 0) sorted_line<C, DENS, 0>(A);
+  else if (blockIdx.y == 1) sorted_line<C, DENS, 1>(A);
+  else sorted_line<C, DENS, 2>(A);
+}
+
+// line texel (g, t): west tap (weight w0) of the samples of cell t + 1, east tap (w1) of cell t; partials added in sub-block order
+template <int C, int S_>
+__device__ __forceinline__ void sorted_line_final(const SortedArgs& A) {
+  constexpr int J = sort_line(S_), AL = vm_line_ax(J);
+  const int n = A.F.res[AL];
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= 2 * n * C) return;
+  const int ch = idx % C, t = (idx / C) % n, g = idx / (C * n);
+  float s0 = 0.f, s1 = 0.f;
+  {
+    const uint32_t lc = (uint32_t)g * (uint32_t)(n + 1) + (uint32_t)t + 1;
+    for (uint32_t w = A.suboff[S_][lc]; w < A.suboff[S_][lc + 1]; ++w) s0 += A.linepart[S_][(int64_t)w * 2 * C + ch];
+  }
+  {
+    const uint32_t lc = (uint32_t)g * (uint32_t)(n + 1) + (uint32_t)t;
+    for (uint32_t w = A.suboff[S_][lc]; w < A.suboff[S_][lc + 1]; ++w) s1 += A.linepart[S_][(int64_t)w * 2 * C + C + ch];
+  }
+  (g ? A.G.line[1][J] : A.G.line[0][J])[t * C + ch] = s0 + s1;
+}
+
+template <int C>
+__global__ void k_sorted_line_final(SortedArgs A) {
+  if (blockIdx.y == 0) sorted_line_final<C, 0>(A);
+  else if (blockIdx.y == 1) sorted_line_final<C, 1>(A);
+  else sorted_line_final<C, 2>(A);
+}
+
+int fill_args(const ego_vm_field& f, const ego_vm_grad* grad, const float* coords, const float* d, const SortGeom& G, void* ws, SortedArgs* a, const char* who) {
+  if (!grad) return ego_fail(EGO_E_BADARG, "%s: null gradient struct", who);
+  for (int g = 0; g < 2; ++g)
+    for (int i = 0; i < 3; ++i) {
+      if (!f.plane[g][i] || !f.line[g][i] || !grad->plane[g][i] || !grad->line[g][i]) return ego_fail(EGO_E_BADARG, "%s: null table", who);
+      a->G.plane[g][i] = grad->plane[g][i];
+      a->G.line[g][i] = grad->line[g][i];
+    }
+  a->F = make_field(f);
+  a->coords = coords; a->d = d;
+  char* base = (char*)ws;
+  for (int s = 0; s < 3; ++s) {
+    a->perm[s] = (const uint32_t*)(base + G.perm[s]);
+    a->start[s] = (const uint32_t*)(base + G.start[s]);
+    a->suboff[s] = (const uint32_t*)(base + G.suboff[s]);
+    a->cellbuf[s] = (float*)(base + G.cellbuf[s]);
+    a->linepart[s] = (float*)(base + G.linepart[s]);
+    a->K[s] = G.K[s]; a->LC[s] = G.LC[s];
+  }
+  return EGO_OK;
+}
+
+template <int C, bool DENS>
+int launch_sorted(const SortedArgs& a, const SortGeom& G, hipStream_t st) {
+  uint32_t kmax = 0;
+  int64_t texmax = 0, linemax = 0;
+  for (int s = 0; s < 3; ++s) {
+    kmax = G.K[s] > kmax ? G.K[s] : kmax;
+    const int I = sort_plane(s);
+    const int64_t tex = (int64_t)2 * G.res[I == 2 ? 1 : 0] * G.res[I == 0 ? 1 : 2] * (C / 4);   // plane I: x axis, y axis (vm_plane_x / _y)
+    texmax = tex > texmax ? tex : texmax;
+    const int64_t ln = (int64_t)2 * G.res[sort_major(s)] * C;
+    linemax = ln > linemax ? ln : linemax;
+  }
+  k_sorted_plane<C, DENS><<<dim3((kmax + 3) / 4, 3), 256, 0, st>>>(a);
+  if (int e = ego_launch_status("k_sorted_plane")) return e;
+  k_sorted_line<C, DENS><<<dim3((G.nsub_max + 3) / 4, 3), 256, 0, st>>>(a);
+  if (int e = ego_launch_status("k_sorted_line")) return e;
+  k_sorted_plane_final<C><<<dim3((unsigned)((texmax + 255) / 256), 3), 256, 0, st>>>(a);
+  if (int e = ego_launch_status("k_sorted_plane_final")) return e;
+  k_sorted_line_final<C><<<dim3((unsigned)((linemax + 255) / 256), 3), 256, 0, st>>>(a);
+  return ego_launch_status("k_sorted_line_final");
+}
+
+int check_sizes(const ego_scene* sc, int64_t N, int32_t S, const char* who) {
+  if (!sc) return ego_fail(EGO_E_BADARG, "%s: null scene", who);
+  if (!(N >= 0 && S >= 1 && N * (int64_t)S < (1ll << 31))) return ego_fail(EGO_E_BADARG, "%s: bad size (N * S must be below 2^31)", who);
+  for (int a = 0; a < 3; ++a)
+    if (sc->density.res[a] < 2 || sc->density.res[a] > 4096) return ego_fail(EGO_E_BADARG, "%s: table resolution out of range [2, 4096]", who);
+  return EGO_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t ego_scatter_sorted_workspace_bytes(const ego_scene* sc, int64_t N, int32_t S) {
+  if (check_sizes(sc, N, S, "scatter_sorted_workspace_bytes")) return -1;
+  return make_geom(sc->density.res, N * (int64_t)S > 0 ? N * (int64_t)S : 1).total;
+}
+
+int ego_scatter_sort(const ego_scene* sc, const float* coords, int64_t N, int32_t S, void* workspace, int64_t workspace_bytes, void* stream) {
+  EGO_TRACE("ego_scatter_sort");
+  if (int e = check_sizes(sc, N, S, "scatter_sort")) return e;
+  if (N == 0) return EGO_OK;
+  EGO_REQUIRE(coords && workspace && ((uintptr_t)workspace & 255) == 0, "scatter_sort: null argument or workspace not 256-byte aligned");
+  for (int a = 0; a < 3; ++a)
+    EGO_REQUIRE(sc->app.res[a] == sc->density.res[a], "scatter_sort: the density and appearance fields must share one resolution (they do: EgoNeRF.py:102-122)");
+  const int64_t M = N * (int64_t)S;
+  const SortGeom G = make_geom(sc->density.res, M);
+  if (workspace_bytes < G.total) return ego_fail(EGO_E_BADARG, "scatter_sort: workspace too small (%lld < %lld bytes)", (long long)workspace_bytes, (long long)G.total);
+  hipStream_t st = (hipStream_t)stream;
+  char* base = (char*)workspace;
+  uint32_t* kin[3] = {(uint32_t*)(base + G.keys_in[0]), (uint32_t*)(base + G.keys_in[1]), (uint32_t*)(base + G.keys_in[2])};
+  uint32_t* kout = (uint32_t*)(base + G.keys_out);
+  uint32_t* idx = (uint32_t*)(base + G.idx_in);
+  k_sort_keys<<<(unsigned)((M + 255) / 256), 256, 0, st>>>(coords, M, G.res[0], G.res[1], G.res[2], G.K[0], G.K[1], G.K[2], kin[0], kin[1], kin[2], idx);
+  if (int e = ego_launch_status("k_sort_keys")) return e;
+  for (int s = 0; s < 3; ++s) {
+    size_t bytes = G.rp_bytes;
+    const hipError_t err = rocprim::radix_sort_pairs((void*)(base + G.rp_temp), bytes, (const uint32_t*)kin[s], kout, (const uint32_t*)idx,
+                                                     (uint32_t*)(base + G.perm[s]), (size_t)M, 0u, (unsigned)G.bits, st);
+    if (err != hipSuccess) return ego_fail((int)err, "scatter_sort: radix sort failed: %s", hipGetErrorString(err));
+    uint32_t* start = (uint32_t*)(base + G.start[s]);
+    k_cell_starts<<<(G.K[s] + 2 + 255) / 256, 256, 0, st>>>(kout, M, G.K[s], start);
+    if (int e = ego_launch_status("k_cell_starts")) return e;
+    k_line_suboff<<<1, 1024, 0, st>>>(start, G.LC[s], (uint32_t)G.res[sort_minor(s)] + 1, (uint32_t*)(base + G.suboff[s]));
+    if (int e = ego_launch_status("k_line_suboff")) return e;
+  }
+  return EGO_OK;
+}
+
+int ego_scatter_density_sorted(const ego_scene* sc, const ego_vm_grad* gdensity, const float* coords, const float* dfeat, int64_t N, int32_t S,
+                               void* workspace, int64_t workspace_bytes, void* stream) {
+  EGO_TRACE("ego_scatter_density_sorted");
+  if (int e = check_sizes(sc, N, S, "scatter_density_sorted")) return e;
+  if (sc->density.n_comp != 16) return ego_fail(EGO_E_UNSUPPORTED, "scatter_density_sorted: n_comp %d (supported: 16)", sc->density.n_comp);
+  if (N == 0) return EGO_OK;
+  EGO_REQUIRE(coords && dfeat && workspace, "scatter_density_sorted: null argument");
+  const SortGeom G = make_geom(sc->density.res, N * (int64_t)S);
+  if (workspace_bytes < G.total) return ego_fail(EGO_E_BADARG, "scatter_density_sorted: workspace too small");
+  SortedArgs a{};
+  if (int e = fill_args(sc->density, gdensity, coords, dfeat, G, workspace, &a, "scatter_density_sorted")) return e;
+  return launch_sorted<16, true>(a, G, (hipStream_t)stream);
+}
+
+int ego_scatter_app_sorted(const ego_scene* sc, const ego_vm_grad* gapp, const float* coords, const float* dv, int64_t N, int32_t S,
+                           void* workspace, int64_t workspace_bytes, void* stream) {
+  EGO_TRACE("ego_scatter_app_sorted");
+  if (int e = check_sizes(sc, N, S, "scatter_app_sorted")) return e;
+  if (sc->app.n_comp != 48) return ego_fail(EGO_E_UNSUPPORTED, "scatter_app_sorted: n_comp %d (supported: 48)", sc->app.n_comp);
+  if (N == 0) return EGO_OK;
+  EGO_REQUIRE(coords && dv && workspace, "scatter_app_sorted: null argument");
+  const SortGeom G = make_geom(sc->app.res, N * (int64_t)S);
+  if (workspace_bytes < G.total) return ego_fail(EGO_E_BADARG, "scatter_app_sorted: workspace too small");
+  SortedArgs a{};
+  if (int e = fill_args(sc->app, gapp, coords, dv, G, workspace, &a, "scatter_app_sorted")) return e;
+  return launch_sorted<48, false>(a, G, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -25,6 +25,7 @@ struct WgradArgs {
   float* G;
   int64_t M;
   int32_t lda, ca, ldb, cb, ones_col, ldg, steps_per_wg;
+  float* Gpart;          // deterministic mode: [workgroup][32 CAB][32 CBB] partial products, summed in workgroup order by k_wgrad_reduce
 };
 
 // fp32 -> bf16 bits in the high half, round to nearest even (finite inputs)
@@ -227,7 +228,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CAB * CBB >
       for (int r = 0; r < 16; ++r) {
         const int row = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * kb, col = 32 * nt + i;
         const float v = acc[k][r];
-        if (v != 0.f) unsafeAtomicAdd(P.G + (int64_t)row * P.ldg + col, v);
+        if (P.Gpart) P.Gpart[((int64_t)blockIdx.x * (32 * CAB) + row) * (32 * CBB) + col] = v;
+        else if (v != 0.f) unsafeAtomicAdd(P.G + (int64_t)row * P.ldg + col, v);
       }
     }
   }
@@ -347,8 +349,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     for (int r = 0; r < 16; ++r) {
       const int row = 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * kb, col = 32 * nt + i;
       const float v = acc[nt][r];
-      if (v != 0.f) unsafeAtomicAdd(P.G + (int64_t)row * P.ldg + col, v);
+      if (P.Gpart) P.Gpart[((int64_t)blockIdx.x * 128 + row) * (32 * CBB) + col] = v;
+      else if (v != 0.f) unsafeAtomicAdd(P.G + (int64_t)row * P.ldg + col, v);
     }
+}
+
+// deterministic mode: G[row][col] = sum over workgroups, in workgroup order (four contiguous quarters, then the quarters in order), of
+// the partial products; overwrites G's [rows][ld] block (no zero fill needed)
+__global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ part, int n_wg, int rows, int ld, float* __restrict__ G, int ldg) {
+  __shared__ float q[4][64];
+  const int e = blockIdx.x * 64 + (threadIdx.x & 63), s = threadIdx.x >> 6;
+  const int E = rows * ld;
+  const int nq = (n_wg + 3) / 4, w0 = s * nq, w1 = min(w0 + nq, n_wg);
+  float sum = 0.f;
+  if (e < E)
+    for (int w = w0; w < w1; ++w) sum += part[(int64_t)w * E + e];
+  q[s][threadIdx.x & 63] = sum;
+  __syncthreads();
+  if (s == 0 && e < E) {
+    const int l = threadIdx.x & 63;
+    G[(int64_t)(e / ld) * ldg + e % ld] = ((q[0][l] + q[1][l]) + q[2][l]) + q[3][l];
+  }
+}
+
+inline int reduce_partials(const WgradArgs& p, unsigned n_wg, int rows, int ld, hipStream_t st) {
+  k_wgrad_reduce<<<(unsigned)((rows * ld + 63) / 64), 256, 0, st>>>(p.Gpart, (int)n_wg, rows, ld, p.G, p.ldg);
+  return ego_launch_status("k_wgrad_reduce");
 }
 
 template <int CBB>
@@ -357,8 +383,10 @@ int launch_h(const WgradArgs& a, hipStream_t st) {
   const int64_t steps = (a.M + 31) / 32;
   const int64_t wgs = steps < 1024 ? steps : 1024;
   p.steps_per_wg = (int32_t)((steps + wgs - 1) / wgs);
-  k_wgrad_h<CBB><<<(unsigned)((steps + p.steps_per_wg - 1) / p.steps_per_wg), 256, 0, st>>>(p);
-  return ego_launch_status("k_wgrad_h");
+  const unsigned n_wg = (unsigned)((steps + p.steps_per_wg - 1) / p.steps_per_wg);
+  k_wgrad_h<CBB><<<n_wg, 256, 0, st>>>(p);
+  if (int e = ego_launch_status("k_wgrad_h")) return e;
+  return p.Gpart ? reduce_partials(p, n_wg, 128, 32 * CBB, st) : EGO_OK;
 }
 
 template <int CAB, int CBB, bool AVEC, int ABLK, int BBLK>
@@ -367,17 +395,27 @@ int launch(const WgradArgs& a, hipStream_t st) {
   const int64_t steps = (a.M + 31) / 32;
   const int64_t wgs = steps < 768 ? steps : 768;
   p.steps_per_wg = (int32_t)((steps + wgs - 1) / wgs);
-  k_wgrad<CAB, CBB, AVEC, ABLK, BBLK><<<(unsigned)((steps + p.steps_per_wg - 1) / p.steps_per_wg), 256, 0, st>>>(p);
-  return ego_launch_status("k_wgrad");
+  const unsigned n_wg = (unsigned)((steps + p.steps_per_wg - 1) / p.steps_per_wg);
+  k_wgrad<CAB, CBB, AVEC, ABLK, BBLK><<<n_wg, 256, 0, st>>>(p);
+  if (int e = ego_launch_status("k_wgrad")) return e;
+  return p.Gpart ? reduce_partials(p, n_wg, 32 * CAB, 32 * CBB, st) : EGO_OK;
 }
 
 }  // namespace
 
 extern "C" {
 
+int64_t ego_weight_grad_partial_floats(void) { return (int64_t)1024 * 128 * 160; }   // workgroups x rows x padded columns, the largest product
+
 int ego_weight_grad(const void* A, int32_t lda, int32_t ca, int32_t a_layout, const float* a_scale, const void* B, int32_t ldb, int32_t cb,
                     int32_t b_layout, int32_t ones_col, int64_t M, float* G, int32_t ldg, void* stream) {
+  return ego_weight_grad_det(A, lda, ca, a_layout, a_scale, B, ldb, cb, b_layout, ones_col, M, G, ldg, nullptr, 0, stream);
+}
+
+int ego_weight_grad_det(const void* A, int32_t lda, int32_t ca, int32_t a_layout, const float* a_scale, const void* B, int32_t ldb, int32_t cb,
+                        int32_t b_layout, int32_t ones_col, int64_t M, float* G, int32_t ldg, float* partial, int64_t partial_floats, void* stream) {
   EGO_TRACE("ego_weight_grad");
+  EGO_REQUIRE(!partial || partial_floats >= ego_weight_grad_partial_floats(), "weight_grad: partial buffer smaller than ego_weight_grad_partial_floats()");
   EGO_REQUIRE(a_layout >= 0 && a_layout <= 3, "weight_grad: a_layout must be 0 (row-major), 1 (blocked fp32), 2 (blocked scaled fp16) or 3 (grid-routed)");
   EGO_REQUIRE(b_layout >= 0 && b_layout <= 2, "weight_grad: b_layout must be 0 (row-major), 1 (blocked fp32) or 2 (blocked fp16)");
   EGO_REQUIRE(b_layout != 2 || ((cb & 15) == 0 && ldb == cb), "weight_grad: the fp16 B layout holds whole k-steps (cb a multiple of 16, ldb = cb)");
@@ -394,7 +432,7 @@ int ego_weight_grad(const void* A, int32_t lda, int32_t ca, int32_t a_layout, co
   EGO_REQUIRE(ldg >= 32 * cbb, "weight_grad: ldg must cover the padded column blocks");
   EGO_REQUIRE((ldb & 3) == 0 && (cb & 3) == 0 && ((uintptr_t)B & 15) == 0, "weight_grad: B rows must be 16-byte aligned, cb a multiple of 4");
   const bool avec = (lda & 3) == 0 && (ca & 3) == 0 && ((uintptr_t)A & 15) == 0;
-  WgradArgs a{(const float*)A, a_scale, (const float*)B, G, M, lda, ca, ldb, cb, ones_col, ldg, 0};
+  WgradArgs a{(const float*)A, a_scale, (const float*)B, G, M, lda, ca, ldb, cb, ones_col, ldg, 0, partial};
   const hipStream_t st = (hipStream_t)stream;
   // instantiations: the training step's four products, their all-fp32 forms and the all-row-major forms of the same shapes
   // (the training step's four products: dh2^T h1, dh1^T x: scaled-fp16 A, fp16 B; do^T h2: ragged row-major A, fp16 B; dfe^T v: grid-routed A,

@@ -350,6 +350,10 @@ class EgoNeRF(TensorBase):
         # EGO_TRAIN_FP32=1 in the environment at construction) trains it through the fp32 compatibility kernels instead: the parity
         # mode, several times slower.
         self.train_fp32_head = os.environ.get("EGO_TRAIN_FP32", "0") not in ("", "0")
+        # Table gradients of a differentiable call: True (default) = sort the step's samples by texel cell and write every gradient texel
+        # once, in a fixed order - no atomics, two runs return the same bits (csrc/ego_scatter_sorted.hip); False (or EGO_SCATTER=atomic
+        # at construction) = the float-atomic scatters of rounds 1-4 (run-to-run differences of ~1e-6 of the largest gradient).
+        self.deterministic_scatter = os.environ.get("EGO_SCATTER", "sorted") != "atomic"
         self._app_table_dtype = "f32"   # "f16": inference gathers appearance taps from a half-precision copy of the tables
         self._app16 = None              # (versions, [12 half tensors])
         # opt-in skipping (EgoNeRF.forward itself evaluates every sample; TensorBase.forward's semantics, tensorBase.py:464-487,

@@ -108,11 +108,11 @@ def _grad_plan(model, device):
     return _INDEX_CACHE[key]
 
 
-def _zeros_like_many(tensors):
+def _zeros_like_many(tensors, zero: bool = True):
     """One zero-filled flat buffer carved into tensors with the shapes AND strides of `tensors` (dense, e.g. channel-last
-    parameters): one fill kernel instead of one per gradient."""
+    parameters): one fill kernel instead of one per gradient.  zero=False: uninitialised (the sorted scatters write every texel)."""
     total = sum(t.numel() for t in tensors)
-    flat = torch.zeros(total, device=tensors[0].device, dtype=tensors[0].dtype)
+    flat = (torch.zeros if zero else torch.empty)(total, device=tensors[0].device, dtype=tensors[0].dtype)
     out, off = [], 0
     for t in tensors:
         out.append(torch.as_strided(flat, t.shape, t.stride(), off))
@@ -195,6 +195,27 @@ class RenderFunction(torch.autograd.Function):
                                              coords.data_ptr(), sigma.data_ptr(), None, st), "ego_march_density")
         M = N * S
         rgb = f(N, S, 3)
+        # Deterministic table gradients (model.deterministic_scatter, the default): the step's samples are binned by texel cell once, from
+        # the coordinates the march just wrote - on the side stream, next to the dumping shade forward - and the backward's two scatters
+        # then write every gradient texel once, in a fixed order (csrc/ego_scatter_sorted.hip).  Tuned table shapes only (16 / 48
+        # components); anything else keeps the atomic scatters.
+        sort_ws = None
+        if model.deterministic_scatter and (model.density_n_comp[0] == 16 or (head_is_tuned(model) and not model.train_fp32_head)):
+            nbytes = lib.ego_scatter_sorted_workspace_bytes(sc, N, S)
+            if nbytes <= 0:
+                raise RuntimeError("ego_scatter_sorted_workspace_bytes rejected the scene: " + lib.ego_last_error().decode())
+            sort_ws = torch.empty(nbytes, device=dev, dtype=torch.uint8)
+            main = torch.cuda.current_stream(dev)
+            side = _side_stream(dev) if SIDE_STREAM_SCATTER else None
+            if side is None:
+                _chk(lib.ego_scatter_sort(sc, coords.data_ptr(), N, S, sort_ws.data_ptr(), nbytes, st), "ego_scatter_sort")
+            else:
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    _chk(lib.ego_scatter_sort(sc, coords.data_ptr(), N, S, sort_ws.data_ptr(), nbytes, _lib.stream_handle()), "ego_scatter_sort")
+                # a forward whose backward never runs must not hand these blocks back to the main stream's pool while the sort is in flight
+                sort_ws.record_stream(side)
+                coords.record_stream(side)
         head_tuned = head_is_tuned(model) and not model.train_fp32_head
         compat = None
         if head_is_tuned(model) and not head_tuned:
@@ -232,7 +253,7 @@ class RenderFunction(torch.autograd.Function):
         _chk(lib.ego_composite(sc, rays.data_ptr(), z.data_ptr(), weight.data_ptr(), bg.data_ptr(), rgb.data_ptr(), N, S,
                                      rgb_map.data_ptr(), depth.data_ptr(), _lib.ptr(bg_map), _lib.ptr(env_map), raw.data_ptr(), st),
                    "ego_composite")
-        ctx.model, ctx.N, ctx.S, ctx.head_tuned, ctx.compat = model, N, S, head_tuned, compat
+        ctx.model, ctx.N, ctx.S, ctx.head_tuned, ctx.compat, ctx.sort_ws = model, N, S, head_tuned, compat, sort_ws
         ctx.saved = dict(z=z, alpha=alpha, weight=weight, sigma=sigma, bg=bg, coords=coords, rgb=rgb, raw=raw, env=env_map, rays=rays,
                          **dump)
         # depth is computed under no_grad in the reference (EgoNeRF.py:595-598); one call: a second would replace the first
@@ -259,8 +280,10 @@ class RenderFunction(torch.autograd.Function):
             g_alpha = g_alpha.contiguous().float()
             assert g_alpha.shape == sv["alpha"].shape
         dens, app = table_params(model, "density"), table_params(model, "app")
-        g_all = _zeros_like_many(dens + app)  # keeps the channel-last strides of the parameters
-        g_dens, g_app = g_all[:len(dens)], g_all[len(dens):]
+        # keeps the channel-last strides of the parameters; the sorted scatters store every texel, the atomic ones add into zeros
+        sorted_dens = ctx.sort_ws is not None and model.density_n_comp[0] == 16
+        sorted_app = ctx.sort_ws is not None and ctx.head_tuned
+        g_dens, g_app = _zeros_like_many(dens, zero=not sorted_dens), _zeros_like_many(app, zero=not sorted_app)
         for p, g in zip(dens + app, g_dens + g_app):
             assert g.stride() == p.stride()
         f = lambda *shape: torch.empty(*shape, device=dev, dtype=torch.float32)
@@ -294,7 +317,11 @@ class RenderFunction(torch.autograd.Function):
 
     @staticmethod
     def _backward_body(ctx, lib, st, model, N, S, sv, dev, M, sc, g_rgb, astride, g_dens, g_app, dc, dfeat, gd, main, side, on_side, f):
-        if model.density_n_comp[0] == 16:
+        ws = ctx.sort_ws
+        if model.density_n_comp[0] == 16 and ws is not None:
+            on_side(lambda s_: _chk(lib.ego_scatter_density_sorted(sc, C.byref(gd), sv["coords"].data_ptr(), dfeat.data_ptr(), N, S, ws.data_ptr(),
+                                                                   ws.numel(), s_), "ego_scatter_density_sorted"))
+        elif model.density_n_comp[0] == 16:
             on_side(lambda s_: _chk(lib.ego_scatter_density(sc, C.byref(gd), sv["coords"].data_ptr(), dfeat.data_ptr(), N, S, s_),
                                           "ego_scatter_density"))
         else:
@@ -313,7 +340,11 @@ class RenderFunction(torch.autograd.Function):
                                           dh2.data_ptr(), dh1.data_ptr(), dh_scale.data_ptr(), dfe.data_ptr(), dv.data_ptr(), N, S, st),
              "ego_shade_backward")
         ga = _grad_struct(g_app)
-        on_side(lambda s_: _chk(lib.ego_scatter_app(sc, C.byref(ga), sv["coords"].data_ptr(), dv.data_ptr(), N, S, s_), "ego_scatter_app"))
+        if ws is not None:   # (this is the tuned-head path: sorted_app above)
+            on_side(lambda s_: _chk(lib.ego_scatter_app_sorted(sc, C.byref(ga), sv["coords"].data_ptr(), dv.data_ptr(), N, S, ws.data_ptr(), ws.numel(), s_),
+                                    "ego_scatter_app_sorted"))
+        else:
+            on_side(lambda s_: _chk(lib.ego_scatter_app(sc, C.byref(ga), sv["coords"].data_ptr(), dv.data_ptr(), N, S, s_), "ego_scatter_app"))
         if side is None:
             del dv
         # ---- weight gradients: one pass of ego_weight_grad (bf16 hi/lo MFMA over transposed LDS tiles, bias gradients from a
@@ -321,13 +352,16 @@ class RenderFunction(torch.autograd.Function):
         # columns into the reference-shaped gradients ----
         do = dc.view(M, 3)  # now d(pre-sigmoid)
         gidx, gsizes, gshapes, pad = _grad_plan(model, dev)  # pad: a padding column of the x dump (holds zeros) doubles as the ones column
+        # deterministic mode (model.deterministic_scatter): per-workgroup partial products added in a fixed order instead of float atomics
+        det = model.deterministic_scatter
         Gall = torch.zeros(352, _G_LD, device=dev)
+        part = f(lib.ego_weight_grad_partial_floats()) if det else None
 
         def wgrad(which, A, ca, a_layout, B, cb, ones_col, a_scale=None):
             G = Gall[_G_ROWS[which][0]:_G_ROWS[which][1]]
             b_layout = 2 if B.dtype == torch.float16 else 1
-            _chk(lib.ego_weight_grad(A.data_ptr(), A.shape[1], ca, a_layout, _lib.ptr(a_scale), B.data_ptr(), B.shape[1], cb, b_layout, ones_col, M,
-                                           G.data_ptr(), _G_LD, st), "ego_weight_grad")
+            _chk(lib.ego_weight_grad_det(A.data_ptr(), A.shape[1], ca, a_layout, _lib.ptr(a_scale), B.data_ptr(), B.shape[1], cb, b_layout, ones_col, M,
+                                         G.data_ptr(), _G_LD, _lib.ptr(part), 0 if part is None else part.numel(), st), "ego_weight_grad")
 
         wgrad("G3", do, 3, 0, sv["h2"], 128, 128)
         wgrad("G2", dh2, 128, 2, sv["h1"], 128, 128, dh_scale[0])
@@ -363,9 +397,12 @@ class RenderFunction(torch.autograd.Function):
         hp = (hid + 31) // 32 * 32
         n_chunks = ldx // _G_LD
 
+        part = f(lib.ego_weight_grad_partial_floats()) if model.deterministic_scatter else None
+
         def product(A, lda, ca, B_ptr, ldb, ones_col, rows):
             G = torch.zeros(rows, _G_LD, device=dev)
-            _chk(lib.ego_weight_grad(A.data_ptr(), lda, ca, 0, None, B_ptr, ldb, _G_LD, 0, ones_col, M, G.data_ptr(), _G_LD, st), "ego_weight_grad")
+            _chk(lib.ego_weight_grad_det(A.data_ptr(), lda, ca, 0, None, B_ptr, ldb, _G_LD, 0, ones_col, M, G.data_ptr(), _G_LD, _lib.ptr(part),
+                                         0 if part is None else part.numel(), st), "ego_weight_grad")
             return G
 
         Gb = product(dfe, 64, 64, sv["v"].data_ptr(), _G_LD, -1, 64)                      # [yin | yang] feature gradients ^T v

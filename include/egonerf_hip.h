@@ -346,7 +346,23 @@ int ego_shade_backward(const ego_scene* sc, const float* train_packed, const flo
 int ego_scatter_density(const ego_scene* sc, const ego_vm_grad* gdensity, const float* coords, const float* dfeat, int64_t N, int32_t S,
                         void* stream);
 int ego_scatter_app(const ego_scene* sc, const ego_vm_grad* gapp, const float* coords, const float* dv, int64_t N, int32_t S,
-                    void* stream); /* dv: ego_shade_backward's blocked layout */
+                    void* stream);
+
+/* ---- the same table gradients without atomics: bit-reproducible (csrc/ego_scatter_sorted.hip) ----
+ * ego_scatter_density / ego_scatter_app add with float atomics: their sums depend on the order the hardware serves them.  The three
+ * entry points below bin the step's samples by texel cell once (three stable radix sorts of the forward's coordinates; both fields share
+ * them) and then write every gradient texel exactly once from sums taken in a fixed order: two calls return the same bits, no zero fill
+ * of `grad` is needed, and there is no atomic traffic (they are also faster: DESIGN.md 4.2).  Same mathematics as F.grid_sample's
+ * backward in compute_densityfeature / compute_appfeature (models/EgoNeRF.py:291-347, :349-413) under train.py:312-314; same argument
+ * meaning as ego_scatter_density / ego_scatter_app.  `workspace` (dev, 256-byte aligned, ego_scatter_sorted_workspace_bytes(sc, N, S)
+ * bytes; -1 = bad arguments) carries the sort from ego_scatter_sort to the two scatters and holds their scratch: calls that share a
+ * workspace must be ordered on one stream (or by events).  The density and appearance fields must have one resolution. */
+int64_t ego_scatter_sorted_workspace_bytes(const ego_scene* sc, int64_t N, int32_t S);
+int ego_scatter_sort(const ego_scene* sc, const float* coords, int64_t N, int32_t S, void* workspace, int64_t workspace_bytes, void* stream);
+int ego_scatter_density_sorted(const ego_scene* sc, const ego_vm_grad* gdensity, const float* coords, const float* dfeat, int64_t N, int32_t S,
+                               void* workspace, int64_t workspace_bytes, void* stream);
+int ego_scatter_app_sorted(const ego_scene* sc, const ego_vm_grad* gapp, const float* coords, const float* dv, int64_t N, int32_t S,
+                           void* workspace, int64_t workspace_bytes, void* stream); /* dv: ego_shade_backward's blocked layout */
 /* d(envmap.emission) [3][2h][h] += backward of bg_weight * sigmoid(bilinear(emission, dir)) (envmap.py:26-34,
  * EgoNeRF.py:588-590).  dirs = N directions dir_stride floats apart (rays + 3 with stride 6, or a packed [N][3]);
  * env_map = the forward's radiance [N][3]; the clamp mask is taken from rgb_raw (pass values in [0,1] for none). */
@@ -364,6 +380,14 @@ int ego_envmap_backward(const ego_scene* sc, const float* dirs, int32_t dir_stri
  * split MFMA, ~17 significand bits per operand. */
 int ego_weight_grad(const void* A, int32_t lda, int32_t ca, int32_t a_layout, const float* a_scale, const void* B, int32_t ldb,
                     int32_t cb, int32_t b_layout, int32_t ones_col, int64_t M, float* G, int32_t ldg, void* stream);
+/* The same product, bit-reproducible: every workgroup stores its partial product block to `partial` (dev, ego_weight_grad_partial_floats()
+ * floats) and a second kernel adds the blocks in workgroup order and STORES the result (G needs no zero fill; rows [0, 32 ceil(ca/32)) x
+ * columns [0, 32 ceil(cols/32)) of G are overwritten).  ego_weight_grad adds with float atomics: its sums depend on the order the
+ * hardware serves them (differences in the last bits from run to run).  partial = NULL is ego_weight_grad. */
+int64_t ego_weight_grad_partial_floats(void);
+int ego_weight_grad_det(const void* A, int32_t lda, int32_t ca, int32_t a_layout, const float* a_scale, const void* B, int32_t ldb, int32_t cb,
+                        int32_t b_layout, int32_t ones_col, int64_t M, float* G, int32_t ldg, float* partial, int64_t partial_floats,
+                        void* stream);
 
 /* ---- training of model shapes other than the tuned one (opt.py:87-100 lets a user choose n_lamb_sigma / n_lamb_sh, data_dim_color,
  * featureC, view_pe, fea_pe; supported shapes as for ego_packed_floats_scene).  Plain fp32 compatibility kernels over ROW-MAJOR
