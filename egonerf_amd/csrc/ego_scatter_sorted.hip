@@ -15,9 +15,9 @@
 //       sort 2: key (grid, theta cell, phi cell) -> cells of plane 2 (x = theta, y = phi), ranges of line 1 (theta)
 //     a cell = the unclamped west tap index + 1 (0 .. n); a sample whose two taps of an axis are both out of range has no gradient
 //     through that axis and sorts behind everything else
-//   k_sorted_plane        : one wave per cell: its samples (contiguous, in ascending sample order: the sort is stable) are dealt to the four
-//                           16-lane groups (lane = channel of a 64-byte line, as in k_vm_scatter), each keeps the four corner sums in
-//                           registers, the groups are folded in a fixed tree and the cell's four corner sums go to a cell buffer
+//   k_sorted_plane        : one 16-lane group per cell (lane = channel of a 64-byte line, as in k_vm_scatter), four cells per wave: the
+//                           cell's samples (contiguous, in ascending sample order: the sort is stable) are added in that order into four
+//                           corner sums in registers, which go to a cell buffer
 //   k_sorted_plane_final  : texel = the four corner sums of its four neighbouring cells, added in a fixed order, one store
 //   k_sorted_line         : a line cell holds thousands of samples: fixed 256-sample sub-blocks of its range, one wave each -> partial sums
 //   k_sorted_line_final   : texel = its two cells' partials, added in sub-block order
@@ -182,21 +182,43 @@ __device__ __forceinline__ float fold_groups(float v) {
 }
 
 // ---- planes: one wave per cell ----------------------------------------------------------------------------------------------------
+// Both reductions run in two stages per batch of 64 sorted samples.  Stage 1, lane = sample: permutation entry -> coordinates -> tap
+// weights and offsets, once per sample (not once per channel lane), written to the wave's LDS record (structure of arrays: conflict-free
+// writes, broadcast reads).  Stage 2, lane = channel: the four 16-lane groups take samples t, t + 1, t + 2, t + 3, U steps are in flight
+// at a time and their loads are issued back to back - the first form of these kernels chased perm -> coords -> taps once per sample and
+// was bound by that latency chain (0.66 / 0.65 ms for the appearance planes / lines).
+constexpr int REC_F = 12;   // dwords per sample record
+struct WaveRec {
+  uint32_t f[REC_F][64];
+};
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// One 16-lane group per cell, four cells per wave (a cell holds 12 - 40 samples on the barbershop grid at 8192 x 256: a wave per cell
+// spent its life waiting for three dependent round trips with 4 096 waves in flight; four cells per wave share them).  Stage 1: lane
+// 16 q + j sets up sample j of the current 16-sample batch of cell q; stage 2: group q walks its own batch in order, U samples in flight.
 template <int C, bool DENS, int S_>
-__device__ __forceinline__ void sorted_plane(const SortedArgs& A) {
+__device__ __forceinline__ void sorted_plane(const SortedArgs& A, WaveRec& R) {
 #pragma clang fp contract(fast)
-  constexpr int NL = C / 16, I = sort_plane(S_);
+  constexpr int NL = C / 16, I = sort_plane(S_), U = 4;
   constexpr int AX = vm_plane_x(I), AY = vm_plane_y(I), AL = vm_line_ax(I);
   const int lane = threadIdx.x & 63, c16 = lane & 15, q = lane >> 4;
-  const uint32_t k = blockIdx.x * 4u + (threadIdx.x >> 6);
-  if (k >= A.K[S_]) return;
-  const uint32_t a = A.start[S_][k], b = A.start[S_][k + 1];
-  if (a == b) return;   // empty cell: nothing written, k_sorted_plane_final does not read it
+  const uint32_t k_raw = (blockIdx.x * 4u + (threadIdx.x >> 6)) * 4u + (uint32_t)q;
+  const bool cell_ok = k_raw < A.K[S_];
+  const uint32_t k = cell_ok ? k_raw : A.K[S_] - 1;
+  const uint32_t a = A.start[S_][k], b = cell_ok ? A.start[S_][k + 1] : a;
+  const uint32_t n_mine = b - a;
+  uint32_t n_max = max(n_mine, (uint32_t)__shfl_xor((int)n_mine, 16, 64));
+  n_max = max(n_max, (uint32_t)__shfl_xor((int)n_max, 32, 64));
+  if (n_max == 0) return;   // four empty cells: nothing written, k_sorted_plane_final does not read them
   const int nmin1 = A.F.res[sort_minor(S_)] + 1, nmaj1 = A.F.res[sort_major(S_)] + 1;
   const int cmin = (int)(k % (uint32_t)nmin1), t_ = (int)(k / (uint32_t)nmin1);
   const int cmaj = t_ % nmaj1, g = t_ / nmaj1;
   const int cX = sort_major(S_) == AX ? cmaj : cmin, cY = sort_major(S_) == AY ? cmaj : cmin;
-  const int W = A.F.res[AX], H = A.F.res[AY];
+  const int W = A.F.res[AX], H = A.F.res[AY], NLn = A.F.res[AL];
   const int x0 = max(cX - 1, 0), x1 = min(cX, W - 1), y0 = max(cY - 1, 0), y1 = min(cY, H - 1);   // the clamped tap indices of lin_setup
   const int oP[4] = {(y0 * W + x0) * C, (y0 * W + x1) * C, (y1 * W + x0) * C, (y1 * W + x1) * C};
   const float* P = (g ? A.F.plane[1][I] : A.F.plane[0][I]) + c16;
@@ -204,52 +226,89 @@ __device__ __forceinline__ void sorted_plane(const SortedArgs& A) {
   float acc[NL][4];
 #pragma unroll
   for (int i = 0; i < NL; ++i) acc[i][0] = acc[i][1] = acc[i][2] = acc[i][3] = 0.f;
-  for (uint32_t p = a + (uint32_t)q; p < b; p += 4) {
-    const int64_t m = A.perm[S_][p];
-    float dsample = 0.f;
-    if (DENS) {
-      dsample = A.d[m];
-      if (dsample == 0.f) continue;   // uniform over the 16-lane group
+  for (uint32_t off = 0; off < n_max; off += 16) {
+    const int cnt = off < n_mine ? (int)min(16u, n_mine - off) : 0;   // this group's samples in the batch
+    {   // stage 1: lane 16 q + j = sample j of cell q's batch (clamped to a valid entry; unused records are never read as data)
+      const uint32_t last = n_mine ? b - 1 : (uint32_t)(A.start[S_][A.K[S_]] ? A.start[S_][A.K[S_]] - 1 : 0);
+      const uint32_t pidx = min(a + off + (uint32_t)c16, last);
+      const uint32_t m = A.perm[S_][pidx];
+      const f32x4 cc = ((const f32x4*)A.coords)[m];
+      const float ax[3] = {cc.x, cc.y, cc.z};
+      const Lin1 X = lin_setup(ax[AX], W), Y = lin_setup(ax[AY], H), Ln = lin_setup(ax[AL], NLn);
+      R.f[0][lane] = m;
+      R.f[1][lane] = __float_as_uint(__fmul_rn(Y.w0, X.w0)); R.f[2][lane] = __float_as_uint(__fmul_rn(Y.w0, X.w1));
+      R.f[3][lane] = __float_as_uint(__fmul_rn(Y.w1, X.w0)); R.f[4][lane] = __float_as_uint(__fmul_rn(Y.w1, X.w1));
+      R.f[5][lane] = (uint32_t)(Ln.i0 * C); R.f[6][lane] = (uint32_t)(Ln.i1 * C);
+      R.f[7][lane] = __float_as_uint(Ln.w0); R.f[8][lane] = __float_as_uint(Ln.w1);
+      if (DENS) R.f[9][lane] = __float_as_uint(A.d[m]);
     }
-    const f32x4 cc = ((const f32x4*)A.coords)[m];
-    const float ax[3] = {cc.x, cc.y, cc.z};
-    const Lin1 X = lin_setup(ax[AX], W), Y = lin_setup(ax[AY], H), Ln = lin_setup(ax[AL], A.F.res[AL]);
-    const float w00 = __fmul_rn(Y.w0, X.w0), w01 = __fmul_rn(Y.w0, X.w1), w10 = __fmul_rn(Y.w1, X.w0), w11 = __fmul_rn(Y.w1, X.w1);
-    const int oL0 = Ln.i0 * C, oL1 = Ln.i1 * C;
-    float lv[NL], di[NL];
+    wave_sync();
+    int cnt_max = max(cnt, __shfl_xor(cnt, 16, 64));
+    cnt_max = max(cnt_max, __shfl_xor(cnt_max, 32, 64));
+    for (int t0 = 0; t0 < cnt_max; t0 += U) {   // stage 2: lane = channel of group q's sample t
+      float w4[U][4], lw[U][2], di[U][NL], l0[U][NL], l1[U][NL], pt[U][4];
+      bool ok[U];
 #pragma unroll
-    for (int i = 0; i < NL; ++i) lv[i] = L[oL0 + 16 * i] * Ln.w0 + L[oL1 + 16 * i] * Ln.w1;
-    if (DENS) {
-      // relu per plane (EgoNeRF.py:340,346): the gradient passes where this plane's sum over channels is positive
-      float dot = (P[oP[0]] * w00 + P[oP[1]] * w01 + P[oP[2]] * w10 + P[oP[3]] * w11) * lv[0];
+      for (int u = 0; u < U; ++u) {
+        const int t = t0 + u;
+        ok[u] = t < cnt;
+        const int tt = 16 * q + (ok[u] ? t : 0);
+        const int64_t m = R.f[0][tt];
 #pragma unroll
-      for (int sh = 8; sh >= 1; sh >>= 1) dot += __shfl_xor(dot, sh, 16);
-      di[0] = dot > 0.f ? dsample : 0.f;
-    } else {
+        for (int c = 0; c < 4; ++c) w4[u][c] = __uint_as_float(R.f[1 + c][tt]);
+        const int oL0 = (int)R.f[5][tt], oL1 = (int)R.f[6][tt];
+        lw[u][0] = __uint_as_float(R.f[7][tt]); lw[u][1] = __uint_as_float(R.f[8][tt]);
 #pragma unroll
-      for (int i = 0; i < NL; ++i) di[i] = A.d[(m >> 5) * (32 * 3 * C) + (I * NL + i) * 512 + (m & 31) * 16 + c16];   // k_shade_bwd's blocked dv
+        for (int i = 0; i < NL; ++i) { l0[u][i] = L[oL0 + 16 * i]; l1[u][i] = L[oL1 + 16 * i]; }
+        if (DENS) {
+          di[u][0] = __uint_as_float(R.f[9][tt]);
+#pragma unroll
+          for (int c = 0; c < 4; ++c) pt[u][c] = P[oP[c]];
+        } else {
+#pragma unroll
+          for (int i = 0; i < NL; ++i) di[u][i] = A.d[(m >> 5) * (32 * 3 * C) + (I * NL + i) * 512 + (m & 31) * 16 + c16];   // k_shade_bwd's blocked dv
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        float lv[NL], dd[NL];
+#pragma unroll
+        for (int i = 0; i < NL; ++i) lv[i] = l0[u][i] * lw[u][0] + l1[u][i] * lw[u][1];
+        if (DENS) {
+          // relu per plane (EgoNeRF.py:340,346): the gradient passes where this plane's sum over channels is positive
+          float dot = (pt[u][0] * w4[u][0] + pt[u][1] * w4[u][1] + pt[u][2] * w4[u][2] + pt[u][3] * w4[u][3]) * lv[0];
+#pragma unroll
+          for (int sh = 8; sh >= 1; sh >>= 1) dot += __shfl_xor(dot, sh, 16);
+          dd[0] = (ok[u] && dot > 0.f) ? di[u][0] : 0.f;
+        } else {
+#pragma unroll
+          for (int i = 0; i < NL; ++i) dd[i] = ok[u] ? di[u][i] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+          const float gp = dd[i] * lv[i];
+          acc[i][0] += gp * w4[u][0]; acc[i][1] += gp * w4[u][1]; acc[i][2] += gp * w4[u][2]; acc[i][3] += gp * w4[u][3];
+        }
+      }
     }
-#pragma unroll
-    for (int i = 0; i < NL; ++i) {
-      const float gp = di[i] * lv[i];
-      acc[i][0] += gp * w00; acc[i][1] += gp * w01; acc[i][2] += gp * w10; acc[i][3] += gp * w11;
-    }
+    wave_sync();   // the next batch overwrites the record
   }
-  float* out = A.cellbuf[S_] + (int64_t)k * 4 * C + c16;
+  if (n_mine) {
+    float* out = A.cellbuf[S_] + (int64_t)k * 4 * C + c16;
 #pragma unroll
-  for (int i = 0; i < NL; ++i)
+    for (int i = 0; i < NL; ++i)
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const float v = fold_groups(acc[i][t]);
-      if (q == 0) out[t * C + 16 * i] = v;
-    }
+      for (int t = 0; t < 4; ++t) out[t * C + 16 * i] = acc[i][t];
+  }
 }
 
 template <int C, bool DENS>
 __global__ __launch_bounds__(256) void k_sorted_plane(SortedArgs A) {
-  if (blockIdx.y == 0) sorted_plane<C, DENS, 0>(A);
-  else if (blockIdx.y == 1) sorted_plane<C, DENS, 1>(A);
-  else sorted_plane<C, DENS, 2>(A);
+  __shared__ WaveRec rec[4];
+  WaveRec& R = rec[threadIdx.x >> 6];
+  if (blockIdx.y == 0) sorted_plane<C, DENS, 0>(A, R);
+  else if (blockIdx.y == 1) sorted_plane<C, DENS, 1>(A, R);
+  else sorted_plane<C, DENS, 2>(A, R);
 }
 
 // texel (g, ty, tx) of plane sort_plane(s): corner 0 (y0, x0) of cell (ty + 1, tx + 1), corner 1 (y0, x1) of cell (ty + 1, tx), corner 2
@@ -286,9 +345,9 @@ __global__ void k_sorted_plane_final(SortedArgs A) {
 
 // ---- lines: one wave per 256-sample sub-block of a line cell's range ------------------------------------------------------------------
 template <int C, bool DENS, int S_>
-__device__ __forceinline__ void sorted_line(const SortedArgs& A) {
+__device__ __forceinline__ void sorted_line(const SortedArgs& A, WaveRec& R) {
 #pragma clang fp contract(fast)
-  constexpr int NL = C / 16, J = sort_line(S_);                      // line J, its co-plane J
+  constexpr int NL = C / 16, J = sort_line(S_), U = 4;     // line J, its co-plane J
   constexpr int AX = vm_plane_x(J), AY = vm_plane_y(J), AL = vm_line_ax(J);
   static_assert(AL == sort_major(S_), "the line's axis is the major key of its sort");
   const int lane = threadIdx.x & 63, c16 = lane & 15, q = lane >> 4;
@@ -306,41 +365,80 @@ __device__ __forceinline__ void sorted_line(const SortedArgs& A) {
   const uint32_t r0 = A.start[S_][lc * nmin1] + j * SUB, rend = A.start[S_][(lc + 1) * nmin1];
   const uint32_t r1 = r0 + SUB < rend ? r0 + SUB : rend;
   const int g = (int)(lc / ((uint32_t)A.F.res[AL] + 1));
-  const int W = A.F.res[AX], H = A.F.res[AY];
+  const int W = A.F.res[AX], H = A.F.res[AY], NLn = A.F.res[AL];
   const float* P = (g ? A.F.plane[1][J] : A.F.plane[0][J]) + c16;
   const float* L = (g ? A.F.line[1][J] : A.F.line[0][J]) + c16;
   float acc[NL][2];
 #pragma unroll
   for (int i = 0; i < NL; ++i) acc[i][0] = acc[i][1] = 0.f;
-  for (uint32_t p = r0 + (uint32_t)q; p < r1; p += 4) {
-    const int64_t m = A.perm[S_][p];
-    float dsample = 0.f;
-    if (DENS) {
-      dsample = A.d[m];
-      if (dsample == 0.f) continue;
+  for (uint32_t base = r0; base < r1; base += 64) {
+    const int cnt = (int)min(64u, r1 - base);
+    {   // stage 1: lane = sample
+      const uint32_t pidx = min(base + (uint32_t)lane, r1 - 1);
+      const uint32_t m = A.perm[S_][pidx];
+      const f32x4 cc = ((const f32x4*)A.coords)[m];
+      const float ax[3] = {cc.x, cc.y, cc.z};
+      const Lin1 X = lin_setup(ax[AX], W), Y = lin_setup(ax[AY], H), Ln = lin_setup(ax[AL], NLn);
+      R.f[0][lane] = m;
+      R.f[1][lane] = __float_as_uint(__fmul_rn(Y.w0, X.w0)); R.f[2][lane] = __float_as_uint(__fmul_rn(Y.w0, X.w1));
+      R.f[3][lane] = __float_as_uint(__fmul_rn(Y.w1, X.w0)); R.f[4][lane] = __float_as_uint(__fmul_rn(Y.w1, X.w1));
+      R.f[5][lane] = (uint32_t)((Y.i0 * W + X.i0) * C); R.f[6][lane] = (uint32_t)((Y.i0 * W + X.i1) * C);
+      R.f[7][lane] = (uint32_t)((Y.i1 * W + X.i0) * C); R.f[8][lane] = (uint32_t)((Y.i1 * W + X.i1) * C);
+      R.f[9][lane] = __float_as_uint(Ln.w0); R.f[10][lane] = __float_as_uint(Ln.w1);
+      if (DENS) R.f[11][lane] = __float_as_uint(A.d[m]);
     }
-    const f32x4 cc = ((const f32x4*)A.coords)[m];
-    const float ax[3] = {cc.x, cc.y, cc.z};
-    const Lin1 X = lin_setup(ax[AX], W), Y = lin_setup(ax[AY], H), Ln = lin_setup(ax[AL], A.F.res[AL]);
-    const float w00 = __fmul_rn(Y.w0, X.w0), w01 = __fmul_rn(Y.w0, X.w1), w10 = __fmul_rn(Y.w1, X.w0), w11 = __fmul_rn(Y.w1, X.w1);
-    const int o00 = (Y.i0 * W + X.i0) * C, o01 = (Y.i0 * W + X.i1) * C, o10 = (Y.i1 * W + X.i0) * C, o11 = (Y.i1 * W + X.i1) * C;
-    float pv[NL], di[NL];
+    wave_sync();
+    // the line's own two taps are the same for the whole range (one line cell): clamped indices of lin_setup for cell c = lc % (n + 1)
+    const int cL = (int)(lc % ((uint32_t)NLn + 1));
+    const int oL0 = max(cL - 1, 0) * C, oL1 = min(cL, NLn - 1) * C;
+    for (int t0 = 0; t0 < cnt; t0 += 4 * U) {   // stage 2: lane = channel
+      float w4[U][4], lw[U][2], di[U][NL], pt[U][NL][4];
+      bool ok[U];
 #pragma unroll
-    for (int i = 0; i < NL; ++i) pv[i] = P[o00 + 16 * i] * w00 + P[o01 + 16 * i] * w01 + P[o10 + 16 * i] * w10 + P[o11 + 16 * i] * w11;
-    if (DENS) {
-      float dot = pv[0] * (L[Ln.i0 * C] * Ln.w0 + L[Ln.i1 * C] * Ln.w1);
+      for (int u = 0; u < U; ++u) {
+        const int t = t0 + 4 * u + q;
+        ok[u] = t < cnt;
+        const int tt = ok[u] ? t : cnt - 1;
+        const int64_t m = R.f[0][tt];
+        int o[4];
 #pragma unroll
-      for (int sh = 8; sh >= 1; sh >>= 1) dot += __shfl_xor(dot, sh, 16);
-      di[0] = dot > 0.f ? dsample : 0.f;
-    } else {
+        for (int c = 0; c < 4; ++c) { w4[u][c] = __uint_as_float(R.f[1 + c][tt]); o[c] = (int)R.f[5 + c][tt]; }
+        lw[u][0] = __uint_as_float(R.f[9][tt]); lw[u][1] = __uint_as_float(R.f[10][tt]);
 #pragma unroll
-      for (int i = 0; i < NL; ++i) di[i] = A.d[(m >> 5) * (32 * 3 * C) + (J * NL + i) * 512 + (m & 31) * 16 + c16];
+        for (int i = 0; i < NL; ++i)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) pt[u][i][c] = P[o[c] + 16 * i];
+        if (DENS) {
+          di[u][0] = __uint_as_float(R.f[11][tt]);
+        } else {
+#pragma unroll
+          for (int i = 0; i < NL; ++i) di[u][i] = A.d[(m >> 5) * (32 * 3 * C) + (J * NL + i) * 512 + (m & 31) * 16 + c16];
+        }
+      }
+      float lt0 = 0.f, lt1 = 0.f;
+      if (DENS) { lt0 = L[oL0]; lt1 = L[oL1]; }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        float pv[NL], dd[NL];
+#pragma unroll
+        for (int i = 0; i < NL; ++i) pv[i] = pt[u][i][0] * w4[u][0] + pt[u][i][1] * w4[u][1] + pt[u][i][2] * w4[u][2] + pt[u][i][3] * w4[u][3];
+        if (DENS) {
+          float dot = pv[0] * (lt0 * lw[u][0] + lt1 * lw[u][1]);
+#pragma unroll
+          for (int sh = 8; sh >= 1; sh >>= 1) dot += __shfl_xor(dot, sh, 16);
+          dd[0] = (ok[u] && dot > 0.f) ? di[u][0] : 0.f;
+        } else {
+#pragma unroll
+          for (int i = 0; i < NL; ++i) dd[i] = ok[u] ? di[u][i] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+          const float gl = dd[i] * pv[i];
+          acc[i][0] += gl * lw[u][0]; acc[i][1] += gl * lw[u][1];
+        }
+      }
     }
-#pragma unroll
-    for (int i = 0; i < NL; ++i) {
-      const float gl = di[i] * pv[i];
-      acc[i][0] += gl * Ln.w0; acc[i][1] += gl * Ln.w1;
-    }
+    wave_sync();
   }
   float* out = A.linepart[S_] + (int64_t)w * 2 * C + c16;
 #pragma unroll
@@ -354,9 +452,11 @@ __device__ __forceinline__ void sorted_line(const SortedArgs& A) {
 
 template <int C, bool DENS>
 __global__ __launch_bounds__(256) void k_sorted_line(SortedArgs A) {
-  if (blockIdx.y == 0) sorted_line<C, DENS, 0>(A);
-  else if (blockIdx.y == 1) sorted_line<C, DENS, 1>(A);
-  else sorted_line<C, DENS, 2>(A);
+  __shared__ WaveRec rec[4];
+  WaveRec& R = rec[threadIdx.x >> 6];
+  if (blockIdx.y == 0) sorted_line<C, DENS, 0>(A, R);
+  else if (blockIdx.y == 1) sorted_line<C, DENS, 1>(A, R);
+  else sorted_line<C, DENS, 2>(A, R);
 }
 
 // line texel (g, t): west tap (weight w0) of the samples of cell t + 1, east tap (w1) of cell t; partials added in sub-block order
@@ -420,7 +520,7 @@ int launch_sorted(const SortedArgs& a, const SortGeom& G, hipStream_t st) {
     const int64_t ln = (int64_t)2 * G.res[sort_major(s)] * C;
     linemax = ln > linemax ? ln : linemax;
   }
-  k_sorted_plane<C, DENS><<<dim3((kmax + 3) / 4, 3), 256, 0, st>>>(a);
+  k_sorted_plane<C, DENS><<<dim3((kmax + 15) / 16, 3), 256, 0, st>>>(a);   // 4 cells per wave, 4 waves per workgroup
   if (int e = ego_launch_status("k_sorted_plane")) return e;
   k_sorted_line<C, DENS><<<dim3((G.nsub_max + 3) / 4, 3), 256, 0, st>>>(a);
   if (int e = ego_launch_status("k_sorted_line")) return e;

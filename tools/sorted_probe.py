@@ -1,0 +1,41 @@
+"""Times the sorted-scatter kernels alone on a real training batch's coordinates (config 4 size) - for rocprofv3 --pmc / --kernel-trace."""
+import ctypes as C, sys, os
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from egonerf_amd import synth, _lib
+from egonerf_amd.train import _grad_struct, table_params
+dev = torch.device("cuda", 0)
+cfg = synth.SceneConfig()
+model = synth.build_model(cfg, synth.make_weights(cfg, seed=1234), dev); model.train()
+N, S = 8192, 256
+rays = torch.from_numpy(synth.make_rays(N, seed=1)).to(dev)
+lib, st = _lib.load(), _lib.stream_handle()
+sc = model.scene(training=True)
+# coordinates of a real step: coarse march -> pdf merge -> fine march
+sched = model._sched(128, dev)
+f = lambda *s: torch.empty(*s, device=dev)
+zc, wc, z, w, bg, crd = f(N, 128), f(N, 128), f(N, S), f(N, S), f(N), f(N, S, 4)
+near = float(model.near_far[0])
+_lib.check(lib.ego_march_density(sc, rays.data_ptr(), N, 128, None, sched.data_ptr(), None, near, 1, zc.data_ptr(), None, 0, wc.data_ptr(), None, None, None, None, st), "m1")
+_lib.check(lib.ego_sample_pdf_merge(zc.data_ptr(), wc.data_ptr(), None, N, 128, 128, 1, z.data_ptr(), None, st), "pdf")
+_lib.check(lib.ego_march_density(sc, rays.data_ptr(), N, S, z.data_ptr(), None, None, near, 2, None, None, 0, w.data_ptr(), bg.data_ptr(), crd.data_ptr(), None, None, st), "m2")
+dfeat = torch.randn(N, S, device=dev); dv = torch.randn(N * S * 144, device=dev)
+dens, app = table_params(model, "density"), table_params(model, "app")
+gd, ga = [torch.zeros_like(p) for p in dens], [torch.zeros_like(p) for p in app]
+sd, sa = _grad_struct(gd), _grad_struct(ga)
+nb = lib.ego_scatter_sorted_workspace_bytes(sc, N, S)
+ws = torch.empty(nb, device=dev, dtype=torch.uint8)
+def run(which):
+    if which == "sort": _lib.check(lib.ego_scatter_sort(sc, crd.data_ptr(), N, S, ws.data_ptr(), nb, st), "sort")
+    if which == "dens": _lib.check(lib.ego_scatter_density_sorted(sc, C.byref(sd), crd.data_ptr(), dfeat.data_ptr(), N, S, ws.data_ptr(), nb, st), "d")
+    if which == "app": _lib.check(lib.ego_scatter_app_sorted(sc, C.byref(sa), crd.data_ptr(), dv.data_ptr(), N, S, ws.data_ptr(), nb, st), "a")
+    if which == "dens_atomic": _lib.check(lib.ego_scatter_density(sc, C.byref(sd), crd.data_ptr(), dfeat.data_ptr(), N, S, st), "d")
+    if which == "app_atomic": _lib.check(lib.ego_scatter_app(sc, C.byref(sa), crd.data_ptr(), dv.data_ptr(), N, S, st), "a")
+for which in ("sort", "dens", "app", "dens_atomic", "app_atomic"):
+    for _ in range(3): run(which)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10): run(which)
+    e1.record(); torch.cuda.synchronize()
+    print(f"{which:12s} {e0.elapsed_time(e1) / 10:.3f} ms")
