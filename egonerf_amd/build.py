@@ -98,7 +98,8 @@ def shipped_isa_report(lib_path: str | None = None) -> dict:
 # weights, and the packed fp32 instructions that then broadcast the high half of such a pair are what every non-reproducible build
 # of these kernels had in common.  The source also pins the weights to separate registers; either measure alone
 # was enough in every soak, neither costs time.
-EXTRA_FLAGS = {"ego_shade.hip": ["-fno-slp-vectorize"]}
+# ego_scatter_sorted.hip (round 5) gets the same flag: with the vectoriser on, k_sorted_plane<16> contained six such instructions.
+EXTRA_FLAGS = {"ego_shade.hip": ["-fno-slp-vectorize"], "ego_scatter_sorted.hip": ["-fno-slp-vectorize"]}
 COMMON_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-munsafe-fp-atomics", "-fPIC"]
 
 
