@@ -4,8 +4,8 @@
 //
 // k_vm_scatter (ego_train.inc) walks rays and sends one float-atomic line per (cell run, tap): ~16 M atomic line requests per 8192 x 256
 // step at the L2's ~21 G/s plus ~0.95 ms of cell bookkeeping, and a sum whose order changes from run to run.  Here the step's samples are
-// binned by texel CELL once (three stable radix sorts of 18-bit keys: rocPRIM's device radix sort, the one library primitive of this
-// file - the sort is plumbing, the reductions are the kernels), and every gradient texel is then written exactly once from sums taken in a
+// binned by texel CELL once (three stable LSD radix sorts of 18-bit keys, 9 bits per pass, all three sorts in the same launches:
+// k_radix_hist / k_radix_scan / k_radix_scatter below), and every gradient texel is then written exactly once from sums taken in a
 // fixed order:
 //
 //   ego_scatter_sort      : coords -> three permutations + cell start offsets (needs only the forward's coordinates: it runs on the side
@@ -23,7 +23,6 @@
 //   k_sorted_line_final   : texel = its two cells' partials, added in sub-block order
 //
 // No zero fill of the gradient tables is needed (every texel is written), no atomics, and two runs return the same bits.
-#include <rocprim/device/device_radix_sort.hpp>
 
 #include "ego_device.h"
 #include "ego_host.h"
@@ -31,6 +30,7 @@
 namespace {
 
 constexpr int SUB = 256;       // samples per line sub-block
+constexpr int RBITS = 9, RADIX = 1 << RBITS, RTILE = 4096;   // radix sort: digit bits, buckets, elements per workgroup tile (256 threads x 16)
 constexpr int CMAX = 48;       // channels of the widest field (appearance)
 
 // sort s: major / minor axis of its key (0 r, 1 theta, 2 phi), the plane whose cells it bins and the line whose ranges it bins
@@ -49,8 +49,9 @@ struct SortGeom {
   // byte offsets into the workspace
   int64_t perm[3], start[3], suboff[3], scratch, total;
   // sort-phase view of the scratch region
-  int64_t keys_in[3], keys_out, idx_in, rp_temp;
-  size_t rp_bytes;
+  int64_t keys_in[3], k1[3], v1[3], k2[3], hist[3];
+  uint32_t nblocks;    // radix tiles (RTILE elements each)
+  int passes;          // ceil(bits / 9)
   // scatter-phase view of the scratch region
   int64_t cellbuf[3], linepart[3];
 };
@@ -79,14 +80,13 @@ SortGeom make_geom(const int32_t res[3], int64_t M) {
   G.scratch = o;
   // sort phase
   int64_t a = o;
+  G.passes = (G.bits + RBITS - 1) / RBITS;
+  G.nblocks = (uint32_t)((M + RTILE - 1) / RTILE);
   for (int s = 0; s < 3; ++s) { G.keys_in[s] = a; a = align256(a + 4 * M); }
-  G.keys_out = a; a = align256(a + 4 * M);
-  G.idx_in = a; a = align256(a + 4 * M);
-  G.rp_temp = a;
-  G.rp_bytes = 0;
-  (void)rocprim::radix_sort_pairs(nullptr, G.rp_bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr,
-                                  (size_t)M, 0u, (unsigned)G.bits, (hipStream_t)0);
-  a = align256(a + (int64_t)G.rp_bytes);
+  for (int s = 0; s < 3; ++s) { G.k1[s] = a; a = align256(a + 4 * M); }
+  for (int s = 0; s < 3; ++s) { G.v1[s] = a; a = align256(a + 4 * M); }
+  for (int s = 0; s < 3; ++s) { G.k2[s] = a; a = align256(a + 4 * M); }
+  for (int s = 0; s < 3; ++s) { G.hist[s] = a; a = align256(a + 4 * ((int64_t)RADIX * G.nblocks + RADIX)); }   // + the digit totals
   // scatter phase
   int64_t b = o;
   for (int s = 0; s < 3; ++s) { G.cellbuf[s] = b; b = align256(b + 4 * (int64_t)G.K[s] * 4 * CMAX); }
@@ -104,7 +104,7 @@ __device__ __forceinline__ int cell_of(float xhat, int n) {
 }
 
 __global__ void k_sort_keys(const float* __restrict__ coords, int64_t M, int nr, int nth, int nph, uint32_t K0, uint32_t K1, uint32_t K2,
-                            uint32_t* __restrict__ k0, uint32_t* __restrict__ k1, uint32_t* __restrict__ k2, uint32_t* __restrict__ idx) {
+                            uint32_t* __restrict__ k0, uint32_t* __restrict__ k1, uint32_t* __restrict__ k2) {
   const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (m >= M) return;
   const f32x4 cc = ((const f32x4*)coords)[m];
@@ -113,11 +113,149 @@ __global__ void k_sort_keys(const float* __restrict__ coords, int64_t M, int nr,
   k0[m] = (cph < 0 || cr < 0) ? K0 : (g * (uint32_t)(nph + 1) + (uint32_t)cph) * (uint32_t)(nr + 1) + (uint32_t)cr;
   k1[m] = (cr < 0 || cth < 0) ? K1 : (g * (uint32_t)(nr + 1) + (uint32_t)cr) * (uint32_t)(nth + 1) + (uint32_t)cth;
   k2[m] = (cth < 0 || cph < 0) ? K2 : (g * (uint32_t)(nth + 1) + (uint32_t)cth) * (uint32_t)(nph + 1) + (uint32_t)cph;
-  idx[m] = (uint32_t)m;
+}
+
+// ---- stable LSD radix sort of (key, sample index), 9 bits per pass, the three sorts side by side (blockIdx.y) -----------------------
+// Plain kernels (no look-back between workgroups, no library state): the whole sort is graph-capturable and bit-reproducible.  A pass =
+//   k_radix_hist    : per 4096-element tile, the digit histogram (LDS integer atomics) -> hist[digit][tile]
+//   k_radix_scan    : per digit, exclusive scan of its per-tile counts + the digit's total (the digit bases are a 512-value scan that every
+//                     scatter workgroup does for itself): where each tile's run of each digit starts
+//   k_radix_scatter : the tile again: every element's rank among the EARLIER elements of its digit (wave w owns elements [1024 w, 1024 w +
+//                     1024) of the tile and walks them 64 at a time in order; inside an iteration the equal-digit lanes are found with 9
+//                     ballots) -> stable position -> (key, value) stored
+struct RadixArgs {
+  const uint32_t* kin[3];
+  const uint32_t* vin[3];    // nullptr: the value is the element's index (first pass)
+  uint32_t* kout[3];
+  uint32_t* vout[3];
+  uint32_t* hist[3];
+  uint32_t* dsum[3];         // [RADIX] per-digit totals of the pass
+  int64_t M;
+  uint32_t nblocks;
+  int shift;
+};
+
+__global__ __launch_bounds__(256) void k_radix_hist(RadixArgs A) {
+  __shared__ uint32_t h[RADIX];
+  const int s = blockIdx.y, t = threadIdx.x;
+  for (int i = t; i < RADIX; i += 256) h[i] = 0;
+  __syncthreads();
+  const int64_t base = (int64_t)blockIdx.x * RTILE;
+#pragma unroll 4
+  for (int j = 0; j < RTILE / 256; ++j) {
+    const int64_t idx = base + j * 256 + t;
+    if (idx < A.M) atomicAdd(&h[(A.kin[s][idx] >> A.shift) & (RADIX - 1)], 1u);
+  }
+  __syncthreads();
+  for (int i = t; i < RADIX; i += 256) A.hist[s][(int64_t)i * A.nblocks + blockIdx.x] = h[i];
+}
+
+// exclusive scan of a workgroup's 256 values (one per thread); returns the thread's prefix, *total = the sum
+__device__ __forceinline__ uint32_t block_excl_scan256(uint32_t v, uint32_t* wsum /* [4] shared */, uint32_t* total) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  uint32_t inc = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t u = __shfl_up(inc, d, 64);
+    if (lane >= d) inc += u;
+  }
+  __syncthreads();   // wsum may still be read from a previous call
+  if (lane == 63) wsum[wv] = inc;
+  __syncthreads();
+  uint32_t before = 0;
+  for (int w = 0; w < wv; ++w) before += wsum[w];
+  *total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+  return before + inc - v;
+}
+
+// one workgroup per (digit, sort): in-place exclusive scan of the digit's per-tile counts; the digit's total goes to dsum[digit]
+// (k_radix_scatter turns the 512 totals into digit bases itself)
+__global__ __launch_bounds__(256) void k_radix_scan(RadixArgs A) {
+  __shared__ uint32_t wsum[4];
+  uint32_t* h = A.hist[blockIdx.y] + (int64_t)blockIdx.x * A.nblocks;
+  uint32_t carry = 0;
+  for (uint32_t base = 0; base < A.nblocks; base += 256) {
+    const uint32_t i = base + threadIdx.x;
+    const uint32_t v = i < A.nblocks ? h[i] : 0u;
+    uint32_t total;
+    const uint32_t ex = block_excl_scan256(v, wsum, &total);
+    if (i < A.nblocks) h[i] = carry + ex;
+    carry += total;
+  }
+  if (threadIdx.x == 0) A.dsum[blockIdx.y][blockIdx.x] = carry;
+}
+
+__global__ __launch_bounds__(256) void k_radix_scatter(RadixArgs A) {
+  __shared__ uint32_t wcnt[4][RADIX];
+  __shared__ uint32_t dbase[RADIX];
+  const int s = blockIdx.y, t = threadIdx.x, lane = t & 63, w = t >> 6;
+  for (int i = t; i < 4 * RADIX; i += 256) (&wcnt[0][0])[i] = 0;
+  __syncthreads();
+  const int64_t wbase = (int64_t)blockIdx.x * RTILE + w * (RTILE / 4);
+  uint32_t key[RTILE / 256];
+#pragma unroll
+  for (int it = 0; it < RTILE / 256; ++it) {
+    const int64_t idx = wbase + it * 64 + lane;
+    key[it] = idx < A.M ? A.kin[s][idx] : 0u;
+    if (idx < A.M) atomicAdd(&wcnt[w][(key[it] >> A.shift) & (RADIX - 1)], 1u);
+  }
+  __syncthreads();
+  {   // digit bases: exclusive scan of the 512 digit totals (two per thread, digits 2 t and 2 t + 1)
+    __shared__ uint32_t wsum[4];
+    const uint32_t d0 = A.dsum[s][2 * t], d1 = A.dsum[s][2 * t + 1];
+    uint32_t total;
+    const uint32_t ex = block_excl_scan256(d0 + d1, wsum, &total);
+    dbase[2 * t] = ex; dbase[2 * t + 1] = ex + d0;
+  }
+  __syncthreads();
+  for (int d = t; d < RADIX; d += 256) {   // counts -> where wave w's run of digit d starts in the output
+    uint32_t run = dbase[d] + A.hist[s][(int64_t)d * A.nblocks + blockIdx.x];
+#pragma unroll
+    for (int ww = 0; ww < 4; ++ww) { const uint32_t c = wcnt[ww][d]; wcnt[ww][d] = run; run += c; }
+  }
+  __syncthreads();
+  const unsigned long long lt = lane ? (~0ull >> (64 - lane)) : 0ull;
+#pragma unroll
+  for (int it = 0; it < RTILE / 256; ++it) {
+    const int64_t idx = wbase + it * 64 + lane;
+    const bool ok = idx < A.M;
+    const uint32_t d = (key[it] >> A.shift) & (RADIX - 1);
+    unsigned long long m = __ballot(ok);
+#pragma unroll
+    for (int b = 0; b < RBITS; ++b) {
+      const unsigned long long bal = __ballot(ok && ((d >> b) & 1u));
+      m &= ((d >> b) & 1u) ? bal : ~bal;
+    }
+    const uint32_t rank = (uint32_t)__popcll(m & lt);
+    uint32_t off = 0;
+    if (ok) off = wcnt[w][d];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (ok && rank == 0) wcnt[w][d] = off + (uint32_t)__popcll(m);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (ok) {
+      const uint32_t pos = off + rank;
+      A.kout[s][pos] = key[it];
+      A.vout[s][pos] = A.vin[s] ? A.vin[s][idx] : (uint32_t)idx;
+    }
+  }
 }
 
 // start[k] = first sorted position whose key is >= k, k = 0 .. K + 1 (start[K] = the number of samples with a gradient)
-__global__ void k_cell_starts(const uint32_t* __restrict__ sorted, int64_t M, uint32_t K, uint32_t* __restrict__ start) {
+struct StartArgs {
+  const uint32_t* sorted[3];
+  uint32_t* start[3];
+  uint32_t* suboff[3];
+  uint32_t K[3], LC[3], nmin1[3];
+  int64_t M;
+};
+
+__global__ void k_cell_starts(StartArgs A) {
+  const uint32_t* __restrict__ sorted = A.sorted[blockIdx.y];
+  uint32_t* __restrict__ start = A.start[blockIdx.y];
+  const uint32_t K = A.K[blockIdx.y];
+  const int64_t M = A.M;
   const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k > K + 1) return;
   int64_t lo = 0, hi = M;
@@ -129,7 +267,10 @@ __global__ void k_cell_starts(const uint32_t* __restrict__ sorted, int64_t M, ui
 }
 
 // suboff[lc] = number of 256-sample sub-blocks of the line cells before lc (exclusive scan; suboff[LC] = total); one workgroup
-__global__ __launch_bounds__(1024) void k_line_suboff(const uint32_t* __restrict__ start, uint32_t LC, uint32_t nmin1, uint32_t* __restrict__ suboff) {
+__global__ __launch_bounds__(1024) void k_line_suboff(StartArgs A) {
+  const uint32_t* __restrict__ start = A.start[blockIdx.y];
+  uint32_t* __restrict__ suboff = A.suboff[blockIdx.y];
+  const uint32_t LC = A.LC[blockIdx.y], nmin1 = A.nmin1[blockIdx.y];
   __shared__ uint32_t wsum[16];
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
   uint32_t carry = 0;
@@ -560,21 +701,42 @@ int ego_scatter_sort(const ego_scene* sc, const float* coords, int64_t N, int32_
   hipStream_t st = (hipStream_t)stream;
   char* base = (char*)workspace;
   uint32_t* kin[3] = {(uint32_t*)(base + G.keys_in[0]), (uint32_t*)(base + G.keys_in[1]), (uint32_t*)(base + G.keys_in[2])};
-  uint32_t* kout = (uint32_t*)(base + G.keys_out);
-  uint32_t* idx = (uint32_t*)(base + G.idx_in);
-  k_sort_keys<<<(unsigned)((M + 255) / 256), 256, 0, st>>>(coords, M, G.res[0], G.res[1], G.res[2], G.K[0], G.K[1], G.K[2], kin[0], kin[1], kin[2], idx);
+  k_sort_keys<<<(unsigned)((M + 255) / 256), 256, 0, st>>>(coords, M, G.res[0], G.res[1], G.res[2], G.K[0], G.K[1], G.K[2], kin[0], kin[1], kin[2]);
   if (int e = ego_launch_status("k_sort_keys")) return e;
-  for (int s = 0; s < 3; ++s) {
-    size_t bytes = G.rp_bytes;
-    const hipError_t err = rocprim::radix_sort_pairs((void*)(base + G.rp_temp), bytes, (const uint32_t*)kin[s], kout, (const uint32_t*)idx,
-                                                     (uint32_t*)(base + G.perm[s]), (size_t)M, 0u, (unsigned)G.bits, st);
-    if (err != hipSuccess) return ego_fail((int)err, "scatter_sort: radix sort failed: %s", hipGetErrorString(err));
-    uint32_t* start = (uint32_t*)(base + G.start[s]);
-    k_cell_starts<<<(G.K[s] + 2 + 255) / 256, 256, 0, st>>>(kout, M, G.K[s], start);
-    if (int e = ego_launch_status("k_cell_starts")) return e;
-    k_line_suboff<<<1, 1024, 0, st>>>(start, G.LC[s], (uint32_t)G.res[sort_minor(s)] + 1, (uint32_t*)(base + G.suboff[s]));
-    if (int e = ego_launch_status("k_line_suboff")) return e;
+  // LSD passes ping-pong between (k1, v1) and (k2, perm); the last pass lands in (k2, perm)
+  for (int p = 0; p < G.passes; ++p) {
+    RadixArgs r{};
+    const bool to2 = ((G.passes - 1 - p) & 1) == 0;
+    for (int s = 0; s < 3; ++s) {
+      r.kin[s] = p == 0 ? kin[s] : (const uint32_t*)(base + (to2 ? G.k1[s] : G.k2[s]));
+      r.vin[s] = p == 0 ? nullptr : (const uint32_t*)(base + (to2 ? G.v1[s] : G.perm[s]));
+      r.kout[s] = (uint32_t*)(base + (to2 ? G.k2[s] : G.k1[s]));
+      r.vout[s] = (uint32_t*)(base + (to2 ? G.perm[s] : G.v1[s]));
+      r.hist[s] = (uint32_t*)(base + G.hist[s]);
+      r.dsum[s] = r.hist[s] + (int64_t)RADIX * G.nblocks;
+    }
+    r.M = M; r.nblocks = G.nblocks; r.shift = p * RBITS;
+    k_radix_hist<<<dim3(G.nblocks, 3), 256, 0, st>>>(r);
+    if (int e = ego_launch_status("k_radix_hist")) return e;
+    k_radix_scan<<<dim3(RADIX, 3), 256, 0, st>>>(r);
+    if (int e = ego_launch_status("k_radix_scan")) return e;
+    k_radix_scatter<<<dim3(G.nblocks, 3), 256, 0, st>>>(r);
+    if (int e = ego_launch_status("k_radix_scatter")) return e;
   }
+  StartArgs sa{};
+  uint32_t kmax = 0;
+  for (int s = 0; s < 3; ++s) {
+    sa.sorted[s] = (const uint32_t*)(base + G.k2[s]);
+    sa.start[s] = (uint32_t*)(base + G.start[s]);
+    sa.suboff[s] = (uint32_t*)(base + G.suboff[s]);
+    sa.K[s] = G.K[s]; sa.LC[s] = G.LC[s]; sa.nmin1[s] = (uint32_t)G.res[sort_minor(s)] + 1;
+    kmax = G.K[s] > kmax ? G.K[s] : kmax;
+  }
+  sa.M = M;
+  k_cell_starts<<<dim3((kmax + 2 + 255) / 256, 3), 256, 0, st>>>(sa);
+  if (int e = ego_launch_status("k_cell_starts")) return e;
+  k_line_suboff<<<dim3(1, 3), 1024, 0, st>>>(sa);
+  if (int e = ego_launch_status("k_line_suboff")) return e;
   return EGO_OK;
 }
 

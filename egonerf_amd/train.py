@@ -55,8 +55,15 @@ def _side_stream(device) -> "torch.cuda.Stream":
 KERNEL_MARKS = None
 
 
+_DEBUG_SYNC = __import__("os").environ.get("EGO_TRAIN_DEBUG_SYNC", "0") != "0"   # debugging: synchronise and print after every library call
+
+
 def _chk(code: int, what: str) -> None:
     _lib.check(code, what)
+    if _DEBUG_SYNC and not torch.cuda.is_current_stream_capturing():
+        print("[ego train] queued", what, flush=True)
+        torch.cuda.synchronize()
+        print("[ego train] done  ", what, flush=True)
     if KERNEL_MARKS is not None:
         ev = torch.cuda.Event(enable_timing=True)
         ev.record()
