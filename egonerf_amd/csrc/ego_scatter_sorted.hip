@@ -187,11 +187,13 @@ __global__ __launch_bounds__(256) void k_radix_scan(RadixArgs A) {
 
 __global__ __launch_bounds__(256) void k_radix_scatter(RadixArgs A) {
   __shared__ uint32_t wcnt[4][RADIX];
-  __shared__ uint32_t dbase[RADIX];
+  __shared__ uint32_t lbase[RADIX], gbase[RADIX];   // where a digit's run starts inside the sorted tile / in the output
+  __shared__ uint32_t skey[RTILE], sval[RTILE];     // the tile in sorted order: the output is then written in runs, not element by element
+  __shared__ uint32_t wsum[4];
   const int s = blockIdx.y, t = threadIdx.x, lane = t & 63, w = t >> 6;
   for (int i = t; i < 4 * RADIX; i += 256) (&wcnt[0][0])[i] = 0;
   __syncthreads();
-  const int64_t wbase = (int64_t)blockIdx.x * RTILE + w * (RTILE / 4);
+  const int64_t tbase = (int64_t)blockIdx.x * RTILE, wbase = tbase + w * (RTILE / 4);
   uint32_t key[RTILE / 256];
 #pragma unroll
   for (int it = 0; it < RTILE / 256; ++it) {
@@ -200,16 +202,20 @@ __global__ __launch_bounds__(256) void k_radix_scatter(RadixArgs A) {
     if (idx < A.M) atomicAdd(&wcnt[w][(key[it] >> A.shift) & (RADIX - 1)], 1u);
   }
   __syncthreads();
-  {   // digit bases: exclusive scan of the 512 digit totals (two per thread, digits 2 t and 2 t + 1)
-    __shared__ uint32_t wsum[4];
-    const uint32_t d0 = A.dsum[s][2 * t], d1 = A.dsum[s][2 * t + 1];
+  {   // two digits per thread (2 t, 2 t + 1): the tile's digit starts, and the digit bases from the 512 digit totals of the pass
+    const uint32_t c0 = wcnt[0][2 * t] + wcnt[1][2 * t] + wcnt[2][2 * t] + wcnt[3][2 * t];
+    const uint32_t c1 = wcnt[0][2 * t + 1] + wcnt[1][2 * t + 1] + wcnt[2][2 * t + 1] + wcnt[3][2 * t + 1];
     uint32_t total;
-    const uint32_t ex = block_excl_scan256(d0 + d1, wsum, &total);
-    dbase[2 * t] = ex; dbase[2 * t + 1] = ex + d0;
+    const uint32_t ex = block_excl_scan256(c0 + c1, wsum, &total);
+    lbase[2 * t] = ex; lbase[2 * t + 1] = ex + c0;
+    const uint32_t d0 = A.dsum[s][2 * t], d1 = A.dsum[s][2 * t + 1];
+    const uint32_t exg = block_excl_scan256(d0 + d1, wsum, &total);
+    gbase[2 * t] = exg + A.hist[s][(int64_t)(2 * t) * A.nblocks + blockIdx.x];
+    gbase[2 * t + 1] = exg + d0 + A.hist[s][(int64_t)(2 * t + 1) * A.nblocks + blockIdx.x];
   }
   __syncthreads();
-  for (int d = t; d < RADIX; d += 256) {   // counts -> where wave w's run of digit d starts in the output
-    uint32_t run = dbase[d] + A.hist[s][(int64_t)d * A.nblocks + blockIdx.x];
+  for (int d = t; d < RADIX; d += 256) {   // counts -> where wave w's run of digit d starts in the sorted tile
+    uint32_t run = lbase[d];
 #pragma unroll
     for (int ww = 0; ww < 4; ++ww) { const uint32_t c = wcnt[ww][d]; wcnt[ww][d] = run; run += c; }
   }
@@ -235,10 +241,17 @@ __global__ __launch_bounds__(256) void k_radix_scatter(RadixArgs A) {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     if (ok) {
-      const uint32_t pos = off + rank;
-      A.kout[s][pos] = key[it];
-      A.vout[s][pos] = A.vin[s] ? A.vin[s][idx] : (uint32_t)idx;
+      skey[off + rank] = key[it];
+      sval[off + rank] = A.vin[s] ? A.vin[s][idx] : (uint32_t)idx;
     }
+  }
+  __syncthreads();
+  const int n_tile = (int)(A.M - tbase < RTILE ? A.M - tbase : RTILE);
+  for (int i = t; i < n_tile; i += 256) {
+    const uint32_t k = skey[i], d = (k >> A.shift) & (RADIX - 1);
+    const uint32_t pos = gbase[d] + ((uint32_t)i - lbase[d]);
+    A.kout[s][pos] = k;
+    A.vout[s][pos] = sval[i];
   }
 }
 

@@ -387,7 +387,8 @@ template <int CBB>
 int launch_h(const WgradArgs& a, hipStream_t st) {
   WgradArgs p = a;
   const int64_t steps = (a.M + 31) / 32;
-  const int64_t wgs = steps < 1024 ? steps : 1024;
+  const int64_t cap = a.Gpart ? 512 : 1024;   // ordered mode: one resident round of workgroups (2 per CU), half the partial blocks to store and add
+  const int64_t wgs = steps < cap ? steps : cap;
   p.steps_per_wg = (int32_t)((steps + wgs - 1) / wgs);
   const unsigned n_wg = (unsigned)((steps + p.steps_per_wg - 1) / p.steps_per_wg);
   k_wgrad_h<CBB><<<n_wg, 256, 0, st>>>(p);
