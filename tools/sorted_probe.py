@@ -39,3 +39,20 @@ for which in ("sort", "dens", "app", "dens_atomic", "app_atomic"):
     for _ in range(10): run(which)
     e1.record(); torch.cuda.synchronize()
     print(f"{which:12s} {e0.elapsed_time(e1) / 10:.3f} ms")
+# cell-size distribution of the three sorts (torch restatement of cell_of / k_sort_keys)
+if os.environ.get("PROBE_CELLS"):
+    res = [int(v) for v in model.gridSize.tolist()]
+    c = crd.view(-1, 4)
+    g = (c[:, 3] != 0).long()
+    def cell(x, n):
+        i0 = torch.floor((x + 1.0) * (0.5 * (n - 1))).clamp(-2, n).long()
+        return torch.where((i0 < -1) | (i0 > n - 1), torch.full_like(i0, -1), i0 + 1)
+    cr, cth, cph = cell(c[:, 0], res[0]), cell(c[:, 1], res[1]), cell(c[:, 2], res[2])
+    for name, (a, na), (b, nb) in (("sort0 (phi,r) plane1", (cph, res[2]), (cr, res[0])), ("sort1 (r,theta) plane0", (cr, res[0]), (cth, res[1])), ("sort2 (theta,phi) plane2", (cth, res[1]), (cph, res[2]))):
+        ok = (a >= 0) & (b >= 0)
+        key = ((g * (na + 1) + a) * (nb + 1) + b)[ok]
+        cnt = torch.bincount(key, minlength=2 * (na + 1) * (nb + 1))
+        nz = cnt[cnt > 0].float()
+        q = torch.quantile(nz, torch.tensor([0.5, 0.9, 0.99, 0.999], device=nz.device)).tolist()
+        top = torch.sort(cnt, descending=True).values[:8].tolist()
+        print(f"{name}: cells {cnt.numel()}, non-empty {nz.numel()}, samples {int(nz.sum())}, mean {nz.mean():.1f}, median/p90/p99/p99.9 {q}, largest {top}, samples in cells > 256: {int(cnt[cnt > 256].sum())}, > 1024: {int(cnt[cnt > 1024].sum())}")
