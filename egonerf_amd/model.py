@@ -574,7 +574,8 @@ class EgoNeRF(TensorBase):
         """True for the model shape every shipped config resolves to (head_is_tuned AND 16 density components): the MFMA / team-gather
         kernels end to end, forward and backward.  Any other shape opt.py:87-100 can produce (n_lamb_sigma / n_lamb_sh multiples of 4
         up to 48, data_dim_color <= 32, featureC 64 | 128, view_pe / fea_pe <= 8, shadingMode 'MLP' / 'RGB') renders and trains through
-        the fp32 compatibility kernels for the part that differs: same results to fp32 rounding, roughly an order of magnitude slower."""
+        the fp32 compatibility kernels for the part that differs: same results to fp32 rounding, 13-32 x slower (tools/generic_timing.py:
+        8.8-21 ms against 0.67 ms per 4096 x 512 inference step, 89-167 ms against 6.4 ms per 8192-ray training step)."""
         return self.head_is_tuned and self.density_n_comp[0] == 16
 
     @property
