@@ -351,3 +351,24 @@ def test_roctx_switch_loads_and_is_off_by_default():
         assert r.returncode == 0, r.stderr[-2000:]
         assert r.stdout.split() == ["0", "-1"], r.stdout        # N = 0 is a no-op; a null argument is still refused inside a range
         assert "roctx" not in r.stderr, r.stderr
+
+
+def test_sorted_scatter_argument_validation_needs_no_gpu():
+    """ego_scatter_sorted_workspace_bytes / ego_scatter_sort refuse bad arguments before touching the device (csrc/ego_scatter_sorted.hip)."""
+    lib = _lib.load()
+    sc = _lib.new_scene()
+    assert lib.ego_scatter_sorted_workspace_bytes(None, 4, 4) == -1
+    sc.density.res[:] = [150, 172, 516]
+    sc.app.res[:] = [150, 172, 516]
+    big = lib.ego_scatter_sorted_workspace_bytes(ctypes.byref(sc), 8192, 256)
+    small = lib.ego_scatter_sorted_workspace_bytes(ctypes.byref(sc), 64, 32)
+    assert big > small > 0 and big % 256 == 0
+    assert lib.ego_scatter_sorted_workspace_bytes(ctypes.byref(sc), 1 << 24, 256) == -1     # N * S must stay below 2^31
+    sc.density.res[:] = [150, 172, 5000]
+    assert lib.ego_scatter_sorted_workspace_bytes(ctypes.byref(sc), 64, 32) == -1 and b"resolution" in lib.ego_last_error()
+    sc.density.res[:] = [150, 172, 516]
+    assert lib.ego_scatter_sort(ctypes.byref(sc), None, 4, 4, None, 0, None) == -1 and b"null" in lib.ego_last_error()
+    assert lib.ego_scatter_sort(ctypes.byref(sc), None, 0, 4, None, 0, None) == 0                      # N = 0 is a no-op
+    sc.app.res[:] = [150, 172, 500]
+    assert lib.ego_scatter_sort(ctypes.byref(sc), 256, 4, 4, 256, 1 << 40, None) == -1 and b"one resolution" in lib.ego_last_error()
+    assert lib.ego_weight_grad_partial_floats() == 1024 * 128 * 160

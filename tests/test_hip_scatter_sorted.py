@@ -40,7 +40,9 @@ def _scatter_both(model, coords, dfeat, dv, N, S):
     return out
 
 
-@pytest.mark.parametrize("n_voxel,N,S,spread", [(20 ** 3, 48, 32, 1.0), (40 ** 3, 333, 45, 1.15), (27e6, 512, 256, 1.0)])
+@pytest.mark.parametrize("n_voxel,N,S,spread", [(20 ** 3, 48, 32, 1.0), (40 ** 3, 333, 45, 1.15), (27e6, 512, 256, 1.0),
+                                                (216e6, 96, 64, 1.05),    # grid [300, 346, 1036]: 20-bit cell keys, three radix passes (odd ping-pong)
+                                                (20 ** 3, 1, 2, 1.0)])    # the smallest call there is
 def test_sorted_scatter_equals_the_atomic_one_and_itself(n_voxel, N, S, spread):
     """Random normalised coordinates (spread > 1: some taps and whole samples beyond the table border: zero padding), random dfeat with
     exact zeros, random dv in k_shade_bwd's blocked layout."""
@@ -53,7 +55,8 @@ def test_sorted_scatter_equals_the_atomic_one_and_itself(n_voxel, N, S, spread):
     # rays are coherent: consecutive samples in neighbouring cells (as the march writes them) for half of the rays
     walk = torch.cumsum(torch.rand(N, S, 3, generator=g) * 0.02, dim=1) - 0.9
     coords[: N // 2, :, :3] = walk[: N // 2].clamp(-spread, spread)
-    coords[0, :4, 0] = torch.tensor([-1.0, 1.0, -1.3, 1.3])   # exactly on / beyond the border
+    if S >= 4:
+        coords[0, :4, 0] = torch.tensor([-1.0, 1.0, -1.3, 1.3])   # exactly on / beyond the border
     dfeat = torch.randn(N, S, generator=g)
     dfeat[torch.rand(N, S, generator=g) < 0.3] = 0.0
     Mp = (M + 31) // 32 * 32
@@ -66,7 +69,7 @@ def test_sorted_scatter_equals_the_atomic_one_and_itself(n_voxel, N, S, spread):
             assert torch.equal(s, s2), (field, k)                                # same bits twice
             scale = max(float(a.abs().max()), 1e-20)
             assert float((a - s).abs().max()) <= 3e-5 * scale, (field, k, float((a - s).abs().max()) / scale)   # summation order only (thousands of terms per texel at the large size)
-            assert float(s.abs().max()) > 0
+            assert M < 64 or float(s.abs().max()) > 0
 
 
 def test_training_gradients_are_bit_reproducible_and_match_the_atomic_path(golden):
