@@ -1320,10 +1320,12 @@ __global__ __launch_bounds__(512) void k_shade_h(ShadeArgs A) {
     for (int i = NCH * 64 + threadIdx.x; i < NQ; i += 512) ((f32x4*)lds)[i] = src[i];
   }
   bool need_sync = MODE != MODE_APP;   // wave-uniform: the barrier that publishes the LDS image is still ahead
-  if (PX) {
+  {
     // MODE.FP16_OVFL = 1: an out-of-range f32 -> fp8 / f16 conversion saturates to the largest finite value instead of producing
     // NaN / inf (v_cvt_pk_fp8_f32 returns NaN above 448, tools/fp8_layout_probe.hip); a saturated correction operand costs accuracy
-    // of one low-order term, a NaN would poison the pixel
+    // of one low-order term, a NaN would poison the pixel.  Round 5: for every arithmetic, not only the fp8 / fp6 ones - in the
+    // three-term fp16 split hi = 65504 and lo = x - hi then carry a value up to twice the half range exactly (inf - inf was NaN), and
+    // the training forward's x / h1 / h2 dumps (halves) stay finite.
     __builtin_amdgcn_s_setreg(1 | (23 << 6) | (0 << 11), 1);
   }
 

@@ -13,5 +13,5 @@ p=glob.glob("/tmp/tp/**/*.db", recursive=True)[0]
 db=sqlite3.connect(p)
 for name, calls, tot, avg, pct in db.execute("select name, total_calls, total_duration, average, percentage from top_kernels limit 22"):
     name=name.replace("(anonymous namespace)::","").replace("void ","")
-    print(f"{name[:92]:92s} {calls:5d} {avg/1e6:10.4f} ms {pct:5.1f}%")
+    print(f"{name[:92]:92s} {calls:5d} {avg:10.1f} us {pct:5.1f}%")
 PY
