@@ -125,6 +125,7 @@ PROTOTYPES = {
     "ego_scatter_generic": (C.c_int, [C.POINTER(VmField), C.POINTER(VmGrad), P, P, I32, I64, I32, P]),
     "ego_weight_grad": (C.c_int, [P, I32, I32, I32, P, P, I32, I32, I32, I32, I64, P, I32, P]),
     "ego_weight_grad_partial_floats": (C.c_int64, []),
+    "ego_weight_grad_x": (C.c_int, [P, P, P, P, I32, I32, I64, P, I32, P, I64, P]),
     "ego_weight_grad_det": (C.c_int, [P, I32, I32, I32, P, P, I32, I32, I32, I32, I64, P, I32, P, I64, P]),
     "ego_tv_plane": (C.c_int, [P, I32, I32, I32, F32, P, P, P]),
     "ego_l1_table": (C.c_int, [P, I64, F32, P, P, P]),

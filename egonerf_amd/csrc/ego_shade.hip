@@ -1612,7 +1612,8 @@ __global__ __launch_bounds__(512) void k_shade_h(ShadeArgs A) {
         if ((kk & 7) == 7) {
           const int step = kk >> 3;
           const HL b = split8(xs, true);
-          if (DUMP && valid) ((u32x4*)A.dump_x)[(tile * KH1 + step) * 64 + lane] = pack8_rn(xs);   // [tile][k-step][lane][8 halves]
+          // [tile][k-step][lane][8 halves]; optional (r05): ego_weight_grad_x re-derives x from the feature slots and the view direction
+          if (DUMP && valid && A.dump_x) ((u32x4*)A.dump_x)[(tile * KH1 + step) * 64 + lane] = pack8_rn(xs);
 #pragma unroll
           for (int mt = 0; mt < 4; ++mt) { ah[mt] = nh[mt]; al[mt] = nl[mt]; }
           if (step + 1 < KH1) {
@@ -1993,8 +1994,8 @@ int ego_shade(const ego_scene* sc, const float* rays, const float* z, const floa
   a.c = make_coords(*sc); a.F = make_field(sc->app); a.packed = sc->packed; a.rays = rays; a.z = z; a.coords = coords; a.out = rgb; a.tile_active = tile_active;
   a.M = N * (int64_t)S; a.S = S;
   if (dump) {
-    EGO_REQUIRE(sc->mlp_precision != EGO_PREC_F32 && dump->x && dump->h1 && dump->h2 && dump->v && dump->relu_bits && dump->fe,
-                "shade: activation dumps need the fp16-split arithmetic (not EGO_PREC_F32) and six non-null buffers");
+    EGO_REQUIRE(sc->mlp_precision != EGO_PREC_F32 && dump->h1 && dump->h2 && dump->v && dump->relu_bits && dump->fe,
+                "shade: activation dumps need the fp16-split arithmetic (not EGO_PREC_F32) and non-null h1 / h2 / v / relu_bits / fe buffers (x is optional)");
     a.dump_x = dump->x; a.dump_h1 = dump->h1; a.dump_h2 = dump->h2; a.dump_v = dump->v; a.dump_bits = dump->relu_bits; a.dump_fe = dump->fe;
     k_shade_h<MODE_SHADE, true><<<shade_grid(a.M), 512, 0, (hipStream_t)stream>>>(a);
   } else if (sc->mlp_precision == EGO_PREC_F32) k_shade<MODE_SHADE><<<shade_grid(a.M), 512, 0, (hipStream_t)stream>>>(a);
@@ -2115,7 +2116,7 @@ int ego_shade_backward(const ego_scene* sc, const float* train_packed, const flo
   EGO_TRACE("ego_shade_backward");
   EGO_REQUIRE(N >= 0 && S >= 1 && N * (int64_t)S < (1ll << 31), "shade_backward: bad size");
   if (N == 0) return EGO_OK;
-  EGO_REQUIRE(sc && train_packed && coords && dc && rgb && fwd && fwd->x && fwd->relu_bits && dh2 && dh1 && dh_scale && dfe && dv,
+  EGO_REQUIRE(sc && train_packed && coords && dc && rgb && fwd && fwd->fe && fwd->relu_bits && dh2 && dh1 && dh_scale && dfe && dv,
               "shade_backward: null argument");
   EGO_REQUIRE((((uintptr_t)dh2 | (uintptr_t)dh1 | (uintptr_t)fwd->relu_bits | (uintptr_t)dv) & 15) == 0,
               "shade_backward: dh2 / dh1 / dv / relu_bits must be 16-byte aligned");

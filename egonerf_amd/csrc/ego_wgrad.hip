@@ -25,6 +25,9 @@ struct WgradArgs {
   float* G;
   int64_t M;
   int32_t lda, ca, ldb, cb, ones_col, ldg, steps_per_wg;
+  const float* fe;       // k_wgrad_h<.., XSYN>: the forward's feature-slot dump and the rays: B = the MLP input x, re-derived
+  const float* rays;
+  int32_t S;
   float* Gpart;          // deterministic mode: [workgroup][32 CAB][32 CBB] partial products, summed in workgroup order by k_wgrad_reduce
 };
 
@@ -291,7 +294,91 @@ struct HTile {   // one operand's rows [row0, row0 + 32): up to two (k-step, lan
   }
 };
 
-template <int CBB>
+// ---- B = the layer-1 input x, re-derived instead of read back (round 5) ----------------------------------------------------------------
+// x is a pure function of the 14 feature slots of a lane half and the ray's view direction (tensorBase.py:68-75: [features, viewdirs,
+// PE(features), PE(viewdirs)] in the shade kernels' K order: slot r -> columns 5 r .. 5 r + 4 = f, sin f, sin 2f, cos f, cos 2f; then the
+// eight view values of the half; then two zeros).  The training forward used to dump it as 160 halves per sample (0.67 GB written, 0.67 GB
+// read back per 8192 x 256 step) only for d(W1) = dh1^T x; the feature slots are dumped anyway (128 B per sample, the shade backward needs
+// them), so this fetch builds the same 8 halves per (k-step, lane half, sample) with the forward's own instructions (sincos_x_2x_hw,
+// round-to-nearest pack): bit-identical operands, 192 B per sample less to read and 320 B less to write.
+__device__ __forceinline__ u32x4 pack8_rn_w(const float x[8]) {
+  u32x4 o;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    typedef float f2v __attribute__((ext_vector_type(2)));
+    typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+    o[q] = __builtin_bit_cast(uint32_t, __builtin_convertvector(f2v{x[2 * q], x[2 * q + 1]}, h2v));
+  }
+  return o;
+}
+
+// One k-step (compile-time STEP) of a sample's lane half hw, in two parts so that the loads travel while the previous step multiplies:
+// x_load = the (at most three) feature slots the step's eight values come from (fe_lane = the half's slot dump, &fe[(tile * 4) * 64 + lane]
+// as floats, quad q 256 floats further on); x_make = the eight values from them and the ray's direction, packed as the forward packs them.
+constexpr int NSLOT_W = 14;
+template <int STEP>
+__device__ __forceinline__ void x_load(const float* __restrict__ fe_lane, float f[3]) {
+  constexpr int r_first = (STEP * 8) / 5;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    constexpr int dummy = 0; (void)dummy;
+    const int r = r_first + k;
+    f[k] = (r < NSLOT_W && r * 5 <= STEP * 8 + 7) ? fe_lane[(r >> 2) * 256 + (r & 3)] : 0.f;
+  }
+}
+template <int STEP>
+__device__ __forceinline__ u32x4 x_make(const float f[3], const float dir[3], int hw) {
+  constexpr int r_first = (STEP * 8) / 5;
+  float xs[8], s1[3], c1[3], s2[3], c2[3], vw[8];
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+    if (r_first + k < NSLOT_W && (r_first + k) * 5 <= STEP * 8 + 7) sincos_x_2x_hw(f[k], s1[k], c1[k], s2[k], c2[k]);
+  if (STEP >= 8) {   // the view values live in the last two steps
+    float sa0, ca0, sb0, cb0, sa1, ca1, sb1, cb1, sa2, ca2, sb2, cb2;
+    sincos_x_2x_hw(dir[0], sa0, ca0, sb0, cb0);
+    sincos_x_2x_hw(dir[1], sa1, ca1, sb1, cb1);
+    sincos_x_2x_hw(dir[2], sa2, ca2, sb2, cb2);
+    vw[0] = hw ? sb2 : dir[0]; vw[1] = hw ? ca0 : dir[1]; vw[2] = hw ? cb0 : dir[2]; vw[3] = hw ? ca1 : sa0;
+    vw[4] = hw ? cb1 : sb0; vw[5] = hw ? ca2 : sa1; vw[6] = hw ? cb2 : sb1; vw[7] = hw ? 0.f : sa2;
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int kk = STEP * 8 + e;
+    float x;
+    if (kk < 5 * NSLOT_W) {
+      const int k = kk / 5 - r_first, kind = kk % 5;
+      x = kind == 0 ? f[k] : (kind == 1 ? s1[k] : (kind == 2 ? s2[k] : (kind == 3 ? c1[k] : c2[k])));
+    } else if (kk < 5 * NSLOT_W + 8) {
+      x = vw[kk - 5 * NSLOT_W];
+    } else {
+      x = 0.f;
+    }
+    xs[e] = x;
+  }
+  return pack8_rn_w(xs);
+}
+#define EGO_X_CASES(CALL)                                                                                                        \
+  switch (s) {                                                                                                                  \
+    case 0: CALL(0); break; case 1: CALL(1); break; case 2: CALL(2); break; case 3: CALL(3); break; case 4: CALL(4); break; \
+    case 5: CALL(5); break; case 6: CALL(6); break; case 7: CALL(7); break; case 8: CALL(8); break; case 9: CALL(9); break; \
+    default: break;                                                                                                             \
+  }
+__device__ __forceinline__ void x_load_any(int s, const float* __restrict__ fe_lane, float f[3]) {
+  f[0] = f[1] = f[2] = 0.f;
+#define EGO_X_CALL(N) x_load<N>(fe_lane, f)
+  EGO_X_CASES(EGO_X_CALL)
+#undef EGO_X_CALL
+}
+__device__ __forceinline__ u32x4 x_make_any(int s, const float f[3], const float dir[3], int hw) {
+  u32x4 o = u32x4{0u, 0u, 0u, 0u};
+#define EGO_X_CALL(N) o = x_make<N>(f, dir, hw)
+  EGO_X_CASES(EGO_X_CALL)
+#undef EGO_X_CALL
+  return o;
+}
+#undef EGO_X_CASES
+
+template <int CBB, bool XSYN = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_wgrad_h(WgradArgs P) {
   __shared__ __attribute__((aligned(16))) uint8_t lds[(4 + CBB) * 32 * WG_ROW];
   uint8_t* la = lds;
@@ -306,10 +393,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const int64_t step0 = (int64_t)blockIdx.x * P.steps_per_wg;
   const int steps_b = P.cb >> 4;   // k-steps of B in memory; the tile's further steps (ones / padding columns) are fetched as zeros
   HTile ta, tb;
+  float x_f[3][3], x_dir[3];   // XSYN: the feature slots of the thread's three (k-step, half, sample) items and its ray's direction
+  bool x_in = false;
   float inv0, inv1;   // the thread's two samples' scales (rows row0 + 2 sp, + 1)
   auto fetch = [&](int64_t row0) {
     ta.fetch(P.A, 8, 1, row0, P.M);
-    tb.fetch(P.B, steps_b, 2, row0, P.M);
+    if (XSYN) {
+      // items = (k-step s = wave + 4 t, lane half hw = lane >> 5, sample row0 + (lane & 31)): the k-step is WAVE-uniform (no divergence in
+      // x_step_any's switch - the first form, with HTile's item order, executed two cases per wave and cost the step 0.15 ms)
+      const uint32_t m = (uint32_t)row0 + (uint32_t)i;
+      const bool in = (int64_t)m < P.M;
+      const float* fe_l = P.fe + ((row0 >> 5) * 4 * 64 + lane) * 4;   // this lane's slots: quad q 256 floats further on
+      const float* dir = P.rays + (int64_t)((in ? m : 0u) / (uint32_t)P.S) * 6 + 3;
+      x_in = in;
+      x_dir[0] = dir[0]; x_dir[1] = dir[1]; x_dir[2] = dir[2];
+#pragma unroll
+      for (int t = 0; t < 3; ++t) x_load_any(wave + 4 * t, fe_l, x_f[t]);   // loads only: the values are made at commit time
+    } else tb.fetch(P.B, steps_b, 2, row0, P.M);
     const int64_t r0 = row0 + 2 * (threadIdx.x & 15);
     inv0 = r0 < P.M ? P.a_scale[r0] : 0.f;
     inv1 = r0 + 1 < P.M ? P.a_scale[r0 + 1] : 0.f;
@@ -325,7 +425,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const float rinv = ref > 0.f ? 1.f / ref : 0.f;   // powers of two: exact
     const h2w ratio = h2w{(_Float16)(inv0 * rinv), (_Float16)(inv1 * rinv)};
     ta.commit<true>(8, 1, -1, __builtin_bit_cast(uint32_t, ratio), la);
-    tb.commit<false>(2 * CBB, 2, P.ones_col, 0u, lb);
+    if (XSYN) {
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        const int s = wave + 4 * t;
+        if (s >= 2 * CBB) break;
+        const u32x4 xb = x_in ? x_make_any(s, x_f[t], x_dir, kb) : u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int col = (2 * s + (e >> 2)) * 8 + kb * 4 + (e & 3);
+          uint16_t hv = (uint16_t)(xb[e >> 1] >> ((e & 1) * 16));
+          if (col == P.ones_col) hv = 0x3c00u;   // 1.0; rows beyond M meet zero rows of A
+          *(uint16_t*)(lb + col * WG_ROW + i * 2) = hv;
+        }
+      }
+    } else tb.commit<false>(2 * CBB, 2, P.ones_col, 0u, lb);
     __syncthreads();
     if (st + 1 < P.steps_per_wg) fetch(row0 + 32);   // next step's rows travel while this step multiplies
     const uint8_t* ra = la + (32 * wave + i) * WG_ROW;
@@ -383,7 +497,7 @@ inline int reduce_partials(const WgradArgs& p, unsigned n_wg, int rows, int ld, 
   return ego_launch_status("k_wgrad_reduce");
 }
 
-template <int CBB>
+template <int CBB, bool XSYN = false>
 int launch_h(const WgradArgs& a, hipStream_t st) {
   WgradArgs p = a;
   const int64_t steps = (a.M + 31) / 32;
@@ -391,7 +505,7 @@ int launch_h(const WgradArgs& a, hipStream_t st) {
   const int64_t wgs = steps < cap ? steps : cap;
   p.steps_per_wg = (int32_t)((steps + wgs - 1) / wgs);
   const unsigned n_wg = (unsigned)((steps + p.steps_per_wg - 1) / p.steps_per_wg);
-  k_wgrad_h<CBB><<<n_wg, 256, 0, st>>>(p);
+  k_wgrad_h<CBB, XSYN><<<n_wg, 256, 0, st>>>(p);
   if (int e = ego_launch_status("k_wgrad_h")) return e;
   return p.Gpart ? reduce_partials(p, n_wg, 128, 32 * CBB, st) : EGO_OK;
 }
@@ -411,6 +525,17 @@ int launch(const WgradArgs& a, hipStream_t st) {
 }  // namespace
 
 extern "C" {
+
+int ego_weight_grad_x(const void* dh1, const float* dh_scale, const float* fe, const float* rays, int32_t S, int32_t ones_col, int64_t M, float* G,
+                      int32_t ldg, float* partial, int64_t partial_floats, void* stream) {
+  EGO_TRACE("ego_weight_grad_x");
+  EGO_REQUIRE(M >= 0 && S >= 1 && ones_col < 160 && ldg >= 160, "weight_grad_x: bad size (ldg >= 160, ones_col < 160)");
+  if (M == 0) return EGO_OK;
+  EGO_REQUIRE(dh1 && dh_scale && fe && rays && G && ((uintptr_t)dh1 & 15) == 0 && ((uintptr_t)fe & 15) == 0, "weight_grad_x: null or unaligned argument");
+  EGO_REQUIRE(!partial || partial_floats >= (int64_t)1024 * 128 * 160, "weight_grad_x: partial buffer smaller than ego_weight_grad_partial_floats()");
+  WgradArgs a{(const float*)dh1, dh_scale, nullptr, G, M, 128, 128, 160, 160, ones_col, ldg, 0, fe, rays, S, partial};
+  return launch_h<5, true>(a, (hipStream_t)stream);
+}
 
 int64_t ego_weight_grad_partial_floats(void) { return (int64_t)1024 * 128 * 160; }   // workgroups x rows x padded columns, the largest product
 
@@ -439,7 +564,7 @@ int ego_weight_grad_det(const void* A, int32_t lda, int32_t ca, int32_t a_layout
   EGO_REQUIRE(ldg >= 32 * cbb, "weight_grad: ldg must cover the padded column blocks");
   EGO_REQUIRE((ldb & 3) == 0 && (cb & 3) == 0 && ((uintptr_t)B & 15) == 0, "weight_grad: B rows must be 16-byte aligned, cb a multiple of 4");
   const bool avec = (lda & 3) == 0 && (ca & 3) == 0 && ((uintptr_t)A & 15) == 0;
-  WgradArgs a{(const float*)A, a_scale, (const float*)B, G, M, lda, ca, ldb, cb, ones_col, ldg, 0, partial};
+  WgradArgs a{(const float*)A, a_scale, (const float*)B, G, M, lda, ca, ldb, cb, ones_col, ldg, 0, nullptr, nullptr, 0, partial};
   const hipStream_t st = (hipStream_t)stream;
   // instantiations: the training step's four products, their all-fp32 forms and the all-row-major forms of the same shapes
   // (the training step's four products: dh2^T h1, dh1^T x: scaled-fp16 A, fp16 B; do^T h2: ragged row-major A, fp16 B; dfe^T v: grid-routed A,

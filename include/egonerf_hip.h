@@ -262,7 +262,7 @@ int ego_march_density(const ego_scene* sc, const float* rays, int64_t N, int32_t
  * the two hidden layers (bit 16 (t & 1) + r of word t >> 1 of lane 32 h + m % 32 <=> unit 32 t + slot_row(r, h) of sample m is
  * > 0): all the shade backward needs of h1 / h2 (autograd of torch.nn.ReLU, tensorBase.py:68-71), 32 B instead of 1 KB per sample. */
 typedef struct ego_shade_dump {
-  uint16_t* x;
+  uint16_t* x;   /* optional (NULL: not written): only d(W1) reads it, and ego_weight_grad_x re-derives it from `fe` and the rays */
   uint16_t* h1;
   uint16_t* h2;
   float* v;
@@ -385,6 +385,15 @@ int ego_weight_grad(const void* A, int32_t lda, int32_t ca, int32_t a_layout, co
  * columns [0, 32 ceil(cols/32)) of G are overwritten).  ego_weight_grad adds with float atomics: its sums depend on the order the
  * hardware serves them (differences in the last bits from run to run).  partial = NULL is ego_weight_grad. */
 int64_t ego_weight_grad_partial_floats(void);
+/* d(W1) and d(b1) of the tuned head WITHOUT the x dump: G [128][ldg >= 160] = dh1^T [x | 1] where x - the MLP input of
+ * tensorBase.py:68-75 in the shade kernels' column order - is re-derived per sample from the forward's feature-slot dump
+ * (ego_shade_dump.fe) and the ray's view direction (rays [N][6], sample m belongs to ray m / S) with the forward's own instructions and
+ * rounding, i.e. the operands are bit-identical to ego_weight_grad(dh1, .., a_layout 2, x dump, b_layout 2, ones_col) and
+ * ego_shade_dump.x may be NULL in the training forward (320 B per sample less to write, 192 B less to read).  dh1 / dh_scale as
+ * ego_shade_backward writes them; ones_col = the zero-padding column that yields the bias gradient; partial as in ego_weight_grad_det
+ * (NULL = float atomics into a zeroed G). */
+int ego_weight_grad_x(const void* dh1, const float* dh_scale, const float* fe, const float* rays, int32_t S, int32_t ones_col, int64_t M, float* G,
+                      int32_t ldg, float* partial, int64_t partial_floats, void* stream);
 int ego_weight_grad_det(const void* A, int32_t lda, int32_t ca, int32_t a_layout, const float* a_scale, const void* B, int32_t ldb, int32_t cb,
                         int32_t b_layout, int32_t ones_col, int64_t M, float* G, int32_t ldg, float* partial, int64_t partial_floats,
                         void* stream);

@@ -236,3 +236,36 @@ def test_full_size_training_step_config4():
         scale = float(g.abs().max())
         assert float((g - ga0[k]).abs().max()) <= 1e-4 * scale + 1e-12, (k, float((g - ga0[k]).abs().max()) / scale)   # another summation order over 2 M samples
         assert float((ga0[k] - ga1[k]).abs().max()) <= 1e-5 * scale + 1e-12, k
+
+
+@pytest.mark.parametrize("n_voxel,N,nc,nf", [(20 ** 3, 48, 16, 16), (27e6, 1000, 45, 0)])
+def test_layer1_weight_gradient_without_the_x_dump(n_voxel, N, nc, nf):
+    """Round 5: the training forward no longer dumps the 160-column MLP input; ego_weight_grad_x re-derives it per sample from the
+    feature slots and the view direction inside the product's B-tile fetch, with the forward's own instructions and rounding.  The
+    operands are the dump's halves bit for bit, so with the ordered sums d(W1) and d(b1) - and every other gradient - must come out
+    IDENTICAL with and without the dump (EGO_TRAIN_DUMP_X).  Ragged sample counts (N * S not a multiple of 32) included."""
+    from egonerf_amd import train as ego_train
+    cfg = synth.SceneConfig(n_voxel=n_voxel)
+    w = synth.make_weights(cfg, seed=4)
+    rays = torch.from_numpy(synth.make_rays(N, seed=6)).to(DEV)
+    gt = torch.from_numpy(synth.hash_uniform(13, 0, N * 3).reshape(N, 3).astype(np.float32)).to(DEV)
+    jit = torch.from_numpy(synth.hash_uniform(13, 1, N * nc).reshape(N, nc).astype(np.float32)).to(DEV)
+    u = torch.from_numpy(synth.hash_uniform(13, 2, N * max(nf, 1)).reshape(N, max(nf, 1)).astype(np.float32)).to(DEV) if nf else None
+    out = {}
+    keep = ego_train.DUMP_X
+    try:
+        for dump_x in (True, False):
+            ego_train.DUMP_X = dump_x
+            model = make_model(cfg, w, DEV)
+            model.train()
+            kw = dict(is_train=True, n_coarse=nc, exp_sampling=True, jitter=jit)
+            if nf:
+                kw.update(n_fine=nf, resampling=True, use_coarse_sample=True, u=u)
+            rgb, *_ = model(rays, **kw)
+            torch.mean((rgb - gt) ** 2).backward()
+            out[dump_x] = {k: p.grad.detach().clone() for k, p in model.named_parameters()}
+    finally:
+        ego_train.DUMP_X = keep
+    assert float(out[False]["renderModule.mlp.0.weight"].abs().max()) > 0 and float(out[False]["renderModule.mlp.0.bias"].abs().max()) > 0
+    for k in out[True]:
+        assert torch.equal(out[True][k], out[False][k]), (k, float((out[True][k] - out[False][k]).abs().max()))
