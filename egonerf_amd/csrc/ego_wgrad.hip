@@ -395,6 +395,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   HTile ta, tb;
   float x_f[3][3], x_dir[3];   // XSYN: the feature slots of the thread's three (k-step, half, sample) items and its ray's direction
   bool x_in = false;
+  u32x4 xb[3];                 // ... and the items themselves, made from them behind the previous step's MFMAs (off the barrier chain)
+  auto make_x = [&]() {
+#pragma unroll
+    for (int t = 0; t < 3; ++t) xb[t] = x_in ? x_make_any(wave + 4 * t, x_f[t], x_dir, kb) : u32x4{0u, 0u, 0u, 0u};
+  };
   float inv0, inv1;   // the thread's two samples' scales (rows row0 + 2 sp, + 1)
   auto fetch = [&](int64_t row0) {
     ta.fetch(P.A, 8, 1, row0, P.M);
@@ -415,6 +420,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     inv1 = r0 + 1 < P.M ? P.a_scale[r0 + 1] : 0.f;
   };
   fetch(step0 * 32);
+  if (XSYN) make_x();
   for (int st = 0; st < P.steps_per_wg; ++st) {
     const int64_t row0 = (step0 + st) * 32;
     if (row0 >= P.M) break;  // uniform over the workgroup
@@ -430,11 +436,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       for (int t = 0; t < 3; ++t) {
         const int s = wave + 4 * t;
         if (s >= 2 * CBB) break;
-        const u32x4 xb = x_in ? x_make_any(s, x_f[t], x_dir, kb) : u32x4{0u, 0u, 0u, 0u};
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const int col = (2 * s + (e >> 2)) * 8 + kb * 4 + (e & 3);
-          uint16_t hv = (uint16_t)(xb[e >> 1] >> ((e & 1) * 16));
+          uint16_t hv = (uint16_t)(xb[t][e >> 1] >> ((e & 1) * 16));
           if (col == P.ones_col) hv = 0x3c00u;   // 1.0; rows beyond M meet zero rows of A
           *(uint16_t*)(lb + col * WG_ROW + i * 2) = hv;
         }
@@ -455,6 +460,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[nt][r] = fmaf(ref, t[r], acc[nt][r]);
     }
+    if (XSYN && st + 1 < P.steps_per_wg) make_x();   // the next step's items, while this step's MFMAs drain
     __syncthreads();
   }
 #pragma unroll
