@@ -408,7 +408,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       // x_step_any's switch - the first form, with HTile's item order, executed two cases per wave and cost the step 0.15 ms)
       const uint32_t m = (uint32_t)row0 + (uint32_t)i;
       const bool in = (int64_t)m < P.M;
-      const float* fe_l = P.fe + ((row0 >> 5) * 4 * 64 + lane) * 4;   // this lane's slots: quad q 256 floats further on
+      // (the prefetch of a workgroup's last step may name a tile behind the last one: clamped, its rows are `!in` and never used)
+      const int64_t tile = (row0 < P.M ? row0 : P.M - 1) >> 5;
+      const float* fe_l = P.fe + (tile * 4 * 64 + lane) * 4;   // this lane's slots: quad q 256 floats further on
       const float* dir = P.rays + (int64_t)((in ? m : 0u) / (uint32_t)P.S) * 6 + 3;
       x_in = in;
       x_dir[0] = dir[0]; x_dir[1] = dir[1]; x_dir[2] = dir[2];

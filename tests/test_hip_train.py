@@ -238,7 +238,7 @@ def test_full_size_training_step_config4():
         assert float((ga0[k] - ga1[k]).abs().max()) <= 1e-5 * scale + 1e-12, k
 
 
-@pytest.mark.parametrize("n_voxel,N,nc,nf", [(20 ** 3, 48, 16, 16), (27e6, 1000, 45, 0)])
+@pytest.mark.parametrize("n_voxel,N,nc,nf", [(20 ** 3, 48, 16, 16), (27e6, 1000, 45, 0), (27e6, 1001, 45, 0)])   # 1001: the last workgroup's prefetch names a tile behind the last
 def test_layer1_weight_gradient_without_the_x_dump(n_voxel, N, nc, nf):
     """Round 5: the training forward no longer dumps the 160-column MLP input; ego_weight_grad_x re-derives it per sample from the
     feature slots and the view direction inside the product's B-tile fetch, with the forward's own instructions and rounding.  The
