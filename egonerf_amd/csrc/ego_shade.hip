@@ -1112,10 +1112,15 @@ __device__ __forceinline__ void team_to_halves(const float ga[12], const float g
 
 // (v as halves - 0.6 GB less per step each way, forward -0.12 ms - puts the basis gradient of the 1.5 k-sample golden at 2.3e-4 of its
 // largest element against the 2e-4 it is held to: v stays fp32)
+// All dump stores of the training forward and backward are NONTEMPORAL (`global_store ... nt`): 2.6 GB per launch that nobody reads before the
+// whole pass is over.  Measured (round 5, timing-only builds, one box): forward without its dump stores 0.49 ms, with them 0.94, with the
+// stores aimed at a per-wave 40 KB region (no HBM traffic at all) 0.74 - the write path into the XCD's L2 (~17 B / clk / CU, half the read
+// rate), not HBM and not the order of loads and stores in the vmcnt queue (moving the stores behind the next loads: +-0), is what a dumping
+// wave waits for; nt stores take the forward to 0.79-0.82 ms.
 __device__ __forceinline__ void dump24(float* dst, const float* v) {
   if (dst) {
 #pragma unroll
-    for (int q = 0; q < 6; ++q) ((f32x4*)dst)[64 * q] = f32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};  // quad pairs 256 floats apart
+    for (int q = 0; q < 6; ++q) __builtin_nontemporal_store(f32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]}, &((f32x4*)dst)[64 * q]);  // quad pairs 256 floats apart
   }
 }
 
@@ -1466,7 +1471,7 @@ __global__ __launch_bounds__(512) void k_shade_h(ShadeArgs A) {
     }
     if (DUMP && valid) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) ((f32x4*)A.dump_fe)[(tile * 4 + q) * 64 + lane] = f32x4{fe[4 * q], fe[4 * q + 1], fe[4 * q + 2], fe[4 * q + 3]};
+      for (int q = 0; q < 4; ++q) __builtin_nontemporal_store(f32x4{fe[4 * q], fe[4 * q + 1], fe[4 * q + 2], fe[4 * q + 3]}, &((f32x4*)A.dump_fe)[(tile * 4 + q) * 64 + lane]);
     }
     float vw[8];
     {
@@ -1613,7 +1618,7 @@ __global__ __launch_bounds__(512) void k_shade_h(ShadeArgs A) {
           const int step = kk >> 3;
           const HL b = split8(xs, true);
           // [tile][k-step][lane][8 halves]; optional (r05): ego_weight_grad_x re-derives x from the feature slots and the view direction
-          if (DUMP && valid && A.dump_x) ((u32x4*)A.dump_x)[(tile * KH1 + step) * 64 + lane] = pack8_rn(xs);
+          if (DUMP && valid && A.dump_x) __builtin_nontemporal_store(pack8_rn(xs), &((u32x4*)A.dump_x)[(tile * KH1 + step) * 64 + lane]);
 #pragma unroll
           for (int mt = 0; mt < 4; ++mt) { ah[mt] = nh[mt]; al[mt] = nl[mt]; }
           if (step + 1 < KH1) {
@@ -1642,10 +1647,10 @@ __global__ __launch_bounds__(512) void k_shade_h(ShadeArgs A) {
         float v8[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) v8[e] = H[st >> 1][8 * (st & 1) + e];
-        ((u32x4*)A.dump_h1)[(tile * KH2 + st) * 64 + lane] = pack8_rn(v8);
+        __builtin_nontemporal_store(pack8_rn(v8), &((u32x4*)A.dump_h1)[(tile * KH2 + st) * 64 + lane]);
       }
       // the ReLU masks as bits: what the shade backward needs of h1 / h2 (it would otherwise re-read both dumps, 1 KB per sample)
-      ((u32x2*)A.dump_bits)[(tile * 2 + 0) * 64 + lane] = relu_bits(H);
+      __builtin_nontemporal_store(relu_bits(H), &((u32x2*)A.dump_bits)[(tile * 2 + 0) * 64 + lane]);
     }
 
     // ---- layer 2 (8 steps), layer 3 on the VALU ----------------------------------------------------------------
@@ -1752,9 +1757,9 @@ __global__ __launch_bounds__(512) void k_shade_h(ShadeArgs A) {
         float v8[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) v8[e] = relu_f(G[st >> 1][8 * (st & 1) + e]);
-        ((u32x4*)A.dump_h2)[(tile * KH2 + st) * 64 + lane] = pack8_rn(v8);
+        __builtin_nontemporal_store(pack8_rn(v8), &((u32x4*)A.dump_h2)[(tile * KH2 + st) * 64 + lane]);
       }
-      ((u32x2*)A.dump_bits)[(tile * 2 + 1) * 64 + lane] = relu_bits(G);
+      __builtin_nontemporal_store(relu_bits(G), &((u32x2*)A.dump_bits)[(tile * 2 + 1) * 64 + lane]);
     }
     float o0 = 0.f, o1 = 0.f, o2 = 0.f;
 #pragma unroll
