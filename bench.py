@@ -66,7 +66,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--config", choices=["render", "train", "erp"], default="render")
+    ap.add_argument("--config", choices=["render", "train", "erp", "metrics"], default="render")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="render: skip the short train / erp runs that the default line carries as `secondary`")
     ap.add_argument("--cpu-rays", type=int, default=1024, help="rays in the single-process CPU-baseline sample")
@@ -91,7 +91,7 @@ def parse():
                     "every shipped config uses, configs/EgoNeRF/common.txt:15-23); N_FINE > 0 = inverse-CDF resampling, coarse samples kept")
     ap.add_argument("--cpu-worker", nargs=2, type=int, metavar=("N_RAYS", "THREADS"), help=argparse.SUPPRESS)
     a = ap.parse_args()
-    dflt = dict(render=(200, 10), train=(20, 3), erp=(4, 1))[a.config]  # render: 0.7 ms steps, amortise the barrier bracket
+    dflt = dict(render=(200, 10), train=(20, 3), erp=(4, 1), metrics=(10, 2))[a.config]  # render: 0.7 ms steps, amortise the barrier bracket
     a.steps = dflt[0] if a.steps is None else a.steps
     a.warmup = dflt[1] if a.warmup is None else a.warmup
     return a
@@ -763,6 +763,67 @@ def run_render_shape(a, rk: Ranks):
                 roofline=roofline, cpu_baseline=cpu, parity=parity, speedup_vs_cpu=None if cpu is None else rays_per_s / cpu["value"])
 
 
+def run_eval_metrics(a, rk: Ranks):
+    """SURVEY 8(f) row 1 on the measurement bar of the other rows: the evaluation metrics of renderer.py:153-163 on a device-resident
+    1024 x 2048 equirectangular image pair - PSNR (renderer.py:156-157), rgb_ssim (utils.py:104-152) with its latitude-weighted variant
+    (extra/ws_ssim.py:12-33) and WS-PSNR.  A step = all four numbers of one image, as `evaluation` asks for them (each returns a host float).
+    Dominant kernel = k_rgb_ssim (`ego_rgb_ssim`); HBM roofline on its algorithmic bytes (both images read once, the map written once)."""
+    from egonerf_amd import metrics
+    dev = rk.dev
+    H, W = (int(v) for v in (a.erp_size or [1024, 2048]))
+    img = torch.from_numpy(synth.hash_uniform(21, 0, H * W * 3).reshape(H, W, 3).astype(np.float32)).to(dev)
+    noise = torch.from_numpy(synth.hash_uniform(21, 1, H * W * 3).reshape(H, W, 3).astype(np.float32)).to(dev)
+    gt = (img + (noise - 0.5) * 0.11).clamp(0, 1)   # ~30 dB
+    out = {}
+
+    def step():
+        out["psnr"] = metrics.psnr(img, gt)
+        out["ssim"], out["ws_ssim"] = metrics.ws_ssim(img, gt, 1.0)
+        out["ws_psnr"] = metrics.ws_psnr(img, gt, 1.0)
+
+    dt = timed(rk, step, a.steps, a.warmup)
+    spread = rk.rank_step_ms(a.steps)
+    if rk.rank != 0:
+        return None
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(12)]
+    for i in range(14):
+        e = evs[max(i - 2, 0)]
+        e[0].record()
+        metrics.rgb_ssim(img, gt, 1.0, return_map=True)
+        e[1].record()
+    torch.cuda.synchronize()
+    t_ssim = float(np.mean([e0.elapsed_time(e1) for e0, e1 in evs])) * 1e-3
+    Ho, Wo = H - 10, W - 10
+    alg = 2 * H * W * 3 * 4 + Ho * Wo * 3 * 4
+    roofline = dict(bound="hbm", kernel="k_rgb_ssim", unit="GB/s", achieved=alg / t_ssim / 1e9, peak=HBM_PEAK_GBPS, frac=alg / t_ssim / 1e9 / HBM_PEAK_GBPS,
+                    traffic=None, ms=t_ssim * 1e3, algorithmic_bytes=alg,
+                    note="event-timed ego_rgb_ssim with the map returned (the form ws_ssim uses, incl. the map's allocation); separable 11-tap 'valid' "
+                         "Gaussian windows over five moment images in float64 like the reference (~145 fp64 multiply-adds per output value through "
+                         "LDS): bound by that arithmetic, not by the 75 MB it moves - the fraction is stated against HBM all the same")
+    cpu = parity = None
+    if not a.no_cpu_baseline and rk.world == 1:
+        from oracle.egonerf_oracle import rgb_ssim as ref_ssim, psnr as ref_psnr
+        hc, wc = H, W   # the whole image: ~1 s of one core
+        ac, bc = img[:hc, :wc].cpu(), gt[:hc, :wc].cpu()
+        t0 = time.perf_counter()
+        s_ref = float(ref_ssim(ac.numpy(), bc.numpy(), 1))
+        p_ref = float(ref_psnr(ac, bc))
+        t_cpu = time.perf_counter() - t0
+        s_hip = metrics.rgb_ssim(img[:hc, :wc].contiguous(), gt[:hc, :wc].contiguous(), 1.0)
+        p_hip = metrics.psnr(img[:hc, :wc], gt[:hc, :wc])
+        parity = dict(abs_ssim_err=abs(s_hip - s_ref), abs_psnr_err_db=abs(p_hip - p_ref), ssim_ref=s_ref, psnr_ref_db=p_ref, crop=[hc, wc],
+                      tolerance=dict(ssim=1e-9, psnr_db=1e-3))
+        cpu = dict(value=hc * wc / t_cpu / 1e6, unit="Mpixel/s", cores=1, kind="port",
+                   sample=f"oracle rgb_ssim (scipy convolve2d, as utils.py:104-152) + PSNR of the {hc} x {wc} image: {t_cpu:.2f} s on one core")
+    mpix = rk.world * H * W * a.steps / dt / 1e6
+    return dict(metric=f"evaluation metrics (PSNR, SSIM, WS-PSNR, WS-SSIM) of one {H} x {W} image on the device", value=mpix, unit="Mpixel/s",
+                n_gpus=rk.world, steps=a.steps, warmup=a.warmup, clock_ramp_s=RAMP_SECONDS, ms_per_step=dt / a.steps * 1e3, rank_step_ms=spread,
+                higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32 images, f64 sums", data="synthetic",
+                config=dict(workload=f"{H} x {W} x 3 equirectangular image pair (~30 dB apart), renderer.py:153-163 + extra/ws_ssim.py", parallelism=f"replicas x{rk.world}"),
+                values={k: float(v) for k, v in out.items()}, roofline=roofline, cpu_baseline=cpu, parity=parity,
+                speedup_vs_cpu=None if cpu is None else mpix / cpu["value"])
+
+
 # =====================================================================================================
 # --config train (BASELINE configs[3])
 # =====================================================================================================
@@ -1217,7 +1278,8 @@ def run_secondary(a, rk: Ranks):
             ("erp_masked", run_erp, sub(config="erp", steps=2, warmup=1, views=2, erp_size=[1024, 2048], mask=True, carve=True, term_eps=0.0,
                                         density_shift=None)),
             ("erp_opaque_field", run_erp, sub(config="erp", steps=2, warmup=1, views=2, erp_size=[1024, 2048], mask=False, term_eps=0.0,
-                                              density_shift=0.0, carve=False)))   # with its own parity leg + cpu_baseline
+                                              density_shift=0.0, carve=False)),   # with its own parity leg + cpu_baseline
+            ("eval_metrics_1024x2048", run_eval_metrics, sub(config="metrics", steps=10, warmup=2, erp_size=[1024, 2048])))
     for name, fn, args in jobs:
         t0 = time.perf_counter()
         try:
@@ -1278,7 +1340,7 @@ def _brief_cpu(cb):
 def _brief_parity(p):
     if not isinstance(p, dict):
         return None
-    return {k: p[k] for k in ("max_abs_rgb_err", "delta_psnr_db", "psnr_hip_vs_gt_db", "psnr_ref_vs_gt_db", "max_abs_depth_err", "rays", "tolerance") if k in p}
+    return {k: p[k] for k in ("max_abs_rgb_err", "delta_psnr_db", "psnr_hip_vs_gt_db", "psnr_ref_vs_gt_db", "max_abs_depth_err", "abs_ssim_err", "abs_psnr_err_db", "rays", "tolerance") if k in p}
 
 
 def compact_line(full: dict, full_paths=()) -> dict:
@@ -1311,7 +1373,7 @@ def compact_line(full: dict, full_paths=()) -> dict:
             if isinstance(ln.get("cpu_baseline"), dict):
                 b["cpu_baseline"] = dict(value=ln["cpu_baseline"].get("value"), cores=ln["cpu_baseline"].get("cores"), kind=ln["cpu_baseline"].get("kind"))
             if isinstance(ln.get("parity"), dict):
-                b["parity"] = {k: ln["parity"][k] for k in ("max_abs_rgb_err", "delta_psnr_db") if k in ln["parity"]}
+                b["parity"] = {k: ln["parity"][k] for k in ("max_abs_rgb_err", "delta_psnr_db", "abs_ssim_err", "abs_psnr_err_db") if k in ln["parity"]}
             brief[name] = b
         out["secondary"] = brief
     out["full_record"] = [os.path.relpath(p, REPO) if p.startswith(REPO) else p for p in full_paths]
@@ -1350,7 +1412,7 @@ def main():
     rk = Ranks(a)
     variant = a.config == "render" and (a.n_voxel or a.fresh_rays or a.shape)
     line = (run_render_shape if (a.config == "render" and a.shape) else run_render_variant if variant
-            else dict(render=run_render, train=run_train, erp=run_erp)[a.config])(a, rk)
+            else dict(render=run_render, train=run_train, erp=run_erp, metrics=run_eval_metrics)[a.config])(a, rk)
     if a.config == "render" and not variant and rk.world == 1 and not a.no_secondary and a.density_shift is None:
         line["secondary"] = run_secondary(a, rk)
     if rk.rank == 0:

@@ -17,11 +17,15 @@ struct SsimArgs {
   float* map;       // [(H-fs+1)][(W-fs+1)][3] or null
 };
 
-// one 16x16-pixel output tile per workgroup; both input tiles staged in LDS; the separable Gaussian is applied as its
-// outer product in double (the reference filters in float64 over float32 images and float32 squares/products)
+// one 16x16-pixel output tile per workgroup; both input tiles staged in LDS.  The Gaussian window is separable and the reference applies
+// it that way (rows, then columns, in float64 over float32 images and float32 squares / products): per channel the five row-filtered
+// moment images of the tile go to LDS once ((16 + fs - 1) x 16 values each) and every output takes its column sums from there - the same
+// additions in the same order as filtering each output's own fs x fs window (the round-3 form: 5 x 121 + 55 float64 multiply-adds per
+// output instead of 5 x (11 x 26 / 16 + 11)), so the map is bit-identical to it.
 __global__ __launch_bounds__(256) void k_rgb_ssim(SsimArgs A) {
   constexpr int TIN = SSIM_TILE + SSIM_MAX_FS - 1;
   __shared__ float t0[TIN * TIN * 3], t1[TIN * TIN * 3];
+  __shared__ double hrow[5][TIN][SSIM_TILE];
   __shared__ double red[256];
   const int Ho = A.H - A.fs + 1, Wo = A.W - A.fs + 1;
   const int y0 = blockIdx.y * SSIM_TILE, x0 = blockIdx.x * SSIM_TILE;
@@ -36,31 +40,39 @@ __global__ __launch_bounds__(256) void k_rgb_ssim(SsimArgs A) {
   }
   __syncthreads();
   double part = 0.0;
-  for (int o = threadIdx.x; o < SSIM_TILE * SSIM_TILE * 3; o += 256) {
-    const int c = o % 3, px = (o / 3) % SSIM_TILE, py = o / (3 * SSIM_TILE);
-    if (y0 + py >= Ho || x0 + px >= Wo) continue;
-    double mu0 = 0, mu1 = 0, s00 = 0, s11 = 0, s01 = 0;
-    for (int dy = 0; dy < A.fs; ++dy) {
+  const int opy = threadIdx.x / SSIM_TILE, opx = threadIdx.x % SSIM_TILE;   // the thread's output pixel of the tile
+  for (int c = 0; c < 3; ++c) {
+    for (int e = threadIdx.x; e < tin * SSIM_TILE; e += 256) {   // rows: (input row py, output column px)
+      const int py = e / SSIM_TILE, px = e % SSIM_TILE;
       double r0 = 0, r1 = 0, r00 = 0, r11 = 0, r01 = 0;
       for (int dx = 0; dx < A.fs; ++dx) {
-        const int e = ((py + dy) * tin + (px + dx)) * 3 + c;
-        const float a = t0[e], b = t1[e];
+        const int i = (py * tin + (px + dx)) * 3 + c;
+        const float a = t0[i], b = t1[i];
         const double w = A.filt[dx];
         r0 += w * (double)a; r1 += w * (double)b;
         r00 += w * (double)__fmul_rn(a, a); r11 += w * (double)__fmul_rn(b, b); r01 += w * (double)__fmul_rn(a, b);
       }
-      const double w = A.filt[dy];
-      mu0 += w * r0; mu1 += w * r1; s00 += w * r00; s11 += w * r11; s01 += w * r01;
+      hrow[0][py][px] = r0; hrow[1][py][px] = r1; hrow[2][py][px] = r00; hrow[3][py][px] = r11; hrow[4][py][px] = r01;
     }
-    const double mu00 = mu0 * mu0, mu11 = mu1 * mu1, mu01 = mu0 * mu1;
-    double sg00 = s00 - mu00, sg11 = s11 - mu11, sg01 = s01 - mu01;
-    sg00 = sg00 > 0.0 ? sg00 : 0.0;
-    sg11 = sg11 > 0.0 ? sg11 : 0.0;
-    const double lim = sqrt(sg00 * sg11), mag = fabs(sg01) < lim ? fabs(sg01) : lim;
-    sg01 = sg01 > 0.0 ? mag : (sg01 < 0.0 ? -mag : 0.0);
-    const double v = ((2.0 * mu01 + A.c1) * (2.0 * sg01 + A.c2)) / ((mu00 + mu11 + A.c1) * (sg00 + sg11 + A.c2));
-    part += v;
-    if (A.map) A.map[((int64_t)(y0 + py) * Wo + (x0 + px)) * 3 + c] = (float)v;
+    __syncthreads();
+    if (y0 + opy < Ho && x0 + opx < Wo) {   // columns
+      double mu0 = 0, mu1 = 0, s00 = 0, s11 = 0, s01 = 0;
+      for (int dy = 0; dy < A.fs; ++dy) {
+        const double w = A.filt[dy];
+        mu0 += w * hrow[0][opy + dy][opx]; mu1 += w * hrow[1][opy + dy][opx];
+        s00 += w * hrow[2][opy + dy][opx]; s11 += w * hrow[3][opy + dy][opx]; s01 += w * hrow[4][opy + dy][opx];
+      }
+      const double mu00 = mu0 * mu0, mu11 = mu1 * mu1, mu01 = mu0 * mu1;
+      double sg00 = s00 - mu00, sg11 = s11 - mu11, sg01 = s01 - mu01;
+      sg00 = sg00 > 0.0 ? sg00 : 0.0;
+      sg11 = sg11 > 0.0 ? sg11 : 0.0;
+      const double lim = sqrt(sg00 * sg11), mag = fabs(sg01) < lim ? fabs(sg01) : lim;
+      sg01 = sg01 > 0.0 ? mag : (sg01 < 0.0 ? -mag : 0.0);
+      const double v = ((2.0 * mu01 + A.c1) * (2.0 * sg01 + A.c2)) / ((mu00 + mu11 + A.c1) * (sg00 + sg11 + A.c2));
+      part += v;
+      if (A.map) A.map[((int64_t)(y0 + opy) * Wo + (x0 + opx)) * 3 + c] = (float)v;
+    }
+    __syncthreads();   // the next channel overwrites the row sums
   }
   red[threadIdx.x] = part;
   __syncthreads();

@@ -192,6 +192,12 @@ def test_bench_default_line_contract():
     assert abs(d["parity"]["delta_psnr_db"]) <= 1e-3 and 28 < d["parity"]["psnr_ref_vs_gt_db"] < 36    # north_star's PSNR clause in the line itself
     assert d["_compact"]["parity"]["delta_psnr_db"] == pytest.approx(d["parity"]["delta_psnr_db"], rel=1e-4, abs=1e-9)
     assert set(d["_compact"]["secondary"]) == set(d["secondary"])
+    # SURVEY 8(f) row 1 on the same bar: the evaluation metrics of one 1024 x 2048 image, with parity and a CPU baseline of their own
+    em = d["secondary"]["eval_metrics_1024x2048"]
+    assert "error" not in em, em.get("error")
+    assert em["unit"] == "Mpixel/s" and em["value"] > 0 and em["roofline"]["bound"] == "hbm" and 0 < em["roofline"]["frac"] < 1.0
+    assert em["parity"]["abs_ssim_err"] <= 1e-9 and em["parity"]["abs_psnr_err_db"] <= 1e-3 and 28 < em["values"]["psnr"] < 32
+    assert 0 < em["values"]["ws_ssim"] < 1 and em["cpu_baseline"]["kind"] == "port" and em["cpu_baseline"]["value"] > 0
     # BASELINE configs[2] as written: occupancy-grid empty-space skipping ON (mask-off and mask-on on the same carved field)
     masked = d["secondary"]["erp_masked"]
     assert "error" not in masked, masked.get("error")
