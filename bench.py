@@ -397,9 +397,9 @@ def run_render(a, rk: Ranks):
     crd = torch.empty(N_RAYS, N_SAMPLES, 4, device=dev)
     rgb_map, depth = torch.empty(N_RAYS, 3, device=dev), torch.empty(N_RAYS, device=dev)
     reps = max(min(a.steps, 200), 5)
-    # EGO_RENDER_FOLD=1: ego_render_forward shades and composites in one launch where it can (tuned shape, fp32 tables, split-precision
-    # arithmetic, S a multiple of 32); then the shade figure below is that kernel's (default: two launches, 0.25 % faster)
-    folded = model.mlp_precision != "f32" and N_SAMPLES % 32 == 0 and bool(os.environ.get("EGO_RENDER_FOLD"))
+    # ego_render_forward shades and composites in one launch where the scene allows it and whole rays divide evenly over the kernel's waves
+    # (ego_render_forward_folds; EGO_RENDER_FOLD=0 keeps two launches); then the shade figure below is that kernel's (compositing included)
+    folded = bool(lib.ego_render_forward_folds(sc, N_RAYS, N_SAMPLES))
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(reps)]
     for i in range(reps + 2):
         e = ev[max(i - 2, 0)]
@@ -623,9 +623,9 @@ def run_render_variant(a, rk: Ranks):
     crd = torch.empty(N_RAYS, N_SAMPLES, 4, device=dev)
     rgb_map, depth = torch.empty(N_RAYS, 3, device=dev), torch.empty(N_RAYS, device=dev)
     reps = max(min(a.steps, 128), B, 8)
-    # EGO_RENDER_FOLD=1: ego_render_forward shades and composites in one launch where it can (tuned shape, fp32 tables, split-precision
-    # arithmetic, S a multiple of 32); then the shade figure below is that kernel's (default: two launches, 0.25 % faster)
-    folded = model.mlp_precision != "f32" and N_SAMPLES % 32 == 0 and bool(os.environ.get("EGO_RENDER_FOLD"))
+    # ego_render_forward shades and composites in one launch where the scene allows it and whole rays divide evenly over the kernel's waves
+    # (ego_render_forward_folds; EGO_RENDER_FOLD=0 keeps two launches); then the shade figure below is that kernel's (compositing included)
+    folded = bool(lib.ego_render_forward_folds(sc, N_RAYS, N_SAMPLES))
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(reps)]
     for i in range(reps + 2):
         e, rays = ev[max(i - 2, 0)], batches[i % B]
@@ -1091,6 +1091,7 @@ def erp_chunk_split(model, rays_c, reps: int = 12, ERP_NC: int = None, ERP_NF: i
     rgb_map, depth, bgm, envm = f(N, 3), f(N), f(N, 3), f(N, 3)
     near = float(model.near_far[0])
     names = ("k_march_density(coarse)", "k_sample_pdf_merge", "k_march_density(fine)", "k_shade", "k_composite")
+    folded = bool(lib.ego_render_forward_folds(sc, N, S))
     evs = [[torch.cuda.Event(enable_timing=True) for _ in range(6)] for _ in range(reps)]
     for i in range(reps + 2):
         e = evs[max(i - 2, 0)]
@@ -1103,10 +1104,15 @@ def erp_chunk_split(model, rays_c, reps: int = 12, ERP_NC: int = None, ERP_NF: i
         _lib.check(lib.ego_march_density(sc, rays_c.data_ptr(), N, S, z.data_ptr(), None, None, near, 2, None, None, 0, w.data_ptr(), bg.data_ptr(),
                                          crd.data_ptr(), None, act.data_ptr(), st), "march fine")
         e[3].record()
-        _lib.check(lib.ego_shade(sc, rays_c.data_ptr(), z.data_ptr(), crd.data_ptr(), N, S, rgb.data_ptr(), None, act.data_ptr(), st), "shade")
-        e[4].record()
-        _lib.check(lib.ego_composite(sc, rays_c.data_ptr(), z.data_ptr(), w.data_ptr(), bg.data_ptr(), rgb.data_ptr(), N, S, rgb_map.data_ptr(),
-                                     depth.data_ptr(), bgm.data_ptr(), envm.data_ptr(), None, st), "composite")
+        if folded:   # what ego_render_forward launches here: shading with the compositing in its epilogue ("k_composite" then times nothing)
+            _lib.check(lib.ego_shade_composite(sc, rays_c.data_ptr(), z.data_ptr(), crd.data_ptr(), w.data_ptr(), bg.data_ptr(), N, S, act.data_ptr(),
+                                               rgb_map.data_ptr(), depth.data_ptr(), bgm.data_ptr(), envm.data_ptr(), st), "shade_composite")
+            e[4].record()
+        else:
+            _lib.check(lib.ego_shade(sc, rays_c.data_ptr(), z.data_ptr(), crd.data_ptr(), N, S, rgb.data_ptr(), None, act.data_ptr(), st), "shade")
+            e[4].record()
+            _lib.check(lib.ego_composite(sc, rays_c.data_ptr(), z.data_ptr(), w.data_ptr(), bg.data_ptr(), rgb.data_ptr(), N, S, rgb_map.data_ptr(),
+                                         depth.data_ptr(), bgm.data_ptr(), envm.data_ptr(), None, st), "composite")
         e[5].record()
     torch.cuda.synchronize()
     ms = np.array([[e[k].elapsed_time(e[k + 1]) for k in range(5)] for e in evs]).mean(0)

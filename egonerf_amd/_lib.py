@@ -73,7 +73,7 @@ SP = C.POINTER(Scene)
 # The EGO_ABI_VERSION (include/egonerf_hip.h) the PROTOTYPES below were written against.  load() refuses a library that reports
 # another one: a stale libegonerf_hip.so can keep every struct size and still disagree on an argument list (ABI 5 -> 7 inserted
 # `normalize` before ego_erp_rays' output pointer), which ctypes would pass through as a wild pointer.
-EXPECTED_ABI_VERSION = 13
+EXPECTED_ABI_VERSION = 14
 
 # name -> (restype, argtypes); mirrors include/egonerf_hip.h one to one
 PROTOTYPES = {
@@ -107,6 +107,7 @@ PROTOTYPES = {
     "ego_alpha_mask_sample": (C.c_int, [SP, P, I64, P, P]),
     "ego_composite": (C.c_int, [SP, P, P, P, P, P, I64, I32, P, P, P, P, P, P]),
     "ego_shade_composite": (C.c_int, [SP, P, P, P, P, P, I64, I32, P, P, P, P, P, P]),
+    "ego_render_forward_folds": (C.c_int32, [SP, I64, I32]),
     "ego_train_packed_floats": (I64, []),
     "ego_pack_train": (C.c_int, [SP, P, P]),
     "ego_train_layout": (C.c_int, [I32, C.POINTER(C.c_int32), I32]),

@@ -25,6 +25,7 @@ inline int ego_fail(int code, const char* fmt, ...) {
 
 // csrc/ego_shade.hip: can ego_shade_composite serve this scene and sample count? (asked by ego_render_forward)
 bool ego_can_fold_composite(const ego_scene* sc, int32_t S);
+bool ego_fold_is_balanced(int64_t N, int32_t S);
 
 inline int ego_launch_status(const char* kernel) {
   const hipError_t e = hipGetLastError();

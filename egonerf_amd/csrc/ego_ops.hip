@@ -627,24 +627,33 @@ __global__ void k_composite(const float* __restrict__ em, int em_h, const float*
                             const float* __restrict__ bgw, const float* __restrict__ rgb, int64_t N, int S,
                             float* __restrict__ rgb_map, float* __restrict__ depth, float* __restrict__ bg_map,
                             float* __restrict__ env_map, float* __restrict__ rgb_raw, float shade_above) {
-  const int lane = threadIdx.x & 63;
+  const int lane = threadIdx.x & 63, j = lane & 31, half = lane >> 5;
   const int64_t ray = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (ray >= N) return;
+  // Summation order = the folded shade kernel's (ego_shade_composite, csrc/ego_shade.hip): lane j of a half adds samples j, j + 32, j + 64,
+  // ... in that order (separately rounded products), then the 32 lanes of the half are added as a balanced tree.  The two forms of
+  // ego_render_forward therefore return the same bits, and a batch renders identically whichever form its size selects.  Half 0 sums
+  // the colours, half 1 the depth; both sum the weights.
   float acc = 0.f, cr = 0.f, cg = 0.f, cb = 0.f, dp = 0.f;
-  for (int s = lane; s < S; s += 64) {
+  for (int s = j; s < S; s += 32) {
     const int64_t o = ray * S + s;
     const float w = weight[o];
     acc += w;
-    dp += w * z[o];
-    // colour only from samples above the threshold (tensorBase.py:482-487; 0 without one: weights are >= 0, and tiles
-    // skipped by ego_shade — mask / early termination / all below the threshold — never wrote their rgb)
-    if (w > shade_above) {
+    if (half) {
+      dp += w * z[o];
+    } else if (w > shade_above) {
+      // colour only from samples above the threshold (tensorBase.py:482-487; 0 without one: weights are >= 0, and tiles
+      // skipped by ego_shade - mask / early termination / all below the threshold - never wrote their rgb)
       cr += w * rgb[o * 3];
       cg += w * rgb[o * 3 + 1];
       cb += w * rgb[o * 3 + 2];
     }
   }
-  acc = wave_sum(acc); cr = wave_sum(cr); cg = wave_sum(cg); cb = wave_sum(cb); dp = wave_sum(dp);
+#pragma unroll
+  for (int d = 1; d <= 16; d <<= 1) {
+    acc += __shfl_xor(acc, d, 64); cr += __shfl_xor(cr, d, 64); cg += __shfl_xor(cg, d, 64); cb += __shfl_xor(cb, d, 64); dp += __shfl_xor(dp, d, 64);
+  }
+  dp = __shfl(dp, 32, 64);
   if (lane != 0) return;
   const float* R = rays + ray * 6;
   if (em) {

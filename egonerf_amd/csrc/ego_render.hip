@@ -76,9 +76,11 @@ int ego_render_forward(const ego_scene* sc, const ego_render_args* a, const floa
                                zc_in ? nullptr : ws + p.zc, alpha, astride, ws + p.w, ws + p.bg, ws + p.crd, nullptr, act, stream))) return e;
     z = zc_in ? zc_in : ws + p.zc;
   }
-  // one launch for shading + compositing: measured 0.25 % SLOWER than the two launches on both render configurations (the epilogue
-  // costs the shade kernel what the small k_composite launch costs), so it is opt-in: it saves the [N][S][3] colour traffic
-  if (getenv("EGO_RENDER_FOLD") && ego_can_fold_composite(sc, S))
+  // one launch for shading + compositing wherever it applies and its ray-granular deal of the work is balanced (ego_render_forward_folds):
+  // since the folded kernel loads a plane's basis fragments ahead of the next plane's taps (it has the registers for that, the two-launch
+  // kernel does not) it is 3.5 % faster than ego_shade, 2.8 % at step level (round 5; before that it lost by 0.25 %).  EGO_RENDER_FOLD=0
+  // keeps the two launches, =1 folds whenever the scene allows it.
+  if (ego_render_forward_folds(sc, N, S))
     return ego_shade_composite(sc, rays, z, ws + p.crd, ws + p.w, ws + p.bg, N, S, act, rgb_map, depth, bg_map, env_map, stream);
   if ((e = ego_shade(sc, rays, z, ws + p.crd, N, S, ws + p.rgb, nullptr, act, stream))) return e;
   return ego_composite(sc, rays, z, ws + p.w, ws + p.bg, ws + p.rgb, N, S, rgb_map, depth, bg_map, env_map, nullptr, stream);

@@ -1144,6 +1144,15 @@ __device__ __forceinline__ void basis_step2(const u32x4* __restrict__ BASH, int 
   }
 }
 
+// the same with the wave's three fragment pairs already loaded (see EGO_ROLL_PLANE)
+template <int STEP0>
+__device__ __forceinline__ void basis3_pre(const u32x4* __restrict__ BASH, int lane, const BasisFrag& f0, const BasisFrag& f1, const BasisFrag& f2,
+                                           bool mixed, const float* v, f32x16& fe, f32x16& fe2) {
+  basis_step2<STEP0>(BASH, lane, f0, mixed, v, fe, fe2);
+  basis_step2<STEP0 + 1>(BASH, lane, f1, mixed, v + 8, fe, fe2);
+  basis_step2<STEP0 + 2>(BASH, lane, f2, mixed, v + 16, fe, fe2);
+}
+
 template <int STEP0>
 __device__ __forceinline__ void basis3(const u32x4* __restrict__ BASH, int lane, int g0, bool mixed, const float* v, f32x16& fe, f32x16& fe2) {
   const BasisFrag f0 = basis_frag<STEP0>(BASH, lane, g0), f1 = basis_frag<STEP0 + 1>(BASH, lane, g0), f2 = basis_frag<STEP0 + 2>(BASH, lane, g0);
@@ -1154,7 +1163,7 @@ __device__ __forceinline__ void basis3(const u32x4* __restrict__ BASH, int lane,
 
 // ROLL: the rolling form of the load buffer (tap_ptrs / line_load / line_finish above); it needs all 256 registers, so only the
 // fused inference kernel uses it (the dumping and stand-alone instantiations would spill)
-template <bool ROLL>
+template <bool ROLL, int HN = 0>
 __device__ __forceinline__ void gather_basis_team(const DevField& F, const TeamSample ts[2], const u32x4* __restrict__ BASH, int lane,
                                                   int g, bool mixed, int gu, f32x16& fe, float* vdump) {
   // EGO_GATHER_TEAMS 1: 4-lane teams (above).  0: no teams - both rounds serve the lane's OWN sample (ts[0] == ts[1]), round 0
@@ -1186,6 +1195,13 @@ __device__ __forceinline__ void gather_basis_team(const DevField& F, const TeamS
         __builtin_amdgcn_sched_barrier(0);                                                                \
       }                                                                                                   \
       NEXT_A;                                                                                             \
+      /* the plane's basis fragments BEFORE the next plane's tap loads: vmcnt retires in order, so fragments loaded behind them */ \
+      /* would make the first basis MFMA wait for all 18 taps of the next plane */                        \
+      BasisFrag bf0, bf1, bf2;                                                                            \
+      if (HN >= 1) bf0 = basis_frag<STEP0>(BASH, lane, g0);                                               \
+      if (HN >= 2) bf1 = basis_frag<STEP0 + 1>(BASH, lane, g0);                                           \
+      if (HN >= 3) bf2 = basis_frag<STEP0 + 2>(BASH, lane, g0);                                           \
+      __builtin_amdgcn_sched_barrier(0);                                                                  \
       _Pragma("unroll") for (int i = 0; i < 3; ++i) {                                                     \
         line_finish(pb, ln[i], gb + 4 * i);                                                               \
         if (PL < 2) line_load(F, pa, i, ln[i]);                                                           \
@@ -1193,7 +1209,10 @@ __device__ __forceinline__ void gather_basis_team(const DevField& F, const TeamS
       }                                                                                                   \
       team_to_halves(ga, gb, v);                                                                          \
       dump24(DUMPPTR, v);                                                                                 \
-      basis3<STEP0>(BASH, lane, g0, mixed, v, fe, fe2);                                                   \
+      if (HN < 1) bf0 = basis_frag<STEP0>(BASH, lane, g0);                                                \
+      if (HN < 2) bf1 = basis_frag<STEP0 + 1>(BASH, lane, g0);                                            \
+      if (HN < 3) bf2 = basis_frag<STEP0 + 2>(BASH, lane, g0);                                            \
+      basis3_pre<STEP0>(BASH, lane, bf0, bf1, bf2, mixed, v, fe, fe2);                                    \
     }
     EGO_ROLL_PLANE(0, pa = tap_ptrs<1>(F, tA, ts[0].g, qa), 0, vdump)
     pb = tap_ptrs<1>(F, tB, ts[1].g, qb);
@@ -1447,7 +1466,7 @@ __global__ __launch_bounds__(512) void k_shade_h(ShadeArgs A) {
         float* vd = (DUMP && valid) ? A.dump_v + dump_off(tile, 144, 0, hw, j) : nullptr;
         // one gather per tile; a border-straddling wave runs the basis steps of each plane twice (yin weights with the
         // yang lanes zeroed, then the reverse) inside gather_basis_team
-        gather_basis_team<(MODE == MODE_SHADE && !DUMP)>(A.F, ts, BASH, lw, g, mixed, gu, fe, vd);
+        gather_basis_team<(MODE == MODE_SHADE && !DUMP), (FOLD ? EGO_HOIST_FOLD : EGO_HOIST_PLAIN)>(A.F, ts, BASH, lw, g, mixed, gu, fe, vd);
       }
     }
 
@@ -1872,7 +1891,25 @@ bool ego_can_fold_composite(const ego_scene* sc, int32_t S) {
   return sc && ego_shape_is_tuned(sc) && !sc->app_f16 && sc->mlp_precision != EGO_PREC_F32 && sc->weight_thres <= 0.f && S >= 32 && (S & 31) == 0;
 }
 
+// ... and does it pay?  The folded kernel deals whole RAYS to its waves (a wave finishes its rays' pixels itself), the two-launch kernel
+// deals 32-sample tiles: with few rays, or a ray count just above a multiple of the wave count, some waves get one ray more than the
+// others and the launch runs as long as they do (4097 rays x 512 samples: 48 tiles on the critical path against 33).  Folded only when
+// its critical path is within 3 % of the tile-granular one.
+bool ego_fold_is_balanced(int64_t N, int32_t S) {
+  if (N <= 0 || S < 32) return false;
+  const int64_t tpr = S >> 5, n_wv = (int64_t)shade_grid(N * (int64_t)S) * 8;
+  const int64_t rays_per_wave = (N + n_wv - 1) / n_wv, tiles_per_wave = (N * tpr + n_wv - 1) / n_wv;
+  return rays_per_wave * tpr * 100 <= tiles_per_wave * 103;
+}
+
 extern "C" {
+
+int32_t ego_render_forward_folds(const ego_scene* sc, int64_t N, int32_t S) {
+  const char* f = getenv("EGO_RENDER_FOLD");
+  if (f && f[0] == '0') return 0;
+  if (!ego_can_fold_composite(sc, S)) return 0;
+  return (f && f[0] == '1') || ego_fold_is_balanced(N, S) ? 1 : 0;
+}
 
 constexpr int BASIS16_FLOATS = 2 * KHB * 2 * 64 * 4;  // [2 g][9 steps][2 terms][64 lanes][8 halves]
 

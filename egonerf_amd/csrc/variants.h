@@ -13,3 +13,14 @@
 // With the SLP vectoriser on (build with EGO_NO_PER_FILE_FLAGS=1) the compiler then forms {w00, w01} pairs and emits packed fp32
 // instructions that broadcast the HIGH half of a pair - the one code-generation feature every non-reproducible build had in common
 // (DESIGN.md 5.1).  THIS IS THE KNOWN-FAULTY FORM: it exists only as the reproducer of that fault, never ship it.
+
+// EGO_HOIST_FOLD / EGO_HOIST_PLAIN (ego_shade.hip): how many of a plane's three basis fragment pairs the rolling gather loads BEFORE it
+// issues the next plane's tap loads (vmcnt retires in order: a fragment loaded behind the taps makes its MFMA wait for all of them).
+// 3 in the folded kernel (k_shade_h<.., FOLD = true>: no spill, -3.4 % kernel time); the two-launch kernel has no registers for it
+// (3 -> 32 VGPRs spilled inside the tile loop, +9 %).
+#ifndef EGO_HOIST_FOLD
+#define EGO_HOIST_FOLD 3
+#endif
+#ifndef EGO_HOIST_PLAIN
+#define EGO_HOIST_PLAIN 0
+#endif

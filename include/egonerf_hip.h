@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define EGO_ABI_VERSION 13
+#define EGO_ABI_VERSION 14
 
 enum { EGO_PREC_F16X3 = 0, EGO_PREC_F32 = 1, EGO_PREC_F16F8 = 2, EGO_PREC_F16F6 = 3 };
 /* ego_scene.head: the appearance head TensorBase.init_render_func selected (models/tensorBase.py:186-200) */
@@ -291,13 +291,19 @@ int ego_shade(const ego_scene* sc, const float* rays, const float* z, const floa
  * pixel in their epilogue, no per-sample colours are written.  For the tuned model shape with fp32 tables, a split-precision arithmetic
  * (not EGO_PREC_F32), weight_thres <= 0 and S a multiple of 32 (EGO_E_UNSUPPORTED otherwise: call ego_shade + ego_composite); coords
  * is required.  Sums run in a different order than ego_composite's (per lane over the ray's tiles, then across 32 lanes): equal to it
- * within fp32 rounding of the sums, not bit for bit.  Measured 0.25 % slower than ego_shade + ego_composite on the 4096 x 512 and the
- * ERP configurations (the epilogue costs the shade kernel what the small second launch costs), so ego_render_forward takes it only
- * with EGO_RENDER_FOLD=1 in the environment; what it saves is the [N][S][3] colour buffer's traffic. */
+ * within fp32 rounding of the sums, not bit for bit.  3.5 % faster than ego_shade alone since round 5 (the folded kernel has the registers
+ * to load a plane's basis fragments ahead of the next plane's taps), so ego_render_forward takes it by default where it applies and
+ * where its ray-granular deal of the work is balanced (ego_render_forward_folds below); it also saves the [N][S][3] colour buffer. */
 int ego_shade_composite(const ego_scene* sc, const float* rays, const float* z, const float* coords, const float* weight,
                         const float* bg_weight /* NULL without an envmap */, int64_t N, int32_t S,
                         const uint8_t* tile_active /* NULL = shade every tile */, float* rgb_map, float* depth /* may be NULL */,
                         float* bg_map /* may be NULL */, float* env_map /* may be NULL */, void* stream);
+
+/* 1 iff ego_render_forward shades and composites N rays x S samples of this scene in ONE launch (ego_shade_composite): the scene
+ * qualifies (above) and whole rays divide evenly enough over the kernel's waves (critical path within 3 % of the tile-granular
+ * ego_shade's: 4096 x 512 and 16384 x 256 fold, 333 or 4097 rays do not).  Environment: EGO_RENDER_FOLD=0 never folds, =1 folds
+ * whenever the scene qualifies.  No device work. */
+int32_t ego_render_forward_folds(const ego_scene* sc, int64_t N, int32_t S);
 
 /* acc, rgb_map (+ envmap background), clamp, depth (+ (1-acc)*d_z quirk, EgoNeRF.py:598).
  * Outputs rgb_map [N][3], depth [N]; bg_map/env_map [N][3] written only when sc->envmap != NULL (may be NULL);

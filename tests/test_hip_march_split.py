@@ -57,8 +57,10 @@ def test_two_waves_per_ray_return_the_same_bits(S, n_rays, density_shift, with_a
 @pytest.mark.parametrize("prec", ["f16f6", "f16f8", "f16x3"])
 @pytest.mark.parametrize("envmap", [False, True])
 def test_folded_compositing_equals_the_two_launch_form(kw, prec, envmap):
-    """EGO_RENDER_FOLD=1: ego_render_forward shades and composites in one launch (ego_shade_composite) wherever it applies; the default
-    is ego_shade + ego_composite.  Same products, sums in another order: equal within fp32 rounding of the sums (2e-6), all five outputs."""
+    """EGO_RENDER_FOLD=1: ego_render_forward shades and composites in one launch (ego_shade_composite) wherever the scene allows it;
+    =0: ego_shade + ego_composite (the default picks by balance: ego_render_forward_folds).  Same products AND - since round 5, when
+    ego_composite took over the folded kernel's summation order - the same sums: all five outputs bit for bit, so a batch renders identically
+    whichever form its size selects."""
     cfg = synth.SceneConfig(n_voxel=40 ** 3, use_envmap=envmap, envmap_res_H=64) if envmap else synth.SceneConfig(n_voxel=40 ** 3)
     model = synth.build_model(cfg, synth.make_weights(cfg, seed=11), "cuda")
     model.mlp_precision = prec
@@ -66,10 +68,7 @@ def test_folded_compositing_equals_the_two_launch_form(kw, prec, envmap):
     out = {}
     try:
         for fold in (True, False):
-            if fold:
-                os.environ["EGO_RENDER_FOLD"] = "1"
-            else:
-                os.environ.pop("EGO_RENDER_FOLD", None)
+            os.environ["EGO_RENDER_FOLD"] = "1" if fold else "0"
             with torch.no_grad():
                 out[fold] = model(rays, exp_sampling=True, **kw)
     finally:
@@ -78,5 +77,30 @@ def test_folded_compositing_equals_the_two_launch_form(kw, prec, envmap):
         a, b = out[True][k], out[False][k]
         assert (a is None) == (b is None), k
         if a is not None:
-            assert float((a - b).abs().max()) <= (2e-6 if k != 1 else 2e-5), (k, float((a - b).abs().max()))
+            assert torch.equal(a, b), (k, float((a - b).abs().max()))
     assert float(out[True][0].max()) > 0.05
+
+
+def test_default_fold_decision_follows_the_balance_of_whole_rays():
+    """ego_render_forward_folds: the folded kernel deals whole rays to its 2048 waves, so it is taken by default only where that costs
+    nothing against the tile-granular two-launch form (round 5: it is 3.5 % faster there); the environment overrides either way."""
+    from egonerf_amd import _lib
+    lib = _lib.load()
+    cfg = synth.SceneConfig(n_voxel=40 ** 3)
+    model = synth.build_model(cfg, synth.make_weights(cfg, seed=11), "cuda")
+    sc = model.scene()
+    old = os.environ.pop("EGO_RENDER_FOLD", None)
+    try:
+        q = lambda N, S: int(lib.ego_render_forward_folds(sc, N, S))
+        assert q(4096, 512) == 1 and q(16384, 256) == 1 and q(8192, 256) == 1 and q(1 << 21, 256) == 1
+        assert q(4097, 512) == 0 and q(333, 512) == 0 and q(256, 64) == 0 and q(4096, 500) == 0 and q(0, 512) == 0
+        os.environ["EGO_RENDER_FOLD"] = "0"
+        assert q(4096, 512) == 0
+        os.environ["EGO_RENDER_FOLD"] = "1"
+        assert q(333, 512) == 1 and q(4096, 500) == 0     # forced, but only where the scene and the sample count qualify
+        model.mlp_precision = "f32"
+        assert int(lib.ego_render_forward_folds(model.scene(), 4096, 512)) == 0
+    finally:
+        os.environ.pop("EGO_RENDER_FOLD", None)
+        if old is not None:
+            os.environ["EGO_RENDER_FOLD"] = old
