@@ -421,6 +421,8 @@ def run_render(a, rk: Ranks):
     ms = np.array([[e[k].elapsed_time(e[k + 1]) for k in range(3)] for e in ev]).mean(0)
     t_march, t_shade, t_comp = (float(x) * 1e-3 for x in ms)
     roofline = shade_roofline(model.mlp_precision, t_shade, M)
+    if folded:   # the instantiation ego_render_forward launches: shading with the compositing in its epilogue
+        roofline["kernel"] = roofline["kernel"].replace(">", ",FOLD>")
     march_gbps = (B_DENSITY + 28) * M / t_march / 1e9
     march = dict(hbm_algorithmic_GBps=march_gbps, frac_of_hbm_peak=march_gbps / HBM_PEAK_GBPS,
                  note="cache-resident like the shade gather (24.7 MB of density tables); the binding resource is VALU issue")

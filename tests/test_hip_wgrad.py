@@ -129,7 +129,7 @@ def test_weight_grad_grid_routed_layout(M):
     assert float((G[:64, :144] - ref).abs().max()) <= 5e-5 * float(ref.abs().max())
     # ... and equals the plain row-major form on the expanded matrix
     G0 = _run(A64.to(DEV), 64, _blocked(B).to(DEV), 144, -1, a_blocked=0, b_blocked=1, M=M).cpu().double()
-    assert float((G - G0).abs().max()) <= 1e-6 * float(ref.abs().max())
+    assert float((G - G0).abs().max()) <= 3e-6 * float(ref.abs().max())   # both runs add their workgroups' partial products with float atomics (order varies: 1.04e-6 seen)
     # ... and with B as the training forward writes v: halves in the kernels' operand order (b_layout 2)
     Bh, Bexact = _half_blocked(B)
     Gh = _run(A32.to(DEV), 64, Bh.to(DEV), 144, -1, a_blocked=3, b_blocked=2, M=M, a_scale=coords.to(DEV)).cpu().double()

@@ -1,7 +1,7 @@
 """Per-phase instruction budget of the SHIPPED shade kernel, from the code object inside libegonerf_hip.so ("a per-phase
 ISA budget that proves where the floor is").
 
-    python tools/isa_budget.py [--kernel 'k_shade_h<0, false, false, 2, false>'] > profiles/rNN/shade_isa_budget.txt
+    python tools/isa_budget.py [--kernel 'k_shade_h<0, false, false, 2, true>'] > profiles/rNN/shade_isa_budget.txt
 
 The tile loop of k_shade_h is straight-line code between `s_setprio 2` (gather + basis phase) ... `s_setprio 0` (MLP phase) ... the branch
 back; instruction classes are counted per phase, priced with the issue costs measured in tools/coissue_probe.hip / fp6_probe.hip
@@ -69,7 +69,7 @@ def valu_kind(l, m):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--kernel", default="k_shade_h<0, false, false, 2, false>")
+    ap.add_argument("--kernel", default="k_shade_h<0, false, false, 2, true>")
     a = ap.parse_args()
     lines = disassemble(a.kernel)
     mn = [(l.split()[0], l) for l in lines]
@@ -89,7 +89,8 @@ def main():
     phases = {"gather + basis (s_setprio 2 ... s_setprio 0)": (g0, g1), "MLP: PE, layers 1-3, sigmoid, store (s_setprio 0 ... loop branch)": (g1, m1)}
     print(f"kernel {a.kernel}: {len(mn)} instructions in the code object; tile loop = instructions {g0} .. {m1}")
     print(f"scratch (spill) instructions: {[(i, s) for i, s in scratch]}")
-    print("  -> " + ("all OUTSIDE the tile loop (prologue store / per-64-tile mask batch reload): the 4 spilled VGPRs cost nothing per tile"
+    print("  -> " + ("none: the kernel does not spill" if not scratch else
+                     "all OUTSIDE the tile loop (prologue store / per-64-tile mask batch reload): the spilled VGPRs cost nothing per tile"
                      if all(i < g0 or i > m1 for i, _ in scratch) else "some INSIDE the tile loop"))
     total = collections.Counter()
     for name, (lo, hi) in phases.items():
