@@ -1112,8 +1112,8 @@ __device__ __forceinline__ void team_to_halves(const float ga[12], const float g
 
 // (v as halves - 0.6 GB less per step each way, forward -0.12 ms - puts the basis gradient of the 1.5 k-sample golden at 2.3e-4 of its
 // largest element against the 2e-4 it is held to: v stays fp32)
-// All dump stores of the training forward and backward are NONTEMPORAL (`global_store ... nt`): 2.6 GB per launch that nobody reads before the
-// whole pass is over.  Measured (round 5, timing-only builds, one box): forward without its dump stores 0.49 ms, with them 0.94, with the
+// All dump stores of the training FORWARD are NONTEMPORAL (`global_store ... nt`): 2.6 GB per launch that nobody reads before the whole pass
+// is over (the backward's dh2 / dh1 are read by the next kernels and stay cached; its dfe / dv are written as quarter lines).  Measured (round 5, timing-only builds, one box): forward without its dump stores 0.49 ms, with them 0.94, with the
 // stores aimed at a per-wave 40 KB region (no HBM traffic at all) 0.74 - the write path into the XCD's L2 (~17 B / clk / CU, half the read
 // rate), not HBM and not the order of loads and stores in the vmcnt queue (moving the stores behind the next loads: +-0), is what a dumping
 // wave waits for; nt stores take the forward to 0.79-0.82 ms.

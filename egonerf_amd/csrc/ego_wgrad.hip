@@ -476,6 +476,82 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
 }
 
+// ---- d(W3) = do^T h2 (+ d(b3) = column sums of do): three rows -----------------------------------------------------------------------------
+// A = d(output) [M][3] fp32, B = the forward's h2 dump (halves, 128 columns, operand order).  The generic kernel above runs this product as a
+// 32 x 160 MFMA tile with 29 empty rows and a bf16 split of both operands: commit -> barrier -> MFMA -> barrier per 32 samples, 0.20 ms for
+// 0.56 GB.  It is 2.1 M x 384 multiply-adds - nothing for the VALU: thread (k-step s, lane) keeps the eight columns its 16-byte item holds
+// ([tile][s][lane = 32 h + j][8 halves]: the same eight columns of sample j in every tile) as 3 x 8 fp32 sums over the workgroup's tiles in
+// order, the 32 lanes of a half are added as a tree at the end.  fp32 products of exact halves; streaming, no LDS staging, no barrier in the loop.
+__global__ __launch_bounds__(512) void k_wgrad3(WgradArgs P) {
+  typedef _Float16 h8v __attribute__((ext_vector_type(8)));
+  const int s = threadIdx.x >> 6, lane = threadIdx.x & 63, h = lane >> 5, j = lane & 31;
+  const int64_t tile0 = (int64_t)blockIdx.x * P.steps_per_wg, n_tiles = (P.M + 31) >> 5;
+  float acc[3][8], accb[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[c][e] = 0.f;
+  const u32x4* B = (const u32x4*)P.B;
+  auto fetch = [&](int64_t tile, u32x4& x, float d[3]) {
+    const int64_t t = tile < n_tiles ? tile : n_tiles - 1, m = t * 32 + j;
+    const bool in = tile < n_tiles && m < P.M;
+    const int64_t mc = in ? m : P.M - 1;
+    const u32x4 xl = B[(t * 8 + s) * 64 + lane];
+    x = in ? xl : u32x4{0u, 0u, 0u, 0u};   // rows behind M may hold anything (0 x NaN)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float v = P.A[mc * P.lda + c];
+      d[c] = in ? v : 0.f;
+    }
+  };
+  u32x4 x, xn;
+  float d[3], dn[3];
+  fetch(tile0, x, d);
+  for (int st = 0; st < P.steps_per_wg; ++st) {
+    const int64_t tile = tile0 + st;
+    if (tile >= n_tiles) break;   // uniform over the workgroup
+    if (st + 1 < P.steps_per_wg) fetch(tile + 1, xn, dn);
+    const h8v hv = __builtin_bit_cast(h8v, x);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[c][e] = fmaf(d[c], (float)hv[e], acc[c][e]);
+      accb[c] += d[c];
+    }
+    x = xn;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) d[c] = dn[c];
+  }
+  // the 32 samples of the half: balanced tree (fixed order)
+#pragma unroll
+  for (int sh = 1; sh <= 16; sh <<= 1) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[c][e] += __shfl_xor(acc[c][e], sh, 64);
+      accb[c] += __shfl_xor(accb[c], sh, 64);
+    }
+  }
+  if (j != 0) return;
+  constexpr int LD = 160;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int col = (2 * s + (e >> 2)) * 8 + h * 4 + (e & 3);
+      if (P.Gpart) P.Gpart[((int64_t)blockIdx.x * 3 + c) * LD + col] = acc[c][e];
+      else if (acc[c][e] != 0.f) unsafeAtomicAdd(P.G + (int64_t)c * P.ldg + col, acc[c][e]);
+    }
+    if (s == 0 && h == 0) {   // the remaining columns of the padded row: the ones column (bias gradient), zeros elsewhere
+      for (int col = 128; col < LD; ++col) {
+        const float v = col == P.ones_col ? accb[c] : 0.f;
+        if (P.Gpart) P.Gpart[((int64_t)blockIdx.x * 3 + c) * LD + col] = v;
+        else if (v != 0.f) unsafeAtomicAdd(P.G + (int64_t)c * P.ldg + col, v);
+      }
+    }
+  }
+}
+
 // deterministic mode: G[row][col] = sum over workgroups, in workgroup order (sixteen contiguous segments, then the segments in order),
 // of the partial products; overwrites G's [rows][ld] block (no zero fill needed)
 __global__ __launch_bounds__(1024) void k_wgrad_reduce(const float* __restrict__ part, int n_wg, int rows, int ld, float* __restrict__ G, int ldg) {
@@ -516,6 +592,17 @@ int launch_h(const WgradArgs& a, hipStream_t st) {
   k_wgrad_h<CBB, XSYN><<<n_wg, 256, 0, st>>>(p);
   if (int e = ego_launch_status("k_wgrad_h")) return e;
   return p.Gpart ? reduce_partials(p, n_wg, 128, 32 * CBB, st) : EGO_OK;
+}
+
+int launch_w3(const WgradArgs& a, hipStream_t st) {
+  WgradArgs p = a;
+  const int64_t steps = (a.M + 31) / 32;
+  const int64_t wgs = steps < 512 ? steps : 512;
+  p.steps_per_wg = (int32_t)((steps + wgs - 1) / wgs);
+  const unsigned n_wg = (unsigned)((steps + p.steps_per_wg - 1) / p.steps_per_wg);
+  k_wgrad3<<<n_wg, 512, 0, st>>>(p);
+  if (int e = ego_launch_status("k_wgrad3")) return e;
+  return p.Gpart ? reduce_partials(p, n_wg, 3, 160, st) : EGO_OK;
 }
 
 template <int CAB, int CBB, bool AVEC, int ABLK, int BBLK>
@@ -581,7 +668,9 @@ int ego_weight_grad_det(const void* A, int32_t lda, int32_t ca, int32_t a_layout
   switch (key) {
     case (1 * 8 + 5) * 16 + 0: return avec ? launch<1, 5, true, 0, 0>(a, st) : launch<1, 5, false, 0, 0>(a, st);
     case (1 * 8 + 5) * 16 + 1: return avec ? launch<1, 5, true, 0, 1>(a, st) : launch<1, 5, false, 0, 1>(a, st);
-    case (1 * 8 + 5) * 16 + 2: return avec ? launch<1, 5, true, 0, 2>(a, st) : launch<1, 5, false, 0, 2>(a, st);
+    case (1 * 8 + 5) * 16 + 2:
+      if (ca == 3 && cb == 128 && lda == 3 && (ones_col < 0 || ones_col >= 128) && ((uintptr_t)B & 15) == 0 && !getenv("EGO_WGRAD3_MFMA")) return launch_w3(a, st);
+      return avec ? launch<1, 5, true, 0, 2>(a, st) : launch<1, 5, false, 0, 2>(a, st);
     case (2 * 8 + 5) * 16 + 0: if (avec) return launch<2, 5, true, 0, 0>(a, st); break;
     case (2 * 8 + 5) * 16 + 1: if (avec) return launch<2, 5, true, 0, 1>(a, st); break;
     case (2 * 8 + 5) * 16 + 13: return launch<2, 5, true, 3, 1>(a, st);
