@@ -621,15 +621,24 @@ __device__ __forceinline__ void sorted_line_final(const SortedArgs& A) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= 2 * n * C) return;
   const int ch = idx % C, t = (idx / C) % n, g = idx / (C * n);
-  float s0 = 0.f, s1 = 0.f;
-  {
-    const uint32_t lc = (uint32_t)g * (uint32_t)(n + 1) + (uint32_t)t + 1;
-    for (uint32_t w = A.suboff[S_][lc]; w < A.suboff[S_][lc + 1]; ++w) s0 += A.linepart[S_][(int64_t)w * 2 * C + ch];
-  }
-  {
-    const uint32_t lc = (uint32_t)g * (uint32_t)(n + 1) + (uint32_t)t;
-    for (uint32_t w = A.suboff[S_][lc]; w < A.suboff[S_][lc + 1]; ++w) s1 += A.linepart[S_][(int64_t)w * 2 * C + C + ch];
-  }
+  // a cell has 8 - 30 sub-blocks: the partials are FETCHED eight at a time (independent loads) and ADDED one after the other in sub-block
+  // order - the same sum, bit for bit, as a one-load-at-a-time loop, without its chain of dependent memory round trips
+  auto ordered_sum = [&](uint32_t lc, int off) {
+    float s = 0.f;
+    const uint32_t w1 = A.suboff[S_][lc + 1];
+    const float* base = A.linepart[S_] + off + ch;
+    for (uint32_t w = A.suboff[S_][lc]; w < w1; w += 8) {
+      float v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = base[(int64_t)(w + k < w1 ? w + k : w1 - 1) * 2 * C];
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        if (w + k < w1) s += v[k];
+    }
+    return s;
+  };
+  const float s0 = ordered_sum((uint32_t)g * (uint32_t)(n + 1) + (uint32_t)t + 1, 0);
+  const float s1 = ordered_sum((uint32_t)g * (uint32_t)(n + 1) + (uint32_t)t, C);
   (g ? A.G.line[1][J] : A.G.line[0][J])[t * C + ch] = s0 + s1;
 }
 
