@@ -504,23 +504,35 @@ __global__ __launch_bounds__(512) void k_wgrad3(WgradArgs P) {
       d[c] = in ? v : 0.f;
     }
   };
-  u32x4 x, xn;
-  float d[3], dn[3];
-  fetch(tile0, x, d);
-  for (int st = 0; st < P.steps_per_wg; ++st) {
+  // two tiles in flight behind the two being added (one 16-byte load per lane and tile: a single tile ahead left the HBM queue short)
+  u32x4 x[2], xn[2];
+  float d[2][3], dn[2][3];
+  fetch(tile0, x[0], d[0]);
+  fetch(tile0 + 1, x[1], d[1]);
+  for (int st = 0; st < P.steps_per_wg; st += 2) {
     const int64_t tile = tile0 + st;
     if (tile >= n_tiles) break;   // uniform over the workgroup
-    if (st + 1 < P.steps_per_wg) fetch(tile + 1, xn, dn);
-    const h8v hv = __builtin_bit_cast(h8v, x);
+    const bool more = st + 2 < P.steps_per_wg;
+    if (more) { fetch(tile + 2, xn[0], dn[0]); fetch(tile + 3, xn[1], dn[1]); }
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
+    for (int k = 0; k < 2; ++k) {
+      if (st + k >= P.steps_per_wg) break;   // odd step count: the second slot of the last pair belongs to the next workgroup
+      const h8v hv = __builtin_bit_cast(h8v, x[k]);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) acc[c][e] = fmaf(d[c], (float)hv[e], acc[c][e]);
-      accb[c] += d[c];
+      for (int c = 0; c < 3; ++c) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[c][e] = fmaf(d[k][c], (float)hv[e], acc[c][e]);
+        accb[c] += d[k][c];
+      }
     }
-    x = xn;
+    if (more) {
 #pragma unroll
-    for (int c = 0; c < 3; ++c) d[c] = dn[c];
+      for (int k = 0; k < 2; ++k) {
+        x[k] = xn[k];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) d[k][c] = dn[k][c];
+      }
+    }
   }
   // the 32 samples of the half: balanced tree (fixed order)
 #pragma unroll
