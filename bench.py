@@ -656,19 +656,21 @@ def run_render_variant(a, rk: Ranks):
     pmc, src, stale = load_pmc_section(key) if key else (None, None, None)
     t_gs = t_march + t_shade
     roofline = dict(bound="hbm", kernel="k_march_density + k_shade_h (the two grid-sample kernels)", unit="GB/s", peak=HBM_PEAK_GBPS,
-                    achieved=(alg_shade + alg_march) / t_gs / 1e9, frac=(alg_shade + alg_march) / t_gs / 1e9 / HBM_PEAK_GBPS,
+                    achieved=None, frac=None, algorithmic_GBps=(alg_shade + alg_march) / t_gs / 1e9,
+                    algorithmic_frac=(alg_shade + alg_march) / t_gs / 1e9 / HBM_PEAK_GBPS,
                     algorithmic_bytes_per_step=alg_shade + alg_march, traffic=None, hbm_counter_GBps=None, hbm_counter_frac=None,
                     kernels_ms=dict(k_march_density=t_march * 1e3, k_shade=t_shade * 1e3, k_composite=t_comp * 1e3),
                     shade=dict(algorithmic_GBps=alg_shade / t_shade / 1e9, mfma_frac=info["flop_per_sample"] * M / t_shade / 1e12 / MFMA_F16_PEAK_TFLOPS),
                     march=dict(algorithmic_GBps=alg_march / t_march / 1e9),
                     table_bytes=table_bytes, infinity_cache_bytes=256 * 2 ** 20, tables_fit_infinity_cache=table_bytes < 256 * 2 ** 20,
-                    definition="achieved = SURVEY 8(d)'s algorithmic tap bytes (4 608 B per sample + coords / outputs) of the two grid-sample kernels "
-                               "per step / their event-timed duration; frac > 1 is possible and means the caches, not HBM, served the taps; "
-                               "traffic / hbm_counter_* = FETCH_SIZE x 2 + WRITE_SIZE of the same two kernels from separate rocprofv3 --pmc passes")
+                    definition="bound 'hbm': achieved / frac = COUNTER bytes (traffic = FETCH_SIZE x 2 + WRITE_SIZE of the two grid-sample kernels, "
+                               "separate rocprofv3 --pmc passes, per step) / their event-timed duration, against 8 TB/s - a physical fraction, <= 1; "
+                               "null when no counter pass is tracked.  algorithmic_GBps / algorithmic_frac = SURVEY 8(d)'s tap bytes (4 608 B per "
+                               "sample + coords / outputs) / the same time: exceeds 1 when the caches, not HBM, serve the taps - not a roofline")
     if pmc is not None and pmc.get("traffic_bytes"):
-        t_pmc = pmc.get("duration_s") or t_gs
         roofline.update(traffic=pmc["traffic_bytes"], hbm_counter_GBps=pmc["traffic_bytes"] / t_gs / 1e9,
                         hbm_counter_frac=pmc["traffic_bytes"] / t_gs / 1e9 / HBM_PEAK_GBPS,
+                        achieved=pmc["traffic_bytes"] / t_gs / 1e9, frac=pmc["traffic_bytes"] / t_gs / 1e9 / HBM_PEAK_GBPS,
                         inputs=dict(source=src, stale_vs_current_sources=stale, per_kernel=pmc.get("per_kernel")))
     rays_per_s = rk.world * N_RAYS * a.steps / dt
     return dict(metric="rays/sec at 4096-ray batch, 512 samples (EgoNeRF volume-rendering forward)", value=rays_per_s, unit="rays/s",
@@ -1323,11 +1325,33 @@ def _clip(text, n: int):
     return text if not isinstance(text, str) or len(text) <= n else text[: n - 1] + "\u2026"
 
 
+def _physical(rf: dict) -> dict:
+    """A roofline object whose `frac` is a physical fraction.  Under `bound: "hbm"` `achieved` / `frac` are COUNTER
+    bytes / time / 8 TB/s; a record that still carries SURVEY 8(d)'s algorithmic tap bytes there (cache-served taps: > 1) has that figure
+    moved to `algorithmic_frac` and the counter fraction - or null - put in its place.  No roofline in the line may exceed 1."""
+    rf = dict(rf)
+    f = rf.get("frac")
+    if rf.get("bound") == "hbm" and isinstance(f, (int, float)) and f > 1.0:
+        rf.setdefault("algorithmic_frac", f)
+        c = rf.get("hbm_counter_frac")
+        ok = isinstance(c, (int, float)) and np.isfinite(c) and c <= 1.0
+        rf["frac"] = c if ok else None
+        rf["achieved"] = rf["traffic"] / (rf["ms"] * 1e-3) / 1e9 if ok and rf.get("traffic") and rf.get("ms") else (c * rf["peak"] if ok and rf.get("peak") else None)
+    return rf
+
+
 def _brief_roofline(rf):
     if not isinstance(rf, dict):
         return None
+    rf = _physical(rf)
     out = {k: rf[k] for k in _ROOFLINE_KEYS if k in rf}
     out.setdefault("traffic", None)
+    if rf.get("algorithmic_frac") is not None:
+        out["algorithmic_frac"] = rf["algorithmic_frac"]
+    # what binds the kernel, in the driver's record itself (VERDICT r05 item 3): SIMD issue time and vector-L1 path time over kernel time
+    for k in ("issue", "l1"):
+        if isinstance(rf.get(k), dict) and rf[k].get("frac") is not None:
+            out[k + "_frac"] = rf[k]["frac"]
     src = (rf.get("inputs") or {}).get("source") or rf.get("traffic_scope")
     # which fields this process measured and which it read from the tracked counter passes (bench.py cannot collect PMC counters itself)
     out["measured_here"] = ["ms", "achieved", "frac"]
@@ -1375,9 +1399,11 @@ def compact_line(full: dict, full_paths=()) -> dict:
             if "error" in ln:
                 brief[name] = dict(error=_clip(ln["error"], 120))
                 continue
-            rf = ln.get("roofline") or {}
+            rf = _physical(ln.get("roofline") or {})
             b = dict(value=ln.get("value"), unit=ln.get("unit"), ms_per_step=ln.get("ms_per_step"), steps=ln.get("steps"),
                      roofline=dict(bound=rf.get("bound"), frac=rf.get("frac"), traffic=rf.get("traffic"), unit=rf.get("unit"), achieved=rf.get("achieved")))
+            if rf.get("algorithmic_frac") is not None:
+                b["roofline"]["algorithmic_frac"] = rf["algorithmic_frac"]
             if isinstance(ln.get("cpu_baseline"), dict):
                 b["cpu_baseline"] = dict(value=ln["cpu_baseline"].get("value"), cores=ln["cpu_baseline"].get("cores"), kind=ln["cpu_baseline"].get("kind"))
             if isinstance(ln.get("parity"), dict):

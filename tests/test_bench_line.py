@@ -31,6 +31,10 @@ def _check(line: dict, full: dict):
     for k in ("bound", "kernel", "unit", "achieved", "peak", "frac", "traffic", "ms"):
         assert k in rf, k
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-5
+    # every `frac` in the line is a physical fraction - an algorithmic byte rate that the caches inflate above the
+    # HBM peak goes to `algorithmic_frac`, never to `frac`
+    for name, r in [("headline", rf)] + [(n, ln.get("roofline") or {}) for n, ln in (back.get("secondary") or {}).items() if "error" not in ln]:
+        assert r.get("frac") is None or 0 < r["frac"] <= 1.0, (name, r)
     cb = back["cpu_baseline"]
     assert set(cb) == {"value", "unit", "cores", "kind", "sample"} and cb["kind"] in ("port", "reference")
     assert back["parity"]["max_abs_rgb_err"] <= 1e-4
@@ -51,6 +55,19 @@ def test_compact_line_of_a_real_record_fits_the_drivers_window():
     # what was measured in the bench process and what was read from the tracked counter passes is said in the line itself
     assert back["roofline"]["measured_here"] == ["ms", "achieved", "frac"]
     assert back["roofline"]["from_counter_pass"]["file"].startswith("profiles/")
+
+
+def test_an_algorithmic_byte_rate_above_the_hbm_peak_is_never_printed_as_frac():
+    b = _bench_module()
+    full = copy.deepcopy(_canned())
+    full["secondary"]["render_big_grid"]["roofline"].update(bound="hbm", frac=1.98, achieved=15840.0, peak=8000.0, hbm_counter_frac=0.36, traffic=1.79e9)
+    full["secondary"]["render_fresh_rays"]["roofline"].update(bound="hbm", frac=2.27, achieved=18160.0, peak=8000.0, hbm_counter_frac=None, traffic=None)
+    back = _check(b.compact_line(full, []), full)
+    big, fresh = back["secondary"]["render_big_grid"]["roofline"], back["secondary"]["render_fresh_rays"]["roofline"]
+    assert big["frac"] == 0.36 and big["algorithmic_frac"] == 1.98
+    assert fresh["frac"] is None and fresh["algorithmic_frac"] == 2.27
+    for k in ("issue_frac", "l1_frac"):   # what binds the headline kernel is in the driver's record itself
+        assert 0 < back["roofline"][k] <= 1.2, k
 
 
 def test_compact_line_sheds_optional_blocks_rather_than_outgrow_the_window():
