@@ -72,6 +72,77 @@ def test_sorted_scatter_equals_the_atomic_one_and_itself(n_voxel, N, S, spread):
             assert M < 64 or float(s.abs().max()) > 0
 
 
+def _float64_grid_sample_gradients(cfg, weights, coords, dfeat, dv_ref):
+    """Independent truth for the stand-alone scatters: float64 autograd THROUGH the oracle's F.grid_sample calls
+    (align_corners=True, zero padding: grid_sampler_2d_backward is an index_add of the 18 taps x C channels per sample) on the CPU.
+    coords [N,S,4] normalised (r, theta, phi, is_yang); dfeat [N,S] = dL/d(density feature); dv_ref [M,144] = dL/d(plane*line products)
+    in the reference's channel order.  -> (density grads, app grads) in table_params() order, reference-shaped float64 tensors."""
+    from tests.helpers import make_oracle
+    sc = make_oracle(cfg, weights, dtype=torch.float64)
+    c4 = coords.reshape(-1, 4).double().cpu()
+    c7 = torch.cat([c4[:, :3], c4[:, :3], c4[:, 3:4]], -1)     # the same normalised triple in the yin and the yang slot; the flag picks the tables
+    keys = lambda kind: [f"{kind}_{what}_{g}.{i}" for g in ("yin", "yang") for what in ("plane", "line") for i in range(3)]
+    for k in keys("density") + keys("app"):
+        sc.w[k] = sc.w[k].clone().requires_grad_(True)
+    loss_d = (sc.density_feature(c7) * dfeat.reshape(-1).double().cpu()).sum()      # sum_i relu(sum_c P L): EgoNeRF.py:291-347
+    gd = torch.autograd.grad(loss_d, [sc.w[k] for k in keys("density")])
+    dvr = dv_ref.double().cpu()
+    loss_a = 0.0
+    is_yin = c7[:, -1] == 0
+    for g, sel in (("yin", is_yin), ("yang", ~is_yin)):
+        if bool(sel.any()):
+            taps = sc._vm_taps([sc.table("app", "plane", g, i) for i in range(3)], [sc.table("app", "line", g, i) for i in range(3)], c7[sel][:, :3])
+            prod = torch.cat([P * L for P, L in taps])                                  # [144, m]: EgoNeRF.py:349-413 before basis_mat
+            loss_a = loss_a + (prod.T * dvr[sel]).sum()
+    ga = torch.autograd.grad(loss_a, [sc.w[k] for k in keys("app")], allow_unused=True)
+    ga = [torch.zeros_like(sc.w[k]) if g is None else g for g, k in zip(ga, keys("app"))]
+    return list(gd), ga
+
+
+def _blocked_dv(dv_ref, M):
+    """[M,144] (reference channel order plane * 48 + c) -> k_shade_bwd's blocked layout [tile of 32][plane * 3 + c / 16][sample][c % 16]."""
+    Mp = (M + 31) // 32 * 32
+    full = torch.zeros(Mp, 144)
+    full[:M] = dv_ref
+    return full.view(Mp // 32, 32, 9, 16).permute(0, 2, 1, 3).contiguous().view(-1)
+
+
+@pytest.mark.parametrize("n_voxel,N,S,spread", [(27e6, 512, 256, 1.0),       # the headline grid [150, 172, 516], 131 072 samples
+                                                (216e6, 96, 64, 1.05),       # 20-bit cell keys, samples beyond the border
+                                                (40 ** 3, 333, 45, 1.15)])
+def test_scatters_against_float64_grid_sample_backward(n_voxel, N, S, spread):
+    """Both forms of both scatters (sorted and float-atomic) against float64 autograd through F.grid_sample - the thing
+    models/EgoNeRF.py:316-345, :377-407 differentiate - at 3e-5 of each table's largest gradient.  (A density sample whose per-plane channel
+    sum lies within float32 rounding of 0 could take the other ReLU branch than float64 does; on these seeded inputs none does - the
+    kernels are deterministic, so this is a fixed property of the case, not a flake.)"""
+    cfg = synth.SceneConfig(n_voxel=n_voxel)
+    weights = synth.make_weights(cfg, seed=21)
+    model = make_model(cfg, weights, DEV)
+    M = N * S
+    g = torch.Generator().manual_seed(5)
+    coords = (torch.rand(N, S, 4, generator=g) * 2 - 1) * spread
+    coords[..., 3] = (torch.rand(N, S, generator=g) > 0.5).float()
+    walk = torch.cumsum(torch.rand(N, S, 3, generator=g) * 0.02, dim=1) - 0.9
+    coords[: N // 2, :, :3] = walk[: N // 2].clamp(-spread, spread)
+    coords[0, :4, 0] = torch.tensor([-1.0, 1.0, -1.3, 1.3])
+    dfeat = torch.randn(N, S, generator=g)
+    dfeat[torch.rand(N, S, generator=g) < 0.3] = 0.0
+    dv_ref = torch.randn(M, 144, generator=g)
+    ref_d, ref_a = _float64_grid_sample_gradients(cfg, weights, coords, dfeat, dv_ref)
+    out = _scatter_both(model, coords.to(DEV).contiguous(), dfeat.to(DEV).contiguous(), _blocked_dv(dv_ref, M).to(DEV), N, S)
+    worst = 0.0
+    for mode in ("sorted", "atomic"):
+        for fi, (field, refs) in enumerate((("density", ref_d), ("app", ref_a))):
+            for k, (got, ref) in enumerate(zip(out[mode][fi], refs)):
+                assert got.shape == ref.shape, (field, k, got.shape, ref.shape)
+                scale = max(float(ref.abs().max()), 1e-20)
+                err = float((got.double().cpu() - ref).abs().max()) / scale
+                worst = max(worst, err)
+                assert err <= 3e-5, (mode, field, k, err)
+                assert float(ref.abs().max()) > 0
+    print(f"scatter vs float64 grid_sample backward: worst {worst:.2e} of a table's largest gradient")
+
+
 def test_training_gradients_are_bit_reproducible_and_match_the_atomic_path(golden):
     """The whole differentiable step on the tiny golden scene: default (sorted scatters, ordered weight-gradient sums) twice -> identical
     bits in all 32 gradients; against model.deterministic_scatter = False (float atomics) -> equal to summation-order rounding; both
