@@ -73,7 +73,7 @@ SP = C.POINTER(Scene)
 # The EGO_ABI_VERSION (include/egonerf_hip.h) the PROTOTYPES below were written against.  load() refuses a library that reports
 # another one: a stale libegonerf_hip.so can keep every struct size and still disagree on an argument list (ABI 5 -> 7 inserted
 # `normalize` before ego_erp_rays' output pointer), which ctypes would pass through as a wild pointer.
-EXPECTED_ABI_VERSION = 14
+EXPECTED_ABI_VERSION = 15
 
 # name -> (restype, argtypes); mirrors include/egonerf_hip.h one to one
 PROTOTYPES = {
@@ -117,9 +117,9 @@ PROTOTYPES = {
     "ego_scatter_sorted_workspace_bytes": (C.c_int64, [SP, I64, I32]),
     "ego_scatter_sort": (C.c_int, [SP, P, I64, I32, P, I64, P]),
     "ego_scatter_density_sorted": (C.c_int, [SP, C.POINTER(VmGrad), P, P, I64, I32, P, I64, P]),
-    "ego_scatter_app_sorted": (C.c_int, [SP, C.POINTER(VmGrad), P, P, I64, I32, P, I64, P]),
+    "ego_scatter_app_sorted": (C.c_int, [SP, C.POINTER(VmGrad), P, P, P, I64, I32, P, I64, P]),
     "ego_envmap_backward": (C.c_int, [SP, P, I32, P, P, P, P, I64, P, P]),
-    "ego_shade_backward": (C.c_int, [SP, P, P, P, P, C.POINTER(ShadeDump), P, P, P, P, P, I64, I32, P]),
+    "ego_shade_backward": (C.c_int, [SP, P, P, P, P, C.POINTER(ShadeDump), P, P, P, P, P, P, I64, I32, P]),
     "ego_sh_render": (C.c_int, [P, P, I64, P, P]),
     "ego_shade_train_generic": (C.c_int, [SP, P, P, I64, I32, P, P, I32, P, P, I32, P, I32, P]),
     "ego_shade_backward_generic": (C.c_int, [SP, P, P, P, P, I32, P, P, I32, P, P, P, P, I32, I64, I32, P]),

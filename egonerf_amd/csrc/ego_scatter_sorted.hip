@@ -23,15 +23,29 @@
 //   k_sorted_line_final   : texel = its two cells' partials, added in sub-block order
 //
 // No zero fill of the gradient tables is needed (every texel is written), no atomics, and two runs return the same bits.
+//
+// Round 6: ONE pass over the gradient activations.  The line kernels above read every sample's d a second time
+// (1.2 GB of dv in another random order) plus four random co-plane taps per sample: 0.68 ms and 4.6 GB of fetches per step.  A plane
+// cell's samples all use the SAME four plane texels, so the line gradient of the plane's own line (the THIRD axis, the one that is not
+// in the sort key) costs four multiply-adds per sample next to the plane's - but its samples land in arbitrary line texels, so the sums
+// cannot be taken in a fixed order.  They are taken in an order-INDEPENDENT arithmetic instead: every contribution is converted to a
+// 64-bit fixed-point integer (one power-of-two unit per table, derived from max |d| x max |plane texel|, both computed on the device:
+// >= 40 bits below the largest possible contribution - an fp32 sum keeps 24) and added with integer LDS atomics into a per-workgroup
+// table of the line; integer addition is associative, so any order gives the same bits.  k_sorted_fused = k_sorted_plane + those
+// four multiply-adds + two ds_add_u64 per channel lane and sample; k_fused_line_final adds the workgroups' tables and converts once.
+// The separate line kernels stay as the fall-back for line tables that do not fit the LDS (EGO_SORTED_LINES=separate forces them).
 
 #include "ego_device.h"
 #include "ego_host.h"
+#include <atomic>
+#include <stdlib.h>
 
 namespace {
 
 constexpr int SUB = 256;       // samples per line sub-block
 constexpr int RBITS = 9, RADIX = 1 << RBITS, RTILE = 4096;   // radix sort: digit bits, buckets, elements per workgroup tile (256 threads x 16)
 constexpr int CMAX = 48;       // channels of the widest field (appearance)
+constexpr int FUSED_MAX_WG = 320;   // workgroups of a fused launch (one per CU: 256 on MI355X; room for a larger part)
 
 // sort s: major / minor axis of its key (0 r, 1 theta, 2 phi), the plane whose cells it bins and the line whose ranges it bins
 __host__ __device__ constexpr int sort_major(int s) { return s == 0 ? 2 : s == 1 ? 0 : 1; }
@@ -54,9 +68,60 @@ struct SortGeom {
   int passes;          // ceil(bits / 9)
   // scatter-phase view of the scratch region
   int64_t cellbuf[3], linepart[3];
+  int64_t fx, fpart;   // fused form: the fixed-point scale block, the per-workgroup integer line tables
+  int64_t fpart_stride;   // entries (8 bytes each) per workgroup table
+  bool dense_cells;    // cell buffer indexed by cell (K <= M) or by the cell's first sorted position (K > M: at most M cells hold samples)
+  uint32_t cell_slots[3];
 };
 
 inline int64_t align256(int64_t v) { return (v + 255) & ~(int64_t)255; }
+
+// ---- launch plan of the fused form ------------------------------------------------------------------------------------------------
+// Sort s serves plane sort_plane(s) AND the line of the axis that is not in its key (line index sort_plane(s), axis vm_line_ax).  A
+// workgroup keeps that line's integer table for ONE grid in LDS: n x 16 nlw x 8 bytes, nlw = channel groups (of 16) per workgroup.
+// nlw = C / 16 when that fits beside the wave records, else 1 (the sort is then walked once per channel group: blockIdx-level "z").
+constexpr int FUSED_LDS_LIMIT = 160 * 1024 - 1024;
+constexpr int FUSED_REC_BYTES = 12 * 64 * 4;   // sizeof(WaveRec)
+struct FusedPlan {
+  bool ok;
+  int nw;          // waves per workgroup (16 or 8)
+  int nlw[3];      // channel groups per workgroup, per sort
+  int ncombo;      // (sort, z) pairs
+  int combo_s[9], combo_z[9], combo_first[3];
+  int entries[3];  // table entries per workgroup, per sort
+  int entries_max;
+  int lds_bytes;
+};
+__host__ __device__ constexpr int fused_line_axis(int s) { return 2 - (s == 0 ? 1 : s == 1 ? 0 : 2); }   // vm_line_ax(sort_plane(s))
+
+inline FusedPlan fused_plan(const int32_t res[3], int C) {
+  FusedPlan P{};
+  const int NL = C / 16;
+  int forced = 0;
+  if (const char* e = getenv("EGO_FUSED_NW")) forced = atoi(e);   // experiments: 16, 12 or 8 waves per workgroup
+  for (int nw : {16, 12, 8}) {
+    if (forced && nw != forced && nw != 8) continue;
+    P.nw = nw;
+    P.ok = true;
+    P.ncombo = 0;
+    P.entries_max = 0;
+    const int room = FUSED_LDS_LIMIT - nw * FUSED_REC_BYTES - 64;
+    for (int s = 0; s < 3; ++s) {
+      const int n = res[fused_line_axis(s)];
+      int nlw = NL;
+      if ((int64_t)n * 16 * nlw * 8 > (nw >= 12 ? 72 * 1024 : room)) nlw = 1;     // many waves: keep the table <= 72 KB (two sorts of the headline grid qualify)
+      if ((int64_t)n * 16 * nlw * 8 > room) P.ok = false;
+      P.nlw[s] = nlw;
+      P.entries[s] = n * 16 * nlw;
+      P.entries_max = P.entries[s] > P.entries_max ? P.entries[s] : P.entries_max;
+      P.combo_first[s] = P.ncombo;
+      for (int z = 0; z < NL / nlw; ++z) { P.combo_s[P.ncombo] = s; P.combo_z[P.ncombo] = z; ++P.ncombo; }
+    }
+    P.lds_bytes = P.entries_max * 8 + nw * FUSED_REC_BYTES + 64;
+    if (P.ok) return P;
+  }
+  return P;
+}
 
 SortGeom make_geom(const int32_t res[3], int64_t M) {
   SortGeom G{};
@@ -89,8 +154,21 @@ SortGeom make_geom(const int32_t res[3], int64_t M) {
   for (int s = 0; s < 3; ++s) { G.hist[s] = a; a = align256(a + 4 * ((int64_t)RADIX * G.nblocks + RADIX)); }   // + the digit totals
   // scatter phase
   int64_t b = o;
-  for (int s = 0; s < 3; ++s) { G.cellbuf[s] = b; b = align256(b + 4 * (int64_t)G.K[s] * 4 * CMAX); }
+  // cell buffer: only cells that hold samples are ever written or read - at most min(K, M) of them (K x 4 x 48 floats was
+  // 1.2 GB on the [300, 346, 1036] grid whatever the batch)
+  G.dense_cells = (int64_t)kmax <= M;
+  for (int s = 0; s < 3; ++s) {
+    G.cell_slots[s] = G.dense_cells ? G.K[s] : (uint32_t)M;   // sparse: slot = the cell's first sorted position (< M, distinct per non-empty cell)
+    G.cellbuf[s] = b; b = align256(b + 4 * (int64_t)G.cell_slots[s] * 4 * CMAX);
+  }
   for (int s = 0; s < 3; ++s) { G.linepart[s] = b; b = align256(b + 4 * (int64_t)G.nsub_max * 2 * CMAX); }
+  // fused form (shares the line-partial region's place in time, not its bytes: both forms are sized so that either can run)
+  G.fx = b; b = align256(b + 256);
+  {
+    const FusedPlan P = fused_plan(res, CMAX);   // the appearance field's plan has the larger tables
+    G.fpart_stride = P.ok ? P.entries_max : 0;
+    G.fpart = b; b = align256(b + 8 * G.fpart_stride * FUSED_MAX_WG);
+  }
   G.total = a > b ? a : b;
   return G;
 }
@@ -326,7 +404,11 @@ struct SortedArgs {
   float* cellbuf[3];
   float* linepart[3];
   uint32_t K[3], LC[3];
+  int dense_cells;
 };
+
+// where cell k of sort s keeps its four corner sums (only called for cells that hold samples)
+__device__ __forceinline__ int64_t cell_slot(const SortedArgs& A, int s, uint32_t k) { return A.dense_cells ? (int64_t)k : (int64_t)A.start[s][k]; }
 
 // fold the four 16-lane groups of a wave: lanes 0..15 end up with (g0 + g1) + (g2 + g3)
 __device__ __forceinline__ float fold_groups(float v) {
@@ -448,7 +530,7 @@ __device__ __forceinline__ void sorted_plane(const SortedArgs& A, WaveRec& R) {
     wave_sync();   // the next batch overwrites the record
   }
   if (n_mine) {
-    float* out = A.cellbuf[S_] + (int64_t)k * 4 * C + c16;
+    float* out = A.cellbuf[S_] + cell_slot(A, S_, k) * 4 * C + c16;
 #pragma unroll
     for (int i = 0; i < NL; ++i)
 #pragma unroll
@@ -484,7 +566,7 @@ __device__ __forceinline__ void sorted_plane_final(const SortedArgs& A) {
     const int cmaj = sort_major(S_) == AX ? cx : cy, cmin = sort_major(S_) == AX ? cy : cx;
     const uint32_t k = ((uint32_t)g * (uint32_t)nmaj1 + (uint32_t)cmaj) * (uint32_t)nmin1 + (uint32_t)cmin;
     sum[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (A.start[S_][k + 1] != A.start[S_][k]) sum[t] = *(const f32x4*)(A.cellbuf[S_] + ((int64_t)k * 4 + t) * C + 4 * c4);
+    if (A.start[S_][k + 1] != A.start[S_][k]) sum[t] = *(const f32x4*)(A.cellbuf[S_] + (cell_slot(A, S_, k) * 4 + t) * C + 4 * c4);
   }
   const f32x4 r = (sum[0] + sum[1]) + (sum[2] + sum[3]);
   *(f32x4*)((g ? A.G.plane[1][I] : A.G.plane[0][I]) + ((int64_t)ty * W + tx) * C + 4 * c4) = r;
@@ -649,6 +731,324 @@ __global__ void k_sorted_line_final(SortedArgs A) {
   else sorted_line_final<C, 2>(A);
 }
 
+// =====================================================================================================================================
+// Fused form (round 6): planes + the line of the third axis in one pass over d
+// =====================================================================================================================================
+// Fixed-point unit of the line sums of one scatter call.  |contribution| = |d| |plane value| |line weight| < 2^(eD + eP + 1) with
+// max |d| < 2^eD and max |plane texel| < 2^eP (the interpolated plane value is a convex combination of texels; the + 1 covers its
+// rounding).  A texel adds at most M contributions, so with unit 2^k, k = eD + eP + 1 - nbits, nbits = min(50, 62 - ceil(log2 M)), the
+// integer sums stay below 2^62.  Conversion: t = fma((double)gl, (double)lw, 1.5 * 2^(52 + k)) rounds the EXACT product to a multiple
+// of 2^k (round to nearest even), and bits(t) - bits(1.5 * 2^(52 + k)) is that multiple as a signed integer (|q| < 2^51).
+struct FxScale {
+  uint32_t pmax_bits[3];   // max |texel| of plane I over both grids (float bits; NaN / Inf compare above every finite value)
+  uint32_t dmax_bits;      // max |d|
+  uint32_t poison;         // a non-finite input: the line gradients are NaN (as a float sum's would be)
+  uint32_t pad_[3];
+  double magic[3];         // per plane / line index I
+  double lsb[3];
+};
+
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, d, 64));
+  return v;
+}
+
+// max |x| over n floats (n a multiple of 4, 16-byte aligned) as float bits -> atomicMax(out)
+__device__ __forceinline__ void absmax_range(const float* __restrict__ x, int64_t n, uint32_t* out) {
+  uint32_t m = 0;
+  const int64_t n4 = n >> 2;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    const u4 v = ((const u4*)x)[i];
+    m = max(max(m, v.x & 0x7fffffffu), max(v.y & 0x7fffffffu, max(v.z & 0x7fffffffu, v.w & 0x7fffffffu)));
+  }
+  for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    m = max(m, __float_as_uint(x[i]) & 0x7fffffffu);
+  m = wave_max_u32(m);
+  if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+}
+
+struct AbsmaxArgs {
+  const float* plane[2][3];
+  int64_t n_plane[3];
+  const float* d;      // nullptr: dmax comes from the caller
+  int64_t n_d;         // floats of d that are all valid (whole 32-sample tiles of a blocked dv; M for dfeat)
+  int32_t tail_rows;   // blocked dv only: valid samples of the last, partial tile (its other rows are uninitialised memory)
+  int32_t tail_block;  // floats per tile (32 x 3 C)
+  FxScale* fx;
+};
+
+// blockIdx.y = 0..5: plane (g, I); 6: d
+__global__ __launch_bounds__(256) void k_fx_absmax(AbsmaxArgs A) {
+  const int y = blockIdx.y;
+  if (y < 6) {
+    absmax_range(A.plane[y / 3][y % 3], A.n_plane[y % 3], &A.fx->pmax_bits[y % 3]);
+  } else if (A.d) {
+    absmax_range(A.d, A.n_d, &A.fx->dmax_bits);
+    if (A.tail_rows && blockIdx.x == 0) {   // [plane * 3 + line][sample j][16]: rows j < tail_rows
+      uint32_t m = 0;
+      for (int i = threadIdx.x; i < A.tail_block; i += blockDim.x)
+        if (((i >> 4) & 31) < A.tail_rows) m = max(m, __float_as_uint(A.d[A.n_d + i]) & 0x7fffffffu);
+      m = wave_max_u32(m);
+      if ((threadIdx.x & 63) == 0 && m) atomicMax(&A.fx->dmax_bits, m);
+    }
+  }
+}
+
+__global__ void k_fx_setup(FxScale* fx, int64_t M, const float* dmax_ext) {
+  if (threadIdx.x || blockIdx.x) return;
+  uint32_t db = fx->dmax_bits;
+  if (dmax_ext) db = __float_as_uint(*dmax_ext) & 0x7fffffffu;
+  int lg = 1;
+  while (((int64_t)1 << lg) < M && lg < 40) ++lg;
+  const int nbits = min(50, 62 - lg);
+  uint32_t poison = (db >= 0x7f800000u) ? 1u : 0u;
+  for (int i = 0; i < 3; ++i) {
+    const uint32_t pb = fx->pmax_bits[i];
+    if (pb >= 0x7f800000u) poison = 1u;
+    // x < 2^(e - 126) for the biased exponent e of x (normal or subnormal: e = 0 -> x < 2^-126)
+    const int eD = (int)(db >> 23) - 126, eP = (int)(pb >> 23) - 126;
+    int k = eD + eP + 1 - nbits;
+    k = max(k, -1000);                    // (all-zero inputs: any unit will do)
+    fx->magic[i] = ldexp(1.5, 52 + k);
+    fx->lsb[i] = ldexp(1.0, k);
+  }
+  fx->poison = poison;
+}
+
+// first k in [lo, hi] with a[k] >= target, given a[hi] >= target; 64-ary search by one wave (three dependent round trips for 2^18 keys)
+__device__ __forceinline__ uint32_t wave_lower_bound(const uint32_t* __restrict__ a, uint32_t lo, uint32_t hi, uint32_t target) {
+  const uint32_t lane = threadIdx.x & 63;
+  while (hi > lo) {
+    const uint32_t span = hi - lo, step = (span + 63) / 64;
+    const uint32_t idx = lo + lane * step;
+    const bool ge = idx < hi ? a[idx] >= target : true;
+    const unsigned long long m = __ballot(ge);
+    if (m == 0ull) { lo = lo + 63 * step + 1; continue; }
+    const uint32_t f = (uint32_t)__ffsll((long long)m) - 1u;
+    hi = min(hi, lo + f * step);
+    if (f > 0) lo = lo + (f - 1) * step + 1;
+  }
+  return lo;
+}
+
+struct FusedArgs {
+  SortedArgs A;
+  const FxScale* fx;
+  unsigned long long* part;   // [workgroup][part_stride]
+  uint32_t part_stride;
+  int32_t ncombo;
+  int32_t wg_off[10];         // combo c owns workgroups [wg_off[c], wg_off[c + 1])
+  int8_t combo_s[9], combo_z[9];
+  int8_t nlw[3], combo_first[3];
+};
+
+// workgroups of a combo that serve grid 0: in proportion to the samples (a grid without samples gets none, any other at least one)
+__device__ __forceinline__ uint32_t fused_split(uint32_t nwg, uint32_t n_g0, uint32_t n_tot) {
+  if (n_g0 == 0) return 0;
+  if (n_g0 == n_tot) return nwg;
+  const uint32_t r = (uint32_t)(((uint64_t)nwg * n_g0 + n_tot / 2) / n_tot);
+  return min(max(r, 1u), nwg - 1);
+}
+
+// One workgroup = one contiguous share of ONE grid's sorted samples of sort S_ (whole cells).  Waves take quads of four consecutive
+// cells in turn; a quad is processed exactly as in sorted_plane (stage 1: lane = sample -> record; stage 2: 16-lane group = cell, lane =
+// channel, U samples in flight), plus: the cell's four plane texels are loaded once per cell, the sample's plane value pv = sum_c
+// texel_c w_c follows from them, and gl = d pv goes - as two fixed-point integers, weights lw0 / lw1 - to the LDS table entries of the
+// sample's two line texels (ds_add_u64; integer sums do not depend on the order).
+template <int C, bool DENS, int S_, int NLW, int NW, int U>
+__device__ __forceinline__ void sorted_fused(const FusedArgs& F, const int combo, const int z, unsigned long long* __restrict__ tab, WaveRec& R, uint32_t* sh) {
+#pragma clang fp contract(fast)
+  constexpr int NL = C / 16, I = sort_plane(S_);
+  constexpr int AX = vm_plane_x(I), AY = vm_plane_y(I), AL = vm_line_ax(I);
+  static_assert(AL != sort_major(S_) && AL != sort_minor(S_), "the fused line is the one whose axis is not in the sort key");
+  const SortedArgs& A = F.A;
+  const int lane = threadIdx.x & 63, c16 = lane & 15, q = lane >> 4, wave = threadIdx.x >> 6;
+  const int ig0 = z * NLW;
+  const int W = A.F.res[AX], H = A.F.res[AY], NLn = A.F.res[AL];
+  const int entries = NLn * 16 * NLW;
+  for (int i = threadIdx.x; i < entries; i += NW * 64) tab[i] = 0ull;
+  // this workgroup's grid and share
+  const uint32_t K = A.K[S_], Kh = K / 2;
+  const uint32_t n_g0 = A.start[S_][Kh], n_tot = A.start[S_][K];
+  const uint32_t nwg = (uint32_t)(F.wg_off[combo + 1] - F.wg_off[combo]), b = blockIdx.x - (uint32_t)F.wg_off[combo];
+  const uint32_t nwg0 = fused_split(nwg, n_g0, n_tot);
+  const int g = b >= nwg0 ? 1 : 0;
+  const uint32_t bl = g ? b - nwg0 : b, nb = g ? nwg - nwg0 : nwg0;
+  const uint32_t gs = g ? n_g0 : 0u, ge = g ? n_tot : n_g0;
+  const uint32_t s_lo = gs + (uint32_t)((uint64_t)(ge - gs) * bl / nb), s_hi = gs + (uint32_t)((uint64_t)(ge - gs) * (bl + 1) / nb);
+  if (wave < 2) {
+    const uint32_t kk = wave_lower_bound(A.start[S_], (uint32_t)g * Kh, (uint32_t)(g + 1) * Kh, wave ? s_hi : s_lo);
+    if (lane == 0) sh[wave] = kk;
+  }
+  __syncthreads();
+  const uint32_t kA = sh[0], kB = sh[1];
+  const int nmin1 = A.F.res[sort_minor(S_)] + 1, nmaj1 = A.F.res[sort_major(S_)] + 1;
+  const float* Pg = (g ? A.F.plane[1][I] : A.F.plane[0][I]) + c16 + 16 * ig0;
+  const float* L = (g ? A.F.line[1][I] : A.F.line[0][I]) + c16 + 16 * ig0;
+  const double magic = F.fx->magic[I];
+  const long long magic_bits = __double_as_longlong(magic);
+  const uint32_t n_any = n_tot ? n_tot - 1 : 0;
+  const uint32_t nquads = (kB - kA + 3) / 4;
+  for (uint32_t j = (uint32_t)wave; j < nquads; j += NW) {
+    const uint32_t k_raw = kA + 4 * j + (uint32_t)q;
+    const bool cell_ok = k_raw < kB;
+    const uint32_t k = cell_ok ? k_raw : kB - 1;
+    const uint32_t a = A.start[S_][k], bnd = cell_ok ? A.start[S_][k + 1] : a;
+    const uint32_t n_mine = bnd - a;
+    uint32_t n_max = max(n_mine, (uint32_t)__shfl_xor((int)n_mine, 16, 64));
+    n_max = max(n_max, (uint32_t)__shfl_xor((int)n_max, 32, 64));
+    if (n_max == 0) continue;
+    const int cmin = (int)(k % (uint32_t)nmin1), cmaj = (int)((k / (uint32_t)nmin1) % (uint32_t)nmaj1);
+    const int cX = sort_major(S_) == AX ? cmaj : cmin, cY = sort_major(S_) == AY ? cmaj : cmin;
+    const int x0 = max(cX - 1, 0), x1 = min(cX, W - 1), y0 = max(cY - 1, 0), y1 = min(cY, H - 1);   // the clamped tap indices of lin_setup
+    const int oP[4] = {(y0 * W + x0) * C, (y0 * W + x1) * C, (y1 * W + x0) * C, (y1 * W + x1) * C};
+    float pt[NLW][4];   // the cell's four plane texels: the same for every sample of the cell
+#pragma unroll
+    for (int i = 0; i < NLW; ++i)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) pt[i][c] = Pg[oP[c] + 16 * i];
+    float acc[NLW][4];
+#pragma unroll
+    for (int i = 0; i < NLW; ++i) acc[i][0] = acc[i][1] = acc[i][2] = acc[i][3] = 0.f;
+    for (uint32_t off = 0; off < n_max; off += 16) {
+      const int cnt = off < n_mine ? (int)min(16u, n_mine - off) : 0;
+      {   // stage 1: lane 16 q + j = sample j of cell q's batch (clamped to a valid entry; unused records are never read as data)
+        const uint32_t last = n_mine ? bnd - 1 : n_any;
+        const uint32_t pidx = min(a + off + (uint32_t)c16, last);
+        const uint32_t m = A.perm[S_][pidx];
+        const f32x4 cc = ((const f32x4*)A.coords)[m];
+        const float ax[3] = {cc.x, cc.y, cc.z};
+        const Lin1 X = lin_setup(ax[AX], W), Y = lin_setup(ax[AY], H), Ln = lin_setup(ax[AL], NLn);
+        R.f[0][lane] = m;
+        R.f[1][lane] = __float_as_uint(__fmul_rn(Y.w0, X.w0)); R.f[2][lane] = __float_as_uint(__fmul_rn(Y.w0, X.w1));
+        R.f[3][lane] = __float_as_uint(__fmul_rn(Y.w1, X.w0)); R.f[4][lane] = __float_as_uint(__fmul_rn(Y.w1, X.w1));
+        R.f[5][lane] = (uint32_t)Ln.i0; R.f[6][lane] = (uint32_t)Ln.i1;
+        R.f[7][lane] = __float_as_uint(Ln.w0); R.f[8][lane] = __float_as_uint(Ln.w1);
+        if (DENS) R.f[9][lane] = __float_as_uint(A.d[m]);
+      }
+      wave_sync();
+      int cnt_max = max(cnt, __shfl_xor(cnt, 16, 64));
+      cnt_max = max(cnt_max, __shfl_xor(cnt_max, 32, 64));
+      for (int t0 = 0; t0 < cnt_max; t0 += U) {   // stage 2: lane = channel of group q's sample t
+        float w4[U][4], lw[U][2], di[U][NLW], l0[U][NLW], l1[U][NLW];
+        int iL0[U], iL1[U];
+        bool ok[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int t = t0 + u;
+          ok[u] = t < cnt;
+          const int tt = 16 * q + (ok[u] ? t : 0);
+          const int64_t m = R.f[0][tt];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) w4[u][c] = __uint_as_float(R.f[1 + c][tt]);
+          iL0[u] = (int)R.f[5][tt]; iL1[u] = (int)R.f[6][tt];
+          lw[u][0] = __uint_as_float(R.f[7][tt]); lw[u][1] = __uint_as_float(R.f[8][tt]);
+#pragma unroll
+          for (int i = 0; i < NLW; ++i) { l0[u][i] = L[iL0[u] * C + 16 * i]; l1[u][i] = L[iL1[u] * C + 16 * i]; }
+          if (DENS) {
+            di[u][0] = __uint_as_float(R.f[9][tt]);
+          } else {
+#pragma unroll
+            for (int i = 0; i < NLW; ++i) di[u][i] = A.d[(m >> 5) * (32 * 3 * C) + (I * NL + ig0 + i) * 512 + (m & 31) * 16 + c16];   // k_shade_bwd's blocked dv
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          float lv[NLW], pv[NLW], dd[NLW];
+#pragma unroll
+          for (int i = 0; i < NLW; ++i) {
+            lv[i] = l0[u][i] * lw[u][0] + l1[u][i] * lw[u][1];
+            pv[i] = pt[i][0] * w4[u][0] + pt[i][1] * w4[u][1] + pt[i][2] * w4[u][2] + pt[i][3] * w4[u][3];
+          }
+          if (DENS) {
+            // relu per plane (EgoNeRF.py:340,346): the gradient passes where this plane's sum over channels is positive
+            float dot = pv[0] * lv[0];
+#pragma unroll
+            for (int sh_ = 8; sh_ >= 1; sh_ >>= 1) dot += __shfl_xor(dot, sh_, 16);
+            dd[0] = (ok[u] && dot > 0.f) ? di[u][0] : 0.f;
+          } else {
+#pragma unroll
+            for (int i = 0; i < NLW; ++i) dd[i] = ok[u] ? di[u][i] : 0.f;
+          }
+          const double lw0 = (double)lw[u][0], lw1 = (double)lw[u][1];
+          unsigned long long* t0p = tab + iL0[u] * (16 * NLW) + c16;
+          unsigned long long* t1p = tab + iL1[u] * (16 * NLW) + c16;
+#pragma unroll
+          for (int i = 0; i < NLW; ++i) {
+            const float gp = dd[i] * lv[i];
+            acc[i][0] += gp * w4[u][0]; acc[i][1] += gp * w4[u][1]; acc[i][2] += gp * w4[u][2]; acc[i][3] += gp * w4[u][3];
+            const double gl = (double)__fmul_rn(dd[i], pv[i]);
+            const long long q0 = __double_as_longlong(__fma_rn(gl, lw0, magic)) - magic_bits;
+            const long long q1 = __double_as_longlong(__fma_rn(gl, lw1, magic)) - magic_bits;
+            if (ok[u]) {
+              __hip_atomic_fetch_add(t0p + 16 * i, (unsigned long long)q0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              __hip_atomic_fetch_add(t1p + 16 * i, (unsigned long long)q1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+          }
+        }
+      }
+      wave_sync();   // the next batch overwrites the record
+    }
+    if (n_mine) {
+      float* out = A.cellbuf[S_] + cell_slot(A, S_, k) * 4 * C + c16 + 16 * ig0;
+#pragma unroll
+      for (int i = 0; i < NLW; ++i)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) out[t * C + 16 * i] = acc[i][t];
+    }
+  }
+  __syncthreads();
+  unsigned long long* out = F.part + (int64_t)blockIdx.x * F.part_stride;
+  for (int i = threadIdx.x; i < entries; i += NW * 64) out[i] = tab[i];
+}
+
+// NW waves per workgroup, U samples in flight per 16-lane group: the 48-channel walk holds 3 x (line taps 2, d 1, plane texels 4, sums 4)
+// values per sample in flight - 144 VGPRs at U = 4 (three waves per SIMD: NW = 12), 128 at U = 2 (four: NW = 16)
+template <int C, bool DENS, int NW, int U>
+__global__ __launch_bounds__(NW * 64) void k_sorted_fused(FusedArgs F) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char fused_lds[];
+  WaveRec* rec = (WaveRec*)fused_lds;
+  uint32_t* sh = (uint32_t*)(fused_lds + NW * sizeof(WaveRec));
+  unsigned long long* tab = (unsigned long long*)(fused_lds + NW * sizeof(WaveRec) + 64);
+  WaveRec& R = rec[threadIdx.x >> 6];
+  constexpr int NL = C / 16;
+  int combo = 0;
+  while (combo + 1 < F.ncombo && (int)blockIdx.x >= F.wg_off[combo + 1]) ++combo;
+  const int s = F.combo_s[combo], z = F.combo_z[combo];
+  const bool whole = F.nlw[s] == NL;
+#define EGO_FUSED(S_)                                                              \
+  if (whole) sorted_fused<C, DENS, S_, NL, NW, U>(F, combo, z, tab, R, sh);        \
+  else sorted_fused<C, DENS, S_, 1, NW, U>(F, combo, z, tab, R, sh)
+  if (s == 0) { EGO_FUSED(0); } else if (s == 1) { EGO_FUSED(1); } else { EGO_FUSED(2); }
+#undef EGO_FUSED
+}
+
+// line texel (g, t, ch) of line I = sort_plane(s): the integer sums of the workgroups that served grid g, converted once
+template <int C>
+__global__ void k_fused_line_final(FusedArgs F) {
+  constexpr int NL = C / 16;
+  const SortedArgs& A = F.A;
+  const int s = blockIdx.y, I = s == 0 ? 1 : s == 1 ? 0 : 2, AL = 2 - I;
+  const int n = A.F.res[AL];
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= 2 * n * C) return;
+  const int ch = idx % C, t = (idx / C) % n, g = idx / (C * n);
+  const bool whole = F.nlw[s] == NL;
+  const int combo = F.combo_first[s] + (whole ? 0 : ch / 16);
+  const int entry = whole ? t * C + ch : t * 16 + (ch & 15);
+  const uint32_t K = A.K[s], n_g0 = A.start[s][K / 2], n_tot = A.start[s][K];
+  const uint32_t nwg = (uint32_t)(F.wg_off[combo + 1] - F.wg_off[combo]);
+  const uint32_t nwg0 = fused_split(nwg, n_g0, n_tot);
+  const uint32_t b0 = g ? nwg0 : 0u, b1 = g ? nwg : nwg0;
+  long long sum = 0;
+  const unsigned long long* p = F.part + (int64_t)F.wg_off[combo] * F.part_stride + entry;
+  for (uint32_t b = b0; b < b1; ++b) sum += (long long)p[(int64_t)b * F.part_stride];
+  const float v = F.fx->poison ? __uint_as_float(0x7fc00000u) : (float)((double)sum * F.fx->lsb[I]);
+  (g ? A.G.line[1][I] : A.G.line[0][I])[t * C + ch] = v;
+}
+
 int fill_args(const ego_vm_field& f, const ego_vm_grad* grad, const float* coords, const float* d, const SortGeom& G, void* ws, SortedArgs* a, const char* who) {
   if (!grad) return ego_fail(EGO_E_BADARG, "%s: null gradient struct", who);
   for (int g = 0; g < 2; ++g)
@@ -668,6 +1068,7 @@ int fill_args(const ego_vm_field& f, const ego_vm_grad* grad, const float* coord
     a->linepart[s] = (float*)(base + G.linepart[s]);
     a->K[s] = G.K[s]; a->LC[s] = G.LC[s];
   }
+  a->dense_cells = G.dense_cells ? 1 : 0;
   return EGO_OK;
 }
 
@@ -691,6 +1092,117 @@ int launch_sorted(const SortedArgs& a, const SortGeom& G, hipStream_t st) {
   if (int e = ego_launch_status("k_sorted_plane_final")) return e;
   k_sorted_line_final<C><<<dim3((unsigned)((linemax + 255) / 256), 3), 256, 0, st>>>(a);
   return ego_launch_status("k_sorted_line_final");
+}
+
+int device_cus() {
+  static std::atomic<int> cus_of[16];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
+  int cus = cus_of[dev].load(std::memory_order_relaxed);
+  if (!cus) {
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    cus_of[dev].store(cus, std::memory_order_relaxed);
+  }
+  return cus;
+}
+
+// may this call take the fused form?  (the plan of the widest field sized the workspace; EGO_SORTED_LINES=separate keeps the two-pass form)
+bool fused_wanted(const int32_t res[3], int C, FusedPlan* P) {
+  if (const char* e = getenv("EGO_SORTED_LINES"))
+    if (e[0] == 's') return false;
+  if (!fused_plan(res, CMAX).ok) return false;
+  *P = fused_plan(res, C);
+  return P->ok;
+}
+
+template <int C, bool DENS, int NW, int U>
+int launch_fused_nw(const FusedArgs& F, int wg_total, int lds_bytes, hipStream_t st) {
+  static std::atomic<int> attr_set{0};
+  if (attr_set.load(std::memory_order_relaxed) < lds_bytes) {
+    if (const hipError_t e = hipFuncSetAttribute((const void*)k_sorted_fused<C, DENS, NW, U>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes))
+      return ego_fail((int)e, "k_sorted_fused: cannot reserve %d bytes of LDS: %s", lds_bytes, hipGetErrorString(e));
+    attr_set.store(lds_bytes, std::memory_order_relaxed);
+  }
+  k_sorted_fused<C, DENS, NW, U><<<wg_total, NW * 64, lds_bytes, st>>>(F);
+  return ego_launch_status("k_sorted_fused");
+}
+
+template <int C, bool DENS>
+int launch_fused(const SortedArgs& a, const SortGeom& G, const FusedPlan& P, char* base, int64_t M, const float* dmax_ext, hipStream_t st) {
+  FxScale* fx = (FxScale*)(base + G.fx);
+  if (const hipError_t e = hipMemsetAsync(fx, 0, 256, st)) return ego_fail((int)e, "scatter_sorted: hipMemsetAsync failed: %s", hipGetErrorString(e));
+  AbsmaxArgs ab{};
+  for (int g = 0; g < 2; ++g)
+    for (int i = 0; i < 3; ++i) ab.plane[g][i] = a.F.plane[g][i];
+  for (int i = 0; i < 3; ++i) ab.n_plane[i] = (int64_t)G.res[i == 2 ? 1 : 0] * G.res[i == 0 ? 1 : 2] * C;
+  ab.fx = fx;
+  if (!dmax_ext) {
+    ab.d = a.d;
+    if (DENS) { ab.n_d = M; }
+    else { ab.n_d = (M / 32) * (32 * 3 * C); ab.tail_rows = (int32_t)(M % 32); ab.tail_block = 32 * 3 * C; }
+  }
+  k_fx_absmax<<<dim3(96, 7), 256, 0, st>>>(ab);
+  if (int e = ego_launch_status("k_fx_absmax")) return e;
+  k_fx_setup<<<1, 64, 0, st>>>(fx, M, dmax_ext);
+  if (int e = ego_launch_status("k_fx_setup")) return e;
+  FusedArgs F{};
+  F.A = a; F.fx = fx;
+  F.part = (unsigned long long*)(base + G.fpart);
+  F.part_stride = (uint32_t)G.fpart_stride;
+  F.ncombo = P.ncombo;
+  // workgroups per (sort, channel group): one workgroup per CU in all, dealt in proportion to the work (a whole-field walk does NL
+  // channel groups per set-up, a split one does one)
+  int wg_total = device_cus();
+  if (wg_total > FUSED_MAX_WG) wg_total = FUSED_MAX_WG;
+  if (wg_total < 2 * P.ncombo) wg_total = 2 * P.ncombo;
+  int wsum = 0, wgt[9];
+  for (int c = 0; c < P.ncombo; ++c) { wgt[c] = P.nlw[P.combo_s[c]] + 1; wsum += wgt[c]; }
+  int off = 0, wacc = 0;
+  for (int c = 0; c < P.ncombo; ++c) {
+    F.wg_off[c] = off;
+    F.combo_s[c] = (int8_t)P.combo_s[c]; F.combo_z[c] = (int8_t)P.combo_z[c];
+    wacc += wgt[c];
+    int end = (int)((int64_t)wg_total * wacc / wsum);
+    const int left = P.ncombo - 1 - c;
+    if (end < off + 2) end = off + 2;
+    if (end > wg_total - 2 * left) end = wg_total - 2 * left;
+    off = end;
+  }
+  F.wg_off[P.ncombo] = off;
+  for (int s = 0; s < 3; ++s) { F.nlw[s] = (int8_t)P.nlw[s]; F.combo_first[s] = (int8_t)P.combo_first[s]; }
+  {
+    int e;
+    if (P.nw == 16) e = launch_fused_nw<C, DENS, 16, (C > 16 ? 2 : 4)>(F, off, P.lds_bytes, st);
+    else if (P.nw == 12) e = launch_fused_nw<C, DENS, 12, 4>(F, off, P.lds_bytes, st);
+    else e = launch_fused_nw<C, DENS, 8, 4>(F, off, P.lds_bytes, st);
+    if (e) return e;
+  }
+  int64_t texmax = 0, linemax = 0;
+  for (int s = 0; s < 3; ++s) {
+    const int I = sort_plane(s);
+    const int64_t tex = (int64_t)2 * G.res[I == 2 ? 1 : 0] * G.res[I == 0 ? 1 : 2] * (C / 4);
+    texmax = tex > texmax ? tex : texmax;
+    const int64_t ln = (int64_t)2 * G.res[fused_line_axis(s)] * C;
+    linemax = ln > linemax ? ln : linemax;
+  }
+  k_sorted_plane_final<C><<<dim3((unsigned)((texmax + 255) / 256), 3), 256, 0, st>>>(a);
+  if (int e = ego_launch_status("k_sorted_plane_final")) return e;
+  k_fused_line_final<C><<<dim3((unsigned)((linemax + 255) / 256), 3), 256, 0, st>>>(F);
+  return ego_launch_status("k_fused_line_final");
+}
+
+// an empty batch: no sample, so every gradient texel is 0 - and "every texel is written" holds for it too (the tables
+// come from torch.empty in the sorted mode)
+int zero_tables(const ego_vm_field& f, const ego_vm_grad* grad, int C, hipStream_t st, const char* who) {
+  if (!grad) return ego_fail(EGO_E_BADARG, "%s: null gradient struct", who);
+  for (int g = 0; g < 2; ++g)
+    for (int i = 0; i < 3; ++i) {
+      if (!grad->plane[g][i] || !grad->line[g][i]) return ego_fail(EGO_E_BADARG, "%s: null table", who);
+      const size_t np = (size_t)f.res[i == 2 ? 1 : 0] * f.res[i == 0 ? 1 : 2] * C * 4, nl = (size_t)f.res[2 - i] * C * 4;
+      if (const hipError_t e = hipMemsetAsync(grad->plane[g][i], 0, np, st)) return ego_fail((int)e, "%s: hipMemsetAsync failed: %s", who, hipGetErrorString(e));
+      if (const hipError_t e = hipMemsetAsync(grad->line[g][i], 0, nl, st)) return ego_fail((int)e, "%s: hipMemsetAsync failed: %s", who, hipGetErrorString(e));
+    }
+  return EGO_OK;
 }
 
 int check_sizes(const ego_scene* sc, int64_t N, int32_t S, const char* who) {
@@ -767,26 +1279,30 @@ int ego_scatter_density_sorted(const ego_scene* sc, const ego_vm_grad* gdensity,
   EGO_TRACE("ego_scatter_density_sorted");
   if (int e = check_sizes(sc, N, S, "scatter_density_sorted")) return e;
   if (sc->density.n_comp != 16) return ego_fail(EGO_E_UNSUPPORTED, "scatter_density_sorted: n_comp %d (supported: 16)", sc->density.n_comp);
-  if (N == 0) return EGO_OK;
+  if (N == 0) return zero_tables(sc->density, gdensity, 16, (hipStream_t)stream, "scatter_density_sorted");
   EGO_REQUIRE(coords && dfeat && workspace, "scatter_density_sorted: null argument");
   const SortGeom G = make_geom(sc->density.res, N * (int64_t)S);
   if (workspace_bytes < G.total) return ego_fail(EGO_E_BADARG, "scatter_density_sorted: workspace too small");
   SortedArgs a{};
   if (int e = fill_args(sc->density, gdensity, coords, dfeat, G, workspace, &a, "scatter_density_sorted")) return e;
+  FusedPlan P;
+  if (fused_wanted(sc->density.res, 16, &P)) return launch_fused<16, true>(a, G, P, (char*)workspace, N * (int64_t)S, nullptr, (hipStream_t)stream);
   return launch_sorted<16, true>(a, G, (hipStream_t)stream);
 }
 
-int ego_scatter_app_sorted(const ego_scene* sc, const ego_vm_grad* gapp, const float* coords, const float* dv, int64_t N, int32_t S,
-                           void* workspace, int64_t workspace_bytes, void* stream) {
+int ego_scatter_app_sorted(const ego_scene* sc, const ego_vm_grad* gapp, const float* coords, const float* dv, const float* dv_absmax, int64_t N,
+                           int32_t S, void* workspace, int64_t workspace_bytes, void* stream) {
   EGO_TRACE("ego_scatter_app_sorted");
   if (int e = check_sizes(sc, N, S, "scatter_app_sorted")) return e;
   if (sc->app.n_comp != 48) return ego_fail(EGO_E_UNSUPPORTED, "scatter_app_sorted: n_comp %d (supported: 48)", sc->app.n_comp);
-  if (N == 0) return EGO_OK;
+  if (N == 0) return zero_tables(sc->app, gapp, 48, (hipStream_t)stream, "scatter_app_sorted");
   EGO_REQUIRE(coords && dv && workspace, "scatter_app_sorted: null argument");
   const SortGeom G = make_geom(sc->app.res, N * (int64_t)S);
   if (workspace_bytes < G.total) return ego_fail(EGO_E_BADARG, "scatter_app_sorted: workspace too small");
   SortedArgs a{};
   if (int e = fill_args(sc->app, gapp, coords, dv, G, workspace, &a, "scatter_app_sorted")) return e;
+  FusedPlan P;
+  if (fused_wanted(sc->app.res, 48, &P)) return launch_fused<48, false>(a, G, P, (char*)workspace, N * (int64_t)S, dv_absmax, (hipStream_t)stream);
   return launch_sorted<48, false>(a, G, (hipStream_t)stream);
 }
 

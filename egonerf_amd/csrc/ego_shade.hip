@@ -2153,11 +2153,15 @@ int ego_march_backward(const ego_scene* sc, const float* z, const float* alpha, 
 }
 
 int ego_shade_backward(const ego_scene* sc, const float* train_packed, const float* coords, float* dc, const float* rgb,
-                       const ego_shade_dump* fwd, uint16_t* dh2, uint16_t* dh1, float* dh_scale, float* dfe, float* dv, int64_t N, int32_t S,
-                       void* stream) {
+                       const ego_shade_dump* fwd, uint16_t* dh2, uint16_t* dh1, float* dh_scale, float* dfe, float* dv, float* dv_absmax, int64_t N,
+                       int32_t S, void* stream) {
   EGO_TRACE("ego_shade_backward");
   EGO_REQUIRE(N >= 0 && S >= 1 && N * (int64_t)S < (1ll << 31), "shade_backward: bad size");
-  if (N == 0) return EGO_OK;
+  if (N == 0) {
+    if (dv_absmax)
+      if (const hipError_t me = hipMemsetAsync(dv_absmax, 0, 4, (hipStream_t)stream)) return ego_fail((int)me, "shade_backward: hipMemsetAsync failed: %s", hipGetErrorString(me));
+    return EGO_OK;
+  }
   EGO_REQUIRE(sc && train_packed && coords && dc && rgb && fwd && fwd->fe && fwd->relu_bits && dh2 && dh1 && dh_scale && dfe && dv,
               "shade_backward: null argument");
   EGO_REQUIRE((((uintptr_t)dh2 | (uintptr_t)dh1 | (uintptr_t)fwd->relu_bits | (uintptr_t)dv) & 15) == 0,
@@ -2166,6 +2170,9 @@ int ego_shade_backward(const ego_scene* sc, const float* train_packed, const flo
   ShadeBwdArgs a{};
   a.tpacked = train_packed; a.coords = coords; a.dc = dc; a.rgb = rgb;
   a.fe = fwd->fe; a.bits = fwd->relu_bits; a.dh2 = dh2; a.dh1 = dh1; a.dh_scale = dh_scale; a.dfe = dfe; a.dv = dv; a.M = N * (int64_t)S;
+  a.dv_absmax = (uint32_t*)dv_absmax;
+  if (dv_absmax)
+    if (const hipError_t me = hipMemsetAsync(dv_absmax, 0, 4, (hipStream_t)stream)) return ego_fail((int)me, "shade_backward: hipMemsetAsync failed: %s", hipGetErrorString(me));
   k_shade_bwd<<<shade_grid(a.M), 512, 0, (hipStream_t)stream>>>(a);
   return ego_launch_status("k_shade_bwd");
 }

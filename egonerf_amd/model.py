@@ -692,7 +692,10 @@ class EgoNeRF(TensorBase):
 
         The struct holds raw device pointers: to the parameter tables (optimiser steps write them in place), and to the pooled density
         tables, which `update_coarse_sigma_grid()` also refreshes IN PLACE while their shapes stand - so a struct returned earlier, or a
-        captured hipGraph that embeds it, reads the refreshed values (what GraphedTrainStep relies on).  A holder that needs a frozen
+        captured hipGraph that embeds it, reads the refreshed values (what GraphedTrainStep relies on).  The packed MLP / basis images
+        are different: a SNAPSHOT taken by this call, one blob per mode (training / inference) - a struct returned earlier keeps reading
+        the weights as of its own pack (a captured graph that contains the pack kernel re-packs on every replay); call scene() again
+        after the weights changed.  A holder that needs a frozen
         snapshot must copy the tables; re-allocation (another shape / device, tables assigned one by one) invalidates the cached
         struct and the next scene() call builds a new one."""
         dev = self.density_plane_yin[0].device
@@ -742,10 +745,16 @@ class EgoNeRF(TensorBase):
         need = lib.ego_packed_floats_scene(C.byref(sc))
         if need <= 0:
             raise RuntimeError("ego_packed_floats_scene rejected the scene")
-        if self._packed is None or self._packed.device != dev or self._packed.numel() != need:
-            self._packed = torch.empty(need, device=dev)
-        _call("ego_pack_mlp_for", sc, self._packed.data_ptr(), int(training), _lib.stream_handle())
-        sc.packed = self._packed.data_ptr()
+        # one blob per mode: a training pack writes only the regions the f16x3 training kernels read, so it must never land
+        # in the blob an earlier INFERENCE struct (or a captured preview-render graph) points to - that holder would mix fresh fp16 main
+        # terms with stale fp8 / fp6 correction terms
+        if self._packed is None:
+            self._packed = {}
+        blob = self._packed.get(bool(training))
+        if blob is None or blob.device != dev or blob.numel() != need:
+            blob = self._packed[bool(training)] = torch.zeros(need, device=dev)
+        _call("ego_pack_mlp_for", sc, blob.data_ptr(), int(training), _lib.stream_handle())
+        sc.packed = blob.data_ptr()
         if self._app_table_dtype == "f16" and not training:
             self._fill_app16(sc)
         if self.use_alpha_mask and self.alphaMask is not None:

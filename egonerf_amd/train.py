@@ -171,6 +171,14 @@ class RenderFunction(torch.autograd.Function):
         dev = rays.device
         # training gathers from the fp32 parameters (the backward re-gathers from them), shades every sample like EgoNeRF.forward (the
         # appearance skip is an inference option) and keeps all three fp16 terms of every product, whatever model.mlp_precision says
+        if model._mlp_precision == "f32" and not model.train_fp32_head and not getattr(model, "_warned_f32_training", False):
+            # mlp_precision is an INFERENCE switch; before r05 a differentiable call with "f32" raised, now it would silently
+            # train through split-fp16 products and half-precision activation dumps - say so once, and say what the real switch is
+            import warnings
+            warnings.warn("EgoNeRF.mlp_precision = 'f32' applies to inference only: the differentiable path runs the f16x3 training kernels "
+                          "(fp16-split MFMA products, half-precision activation dumps).  For fp32 activations and operands in training set "
+                          "model.train_fp32_head = True (or EGO_TRAIN_FP32=1): the parity mode, several times slower.", RuntimeWarning, stacklevel=3)
+            model._warned_f32_training = True
         sc = model.scene(training=True)
         N = rays.shape[0]
         n_coarse, n_fine = opts["n_coarse"], opts["n_fine"]
@@ -345,14 +353,15 @@ class RenderFunction(torch.autograd.Function):
         # dh2 / dh1: scaled fp16 in the kernel's own operand order + one power of two per sample (include/egonerf_hip.h); dv: blocked fp32
         half = lambda *shape: torch.empty(*shape, device=dev, dtype=torch.float16)
         dh2, dh1, dh_scale, dfe, dv = half(Mp, 128), half(Mp, 128), f(2, Mp), f(M, 32), f(Mp, 144)
+        dv_absmax = f(1)   # max |dv|, found by the backward while it holds the values: the sorted scatter's fixed-point unit comes from it
         ds = _lib.ShadeDump(*(_lib.ptr(sv[k]) for k in ("x", "h1", "h2", "v", "relu_bits", "fe")))
         _chk(lib.ego_shade_backward(sc, tp.data_ptr(), sv["coords"].data_ptr(), dc.data_ptr(), sv["rgb"].data_ptr(), C.byref(ds),
-                                          dh2.data_ptr(), dh1.data_ptr(), dh_scale.data_ptr(), dfe.data_ptr(), dv.data_ptr(), N, S, st),
+                                          dh2.data_ptr(), dh1.data_ptr(), dh_scale.data_ptr(), dfe.data_ptr(), dv.data_ptr(), dv_absmax.data_ptr(), N, S, st),
              "ego_shade_backward")
         ga = _grad_struct(g_app)
         if ws is not None:   # (this is the tuned-head path: sorted_app above)
-            on_side(lambda s_: _chk(lib.ego_scatter_app_sorted(sc, C.byref(ga), sv["coords"].data_ptr(), dv.data_ptr(), N, S, ws.data_ptr(), ws.numel(), s_),
-                                    "ego_scatter_app_sorted"))
+            on_side(lambda s_: _chk(lib.ego_scatter_app_sorted(sc, C.byref(ga), sv["coords"].data_ptr(), dv.data_ptr(), dv_absmax.data_ptr(), N, S,
+                                                               ws.data_ptr(), ws.numel(), s_), "ego_scatter_app_sorted"))
         else:
             on_side(lambda s_: _chk(lib.ego_scatter_app(sc, C.byref(ga), sv["coords"].data_ptr(), dv.data_ptr(), N, S, s_), "ego_scatter_app"))
         if side is None:

@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define EGO_ABI_VERSION 14
+#define EGO_ABI_VERSION 15
 
 enum { EGO_PREC_F16X3 = 0, EGO_PREC_F32 = 1, EGO_PREC_F16F8 = 2, EGO_PREC_F16F6 = 3 };
 /* ego_scene.head: the appearance head TensorBase.init_render_func selected (models/tensorBase.py:186-200) */
@@ -345,8 +345,10 @@ int ego_march_backward(const ego_scene* sc, const float* z, const float* alpha, 
  * [tile][plane * 3 + line][sample][16 channels] fp32 (it feeds single table texels, where fp16 rounding would show); all three
  * need ceil(M / 32) * 32 rows.  Reads fwd->fe and fwd->relu_bits only. */
 int ego_shade_backward(const ego_scene* sc, const float* train_packed, const float* coords, float* dc, const float* rgb,
-                       const ego_shade_dump* fwd, uint16_t* dh2, uint16_t* dh1, float* dh_scale, float* dfe, float* dv, int64_t N,
-                       int32_t S, void* stream);
+                       const ego_shade_dump* fwd, uint16_t* dh2, uint16_t* dh1, float* dh_scale, float* dfe, float* dv, float* dv_absmax,
+                       int64_t N, int32_t S, void* stream);
+/* dv_absmax (v15; dev, one float, may be NULL): receives max |dv| over the valid samples (NaN if a sample's gradient is not finite) - the
+ * bound ego_scatter_app_sorted derives the fixed-point unit of its line sums from, so that it need not read dv once more to find it. */
 /* backward of the VM lookups (autograd of F.grid_sample in EgoNeRF.py:291-347 / :349-413): accumulates into the gradient
  * tables (same channel-last layout as the parameters).  coords [N][S][4] = the forward's normalised (r, theta, phi, grid). */
 int ego_scatter_density(const ego_scene* sc, const ego_vm_grad* gdensity, const float* coords, const float* dfeat, int64_t N, int32_t S,
@@ -367,8 +369,19 @@ int64_t ego_scatter_sorted_workspace_bytes(const ego_scene* sc, int64_t N, int32
 int ego_scatter_sort(const ego_scene* sc, const float* coords, int64_t N, int32_t S, void* workspace, int64_t workspace_bytes, void* stream);
 int ego_scatter_density_sorted(const ego_scene* sc, const ego_vm_grad* gdensity, const float* coords, const float* dfeat, int64_t N, int32_t S,
                                void* workspace, int64_t workspace_bytes, void* stream);
-int ego_scatter_app_sorted(const ego_scene* sc, const ego_vm_grad* gapp, const float* coords, const float* dv, int64_t N, int32_t S,
-                           void* workspace, int64_t workspace_bytes, void* stream); /* dv: ego_shade_backward's blocked layout */
+int ego_scatter_app_sorted(const ego_scene* sc, const ego_vm_grad* gapp, const float* coords, const float* dv, const float* dv_absmax, int64_t N,
+                           int32_t S, void* workspace, int64_t workspace_bytes, void* stream); /* dv: ego_shade_backward's blocked layout */
+/* v15: ONE pass over dfeat / dv.  The gradient of a plane and of the line it is multiplied with (the table of the axis that is not in the
+ * plane) come out of the same walk over the plane's cells: a cell's samples share the four plane texels, so the line's contribution of a
+ * sample is four multiply-adds away - but it lands in an arbitrary line texel.  Those sums are therefore taken in 64-bit FIXED POINT
+ * (integer LDS atomics per workgroup, integer partial tables added at the end: integer addition is associative, any order returns the same
+ * bits).  The unit is one power of two per table: 2^k with k = e(max |d|) + e(max |plane texel|) + 1 - nbits, nbits = min(50, 62 -
+ * ceil(log2(N S))), i.e. >= 40 bits below the largest possible contribution at 2^21 samples (an fp32 sum keeps 24 bits below its running
+ * value; a contribution more than ~2^-40 below the table's largest possible one is rounded to the unit).  max |plane texel| is taken by
+ * the call itself; max |dfeat| too; dv_absmax (dev, one float, may be NULL = computed here by one more read of dv) is ego_shade_backward's.
+ * Non-finite inputs give NaN line gradients.  Line tables too large for the LDS (axis > ~1 200 texels) and EGO_SORTED_LINES=separate take
+ * the two-pass form of v14 (float partial sums of fixed 256-sample sub-blocks, added in sub-block order).  An empty batch (N = 0)
+ * zero-fills the tables. */
 /* d(envmap.emission) [3][2h][h] += backward of bg_weight * sigmoid(bilinear(emission, dir)) (envmap.py:26-34,
  * EgoNeRF.py:588-590).  dirs = N directions dir_stride floats apart (rays + 3 with stride 6, or a packed [N][3]);
  * env_map = the forward's radiance [N][3]; the clamp mask is taken from rgb_raw (pass values in [0,1] for none). */
@@ -388,7 +401,9 @@ int ego_weight_grad(const void* A, int32_t lda, int32_t ca, int32_t a_layout, co
                     int32_t cb, int32_t b_layout, int32_t ones_col, int64_t M, float* G, int32_t ldg, void* stream);
 /* The same product, bit-reproducible: every workgroup stores its partial product block to `partial` (dev, ego_weight_grad_partial_floats()
  * floats) and a second kernel adds the blocks in workgroup order and STORES the result (G needs no zero fill; rows [0, 32 ceil(ca/32)) x
- * columns [0, 32 ceil(cols/32)) of G are overwritten).  ego_weight_grad adds with float atomics: its sums depend on the order the
+ * columns [0, 32 ceil(cols/32)) of G are overwritten - EXCEPT on the d(W3) fast path (ca == 3, cb == 128, b_layout 2: the VALU kernel
+ * k_wgrad3), which writes rows [0, 3) x columns [0, 160) only and leaves the padding rows 3..31 as they were: zero G once if those rows
+ * are read).  ego_weight_grad adds with float atomics: its sums depend on the order the
  * hardware serves them (differences in the last bits from run to run).  partial = NULL is ego_weight_grad. */
 int64_t ego_weight_grad_partial_floats(void);
 /* d(W1) and d(b1) of the tuned head WITHOUT the x dump: G [128][ldg >= 160] = dh1^T [x | 1] where x - the MLP input of

@@ -12,6 +12,18 @@ GOLDEN = os.path.join(REPO, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (runs the HIP library through the C-ABI)")
+    config.addinivalue_line("markers", "slow: long soak (tens of minutes of CPU oracle time); runs only when the -m expression names it, e.g. -m 'gpu and slow'")
+
+
+def pytest_collection_modifyitems(config, items):
+    """`slow` tests are opt-in: the driver's plain `-m gpu` run must stay within minutes, so they are skipped unless the marker expression
+    itself mentions `slow` (or EGO_RUN_SLOW=1)."""
+    if "slow" in (config.getoption("markexpr") or "") or os.environ.get("EGO_RUN_SLOW") == "1":
+        return
+    skip = pytest.mark.skip(reason="slow soak: select with -m 'gpu and slow'")
+    for it in items:
+        if "slow" in it.keywords:
+            it.add_marker(skip)
 
 
 @pytest.fixture(scope="session", autouse=True)

@@ -118,3 +118,30 @@ def test_activations_beyond_the_half_range_do_not_poison_a_pixel():
     rgb, *_ = model(rays.cuda(), is_train=True, n_coarse=32, exp_sampling=True)
     torch.mean(rgb ** 2).backward()
     assert all(bool(torch.isfinite(p.grad).all()) for p in model.parameters())
+
+
+@pytest.mark.parametrize("where", ["pageable", "pinned", "device"])
+def test_volume_renderer_host_hand_over_equals_the_resident_path(where):
+    """the reference's own call pattern - volume_renderer(..., empty_gpu_cache=True), every chunk's outputs (the
+    [chunk, S + 1] alpha included) copied back (renderer.py:26, :39-53) - through pinned staging and a copy stream that runs under the
+    next chunk's kernels.  Same kernels per chunk, so the host arrays must equal the resident tensors bit for bit; ragged last chunk,
+    an envmap scene (all five outputs present), keep_alpha on and off, and an empty ray list."""
+    from egonerf_amd.renderer import volume_renderer
+    cfg = synth.SceneConfig(n_voxel=24 ** 3, use_envmap=True, envmap_res_H=16)
+    model = make_model(cfg, synth.make_weights(cfg, seed=77), "cuda")
+    host = torch.from_numpy(synth.make_rays(1000, seed=9))
+    rays = {"pageable": host, "pinned": host.pin_memory(), "device": host.cuda()}[where]
+    kw = dict(chunk=192, n_coarse=32, n_fine=32, resampling=True, exp_sampling=True, device="cuda")
+    with torch.no_grad():
+        for keep_alpha in (True, False):
+            want = volume_renderer(host.cuda(), model, keep_alpha=keep_alpha, **kw)
+            got = volume_renderer(rays, model, keep_alpha=keep_alpha, empty_gpu_cache=True, **kw)
+            assert len(got) == 5
+            for j, (w_, g_) in enumerate(zip(want, got)):
+                assert (w_ is None) == (g_ is None), j
+                if w_ is not None:
+                    assert isinstance(g_, np.ndarray) and g_.shape == tuple(w_.shape), (j, g_.shape, w_.shape)
+                    assert np.array_equal(g_, w_.cpu().numpy()), j
+            assert (got[4] is None) == (not keep_alpha)
+        empty = volume_renderer(rays[:0], model, empty_gpu_cache=True, **kw)
+        assert empty[0].shape == (0, 3) and empty[1].shape == (0,)

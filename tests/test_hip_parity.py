@@ -55,7 +55,7 @@ def test_device_packer_is_bit_exact(tiny):
     _, _, w, model = tiny
     model.scene()
     torch.cuda.synchronize()
-    blob = model._packed.cpu().numpy()
+    blob = model._packed[False].cpu().numpy()   # the inference blob (training packs go to one of their own)
     assert np.array_equal(blob[:em.PACKED_FLOATS], em.pack_mlp(w))
     assert np.array_equal(blob[em.PACKED_FLOATS:2 * em.PACKED_FLOATS].view(np.uint32), em.pack_mlp_f16(w).view(np.uint32))
     assert blob.shape[0] == 2 * em.PACKED_FLOATS + 9216 + em.F8_FLOATS + em.F6_FLOATS  # + basis fragments in the fp16-table K order + f16f8 + f16f6 images

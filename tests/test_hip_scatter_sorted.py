@@ -2,6 +2,7 @@
 item 3) against the float-atomic scatter of rounds 1-4 (same mathematics, another summation order) and against itself (same bits twice).
 Backward of F.grid_sample in compute_densityfeature / compute_appfeature (models/EgoNeRF.py:291-347, :349-413) under train.py:312-314."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -21,10 +22,21 @@ def _scatter_both(model, coords, dfeat, dv, N, S):
     sc = model.scene(training=True)
     dens, app = table_params(model, "density"), table_params(model, "app")
     out = {}
-    for mode in ("atomic", "sorted", "sorted_again"):
+    M = N * S
+    for mode in ("atomic", "sorted", "sorted_again", "sorted_absmax", "sorted_separate"):
         gd = [torch.zeros_like(p) if mode == "atomic" else torch.full_like(p, float("nan")) for p in dens]   # the sorted form must write every texel
         ga = [torch.zeros_like(p) if mode == "atomic" else torch.full_like(p, float("nan")) for p in app]
         sd, sa = _grad_struct(gd), _grad_struct(ga)
+        # v15: "sorted" = one pass (lines in fixed point, dv_absmax found by the call); "sorted_absmax": the caller hands max |dv| over
+        # the valid samples, as ego_shade_backward does; "sorted_separate": the two-pass form of v14 (EGO_SORTED_LINES is read per call)
+        absmax = None
+        if mode == "sorted_absmax":
+            blk = dv.view(-1, 9, 32, 16)
+            valid = (torch.arange(blk.shape[0] * 32, device=dv.device).view(-1, 1, 32, 1) < M) if M % 32 else None
+            absmax = (blk.abs() if valid is None else (blk.abs() * valid)).max().reshape(1).contiguous() if M else torch.zeros(1, device=dv.device)
+        os.environ.pop("EGO_SORTED_LINES", None)
+        if mode == "sorted_separate":
+            os.environ["EGO_SORTED_LINES"] = "separate"
         if mode == "atomic":
             _lib.check(lib.ego_scatter_density(sc, C.byref(sd), coords.data_ptr(), dfeat.data_ptr(), N, S, st), "scatter_density")
             _lib.check(lib.ego_scatter_app(sc, C.byref(sa), coords.data_ptr(), dv.data_ptr(), N, S, st), "scatter_app")
@@ -34,8 +46,9 @@ def _scatter_both(model, coords, dfeat, dv, N, S):
             ws = torch.empty(nbytes, device=DEV, dtype=torch.uint8)
             _lib.check(lib.ego_scatter_sort(sc, coords.data_ptr(), N, S, ws.data_ptr(), nbytes, st), "scatter_sort")
             _lib.check(lib.ego_scatter_density_sorted(sc, C.byref(sd), coords.data_ptr(), dfeat.data_ptr(), N, S, ws.data_ptr(), nbytes, st), "density_sorted")
-            _lib.check(lib.ego_scatter_app_sorted(sc, C.byref(sa), coords.data_ptr(), dv.data_ptr(), N, S, ws.data_ptr(), nbytes, st), "app_sorted")
+            _lib.check(lib.ego_scatter_app_sorted(sc, C.byref(sa), coords.data_ptr(), dv.data_ptr(), _lib.ptr(absmax), N, S, ws.data_ptr(), nbytes, st), "app_sorted")
         torch.cuda.synchronize()
+        os.environ.pop("EGO_SORTED_LINES", None)
         out[mode] = (gd, ga)
     return out
 
@@ -64,12 +77,37 @@ def test_sorted_scatter_equals_the_atomic_one_and_itself(n_voxel, N, S, spread):
     coords, dfeat, dv = coords.to(DEV).contiguous(), dfeat.to(DEV).contiguous(), dv.to(DEV)
     out = _scatter_both(model, coords, dfeat, dv, N, S)
     for fi, field in enumerate(("density", "app")):
-        for k, (a, s, s2) in enumerate(zip(out["atomic"][fi], out["sorted"][fi], out["sorted_again"][fi])):
-            assert bool(torch.isfinite(s).all()), (field, k)                      # every texel written (the buffers started as NaN)
+        for k, (a, s, s2, s3, sep) in enumerate(zip(out["atomic"][fi], out["sorted"][fi], out["sorted_again"][fi], out["sorted_absmax"][fi],
+                                                    out["sorted_separate"][fi])):
+            assert bool(torch.isfinite(s).all()) and bool(torch.isfinite(sep).all()), (field, k)   # every texel written (the buffers started as NaN)
             assert torch.equal(s, s2), (field, k)                                # same bits twice
+            assert torch.equal(s, s3), (field, k)                                # ... and with the caller's max |dv| (the same value -> the same unit)
             scale = max(float(a.abs().max()), 1e-20)
             assert float((a - s).abs().max()) <= 3e-5 * scale, (field, k, float((a - s).abs().max()) / scale)   # summation order only (thousands of terms per texel at the large size)
+            assert float((sep - s).abs().max()) <= 3e-5 * scale, (field, k)
+            if k % 6 < 3:
+                assert torch.equal(s, sep), (field, k)    # planes: both forms add a cell's samples in the same order
             assert M < 64 or float(s.abs().max()) > 0
+
+
+def test_an_empty_batch_zero_fills_the_tables():
+    """the sorted scatters promise 'every texel is written' and train.py allocates the gradient tables with torch.empty."""
+    cfg = synth.SceneConfig(n_voxel=20 ** 3)
+    model = make_model(cfg, synth.make_weights(cfg, seed=21), DEV)
+    lib, st = _lib.load(), _lib.stream_handle()
+    sc = model.scene(training=True)
+    gd = [torch.full_like(p, float("nan")) for p in table_params(model, "density")]
+    ga = [torch.full_like(p, float("nan")) for p in table_params(model, "app")]
+    sd, sa = _grad_struct(gd), _grad_struct(ga)
+    nbytes = lib.ego_scatter_sorted_workspace_bytes(sc, 0, 8)
+    assert nbytes > 0
+    ws = torch.empty(nbytes, device=DEV, dtype=torch.uint8)
+    _lib.check(lib.ego_scatter_sort(sc, None, 0, 8, ws.data_ptr(), nbytes, st), "scatter_sort")
+    _lib.check(lib.ego_scatter_density_sorted(sc, C.byref(sd), None, None, 0, 8, ws.data_ptr(), nbytes, st), "density_sorted")
+    _lib.check(lib.ego_scatter_app_sorted(sc, C.byref(sa), None, None, None, 0, 8, ws.data_ptr(), nbytes, st), "app_sorted")
+    torch.cuda.synchronize()
+    for g in gd + ga:
+        assert float(g.abs().max()) == 0.0
 
 
 def _float64_grid_sample_gradients(cfg, weights, coords, dfeat, dv_ref):
