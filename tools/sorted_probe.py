@@ -31,14 +31,33 @@ def run(which):
     if which == "app": _lib.check(lib.ego_scatter_app_sorted(sc, C.byref(sa), crd.data_ptr(), dv.data_ptr(), None, N, S, ws.data_ptr(), nb, st), "a")
     if which == "dens_atomic": _lib.check(lib.ego_scatter_density(sc, C.byref(sd), crd.data_ptr(), dfeat.data_ptr(), N, S, st), "d")
     if which == "app_atomic": _lib.check(lib.ego_scatter_app(sc, C.byref(sa), crd.data_ptr(), dv.data_ptr(), N, S, st), "a")
-for which in ("sort", "dens", "app", "dens_atomic", "app_atomic"):
+def timed(which, label):
     for _ in range(3): run(which)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(10): run(which)
     e1.record(); torch.cuda.synchronize()
-    print(f"{which:12s} {e0.elapsed_time(e1) / 10:.3f} ms")
+    print(f"{label:28s} {e0.elapsed_time(e1) / 10:.3f} ms", flush=True)
+timed("sort", "sort")
+# round 6: the one-pass (fused, fixed-point lines) form against the two-pass form of round 5, and the fused kernel's workgroup shapes
+ref = None
+for label, env in (("separate", dict(EGO_SORTED_LINES="separate")), ("fused nw16", dict(EGO_FUSED_NW="16")), ("fused nw12", dict(EGO_FUSED_NW="12")),
+                   ("fused nw8", dict(EGO_FUSED_NW="8")), ("separate again", dict(EGO_SORTED_LINES="separate")), ("fused default", {})):
+    for k in ("EGO_SORTED_LINES", "EGO_FUSED_NW"): os.environ.pop(k, None)
+    os.environ.update(env)
+    for which in ("dens", "app"):
+        timed(which, f"{which} {label}")
+    torch.cuda.synchronize()
+    cur = [g.clone() for g in gd + ga]
+    if ref is None:
+        ref = cur
+    else:
+        worst = max(float((a - b).abs().max()) / max(float(b.abs().max()), 1e-30) for a, b in zip(cur, ref))
+        print(f"    worst |diff| vs the separate form, relative to each table's max: {worst:.2e}", flush=True)
+for k in ("EGO_SORTED_LINES", "EGO_FUSED_NW"): os.environ.pop(k, None)
+for which in ("dens_atomic", "app_atomic"):
+    timed(which, which)
 # cell-size distribution of the three sorts (torch restatement of cell_of / k_sort_keys)
 if os.environ.get("PROBE_CELLS"):
     res = [int(v) for v in model.gridSize.tolist()]
