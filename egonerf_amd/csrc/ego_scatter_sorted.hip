@@ -31,9 +31,10 @@
 // cannot be taken in a fixed order.  They are taken in an order-INDEPENDENT arithmetic instead: every contribution is converted to a
 // 64-bit fixed-point integer (one power-of-two unit per table, derived from max |d| x max |plane texel|, both computed on the device:
 // >= 40 bits below the largest possible contribution - an fp32 sum keeps 24) and added with integer LDS atomics into a per-workgroup
-// table of the line; integer addition is associative, so any order gives the same bits.  k_sorted_fused = k_sorted_plane + those
+// table of the line; integer addition is associative, so any order gives the same bits.  k_sorted_walk = the plane walk + those
 // four multiply-adds + two ds_add_u64 per channel lane and sample; k_fused_line_final adds the workgroups' tables and converts once.
-// The separate line kernels stay as the fall-back for line tables that do not fit the LDS (EGO_SORTED_LINES=separate forces them).
+// The separate line kernels stay for line tables that do not fit the LDS (the appearance field's r line on the headline grid;
+// EGO_SORTED_LINES=separate forces them for every line, EGO_SORTED_WALK=0 the whole round-5 form).
 
 #include "ego_device.h"
 #include "ego_host.h"
@@ -62,6 +63,9 @@ struct SortGeom {
   int bits;            // key bits (covers max K)
   // byte offsets into the workspace
   int64_t perm[3], start[3], suboff[3], scratch, total;
+  int64_t stepsum[3], steps[3];   // the walk's step list (round 6): per cell the number of 16-sample steps before it; the steps themselves
+  int64_t costsum[3];             // per cell the COST of the steps before it (what the walk is dealt by)
+  int64_t step_cap[3];            // entries of steps[s]
   // sort-phase view of the scratch region
   int64_t keys_in[3], k1[3], v1[3], k2[3], hist[3];
   uint32_t nblocks;    // radix tiles (RTILE elements each)
@@ -76,50 +80,35 @@ struct SortGeom {
 
 inline int64_t align256(int64_t v) { return (v + 255) & ~(int64_t)255; }
 
-// ---- launch plan of the fused form ------------------------------------------------------------------------------------------------
-// Sort s serves plane sort_plane(s) AND the line of the axis that is not in its key (line index sort_plane(s), axis vm_line_ax).  A
-// workgroup keeps that line's integer table for ONE grid in LDS: n x 16 nlw x 8 bytes, nlw = channel groups (of 16) per workgroup.
-// nlw = C / 16 when that fits beside the wave records, else 1 (the sort is then walked once per channel group: blockIdx-level "z").
+// ---- launch plan of the walk --------------------------------------------------------------------------------------------------------
+// Sort s serves plane sort_plane(s) AND - where it fits - the line of the axis that is not in its key (line index sort_plane(s)).  A
+// workgroup keeps that line's integer table for ONE grid in LDS: n x C x 8 bytes beside the waves' records.  The headline grid
+// [150, 172, 516]: the density field's three lines fit (C = 16), of the appearance field's (C = 48) the theta and phi lines do and the r
+// line (198 KB) does not - it keeps the two-pass form (k_sorted_line of the sort whose major key is r).
 constexpr int FUSED_LDS_LIMIT = 160 * 1024 - 1024;
-constexpr int FUSED_REC_BYTES = 12 * 64 * 4;   // sizeof(WaveRec)
+constexpr int WALK_NW_APP = 12, WALK_NW_DENS = 16;   // waves per workgroup: 144+ VGPRs at 48 channels (three waves per SIMD), ~110 at 16
 struct FusedPlan {
-  bool ok;
-  int nw;          // waves per workgroup (16 or 8)
-  int nlw[3];      // channel groups per workgroup, per sort
-  int ncombo;      // (sort, z) pairs
-  int combo_s[9], combo_z[9], combo_first[3];
-  int entries[3];  // table entries per workgroup, per sort
-  int entries_max;
+  int nw;
+  bool do_line[3];   // per sort
+  int entries_max;   // 8-byte table entries per workgroup (0: no fused line at all)
   int lds_bytes;
 };
 __host__ __device__ constexpr int fused_line_axis(int s) { return 2 - (s == 0 ? 1 : s == 1 ? 0 : 2); }   // vm_line_ax(sort_plane(s))
+inline int walk_wave_bytes(int C) { return 12 * 64 * 4 + (C / 16) * 4 * 64 * 4; }   // sizeof(WalkLds<C / 16>)
 
 inline FusedPlan fused_plan(const int32_t res[3], int C) {
   FusedPlan P{};
-  const int NL = C / 16;
-  int forced = 0;
-  if (const char* e = getenv("EGO_FUSED_NW")) forced = atoi(e);   // experiments: 16, 12 or 8 waves per workgroup
-  for (int nw : {16, 12, 8}) {
-    if (forced && nw != forced && nw != 8) continue;
-    P.nw = nw;
-    P.ok = true;
-    P.ncombo = 0;
-    P.entries_max = 0;
-    const int room = FUSED_LDS_LIMIT - nw * FUSED_REC_BYTES - 64;
-    for (int s = 0; s < 3; ++s) {
-      const int n = res[fused_line_axis(s)];
-      int nlw = NL;
-      if ((int64_t)n * 16 * nlw * 8 > (nw >= 12 ? 72 * 1024 : room)) nlw = 1;     // many waves: keep the table <= 72 KB (two sorts of the headline grid qualify)
-      if ((int64_t)n * 16 * nlw * 8 > room) P.ok = false;
-      P.nlw[s] = nlw;
-      P.entries[s] = n * 16 * nlw;
-      P.entries_max = P.entries[s] > P.entries_max ? P.entries[s] : P.entries_max;
-      P.combo_first[s] = P.ncombo;
-      for (int z = 0; z < NL / nlw; ++z) { P.combo_s[P.ncombo] = s; P.combo_z[P.ncombo] = z; ++P.ncombo; }
-    }
-    P.lds_bytes = P.entries_max * 8 + nw * FUSED_REC_BYTES + 64;
-    if (P.ok) return P;
+  P.nw = C > 16 ? WALK_NW_APP : WALK_NW_DENS;
+  const int fixed = P.nw * walk_wave_bytes(C) + 64;
+  const int room = FUSED_LDS_LIMIT - fixed;
+  bool separate = false;
+  if (const char* e = getenv("EGO_SORTED_LINES")) separate = e[0] == 's';   // experiments / tests: every line in the two-pass form
+  for (int s = 0; s < 3; ++s) {
+    const int64_t bytes = (int64_t)res[fused_line_axis(s)] * C * 8;
+    P.do_line[s] = !separate && bytes <= room;
+    if (P.do_line[s] && (int)(bytes / 8) > P.entries_max) P.entries_max = (int)(bytes / 8);
   }
+  P.lds_bytes = fixed + P.entries_max * 8;
   return P;
 }
 
@@ -142,6 +131,13 @@ SortGeom make_geom(const int32_t res[3], int64_t M) {
   for (int s = 0; s < 3; ++s) { G.perm[s] = o; o = align256(o + 4 * M); }
   for (int s = 0; s < 3; ++s) { G.start[s] = o; o = align256(o + 4 * ((int64_t)G.K[s] + 2)); }
   for (int s = 0; s < 3; ++s) { G.suboff[s] = o; o = align256(o + 4 * ((int64_t)G.LC[s] + 1)); }
+  for (int s = 0; s < 3; ++s) { G.stepsum[s] = o; o = align256(o + 4 * ((int64_t)G.K[s] + 2)); }
+  for (int s = 0; s < 3; ++s) { G.costsum[s] = o; o = align256(o + 4 * ((int64_t)G.K[s] + 2)); }
+  for (int s = 0; s < 3; ++s) {
+    // a cell of n samples takes ceil(n / 16) steps: at most M / 16 + one per cell that holds samples
+    G.step_cap[s] = M / 16 + (M < (int64_t)G.K[s] ? M : (int64_t)G.K[s]) + 1;
+    G.steps[s] = o; o = align256(o + 16 * G.step_cap[s]);
+  }
   G.scratch = o;
   // sort phase
   int64_t a = o;
@@ -163,10 +159,18 @@ SortGeom make_geom(const int32_t res[3], int64_t M) {
   }
   for (int s = 0; s < 3; ++s) { G.linepart[s] = b; b = align256(b + 4 * (int64_t)G.nsub_max * 2 * CMAX); }
   // fused form (shares the line-partial region's place in time, not its bytes: both forms are sized so that either can run)
-  G.fx = b; b = align256(b + 256);
+  G.fx = b; b = align256(b + 256 + 4 * 7 * 128);   // FxScale + k_fx_absmax's per-workgroup maxima
   {
-    const FusedPlan P = fused_plan(res, CMAX);   // the appearance field's plan has the larger tables
-    G.fpart_stride = P.ok ? P.entries_max : 0;
+    // the largest line table either field can keep in LDS bounds the per-workgroup stride (independent of EGO_SORTED_LINES)
+    int64_t emax = 0;
+    for (int C : {16, CMAX}) {
+      const int room = FUSED_LDS_LIMIT - (C > 16 ? WALK_NW_APP : WALK_NW_DENS) * walk_wave_bytes(C) - 64;
+      for (int a3 = 0; a3 < 3; ++a3) {
+        const int64_t e = (int64_t)res[a3] * C;
+        if (e * 8 <= room && e > emax) emax = e;
+      }
+    }
+    G.fpart_stride = emax;
     G.fpart = b; b = align256(b + 8 * G.fpart_stride * FUSED_MAX_WG);
   }
   G.total = a > b ? a : b;
@@ -338,6 +342,9 @@ struct StartArgs {
   const uint32_t* sorted[3];
   uint32_t* start[3];
   uint32_t* suboff[3];
+  uint32_t* stepsum[3];
+  uint32_t* costsum[3];
+  uint4* steps[3];
   uint32_t K[3], LC[3], nmin1[3];
   int64_t M;
 };
@@ -388,6 +395,74 @@ __global__ __launch_bounds__(1024) void k_line_suboff(StartArgs A) {
   if (t == 0) suboff[LC] = carry;
 }
 
+// ---- the walk's step list -------------------------------------------------------------------------------------------------------------
+// A STEP = up to 16 consecutive sorted samples of one cell (what a 16-lane group of k_sorted_walk handles at a time).
+// stepsum[k] = number of steps of the cells before k (k = 0 .. K; the cells of grid 0 come first), one workgroup per sort;
+// steps[j] = {first sorted position, cell, samples | first step of its cell << 8 | last << 9, 0}.  With the list the walk is dealt in
+// EQUAL numbers of steps per group, whatever the cells' sizes - a first version that dealt cells in chunks had its slowest wave at 3.5 x
+// the mean (tools/sorted_probe.py PROBE_PROF on a -DEGO_WALK_PROF build).
+// cost of a cell's steps in units of one stage-2 iteration of the walk (U = 4 samples per group): a step = its fixed part (prefetches,
+// set-up, record: about one iteration's time, measured with -DEGO_WALK_PROF) + ceil(samples / 4) iterations
+__device__ __forceinline__ uint32_t cell_cost(uint32_t n) {
+  const uint32_t full = n / 16u, r = n % 16u;
+  return full * 5u + (r ? 1u + (r + 3u) / 4u : 0u);
+}
+
+// blockIdx.x = 0: stepsum, 1: costsum
+__global__ __launch_bounds__(1024) void k_step_scan(StartArgs A) {
+  const uint32_t* __restrict__ start = A.start[blockIdx.y];
+  const bool cost = blockIdx.x == 1;
+  uint32_t* __restrict__ out = cost ? A.costsum[blockIdx.y] : A.stepsum[blockIdx.y];
+  const uint32_t K = A.K[blockIdx.y];
+  __shared__ uint32_t wsum[16];
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  uint32_t carry = 0;
+  for (uint32_t base = 0; base < K; base += 4096) {   // four cells per thread and round
+    const uint32_t k0 = base + 4u * (uint32_t)t;
+    uint32_t n[4], own = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const uint32_t k = k0 + i;
+      const uint32_t ns = k < K ? start[k + 1] - start[k] : 0u;
+      n[i] = cost ? cell_cost(ns) : (ns + 15u) / 16u;
+      own += n[i];
+    }
+    uint32_t inc = own;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t v = __shfl_up(inc, d, 64);
+      if (lane >= d) inc += v;
+    }
+    if (lane == 63) wsum[wv] = inc;
+    __syncthreads();
+    uint32_t before = 0, all = 0;
+    for (int w = 0; w < 16; ++w) { if (w < wv) before += wsum[w]; all += wsum[w]; }
+    uint32_t run = carry + before + inc - own;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (k0 + i < K) out[k0 + i] = run;
+      run += n[i];
+    }
+    carry += all;
+    __syncthreads();
+  }
+  if (t == 0) { out[K] = carry; out[K + 1] = carry; }
+}
+
+__global__ void k_step_fill(StartArgs A) {
+  const int s = blockIdx.y;
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= A.K[s]) return;
+  const uint32_t a = A.start[s][k], n = A.start[s][k + 1] - a;
+  if (!n) return;
+  uint4* out = A.steps[s] + A.stepsum[s][k];
+  const uint32_t nb = (n + 15u) / 16u;
+  for (uint32_t b = 0; b < nb; ++b) {
+    const uint32_t cnt = min(16u, n - 16u * b);
+    out[b] = uint4{a + 16u * b, k, cnt | (b == 0 ? 256u : 0u) | (b + 1 == nb ? 512u : 0u), 0u};
+  }
+}
+
 struct GradTables {
   float* plane[2][3];
   float* line[2][3];
@@ -401,10 +476,14 @@ struct SortedArgs {
   const uint32_t* perm[3];
   const uint32_t* start[3];
   const uint32_t* suboff[3];
+  const uint32_t* stepsum[3];
+  const uint32_t* costsum[3];
+  const uint4* steps[3];
   float* cellbuf[3];
   float* linepart[3];
   uint32_t K[3], LC[3];
   int dense_cells;
+  int line_mask;   // bit s: k_sorted_line / k_sorted_line_final take the line of sort s (the walk takes the others)
 };
 
 // where cell k of sort s keeps its four corner sums (only called for cells that hold samples)
@@ -690,6 +769,7 @@ template <int C, bool DENS>
 __global__ __launch_bounds__(256) void k_sorted_line(SortedArgs A) {
   __shared__ WaveRec rec[4];
   WaveRec& R = rec[threadIdx.x >> 6];
+  if (!((A.line_mask >> blockIdx.y) & 1)) return;
   if (blockIdx.y == 0) sorted_line<C, DENS, 0>(A, R);
   else if (blockIdx.y == 1) sorted_line<C, DENS, 1>(A, R);
   else sorted_line<C, DENS, 2>(A, R);
@@ -726,6 +806,7 @@ __device__ __forceinline__ void sorted_line_final(const SortedArgs& A) {
 
 template <int C>
 __global__ void k_sorted_line_final(SortedArgs A) {
+  if (!((A.line_mask >> blockIdx.y) & 1)) return;
   if (blockIdx.y == 0) sorted_line_final<C, 0>(A);
   else if (blockIdx.y == 1) sorted_line_final<C, 1>(A);
   else sorted_line_final<C, 2>(A);
@@ -758,18 +839,34 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 __device__ __forceinline__ void absmax_range(const float* __restrict__ x, int64_t n, uint32_t* out) {
   uint32_t m = 0;
   const int64_t n4 = n >> 2;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
-    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+  typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; i + 3 * stride < n4; i += 4 * stride) {   // four independent loads in flight
+    const u4 v0 = ((const u4*)x)[i], v1 = ((const u4*)x)[i + stride], v2 = ((const u4*)x)[i + 2 * stride], v3 = ((const u4*)x)[i + 3 * stride];
+    m = max(m, max(max(v0.x & 0x7fffffffu, v0.y & 0x7fffffffu), max(v0.z & 0x7fffffffu, v0.w & 0x7fffffffu)));
+    m = max(m, max(max(v1.x & 0x7fffffffu, v1.y & 0x7fffffffu), max(v1.z & 0x7fffffffu, v1.w & 0x7fffffffu)));
+    m = max(m, max(max(v2.x & 0x7fffffffu, v2.y & 0x7fffffffu), max(v2.z & 0x7fffffffu, v2.w & 0x7fffffffu)));
+    m = max(m, max(max(v3.x & 0x7fffffffu, v3.y & 0x7fffffffu), max(v3.z & 0x7fffffffu, v3.w & 0x7fffffffu)));
+  }
+  for (; i < n4; i += stride) {
     const u4 v = ((const u4*)x)[i];
     m = max(max(m, v.x & 0x7fffffffu), max(v.y & 0x7fffffffu, max(v.z & 0x7fffffffu, v.w & 0x7fffffffu)));
   }
   for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
     m = max(m, __float_as_uint(x[i]) & 0x7fffffffu);
+  // one value per workgroup, stored: thousands of atomicMax on ONE address serialise at ~150 ns each (a 0.4 ms kernel for 14 MB)
+  __shared__ uint32_t wm[4];
   m = wave_max_u32(m);
-  if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+  if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) *out = max(max(wm[0], wm[1]), max(wm[2], wm[3]));
+  __syncthreads();
 }
 
+constexpr int FX_BLOCKS = 128;   // workgroups per array of k_fx_absmax; their maxima go to FxScale-adjacent slots [7][FX_BLOCKS]
 struct AbsmaxArgs {
+  uint32_t* part;      // [7][FX_BLOCKS]: per-workgroup maxima (6 planes, d), reduced by k_fx_setup
   const float* plane[2][3];
   int64_t n_plane[3];
   const float* d;      // nullptr: dmax comes from the caller
@@ -782,22 +879,35 @@ struct AbsmaxArgs {
 // blockIdx.y = 0..5: plane (g, I); 6: d
 __global__ __launch_bounds__(256) void k_fx_absmax(AbsmaxArgs A) {
   const int y = blockIdx.y;
+  uint32_t* out = A.part + y * FX_BLOCKS + blockIdx.x;
   if (y < 6) {
-    absmax_range(A.plane[y / 3][y % 3], A.n_plane[y % 3], &A.fx->pmax_bits[y % 3]);
+    absmax_range(A.plane[y / 3][y % 3], A.n_plane[y % 3], out);
   } else if (A.d) {
-    absmax_range(A.d, A.n_d, &A.fx->dmax_bits);
+    absmax_range(A.d, A.n_d, out);
     if (A.tail_rows && blockIdx.x == 0) {   // [plane * 3 + line][sample j][16]: rows j < tail_rows
       uint32_t m = 0;
       for (int i = threadIdx.x; i < A.tail_block; i += blockDim.x)
         if (((i >> 4) & 31) < A.tail_rows) m = max(m, __float_as_uint(A.d[A.n_d + i]) & 0x7fffffffu);
       m = wave_max_u32(m);
-      if ((threadIdx.x & 63) == 0 && m) atomicMax(&A.fx->dmax_bits, m);
+      if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);   // (four waves, one workgroup)
     }
+  } else if (threadIdx.x == 0) {
+    *out = 0u;
   }
 }
 
-__global__ void k_fx_setup(FxScale* fx, int64_t M, const float* dmax_ext) {
-  if (threadIdx.x || blockIdx.x) return;
+__global__ void k_fx_setup(FxScale* fx, const uint32_t* part, int64_t M, const float* dmax_ext) {
+  // one wave: the workgroups' maxima -> the four scalars
+  for (int y = 0; y < 7; ++y) {
+    uint32_t m = 0;
+    for (int i = threadIdx.x; i < FX_BLOCKS; i += 64) m = max(m, part[y * FX_BLOCKS + i]);
+    m = wave_max_u32(m);
+    if (threadIdx.x == 0) {
+      if (y < 6) fx->pmax_bits[y % 3] = y < 3 ? m : max(fx->pmax_bits[y % 3], m);
+      else fx->dmax_bits = m;
+    }
+  }
+  if (threadIdx.x) return;
   uint32_t db = fx->dmax_bits;
   if (dmax_ext) db = __float_as_uint(*dmax_ext) & 0x7fffffffu;
   int lg = 1;
@@ -833,106 +943,202 @@ __device__ __forceinline__ uint32_t wave_lower_bound(const uint32_t* __restrict_
   return lo;
 }
 
+// ---- the walk ----------------------------------------------------------------------------------------------------------------------
+// Round 5's plane kernel gave each wave four cells and walked them in lockstep: 16 sample slots per cell and batch whatever the cells
+// held (75 % of a batch's time went to its chain of dependent round trips: cell starts -> permutation -> coordinates -> d and taps x 4),
+// a workgroup per 16 cells.  Here
+//   * the unit of work is a STEP of the step list (k_step_fill): up to 16 samples of one cell, for one 16-lane group; every group of the
+//     launch gets the same number of consecutive steps (cut at cell boundaries), so nobody waits for a larger cell or a fuller chunk;
+//   * the four groups of a wave walk their own steps independently;
+//   * step t + 3's list entry, step t + 2's permutation entries and step t + 1's coordinates are fetched at the top of step t, and the
+//     four plane texels of a cell go to LDS by the load itself when its first step begins (global_load_lds: no registers, no
+//     compiler-inserted wait), so a step's only exposed round trips are its own 16 / U gathers of d;
+//   * where the line table of the plane's third axis fits the LDS (fused_plan), the line gradient is taken in the same step (fixed
+//     point, see above); the workgroup's table goes to `part` at the end.
+// -DEGO_WALK_PROF: per-phase cycle counts of the walk (s_memtime), summed over all waves into g_walk_prof (tools/sorted_probe.py PROBE_PROF)
+#ifdef EGO_WALK_PROF
+__device__ unsigned long long g_walk_prof[16];
+__device__ unsigned long long g_walk_span[4];   // -, -, slowest wave, -
+__device__ uint32_t g_walk_wave[4096 * 4];   // per wave of the last launch: busy ticks, steps, iterations, pair
+#define WPROF_T(v) const unsigned long long v = __builtin_amdgcn_s_memtime()
+#define WPROF_ADD(i, x) prof[i] += (x)
+#else
+#define WPROF_T(v)
+#define WPROF_ADD(i, x)
+#endif
+template <int NL>
+struct WalkLds {           // per wave
+  WaveRec rec;
+  float pt[NL * 4][64];    // [channel group * 4 + corner][lane]: the four texels of the lane's group's current cell
+};
+
 struct FusedArgs {
   SortedArgs A;
   const FxScale* fx;
-  unsigned long long* part;   // [workgroup][part_stride]
+  unsigned long long* part;   // [workgroup][part_stride]: the workgroups' integer line tables
   uint32_t part_stride;
-  int32_t ncombo;
-  int32_t wg_off[10];         // combo c owns workgroups [wg_off[c], wg_off[c + 1])
-  int8_t combo_s[9], combo_z[9];
-  int8_t nlw[3], combo_first[3];
+  int32_t nwg;                // workgroups of the launch
+  int8_t do_line[3];          // sort s also takes the gradient of line sort_plane(s)
+  int32_t dbg;                // experiments (EGO_FUSED_DBG): 1 = no LDS atomics, 2 = no line part at all (timing only: wrong line gradients)
 };
 
-// workgroups of a combo that serve grid 0: in proportion to the samples (a grid without samples gets none, any other at least one)
-__device__ __forceinline__ uint32_t fused_split(uint32_t nwg, uint32_t n_g0, uint32_t n_tot) {
-  if (n_g0 == 0) return 0;
-  if (n_g0 == n_tot) return nwg;
-  const uint32_t r = (uint32_t)(((uint64_t)nwg * n_g0 + n_tot / 2) / n_tot);
-  return min(max(r, 1u), nwg - 1);
+// Workgroups are dealt to the six (sort, grid) pairs in proportion to the COST of their steps (cell_cost; x 5 / 4 where the line rides
+// along); every pair that has steps gets at least one.  j0 / j1: the pair's range of the sort's cost prefix.  Evaluated identically by every workgroup of the walk and by k_fused_line_final.
+struct WalkDeal { int32_t off[7]; uint32_t j0[6], j1[6]; };
+__device__ __forceinline__ WalkDeal walk_deal(const FusedArgs& F) {
+  WalkDeal D;
+  uint64_t w[6], W = 0;
+  int nz = 0;
+#pragma unroll
+  for (int s = 0; s < 3; ++s) {
+    const uint32_t K = F.A.K[s], mid = F.A.costsum[s][K / 2], tot = F.A.costsum[s][K];
+    D.j0[2 * s] = 0; D.j1[2 * s] = mid; D.j0[2 * s + 1] = mid; D.j1[2 * s + 1] = tot;
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      w[2 * s + g] = (uint64_t)(D.j1[2 * s + g] - D.j0[2 * s + g]) * (F.do_line[s] ? 5u : 4u);
+      W += w[2 * s + g];
+      nz += w[2 * s + g] != 0;
+    }
+  }
+  int off = 0;
+  uint64_t acc = 0;
+#pragma unroll
+  for (int p = 0; p < 6; ++p) {
+    D.off[p] = off;
+    if (w[p]) {
+      acc += w[p];
+      --nz;
+      int end = (int)(((uint64_t)F.nwg * acc + W / 2) / W);
+      end = max(end, off + 1);
+      end = min(end, F.nwg - nz);
+      off = end;
+    }
+  }
+  D.off[6] = off;
+  return D;
 }
 
-// One workgroup = one contiguous share of ONE grid's sorted samples of sort S_ (whole cells).  Waves take quads of four consecutive
-// cells in turn; a quad is processed exactly as in sorted_plane (stage 1: lane = sample -> record; stage 2: 16-lane group = cell, lane =
-// channel, U samples in flight), plus: the cell's four plane texels are loaded once per cell, the sample's plane value pv = sum_c
-// texel_c w_c follows from them, and gl = d pv goes - as two fixed-point integers, weights lw0 / lw1 - to the LDS table entries of the
-// sample's two line texels (ds_add_u64; integer sums do not depend on the order).
-template <int C, bool DENS, int S_, int NLW, int NW, int U>
-__device__ __forceinline__ void sorted_fused(const FusedArgs& F, const int combo, const int z, unsigned long long* __restrict__ tab, WaveRec& R, uint32_t* sh) {
+// sum over the 16 lanes of a row on the DPP path (every lane gets the total): quad_perm xor 1, xor 2, row_half_mirror, row_mirror
+__device__ __forceinline__ float row_sum16(float v) {
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xb1, 0xf, 0xf, false));    // quad_perm [1,0,3,2]
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4e, 0xf, 0xf, false));    // quad_perm [2,3,0,1]
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xf, 0xf, false));   // row_half_mirror
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xf, 0xf, false));   // row_mirror
+  return v;
+}
+
+template <int C, bool DENS, int S_, int NW, int U>
+__device__ __forceinline__ void sorted_walk(const FusedArgs& F, const WalkDeal& D, const int g, unsigned long long* __restrict__ tab,
+                                            WalkLds<C / 16>* wl, const bool do_line) {
 #pragma clang fp contract(fast)
   constexpr int NL = C / 16, I = sort_plane(S_);
   constexpr int AX = vm_plane_x(I), AY = vm_plane_y(I), AL = vm_line_ax(I);
   static_assert(AL != sort_major(S_) && AL != sort_minor(S_), "the fused line is the one whose axis is not in the sort key");
   const SortedArgs& A = F.A;
-  const int lane = threadIdx.x & 63, c16 = lane & 15, q = lane >> 4, wave = threadIdx.x >> 6;
-  const int ig0 = z * NLW;
-  const int W = A.F.res[AX], H = A.F.res[AY], NLn = A.F.res[AL];
-  const int entries = NLn * 16 * NLW;
+  WalkLds<NL>& W = wl[threadIdx.x >> 6];
+  const int lane = threadIdx.x & 63, c16 = lane & 15, q = lane >> 4;
+  const int Wd = A.F.res[AX], H = A.F.res[AY], NLn = A.F.res[AL];
+  const int entries = do_line ? NLn * C : 0;
   for (int i = threadIdx.x; i < entries; i += NW * 64) tab[i] = 0ull;
-  // this workgroup's grid and share
-  const uint32_t K = A.K[S_], Kh = K / 2;
-  const uint32_t n_g0 = A.start[S_][Kh], n_tot = A.start[S_][K];
-  const uint32_t nwg = (uint32_t)(F.wg_off[combo + 1] - F.wg_off[combo]), b = blockIdx.x - (uint32_t)F.wg_off[combo];
-  const uint32_t nwg0 = fused_split(nwg, n_g0, n_tot);
-  const int g = b >= nwg0 ? 1 : 0;
-  const uint32_t bl = g ? b - nwg0 : b, nb = g ? nwg - nwg0 : nwg0;
-  const uint32_t gs = g ? n_g0 : 0u, ge = g ? n_tot : n_g0;
-  const uint32_t s_lo = gs + (uint32_t)((uint64_t)(ge - gs) * bl / nb), s_hi = gs + (uint32_t)((uint64_t)(ge - gs) * (bl + 1) / nb);
-  if (wave < 2) {
-    const uint32_t kk = wave_lower_bound(A.start[S_], (uint32_t)g * Kh, (uint32_t)(g + 1) * Kh, wave ? s_hi : s_lo);
-    if (lane == 0) sh[wave] = kk;
+  const uint32_t K = A.K[S_], Kh = K / 2, kbase = (uint32_t)g * Kh;
+  const uint32_t T0 = g ? D.j0[2 * S_ + 1] : D.j0[2 * S_], T1 = g ? D.j1[2 * S_ + 1] : D.j1[2 * S_], Tall = A.stepsum[S_][K];
+  // this group's steps: an equal share of the pair's COST, cut at the cell boundaries at or behind the nominal cuts
+  const int wg0 = g ? D.off[2 * S_ + 1] : D.off[2 * S_], wg1 = g ? D.off[2 * S_ + 2] : D.off[2 * S_ + 1];   // (compile-time indices: the deal stays in registers)
+  const uint32_t nb = (uint32_t)(wg1 - wg0), bl = blockIdx.x - (uint32_t)wg0;
+  const uint32_t ng = nb * NW * 4u, gi = (bl * NW + (uint32_t)(threadIdx.x >> 6)) * 4u + (uint32_t)q;
+  uint32_t js, je;
+  {
+    const uint32_t* __restrict__ ss = A.costsum[S_];
+    const uint32_t tl = T0 + (uint32_t)((uint64_t)(T1 - T0) * gi / ng), th = T0 + (uint32_t)((uint64_t)(T1 - T0) * (gi + 1) / ng);
+    // two 16-ary searches side by side: first cell k in [kbase, kbase + Kh] with costsum[k] >= target (true at kbase + Kh: = T1 >= target)
+    uint32_t lo[2] = {kbase, kbase}, hi[2] = {kbase + Kh, kbase + Kh};
+    const uint32_t tg[2] = {tl, th};
+    while (__ballot(hi[0] > lo[0] || hi[1] > lo[1]) != 0ull) {
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const uint32_t span = hi[e] - lo[e], step = (span + 15) / 16;
+        const uint32_t idx = lo[e] + (uint32_t)c16 * step;
+        const bool ge = (span == 0 || idx >= hi[e]) ? true : ss[idx] >= tg[e];
+        const uint32_t m16 = (uint32_t)(__ballot(ge) >> (16 * q)) & 0xffffu;
+        if (span) {
+          if (m16 == 0) { lo[e] = lo[e] + 15 * step + 1; }
+          else {
+            const uint32_t f = (uint32_t)__ffs((int)m16) - 1u;
+            hi[e] = min(hi[e], lo[e] + f * step);
+            if (f > 0) lo[e] = lo[e] + (f - 1) * step + 1;
+          }
+        }
+      }
+    }
+    js = A.stepsum[S_][lo[0]]; je = A.stepsum[S_][lo[1]];
   }
-  __syncthreads();
-  const uint32_t kA = sh[0], kB = sh[1];
-  const int nmin1 = A.F.res[sort_minor(S_)] + 1, nmaj1 = A.F.res[sort_major(S_)] + 1;
-  const float* Pg = (g ? A.F.plane[1][I] : A.F.plane[0][I]) + c16 + 16 * ig0;
-  const float* L = (g ? A.F.line[1][I] : A.F.line[0][I]) + c16 + 16 * ig0;
+  const float* Pg = (g ? A.F.plane[1][I] : A.F.plane[0][I]) + c16;
+  const float* L = (g ? A.F.line[1][I] : A.F.line[0][I]) + c16;
+  const int nmin1 = A.F.res[sort_minor(S_)] + 1;
   const double magic = F.fx->magic[I];
   const long long magic_bits = __double_as_longlong(magic);
-  const uint32_t n_any = n_tot ? n_tot - 1 : 0;
-  const uint32_t nquads = (kB - kA + 3) / 4;
-  for (uint32_t j = (uint32_t)wave; j < nquads; j += NW) {
-    const uint32_t k_raw = kA + 4 * j + (uint32_t)q;
-    const bool cell_ok = k_raw < kB;
-    const uint32_t k = cell_ok ? k_raw : kB - 1;
-    const uint32_t a = A.start[S_][k], bnd = cell_ok ? A.start[S_][k + 1] : a;
-    const uint32_t n_mine = bnd - a;
-    uint32_t n_max = max(n_mine, (uint32_t)__shfl_xor((int)n_mine, 16, 64));
-    n_max = max(n_max, (uint32_t)__shfl_xor((int)n_max, 32, 64));
-    if (n_max == 0) continue;
-    const int cmin = (int)(k % (uint32_t)nmin1), cmaj = (int)((k / (uint32_t)nmin1) % (uint32_t)nmaj1);
-    const int cX = sort_major(S_) == AX ? cmaj : cmin, cY = sort_major(S_) == AY ? cmaj : cmin;
-    const int x0 = max(cX - 1, 0), x1 = min(cX, W - 1), y0 = max(cY - 1, 0), y1 = min(cY, H - 1);   // the clamped tap indices of lin_setup
-    const int oP[4] = {(y0 * W + x0) * C, (y0 * W + x1) * C, (y1 * W + x0) * C, (y1 * W + x1) * C};
-    float pt[NLW][4];   // the cell's four plane texels: the same for every sample of the cell
+  const uint32_t* __restrict__ perm = A.perm[S_];
+  const f32x4* __restrict__ coords4 = (const f32x4*)A.coords;
+  const uint4* __restrict__ steps = A.steps[S_];
+  __syncthreads();   // the table is zero before anyone adds to it
+#ifdef EGO_WALK_PROF
+  unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const unsigned long long t_wave0 = __builtin_amdgcn_s_memtime();
+#endif
+  if (Tall) {
+    const uint32_t jlast = Tall - 1;   // every index below is clamped to a step that exists
+    auto entry = [&](uint32_t j) -> uint4 { return steps[min(j, jlast)]; };
+    auto pos = [&](const uint4& e) -> uint32_t { return e.x + min((uint32_t)c16, (e.z & 0xffu) - 1u); };
+    uint32_t j = js;
+    uint4 e0 = entry(j), e1 = entry(j + 1), e2 = entry(j + 2), e3;
+    uint32_t m0 = perm[pos(e0)], m1 = perm[pos(e1)], m2;
+    f32x4 cc0 = coords4[m0], cc1;
+    float d0 = DENS ? A.d[m0] : 0.f, d1 = 0.f;   // dfeat of the step's samples travels with their coordinates
+    float acc[NL][4];
 #pragma unroll
-    for (int i = 0; i < NLW; ++i)
+    for (int i = 0; i < NL; ++i) acc[i][0] = acc[i][1] = acc[i][2] = acc[i][3] = 0.f;
+    while (__ballot(j < je) != 0ull) {
+      WPROF_T(ts0);
+      e3 = entry(j + 3);          // step t + 3's entry, t + 2's permutation entries, t + 1's coordinates: in flight under this step
+      m2 = perm[pos(e2)];
+      cc1 = coords4[m1];
+      if (DENS) d1 = A.d[m1];
+      const bool act = j < je;
+      const int cnt = act ? (int)(e0.z & 0xffu) : 0;
+      const uint32_t k = e0.y;
+      if (act && (e0.z & 256u)) {   // the cell's first step: its four plane texels -> LDS (clamped tap indices of lin_setup)
+        const uint32_t kl = k - kbase;
+        const int cmin = (int)(kl % (uint32_t)nmin1), cmaj = (int)(kl / (uint32_t)nmin1);
+        const int cX = sort_major(S_) == AX ? cmaj : cmin, cY = sort_major(S_) == AY ? cmaj : cmin;
+        const int x0 = max(cX - 1, 0), x1 = min(cX, Wd - 1), y0 = max(cY - 1, 0), y1 = min(cY, H - 1);
+        const int oP[4] = {(y0 * Wd + x0) * C, (y0 * Wd + x1) * C, (y1 * Wd + x0) * C, (y1 * Wd + x1) * C};
 #pragma unroll
-      for (int c = 0; c < 4; ++c) pt[i][c] = Pg[oP[c] + 16 * i];
-    float acc[NLW][4];
+        for (int i = 0; i < NL; ++i)
 #pragma unroll
-    for (int i = 0; i < NLW; ++i) acc[i][0] = acc[i][1] = acc[i][2] = acc[i][3] = 0.f;
-    for (uint32_t off = 0; off < n_max; off += 16) {
-      const int cnt = off < n_mine ? (int)min(16u, n_mine - off) : 0;
-      {   // stage 1: lane 16 q + j = sample j of cell q's batch (clamped to a valid entry; unused records are never read as data)
-        const uint32_t last = n_mine ? bnd - 1 : n_any;
-        const uint32_t pidx = min(a + off + (uint32_t)c16, last);
-        const uint32_t m = A.perm[S_][pidx];
-        const f32x4 cc = ((const f32x4*)A.coords)[m];
-        const float ax[3] = {cc.x, cc.y, cc.z};
-        const Lin1 X = lin_setup(ax[AX], W), Y = lin_setup(ax[AY], H), Ln = lin_setup(ax[AL], NLn);
-        R.f[0][lane] = m;
+          for (int c = 0; c < 4; ++c)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Pg + oP[c] + 16 * i),
+                                             (__attribute__((address_space(3))) void*)&W.pt[i * 4 + c][0], 4, 0, 0);
+      }
+      {   // stage 1: lane 16 q + i = sample i of group q's step
+        const float ax[3] = {cc0.x, cc0.y, cc0.z};
+        const Lin1 X = lin_setup(ax[AX], Wd), Y = lin_setup(ax[AY], H), Ln = lin_setup(ax[AL], NLn);
+        WaveRec& R = W.rec;
+        R.f[0][lane] = m0;
         R.f[1][lane] = __float_as_uint(__fmul_rn(Y.w0, X.w0)); R.f[2][lane] = __float_as_uint(__fmul_rn(Y.w0, X.w1));
         R.f[3][lane] = __float_as_uint(__fmul_rn(Y.w1, X.w0)); R.f[4][lane] = __float_as_uint(__fmul_rn(Y.w1, X.w1));
         R.f[5][lane] = (uint32_t)Ln.i0; R.f[6][lane] = (uint32_t)Ln.i1;
         R.f[7][lane] = __float_as_uint(Ln.w0); R.f[8][lane] = __float_as_uint(Ln.w1);
-        if (DENS) R.f[9][lane] = __float_as_uint(A.d[m]);
+        if (DENS) R.f[9][lane] = __float_as_uint(d0);
       }
       wave_sync();
       int cnt_max = max(cnt, __shfl_xor(cnt, 16, 64));
       cnt_max = max(cnt_max, __shfl_xor(cnt_max, 32, 64));
+      float pt[NL][4];
+      WPROF_T(ts1); WPROF_ADD(0, ts1 - ts0); WPROF_ADD(5, 1);
       for (int t0 = 0; t0 < cnt_max; t0 += U) {   // stage 2: lane = channel of group q's sample t
-        float w4[U][4], lw[U][2], di[U][NLW], l0[U][NLW], l1[U][NLW];
+        WPROF_T(ti0); WPROF_ADD(6, 1);
+        const WaveRec& R = W.rec;
+        float w4[U][4], lw[U][2], di[U][NL], l0[U][NL], l1[U][NL];
         int iL0[U], iL1[U];
         bool ok[U];
 #pragma unroll
@@ -946,105 +1152,139 @@ __device__ __forceinline__ void sorted_fused(const FusedArgs& F, const int combo
           iL0[u] = (int)R.f[5][tt]; iL1[u] = (int)R.f[6][tt];
           lw[u][0] = __uint_as_float(R.f[7][tt]); lw[u][1] = __uint_as_float(R.f[8][tt]);
 #pragma unroll
-          for (int i = 0; i < NLW; ++i) { l0[u][i] = L[iL0[u] * C + 16 * i]; l1[u][i] = L[iL1[u] * C + 16 * i]; }
+          for (int i = 0; i < NL; ++i) { l0[u][i] = L[iL0[u] * C + 16 * i]; l1[u][i] = L[iL1[u] * C + 16 * i]; }
           if (DENS) {
             di[u][0] = __uint_as_float(R.f[9][tt]);
           } else {
 #pragma unroll
-            for (int i = 0; i < NLW; ++i) di[u][i] = A.d[(m >> 5) * (32 * 3 * C) + (I * NL + ig0 + i) * 512 + (m & 31) * 16 + c16];   // k_shade_bwd's blocked dv
+            for (int i = 0; i < NL; ++i) di[u][i] = A.d[(m >> 5) * (32 * 3 * C) + (I * NL + i) * 512 + (m & 31) * 16 + c16];   // k_shade_bwd's blocked dv
           }
+        }
+        WPROF_T(ti1); WPROF_ADD(1, ti1 - ti0);
+#ifdef EGO_WALK_PROF
+        __builtin_amdgcn_s_waitcnt(0x0f70);
+        WPROF_T(ti2); WPROF_ADD(2, ti2 - ti1);
+#endif
+        if (t0 == 0) {
+          // the texels of a cell that started in this step were sent to LDS ahead of the loads above; vector memory returns in order
+          // and vmcnt counts the LDS-bound loads too, so after this wait they have landed (the compiler knows of no dependency)
+          __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0)
+          asm volatile("" ::: "memory");
+#pragma unroll
+          for (int i = 0; i < NL; ++i)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) pt[i][c] = W.pt[i * 4 + c][lane];
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-          float lv[NLW], pv[NLW], dd[NLW];
+          float lv[NL], pv[NL], dd[NL];
 #pragma unroll
-          for (int i = 0; i < NLW; ++i) {
+          for (int i = 0; i < NL; ++i) {
             lv[i] = l0[u][i] * lw[u][0] + l1[u][i] * lw[u][1];
             pv[i] = pt[i][0] * w4[u][0] + pt[i][1] * w4[u][1] + pt[i][2] * w4[u][2] + pt[i][3] * w4[u][3];
           }
           if (DENS) {
             // relu per plane (EgoNeRF.py:340,346): the gradient passes where this plane's sum over channels is positive
-            float dot = pv[0] * lv[0];
-#pragma unroll
-            for (int sh_ = 8; sh_ >= 1; sh_ >>= 1) dot += __shfl_xor(dot, sh_, 16);
+            const float dot = row_sum16(pv[0] * lv[0]);
             dd[0] = (ok[u] && dot > 0.f) ? di[u][0] : 0.f;
           } else {
 #pragma unroll
-            for (int i = 0; i < NLW; ++i) dd[i] = ok[u] ? di[u][i] : 0.f;
+            for (int i = 0; i < NL; ++i) dd[i] = ok[u] ? di[u][i] : 0.f;
           }
-          const double lw0 = (double)lw[u][0], lw1 = (double)lw[u][1];
-          unsigned long long* t0p = tab + iL0[u] * (16 * NLW) + c16;
-          unsigned long long* t1p = tab + iL1[u] * (16 * NLW) + c16;
 #pragma unroll
-          for (int i = 0; i < NLW; ++i) {
+          for (int i = 0; i < NL; ++i) {
             const float gp = dd[i] * lv[i];
             acc[i][0] += gp * w4[u][0]; acc[i][1] += gp * w4[u][1]; acc[i][2] += gp * w4[u][2]; acc[i][3] += gp * w4[u][3];
-            const double gl = (double)__fmul_rn(dd[i], pv[i]);
-            const long long q0 = __double_as_longlong(__fma_rn(gl, lw0, magic)) - magic_bits;
-            const long long q1 = __double_as_longlong(__fma_rn(gl, lw1, magic)) - magic_bits;
-            if (ok[u]) {
-              __hip_atomic_fetch_add(t0p + 16 * i, (unsigned long long)q0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-              __hip_atomic_fetch_add(t1p + 16 * i, (unsigned long long)q1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          }
+          if (do_line) {
+            const double lw0 = (double)lw[u][0], lw1 = (double)lw[u][1];
+            unsigned long long* t0p = tab + iL0[u] * C + c16;
+            unsigned long long* t1p = tab + iL1[u] * C + c16;
+#pragma unroll
+            for (int i = 0; i < NL; ++i) {
+              const double gl = (double)__fmul_rn(dd[i], pv[i]);
+              const long long q0 = __double_as_longlong(__fma_rn(gl, lw0, magic)) - magic_bits;
+              const long long q1 = __double_as_longlong(__fma_rn(gl, lw1, magic)) - magic_bits;
+              if (ok[u]) {
+                __hip_atomic_fetch_add(t0p + 16 * i, (unsigned long long)q0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(t1p + 16 * i, (unsigned long long)q1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              }
             }
           }
         }
       }
-      wave_sync();   // the next batch overwrites the record
-    }
-    if (n_mine) {
-      float* out = A.cellbuf[S_] + cell_slot(A, S_, k) * 4 * C + c16 + 16 * ig0;
+      WPROF_T(ts2); WPROF_ADD(3, ts2 - ts1);
+      wave_sync();   // the next step overwrites the record (and, for a group that starts a cell, its texels)
+      if (act && (e0.z & 512u)) {    // the cell's last step: its four corner sums - one writer per cell, its samples added in ascending order
+        const int64_t slot = A.dense_cells ? (int64_t)k : (int64_t)A.start[S_][k];
+        float* out = A.cellbuf[S_] + slot * 4 * C + c16;
 #pragma unroll
-      for (int i = 0; i < NLW; ++i)
+        for (int i = 0; i < NL; ++i)
 #pragma unroll
-        for (int t = 0; t < 4; ++t) out[t * C + 16 * i] = acc[i][t];
+          for (int t = 0; t < 4; ++t) { out[t * C + 16 * i] = acc[i][t]; acc[i][t] = 0.f; }
+      }
+      ++j;
+      e0 = e1; e1 = e2; e2 = e3;
+      m0 = m1; cc0 = cc1; m1 = m2; d0 = d1;
+      WPROF_T(ts3); WPROF_ADD(4, ts3 - ts2);
     }
   }
+#ifdef EGO_WALK_PROF
+  if (lane == 0) {
+    for (int i = 0; i < 8; ++i) atomicAdd(&g_walk_prof[i + (DENS ? 0 : 8)], prof[i]);
+    const unsigned long long busy = __builtin_amdgcn_s_memtime() - t_wave0;
+    atomicMax(&g_walk_span[2], busy);
+    const uint32_t wid = blockIdx.x * NW + (threadIdx.x >> 6);
+    if (wid < 4096) { g_walk_wave[4 * wid] = (uint32_t)busy; g_walk_wave[4 * wid + 1] = (uint32_t)prof[5]; g_walk_wave[4 * wid + 2] = (uint32_t)prof[6]; g_walk_wave[4 * wid + 3] = 2 * S_ + g; }
+
+  }
+#endif
   __syncthreads();
-  unsigned long long* out = F.part + (int64_t)blockIdx.x * F.part_stride;
-  for (int i = threadIdx.x; i < entries; i += NW * 64) out[i] = tab[i];
+  if (do_line) {
+    unsigned long long* out = F.part + (int64_t)blockIdx.x * F.part_stride;
+    for (int i = threadIdx.x; i < entries; i += NW * 64) out[i] = tab[i];
+  }
 }
 
-// NW waves per workgroup, U samples in flight per 16-lane group: the 48-channel walk holds 3 x (line taps 2, d 1, plane texels 4, sums 4)
-// values per sample in flight - 144 VGPRs at U = 4 (three waves per SIMD: NW = 12), 128 at U = 2 (four: NW = 16)
+// NW waves per workgroup, U samples in flight per 16-lane group
 template <int C, bool DENS, int NW, int U>
-__global__ __launch_bounds__(NW * 64) void k_sorted_fused(FusedArgs F) {
+__global__ __launch_bounds__(NW * 64) void k_sorted_walk(FusedArgs F) {
   extern __shared__ __attribute__((aligned(16))) unsigned char fused_lds[];
-  WaveRec* rec = (WaveRec*)fused_lds;
-  uint32_t* sh = (uint32_t*)(fused_lds + NW * sizeof(WaveRec));
-  unsigned long long* tab = (unsigned long long*)(fused_lds + NW * sizeof(WaveRec) + 64);
-  WaveRec& R = rec[threadIdx.x >> 6];
-  constexpr int NL = C / 16;
-  int combo = 0;
-  while (combo + 1 < F.ncombo && (int)blockIdx.x >= F.wg_off[combo + 1]) ++combo;
-  const int s = F.combo_s[combo], z = F.combo_z[combo];
-  const bool whole = F.nlw[s] == NL;
-#define EGO_FUSED(S_)                                                              \
-  if (whole) sorted_fused<C, DENS, S_, NL, NW, U>(F, combo, z, tab, R, sh);        \
-  else sorted_fused<C, DENS, S_, 1, NW, U>(F, combo, z, tab, R, sh)
-  if (s == 0) { EGO_FUSED(0); } else if (s == 1) { EGO_FUSED(1); } else { EGO_FUSED(2); }
-#undef EGO_FUSED
+  typedef WalkLds<C / 16> WL;
+  WL* wl = (WL*)fused_lds;
+  unsigned long long* tab = (unsigned long long*)(fused_lds + NW * sizeof(WL));
+  const WalkDeal D = walk_deal(F);
+  if ((int)blockIdx.x >= D.off[6]) return;
+  int p = 0;
+#pragma unroll
+  for (int i = 1; i < 6; ++i) p += (int)blockIdx.x >= D.off[i] ? 1 : 0;
+  const int s = p >> 1, g = p & 1;
+  if (F.dbg >= 16 && (F.dbg >> 4) - 1 != p) return;   // experiments: one (sort, grid) pair alone (timing only)
+  const bool do_line = F.do_line[s] != 0;
+  if (s == 0) sorted_walk<C, DENS, 0, NW, U>(F, D, g, tab, wl, do_line);
+  else if (s == 1) sorted_walk<C, DENS, 1, NW, U>(F, D, g, tab, wl, do_line);
+  else sorted_walk<C, DENS, 2, NW, U>(F, D, g, tab, wl, do_line);
 }
 
-// line texel (g, t, ch) of line I = sort_plane(s): the integer sums of the workgroups that served grid g, converted once
+// line texel (g, t, ch) of line I = sort_plane(s): the integer sums of the workgroups that served (s, g), converted once
 template <int C>
 __global__ void k_fused_line_final(FusedArgs F) {
-  constexpr int NL = C / 16;
   const SortedArgs& A = F.A;
   const int s = blockIdx.y, I = s == 0 ? 1 : s == 1 ? 0 : 2, AL = 2 - I;
+  if (!F.do_line[s]) return;
   const int n = A.F.res[AL];
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= 2 * n * C) return;
   const int ch = idx % C, t = (idx / C) % n, g = idx / (C * n);
-  const bool whole = F.nlw[s] == NL;
-  const int combo = F.combo_first[s] + (whole ? 0 : ch / 16);
-  const int entry = whole ? t * C + ch : t * 16 + (ch & 15);
-  const uint32_t K = A.K[s], n_g0 = A.start[s][K / 2], n_tot = A.start[s][K];
-  const uint32_t nwg = (uint32_t)(F.wg_off[combo + 1] - F.wg_off[combo]);
-  const uint32_t nwg0 = fused_split(nwg, n_g0, n_tot);
-  const uint32_t b0 = g ? nwg0 : 0u, b1 = g ? nwg : nwg0;
+  const int entry = t * C + ch;
+  const WalkDeal D = walk_deal(F);
+  int b0 = 0, b1 = 0;
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+    if (i == 2 * s + g) { b0 = D.off[i]; b1 = D.off[i + 1]; }
   long long sum = 0;
-  const unsigned long long* p = F.part + (int64_t)F.wg_off[combo] * F.part_stride + entry;
-  for (uint32_t b = b0; b < b1; ++b) sum += (long long)p[(int64_t)b * F.part_stride];
+  const unsigned long long* p = F.part + entry;
+  for (int b = b0; b < b1; ++b) sum += (long long)p[(int64_t)b * F.part_stride];
   const float v = F.fx->poison ? __uint_as_float(0x7fc00000u) : (float)((double)sum * F.fx->lsb[I]);
   (g ? A.G.line[1][I] : A.G.line[0][I])[t * C + ch] = v;
 }
@@ -1064,11 +1304,15 @@ int fill_args(const ego_vm_field& f, const ego_vm_grad* grad, const float* coord
     a->perm[s] = (const uint32_t*)(base + G.perm[s]);
     a->start[s] = (const uint32_t*)(base + G.start[s]);
     a->suboff[s] = (const uint32_t*)(base + G.suboff[s]);
+    a->stepsum[s] = (const uint32_t*)(base + G.stepsum[s]);
+    a->costsum[s] = (const uint32_t*)(base + G.costsum[s]);
+    a->steps[s] = (const uint4*)(base + G.steps[s]);
     a->cellbuf[s] = (float*)(base + G.cellbuf[s]);
     a->linepart[s] = (float*)(base + G.linepart[s]);
     a->K[s] = G.K[s]; a->LC[s] = G.LC[s];
   }
   a->dense_cells = G.dense_cells ? 1 : 0;
+  a->line_mask = 7;
   return EGO_OK;
 }
 
@@ -1106,89 +1350,93 @@ int device_cus() {
   return cus;
 }
 
-// may this call take the fused form?  (the plan of the widest field sized the workspace; EGO_SORTED_LINES=separate keeps the two-pass form)
-bool fused_wanted(const int32_t res[3], int C, FusedPlan* P) {
-  if (const char* e = getenv("EGO_SORTED_LINES"))
-    if (e[0] == 's') return false;
-  if (!fused_plan(res, CMAX).ok) return false;
-  *P = fused_plan(res, C);
-  return P->ok;
+// the round-5 form (lockstep plane kernel + line kernels) stays reachable for A/B: EGO_SORTED_WALK=0
+bool walk_wanted() {
+  const char* e = getenv("EGO_SORTED_WALK");
+  return !(e && e[0] == '0');
 }
 
 template <int C, bool DENS, int NW, int U>
-int launch_fused_nw(const FusedArgs& F, int wg_total, int lds_bytes, hipStream_t st) {
+int launch_walk_nw(const FusedArgs& F, int wg_total, int lds_bytes, hipStream_t st) {
   static std::atomic<int> attr_set{0};
   if (attr_set.load(std::memory_order_relaxed) < lds_bytes) {
-    if (const hipError_t e = hipFuncSetAttribute((const void*)k_sorted_fused<C, DENS, NW, U>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes))
-      return ego_fail((int)e, "k_sorted_fused: cannot reserve %d bytes of LDS: %s", lds_bytes, hipGetErrorString(e));
+    if (const hipError_t e = hipFuncSetAttribute((const void*)k_sorted_walk<C, DENS, NW, U>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes))
+      return ego_fail((int)e, "k_sorted_walk: cannot reserve %d bytes of LDS: %s", lds_bytes, hipGetErrorString(e));
     attr_set.store(lds_bytes, std::memory_order_relaxed);
   }
-  k_sorted_fused<C, DENS, NW, U><<<wg_total, NW * 64, lds_bytes, st>>>(F);
-  return ego_launch_status("k_sorted_fused");
+  k_sorted_walk<C, DENS, NW, U><<<wg_total, NW * 64, lds_bytes, st>>>(F);
+  return ego_launch_status("k_sorted_walk");
 }
 
 template <int C, bool DENS>
-int launch_fused(const SortedArgs& a, const SortGeom& G, const FusedPlan& P, char* base, int64_t M, const float* dmax_ext, hipStream_t st) {
+int launch_walk(SortedArgs a, const SortGeom& G, char* base, int64_t M, const float* dmax_ext, hipStream_t st) {
+  static_assert(sizeof(WalkLds<C / 16>) == 12 * 64 * 4 + (C / 16) * 4 * 64 * 4, "walk_wave_bytes() mirrors WalkLds");
+  const FusedPlan P = fused_plan(G.res, C);
   FxScale* fx = (FxScale*)(base + G.fx);
   if (const hipError_t e = hipMemsetAsync(fx, 0, 256, st)) return ego_fail((int)e, "scatter_sorted: hipMemsetAsync failed: %s", hipGetErrorString(e));
-  AbsmaxArgs ab{};
-  for (int g = 0; g < 2; ++g)
-    for (int i = 0; i < 3; ++i) ab.plane[g][i] = a.F.plane[g][i];
-  for (int i = 0; i < 3; ++i) ab.n_plane[i] = (int64_t)G.res[i == 2 ? 1 : 0] * G.res[i == 0 ? 1 : 2] * C;
-  ab.fx = fx;
-  if (!dmax_ext) {
-    ab.d = a.d;
-    if (DENS) { ab.n_d = M; }
-    else { ab.n_d = (M / 32) * (32 * 3 * C); ab.tail_rows = (int32_t)(M % 32); ab.tail_block = 32 * 3 * C; }
+  const bool any_line = P.do_line[0] || P.do_line[1] || P.do_line[2];
+  if (any_line) {
+    AbsmaxArgs ab{};
+    for (int g = 0; g < 2; ++g)
+      for (int i = 0; i < 3; ++i) ab.plane[g][i] = a.F.plane[g][i];
+    for (int i = 0; i < 3; ++i) ab.n_plane[i] = (int64_t)G.res[i == 2 ? 1 : 0] * G.res[i == 0 ? 1 : 2] * C;
+    ab.fx = fx;
+    ab.part = (uint32_t*)(base + G.fx + 256);
+    if (!dmax_ext) {
+      ab.d = a.d;
+      if (DENS) { ab.n_d = M; }
+      else { ab.n_d = (M / 32) * (32 * 3 * C); ab.tail_rows = (int32_t)(M % 32); ab.tail_block = 32 * 3 * C; }
+    }
+    k_fx_absmax<<<dim3(FX_BLOCKS, 7), 256, 0, st>>>(ab);
+    if (int e = ego_launch_status("k_fx_absmax")) return e;
+    k_fx_setup<<<1, 64, 0, st>>>(fx, ab.part, M, dmax_ext);
+    if (int e = ego_launch_status("k_fx_setup")) return e;
   }
-  k_fx_absmax<<<dim3(96, 7), 256, 0, st>>>(ab);
-  if (int e = ego_launch_status("k_fx_absmax")) return e;
-  k_fx_setup<<<1, 64, 0, st>>>(fx, M, dmax_ext);
-  if (int e = ego_launch_status("k_fx_setup")) return e;
   FusedArgs F{};
-  F.A = a; F.fx = fx;
+  F.fx = fx;
   F.part = (unsigned long long*)(base + G.fpart);
   F.part_stride = (uint32_t)G.fpart_stride;
-  F.ncombo = P.ncombo;
-  // workgroups per (sort, channel group): one workgroup per CU in all, dealt in proportion to the work (a whole-field walk does NL
-  // channel groups per set-up, a split one does one)
+  if (const char* e = getenv("EGO_FUSED_DBG")) F.dbg = atoi(e);
+  // one workgroup per CU; the kernel deals them to the (sort, grid) pairs in proportion to their steps (walk_deal)
   int wg_total = device_cus();
   if (wg_total > FUSED_MAX_WG) wg_total = FUSED_MAX_WG;
-  if (wg_total < 2 * P.ncombo) wg_total = 2 * P.ncombo;
-  int wsum = 0, wgt[9];
-  for (int c = 0; c < P.ncombo; ++c) { wgt[c] = P.nlw[P.combo_s[c]] + 1; wsum += wgt[c]; }
-  int off = 0, wacc = 0;
-  for (int c = 0; c < P.ncombo; ++c) {
-    F.wg_off[c] = off;
-    F.combo_s[c] = (int8_t)P.combo_s[c]; F.combo_z[c] = (int8_t)P.combo_z[c];
-    wacc += wgt[c];
-    int end = (int)((int64_t)wg_total * wacc / wsum);
-    const int left = P.ncombo - 1 - c;
-    if (end < off + 2) end = off + 2;
-    if (end > wg_total - 2 * left) end = wg_total - 2 * left;
-    off = end;
-  }
-  F.wg_off[P.ncombo] = off;
-  for (int s = 0; s < 3; ++s) { F.nlw[s] = (int8_t)P.nlw[s]; F.combo_first[s] = (int8_t)P.combo_first[s]; }
+  if (wg_total < 6) wg_total = 6;
+  F.nwg = wg_total;
+  const int off = wg_total;
+  for (int s = 0; s < 3; ++s) F.do_line[s] = P.do_line[s] ? 1 : 0;
+  // the lines the walk does not take keep the two-pass form
+  int mask = 0;
+  for (int s = 0; s < 3; ++s)
+    if (!P.do_line[s]) { const int Ln = sort_plane(s); mask |= 1 << (Ln == 0 ? 0 : Ln == 1 ? 2 : 1); }   // the sort whose major key is line Ln's axis
+  a.line_mask = mask;
+  F.A = a;
   {
-    int e;
-    if (P.nw == 16) e = launch_fused_nw<C, DENS, 16, (C > 16 ? 2 : 4)>(F, off, P.lds_bytes, st);
-    else if (P.nw == 12) e = launch_fused_nw<C, DENS, 12, 4>(F, off, P.lds_bytes, st);
-    else e = launch_fused_nw<C, DENS, 8, 4>(F, off, P.lds_bytes, st);
-    if (e) return e;
+    constexpr int NW = C > 16 ? WALK_NW_APP : WALK_NW_DENS;
+    if (int e = launch_walk_nw<C, DENS, NW, 4>(F, off, P.lds_bytes, st)) return e;
+  }
+  if (mask) {
+    k_sorted_line<C, DENS><<<dim3((G.nsub_max + 3) / 4, 3), 256, 0, st>>>(a);
+    if (int e = ego_launch_status("k_sorted_line")) return e;
   }
   int64_t texmax = 0, linemax = 0;
   for (int s = 0; s < 3; ++s) {
     const int I = sort_plane(s);
     const int64_t tex = (int64_t)2 * G.res[I == 2 ? 1 : 0] * G.res[I == 0 ? 1 : 2] * (C / 4);
     texmax = tex > texmax ? tex : texmax;
-    const int64_t ln = (int64_t)2 * G.res[fused_line_axis(s)] * C;
+    const int64_t ln = (int64_t)2 * G.res[s] * C;
     linemax = ln > linemax ? ln : linemax;
   }
   k_sorted_plane_final<C><<<dim3((unsigned)((texmax + 255) / 256), 3), 256, 0, st>>>(a);
   if (int e = ego_launch_status("k_sorted_plane_final")) return e;
-  k_fused_line_final<C><<<dim3((unsigned)((linemax + 255) / 256), 3), 256, 0, st>>>(F);
-  return ego_launch_status("k_fused_line_final");
+  if (mask) {
+    k_sorted_line_final<C><<<dim3((unsigned)((linemax + 255) / 256), 3), 256, 0, st>>>(a);
+    if (int e = ego_launch_status("k_sorted_line_final")) return e;
+  }
+  if (any_line) {
+    k_fused_line_final<C><<<dim3((unsigned)((linemax + 255) / 256), 3), 256, 0, st>>>(F);
+    if (int e = ego_launch_status("k_fused_line_final")) return e;
+  }
+  return EGO_OK;
 }
 
 // an empty batch: no sample, so every gradient texel is 0 - and "every texel is written" holds for it too (the tables
@@ -1214,6 +1462,21 @@ int check_sizes(const ego_scene* sc, int64_t N, int32_t S, const char* who) {
 }
 
 }  // namespace
+
+#ifdef EGO_WALK_PROF
+extern "C" int ego_debug_walk_prof(unsigned long long* out16) {   // experiment builds only: read and clear the counters
+  unsigned long long z[16] = {};
+  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_walk_prof), sizeof(z)) != hipSuccess) return -1;
+  if (hipMemcpyFromSymbol(out16 + 16, HIP_SYMBOL(g_walk_span), 32) != hipSuccess) return -1;
+  unsigned long long sp[4] = {0ull, 0ull, 0ull, 0ull};
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_walk_span), sp, 32) != hipSuccess) return -1;
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_walk_prof), z, sizeof(z)) == hipSuccess ? 0 : -1;
+}
+#endif
+
+#ifdef EGO_WALK_PROF
+extern "C" int ego_debug_walk_waves(uint32_t* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_walk_wave), 4096 * 16) == hipSuccess ? 0 : -1; }
+#endif
 
 extern "C" {
 
@@ -1263,6 +1526,9 @@ int ego_scatter_sort(const ego_scene* sc, const float* coords, int64_t N, int32_
     sa.sorted[s] = (const uint32_t*)(base + G.k2[s]);
     sa.start[s] = (uint32_t*)(base + G.start[s]);
     sa.suboff[s] = (uint32_t*)(base + G.suboff[s]);
+    sa.stepsum[s] = (uint32_t*)(base + G.stepsum[s]);
+    sa.costsum[s] = (uint32_t*)(base + G.costsum[s]);
+    sa.steps[s] = (uint4*)(base + G.steps[s]);
     sa.K[s] = G.K[s]; sa.LC[s] = G.LC[s]; sa.nmin1[s] = (uint32_t)G.res[sort_minor(s)] + 1;
     kmax = G.K[s] > kmax ? G.K[s] : kmax;
   }
@@ -1271,6 +1537,10 @@ int ego_scatter_sort(const ego_scene* sc, const float* coords, int64_t N, int32_
   if (int e = ego_launch_status("k_cell_starts")) return e;
   k_line_suboff<<<dim3(1, 3), 1024, 0, st>>>(sa);
   if (int e = ego_launch_status("k_line_suboff")) return e;
+  k_step_scan<<<dim3(2, 3), 1024, 0, st>>>(sa);
+  if (int e = ego_launch_status("k_step_scan")) return e;
+  k_step_fill<<<dim3((kmax + 255) / 256, 3), 256, 0, st>>>(sa);
+  if (int e = ego_launch_status("k_step_fill")) return e;
   return EGO_OK;
 }
 
@@ -1285,8 +1555,7 @@ int ego_scatter_density_sorted(const ego_scene* sc, const ego_vm_grad* gdensity,
   if (workspace_bytes < G.total) return ego_fail(EGO_E_BADARG, "scatter_density_sorted: workspace too small");
   SortedArgs a{};
   if (int e = fill_args(sc->density, gdensity, coords, dfeat, G, workspace, &a, "scatter_density_sorted")) return e;
-  FusedPlan P;
-  if (fused_wanted(sc->density.res, 16, &P)) return launch_fused<16, true>(a, G, P, (char*)workspace, N * (int64_t)S, nullptr, (hipStream_t)stream);
+  if (walk_wanted()) return launch_walk<16, true>(a, G, (char*)workspace, N * (int64_t)S, nullptr, (hipStream_t)stream);
   return launch_sorted<16, true>(a, G, (hipStream_t)stream);
 }
 
@@ -1301,8 +1570,7 @@ int ego_scatter_app_sorted(const ego_scene* sc, const ego_vm_grad* gapp, const f
   if (workspace_bytes < G.total) return ego_fail(EGO_E_BADARG, "scatter_app_sorted: workspace too small");
   SortedArgs a{};
   if (int e = fill_args(sc->app, gapp, coords, dv, G, workspace, &a, "scatter_app_sorted")) return e;
-  FusedPlan P;
-  if (fused_wanted(sc->app.res, 48, &P)) return launch_fused<48, false>(a, G, P, (char*)workspace, N * (int64_t)S, dv_absmax, (hipStream_t)stream);
+  if (walk_wanted()) return launch_walk<48, false>(a, G, (char*)workspace, N * (int64_t)S, dv_absmax, (hipStream_t)stream);
   return launch_sorted<48, false>(a, G, (hipStream_t)stream);
 }
 

@@ -110,21 +110,21 @@ def test_an_empty_batch_zero_fills_the_tables():
         assert float(g.abs().max()) == 0.0
 
 
-def _float64_grid_sample_gradients(cfg, weights, coords, dfeat, dv_ref):
+def _float64_grid_sample_gradients(cfg, weights, coords, dfeat, dv_ref, dtype=torch.float64):
     """Independent truth for the stand-alone scatters: float64 autograd THROUGH the oracle's F.grid_sample calls
     (align_corners=True, zero padding: grid_sampler_2d_backward is an index_add of the 18 taps x C channels per sample) on the CPU.
     coords [N,S,4] normalised (r, theta, phi, is_yang); dfeat [N,S] = dL/d(density feature); dv_ref [M,144] = dL/d(plane*line products)
     in the reference's channel order.  -> (density grads, app grads) in table_params() order, reference-shaped float64 tensors."""
     from tests.helpers import make_oracle
-    sc = make_oracle(cfg, weights, dtype=torch.float64)
-    c4 = coords.reshape(-1, 4).double().cpu()
+    sc = make_oracle(cfg, weights, dtype=dtype)
+    c4 = coords.reshape(-1, 4).to(dtype).cpu()
     c7 = torch.cat([c4[:, :3], c4[:, :3], c4[:, 3:4]], -1)     # the same normalised triple in the yin and the yang slot; the flag picks the tables
     keys = lambda kind: [f"{kind}_{what}_{g}.{i}" for g in ("yin", "yang") for what in ("plane", "line") for i in range(3)]
     for k in keys("density") + keys("app"):
         sc.w[k] = sc.w[k].clone().requires_grad_(True)
-    loss_d = (sc.density_feature(c7) * dfeat.reshape(-1).double().cpu()).sum()      # sum_i relu(sum_c P L): EgoNeRF.py:291-347
+    loss_d = (sc.density_feature(c7) * dfeat.reshape(-1).to(dtype).cpu()).sum()      # sum_i relu(sum_c P L): EgoNeRF.py:291-347
     gd = torch.autograd.grad(loss_d, [sc.w[k] for k in keys("density")])
-    dvr = dv_ref.double().cpu()
+    dvr = dv_ref.to(dtype).cpu()
     loss_a = 0.0
     is_yin = c7[:, -1] == 0
     for g, sel in (("yin", is_yin), ("yang", ~is_yin)):
@@ -145,14 +145,20 @@ def _blocked_dv(dv_ref, M):
     return full.view(Mp // 32, 32, 9, 16).permute(0, 2, 1, 3).contiguous().view(-1)
 
 
-@pytest.mark.parametrize("n_voxel,N,S,spread", [(27e6, 512, 256, 1.0),       # the headline grid [150, 172, 516], 131 072 samples
-                                                (216e6, 96, 64, 1.05),       # 20-bit cell keys, samples beyond the border
-                                                (40 ** 3, 333, 45, 1.15)])
-def test_scatters_against_float64_grid_sample_backward(n_voxel, N, S, spread):
+@pytest.mark.parametrize("n_voxel,N,S,spread,tol64", [(27e6, 512, 256, 1.0, 3e-5),       # the headline grid [150, 172, 516], 131 072 samples
+                                                      (216e6, 96, 64, 1.05, 1.5e-4),     # 20-bit cell keys, samples beyond the border
+                                                      (40 ** 3, 333, 45, 1.15, 3e-5)])
+def test_scatters_against_float64_grid_sample_backward(n_voxel, N, S, spread, tol64):
     """Both forms of both scatters (sorted and float-atomic) against float64 autograd through F.grid_sample - the thing
     models/EgoNeRF.py:316-345, :377-407 differentiate - at 3e-5 of each table's largest gradient.  (A density sample whose per-plane channel
     sum lies within float32 rounding of 0 could take the other ReLU branch than float64 does; on these seeded inputs none does - the
-    kernels are deterministic, so this is a fixed property of the case, not a flake.)"""
+    kernels are deterministic, so this is a fixed property of the case, not a flake.)
+
+    On the [300, 346, 1036] grid the float64 figure is dominated by the COORDINATES, not by the sums: a float32 pixel coordinate near
+    1 000 carries half an ulp = 3e-5 of a texel, so an interpolation weight - and with 6 144 samples over 10^5 texels, a whole texel's
+    gradient - is off by that much against float64 whatever the kernel does (the reference's float32 grid_sample has the same error).
+    There the float64 bound is 1.5e-4 and the kernels are ALSO held to 3e-5 of the reference's own arithmetic: float32 autograd through
+    the same F.grid_sample calls (a few terms per texel: its summation error is negligible)."""
     cfg = synth.SceneConfig(n_voxel=n_voxel)
     weights = synth.make_weights(cfg, seed=21)
     model = make_model(cfg, weights, DEV)
@@ -167,6 +173,7 @@ def test_scatters_against_float64_grid_sample_backward(n_voxel, N, S, spread):
     dfeat[torch.rand(N, S, generator=g) < 0.3] = 0.0
     dv_ref = torch.randn(M, 144, generator=g)
     ref_d, ref_a = _float64_grid_sample_gradients(cfg, weights, coords, dfeat, dv_ref)
+    ref32 = _float64_grid_sample_gradients(cfg, weights, coords, dfeat, dv_ref, dtype=torch.float32) if tol64 > 3e-5 else None
     out = _scatter_both(model, coords.to(DEV).contiguous(), dfeat.to(DEV).contiguous(), _blocked_dv(dv_ref, M).to(DEV), N, S)
     worst = 0.0
     for mode in ("sorted", "atomic"):
@@ -176,8 +183,11 @@ def test_scatters_against_float64_grid_sample_backward(n_voxel, N, S, spread):
                 scale = max(float(ref.abs().max()), 1e-20)
                 err = float((got.double().cpu() - ref).abs().max()) / scale
                 worst = max(worst, err)
-                assert err <= 3e-5, (mode, field, k, err)
+                assert err <= tol64, (mode, field, k, err)
                 assert float(ref.abs().max()) > 0
+                if ref32 is not None:
+                    e32 = float((got.double().cpu() - ref32[fi][k].double()).abs().max()) / scale
+                    assert e32 <= 3e-5, (mode, field, k, e32, "vs float32 autograd")
     print(f"scatter vs float64 grid_sample backward: worst {worst:.2e} of a table's largest gradient")
 
 
