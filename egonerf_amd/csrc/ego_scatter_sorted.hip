@@ -401,11 +401,11 @@ __global__ __launch_bounds__(1024) void k_line_suboff(StartArgs A) {
 // steps[j] = {first sorted position, cell, samples | first step of its cell << 8 | last << 9, 0}.  With the list the walk is dealt in
 // EQUAL numbers of steps per group, whatever the cells' sizes - a first version that dealt cells in chunks had its slowest wave at 3.5 x
 // the mean (tools/sorted_probe.py PROBE_PROF on a -DEGO_WALK_PROF build).
-// cost of a cell's steps in units of one stage-2 iteration of the walk (U = 4 samples per group): a step = its fixed part (prefetches,
-// set-up, record: about one iteration's time, measured with -DEGO_WALK_PROF) + ceil(samples / 4) iterations
-__device__ __forceinline__ uint32_t cell_cost(uint32_t n) {
+// cost of a cell's steps: a step = its fixed part (prefetches, set-up, record: 0.6 of an iteration's time, measured with
+// -DEGO_WALK_PROF: 3.2 k against 5.3 k clocks in the 48-channel walk) + ceil(samples / 4) stage-2 iterations (U = 4 samples per group)
+__device__ __forceinline__ uint32_t cell_cost(uint32_t n) {   // in fifths of an iteration: a step's fixed part = 3, an iteration = 5
   const uint32_t full = n / 16u, r = n % 16u;
-  return full * 5u + (r ? 1u + (r + 3u) / 4u : 0u);
+  return full * 23u + (r ? 3u + 5u * ((r + 3u) / 4u) : 0u);
 }
 
 // blockIdx.x = 0: stepsum, 1: costsum
@@ -982,8 +982,8 @@ struct FusedArgs {
   int32_t dbg;                // experiments (EGO_FUSED_DBG): 1 = no LDS atomics, 2 = no line part at all (timing only: wrong line gradients)
 };
 
-// Workgroups are dealt to the six (sort, grid) pairs in proportion to the COST of their steps (cell_cost; x 5 / 4 where the line rides
-// along); every pair that has steps gets at least one.  j0 / j1: the pair's range of the sort's cost prefix.  Evaluated identically by every workgroup of the walk and by k_fused_line_final.
+// Workgroups are dealt to the six (sort, grid) pairs in proportion to the COST of their steps (cell_cost; x 6 / 5 where the line rides
+// along: measured); every pair that has steps gets at least one.  j0 / j1: the pair's range of the sort's cost prefix.  Evaluated identically by every workgroup of the walk and by k_fused_line_final.
 struct WalkDeal { int32_t off[7]; uint32_t j0[6], j1[6]; };
 __device__ __forceinline__ WalkDeal walk_deal(const FusedArgs& F) {
   WalkDeal D;
@@ -995,7 +995,7 @@ __device__ __forceinline__ WalkDeal walk_deal(const FusedArgs& F) {
     D.j0[2 * s] = 0; D.j1[2 * s] = mid; D.j0[2 * s + 1] = mid; D.j1[2 * s + 1] = tot;
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
-      w[2 * s + g] = (uint64_t)(D.j1[2 * s + g] - D.j0[2 * s + g]) * (F.do_line[s] ? 5u : 4u);
+      w[2 * s + g] = (uint64_t)(D.j1[2 * s + g] - D.j0[2 * s + g]) * (F.do_line[s] ? 6u : 5u);
       W += w[2 * s + g];
       nz += w[2 * s + g] != 0;
     }
@@ -1072,8 +1072,13 @@ __device__ __forceinline__ void sorted_walk(const FusedArgs& F, const WalkDeal& 
     }
     js = A.stepsum[S_][lo[0]]; je = A.stepsum[S_][lo[1]];
   }
-  const float* Pg = (g ? A.F.plane[1][I] : A.F.plane[0][I]) + c16;
-  const float* L = (g ? A.F.line[1][I] : A.F.line[0][I]) + c16;
+  // wave-uniform table bases; the lane's channel (c16) goes into the 32-bit element offsets, so a tap address is `scalar base + one VGPR`
+  // instead of a 64-bit per-lane pointer sum (the 48-channel walk is VALU-bound: ~470 instructions per iteration, three waves per SIMD)
+  const float* __restrict__ Pg = g ? A.F.plane[1][I] : A.F.plane[0][I];
+  const float* __restrict__ L = g ? A.F.line[1][I] : A.F.line[0][I];
+  const float* __restrict__ Dv = A.d;
+  // (BYTE offsets: `base + zext(u32)` is what selects the scalar-base form of global_load; an element index would need a 64-bit shift)
+  auto at = [](const float* base, uint32_t byte_off) -> float { return *(const float*)((const char*)base + byte_off); };
   const int nmin1 = A.F.res[sort_minor(S_)] + 1;
   const double magic = F.fx->magic[I];
   const long long magic_bits = __double_as_longlong(magic);
@@ -1111,12 +1116,13 @@ __device__ __forceinline__ void sorted_walk(const FusedArgs& F, const WalkDeal& 
         const int cmin = (int)(kl % (uint32_t)nmin1), cmaj = (int)(kl / (uint32_t)nmin1);
         const int cX = sort_major(S_) == AX ? cmaj : cmin, cY = sort_major(S_) == AY ? cmaj : cmin;
         const int x0 = max(cX - 1, 0), x1 = min(cX, Wd - 1), y0 = max(cY - 1, 0), y1 = min(cY, H - 1);
-        const int oP[4] = {(y0 * Wd + x0) * C, (y0 * Wd + x1) * C, (y1 * Wd + x0) * C, (y1 * Wd + x1) * C};
+        const uint32_t oP[4] = {(uint32_t)((y0 * Wd + x0) * C + c16), (uint32_t)((y0 * Wd + x1) * C + c16), (uint32_t)((y1 * Wd + x0) * C + c16),
+                                (uint32_t)((y1 * Wd + x1) * C + c16)};
 #pragma unroll
         for (int i = 0; i < NL; ++i)
 #pragma unroll
           for (int c = 0; c < 4; ++c)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Pg + oP[c] + 16 * i),
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Pg + (oP[c] + 16u * i)),
                                              (__attribute__((address_space(3))) void*)&W.pt[i * 4 + c][0], 4, 0, 0);
       }
       {   // stage 1: lane 16 q + i = sample i of group q's step
@@ -1146,18 +1152,21 @@ __device__ __forceinline__ void sorted_walk(const FusedArgs& F, const WalkDeal& 
           const int t = t0 + u;
           ok[u] = t < cnt;
           const int tt = 16 * q + (ok[u] ? t : 0);
-          const int64_t m = R.f[0][tt];
+          const uint32_t m = R.f[0][tt];
 #pragma unroll
           for (int c = 0; c < 4; ++c) w4[u][c] = __uint_as_float(R.f[1 + c][tt]);
           iL0[u] = (int)R.f[5][tt]; iL1[u] = (int)R.f[6][tt];
           lw[u][0] = __uint_as_float(R.f[7][tt]); lw[u][1] = __uint_as_float(R.f[8][tt]);
+          const uint32_t oL0 = (uint32_t)(iL0[u] * C + c16) * 4u, oL1 = (uint32_t)(iL1[u] * C + c16) * 4u;
 #pragma unroll
-          for (int i = 0; i < NL; ++i) { l0[u][i] = L[iL0[u] * C + 16 * i]; l1[u][i] = L[iL1[u] * C + 16 * i]; }
+          for (int i = 0; i < NL; ++i) { l0[u][i] = at(L, oL0 + 64u * i); l1[u][i] = at(L, oL1 + 64u * i); }
           if (DENS) {
             di[u][0] = __uint_as_float(R.f[9][tt]);
           } else {
+            // k_shade_bwd's blocked dv; 32-bit element offsets (byte offsets below 2^32: the launcher takes this path only below 2^30 elements)
+            const uint32_t od = ((m >> 5) * (uint32_t)(32 * 3 * C) + (uint32_t)(I * NL) * 512u + (m & 31u) * 16u + (uint32_t)c16) * 4u;
 #pragma unroll
-            for (int i = 0; i < NL; ++i) di[u][i] = A.d[(m >> 5) * (32 * 3 * C) + (I * NL + i) * 512 + (m & 31) * 16 + c16];   // k_shade_bwd's blocked dv
+            for (int i = 0; i < NL; ++i) di[u][i] = at(Dv, od + 2048u * i);
           }
         }
         WPROF_T(ti1); WPROF_ADD(1, ti1 - ti0);
@@ -1570,7 +1579,8 @@ int ego_scatter_app_sorted(const ego_scene* sc, const ego_vm_grad* gapp, const f
   if (workspace_bytes < G.total) return ego_fail(EGO_E_BADARG, "scatter_app_sorted: workspace too small");
   SortedArgs a{};
   if (int e = fill_args(sc->app, gapp, coords, dv, G, workspace, &a, "scatter_app_sorted")) return e;
-  if (walk_wanted()) return launch_walk<48, false>(a, G, (char*)workspace, N * (int64_t)S, dv_absmax, (hipStream_t)stream);
+  if (walk_wanted() && (N * (int64_t)S + 31) / 32 * 32 * 144 < (1ll << 30))   // (the walk addresses dv with 32-bit element offsets)
+    return launch_walk<48, false>(a, G, (char*)workspace, N * (int64_t)S, dv_absmax, (hipStream_t)stream);
   return launch_sorted<48, false>(a, G, (hipStream_t)stream);
 }
 
