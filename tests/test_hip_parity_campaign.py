@@ -1,8 +1,7 @@
 """Randomised parity campaign inside the GPU suite: HIP render vs the CPU oracle over random scene seeds,
 tiny grids, ray / sample counts, resampling modes and envmap settings, in every shipped split arithmetic - the streams of seeds 13 and 23
-(whose cases 6 / 7 were the worst of round 2's 160-case campaign) and 4 and 7 (seed 4: the worst of round 3), 40 cases each; the full
-4 x 160-case campaign of seeds 0-3 runs behind `-m "gpu and slow"` and leaves its summary in
-gpurun_out/parity_campaign_full.json -> profiles/rNN/.  Original note on seeds 13 / 23: their cases 6 / 7 were the worst of round 2's campaign (|dRGB| 8e-5, from the float32 sensitivity of sample_pdf on
+(whose cases 6 / 7 were the worst of round 2's 160-case campaign) and 4 and 7 (seed 4: the worst of round 3), 40 cases each, and the full
+4 x 160-case campaign of seeds 0-3, which leaves its summary in gpurun_out/parity_campaign_full.json -> profiles/rNN/.  Original note on seeds 13 / 23: their cases 6 / 7 were the worst of round 2's campaign (|dRGB| 8e-5, from the float32 sensitivity of sample_pdf on
 steep tiny grids, dataLoader/ray_utils.py:156-187).
 
 Tolerance (north_star): 1e-4 RGB against the reference's float32 evaluation.  On top of that the argument "what is left comes
@@ -104,12 +103,12 @@ def test_campaign_vs_float32_and_float64_oracle(seed):
         assert st["excused"] <= MAX_EXCUSED, f"seed {seed} {prec}: {st['excused']} rays needed the float64 excuse (allowed: {MAX_EXCUSED})"
 
 
-@pytest.mark.slow
 def test_full_campaign_4_seeds_x_160_cases_x_3_arithmetics():
-    """the whole campaign (seeds 0-3 x 160 cases x f16f6 / f16f8 / f16x3) as a test the builder runs once per round on
-    the final tree (`pytest -m "gpu and slow"`; deselected from the plain `-m gpu` run by tests/conftest.py).  Same bounds as the
-    in-suite campaign, except that the excused-ray allowance scales with the case count (MAX_EXCUSED per 40 cases).  The summary
-    (worst |dRGB|, excused rays, worst dPSNR per seed and arithmetic) is written to gpurun_out/parity_campaign_full.json."""
+    """the whole campaign (seeds 0-3 x 160 cases x f16f6 / f16f8 / f16x3) - what used to live in tools/soak_*.sh - is
+    part of the plain `-m gpu` suite: with the float32 oracle evaluated once per case it takes 15 s on the GPU box.  Same bounds as the
+    per-seed test above, except that the excused-ray allowance scales with the case count (MAX_EXCUSED per 40 cases).  The summary
+    (worst |dRGB|, excused rays, worst dPSNR per seed and arithmetic) is written to gpurun_out/parity_campaign_full.json (copied to
+    profiles/rNN/ at the end of a round).  (tests/conftest.py keeps a `slow` marker for soaks that do not fit the suite: none today.)"""
     import json
     import os
     from egonerf_amd.build import source_hash
