@@ -65,6 +65,9 @@ struct SortGeom {
   int64_t perm[3], start[3], suboff[3], scratch, total;
   int64_t stepsum[3], steps[3];   // the walk's step list (round 6): per cell the number of 16-sample steps before it; the steps themselves
   int64_t costsum[3];             // per cell the COST of the steps before it (what the walk is dealt by)
+  // line blocks (round 6): sort s's key carries, above its two plane axes, the BLOCK of the sample's cell along the third axis (nb[s]
+  // blocks of bs[s] cells), so that a workgroup of the walk needs only one block's texels of the fused line in LDS
+  uint32_t nb[3], bs[3], kc[3];   // kc = cells of one (grid, block): (n_major + 1) (n_minor + 1)
   int64_t step_cap[3];            // entries of steps[s]
   // sort-phase view of the scratch region
   int64_t keys_in[3], k1[3], v1[3], k2[3], hist[3];
@@ -86,6 +89,7 @@ inline int64_t align256(int64_t v) { return (v + 255) & ~(int64_t)255; }
 // [150, 172, 516]: the density field's three lines fit (C = 16), of the appearance field's (C = 48) the theta and phi lines do and the r
 // line (198 KB) does not - it keeps the two-pass form (k_sorted_line of the sort whose major key is r).
 constexpr int FUSED_LDS_LIMIT = 160 * 1024 - 1024;
+constexpr int WALK_MAX_BLOCKS = 16, WALK_MAX_SEG = 6 * WALK_MAX_BLOCKS;   // line blocks per sort; (sort, grid, block) segments of a launch
 constexpr int WALK_NW_APP = 12, WALK_NW_DENS = 16;   // waves per workgroup: 144+ VGPRs at 48 channels (three waves per SIMD), ~110 at 16
 struct FusedPlan {
   int nw;
@@ -96,20 +100,24 @@ struct FusedPlan {
 __host__ __device__ constexpr int fused_line_axis(int s) { return 2 - (s == 0 ? 1 : s == 1 ? 0 : 2); }   // vm_line_ax(sort_plane(s))
 inline int walk_wave_bytes(int C) { return 12 * 64 * 4 + (C / 16) * 4 * 64 * 4; }   // sizeof(WalkLds<C / 16>)
 
-inline FusedPlan fused_plan(const int32_t res[3], int C) {
-  FusedPlan P{};
-  P.nw = C > 16 ? WALK_NW_APP : WALK_NW_DENS;
-  const int fixed = P.nw * walk_wave_bytes(C) + 64;
-  const int room = FUSED_LDS_LIMIT - fixed;
-  bool separate = false;
-  if (const char* e = getenv("EGO_SORTED_LINES")) separate = e[0] == 's';   // experiments / tests: every line in the two-pass form
-  for (int s = 0; s < 3; ++s) {
-    const int64_t bytes = (int64_t)res[fused_line_axis(s)] * C * 8;
-    P.do_line[s] = !separate && bytes <= room;
-    if (P.do_line[s] && (int)(bytes / 8) > P.entries_max) P.entries_max = (int)(bytes / 8);
-  }
-  P.lds_bytes = fixed + P.entries_max * 8;
-  return P;
+// the round-5 form (lockstep plane kernel + line kernels) stays reachable for A/B: EGO_SORTED_WALK=0; EGO_SORTED_LINES=separate keeps the
+// two-pass LINES under the walk's planes.  Both are read per call: a sort and the scatters that use it must see the same values.
+bool walk_wanted() {
+  const char* e = getenv("EGO_SORTED_WALK");
+  return !(e && e[0] == '0');
+}
+bool lines_separate() {
+  const char* e = getenv("EGO_SORTED_LINES");
+  return e && e[0] == 's';
+}
+
+// blocks of the third axis (n texels, n + 1 cells): the fewest whose window of bs + 1 texels x 48 channels x 8 bytes fits the LDS
+// beside the 48-channel walk's wave records (the 16-channel walk has more room)
+inline void line_blocks(int n, uint32_t* nb, uint32_t* bs) {
+  const int room = FUSED_LDS_LIMIT - WALK_NW_APP * walk_wave_bytes(CMAX) - 1024;
+  uint32_t k = 1;
+  while (k < WALK_MAX_BLOCKS && ((int64_t)((n + 1 + k - 1) / k) + 1) * CMAX * 8 > room) ++k;
+  *nb = k; *bs = (uint32_t)(n + 1 + k - 1) / k;
 }
 
 SortGeom make_geom(const int32_t res[3], int64_t M) {
@@ -117,9 +125,21 @@ SortGeom make_geom(const int32_t res[3], int64_t M) {
   G.M = M;
   uint32_t kmax = 0, lcmax = 0;
   for (int a = 0; a < 3; ++a) G.res[a] = res[a];
+  bool blocked = walk_wanted() && !lines_separate();
+  if (blocked) {   // all or nothing: a line that does not fit even in WALK_MAX_BLOCKS blocks needs the two-pass kernels, which read the plain key layout
+    const int room = FUSED_LDS_LIMIT - WALK_NW_APP * walk_wave_bytes(CMAX) - 1024;
+    for (int s = 0; s < 3; ++s) {
+      uint32_t nb_, bs_;
+      line_blocks(res[fused_line_axis(s)], &nb_, &bs_);
+      if ((int64_t)(bs_ + 1) * CMAX * 8 > room) blocked = false;
+    }
+  }
   for (int s = 0; s < 3; ++s) {
     const uint32_t nmaj = (uint32_t)res[sort_major(s)] + 1, nmin = (uint32_t)res[sort_minor(s)] + 1;
-    G.K[s] = 2u * nmaj * nmin;
+    G.nb[s] = 1; G.bs[s] = (uint32_t)res[fused_line_axis(s)] + 1;
+    if (blocked) line_blocks(res[fused_line_axis(s)], &G.nb[s], &G.bs[s]);
+    G.kc[s] = nmaj * nmin;
+    G.K[s] = 2u * G.nb[s] * nmaj * nmin;
     G.LC[s] = 2u * nmaj;
     kmax = G.K[s] > kmax ? G.K[s] : kmax;
     lcmax = G.LC[s] > lcmax ? G.LC[s] : lcmax;
@@ -159,22 +179,35 @@ SortGeom make_geom(const int32_t res[3], int64_t M) {
   }
   for (int s = 0; s < 3; ++s) { G.linepart[s] = b; b = align256(b + 4 * (int64_t)G.nsub_max * 2 * CMAX); }
   // fused form (shares the line-partial region's place in time, not its bytes: both forms are sized so that either can run)
-  G.fx = b; b = align256(b + 256 + 4 * 7 * 128);   // FxScale + k_fx_absmax's per-workgroup maxima
+  G.fx = b; b = align256(b + 256 + 4 * 7 * 128 + 4 * (WALK_MAX_SEG + 1));   // FxScale + k_fx_absmax's per-workgroup maxima + the walk's deal
   {
-    // the largest line table either field can keep in LDS bounds the per-workgroup stride (independent of EGO_SORTED_LINES)
+    // a workgroup's line table: one block's window of the third axis (bs + 1 texels) x the widest field's channels
     int64_t emax = 0;
-    for (int C : {16, CMAX}) {
-      const int room = FUSED_LDS_LIMIT - (C > 16 ? WALK_NW_APP : WALK_NW_DENS) * walk_wave_bytes(C) - 64;
-      for (int a3 = 0; a3 < 3; ++a3) {
-        const int64_t e = (int64_t)res[a3] * C;
-        if (e * 8 <= room && e > emax) emax = e;
-      }
+    for (int s = 0; s < 3; ++s) {
+      const int64_t e = (int64_t)(G.bs[s] + 1) * CMAX;
+      const int room = FUSED_LDS_LIMIT - WALK_NW_APP * walk_wave_bytes(CMAX) - 1024;
+      if (e * 8 <= room && e > emax) emax = e;
     }
     G.fpart_stride = emax;
     G.fpart = b; b = align256(b + 8 * G.fpart_stride * FUSED_MAX_WG);
   }
   G.total = a > b ? a : b;
   return G;
+}
+
+// which lines the walk of a C-channel field takes along: a sort's line rides along when one block's window of it fits the LDS
+inline FusedPlan fused_plan(const SortGeom& G, int C) {
+  FusedPlan P{};
+  P.nw = C > 16 ? WALK_NW_APP : WALK_NW_DENS;
+  const int fixed = P.nw * walk_wave_bytes(C) + 1024;   // + the deal table
+  const int room = FUSED_LDS_LIMIT - fixed;
+  for (int s = 0; s < 3; ++s) {
+    const int64_t bytes = (int64_t)(G.bs[s] + 1) * C * 8;
+    P.do_line[s] = !lines_separate() && bytes <= room;
+    if (P.do_line[s] && (int)(bytes / 8) > P.entries_max) P.entries_max = (int)(bytes / 8);
+  }
+  P.lds_bytes = fixed + P.entries_max * 8;
+  return P;
 }
 
 // the unclamped west tap index + 1 (0 .. n) with lin_setup's arithmetic, or -1 when both taps are out of range
@@ -185,16 +218,22 @@ __device__ __forceinline__ int cell_of(float xhat, int n) {
   return (i0 < -1 || i0 > n - 1) ? -1 : i0 + 1;
 }
 
-__global__ void k_sort_keys(const float* __restrict__ coords, int64_t M, int nr, int nth, int nph, uint32_t K0, uint32_t K1, uint32_t K2,
+struct KeyArgs {
+  uint32_t K[3], nb[3], bs[3];
+};
+// key of sort s = ((grid * nb + block of the third axis' cell) * (n_major + 1) + major cell) * (n_minor + 1) + minor cell; a sample
+// without a gradient through the third axis (both taps out of range: its line weights are 0) goes to block 0
+__global__ void k_sort_keys(const float* __restrict__ coords, int64_t M, int nr, int nth, int nph, KeyArgs A,
                             uint32_t* __restrict__ k0, uint32_t* __restrict__ k1, uint32_t* __restrict__ k2) {
   const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (m >= M) return;
   const f32x4 cc = ((const f32x4*)coords)[m];
   const uint32_t g = cc.w != 0.f ? 1u : 0u;
   const int cr = cell_of(cc.x, nr), cth = cell_of(cc.y, nth), cph = cell_of(cc.z, nph);
-  k0[m] = (cph < 0 || cr < 0) ? K0 : (g * (uint32_t)(nph + 1) + (uint32_t)cph) * (uint32_t)(nr + 1) + (uint32_t)cr;
-  k1[m] = (cr < 0 || cth < 0) ? K1 : (g * (uint32_t)(nr + 1) + (uint32_t)cr) * (uint32_t)(nth + 1) + (uint32_t)cth;
-  k2[m] = (cth < 0 || cph < 0) ? K2 : (g * (uint32_t)(nth + 1) + (uint32_t)cth) * (uint32_t)(nph + 1) + (uint32_t)cph;
+  const uint32_t b0 = cth < 0 ? 0u : (uint32_t)cth / A.bs[0], b1 = cph < 0 ? 0u : (uint32_t)cph / A.bs[1], b2 = cr < 0 ? 0u : (uint32_t)cr / A.bs[2];
+  k0[m] = (cph < 0 || cr < 0) ? A.K[0] : ((g * A.nb[0] + b0) * (uint32_t)(nph + 1) + (uint32_t)cph) * (uint32_t)(nr + 1) + (uint32_t)cr;
+  k1[m] = (cr < 0 || cth < 0) ? A.K[1] : ((g * A.nb[1] + b1) * (uint32_t)(nr + 1) + (uint32_t)cr) * (uint32_t)(nth + 1) + (uint32_t)cth;
+  k2[m] = (cth < 0 || cph < 0) ? A.K[2] : ((g * A.nb[2] + b2) * (uint32_t)(nth + 1) + (uint32_t)cth) * (uint32_t)(nph + 1) + (uint32_t)cph;
 }
 
 // ---- stable LSD radix sort of (key, sample index), 9 bits per pass, the three sorts side by side (blockIdx.y) -----------------------
@@ -483,6 +522,7 @@ struct SortedArgs {
   float* linepart[3];
   uint32_t K[3], LC[3];
   int dense_cells;
+  uint32_t nb[3], bs[3], kc[3];   // line blocks of the sort keys (SortGeom)
   int line_mask;   // bit s: k_sorted_line / k_sorted_line_final take the line of sort s (the walk takes the others)
 };
 
@@ -638,14 +678,21 @@ __device__ __forceinline__ void sorted_plane_final(const SortedArgs& A) {
   const int64_t tex = idx / Q;
   const int tx = (int)(tex % W), ty = (int)((tex / W) % H), g = (int)(tex / ((int64_t)W * H));
   const int nmin1 = A.F.res[sort_minor(S_)] + 1, nmaj1 = A.F.res[sort_major(S_)] + 1;
+  // a texel's cell exists once per line block (nb = 1 in the round-5 key layout): blocks are added in order, then the four corners
   f32x4 sum[4];
+  const uint32_t nbk = A.nb[S_];
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
     const int cy = ty + (t < 2 ? 1 : 0), cx = tx + ((t & 1) ? 0 : 1);
     const int cmaj = sort_major(S_) == AX ? cx : cy, cmin = sort_major(S_) == AX ? cy : cx;
-    const uint32_t k = ((uint32_t)g * (uint32_t)nmaj1 + (uint32_t)cmaj) * (uint32_t)nmin1 + (uint32_t)cmin;
     sum[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (A.start[S_][k + 1] != A.start[S_][k]) sum[t] = *(const f32x4*)(A.cellbuf[S_] + (cell_slot(A, S_, k) * 4 + t) * C + 4 * c4);
+    for (uint32_t bk = 0; bk < nbk; ++bk) {
+      const uint32_t k = (((uint32_t)g * nbk + bk) * (uint32_t)nmaj1 + (uint32_t)cmaj) * (uint32_t)nmin1 + (uint32_t)cmin;
+      if (A.start[S_][k + 1] != A.start[S_][k]) {
+        const f32x4 v = *(const f32x4*)(A.cellbuf[S_] + (cell_slot(A, S_, k) * 4 + t) * C + 4 * c4);
+        sum[t] = bk ? sum[t] + v : v;
+      }
+    }
   }
   const f32x4 r = (sum[0] + sum[1]) + (sum[2] + sum[3]);
   *(f32x4*)((g ? A.G.plane[1][I] : A.G.plane[0][I]) + ((int64_t)ty * W + tx) * C + 4 * c4) = r;
@@ -977,45 +1024,61 @@ struct FusedArgs {
   const FxScale* fx;
   unsigned long long* part;   // [workgroup][part_stride]: the workgroups' integer line tables
   uint32_t part_stride;
+  int32_t* deal;              // [WALK_MAX_SEG + 1] the launch's deal of workgroups to segments (written by workgroup 0, read by k_fused_line_final)
   int32_t nwg;                // workgroups of the launch
   int8_t do_line[3];          // sort s also takes the gradient of line sort_plane(s)
   int32_t dbg;                // experiments (EGO_FUSED_DBG): 1 = no LDS atomics, 2 = no line part at all (timing only: wrong line gradients)
 };
 
-// Workgroups are dealt to the six (sort, grid) pairs in proportion to the COST of their steps (cell_cost; x 6 / 5 where the line rides
-// along: measured); every pair that has steps gets at least one.  j0 / j1: the pair's range of the sort's cost prefix.  Evaluated identically by every workgroup of the walk and by k_fused_line_final.
-struct WalkDeal { int32_t off[7]; uint32_t j0[6], j1[6]; };
-__device__ __forceinline__ WalkDeal walk_deal(const FusedArgs& F) {
-  WalkDeal D;
-  uint64_t w[6], W = 0;
-  int nz = 0;
-#pragma unroll
-  for (int s = 0; s < 3; ++s) {
-    const uint32_t K = F.A.K[s], mid = F.A.costsum[s][K / 2], tot = F.A.costsum[s][K];
-    D.j0[2 * s] = 0; D.j1[2 * s] = mid; D.j0[2 * s + 1] = mid; D.j1[2 * s + 1] = tot;
-#pragma unroll
-    for (int g = 0; g < 2; ++g) {
-      w[2 * s + g] = (uint64_t)(D.j1[2 * s + g] - D.j0[2 * s + g]) * (F.do_line[s] ? 6u : 5u);
-      W += w[2 * s + g];
-      nz += w[2 * s + g] != 0;
+// SEGMENT = (sort, grid, line block): a contiguous range of kc[s] cells of the sort's key order.  Workgroups are dealt to the segments in
+// proportion to the COST of their steps (cell_cost; x 6 / 5 where the line rides along: measured); every segment that has steps gets
+// at least one.  Wave 0 of every workgroup computes the same deal into LDS; workgroup 0 also leaves it in memory for k_fused_line_final.
+struct WalkDealLds {
+  int32_t off[WALK_MAX_SEG + 1];   // segment i owns workgroups [off[i], off[i + 1])
+  uint32_t w[WALK_MAX_SEG];
+};
+__device__ __forceinline__ int seg_base(const SortedArgs& A, int s) { return s == 0 ? 0 : s == 1 ? 2 * (int)A.nb[0] : 2 * (int)(A.nb[0] + A.nb[1]); }
+
+__device__ __forceinline__ void walk_deal(const FusedArgs& F, WalkDealLds* D) {
+  const SortedArgs& A = F.A;
+  const int nseg = 2 * (int)(A.nb[0] + A.nb[1] + A.nb[2]);
+  if (threadIdx.x < 64) {
+    for (int i = threadIdx.x; i < nseg; i += 64) {
+      const int s = i >= seg_base(A, 2) ? 2 : i >= seg_base(A, 1) ? 1 : 0;
+      const uint32_t gb = (uint32_t)(i - seg_base(A, s));                 // g * nb + b
+      const uint32_t kb = gb * A.kc[s];
+      const uint32_t c = A.costsum[s][kb + A.kc[s]] - A.costsum[s][kb];
+      D->w[i] = c;
     }
   }
-  int off = 0;
-  uint64_t acc = 0;
-#pragma unroll
-  for (int p = 0; p < 6; ++p) {
-    D.off[p] = off;
-    if (w[p]) {
-      acc += w[p];
-      --nz;
-      int end = (int)(((uint64_t)F.nwg * acc + W / 2) / W);
-      end = max(end, off + 1);
-      end = min(end, F.nwg - nz);
-      off = end;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint64_t W = 0;
+    int nz = 0;
+    for (int i = 0; i < nseg; ++i) {
+      const int s = i >= seg_base(A, 2) ? 2 : i >= seg_base(A, 1) ? 1 : 0;
+      W += (uint64_t)D->w[i] * (F.do_line[s] ? 6u : 5u);
+      nz += D->w[i] != 0;
     }
+    int off = 0;
+    uint64_t acc = 0;
+    for (int i = 0; i < nseg; ++i) {
+      D->off[i] = off;
+      if (D->w[i]) {
+        const int s = i >= seg_base(A, 2) ? 2 : i >= seg_base(A, 1) ? 1 : 0;
+        acc += (uint64_t)D->w[i] * (F.do_line[s] ? 6u : 5u);
+        --nz;
+        int end = (int)(((uint64_t)F.nwg * acc + W / 2) / W);
+        end = max(end, off + 1);
+        end = min(end, F.nwg - nz);
+        off = end;
+      }
+    }
+    D->off[nseg] = off;
+    if (blockIdx.x == 0)
+      for (int i = 0; i <= nseg; ++i) F.deal[i] = D->off[i];
   }
-  D.off[6] = off;
-  return D;
+  __syncthreads();
 }
 
 // sum over the 16 lanes of a row on the DPP path (every lane gets the total): quad_perm xor 1, xor 2, row_half_mirror, row_mirror
@@ -1028,7 +1091,7 @@ __device__ __forceinline__ float row_sum16(float v) {
 }
 
 template <int C, bool DENS, int S_, int NW, int U>
-__device__ __forceinline__ void sorted_walk(const FusedArgs& F, const WalkDeal& D, const int g, unsigned long long* __restrict__ tab,
+__device__ __forceinline__ void sorted_walk(const FusedArgs& F, const int gb, const int wg0, const int wg1, unsigned long long* __restrict__ tab,
                                             WalkLds<C / 16>* wl, const bool do_line) {
 #pragma clang fp contract(fast)
   constexpr int NL = C / 16, I = sort_plane(S_);
@@ -1038,12 +1101,14 @@ __device__ __forceinline__ void sorted_walk(const FusedArgs& F, const WalkDeal& 
   WalkLds<NL>& W = wl[threadIdx.x >> 6];
   const int lane = threadIdx.x & 63, c16 = lane & 15, q = lane >> 4;
   const int Wd = A.F.res[AX], H = A.F.res[AY], NLn = A.F.res[AL];
-  const int entries = do_line ? NLn * C : 0;
+  // the segment: grid g, line block blk -> kc cells from kbase; the block's window of the line: texels [lbase, lbase + lsize)
+  const int g = gb / (int)A.nb[S_], blk = gb % (int)A.nb[S_];
+  const int lbase = max(blk * (int)A.bs[S_] - 1, 0), lsize = min((blk + 1) * (int)A.bs[S_] - 1, NLn - 1) - lbase + 1;
+  const int entries = do_line ? lsize * C : 0;
   for (int i = threadIdx.x; i < entries; i += NW * 64) tab[i] = 0ull;
-  const uint32_t K = A.K[S_], Kh = K / 2, kbase = (uint32_t)g * Kh;
-  const uint32_t T0 = g ? D.j0[2 * S_ + 1] : D.j0[2 * S_], T1 = g ? D.j1[2 * S_ + 1] : D.j1[2 * S_], Tall = A.stepsum[S_][K];
-  // this group's steps: an equal share of the pair's COST, cut at the cell boundaries at or behind the nominal cuts
-  const int wg0 = g ? D.off[2 * S_ + 1] : D.off[2 * S_], wg1 = g ? D.off[2 * S_ + 2] : D.off[2 * S_ + 1];   // (compile-time indices: the deal stays in registers)
+  const uint32_t K = A.K[S_], Kh = A.kc[S_], kbase = (uint32_t)gb * Kh;
+  const uint32_t T0 = A.costsum[S_][kbase], T1 = A.costsum[S_][kbase + Kh], Tall = A.stepsum[S_][K];
+  // this group's steps: an equal share of the segment's COST, cut at the cell boundaries at or behind the nominal cuts
   const uint32_t nb = (uint32_t)(wg1 - wg0), bl = blockIdx.x - (uint32_t)wg0;
   const uint32_t ng = nb * NW * 4u, gi = (bl * NW + (uint32_t)(threadIdx.x >> 6)) * 4u + (uint32_t)q;
   uint32_t js, je;
@@ -1207,8 +1272,8 @@ __device__ __forceinline__ void sorted_walk(const FusedArgs& F, const WalkDeal& 
           }
           if (do_line) {
             const double lw0 = (double)lw[u][0], lw1 = (double)lw[u][1];
-            unsigned long long* t0p = tab + iL0[u] * C + c16;
-            unsigned long long* t1p = tab + iL1[u] * C + c16;
+            unsigned long long* t0p = tab + min(max(iL0[u] - lbase, 0), lsize - 1) * C + c16;   // (a tap outside the window has weight 0)
+            unsigned long long* t1p = tab + min(max(iL1[u] - lbase, 0), lsize - 1) * C + c16;
 #pragma unroll
             for (int i = 0; i < NL; ++i) {
               const double gl = (double)__fmul_rn(dd[i], pv[i]);
@@ -1261,21 +1326,27 @@ __global__ __launch_bounds__(NW * 64) void k_sorted_walk(FusedArgs F) {
   extern __shared__ __attribute__((aligned(16))) unsigned char fused_lds[];
   typedef WalkLds<C / 16> WL;
   WL* wl = (WL*)fused_lds;
-  unsigned long long* tab = (unsigned long long*)(fused_lds + NW * sizeof(WL));
-  const WalkDeal D = walk_deal(F);
-  if ((int)blockIdx.x >= D.off[6]) return;
-  int p = 0;
-#pragma unroll
-  for (int i = 1; i < 6; ++i) p += (int)blockIdx.x >= D.off[i] ? 1 : 0;
-  const int s = p >> 1, g = p & 1;
-  if (F.dbg >= 16 && (F.dbg >> 4) - 1 != p) return;   // experiments: one (sort, grid) pair alone (timing only)
+  WalkDealLds* D = (WalkDealLds*)(fused_lds + NW * sizeof(WL));
+  unsigned long long* tab2 = (unsigned long long*)(fused_lds + NW * sizeof(WL) + 1024);
+  static_assert(sizeof(WalkDealLds) <= 1024, "deal table");
+  walk_deal(F, D);
+  const SortedArgs& A = F.A;
+  const int nseg = 2 * (int)(A.nb[0] + A.nb[1] + A.nb[2]);
+  if ((int)blockIdx.x >= D->off[nseg]) return;
+  int seg = 0;
+  for (int i = 1; i < nseg; ++i) seg += (int)blockIdx.x >= D->off[i] ? 1 : 0;   // (empty segments own no workgroup: off[i] == off[i + 1])
+  const int wg0 = D->off[seg], wg1 = D->off[seg + 1];
+  const int s = seg >= seg_base(A, 2) ? 2 : seg >= seg_base(A, 1) ? 1 : 0;
+  const int gb = seg - seg_base(A, s);
+  if (F.dbg >= 16 && (F.dbg >> 4) - 1 != seg) return;   // experiments: one segment alone (timing only)
   const bool do_line = F.do_line[s] != 0;
-  if (s == 0) sorted_walk<C, DENS, 0, NW, U>(F, D, g, tab, wl, do_line);
-  else if (s == 1) sorted_walk<C, DENS, 1, NW, U>(F, D, g, tab, wl, do_line);
-  else sorted_walk<C, DENS, 2, NW, U>(F, D, g, tab, wl, do_line);
+  if (s == 0) sorted_walk<C, DENS, 0, NW, U>(F, gb, wg0, wg1, tab2, wl, do_line);
+  else if (s == 1) sorted_walk<C, DENS, 1, NW, U>(F, gb, wg0, wg1, tab2, wl, do_line);
+  else sorted_walk<C, DENS, 2, NW, U>(F, gb, wg0, wg1, tab2, wl, do_line);
 }
 
-// line texel (g, t, ch) of line I = sort_plane(s): the integer sums of the workgroups that served (s, g), converted once
+// line texel (g, t, ch) of line I = sort_plane(s): the integer sums of the workgroups that served the (one or two) blocks whose window
+// holds the texel, converted once
 template <int C>
 __global__ void k_fused_line_final(FusedArgs F) {
   const SortedArgs& A = F.A;
@@ -1285,15 +1356,16 @@ __global__ void k_fused_line_final(FusedArgs F) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= 2 * n * C) return;
   const int ch = idx % C, t = (idx / C) % n, g = idx / (C * n);
-  const int entry = t * C + ch;
-  const WalkDeal D = walk_deal(F);
-  int b0 = 0, b1 = 0;
-#pragma unroll
-  for (int i = 0; i < 6; ++i)
-    if (i == 2 * s + g) { b0 = D.off[i]; b1 = D.off[i + 1]; }
+  const int nbk = (int)A.nb[s], bsz = (int)A.bs[s];
   long long sum = 0;
-  const unsigned long long* p = F.part + entry;
-  for (int b = b0; b < b1; ++b) sum += (long long)p[(int64_t)b * F.part_stride];
+  for (int blk = 0; blk < nbk; ++blk) {
+    const int lbase = max(blk * bsz - 1, 0), lsize = min((blk + 1) * bsz - 1, n - 1) - lbase + 1;
+    if (t < lbase || t >= lbase + lsize) continue;
+    const int seg = seg_base(A, s) + g * nbk + blk;
+    const int b0 = F.deal[seg], b1 = F.deal[seg + 1];
+    const unsigned long long* p = F.part + (t - lbase) * C + ch;
+    for (int b = b0; b < b1; ++b) sum += (long long)p[(int64_t)b * F.part_stride];
+  }
   const float v = F.fx->poison ? __uint_as_float(0x7fc00000u) : (float)((double)sum * F.fx->lsb[I]);
   (g ? A.G.line[1][I] : A.G.line[0][I])[t * C + ch] = v;
 }
@@ -1321,6 +1393,7 @@ int fill_args(const ego_vm_field& f, const ego_vm_grad* grad, const float* coord
     a->K[s] = G.K[s]; a->LC[s] = G.LC[s];
   }
   a->dense_cells = G.dense_cells ? 1 : 0;
+  for (int s = 0; s < 3; ++s) { a->nb[s] = G.nb[s]; a->bs[s] = G.bs[s]; a->kc[s] = G.kc[s]; }
   a->line_mask = 7;
   return EGO_OK;
 }
@@ -1359,12 +1432,6 @@ int device_cus() {
   return cus;
 }
 
-// the round-5 form (lockstep plane kernel + line kernels) stays reachable for A/B: EGO_SORTED_WALK=0
-bool walk_wanted() {
-  const char* e = getenv("EGO_SORTED_WALK");
-  return !(e && e[0] == '0');
-}
-
 template <int C, bool DENS, int NW, int U>
 int launch_walk_nw(const FusedArgs& F, int wg_total, int lds_bytes, hipStream_t st) {
   static std::atomic<int> attr_set{0};
@@ -1380,7 +1447,7 @@ int launch_walk_nw(const FusedArgs& F, int wg_total, int lds_bytes, hipStream_t 
 template <int C, bool DENS>
 int launch_walk(SortedArgs a, const SortGeom& G, char* base, int64_t M, const float* dmax_ext, hipStream_t st) {
   static_assert(sizeof(WalkLds<C / 16>) == 12 * 64 * 4 + (C / 16) * 4 * 64 * 4, "walk_wave_bytes() mirrors WalkLds");
-  const FusedPlan P = fused_plan(G.res, C);
+  const FusedPlan P = fused_plan(G, C);
   FxScale* fx = (FxScale*)(base + G.fx);
   if (const hipError_t e = hipMemsetAsync(fx, 0, 256, st)) return ego_fail((int)e, "scatter_sorted: hipMemsetAsync failed: %s", hipGetErrorString(e));
   const bool any_line = P.do_line[0] || P.do_line[1] || P.do_line[2];
@@ -1405,11 +1472,13 @@ int launch_walk(SortedArgs a, const SortGeom& G, char* base, int64_t M, const fl
   F.fx = fx;
   F.part = (unsigned long long*)(base + G.fpart);
   F.part_stride = (uint32_t)G.fpart_stride;
+  F.deal = (int32_t*)(base + G.fx + 256 + 4 * 7 * 128);
   if (const char* e = getenv("EGO_FUSED_DBG")) F.dbg = atoi(e);
   // one workgroup per CU; the kernel deals them to the (sort, grid) pairs in proportion to their steps (walk_deal)
   int wg_total = device_cus();
   if (wg_total > FUSED_MAX_WG) wg_total = FUSED_MAX_WG;
-  if (wg_total < 6) wg_total = 6;
+  const int nseg = 2 * (int)(G.nb[0] + G.nb[1] + G.nb[2]);
+  if (wg_total < nseg) wg_total = nseg;   // (<= WALK_MAX_SEG = 96 <= FUSED_MAX_WG)
   F.nwg = wg_total;
   const int off = wg_total;
   for (int s = 0; s < 3; ++s) F.do_line[s] = P.do_line[s] ? 1 : 0;
@@ -1507,7 +1576,9 @@ int ego_scatter_sort(const ego_scene* sc, const float* coords, int64_t N, int32_
   hipStream_t st = (hipStream_t)stream;
   char* base = (char*)workspace;
   uint32_t* kin[3] = {(uint32_t*)(base + G.keys_in[0]), (uint32_t*)(base + G.keys_in[1]), (uint32_t*)(base + G.keys_in[2])};
-  k_sort_keys<<<(unsigned)((M + 255) / 256), 256, 0, st>>>(coords, M, G.res[0], G.res[1], G.res[2], G.K[0], G.K[1], G.K[2], kin[0], kin[1], kin[2]);
+  KeyArgs ka{};
+  for (int s = 0; s < 3; ++s) { ka.K[s] = G.K[s]; ka.nb[s] = G.nb[s]; ka.bs[s] = G.bs[s]; }
+  k_sort_keys<<<(unsigned)((M + 255) / 256), 256, 0, st>>>(coords, M, G.res[0], G.res[1], G.res[2], ka, kin[0], kin[1], kin[2]);
   if (int e = ego_launch_status("k_sort_keys")) return e;
   // LSD passes ping-pong between (k1, v1) and (k2, perm); the last pass lands in (k2, perm)
   for (int p = 0; p < G.passes; ++p) {

@@ -85,8 +85,8 @@ def test_sorted_scatter_equals_the_atomic_one_and_itself(n_voxel, N, S, spread):
             scale = max(float(a.abs().max()), 1e-20)
             assert float((a - s).abs().max()) <= 3e-5 * scale, (field, k, float((a - s).abs().max()) / scale)   # summation order only (thousands of terms per texel at the large size)
             assert float((sep - s).abs().max()) <= 3e-5 * scale, (field, k)
-            if k % 6 < 3:
-                assert torch.equal(s, sep), (field, k)    # planes: both forms add a cell's samples in the same order
+            # (planes: the one-pass form adds a cell's samples per LINE BLOCK and then the blocks - another order than the two-pass form's
+            # where a line needs more than one block; covered by the 3e-5 bound above)
             assert M < 64 or float(s.abs().max()) > 0
 
 

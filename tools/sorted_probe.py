@@ -26,6 +26,7 @@ sd, sa = _grad_struct(gd), _grad_struct(ga)
 nb = lib.ego_scatter_sorted_workspace_bytes(sc, N, S)
 ws = torch.empty(nb, device=dev, dtype=torch.uint8)
 def run(which):
+    global ws, nb
     if which == "sort": _lib.check(lib.ego_scatter_sort(sc, crd.data_ptr(), N, S, ws.data_ptr(), nb, st), "sort")
     if which == "dens": _lib.check(lib.ego_scatter_density_sorted(sc, C.byref(sd), crd.data_ptr(), dfeat.data_ptr(), N, S, ws.data_ptr(), nb, st), "d")
     if which == "app": _lib.check(lib.ego_scatter_app_sorted(sc, C.byref(sa), crd.data_ptr(), dv.data_ptr(), None, N, S, ws.data_ptr(), nb, st), "a")
@@ -91,6 +92,9 @@ for label, env in (("r05 form", dict(EGO_SORTED_WALK="0")), ("walk", {}), ("walk
                    ("walk again", {})):
     for k in ENV_KEYS: os.environ.pop(k, None)
     os.environ.update(env)
+    nb = lib.ego_scatter_sorted_workspace_bytes(sc, N, S)          # the key layout (line blocks) follows the environment: size and sort again
+    ws = torch.empty(nb, device=dev, dtype=torch.uint8)
+    run("sort")
     for which in ("dens", "app"):
         timed(which, f"{which} {label}")
     torch.cuda.synchronize()
