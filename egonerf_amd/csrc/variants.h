@@ -24,3 +24,9 @@
 #ifndef EGO_HOIST_PLAIN
 #define EGO_HOIST_PLAIN 0
 #endif
+
+// EGO_WALK_PROF (ego_scatter_sorted.hip, default undefined): an INSTRUMENT, not a variant of the arithmetic - the walk kernel of the
+// sorted scatter reads s_memtime around its phases (step head + set-up, load issue, wait, compute, tail) and sums the cycles of all
+// waves into device counters, per wave the busy time, steps and iterations (ego_debug_walk_prof / ego_debug_walk_waves, read by
+// tools/sorted_probe.py with PROBE_PROF=1 on a tools/build_variant.sh build).  It is how round 6 found that the first walk's slowest
+// wave took 3.5 x the mean (chunks of cells dealt by count) and that the 48-channel walk is bound by VALU issue, not by its gathers.
