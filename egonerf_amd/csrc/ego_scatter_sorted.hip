@@ -1197,9 +1197,13 @@ __device__ __forceinline__ void sorted_walk(const FusedArgs& F, const int gb, co
         R.f[0][lane] = m0;
         R.f[1][lane] = __float_as_uint(__fmul_rn(Y.w0, X.w0)); R.f[2][lane] = __float_as_uint(__fmul_rn(Y.w0, X.w1));
         R.f[3][lane] = __float_as_uint(__fmul_rn(Y.w1, X.w0)); R.f[4][lane] = __float_as_uint(__fmul_rn(Y.w1, X.w1));
-        R.f[5][lane] = (uint32_t)Ln.i0; R.f[6][lane] = (uint32_t)Ln.i1;
+        // per tap: the byte offset of its texel row in the line table, and of its row in the block's LDS window (a tap outside the
+        // window has weight 0) - once per sample here instead of once per channel lane in stage 2
+        R.f[5][lane] = (uint32_t)(Ln.i0 * C) * 4u; R.f[6][lane] = (uint32_t)(Ln.i1 * C) * 4u;
         R.f[7][lane] = __float_as_uint(Ln.w0); R.f[8][lane] = __float_as_uint(Ln.w1);
         if (DENS) R.f[9][lane] = __float_as_uint(d0);
+        R.f[10][lane] = (uint32_t)(min(max(Ln.i0 - lbase, 0), lsize - 1) * C) * 8u;
+        R.f[11][lane] = (uint32_t)(min(max(Ln.i1 - lbase, 0), lsize - 1) * C) * 8u;
       }
       wave_sync();
       int cnt_max = max(cnt, __shfl_xor(cnt, 16, 64));
@@ -1210,7 +1214,7 @@ __device__ __forceinline__ void sorted_walk(const FusedArgs& F, const int gb, co
         WPROF_T(ti0); WPROF_ADD(6, 1);
         const WaveRec& R = W.rec;
         float w4[U][4], lw[U][2], di[U][NL], l0[U][NL], l1[U][NL];
-        int iL0[U], iL1[U];
+        uint32_t tL0[U], tL1[U];
         bool ok[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -1220,9 +1224,9 @@ __device__ __forceinline__ void sorted_walk(const FusedArgs& F, const int gb, co
           const uint32_t m = R.f[0][tt];
 #pragma unroll
           for (int c = 0; c < 4; ++c) w4[u][c] = __uint_as_float(R.f[1 + c][tt]);
-          iL0[u] = (int)R.f[5][tt]; iL1[u] = (int)R.f[6][tt];
           lw[u][0] = __uint_as_float(R.f[7][tt]); lw[u][1] = __uint_as_float(R.f[8][tt]);
-          const uint32_t oL0 = (uint32_t)(iL0[u] * C + c16) * 4u, oL1 = (uint32_t)(iL1[u] * C + c16) * 4u;
+          tL0[u] = R.f[10][tt]; tL1[u] = R.f[11][tt];
+          const uint32_t oL0 = R.f[5][tt] + (uint32_t)c16 * 4u, oL1 = R.f[6][tt] + (uint32_t)c16 * 4u;
 #pragma unroll
           for (int i = 0; i < NL; ++i) { l0[u][i] = at(L, oL0 + 64u * i); l1[u][i] = at(L, oL1 + 64u * i); }
           if (DENS) {
@@ -1272,8 +1276,8 @@ __device__ __forceinline__ void sorted_walk(const FusedArgs& F, const int gb, co
           }
           if (do_line) {
             const double lw0 = (double)lw[u][0], lw1 = (double)lw[u][1];
-            unsigned long long* t0p = tab + min(max(iL0[u] - lbase, 0), lsize - 1) * C + c16;   // (a tap outside the window has weight 0)
-            unsigned long long* t1p = tab + min(max(iL1[u] - lbase, 0), lsize - 1) * C + c16;
+            unsigned long long* t0p = (unsigned long long*)((char*)tab + tL0[u]) + c16;
+            unsigned long long* t1p = (unsigned long long*)((char*)tab + tL1[u]) + c16;
 #pragma unroll
             for (int i = 0; i < NL; ++i) {
               const double gl = (double)__fmul_rn(dd[i], pv[i]);
