@@ -79,7 +79,8 @@ for key, prefix, unit_like, what in (("train_step", "pmctrain", "k_adam", "one t
 # render variants (bench.py --fresh-rays / --n-voxel): HBM bytes of the two grid-sample kernels per step
 for key, prefix, what in (("big_grid", "pmcbig", "one step of bench.py --n-voxel 216e6 --fresh-rays 64 (grid [300,346,1036], ~400 MB of tables): k_march_density + k_shade_h"),
                           ("fresh_rays", "pmcfresh", "one step of bench.py --fresh-rays 64 (headline grid, a different ray batch every step): k_march_density + k_shade_h")):
-    sec = whole_step(prefix, "k_composite", what)
+    # one shade launch per step (k_composite is folded into it since round 5 wherever whole rays divide evenly: it no longer marks a step)
+    sec = whole_step(prefix, "k_shade_h", what)
     if sec is not None:
         pk = {k: v for k, v in sec["per_kernel"].items() if "k_march_density" in k or "k_shade" in k}
         sec["per_kernel"] = pk
