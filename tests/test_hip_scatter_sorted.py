@@ -216,3 +216,34 @@ def test_training_gradients_are_bit_reproducible_and_match_the_atomic_path(golde
         scale = max(float(np.abs(ref).max()), 1e-12)
         assert float((a[k] - c[k]).abs().max()) <= 2e-5 * scale, k
         assert float(np.abs(a[k].cpu().numpy() - ref).max()) <= 2e-4 * scale, k
+
+
+def test_fixed_point_line_sums_are_at_least_as_close_to_float64_as_float_sums():
+    """The one-pass form adds a line's contributions as 64-bit fixed-point integers (unit >= 40 bits below the largest possible
+    contribution), the two-pass form as float32 partial sums.  On the headline grid (131 072 samples, ~800 per line texel) the
+    fixed-point sums must not be farther from float64 autograd than the float sums are - and a non-finite gradient input must give
+    NaN line gradients, as a float sum's would be (the fixed-point conversion of a NaN is not a number either way: the call says so)."""
+    cfg = synth.SceneConfig(n_voxel=27e6)
+    weights = synth.make_weights(cfg, seed=21)
+    model = make_model(cfg, weights, DEV)
+    N, S = 512, 256
+    M = N * S
+    g = torch.Generator().manual_seed(11)
+    coords = torch.rand(N, S, 4, generator=g) * 2 - 1
+    coords[..., 3] = (torch.rand(N, S, generator=g) > 0.5).float()
+    dfeat = torch.randn(N, S, generator=g)
+    dv_ref = torch.randn(M, 144, generator=g)
+    ref_d, ref_a = _float64_grid_sample_gradients(cfg, weights, coords, dfeat, dv_ref)
+    out = _scatter_both(model, coords.to(DEV).contiguous(), dfeat.to(DEV).contiguous(), _blocked_dv(dv_ref, M).to(DEV), N, S)
+    for fi, refs in enumerate((ref_d, ref_a)):
+        for k in (3, 4, 5, 9, 10, 11):   # the six line tables of a field (table_params order: planes 0-2, lines 3-5 per grid)
+            ref = refs[k]
+            scale = float(ref.abs().max())
+            e_fx = float((out["sorted"][fi][k].double().cpu() - ref).abs().max()) / scale
+            e_fl = float((out["sorted_separate"][fi][k].double().cpu() - ref).abs().max()) / scale
+            assert e_fx <= 1.05 * e_fl + 1e-7, (fi, k, e_fx, e_fl)   # (both ~1e-5 of max: the float32 factors of a contribution, not its sum, set it)
+    bad = dfeat.clone()
+    bad[3, 5] = float("nan")
+    out = _scatter_both(model, coords.to(DEV).contiguous(), bad.to(DEV).contiguous(), _blocked_dv(dv_ref, M).to(DEV), N, S)
+    for k in (3, 4, 5, 9, 10, 11):
+        assert bool(torch.isnan(out["sorted"][0][k]).all()), k
