@@ -11,5 +11,5 @@ p=glob.glob("/tmp/sk/**/*.db", recursive=True)[0]
 db=sqlite3.connect(p)
 for name, calls, tot, avg, pct in db.execute("select name, total_calls, total_duration, average, percentage from top_kernels limit 24"):
     name=name.replace("(anonymous namespace)::","").replace("void ","")
-    print(f"{name[:80]:80s} {calls:5d} {avg:10.2f} (avg, top_kernels unit) {tot:12.1f} {pct:5.1f}%")
+    print(f"{name[:80]:80s} {calls:5d} {avg:10.2f} us avg {tot:12.1f} {pct:5.1f}%")
 PY
