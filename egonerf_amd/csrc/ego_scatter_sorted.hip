@@ -70,7 +70,7 @@ struct SortGeom {
   uint32_t nb[3], bs[3], kc[3];   // kc = cells of one (grid, block): (n_major + 1) (n_minor + 1)
   int64_t step_cap[3];            // entries of steps[s]
   // sort-phase view of the scratch region
-  int64_t keys_in[3], k1[3], v1[3], k2[3], hist[3];
+  int64_t keys_in[3], k1[3], v1[3], k2[3], hist[3], scanpart[3];
   uint32_t nblocks;    // radix tiles (RTILE elements each)
   int passes;          // ceil(bits / 9)
   // scatter-phase view of the scratch region
@@ -168,6 +168,7 @@ SortGeom make_geom(const int32_t res[3], int64_t M) {
   for (int s = 0; s < 3; ++s) { G.v1[s] = a; a = align256(a + 4 * M); }
   for (int s = 0; s < 3; ++s) { G.k2[s] = a; a = align256(a + 4 * M); }
   for (int s = 0; s < 3; ++s) { G.hist[s] = a; a = align256(a + 4 * ((int64_t)RADIX * G.nblocks + RADIX)); }   // + the digit totals
+  for (int s = 0; s < 3; ++s) { G.scanpart[s] = a; a = align256(a + 4 * 2 * ((int64_t)G.K[s] / 4096 + 2)); }   // k_step_scan's per-workgroup totals (steps, cost)
   // scatter phase
   int64_t b = o;
   // cell buffer: only cells that hold samples are ever written or read - at most min(K, M) of them (K x 4 x 48 floats was
@@ -384,6 +385,7 @@ struct StartArgs {
   uint32_t* stepsum[3];
   uint32_t* costsum[3];
   uint4* steps[3];
+  uint32_t* scanpart[3];   // k_step_scan's per-workgroup totals
   uint32_t K[3], LC[3], nmin1[3];
   int64_t M;
 };
@@ -447,58 +449,83 @@ __device__ __forceinline__ uint32_t cell_cost(uint32_t n) {   // in fifths of an
   return full * 23u + (r ? 3u + 5u * ((r + 3u) / 4u) : 0u);
 }
 
-// blockIdx.x = 0: stepsum, 1: costsum
+// stepsum / costsum = exclusive prefix sums over the sort's cells, in three launches: per 4096-cell workgroup the local prefixes + its
+// total (PHASE 0), the totals' scan by one workgroup (1), the offsets added (2).  blockIdx.y = 0 steps, 1 cost; z = sort.  (A
+// single-workgroup loop took 0.1 ms.)
+template <int PHASE>
 __global__ __launch_bounds__(1024) void k_step_scan(StartArgs A) {
-  const uint32_t* __restrict__ start = A.start[blockIdx.y];
-  const bool cost = blockIdx.x == 1;
-  uint32_t* __restrict__ out = cost ? A.costsum[blockIdx.y] : A.stepsum[blockIdx.y];
-  const uint32_t K = A.K[blockIdx.y];
+  const int s = blockIdx.z;
+  const uint32_t* __restrict__ start = A.start[s];
+  const bool cost = blockIdx.y == 1;
+  uint32_t* __restrict__ out = cost ? A.costsum[s] : A.stepsum[s];
+  uint32_t* __restrict__ part = A.scanpart[s] + (cost ? (A.K[s] / 4096u + 2u) : 0u);
+  const uint32_t K = A.K[s], nblk = (K + 4095u) / 4096u;
   __shared__ uint32_t wsum[16];
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-  uint32_t carry = 0;
-  for (uint32_t base = 0; base < K; base += 4096) {   // four cells per thread and round
-    const uint32_t k0 = base + 4u * (uint32_t)t;
-    uint32_t n[4], own = 0;
+  if (PHASE == 1) {   // one workgroup: exclusive scan of the workgroup totals, the grand total behind them
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < nblk; base += 1024) {
+      const uint32_t i = base + (uint32_t)t;
+      const uint32_t v = i < nblk ? part[i] : 0u;
+      uint32_t inc = v;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const uint32_t k = k0 + i;
-      const uint32_t ns = k < K ? start[k + 1] - start[k] : 0u;
-      n[i] = cost ? cell_cost(ns) : (ns + 15u) / 16u;
-      own += n[i];
+      for (int d = 1; d < 64; d <<= 1) { const uint32_t u = __shfl_up(inc, d, 64); if (lane >= d) inc += u; }
+      if (lane == 63) wsum[wv] = inc;
+      __syncthreads();
+      uint32_t before = 0, all = 0;
+      for (int w = 0; w < 16; ++w) { if (w < wv) before += wsum[w]; all += wsum[w]; }
+      if (i < nblk) part[i] = carry + before + inc - v;
+      carry += all;
+      __syncthreads();
     }
-    uint32_t inc = own;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const uint32_t v = __shfl_up(inc, d, 64);
-      if (lane >= d) inc += v;
-    }
-    if (lane == 63) wsum[wv] = inc;
-    __syncthreads();
-    uint32_t before = 0, all = 0;
-    for (int w = 0; w < 16; ++w) { if (w < wv) before += wsum[w]; all += wsum[w]; }
-    uint32_t run = carry + before + inc - own;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      if (k0 + i < K) out[k0 + i] = run;
-      run += n[i];
-    }
-    carry += all;
-    __syncthreads();
+    if (t == 0) { out[K] = carry; out[K + 1] = carry; }
+    return;
   }
-  if (t == 0) { out[K] = carry; out[K + 1] = carry; }
+  if (blockIdx.x >= nblk) return;
+  const uint32_t k0 = blockIdx.x * 4096u + 4u * (uint32_t)t;
+  if (PHASE == 2) {
+    const uint32_t off = part[blockIdx.x];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (k0 + i < K) out[k0 + i] += off;
+    return;
+  }
+  uint32_t n[4], own = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const uint32_t k = k0 + i;
+    const uint32_t ns = k < K ? start[k + 1] - start[k] : 0u;
+    n[i] = cost ? cell_cost(ns) : (ns + 15u) / 16u;
+    own += n[i];
+  }
+  uint32_t inc = own;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) { const uint32_t u = __shfl_up(inc, d, 64); if (lane >= d) inc += u; }
+  if (lane == 63) wsum[wv] = inc;
+  __syncthreads();
+  uint32_t before = 0, all = 0;
+  for (int w = 0; w < 16; ++w) { if (w < wv) before += wsum[w]; all += wsum[w]; }
+  uint32_t run = before + inc - own;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (k0 + i < K) out[k0 + i] = run;
+    run += n[i];
+  }
+  if (t == 0) part[blockIdx.x] = all;
 }
 
 __global__ void k_step_fill(StartArgs A) {
   const int s = blockIdx.y;
   const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= A.K[s]) return;
-  const uint32_t a = A.start[s][k], n = A.start[s][k + 1] - a;
+  const uint32_t c = k;
+  const uint32_t a = A.start[s][c], n = A.start[s][c + 1] - a;
   if (!n) return;
   uint4* out = A.steps[s] + A.stepsum[s][k];
   const uint32_t nb = (n + 15u) / 16u;
   for (uint32_t b = 0; b < nb; ++b) {
     const uint32_t cnt = min(16u, n - 16u * b);
-    out[b] = uint4{a + 16u * b, k, cnt | (b == 0 ? 256u : 0u) | (b + 1 == nb ? 512u : 0u), 0u};
+    out[b] = uint4{a + 16u * b, c, cnt | (b == 0 ? 256u : 0u) | (b + 1 == nb ? 512u : 0u), 0u};
   }
 }
 
@@ -1621,8 +1648,16 @@ int ego_scatter_sort(const ego_scene* sc, const float* coords, int64_t N, int32_
   if (int e = ego_launch_status("k_cell_starts")) return e;
   k_line_suboff<<<dim3(1, 3), 1024, 0, st>>>(sa);
   if (int e = ego_launch_status("k_line_suboff")) return e;
-  k_step_scan<<<dim3(2, 3), 1024, 0, st>>>(sa);
-  if (int e = ego_launch_status("k_step_scan")) return e;
+  for (int s = 0; s < 3; ++s) sa.scanpart[s] = (uint32_t*)(base + G.scanpart[s]);
+  {
+    const unsigned nblk = (kmax + 4095) / 4096;
+    k_step_scan<0><<<dim3(nblk, 2, 3), 1024, 0, st>>>(sa);
+    if (int e = ego_launch_status("k_step_scan<0>")) return e;
+    k_step_scan<1><<<dim3(1, 2, 3), 1024, 0, st>>>(sa);
+    if (int e = ego_launch_status("k_step_scan<1>")) return e;
+    k_step_scan<2><<<dim3(nblk, 2, 3), 1024, 0, st>>>(sa);
+    if (int e = ego_launch_status("k_step_scan<2>")) return e;
+  }
   k_step_fill<<<dim3((kmax + 255) / 256, 3), 256, 0, st>>>(sa);
   if (int e = ego_launch_status("k_step_fill")) return e;
   return EGO_OK;
