@@ -123,7 +123,8 @@ def _float64_grid_sample_gradients(cfg, weights, coords, dfeat, dv_ref, dtype=to
     for k in keys("density") + keys("app"):
         sc.w[k] = sc.w[k].clone().requires_grad_(True)
     loss_d = (sc.density_feature(c7) * dfeat.reshape(-1).to(dtype).cpu()).sum()      # sum_i relu(sum_c P L): EgoNeRF.py:291-347
-    gd = torch.autograd.grad(loss_d, [sc.w[k] for k in keys("density")])
+    gd = torch.autograd.grad(loss_d, [sc.w[k] for k in keys("density")], allow_unused=True)
+    gd = [torch.zeros_like(sc.w[k]) if g is None else g for g, k in zip(gd, keys("density"))]
     dvr = dv_ref.to(dtype).cpu()
     loss_a = 0.0
     is_yin = c7[:, -1] == 0
@@ -247,3 +248,59 @@ def test_fixed_point_line_sums_are_at_least_as_close_to_float64_as_float_sums():
     out = _scatter_both(model, coords.to(DEV).contiguous(), bad.to(DEV).contiguous(), _blocked_dv(dv_ref, M).to(DEV), N, S)
     for k in (3, 4, 5, 9, 10, 11):
         assert bool(torch.isnan(out["sorted"][0][k]).all()), k
+
+
+def test_fixed_point_line_sums_do_not_overflow_when_every_sample_hits_one_texel():
+    """The unit of the fixed-point line sums leaves ceil(log2(N S)) bits of headroom for a texel that receives EVERY sample's largest
+    possible contribution.  65 536 identical samples (one cell, weights (1, 0) on every axis after rounding the coordinates onto a texel)
+    with dfeat = dv = the largest magnitude in the batch: the line texel's gradient is M x d x plane value, far above any single
+    contribution - and must come out exact to float32 rounding of a single contribution, in both fields (the planes' ordered float32
+    chains of 65 536 equal terms, by contrast, carry their own 5e-4: the fixed-point sums are the MORE accurate ones here)."""
+    cfg = synth.SceneConfig(n_voxel=20 ** 3)
+    weights = synth.make_weights(cfg, seed=21)
+    model = make_model(cfg, weights, DEV)
+    N, S = 256, 256
+    M = N * S
+    res = [int(v) for v in model.gridSize.tolist()]          # (N_r, N_theta, N_phi)
+    tex = [3, 4, 5]                                           # an interior texel per axis: x^ = 2 i / (n - 1) - 1 lands on it exactly enough
+    xyz = [2.0 * t / (n - 1) - 1.0 for t, n in zip(tex, res)]
+    coords = torch.tensor(xyz + [0.0]).repeat(N, S, 1).contiguous()
+    dfeat = torch.full((N, S), 3.0)
+    dv_ref = torch.full((M, 144), -2.0)
+    ref_d, ref_a = _float64_grid_sample_gradients(cfg, weights, coords, dfeat, dv_ref)
+    out = _scatter_both(model, coords.to(DEV), dfeat.to(DEV), _blocked_dv(dv_ref, M).to(DEV), N, S)
+    for fi, refs in enumerate((ref_d, ref_a)):
+        for k, (got, ref) in enumerate(zip(out["sorted"][fi], refs)):
+            scale = float(ref.abs().max())
+            if k >= 6:   # every sample lies in the yin grid: the yang tables' gradients are exactly 0 (and written)
+                assert scale == 0.0 and float(got.abs().max()) == 0.0, (fi, k)
+                continue
+            assert scale > 1e3 or fi == 0, (fi, k, scale)      # sums of 65 536 terms
+            err = float((got.double().cpu() - ref).abs().max()) / max(scale, 1e-30)
+            # planes: 65 536 equal terms added one after the other in float32 (a real cell holds <= ~350 samples) - 5e-4 is that
+            # chain's own rounding; lines: integer sums, exact up to the float32 factors of a contribution
+            assert err <= (2e-3 if k % 6 < 3 else 2e-6), (fi, k, err)
+            assert torch.equal(got, out["sorted_again"][fi][k])
+
+
+def test_fixed_point_unit_follows_the_batch_not_a_constant():
+    """Gradients 2^-60 small and 2^40 large go through the same kernels: the unit is derived from max |d| x max |plane texel| of the call,
+    so scaling d by a power of two scales every gradient by exactly that power of two (bit for bit: float32 products and sums by a power
+    of two are exact without overflow / underflow, and the fixed-point unit moves with it)."""
+    cfg = synth.SceneConfig(n_voxel=24 ** 3)
+    weights = synth.make_weights(cfg, seed=21)
+    model = make_model(cfg, weights, DEV)
+    N, S = 64, 48
+    M = N * S
+    g = torch.Generator().manual_seed(2)
+    coords = torch.rand(N, S, 4, generator=g) * 2 - 1
+    coords[..., 3] = (torch.rand(N, S, generator=g) > 0.5).float()
+    dfeat = torch.randn(N, S, generator=g)
+    dv_ref = torch.randn(M, 144, generator=g)
+    base = _scatter_both(model, coords.to(DEV), dfeat.to(DEV), _blocked_dv(dv_ref, M).to(DEV), N, S)["sorted"]
+    for e in (-60, 40):
+        f = 2.0 ** e
+        got = _scatter_both(model, coords.to(DEV), (dfeat * f).to(DEV), _blocked_dv(dv_ref * f, M).to(DEV), N, S)["sorted"]
+        for fi in range(2):
+            for k, (a, b) in enumerate(zip(got[fi], base[fi])):
+                assert torch.equal(a, b * f), (e, fi, k, float((a - b * f).abs().max()))
