@@ -117,7 +117,7 @@ PROTOTYPES = {
     "ego_scatter_sorted_workspace_bytes": (C.c_int64, [SP, I64, I32]),
     "ego_scatter_sort": (C.c_int, [SP, P, I64, I32, P, I64, P]),
     "ego_scatter_density_sorted": (C.c_int, [SP, C.POINTER(VmGrad), P, P, I64, I32, P, I64, P]),
-    "ego_scatter_app_sorted": (C.c_int, [SP, C.POINTER(VmGrad), P, P, P, I64, I32, P, I64, P]),
+    "ego_scatter_app_sorted": (C.c_int, [SP, C.POINTER(VmGrad), P, P, P, P, P, I32, I64, I32, P, I64, P]),
     "ego_envmap_backward": (C.c_int, [SP, P, I32, P, P, P, P, I64, P, P]),
     "ego_shade_backward": (C.c_int, [SP, P, P, P, P, C.POINTER(ShadeDump), P, P, P, P, P, P, I64, I32, P]),
     "ego_sh_render": (C.c_int, [P, P, I64, P, P]),

@@ -76,6 +76,7 @@ struct SortGeom {
   // scatter-phase view of the scratch region
   int64_t cellbuf[3], linepart[3];
   int64_t fx, fpart;   // fused form: the fixed-point scale block, the per-workgroup integer line tables
+  int64_t bpart;       // the walk's per-wave shares of d(basis): [FUSED_MAX_WG x WALK_NW_BAS][6][64][4] floats
   int64_t fpart_stride;   // entries (8 bytes each) per workgroup table
   bool dense_cells;    // cell buffer indexed by cell (K <= M) or by the cell's first sorted position (K > M: at most M cells hold samples)
   uint32_t cell_slots[3];
@@ -90,7 +91,7 @@ inline int64_t align256(int64_t v) { return (v + 255) & ~(int64_t)255; }
 // line (198 KB) does not - it keeps the two-pass form (k_sorted_line of the sort whose major key is r).
 constexpr int FUSED_LDS_LIMIT = 160 * 1024 - 1024;
 constexpr int WALK_MAX_BLOCKS = 16, WALK_MAX_SEG = 6 * WALK_MAX_BLOCKS;   // line blocks per sort; (sort, grid, block) segments of a launch
-constexpr int WALK_NW_APP = 12, WALK_NW_DENS = 16;   // waves per workgroup: 144+ VGPRs at 48 channels (three waves per SIMD), ~110 at 16
+constexpr int WALK_NW_APP = 12, WALK_NW_DENS = 16, WALK_NW_BAS = 8;   // waves per workgroup: 144+ VGPRs at 48 channels (three waves per SIMD), ~110 at 16
 struct FusedPlan {
   int nw;
   bool do_line[3];   // per sort
@@ -192,6 +193,7 @@ SortGeom make_geom(const int32_t res[3], int64_t M) {
     G.fpart_stride = emax;
     G.fpart = b; b = align256(b + 8 * G.fpart_stride * FUSED_MAX_WG);
   }
+  G.bpart = b; b = align256(b + (int64_t)FUSED_MAX_WG * WALK_NW_BAS * 6 * 256 * 4);
   G.total = a > b ? a : b;
   return G;
 }
@@ -1054,6 +1056,8 @@ struct FusedArgs {
   int32_t* deal;              // [WALK_MAX_SEG + 1] the launch's deal of workgroups to segments (written by workgroup 0, read by k_fused_line_final)
   int32_t nwg;                // workgroups of the launch
   int8_t do_line[3];          // sort s also takes the gradient of line sort_plane(s)
+  const float* dfe;           // BAS (48 channels): ego_shade_backward's feature-slot gradients [M][32]
+  float* bpart;               // BAS: per wave [2 slot tiles][3 channel groups][64 lanes][4]: its share of d(basis)
   int32_t dbg;                // experiments (EGO_FUSED_DBG): 1 = no LDS atomics, 2 = no line part at all (timing only: wrong line gradients)
 };
 
@@ -1117,7 +1121,26 @@ __device__ __forceinline__ float row_sum16(float v) {
   return v;
 }
 
-template <int C, bool DENS, int S_, int NW, int U>
+// v = hi + lo + O(2^-18 |v|) as bf16 (round to nearest even: unbiased), the split csrc/ego_wgrad.hip uses for its fp32 operands
+__device__ __forceinline__ uint32_t walk_bf16_rn(float v) {
+  const uint32_t u = __float_as_uint(v);
+  return (u + 0x7fffu + ((u >> 16) & 1u)) & 0xffff0000u;
+}
+typedef short walk_s4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2_w __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void walk_split4(const float x[4], walk_s4& hi, walk_s4& lo) {
+  uint32_t h[4], l[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    h[e] = walk_bf16_rn(x[e]);
+    l[e] = walk_bf16_rn(__fsub_rn(x[e], __uint_as_float(h[e])));
+  }
+  const u32x2_w ph = {(h[0] >> 16) | h[1], (h[2] >> 16) | h[3]}, pl = {(l[0] >> 16) | l[1], (l[2] >> 16) | l[3]};
+  hi = __builtin_bit_cast(walk_s4, ph);
+  lo = __builtin_bit_cast(walk_s4, pl);
+}
+
+template <int C, bool DENS, int S_, int NW, int U, bool BAS = false>
 __device__ __forceinline__ void sorted_walk(const FusedArgs& F, const int gb, const int wg0, const int wg1, unsigned long long* __restrict__ tab,
                                             WalkLds<C / 16>* wl, const bool do_line) {
 #pragma clang fp contract(fast)
@@ -1194,6 +1217,17 @@ __device__ __forceinline__ void sorted_walk(const FusedArgs& F, const int gb, co
     float acc[NL][4];
 #pragma unroll
     for (int i = 0; i < NL; ++i) acc[i][0] = acc[i][1] = acc[i][2] = acc[i][3] = 0.f;
+    // BAS: this wave's share of d(basis)[slot][channel of plane I] = sum_samples dfe[s][slot] v[s][channel], v = plane value x line
+    // value - the walk has both in registers, so the forward need not dump v (576 B per sample) for a weight-gradient pass to read.
+    // v_mfma_f32_16x16x16_bf16: K = the 16 samples of one iteration (group q's sample u is k = 4 q + u: what lane 16 q + c holds for
+    // both operands), A = dfe^T (row = slot 16 mt + c16), B = v (column = channel 16 i + c16), bf16 hi / lo split, three terms.
+    f32x4 bacc[BAS ? 2 : 1][BAS ? NL : 1];
+    if constexpr (BAS) {
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int i = 0; i < NL; ++i) bacc[mt][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     while (__ballot(j < je) != 0ull) {
       WPROF_T(ts0);
       e3 = entry(j + 3);          // step t + 3's entry, t + 2's permutation entries, t + 1's coordinates: in flight under this step
@@ -1241,6 +1275,8 @@ __device__ __forceinline__ void sorted_walk(const FusedArgs& F, const int gb, co
         WPROF_T(ti0); WPROF_ADD(6, 1);
         const WaveRec& R = W.rec;
         float w4[U][4], lw[U][2], di[U][NL], l0[U][NL], l1[U][NL];
+        float fa[BAS ? 2 : 1][4], vv[BAS ? NL : 1][4];
+        static_assert(!BAS || U == 4, "one MFMA per iteration: 4 groups x 4 samples = K 16");
         uint32_t tL0[U], tL1[U];
         bool ok[U];
 #pragma unroll
@@ -1263,6 +1299,10 @@ __device__ __forceinline__ void sorted_walk(const FusedArgs& F, const int gb, co
             const uint32_t od = ((m >> 5) * (uint32_t)(32 * 3 * C) + (uint32_t)(I * NL) * 512u + (m & 31u) * 16u + (uint32_t)c16) * 4u;
 #pragma unroll
             for (int i = 0; i < NL; ++i) di[u][i] = at(Dv, od + 2048u * i);
+            if constexpr (BAS) {
+              const uint32_t of = (m * 32u + (uint32_t)c16) * 4u;
+              fa[0][u] = at(F.dfe, of); fa[1][u] = at(F.dfe, of + 64u);
+            }
           }
         }
         WPROF_T(ti1); WPROF_ADD(1, ti1 - ti0);
@@ -1300,6 +1340,7 @@ __device__ __forceinline__ void sorted_walk(const FusedArgs& F, const int gb, co
           for (int i = 0; i < NL; ++i) {
             const float gp = dd[i] * lv[i];
             acc[i][0] += gp * w4[u][0]; acc[i][1] += gp * w4[u][1]; acc[i][2] += gp * w4[u][2]; acc[i][3] += gp * w4[u][3];
+            if constexpr (BAS) vv[i][u] = ok[u] ? __fmul_rn(pv[i], lv[i]) : 0.f;
           }
           if (do_line) {
             const double lw0 = (double)lw[u][0], lw1 = (double)lw[u][1];
@@ -1317,6 +1358,21 @@ __device__ __forceinline__ void sorted_walk(const FusedArgs& F, const int gb, co
             }
           }
         }
+        if constexpr (BAS) {
+          walk_s4 ah[2], al[2], bh[NL], bl[NL];
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt) walk_split4(fa[mt], ah[mt], al[mt]);
+#pragma unroll
+          for (int i = 0; i < NL; ++i) walk_split4(vv[i], bh[i], bl[i]);
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int i = 0; i < NL; ++i) {
+              bacc[mt][i] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah[mt], bh[i], bacc[mt][i], 0, 0, 0);
+              bacc[mt][i] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(al[mt], bh[i], bacc[mt][i], 0, 0, 0);
+              bacc[mt][i] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah[mt], bl[i], bacc[mt][i], 0, 0, 0);
+            }
+        }
       }
       WPROF_T(ts2); WPROF_ADD(3, ts2 - ts1);
       wave_sync();   // the next step overwrites the record (and, for a group that starts a cell, its texels)
@@ -1333,6 +1389,17 @@ __device__ __forceinline__ void sorted_walk(const FusedArgs& F, const int gb, co
       m0 = m1; cc0 = cc1; m1 = m2; d0 = d1;
       WPROF_T(ts3); WPROF_ADD(4, ts3 - ts2);
     }
+    if constexpr (BAS) {   // lane 16 q + c16 holds D[slot 16 mt + 4 q + r][channel 16 i + c16], r = 0 .. 3
+      f32x4* o = (f32x4*)F.bpart + ((int64_t)blockIdx.x * NW + (threadIdx.x >> 6)) * (2 * NL * 64) + lane;
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int i = 0; i < NL; ++i) o[(mt * NL + i) * 64] = bacc[mt][i];
+    }
+  } else if (BAS) {
+    f32x4* o = (f32x4*)F.bpart + ((int64_t)blockIdx.x * NW + (threadIdx.x >> 6)) * (2 * NL * 64) + lane;
+#pragma unroll
+    for (int e = 0; e < 2 * NL; ++e) o[e * 64] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
 #ifdef EGO_WALK_PROF
   if (lane == 0) {
@@ -1352,7 +1419,7 @@ __device__ __forceinline__ void sorted_walk(const FusedArgs& F, const int gb, co
 }
 
 // NW waves per workgroup, U samples in flight per 16-lane group
-template <int C, bool DENS, int NW, int U>
+template <int C, bool DENS, int NW, int U, bool BAS = false>
 __global__ __launch_bounds__(NW * 64) void k_sorted_walk(FusedArgs F) {
   extern __shared__ __attribute__((aligned(16))) unsigned char fused_lds[];
   typedef WalkLds<C / 16> WL;
@@ -1371,9 +1438,29 @@ __global__ __launch_bounds__(NW * 64) void k_sorted_walk(FusedArgs F) {
   const int gb = seg - seg_base(A, s);
   if (F.dbg >= 16 && (F.dbg >> 4) - 1 != seg) return;   // experiments: one segment alone (timing only)
   const bool do_line = F.do_line[s] != 0;
-  if (s == 0) sorted_walk<C, DENS, 0, NW, U>(F, gb, wg0, wg1, tab2, wl, do_line);
-  else if (s == 1) sorted_walk<C, DENS, 1, NW, U>(F, gb, wg0, wg1, tab2, wl, do_line);
-  else sorted_walk<C, DENS, 2, NW, U>(F, gb, wg0, wg1, tab2, wl, do_line);
+  if (s == 0) sorted_walk<C, DENS, 0, NW, U, BAS>(F, gb, wg0, wg1, tab2, wl, do_line);
+  else if (s == 1) sorted_walk<C, DENS, 1, NW, U, BAS>(F, gb, wg0, wg1, tab2, wl, do_line);
+  else sorted_walk<C, DENS, 2, NW, U, BAS>(F, gb, wg0, wg1, tab2, wl, do_line);
+}
+
+// d(basis) [2 grids][32 slots][144 = plane x 48 + channel] = the waves' partial products (k_sorted_walk<.., BAS>) added in workgroup / wave
+// order: bit-reproducible.  Plane I's 48 columns come from the sort that walks plane I; slot = ego_shade_backward's dfe column.
+template <int NW>
+__global__ void k_basis_reduce(FusedArgs F, float* __restrict__ G, int ldg) {
+  const SortedArgs& A = F.A;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= 2 * 32 * 144) return;
+  const int col = idx % 144, slot = (idx / 144) % 32, g = idx / (144 * 32);
+  const int I = col / 48, i = (col % 48) / 16, c16 = col % 16, mt = slot / 16, q = (slot % 16) / 4, r = slot % 4;
+  const int s = I == 1 ? 0 : I == 0 ? 1 : 2;   // sort_plane(s) == I
+  const int nbk = (int)A.nb[s];
+  float sum = 0.f;
+  for (int blk = 0; blk < nbk; ++blk) {
+    const int seg = seg_base(A, s) + g * nbk + blk;
+    for (int b = F.deal[seg]; b < F.deal[seg + 1]; ++b)
+      for (int w = 0; w < NW; ++w) sum += F.bpart[(((int64_t)b * NW + w) * 6 + mt * 3 + i) * 256 + (16 * q + c16) * 4 + r];
+  }
+  G[(32 * g + slot) * ldg + col] = sum;
 }
 
 // line texel (g, t, ch) of line I = sort_plane(s): the integer sums of the workgroups that served the (one or two) blocks whose window
@@ -1463,20 +1550,21 @@ int device_cus() {
   return cus;
 }
 
-template <int C, bool DENS, int NW, int U>
+template <int C, bool DENS, int NW, int U, bool BAS = false>
 int launch_walk_nw(const FusedArgs& F, int wg_total, int lds_bytes, hipStream_t st) {
   static std::atomic<int> attr_set{0};
   if (attr_set.load(std::memory_order_relaxed) < lds_bytes) {
-    if (const hipError_t e = hipFuncSetAttribute((const void*)k_sorted_walk<C, DENS, NW, U>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes))
+    if (const hipError_t e = hipFuncSetAttribute((const void*)k_sorted_walk<C, DENS, NW, U, BAS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes))
       return ego_fail((int)e, "k_sorted_walk: cannot reserve %d bytes of LDS: %s", lds_bytes, hipGetErrorString(e));
     attr_set.store(lds_bytes, std::memory_order_relaxed);
   }
-  k_sorted_walk<C, DENS, NW, U><<<wg_total, NW * 64, lds_bytes, st>>>(F);
+  k_sorted_walk<C, DENS, NW, U, BAS><<<wg_total, NW * 64, lds_bytes, st>>>(F);
   return ego_launch_status("k_sorted_walk");
 }
 
 template <int C, bool DENS>
-int launch_walk(SortedArgs a, const SortGeom& G, char* base, int64_t M, const float* dmax_ext, hipStream_t st) {
+int launch_walk(SortedArgs a, const SortGeom& G, char* base, int64_t M, const float* dmax_ext, hipStream_t st, const float* dfe = nullptr,
+                float* gbasis = nullptr, int ldg = 0) {
   static_assert(sizeof(WalkLds<C / 16>) == 12 * 64 * 4 + (C / 16) * 4 * 64 * 4, "walk_wave_bytes() mirrors WalkLds");
   const FusedPlan P = fused_plan(G, C);
   FxScale* fx = (FxScale*)(base + G.fx);
@@ -1519,7 +1607,16 @@ int launch_walk(SortedArgs a, const SortGeom& G, char* base, int64_t M, const fl
     if (!P.do_line[s]) { const int Ln = sort_plane(s); mask |= 1 << (Ln == 0 ? 0 : Ln == 1 ? 2 : 1); }   // the sort whose major key is line Ln's axis
   a.line_mask = mask;
   F.A = a;
-  {
+  const bool bas = !DENS && dfe && gbasis;
+  if (bas) {   // 8 waves per workgroup: the basis product's accumulators and operands take the walk past 170 VGPRs (the 48-channel walk runs as fast at two waves per SIMD as at three)
+    F.dfe = dfe;
+    F.bpart = (float*)(base + G.bpart);
+    if constexpr (!DENS) {
+      if (int e = launch_walk_nw<C, DENS, WALK_NW_BAS, 4, true>(F, off, P.lds_bytes, st)) return e;
+      k_basis_reduce<WALK_NW_BAS><<<(2 * 32 * 144 + 255) / 256, 256, 0, st>>>(F, gbasis, ldg);
+      if (int e = ego_launch_status("k_basis_reduce")) return e;
+    }
+  } else {
     constexpr int NW = C > 16 ? WALK_NW_APP : WALK_NW_DENS;
     if (int e = launch_walk_nw<C, DENS, NW, 4>(F, off, P.lds_bytes, st)) return e;
   }
@@ -1678,8 +1775,8 @@ int ego_scatter_density_sorted(const ego_scene* sc, const ego_vm_grad* gdensity,
   return launch_sorted<16, true>(a, G, (hipStream_t)stream);
 }
 
-int ego_scatter_app_sorted(const ego_scene* sc, const ego_vm_grad* gapp, const float* coords, const float* dv, const float* dv_absmax, int64_t N,
-                           int32_t S, void* workspace, int64_t workspace_bytes, void* stream) {
+int ego_scatter_app_sorted(const ego_scene* sc, const ego_vm_grad* gapp, const float* coords, const float* dv, const float* dv_absmax,
+                           const float* dfe, float* gbasis, int32_t ldg, int64_t N, int32_t S, void* workspace, int64_t workspace_bytes, void* stream) {
   EGO_TRACE("ego_scatter_app_sorted");
   if (int e = check_sizes(sc, N, S, "scatter_app_sorted")) return e;
   if (sc->app.n_comp != 48) return ego_fail(EGO_E_UNSUPPORTED, "scatter_app_sorted: n_comp %d (supported: 48)", sc->app.n_comp);
@@ -1690,7 +1787,8 @@ int ego_scatter_app_sorted(const ego_scene* sc, const ego_vm_grad* gapp, const f
   SortedArgs a{};
   if (int e = fill_args(sc->app, gapp, coords, dv, G, workspace, &a, "scatter_app_sorted")) return e;
   if (walk_wanted() && (N * (int64_t)S + 31) / 32 * 32 * 144 < (1ll << 30))   // (the walk addresses dv with 32-bit element offsets)
-    return launch_walk<48, false>(a, G, (char*)workspace, N * (int64_t)S, dv_absmax, (hipStream_t)stream);
+    return launch_walk<48, false>(a, G, (char*)workspace, N * (int64_t)S, dv_absmax, (hipStream_t)stream, dfe, gbasis, ldg);
+  if (dfe || gbasis) return ego_fail(EGO_E_UNSUPPORTED, "scatter_app_sorted: d(basis) rides along only in the walk form (EGO_SORTED_WALK=0 or a batch above 2^30 dv elements was asked for)");
   return launch_sorted<48, false>(a, G, (hipStream_t)stream);
 }
 

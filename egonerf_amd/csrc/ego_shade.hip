@@ -1463,7 +1463,7 @@ __global__ __launch_bounds__(512) void k_shade_h(ShadeArgs A) {
             ts[rd].a_r = c4.x; ts[rd].a_th = c4.y; ts[rd].a_ph = c4.z; ts[rd].g = c4.w != 0.f;
           }
         }
-        float* vd = (DUMP && valid) ? A.dump_v + dump_off(tile, 144, 0, hw, j) : nullptr;
+        float* vd = (DUMP && valid && A.dump_v) ? A.dump_v + dump_off(tile, 144, 0, hw, j) : nullptr;   // (v is optional since ABI v15: the sorted scatter can take d(basis) along)
         // one gather per tile; a border-straddling wave runs the basis steps of each plane twice (yin weights with the
         // yang lanes zeroed, then the reverse) inside gather_basis_team
         gather_basis_team<(MODE == MODE_SHADE && !DUMP), (FOLD ? EGO_HOIST_FOLD : EGO_HOIST_PLAIN)>(A.F, ts, BASH, lw, g, mixed, gu, fe, vd);
@@ -2036,7 +2036,7 @@ int ego_shade(const ego_scene* sc, const float* rays, const float* z, const floa
   a.c = make_coords(*sc); a.F = make_field(sc->app); a.packed = sc->packed; a.rays = rays; a.z = z; a.coords = coords; a.out = rgb; a.tile_active = tile_active;
   a.M = N * (int64_t)S; a.S = S;
   if (dump) {
-    EGO_REQUIRE(sc->mlp_precision != EGO_PREC_F32 && dump->h1 && dump->h2 && dump->v && dump->relu_bits && dump->fe,
+    EGO_REQUIRE(sc->mlp_precision != EGO_PREC_F32 && dump->h1 && dump->h2 && dump->relu_bits && dump->fe,   // (x and v are optional)
                 "shade: activation dumps need the fp16-split arithmetic (not EGO_PREC_F32) and non-null h1 / h2 / v / relu_bits / fe buffers (x is optional)");
     a.dump_x = dump->x; a.dump_h1 = dump->h1; a.dump_h2 = dump->h2; a.dump_v = dump->v; a.dump_bits = dump->relu_bits; a.dump_fe = dump->fe;
     k_shade_h<MODE_SHADE, true><<<shade_grid(a.M), 512, 0, (hipStream_t)stream>>>(a);

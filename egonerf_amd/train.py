@@ -39,6 +39,9 @@ _INDEX_CACHE = {}
 # stream still reads (the intermittent wrong appearance gradient of the first attempt).  EGO_TRAIN_SIDE_STREAM=0
 # serialises everything on one stream.
 SIDE_STREAM_SCATTER = __import__("os").environ.get("EGO_TRAIN_SIDE_STREAM", "1") != "0"
+# r06: d(basis) rides along in the sorted appearance scatter's walk (plane value x line value = v is in its registers), so the forward
+# dumps no v and the d(basis) weight-gradient pass is gone; EGO_TRAIN_WALK_BASIS=0 keeps the dump + ego_weight_grad form
+WALK_BASIS = __import__("os").environ.get("EGO_TRAIN_WALK_BASIS", "1") != "0"
 DUMP_X = __import__("os").environ.get("EGO_TRAIN_DUMP_X", "0") != "0"   # keep the forward's x dump (rounds 1-4) instead of re-deriving x for d(W1)
 _SIDE_STREAMS = {}
 
@@ -86,9 +89,11 @@ _G_ROWS = dict(G3=(0, 32), G2=(32, 160), G1=(160, 288), Gb=(288, 352))
 _G_LD = 160
 
 
-def _grad_plan(model, device):
-    """(flat gather index, split sizes, shapes, pad column) derived once from the layouts (no host synchronisation per step)."""
-    key = str(device)
+def _grad_plan(model, device, basis_reference_columns: bool = False):
+    """(flat gather index, split sizes, shapes, pad column) derived once from the layouts (no host synchronisation per step).
+    basis_reference_columns: the Gb block's columns are already plane x 48 + channel (ego_scatter_app_sorted's gbasis) instead of the
+    v dump's column order (ego_weight_grad over ego_shade_dump.v)."""
+    key = (str(device), bool(basis_reference_columns))
     if key not in _INDEX_CACHE:
         hid, xmap, fmap, vmap = (_layout(w, n, "cpu") for w, n in ((1, 128), (0, 160), (2, 32), (3, 144)))
         x_sel = (xmap >= 0).nonzero().flatten()
@@ -107,7 +112,8 @@ def _grad_plan(model, device):
         gbasis = []
         for g in range(2):
             gb = neg(model.app_dim, 144)
-            gb[f_rows[:, None], vmap[None, :]] = Gb[32 * g: 32 * g + 32, :144][f_sel]
+            cols = torch.arange(144) if basis_reference_columns else vmap
+            gb[f_rows[:, None], cols[None, :]] = Gb[32 * g: 32 * g + 32, :144][f_sel]
             gbasis.append(gb)
         parts = gbasis + [gw1, gb1, gw2, gb2, gw3, gb3]
         flat = torch.cat([p.reshape(-1) for p in parts])
@@ -247,7 +253,8 @@ class RenderFunction(torch.autograd.Function):
             f16 = lambda *shape: torch.empty(*shape, device=dev, dtype=torch.float16)   # x / h1 / h2: halves in the kernels' operand order
             # x (the 160-column MLP input) is not dumped: d(W1) re-derives it from the feature slots `fe` and the view direction
             # (ego_weight_grad_x: bit-identical operands, 0.67 GB less written and 0.4 GB less read per 8192 x 256 step); DUMP_X keeps the dump
-            dump = dict(x=f16(Mp, 160) if DUMP_X else None, h1=f16(Mp, 128), h2=f16(Mp, 128), v=f(Mp, 144),
+            walk_basis = bool(WALK_BASIS and sort_ws is not None and __import__("os").environ.get("EGO_SORTED_WALK", "1") != "0" and Mp * 144 < 2 ** 30)
+            dump = dict(x=f16(Mp, 160) if DUMP_X else None, h1=f16(Mp, 128), h2=f16(Mp, 128), v=None if walk_basis else f(Mp, 144),
                         relu_bits=torch.empty(Mp // 32, 2, 64, 2, device=dev, dtype=torch.int32), fe=f(Mp // 32, 4, 64, 4))
             ds = _lib.ShadeDump(*(_lib.ptr(dump[k]) for k in ("x", "h1", "h2", "v", "relu_bits", "fe")))
             _chk(lib.ego_shade(sc, rays.data_ptr(), z.data_ptr(), coords.data_ptr(), N, S, rgb.data_ptr(), C.byref(ds), None, st), "ego_shade")
@@ -359,8 +366,13 @@ class RenderFunction(torch.autograd.Function):
                                           dh2.data_ptr(), dh1.data_ptr(), dh_scale.data_ptr(), dfe.data_ptr(), dv.data_ptr(), dv_absmax.data_ptr(), N, S, st),
              "ego_shade_backward")
         ga = _grad_struct(g_app)
+        # the product buffer exists (zero-filled, on the main stream) BEFORE the side stream is allowed to write its d(basis) block into it
+        Gall = torch.zeros(352, _G_LD, device=dev)
+        walk_basis = ws is not None and sv["v"] is None
         if ws is not None:   # (this is the tuned-head path: sorted_app above)
-            on_side(lambda s_: _chk(lib.ego_scatter_app_sorted(sc, C.byref(ga), sv["coords"].data_ptr(), dv.data_ptr(), dv_absmax.data_ptr(), N, S,
+            Gb_ptr = Gall[_G_ROWS["Gb"][0]:].data_ptr() if walk_basis else None
+            on_side(lambda s_: _chk(lib.ego_scatter_app_sorted(sc, C.byref(ga), sv["coords"].data_ptr(), dv.data_ptr(), dv_absmax.data_ptr(),
+                                                               dfe.data_ptr() if walk_basis else None, Gb_ptr, _G_LD if walk_basis else 0, N, S,
                                                                ws.data_ptr(), ws.numel(), s_), "ego_scatter_app_sorted"))
         else:
             on_side(lambda s_: _chk(lib.ego_scatter_app(sc, C.byref(ga), sv["coords"].data_ptr(), dv.data_ptr(), N, S, s_), "ego_scatter_app"))
@@ -370,10 +382,9 @@ class RenderFunction(torch.autograd.Function):
         # ones column) per layer over the dumped buffers into one product buffer, then one gather un-permutes the lane-order
         # columns into the reference-shaped gradients ----
         do = dc.view(M, 3)  # now d(pre-sigmoid)
-        gidx, gsizes, gshapes, pad = _grad_plan(model, dev)  # pad: a padding column of the x dump (holds zeros) doubles as the ones column
+        gidx, gsizes, gshapes, pad = _grad_plan(model, dev, walk_basis)  # pad: a padding column of the x dump (holds zeros) doubles as the ones column
         # deterministic mode (model.deterministic_scatter): per-workgroup partial products added in a fixed order instead of float atomics
         det = model.deterministic_scatter
-        Gall = torch.zeros(352, _G_LD, device=dev)
         part = f(lib.ego_weight_grad_partial_floats()) if det else None
 
         def wgrad(which, A, ca, a_layout, B, cb, ones_col, a_scale=None):
@@ -390,7 +401,10 @@ class RenderFunction(torch.autograd.Function):
             G1 = Gall[_G_ROWS["G1"][0]:_G_ROWS["G1"][1]]
             _chk(lib.ego_weight_grad_x(dh1.data_ptr(), dh_scale[1].data_ptr(), sv["fe"].data_ptr(), sv["rays"].data_ptr(), S, pad, M, G1.data_ptr(), _G_LD,
                                        _lib.ptr(part), 0 if part is None else part.numel(), st), "ego_weight_grad")
-        wgrad("Gb", dfe, 64, 3, sv["v"], 144, -1, sv["coords"].view(M, 4))   # 32 stored columns, routed to the yin / yang block by coords.w
+        if walk_basis:
+            main.wait_stream(side) if side is not None else None   # the walk's k_basis_reduce wrote Gall's Gb block on the side stream
+        else:
+            wgrad("Gb", dfe, 64, 3, sv["v"], 144, -1, sv["coords"].view(M, 4))   # 32 stored columns, routed to the yin / yang block by coords.w
         wg = [t.view(shp) for t, shp in zip(Gall.view(-1).index_select(0, gidx).split(gsizes), gshapes)]
         grads = g_dens + g_app + wg  # wg: basis yin, basis yang, w1, b1, w2, b2, w3, b3 (differentiable_params order)
         if sv["env"] is not None:

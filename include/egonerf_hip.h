@@ -369,8 +369,15 @@ int64_t ego_scatter_sorted_workspace_bytes(const ego_scene* sc, int64_t N, int32
 int ego_scatter_sort(const ego_scene* sc, const float* coords, int64_t N, int32_t S, void* workspace, int64_t workspace_bytes, void* stream);
 int ego_scatter_density_sorted(const ego_scene* sc, const ego_vm_grad* gdensity, const float* coords, const float* dfeat, int64_t N, int32_t S,
                                void* workspace, int64_t workspace_bytes, void* stream);
-int ego_scatter_app_sorted(const ego_scene* sc, const ego_vm_grad* gapp, const float* coords, const float* dv, const float* dv_absmax, int64_t N,
-                           int32_t S, void* workspace, int64_t workspace_bytes, void* stream); /* dv: ego_shade_backward's blocked layout */
+int ego_scatter_app_sorted(const ego_scene* sc, const ego_vm_grad* gapp, const float* coords, const float* dv, const float* dv_absmax,
+                           const float* dfe, float* gbasis, int32_t ldg, int64_t N, int32_t S, void* workspace, int64_t workspace_bytes,
+                           void* stream); /* dv: ego_shade_backward's blocked layout */
+/* dfe / gbasis (v15; both or neither; NULL = as before): the basis gradient rides along as well.  d(basis_mat)[slot][plane x 48 + channel] =
+ * sum over samples of dfe[s][slot] x (plane value x line value)[s][channel] - and the walk has both factors of that product in registers,
+ * so the forward need not dump v (ego_shade_dump.v = NULL: 576 B per sample less to write) for ego_weight_grad to read it back.  dfe =
+ * ego_shade_backward's [M][32] (the sample's own grid's slots); gbasis [64][ldg >= 144] receives row 32 g + slot, column plane x 48 +
+ * channel (reference channel order), written, not accumulated; bf16 hi / lo split MFMA like ego_weight_grad, per-wave partial products added
+ * in a fixed order (bit-reproducible).  Only in the walk form (EGO_E_UNSUPPORTED with EGO_SORTED_WALK=0). */
 /* v15: ONE pass over dfeat / dv.  The gradient of a plane and of the line it is multiplied with (the table of the axis that is not in the
  * plane) come out of the same walk over the plane's cells: a cell's samples share the four plane texels, so the line's contribution of a
  * sample is four multiply-adds away - but it lands in an arbitrary line texel.  Those sums are therefore taken in 64-bit FIXED POINT

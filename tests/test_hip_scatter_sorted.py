@@ -46,7 +46,7 @@ def _scatter_both(model, coords, dfeat, dv, N, S):
             ws = torch.empty(nbytes, device=DEV, dtype=torch.uint8)
             _lib.check(lib.ego_scatter_sort(sc, coords.data_ptr(), N, S, ws.data_ptr(), nbytes, st), "scatter_sort")
             _lib.check(lib.ego_scatter_density_sorted(sc, C.byref(sd), coords.data_ptr(), dfeat.data_ptr(), N, S, ws.data_ptr(), nbytes, st), "density_sorted")
-            _lib.check(lib.ego_scatter_app_sorted(sc, C.byref(sa), coords.data_ptr(), dv.data_ptr(), _lib.ptr(absmax), N, S, ws.data_ptr(), nbytes, st), "app_sorted")
+            _lib.check(lib.ego_scatter_app_sorted(sc, C.byref(sa), coords.data_ptr(), dv.data_ptr(), _lib.ptr(absmax), None, None, 0, N, S, ws.data_ptr(), nbytes, st), "app_sorted")
         torch.cuda.synchronize()
         os.environ.pop("EGO_SORTED_LINES", None)
         out[mode] = (gd, ga)
@@ -104,7 +104,7 @@ def test_an_empty_batch_zero_fills_the_tables():
     ws = torch.empty(nbytes, device=DEV, dtype=torch.uint8)
     _lib.check(lib.ego_scatter_sort(sc, None, 0, 8, ws.data_ptr(), nbytes, st), "scatter_sort")
     _lib.check(lib.ego_scatter_density_sorted(sc, C.byref(sd), None, None, 0, 8, ws.data_ptr(), nbytes, st), "density_sorted")
-    _lib.check(lib.ego_scatter_app_sorted(sc, C.byref(sa), None, None, None, 0, 8, ws.data_ptr(), nbytes, st), "app_sorted")
+    _lib.check(lib.ego_scatter_app_sorted(sc, C.byref(sa), None, None, None, None, None, 0, 0, 8, ws.data_ptr(), nbytes, st), "app_sorted")
     torch.cuda.synchronize()
     for g in gd + ga:
         assert float(g.abs().max()) == 0.0

@@ -29,7 +29,7 @@ def run(which):
     global ws, nb
     if which == "sort": _lib.check(lib.ego_scatter_sort(sc, crd.data_ptr(), N, S, ws.data_ptr(), nb, st), "sort")
     if which == "dens": _lib.check(lib.ego_scatter_density_sorted(sc, C.byref(sd), crd.data_ptr(), dfeat.data_ptr(), N, S, ws.data_ptr(), nb, st), "d")
-    if which == "app": _lib.check(lib.ego_scatter_app_sorted(sc, C.byref(sa), crd.data_ptr(), dv.data_ptr(), None, N, S, ws.data_ptr(), nb, st), "a")
+    if which == "app": _lib.check(lib.ego_scatter_app_sorted(sc, C.byref(sa), crd.data_ptr(), dv.data_ptr(), None, None, None, 0, N, S, ws.data_ptr(), nb, st), "a")
     if which == "dens_atomic": _lib.check(lib.ego_scatter_density(sc, C.byref(sd), crd.data_ptr(), dfeat.data_ptr(), N, S, st), "d")
     if which == "app_atomic": _lib.check(lib.ego_scatter_app(sc, C.byref(sa), crd.data_ptr(), dv.data_ptr(), N, S, st), "a")
 def timed(which, label):
