@@ -1121,21 +1121,21 @@ __device__ __forceinline__ float row_sum16(float v) {
   return v;
 }
 
-// v = hi + lo + O(2^-18 |v|) as bf16 (round to nearest even: unbiased), the split csrc/ego_wgrad.hip uses for its fp32 operands
-__device__ __forceinline__ uint32_t walk_bf16_rn(float v) {
-  const uint32_t u = __float_as_uint(v);
-  return (u + 0x7fffu + ((u >> 16) & 1u)) & 0xffff0000u;
-}
+// x = hi + lo + O(2^-17 |x|) as two bf16: hi = the top 16 bits of x as they are (truncation - the residual x - hi is exact in fp32 and
+// carries what was cut), lo = that residual rounded to its top 16 bits (+ 0x8000).  Four VALU per value (and, sub, add, half a v_perm per
+// packed pair and term) where rounding both terms to nearest even takes ten: the walk is bound by VALU issue.
 typedef short walk_s4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2_w __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void walk_split4(const float x[4], walk_s4& hi, walk_s4& lo) {
-  uint32_t h[4], l[4];
+  uint32_t xb[4], lb[4];
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
-    h[e] = walk_bf16_rn(x[e]);
-    l[e] = walk_bf16_rn(__fsub_rn(x[e], __uint_as_float(h[e])));
+    xb[e] = __float_as_uint(x[e]);
+    lb[e] = __float_as_uint(__fsub_rn(x[e], __uint_as_float(xb[e] & 0xffff0000u))) + 0x8000u;   // the residual rounded, not cut: ~17 bits in all, unbiased
   }
-  const u32x2_w ph = {(h[0] >> 16) | h[1], (h[2] >> 16) | h[3]}, pl = {(l[0] >> 16) | l[1], (l[2] >> 16) | l[3]};
+  // v_perm_b32: {top half of the second value, top half of the first}
+  const u32x2_w ph = {__builtin_amdgcn_perm(xb[1], xb[0], 0x07060302u), __builtin_amdgcn_perm(xb[3], xb[2], 0x07060302u)};
+  const u32x2_w pl = {__builtin_amdgcn_perm(lb[1], lb[0], 0x07060302u), __builtin_amdgcn_perm(lb[3], lb[2], 0x07060302u)};
   hi = __builtin_bit_cast(walk_s4, ph);
   lo = __builtin_bit_cast(walk_s4, pl);
 }
@@ -1446,21 +1446,26 @@ __global__ __launch_bounds__(NW * 64) void k_sorted_walk(FusedArgs F) {
 // d(basis) [2 grids][32 slots][144 = plane x 48 + channel] = the waves' partial products (k_sorted_walk<.., BAS>) added in workgroup / wave
 // order: bit-reproducible.  Plane I's 48 columns come from the sort that walks plane I; slot = ego_shade_backward's dfe column.
 template <int NW>
-__global__ void k_basis_reduce(FusedArgs F, float* __restrict__ G, int ldg) {
+__global__ __launch_bounds__(256) void k_basis_reduce(FusedArgs F, float* __restrict__ G, int ldg) {
+  // one wave per output element: lane L adds the partials L, L + 64, ... of the element's (workgroup, wave) list in that order, the 64
+  // lane sums are added as a fixed tree - the same bits every run (a thread per element walked ~700 partials alone: 60 us)
   const SortedArgs& A = F.A;
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int idx = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (idx >= 2 * 32 * 144) return;
   const int col = idx % 144, slot = (idx / 144) % 32, g = idx / (144 * 32);
   const int I = col / 48, i = (col % 48) / 16, c16 = col % 16, mt = slot / 16, q = (slot % 16) / 4, r = slot % 4;
   const int s = I == 1 ? 0 : I == 0 ? 1 : 2;   // sort_plane(s) == I
   const int nbk = (int)A.nb[s];
+  const int64_t elem = (int64_t)(mt * 3 + i) * 256 + (16 * q + c16) * 4 + r;
   float sum = 0.f;
   for (int blk = 0; blk < nbk; ++blk) {
     const int seg = seg_base(A, s) + g * nbk + blk;
-    for (int b = F.deal[seg]; b < F.deal[seg + 1]; ++b)
-      for (int w = 0; w < NW; ++w) sum += F.bpart[(((int64_t)b * NW + w) * 6 + mt * 3 + i) * 256 + (16 * q + c16) * 4 + r];
+    const int b0 = F.deal[seg], n = (F.deal[seg + 1] - b0) * NW;
+    for (int t = lane; t < n; t += 64) sum += F.bpart[((int64_t)b0 * NW + t) * (6 * 256) + elem];
   }
-  G[(32 * g + slot) * ldg + col] = sum;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) sum += __shfl_xor(sum, d, 64);
+  if (lane == 0) G[(32 * g + slot) * ldg + col] = sum;
 }
 
 // line texel (g, t, ch) of line I = sort_plane(s): the integer sums of the workgroups that served the (one or two) blocks whose window
@@ -1613,7 +1618,7 @@ int launch_walk(SortedArgs a, const SortGeom& G, char* base, int64_t M, const fl
     F.bpart = (float*)(base + G.bpart);
     if constexpr (!DENS) {
       if (int e = launch_walk_nw<C, DENS, WALK_NW_BAS, 4, true>(F, off, P.lds_bytes, st)) return e;
-      k_basis_reduce<WALK_NW_BAS><<<(2 * 32 * 144 + 255) / 256, 256, 0, st>>>(F, gbasis, ldg);
+      k_basis_reduce<WALK_NW_BAS><<<(2 * 32 * 144 + 3) / 4, 256, 0, st>>>(F, gbasis, ldg);
       if (int e = ego_launch_status("k_basis_reduce")) return e;
     }
   } else {

@@ -376,7 +376,7 @@ int ego_scatter_app_sorted(const ego_scene* sc, const ego_vm_grad* gapp, const f
  * sum over samples of dfe[s][slot] x (plane value x line value)[s][channel] - and the walk has both factors of that product in registers,
  * so the forward need not dump v (ego_shade_dump.v = NULL: 576 B per sample less to write) for ego_weight_grad to read it back.  dfe =
  * ego_shade_backward's [M][32] (the sample's own grid's slots); gbasis [64][ldg >= 144] receives row 32 g + slot, column plane x 48 +
- * channel (reference channel order), written, not accumulated; bf16 hi / lo split MFMA like ego_weight_grad, per-wave partial products added
+ * channel (reference channel order), written, not accumulated; bf16 hi / lo split MFMA (three terms, ~16 significand bits per operand), per-wave partial products added
  * in a fixed order (bit-reproducible).  Only in the walk form (EGO_E_UNSUPPORTED with EGO_SORTED_WALK=0). */
 /* v15: ONE pass over dfeat / dv.  The gradient of a plane and of the line it is multiplied with (the table of the axis that is not in the
  * plane) come out of the same walk over the plane's cells: a cell's samples share the four plane texels, so the line's contribution of a
