@@ -265,7 +265,7 @@ typedef struct ego_shade_dump {
   uint16_t* x;   /* optional (NULL: not written): only d(W1) reads it, and ego_weight_grad_x re-derives it from `fe` and the rays */
   uint16_t* h1;
   uint16_t* h2;
-  float* v;
+  float* v;      /* optional since v15 (NULL: not written): only d(basis) reads it, and ego_scatter_app_sorted(dfe, gbasis) takes that product along */
   uint32_t* relu_bits;
   float* fe;   /* [ceil(M / 32)][4][64 lanes][4] fp32: the 16 feature slots of lane 32 h + m % 32 (basis output, slot r = feature 2 r + h);
                 * the backward re-derives the encodings' sines and cosines from them with the forward's own instructions */
