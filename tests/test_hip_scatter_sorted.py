@@ -304,3 +304,58 @@ def test_fixed_point_unit_follows_the_batch_not_a_constant():
         for fi in range(2):
             for k, (a, b) in enumerate(zip(got[fi], base[fi])):
                 assert torch.equal(a, b * f), (e, fi, k, float((a - b * f).abs().max()))
+
+
+def test_basis_gradient_rides_along_in_the_appearance_scatter():
+    """ABI v15, late round 6: ego_scatter_app_sorted(dfe, gbasis) returns d(basis)[32 g + slot][plane x 48 + channel] = sum over the grid's
+    samples of dfe[s][slot] x (plane value x line value)[s][channel] - the product ego_weight_grad(dfe, v dump) used to take - from the
+    walk's own interpolated values.  Against float64 (the oracle's F.grid_sample taps) at 2e-5 of the largest element (bf16 hi + rounded
+    residual operands: ~17 bits each), bit-identical twice, and the table gradients unchanged by the extra output."""
+    from tests.helpers import make_oracle
+    cfg = synth.SceneConfig(n_voxel=27e6)
+    weights = synth.make_weights(cfg, seed=21)
+    model = make_model(cfg, weights, DEV)
+    N, S = 512, 96
+    M = N * S
+    g = torch.Generator().manual_seed(17)
+    coords = (torch.rand(N, S, 4, generator=g) * 2 - 1) * 1.05
+    coords[..., 3] = (torch.rand(N, S, generator=g) > 0.4).float()
+    dv_ref = torch.randn(M, 144, generator=g)
+    dfe = torch.randn(M, 32, generator=g) * torch.rand(M, 1, generator=g) * 1e-3
+    lib, st = _lib.load(), _lib.stream_handle()
+    sc = model.scene(training=True)
+    cd, dvd, dfed = coords.to(DEV).contiguous(), _blocked_dv(dv_ref, M).to(DEV), dfe.to(DEV).contiguous()
+    nbytes = lib.ego_scatter_sorted_workspace_bytes(sc, N, S)
+    ws = torch.empty(nbytes, device=DEV, dtype=torch.uint8)
+    _lib.check(lib.ego_scatter_sort(sc, cd.data_ptr(), N, S, ws.data_ptr(), nbytes, st), "scatter_sort")
+    outs = []
+    for with_basis in (True, True, False):
+        ga = [torch.full_like(p, float("nan")) for p in table_params(model, "app")]
+        sa = _grad_struct(ga)
+        gb = torch.full((64, 160), float("nan"), device=DEV)
+        _lib.check(lib.ego_scatter_app_sorted(sc, C.byref(sa), cd.data_ptr(), dvd.data_ptr(), None, dfed.data_ptr() if with_basis else None,
+                                              gb.data_ptr() if with_basis else None, 160 if with_basis else 0, N, S, ws.data_ptr(), nbytes, st), "app_sorted")
+        torch.cuda.synchronize()
+        outs.append((ga, gb))
+    for k, (a, b) in enumerate(zip(outs[0][0], outs[1][0])):
+        assert torch.equal(a, b), ("run to run", k, float((a - b).abs().max()))
+    for k, (a, b) in enumerate(zip(outs[0][0], outs[2][0])):
+        # the tables do not notice the extra product - up to the last bit of the planes: the two template instantiations are compiled with
+        # fp-contract(fast), and the compiler fuses different multiply-adds in them (each form is bit-reproducible by itself: above)
+        assert float((a - b).abs().max()) <= 1e-6 * float(b.abs().max()), ("with / without the basis product", k, float((a - b).abs().max()))
+        if k % 6 >= 3:
+            assert torch.equal(a, b), ("lines are integer sums of the same contributions", k)
+    assert torch.equal(outs[0][1][:, :144], outs[1][1][:, :144])          # same bits twice (columns 144.. of the [64][160] block are not the call's)
+    assert bool(torch.isfinite(outs[0][1][:, :144]).all())
+    got = outs[0][1][:, :144].double().cpu()
+    # float64 truth from the oracle's taps
+    o = make_oracle(cfg, weights, dtype=torch.float64)
+    c4 = coords.reshape(-1, 4).double()
+    ref = torch.zeros(64, 144, dtype=torch.float64)
+    for gi, (name, sel) in enumerate((("yin", c4[:, 3] == 0), ("yang", c4[:, 3] != 0))):
+        taps = o._vm_taps([o.table("app", "plane", name, i) for i in range(3)], [o.table("app", "line", name, i) for i in range(3)], c4[sel][:, :3])
+        v = torch.cat([P * L for P, L in taps])          # [144, m]
+        ref[32 * gi: 32 * gi + 32] = dfe[sel].double().T @ v.T
+    scale = float(ref.abs().max())
+    err = float((got - ref).abs().max()) / scale
+    assert err <= 2e-5, err
