@@ -33,8 +33,10 @@
 // >= 40 bits below the largest possible contribution - an fp32 sum keeps 24) and added with integer LDS atomics into a per-workgroup
 // table of the line; integer addition is associative, so any order gives the same bits.  k_sorted_walk = the plane walk + those
 // four multiply-adds + two ds_add_u64 per channel lane and sample; k_fused_line_final adds the workgroups' tables and converts once.
-// The separate line kernels stay for line tables that do not fit the LDS (the appearance field's r line on the headline grid;
-// EGO_SORTED_LINES=separate forces them for every line, EGO_SORTED_WALK=0 the whole round-5 form).
+// Lines too long for the LDS are cut into BLOCKS by the sort keys (a workgroup's table holds one block's window), so every line rides
+// along on every shipped grid; the separate line kernels stay as the fall-back (EGO_SORTED_LINES=separate forces them for every line,
+// EGO_SORTED_WALK=0 the whole round-5 form).  Late in the round the appearance walk also took the basis gradient along (BAS: it holds
+// plane value x line value, one bf16 MFMA per iteration multiplies it with the sample's feature-slot gradients): no v dump, no d(basis) pass.
 
 #include "ego_device.h"
 #include "ego_host.h"
@@ -85,10 +87,10 @@ struct SortGeom {
 inline int64_t align256(int64_t v) { return (v + 255) & ~(int64_t)255; }
 
 // ---- launch plan of the walk --------------------------------------------------------------------------------------------------------
-// Sort s serves plane sort_plane(s) AND - where it fits - the line of the axis that is not in its key (line index sort_plane(s)).  A
-// workgroup keeps that line's integer table for ONE grid in LDS: n x C x 8 bytes beside the waves' records.  The headline grid
-// [150, 172, 516]: the density field's three lines fit (C = 16), of the appearance field's (C = 48) the theta and phi lines do and the r
-// line (198 KB) does not - it keeps the two-pass form (k_sorted_line of the sort whose major key is r).
+// Sort s serves plane sort_plane(s) AND the line of the axis that is not in its key (line index sort_plane(s)).  A workgroup keeps ONE
+// line block's window of that line's integer table for ONE grid in LDS: (bs + 1) x C x 8 bytes beside the waves' records; the sort keys
+// carry the block (line_blocks / make_geom: the headline grid [150, 172, 516] needs 1 / 1 / 3 blocks for theta / phi / r at C = 48 -
+// the r line alone would be 198 KB).  Only a line whose block window does not fit even in WALK_MAX_BLOCKS blocks keeps the two-pass form.
 constexpr int FUSED_LDS_LIMIT = 160 * 1024 - 1024;
 constexpr int WALK_MAX_BLOCKS = 16, WALK_MAX_SEG = 6 * WALK_MAX_BLOCKS;   // line blocks per sort; (sort, grid, block) segments of a launch
 constexpr int WALK_NW_APP = 12, WALK_NW_DENS = 16, WALK_NW_BAS = 8;   // waves per workgroup: 144+ VGPRs at 48 channels (three waves per SIMD), ~110 at 16
@@ -1058,7 +1060,7 @@ struct FusedArgs {
   int8_t do_line[3];          // sort s also takes the gradient of line sort_plane(s)
   const float* dfe;           // BAS (48 channels): ego_shade_backward's feature-slot gradients [M][32]
   float* bpart;               // BAS: per wave [2 slot tiles][3 channel groups][64 lanes][4]: its share of d(basis)
-  int32_t dbg;                // experiments (EGO_FUSED_DBG): 1 = no LDS atomics, 2 = no line part at all (timing only: wrong line gradients)
+  int32_t dbg;                // experiments (EGO_FUSED_DBG = 16 (n + 1)): segment n alone (timing only: the other segments' gradients are not written)
 };
 
 // SEGMENT = (sort, grid, line block): a contiguous range of kc[s] cells of the sort's key order.  Workgroups are dealt to the segments in

@@ -75,12 +75,6 @@ if os.environ.get("PROBE_PAIRS"):   # the walk with ONE (sort, grid) pair active
         os.environ["EGO_FUSED_DBG"] = str(dbg)
         timed("dens", f"dens pair={dbg // 16 - 1}"); timed("app", f"app pair={dbg // 16 - 1}")
     sys.exit(0)
-if os.environ.get("PROBE_DBG"):   # timing-only ablations of the walk kernel (wrong gradients), lines separate so that nothing else is in the figure
-    os.environ["EGO_SORTED_LINES"] = "separate"
-    for dbg in (0, 4, 8, 12, 16, 0):
-        os.environ["EGO_FUSED_DBG"] = str(dbg)
-        timed("dens", f"dens dbg={dbg}"); timed("app", f"app dbg={dbg}")
-    sys.exit(0)
 if os.environ.get("PROBE_ONLY"):   # tools/sorted_kernels.sh: the current environment's form only, for a kernel trace
     timed("dens", "dens"); timed("app", "app")
     sys.exit(0)
@@ -88,7 +82,7 @@ if os.environ.get("PROBE_ONLY"):   # tools/sorted_kernels.sh: the current enviro
 ref = None
 ENV_KEYS = ("EGO_SORTED_LINES", "EGO_SORTED_WALK", "EGO_FUSED_DBG")
 for label, env in (("r05 form", dict(EGO_SORTED_WALK="0")), ("walk", {}), ("walk, lines separate", dict(EGO_SORTED_LINES="separate")),
-                   ("walk no-atomics", dict(EGO_FUSED_DBG="1")), ("walk no-line-part", dict(EGO_FUSED_DBG="2")), ("r05 form again", dict(EGO_SORTED_WALK="0")),
+                   ("r05 form again", dict(EGO_SORTED_WALK="0")),
                    ("walk again", {})):
     for k in ENV_KEYS: os.environ.pop(k, None)
     os.environ.update(env)
