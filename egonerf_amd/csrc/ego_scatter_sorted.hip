@@ -974,7 +974,19 @@ __global__ __launch_bounds__(256) void k_fx_absmax(AbsmaxArgs A) {
   }
 }
 
-__global__ void k_fx_setup(FxScale* fx, const uint32_t* part, int64_t M, const float* dmax_ext) {
+__global__ void k_fx_setup(FxScale* fx, const uint32_t* part, int64_t M, const float* dmax_ext, const float* basis0 = nullptr,
+                           const float* basis1 = nullptr) {
+  // RDV (the walk re-derives dv = B^T dfe): dmax_ext is max |dfe|, and |dv| <= max |dfe| x the largest column sum of |B| (27 x 144 per grid)
+  float colmax = 0.f;
+  if (basis0) {
+    for (int c = threadIdx.x; c < 2 * 144; c += 64) {
+      const float* B = c < 144 ? basis0 : basis1;
+      float sum = 0.f;
+      for (int f = 0; f < 27; ++f) sum += fabsf(B[f * 144 + c % 144]);
+      colmax = fmaxf(colmax, sum);   // (a NaN weight: fmaxf drops it - the plane / dfe maxima still poison what it touches, and the walk's result is NaN wherever it is used)
+    }
+    colmax = __uint_as_float(wave_max_u32(__float_as_uint(colmax)));
+  }
   // one wave: the workgroups' maxima -> the four scalars
   for (int y = 0; y < 7; ++y) {
     uint32_t m = 0;
@@ -988,6 +1000,10 @@ __global__ void k_fx_setup(FxScale* fx, const uint32_t* part, int64_t M, const f
   if (threadIdx.x) return;
   uint32_t db = fx->dmax_bits;
   if (dmax_ext) db = __float_as_uint(*dmax_ext) & 0x7fffffffu;
+  if (basis0 && db < 0x7f800000u) {
+    const float bound = __uint_as_float(db) * colmax * 1.01f;   // (+ 1 %: the walk's fp16 three-term products are within 2^-20 of exact)
+    db = bound < 3.0e38f ? __float_as_uint(bound) : 0x7f800000u;
+  }
   int lg = 1;
   while (((int64_t)1 << lg) < M && lg < 40) ++lg;
   const int nbits = min(50, 62 - lg);
@@ -1060,6 +1076,7 @@ struct FusedArgs {
   int8_t do_line[3];          // sort s also takes the gradient of line sort_plane(s)
   const float* dfe;           // BAS (48 channels): ego_shade_backward's feature-slot gradients [M][32]
   float* bpart;               // BAS: per wave [2 slot tiles][3 channel groups][64 lanes][4]: its share of d(basis)
+  const float* basis[2];      // RDV: nn.Linear(144 -> 27).weight [27][144] of each grid: the walk re-derives dv = B^T dfe itself
   int32_t dbg;                // experiments (EGO_FUSED_DBG = 16 (n + 1)): segment n alone (timing only: the other segments' gradients are not written)
 };
 
@@ -1142,7 +1159,33 @@ __device__ __forceinline__ void walk_split4(const float x[4], walk_s4& hi, walk_
   lo = __builtin_bit_cast(walk_s4, pl);
 }
 
-template <int C, bool DENS, int S_, int NW, int U, bool BAS = false>
+// x (already scaled into fp16's normal range: |x| < 2^13) = hi + lo + O(2^-21 |x|) as two fp16: hi rounded to nearest, lo = the exact fp32
+// residual cut to fp16 - the operand form of k_shade_bwd's data-gradient chain (ego_train.inc: split8_rn), here for v_mfma_f32_16x16x16_f16
+typedef _Float16 walk_h4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void walk_split4_f16(const float x[4], walk_h4& hi, walk_h4& lo) {
+  typedef float f2v __attribute__((ext_vector_type(2)));
+  typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+  uint32_t hw[2], lw[2];
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const float a = x[2 * p], b = x[2 * p + 1];
+    const h2v hp = __builtin_convertvector(f2v{a, b}, h2v);
+    hw[p] = __builtin_bit_cast(uint32_t, hp);
+    lw[p] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(__fsub_rn(a, (float)hp[0]), __fsub_rn(b, (float)hp[1])));
+  }
+  hi = __builtin_bit_cast(walk_h4, u32x2_w{hw[0], hw[1]});
+  lo = __builtin_bit_cast(walk_h4, u32x2_w{lw[0], lw[1]});
+}
+// the power of two that takes amax into [2^12, 2^13) and its inverse (1 for zero, subnormal and non-finite amax), as ego_train.inc's sample_scale
+__device__ __forceinline__ float walk_pow2_scale(float amax, float& inv) {
+  const int e = (__float_as_int(amax) >> 23) & 0xff;
+  const int k = (e == 0 || e > 254) ? 0 : 139 - e;
+  const int kc = k > 100 ? 100 : (k < -100 ? -100 : k);
+  inv = __int_as_float((127 - kc) << 23);
+  return __int_as_float((127 + kc) << 23);
+}
+
+template <int C, bool DENS, int S_, int NW, int U, bool BAS = false, bool RDV = false>
 __device__ __forceinline__ void sorted_walk(const FusedArgs& F, const int gb, const int wg0, const int wg1, unsigned long long* __restrict__ tab,
                                             WalkLds<C / 16>* wl, const bool do_line) {
 #pragma clang fp contract(fast)
@@ -1230,6 +1273,40 @@ __device__ __forceinline__ void sorted_walk(const FusedArgs& F, const int gb, co
 #pragma unroll
         for (int i = 0; i < NL; ++i) bacc[mt][i] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
+    // RDV: dv = B_g^T dfe is a linear map of the 27 feature-slot gradients the walk loads anyway: it is re-derived here, 16 samples x 48
+    // channels per iteration, instead of being written by k_shade_bwd (576 B per sample) and gathered back.  v_mfma_f32_16x16x16_f16,
+    // M = the iteration's 16 samples (row 4 q' + u'), K = 16 slots (two k-blocks), N = channel: lane 16 q + c supplies A[row c][slots
+    // 16 kb + 4 q ..] = four feature-slot gradients of sample (c / 4, c % 4) and B[slots 16 kb + 4 q ..][channel 16 i + c] (constants of
+    // the launch, split once), and receives D[rows 4 q ..][channel] = dv of ITS OWN group's four samples.  Arithmetic = k_shade_bwd's for
+    // the same product: operands scaled by a power of two per sample (A) / per channel lane (B) into fp16's normal range, fp16 hi + lo,
+    // three terms, fp32 accumulation (~2^-21 per product; a bf16 split's 2^-16 showed at 2e-5 of the largest texel gradient).
+    walk_h4 bfh[RDV ? 2 : 1][RDV ? NL : 1], bfl[RDV ? 2 : 1][RDV ? NL : 1];
+    float inv_b = 1.f;
+    if constexpr (RDV) {
+      const float* Bg = g ? F.basis[1] : F.basis[0];
+      float w[2][NL][4], am = 0.f;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int i = 0; i < NL; ++i)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int r = 4 * q + e, f = 2 * r + kb;   // dfe column 16 kb + r holds feature 2 r + kb (slot r of lane half kb), r <= 13
+            w[kb][i][e] = (r <= 13 && f < 27) ? Bg[f * (3 * C) + I * C + 16 * i + c16] : 0.f;
+            am = fmaxf(am, fabsf(w[kb][i][e]));
+          }
+      am = fmaxf(am, __shfl_xor(am, 16, 64));
+      am = fmaxf(am, __shfl_xor(am, 32, 64));   // the channel lane's column maximum: the four lanes that supply a column agree on its scale
+      const float sb = walk_pow2_scale(am, inv_b);
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) w[kb][i][e] *= sb;
+          walk_split4_f16(w[kb][i], bfh[kb][i], bfl[kb][i]);
+        }
+    }
     while (__ballot(j < je) != 0ull) {
       WPROF_T(ts0);
       e3 = entry(j + 3);          // step t + 3's entry, t + 2's permutation entries, t + 1's coordinates: in flight under this step
@@ -1298,14 +1375,25 @@ __device__ __forceinline__ void sorted_walk(const FusedArgs& F, const int gb, co
             di[u][0] = __uint_as_float(R.f[9][tt]);
           } else {
             // k_shade_bwd's blocked dv; 32-bit element offsets (byte offsets below 2^32: the launcher takes this path only below 2^30 elements)
-            const uint32_t od = ((m >> 5) * (uint32_t)(32 * 3 * C) + (uint32_t)(I * NL) * 512u + (m & 31u) * 16u + (uint32_t)c16) * 4u;
+            if constexpr (!RDV) {
+              const uint32_t od = ((m >> 5) * (uint32_t)(32 * 3 * C) + (uint32_t)(I * NL) * 512u + (m & 31u) * 16u + (uint32_t)c16) * 4u;
 #pragma unroll
-            for (int i = 0; i < NL; ++i) di[u][i] = at(Dv, od + 2048u * i);
+              for (int i = 0; i < NL; ++i) di[u][i] = at(Dv, od + 2048u * i);
+            }
             if constexpr (BAS) {
               const uint32_t of = (m * 32u + (uint32_t)c16) * 4u;
               fa[0][u] = at(F.dfe, of); fa[1][u] = at(F.dfe, of + 64u);
             }
           }
+        }
+        f32x4 ra[RDV ? 2 : 1];
+        bool rok = false;
+        if constexpr (RDV) {   // A operand: row c16 = sample (group c16 / 4, slot t0 + c16 % 4)
+          const int gq = c16 >> 2, tr = t0 + (c16 & 3);
+          rok = tr < __shfl(cnt, 16 * gq, 64);
+          const uint32_t mr = R.f[0][16 * gq + (rok ? tr : 0)];
+          const f32x4* pa = (const f32x4*)((const char*)F.dfe + (mr * 32u + 4u * (uint32_t)q) * 4u);
+          ra[0] = pa[0]; ra[1] = pa[4];   // slots 4 q .. 4 q + 3 of k-block 0 (dfe columns 0 .. 15) and of k-block 1 (columns 16 .. 31)
         }
         WPROF_T(ti1); WPROF_ADD(1, ti1 - ti0);
 #ifdef EGO_WALK_PROF
@@ -1321,6 +1409,39 @@ __device__ __forceinline__ void sorted_walk(const FusedArgs& F, const int gb, co
           for (int i = 0; i < NL; ++i)
 #pragma unroll
             for (int c = 0; c < 4; ++c) pt[i][c] = W.pt[i * 4 + c][lane];
+        }
+        if constexpr (RDV) {
+          float a8[2][4] = {{ra[0].x, ra[0].y, ra[0].z, ra[0].w}, {ra[1].x, ra[1].y, ra[1].z, ra[1].w}};
+          float am = 0.f;
+#pragma unroll
+          for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { a8[kb][e] = rok ? a8[kb][e] : 0.f; am = fmaxf(am, fabsf(a8[kb][e])); }
+          am = fmaxf(am, __shfl_xor(am, 16, 64));
+          am = fmaxf(am, __shfl_xor(am, 32, 64));   // the sample's (row c16's) largest slot gradient
+          float inv_a;
+          const float sa = walk_pow2_scale(am, inv_a);
+          walk_h4 ah[2], al[2];
+#pragma unroll
+          for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a8[kb][e] *= sa;
+            walk_split4_f16(a8[kb], ah[kb], al[kb]);
+          }
+          float inv_d[4];   // rows 4 q + r belong to this group's samples: their scales sit in the lanes that supplied those rows
+#pragma unroll
+          for (int r = 0; r < 4; ++r) inv_d[r] = __shfl(inv_a, 4 * q + r, 64) * inv_b;
+#pragma unroll
+          for (int i = 0; i < NL; ++i) {
+            f32x4 d4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+              d4 = __builtin_amdgcn_mfma_f32_16x16x16f16(ah[kb], bfh[kb][i], d4, 0, 0, 0);
+              d4 = __builtin_amdgcn_mfma_f32_16x16x16f16(al[kb], bfh[kb][i], d4, 0, 0, 0);
+              d4 = __builtin_amdgcn_mfma_f32_16x16x16f16(ah[kb], bfl[kb][i], d4, 0, 0, 0);
+            }
+            di[0][i] = d4.x * inv_d[0]; di[1][i] = d4.y * inv_d[1]; di[2][i] = d4.z * inv_d[2]; di[3][i] = d4.w * inv_d[3];
+          }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -1421,7 +1542,7 @@ __device__ __forceinline__ void sorted_walk(const FusedArgs& F, const int gb, co
 }
 
 // NW waves per workgroup, U samples in flight per 16-lane group
-template <int C, bool DENS, int NW, int U, bool BAS = false>
+template <int C, bool DENS, int NW, int U, bool BAS = false, bool RDV = false>
 __global__ __launch_bounds__(NW * 64) void k_sorted_walk(FusedArgs F) {
   extern __shared__ __attribute__((aligned(16))) unsigned char fused_lds[];
   typedef WalkLds<C / 16> WL;
@@ -1440,9 +1561,9 @@ __global__ __launch_bounds__(NW * 64) void k_sorted_walk(FusedArgs F) {
   const int gb = seg - seg_base(A, s);
   if (F.dbg >= 16 && (F.dbg >> 4) - 1 != seg) return;   // experiments: one segment alone (timing only)
   const bool do_line = F.do_line[s] != 0;
-  if (s == 0) sorted_walk<C, DENS, 0, NW, U, BAS>(F, gb, wg0, wg1, tab2, wl, do_line);
-  else if (s == 1) sorted_walk<C, DENS, 1, NW, U, BAS>(F, gb, wg0, wg1, tab2, wl, do_line);
-  else sorted_walk<C, DENS, 2, NW, U, BAS>(F, gb, wg0, wg1, tab2, wl, do_line);
+  if (s == 0) sorted_walk<C, DENS, 0, NW, U, BAS, RDV>(F, gb, wg0, wg1, tab2, wl, do_line);
+  else if (s == 1) sorted_walk<C, DENS, 1, NW, U, BAS, RDV>(F, gb, wg0, wg1, tab2, wl, do_line);
+  else sorted_walk<C, DENS, 2, NW, U, BAS, RDV>(F, gb, wg0, wg1, tab2, wl, do_line);
 }
 
 // d(basis) [2 grids][32 slots][144 = plane x 48 + channel] = the waves' partial products (k_sorted_walk<.., BAS>) added in workgroup / wave
@@ -1557,21 +1678,21 @@ int device_cus() {
   return cus;
 }
 
-template <int C, bool DENS, int NW, int U, bool BAS = false>
+template <int C, bool DENS, int NW, int U, bool BAS = false, bool RDV = false>
 int launch_walk_nw(const FusedArgs& F, int wg_total, int lds_bytes, hipStream_t st) {
   static std::atomic<int> attr_set{0};
   if (attr_set.load(std::memory_order_relaxed) < lds_bytes) {
-    if (const hipError_t e = hipFuncSetAttribute((const void*)k_sorted_walk<C, DENS, NW, U, BAS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes))
+    if (const hipError_t e = hipFuncSetAttribute((const void*)k_sorted_walk<C, DENS, NW, U, BAS, RDV>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes))
       return ego_fail((int)e, "k_sorted_walk: cannot reserve %d bytes of LDS: %s", lds_bytes, hipGetErrorString(e));
     attr_set.store(lds_bytes, std::memory_order_relaxed);
   }
-  k_sorted_walk<C, DENS, NW, U, BAS><<<wg_total, NW * 64, lds_bytes, st>>>(F);
+  k_sorted_walk<C, DENS, NW, U, BAS, RDV><<<wg_total, NW * 64, lds_bytes, st>>>(F);
   return ego_launch_status("k_sorted_walk");
 }
 
 template <int C, bool DENS>
 int launch_walk(SortedArgs a, const SortGeom& G, char* base, int64_t M, const float* dmax_ext, hipStream_t st, const float* dfe = nullptr,
-                float* gbasis = nullptr, int ldg = 0) {
+                float* gbasis = nullptr, int ldg = 0, const float* const* basis = nullptr) {
   static_assert(sizeof(WalkLds<C / 16>) == 12 * 64 * 4 + (C / 16) * 4 * 64 * 4, "walk_wave_bytes() mirrors WalkLds");
   const FusedPlan P = fused_plan(G, C);
   FxScale* fx = (FxScale*)(base + G.fx);
@@ -1591,7 +1712,7 @@ int launch_walk(SortedArgs a, const SortGeom& G, char* base, int64_t M, const fl
     }
     k_fx_absmax<<<dim3(FX_BLOCKS, 7), 256, 0, st>>>(ab);
     if (int e = ego_launch_status("k_fx_absmax")) return e;
-    k_fx_setup<<<1, 64, 0, st>>>(fx, ab.part, M, dmax_ext);
+    k_fx_setup<<<1, 64, 0, st>>>(fx, ab.part, M, dmax_ext, basis ? basis[0] : nullptr, basis ? basis[1] : nullptr);
     if (int e = ego_launch_status("k_fx_setup")) return e;
   }
   FusedArgs F{};
@@ -1619,7 +1740,10 @@ int launch_walk(SortedArgs a, const SortGeom& G, char* base, int64_t M, const fl
     F.dfe = dfe;
     F.bpart = (float*)(base + G.bpart);
     if constexpr (!DENS) {
-      if (int e = launch_walk_nw<C, DENS, WALK_NW_BAS, 4, true>(F, off, P.lds_bytes, st)) return e;
+      if (basis) {
+        F.basis[0] = basis[0]; F.basis[1] = basis[1];
+        if (int e = launch_walk_nw<C, DENS, WALK_NW_BAS, 4, true, true>(F, off, P.lds_bytes, st)) return e;
+      } else if (int e = launch_walk_nw<C, DENS, WALK_NW_BAS, 4, true>(F, off, P.lds_bytes, st)) return e;
       k_basis_reduce<WALK_NW_BAS><<<(2 * 32 * 144 + 3) / 4, 256, 0, st>>>(F, gbasis, ldg);
       if (int e = ego_launch_status("k_basis_reduce")) return e;
     }
@@ -1788,13 +1912,16 @@ int ego_scatter_app_sorted(const ego_scene* sc, const ego_vm_grad* gapp, const f
   if (int e = check_sizes(sc, N, S, "scatter_app_sorted")) return e;
   if (sc->app.n_comp != 48) return ego_fail(EGO_E_UNSUPPORTED, "scatter_app_sorted: n_comp %d (supported: 48)", sc->app.n_comp);
   if (N == 0) return zero_tables(sc->app, gapp, 48, (hipStream_t)stream, "scatter_app_sorted");
-  EGO_REQUIRE(coords && dv && workspace, "scatter_app_sorted: null argument");
+  EGO_REQUIRE(coords && workspace, "scatter_app_sorted: null argument");
+  const bool rdv = dv == nullptr;   // v16: dv re-derived in the walk from dfe and the scene's basis matrices
+  if (rdv) EGO_REQUIRE(dfe && gbasis && dv_absmax && sc->basis[0] && sc->basis[1],
+                       "scatter_app_sorted: dv == NULL asks the walk to re-derive it: dfe, gbasis, dv_absmax (= max |dfe|) and sc->basis are needed");
   const SortGeom G = make_geom(sc->app.res, N * (int64_t)S);
   if (workspace_bytes < G.total) return ego_fail(EGO_E_BADARG, "scatter_app_sorted: workspace too small");
   SortedArgs a{};
   if (int e = fill_args(sc->app, gapp, coords, dv, G, workspace, &a, "scatter_app_sorted")) return e;
   if (walk_wanted() && (N * (int64_t)S + 31) / 32 * 32 * 144 < (1ll << 30))   // (the walk addresses dv with 32-bit element offsets)
-    return launch_walk<48, false>(a, G, (char*)workspace, N * (int64_t)S, dv_absmax, (hipStream_t)stream, dfe, gbasis, ldg);
+    return launch_walk<48, false>(a, G, (char*)workspace, N * (int64_t)S, dv_absmax, (hipStream_t)stream, dfe, gbasis, ldg, rdv ? sc->basis : nullptr);
   if (dfe || gbasis) return ego_fail(EGO_E_UNSUPPORTED, "scatter_app_sorted: d(basis) rides along only in the walk form (EGO_SORTED_WALK=0 or a batch above 2^30 dv elements was asked for)");
   return launch_sorted<48, false>(a, G, (hipStream_t)stream);
 }

@@ -2162,7 +2162,7 @@ int ego_shade_backward(const ego_scene* sc, const float* train_packed, const flo
       if (const hipError_t me = hipMemsetAsync(dv_absmax, 0, 4, (hipStream_t)stream)) return ego_fail((int)me, "shade_backward: hipMemsetAsync failed: %s", hipGetErrorString(me));
     return EGO_OK;
   }
-  EGO_REQUIRE(sc && train_packed && coords && dc && rgb && fwd && fwd->fe && fwd->relu_bits && dh2 && dh1 && dh_scale && dfe && dv,
+  EGO_REQUIRE(sc && train_packed && coords && dc && rgb && fwd && fwd->fe && fwd->relu_bits && dh2 && dh1 && dh_scale && dfe && (dv || dv_absmax),
               "shade_backward: null argument");
   EGO_REQUIRE((((uintptr_t)dh2 | (uintptr_t)dh1 | (uintptr_t)fwd->relu_bits | (uintptr_t)dv) & 15) == 0,
               "shade_backward: dh2 / dh1 / dv / relu_bits must be 16-byte aligned");

@@ -42,6 +42,9 @@ SIDE_STREAM_SCATTER = __import__("os").environ.get("EGO_TRAIN_SIDE_STREAM", "1")
 # r06: d(basis) rides along in the sorted appearance scatter's walk (plane value x line value = v is in its registers), so the forward
 # dumps no v and the d(basis) weight-gradient pass is gone; EGO_TRAIN_WALK_BASIS=0 keeps the dump + ego_weight_grad form
 WALK_BASIS = __import__("os").environ.get("EGO_TRAIN_WALK_BASIS", "1") != "0"
+# r06: ... and re-derives dv = basis^T dfe there too (27 slot gradients in, 48 channels out per plane), so ego_shade_backward writes no dv
+# (576 B per sample) for the scatter to read back; EGO_TRAIN_WALK_DV=0 keeps the dv hand-over
+WALK_DV = __import__("os").environ.get("EGO_TRAIN_WALK_DV", "1") != "0"
 DUMP_X = __import__("os").environ.get("EGO_TRAIN_DUMP_X", "0") != "0"   # keep the forward's x dump (rounds 1-4) instead of re-deriving x for d(W1)
 _SIDE_STREAMS = {}
 
@@ -359,19 +362,20 @@ class RenderFunction(torch.autograd.Function):
         Mp = (M + 31) // 32 * 32
         # dh2 / dh1: scaled fp16 in the kernel's own operand order + one power of two per sample (include/egonerf_hip.h); dv: blocked fp32
         half = lambda *shape: torch.empty(*shape, device=dev, dtype=torch.float16)
-        dh2, dh1, dh_scale, dfe, dv = half(Mp, 128), half(Mp, 128), f(2, Mp), f(M, 32), f(Mp, 144)
-        dv_absmax = f(1)   # max |dv|, found by the backward while it holds the values: the sorted scatter's fixed-point unit comes from it
+        walk_basis = ws is not None and sv["v"] is None
+        walk_dv = walk_basis and WALK_DV
+        dh2, dh1, dh_scale, dfe, dv = half(Mp, 128), half(Mp, 128), f(2, Mp), f(M, 32), (None if walk_dv else f(Mp, 144))
+        dv_absmax = f(1)   # max |dv| (walk_dv: max |dfe|), found by the backward while it holds the values: the sorted scatter's fixed-point unit comes from it
         ds = _lib.ShadeDump(*(_lib.ptr(sv[k]) for k in ("x", "h1", "h2", "v", "relu_bits", "fe")))
         _chk(lib.ego_shade_backward(sc, tp.data_ptr(), sv["coords"].data_ptr(), dc.data_ptr(), sv["rgb"].data_ptr(), C.byref(ds),
-                                          dh2.data_ptr(), dh1.data_ptr(), dh_scale.data_ptr(), dfe.data_ptr(), dv.data_ptr(), dv_absmax.data_ptr(), N, S, st),
+                                          dh2.data_ptr(), dh1.data_ptr(), dh_scale.data_ptr(), dfe.data_ptr(), _lib.ptr(dv), dv_absmax.data_ptr(), N, S, st),
              "ego_shade_backward")
         ga = _grad_struct(g_app)
         # the product buffer exists (zero-filled, on the main stream) BEFORE the side stream is allowed to write its d(basis) block into it
         Gall = torch.zeros(352, _G_LD, device=dev)
-        walk_basis = ws is not None and sv["v"] is None
         if ws is not None:   # (this is the tuned-head path: sorted_app above)
             Gb_ptr = Gall[_G_ROWS["Gb"][0]:].data_ptr() if walk_basis else None
-            on_side(lambda s_: _chk(lib.ego_scatter_app_sorted(sc, C.byref(ga), sv["coords"].data_ptr(), dv.data_ptr(), dv_absmax.data_ptr(),
+            on_side(lambda s_: _chk(lib.ego_scatter_app_sorted(sc, C.byref(ga), sv["coords"].data_ptr(), _lib.ptr(dv), dv_absmax.data_ptr(),
                                                                dfe.data_ptr() if walk_basis else None, Gb_ptr, _G_LD if walk_basis else 0, N, S,
                                                                ws.data_ptr(), ws.numel(), s_), "ego_scatter_app_sorted"))
         else:

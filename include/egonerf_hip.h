@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define EGO_ABI_VERSION 15
+#define EGO_ABI_VERSION 16
 
 enum { EGO_PREC_F16X3 = 0, EGO_PREC_F32 = 1, EGO_PREC_F16F8 = 2, EGO_PREC_F16F6 = 3 };
 /* ego_scene.head: the appearance head TensorBase.init_render_func selected (models/tensorBase.py:186-200) */
@@ -378,6 +378,12 @@ int ego_scatter_app_sorted(const ego_scene* sc, const ego_vm_grad* gapp, const f
  * ego_shade_backward's [M][32] (the sample's own grid's slots); gbasis [64][ldg >= 144] receives row 32 g + slot, column plane x 48 +
  * channel (reference channel order), written, not accumulated; bf16 hi / lo split MFMA (three terms, ~16 significand bits per operand), per-wave partial products added
  * in a fixed order (bit-reproducible).  Only in the walk form (EGO_E_UNSUPPORTED with EGO_SORTED_WALK=0). */
+/* dv == NULL (v16; needs dfe, gbasis, dv_absmax and sc->basis): the walk re-derives dv = basis_g^T dfe for its own plane's 48 channels (the
+ * 27 feature-slot gradients of a sample are 128 B where its dv is 576 B) in ego_shade_backward's own arithmetic for that product (operands scaled
+ * by a power of two per sample / per channel, fp16 hi + lo, three MFMA terms, fp32 accumulation), so ego_shade_backward
+ * need not write dv at all (pass it dv = NULL: its dv_absmax then carries max |dfe|, which is what this call expects in that case - the
+ * fixed-point unit comes from max |dfe| x the largest column sum of |basis|).  A sample's dv differs from ego_shade_backward's by the
+ * rounding of that arithmetic (~2^-21 per product; the fp32 summation order over the 27 slots differs). */
 /* v15: ONE pass over dfeat / dv.  The gradient of a plane and of the line it is multiplied with (the table of the axis that is not in the
  * plane) come out of the same walk over the plane's cells: a cell's samples share the four plane texels, so the line's contribution of a
  * sample is four multiply-adds away - but it lands in an arbitrary line texel.  Those sums are therefore taken in 64-bit FIXED POINT

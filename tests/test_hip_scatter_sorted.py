@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from egonerf_amd import _lib, synth
+from egonerf_amd import _lib, synth, train
 from egonerf_amd.train import _grad_struct, table_params
 from tests.helpers import make_model
 
@@ -359,3 +359,68 @@ def test_basis_gradient_rides_along_in_the_appearance_scatter():
     scale = float(ref.abs().max())
     err = float((got - ref).abs().max()) / scale
     assert err <= 2e-5, err
+
+
+def test_walk_rederives_dv_from_the_feature_slot_gradients():
+    """ABI v16: ego_scatter_app_sorted(dv = NULL) - the walk takes dv = basis_g^T dfe itself (scaled fp16 hi / lo three-term MFMA on the 27 slot
+    gradients of the sample's own grid: ego_shade_backward's arithmetic for that product) instead of reading ego_shade_backward's 576-byte dv row.  Held against the same call fed a float64
+    dv = dfe @ basis_g (rounded to fp32): tables within 2e-6 of the largest texel gradient (two ~22-bit operands), the d(basis) by-product
+    unchanged at that order, the same bits twice, NaN-poisoning through max |dfe|, and the argument checks."""
+    cfg = synth.SceneConfig(n_voxel=27e6)
+    weights = synth.make_weights(cfg, seed=22)
+    model = make_model(cfg, weights, DEV)
+    N, S = 512, 96
+    M = N * S
+    g = torch.Generator().manual_seed(18)
+    coords = (torch.rand(N, S, 4, generator=g) * 2 - 1) * 1.05
+    coords[..., 3] = (torch.rand(N, S, generator=g) > 0.4).float()
+    fmap = train._layout(2, 32, "cpu")                       # dfe column -> feature (-1: padding, zero in ego_shade_backward's output)
+    dfe = torch.randn(M, 32, generator=g) * torch.rand(M, 1, generator=g) * 1e-3
+    dfe[:, fmap < 0] = 0.0
+    basis = [model.basis_mat_yin.weight.detach().double().cpu(), model.basis_mat_yang.weight.detach().double().cpu()]   # [27][144] each
+    sel = fmap >= 0
+    dv_ref = torch.zeros(M, 144, dtype=torch.float64)
+    yang = coords.reshape(M, 4)[:, 3] != 0
+    for gi, rows in enumerate((~yang, yang)):
+        dv_ref[rows] = dfe[rows][:, sel].double() @ basis[gi][fmap[sel]]
+    dv_ref = dv_ref.float()
+    lib, st = _lib.load(), _lib.stream_handle()
+    sc = model.scene(training=True)
+    cd, dvd, dfed = coords.to(DEV).contiguous(), _blocked_dv(dv_ref, M).to(DEV), dfe.to(DEV).contiguous()
+    nbytes = lib.ego_scatter_sorted_workspace_bytes(sc, N, S)
+    ws = torch.empty(nbytes, device=DEV, dtype=torch.uint8)
+    _lib.check(lib.ego_scatter_sort(sc, cd.data_ptr(), N, S, ws.data_ptr(), nbytes, st), "scatter_sort")
+    dfe_max = dfe.abs().max().reshape(1).to(DEV)
+    dv_max = dv_ref.abs().max().reshape(1).to(DEV)
+
+    def run(dv, amax, dfe_t=dfed):
+        ga = [torch.full_like(p, float("nan")) for p in table_params(model, "app")]
+        gb = torch.full((64, 160), float("nan"), device=DEV)
+        sa = _grad_struct(ga)
+        _lib.check(lib.ego_scatter_app_sorted(sc, C.byref(sa), cd.data_ptr(), _lib.ptr(dv), _lib.ptr(amax), dfe_t.data_ptr(), gb.data_ptr(), 160, N, S,
+                                              ws.data_ptr(), nbytes, st), "app_sorted")
+        torch.cuda.synchronize()
+        return ga, gb
+
+    want, want_gb = run(dvd, dv_max)
+    got, got_gb = run(None, dfe_max)
+    again, again_gb = run(None, dfe_max)
+    for k, (a, b) in enumerate(zip(got, again)):
+        assert torch.equal(a, b), ("run to run", k)
+    assert torch.equal(got_gb[:, :144], again_gb[:, :144])
+    for k, (a, b) in enumerate(zip(got, want)):
+        assert bool(torch.isfinite(a).all()), k
+        err = float((a - b).abs().max()) / float(b.abs().max())
+        assert err <= 2e-6, ("re-derived dv vs dv handed over", k, err)
+    assert float((got_gb[:, :144] - want_gb[:, :144]).abs().max()) <= 1e-6 * float(want_gb[:, :144].abs().max())
+    # a non-finite feature gradient arrives as max |dfe| = NaN bits: every line texel is NaN (no silent integer overflow), as with dv handed over
+    bad = dfed.clone(); bad[123, 3] = float("nan")
+    nan_max = torch.full((1,), float("nan"), device=DEV)
+    poisoned, _ = run(None, nan_max, bad)
+    for k in (3, 4, 5, 9, 10, 11):
+        assert bool(torch.isnan(poisoned[k]).all()), k
+    # dv == NULL needs all of dfe, gbasis and max |dfe|
+    ga = [torch.zeros_like(p) for p in table_params(model, "app")]
+    sa = _grad_struct(ga)
+    assert lib.ego_scatter_app_sorted(sc, C.byref(sa), cd.data_ptr(), None, None, dfed.data_ptr(), got_gb.data_ptr(), 160, N, S, ws.data_ptr(), nbytes, st) != 0
+    assert lib.ego_scatter_app_sorted(sc, C.byref(sa), cd.data_ptr(), None, dfe_max.data_ptr(), None, None, 0, N, S, ws.data_ptr(), nbytes, st) != 0
