@@ -1201,6 +1201,9 @@ __device__ __forceinline__ void sorted_walk(const FusedArgs& F, const int gb, co
   const int lbase = max(blk * (int)A.bs[S_] - 1, 0), lsize = min((blk + 1) * (int)A.bs[S_] - 1, NLn - 1) - lbase + 1;
   const int entries = do_line ? lsize * C : 0;
   for (int i = threadIdx.x; i < entries; i += NW * 64) tab[i] = 0ull;
+  // a group that never starts a cell (an empty share) multiplies these texels by its zero weights: they must be finite, not what LDS held
+#pragma unroll
+  for (int i = 0; i < NL * 4; ++i) W.pt[i][lane] = 0.f;
   const uint32_t K = A.K[S_], Kh = A.kc[S_], kbase = (uint32_t)gb * Kh;
   const uint32_t T0 = A.costsum[S_][kbase], T1 = A.costsum[S_][kbase + Kh], Tall = A.stepsum[S_][K];
   // this group's steps: an equal share of the segment's COST, cut at the cell boundaries at or behind the nominal cuts
@@ -1241,7 +1244,7 @@ __device__ __forceinline__ void sorted_walk(const FusedArgs& F, const int gb, co
   auto at = [](const float* base, uint32_t byte_off) -> float { return *(const float*)((const char*)base + byte_off); };
   const int nmin1 = A.F.res[sort_minor(S_)] + 1;
   const double magic = F.fx->magic[I];
-  const long long magic_bits = __double_as_longlong(magic);
+  const uint32_t magic_hi = (uint32_t)((unsigned long long)__double_as_longlong(magic) >> 32);
   const uint32_t* __restrict__ perm = A.perm[S_];
   const f32x4* __restrict__ coords4 = (const f32x4*)A.coords;
   const uint4* __restrict__ steps = A.steps[S_];
@@ -1334,20 +1337,23 @@ __device__ __forceinline__ void sorted_walk(const FusedArgs& F, const int gb, co
         const float ax[3] = {cc0.x, cc0.y, cc0.z};
         const Lin1 X = lin_setup(ax[AX], Wd), Y = lin_setup(ax[AY], H), Ln = lin_setup(ax[AL], NLn);
         WaveRec& R = W.rec;
+        // a slot past the step's samples repeats the last sample (pos()) with ALL WEIGHTS ZERO: its plane value, line value and every
+        // product with them are exact zeros, so stage 2 masks nothing per channel (its d / dv is the repeated sample's: finite)
+        const bool live = c16 < cnt;
         R.f[0][lane] = m0;
-        R.f[1][lane] = __float_as_uint(__fmul_rn(Y.w0, X.w0)); R.f[2][lane] = __float_as_uint(__fmul_rn(Y.w0, X.w1));
-        R.f[3][lane] = __float_as_uint(__fmul_rn(Y.w1, X.w0)); R.f[4][lane] = __float_as_uint(__fmul_rn(Y.w1, X.w1));
+        R.f[1][lane] = live ? __float_as_uint(__fmul_rn(Y.w0, X.w0)) : 0u; R.f[2][lane] = live ? __float_as_uint(__fmul_rn(Y.w0, X.w1)) : 0u;
+        R.f[3][lane] = live ? __float_as_uint(__fmul_rn(Y.w1, X.w0)) : 0u; R.f[4][lane] = live ? __float_as_uint(__fmul_rn(Y.w1, X.w1)) : 0u;
         // per tap: the byte offset of its texel row in the line table, and of its row in the block's LDS window (a tap outside the
         // window has weight 0) - once per sample here instead of once per channel lane in stage 2
         R.f[5][lane] = (uint32_t)(Ln.i0 * C) * 4u; R.f[6][lane] = (uint32_t)(Ln.i1 * C) * 4u;
-        R.f[7][lane] = __float_as_uint(Ln.w0); R.f[8][lane] = __float_as_uint(Ln.w1);
-        if (DENS) R.f[9][lane] = __float_as_uint(d0);
+        R.f[7][lane] = live ? __float_as_uint(Ln.w0) : 0u; R.f[8][lane] = live ? __float_as_uint(Ln.w1) : 0u;
+        if (DENS) R.f[9][lane] = live ? __float_as_uint(d0) : 0u;
         R.f[10][lane] = (uint32_t)(min(max(Ln.i0 - lbase, 0), lsize - 1) * C) * 8u;
         R.f[11][lane] = (uint32_t)(min(max(Ln.i1 - lbase, 0), lsize - 1) * C) * 8u;
       }
       wave_sync();
       int cnt_max = max(cnt, __shfl_xor(cnt, 16, 64));
-      cnt_max = max(cnt_max, __shfl_xor(cnt_max, 32, 64));
+      cnt_max = __builtin_amdgcn_readfirstlane(max(cnt_max, __shfl_xor(cnt_max, 32, 64)));
       float pt[NL][4];
       WPROF_T(ts1); WPROF_ADD(0, ts1 - ts0); WPROF_ADD(5, 1);
       for (int t0 = 0; t0 < cnt_max; t0 += U) {   // stage 2: lane = channel of group q's sample t
@@ -1360,9 +1366,9 @@ __device__ __forceinline__ void sorted_walk(const FusedArgs& F, const int gb, co
         bool ok[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-          const int t = t0 + u;
+          const int t = t0 + u;   // (<= 15: t0 is a multiple of U = 4 below cnt_max <= 16)
           ok[u] = t < cnt;
-          const int tt = 16 * q + (ok[u] ? t : 0);
+          const int tt = 16 * q + t;
           const uint32_t m = R.f[0][tt];
 #pragma unroll
           for (int c = 0; c < 4; ++c) w4[u][c] = __uint_as_float(R.f[1 + c][tt]);
@@ -1390,8 +1396,8 @@ __device__ __forceinline__ void sorted_walk(const FusedArgs& F, const int gb, co
         bool rok = false;
         if constexpr (RDV) {   // A operand: row c16 = sample (group c16 / 4, slot t0 + c16 % 4)
           const int gq = c16 >> 2, tr = t0 + (c16 & 3);
-          rok = tr < __shfl(cnt, 16 * gq, 64);
-          const uint32_t mr = R.f[0][16 * gq + (rok ? tr : 0)];
+          rok = true;   // (a slot past the step's samples: the repeated sample's row, multiplied by zero weights below)
+          const uint32_t mr = R.f[0][16 * gq + tr];
           const f32x4* pa = (const f32x4*)((const char*)F.dfe + (mr * 32u + 4u * (uint32_t)q) * 4u);
           ra[0] = pa[0]; ra[1] = pa[4];   // slots 4 q .. 4 q + 3 of k-block 0 (dfe columns 0 .. 15) and of k-block 1 (columns 16 .. 31)
         }
@@ -1454,16 +1460,16 @@ __device__ __forceinline__ void sorted_walk(const FusedArgs& F, const int gb, co
           if (DENS) {
             // relu per plane (EgoNeRF.py:340,346): the gradient passes where this plane's sum over channels is positive
             const float dot = row_sum16(pv[0] * lv[0]);
-            dd[0] = (ok[u] && dot > 0.f) ? di[u][0] : 0.f;
+            dd[0] = dot > 0.f ? di[u][0] : 0.f;
           } else {
 #pragma unroll
-            for (int i = 0; i < NL; ++i) dd[i] = ok[u] ? di[u][i] : 0.f;
+            for (int i = 0; i < NL; ++i) dd[i] = di[u][i];
           }
 #pragma unroll
           for (int i = 0; i < NL; ++i) {
             const float gp = dd[i] * lv[i];
             acc[i][0] += gp * w4[u][0]; acc[i][1] += gp * w4[u][1]; acc[i][2] += gp * w4[u][2]; acc[i][3] += gp * w4[u][3];
-            if constexpr (BAS) vv[i][u] = ok[u] ? __fmul_rn(pv[i], lv[i]) : 0.f;
+            if constexpr (BAS) vv[i][u] = __fmul_rn(pv[i], lv[i]);
           }
           if (do_line) {
             const double lw0 = (double)lw[u][0], lw1 = (double)lw[u][1];
@@ -1472,8 +1478,12 @@ __device__ __forceinline__ void sorted_walk(const FusedArgs& F, const int gb, co
 #pragma unroll
             for (int i = 0; i < NL; ++i) {
               const double gl = (double)__fmul_rn(dd[i], pv[i]);
-              const long long q0 = __double_as_longlong(__fma_rn(gl, lw0, magic)) - magic_bits;
-              const long long q1 = __double_as_longlong(__fma_rn(gl, lw1, magic)) - magic_bits;
+              // bits(x + magic) - bits(magic); magic = 1.5 x 2^(52 + k) has no bit in its low dword: one 32-bit subtraction
+              const unsigned long long b0 = (unsigned long long)__double_as_longlong(__fma_rn(gl, lw0, magic));
+              const unsigned long long b1 = (unsigned long long)__double_as_longlong(__fma_rn(gl, lw1, magic));
+              uint32_t h0 = (uint32_t)(b0 >> 32) - magic_hi, h1 = (uint32_t)(b1 >> 32) - magic_hi;
+              asm("" : "+v"(h0), "+v"(h1));   // (keeps the compiler from widening this back into a 64-bit subtraction with a zero low half)
+              const unsigned long long q0 = ((unsigned long long)h0 << 32) | (uint32_t)b0, q1 = ((unsigned long long)h1 << 32) | (uint32_t)b1;
               if (ok[u]) {
                 __hip_atomic_fetch_add(t0p + 16 * i, (unsigned long long)q0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 __hip_atomic_fetch_add(t1p + 16 * i, (unsigned long long)q1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1556,7 +1566,10 @@ __global__ __launch_bounds__(NW * 64) void k_sorted_walk(FusedArgs F) {
   if ((int)blockIdx.x >= D->off[nseg]) return;
   int seg = 0;
   for (int i = 1; i < nseg; ++i) seg += (int)blockIdx.x >= D->off[i] ? 1 : 0;   // (empty segments own no workgroup: off[i] == off[i + 1])
-  const int wg0 = D->off[seg], wg1 = D->off[seg + 1];
+  // read from LDS, so the compiler takes them for per-lane values: as scalars the table bases stay in SGPRs (global_load with a scalar base
+  // and an immediate offset instead of a 64-bit VALU address sum per load) and the loops over steps / iterations branch on scalars
+  seg = __builtin_amdgcn_readfirstlane(seg);
+  const int wg0 = __builtin_amdgcn_readfirstlane(D->off[seg]), wg1 = __builtin_amdgcn_readfirstlane(D->off[seg + 1]);
   const int s = seg >= seg_base(A, 2) ? 2 : seg >= seg_base(A, 1) ? 1 : 0;
   const int gb = seg - seg_base(A, s);
   if (F.dbg >= 16 && (F.dbg >> 4) - 1 != seg) return;   // experiments: one segment alone (timing only)

