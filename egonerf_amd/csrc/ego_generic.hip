@@ -77,11 +77,39 @@ __global__ void k_generic_pack(const float* __restrict__ w1, const float* __rest
 }
 
 enum { G_SHADE = 0, G_APP = 1, G_MLP = 2 };
+typedef __attribute__((address_space(4))) float gen_cfloat;
+
+// torch.sin / torch.cos of the positional encodings (tensorBase.py:10-19), both from ONE argument reduction, branch-free: the reduction
+// by pi/2 runs in float64 (x - k pi/2 with a two-term pi/2: exact to the last bit of the float32 remainder while |x| < ~1e15 - libm's
+// float32 route needs a Payne-Hanek slow path for that, and sinf + cosf inlined 2 x 32 times per frequency were two thirds of this
+// kernel's instructions), the Cephes minimax polynomials of sincos_f32 (ego_device.h) on [-pi/4, pi/4] follow in float32: ~1 ulp.
+__device__ __forceinline__ void gen_sincos(float x, float& s_out, float& c_out) {
+  const double xd = (double)x;
+  const double kd = rint(xd * 0.63661977236758134308);
+  double rd = fma(kd, -1.57079632679489655800e+00, xd);      // double(pi/2)
+  rd = fma(kd, -6.12323399573676603587e-17, rd);             // pi/2 - double(pi/2)
+  const float r = (float)rd, r2 = r * r;
+  const float ps = fmaf(fmaf(fmaf(-1.9515295891e-4f, r2, 8.3321608736e-3f), r2, -1.6666654611e-1f), r2 * r, r);
+  const float pc = fmaf(fmaf(fmaf(2.443315711809948e-5f, r2, -1.388731625493765e-3f), r2, 4.166664568298827e-2f), r2 * r2, fmaf(-0.5f, r2, 1.0f));
+  const int q = (int)(kd - 4.0 * floor(kd * 0.25));          // k mod 4 in 0 .. 3, whatever the size of k
+  const float s = (q & 1) ? pc : ps, c = (q & 1) ? ps : pc;
+  s_out = (q & 2) ? -s : s;
+  c_out = ((q + 1) & 2) ? -c : c;
+}
 
 // one wave = 64 samples (lane = sample); 2 waves per workgroup; per wave an LDS slab [HID][64] that first stages chunks of the MLP
 // input and then holds relu(h1)
 template <int HID, int MODE, bool DUMP = false>
 __global__ __launch_bounds__(128) void k_shade_generic(GenShadeArgs A) {
+  // the weight blob through the CONSTANT address space: the dumping variant's stores may alias a plain global pointer as far as the
+  // compiler can tell, the uniform weight rows then come through VECTOR loads (128 VGPRs per row) instead of scalar ones and the kernel
+  // spills 434 registers (restrict-qualified locals did not convince it); nothing writes the blob while a kernel reads it
+  const gen_cfloat* gp = (const gen_cfloat*)A.gp;
+  float* dump_x = A.dump_x;
+  float* dump_h1 = A.dump_h1;
+  float* dump_h2 = A.dump_h2;
+  float* dump_v = A.dump_v;
+  float* outp = A.out;
   __shared__ float slab[2][HID][64];
   const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   float (*sl)[64] = slab[wv];
@@ -140,12 +168,12 @@ __global__ __launch_bounds__(128) void k_shade_generic(GenShadeArgs A) {
                            *(const f32x4*)(p11 + c4) * w11;
           const f32x4 lv = *(const f32x4*)(l0 + c4) * Ln.w0 + *(const f32x4*)(l1 + c4) * Ln.w1;
           const f32x4 pr = pv * lv;
-          if (DUMP && valid) *(f32x4*)(A.dump_v + m * A.ldv + i * C + c4) = pr;
+          if (DUMP && valid) *(f32x4*)(dump_v + m * A.ldv + i * C + c4) = pr;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             // basisT [g][col][32]: uniform addresses -> scalar loads of both grids' rows, selected per lane
-            const float* b0 = A.gp + L.basis + (int64_t)(i * C + c4 + e) * 32;
-            const float* b1 = b0 + (int64_t)3 * C * 32;
+            const gen_cfloat* b0 = gp + L.basis + (int64_t)(i * C + c4 + e) * 32;
+            const gen_cfloat* b1 = b0 + (int64_t)3 * C * 32;
 #pragma unroll
             for (int f = 0; f < 32; ++f)
               if (f < A.app_dim) feat[f] = fmaf(g ? b1[f] : b0[f], pr[e], feat[f]);
@@ -157,13 +185,13 @@ __global__ __launch_bounds__(128) void k_shade_generic(GenShadeArgs A) {
       if (valid) {
 #pragma unroll
         for (int f = 0; f < 32; ++f)
-          if (f < A.app_dim) A.out[m * A.app_dim + f] = feat[f];
+          if (f < A.app_dim) outp[m * A.app_dim + f] = feat[f];
       }
       continue;
     }
     if (A.head == EGO_HEAD_RGB) {   // RGBRender (tensorBase.py:37-39): the colour IS the (3-channel) appearance feature; no sigmoid, no clamp
       if (valid) {
-        float* op = A.out + m * 3;
+        float* op = outp + m * 3;
         op[0] = feat[0]; op[1] = feat[1]; op[2] = feat[2];
       }
       continue;
@@ -171,16 +199,16 @@ __global__ __launch_bounds__(128) void k_shade_generic(GenShadeArgs A) {
     // ---- row G: mlp_in = [features, viewdirs, PE(features), PE(viewdirs)] (tensorBase.py:68-75) -> Linear relu Linear relu Linear ----
     float h[HID];
     {
-      const float* b1 = A.gp + L.b1;
+      const gen_cfloat* b1 = gp + L.b1;
 #pragma unroll
       for (int j = 0; j < HID; ++j) h[j] = b1[j];
     }
     // consume n staged inputs: input t of the chunk sits in sl[t][lane] and multiplies row (row0 + t * stride) of W1^T
-    auto consume = [&](int n, int row0, int stride) {
+    auto consume = [&](int n, int row0, int stride, int off = 0) {
       for (int tt = 0; tt < n; ++tt) {
-        const float xk = sl[tt][lane];
-        if (DUMP && valid) A.dump_x[m * A.ldx + row0 + tt * stride] = xk;
-        const float* wrow = A.gp + L.w1t + (int64_t)(row0 + tt * stride) * HID;   // uniform: scalar loads
+        const float xk = sl[off + tt][lane];
+        if (DUMP && valid) dump_x[m * A.ldx + row0 + tt * stride] = xk;
+        const gen_cfloat* wrow = gp + L.w1t + (int64_t)(row0 + tt * stride) * HID;   // uniform: scalar loads
 #pragma unroll
         for (int j = 0; j < HID; ++j) h[j] = fmaf(wrow[j], xk, h[j]);
       }
@@ -197,53 +225,59 @@ __global__ __launch_bounds__(128) void k_shade_generic(GenShadeArgs A) {
       const int base_s = D + 3, base_c = base_s + D * A.fea_pe;
       float fr = 1.f;
       for (int q = 0; q < A.fea_pe; ++q, fr *= 2.f) {
+        // sine and cosine of one argument from ONE reduction (gen_sincos), the cosines parked in rows D .. 2 D - 1 of the slab
+        // (2 D <= 64 <= HID): libm's sinf + cosf inlined 2 x 32 times per frequency were 2/3 of this kernel's instructions
 #pragma unroll
         for (int f = 0; f < 32; ++f)
-          if (f < D) sl[f][lane] = sinf(__fmul_rn(feat[f], fr));
+          if (f < D) {
+            float sv, cv;
+            gen_sincos(__fmul_rn(feat[f], fr), sv, cv);
+            sl[f][lane] = sv; sl[D + f][lane] = cv;
+          }
         consume(D, base_s + q, A.fea_pe);
-#pragma unroll
-        for (int f = 0; f < 32; ++f)
-          if (f < D) sl[f][lane] = cosf(__fmul_rn(feat[f], fr));
-        consume(D, base_c + q, A.fea_pe);
+        consume(D, base_c + q, A.fea_pe, D);
       }
       const int vbase_s = base_c + D * A.fea_pe, vbase_c = vbase_s + 3 * A.view_pe;
       fr = 1.f;
       for (int q = 0; q < A.view_pe; ++q, fr *= 2.f) {
 #pragma unroll
-        for (int d = 0; d < 3; ++d) { sl[d][lane] = sinf(__fmul_rn(vd[d], fr)); sl[3 + d][lane] = cosf(__fmul_rn(vd[d], fr)); }
+        for (int d = 0; d < 3; ++d) {
+          float sv, cv;
+          gen_sincos(__fmul_rn(vd[d], fr), sv, cv);
+          sl[d][lane] = sv; sl[3 + d][lane] = cv;
+        }
         consume(3, vbase_s + q, A.view_pe);
-        for (int d = 0; d < 3; ++d) sl[d][lane] = sl[3 + d][lane];
-        consume(3, vbase_c + q, A.view_pe);
+        consume(3, vbase_c + q, A.view_pe, 3);
       }
     }
     // relu(h1) -> LDS, layer 2 with the hidden index as the (runtime) loop
 #pragma unroll
     for (int j = 0; j < HID; ++j) {
       sl[j][lane] = fmaxf(h[j], 0.f);
-      if (DUMP && valid) A.dump_h1[m * A.ldh + j] = fmaxf(h[j], 0.f);
+      if (DUMP && valid) dump_h1[m * A.ldh + j] = fmaxf(h[j], 0.f);
     }
     {
-      const float* b2 = A.gp + L.b2;
+      const gen_cfloat* b2 = gp + L.b2;
 #pragma unroll
       for (int j = 0; j < HID; ++j) h[j] = b2[j];
       for (int k = 0; k < HID; ++k) {
         const float xk = sl[k][lane];
-        const float* wrow = A.gp + L.w2t + (int64_t)k * HID;
+        const gen_cfloat* wrow = gp + L.w2t + (int64_t)k * HID;
 #pragma unroll
         for (int j = 0; j < HID; ++j) h[j] = fmaf(wrow[j], xk, h[j]);
       }
     }
-    const float* w3 = A.gp + L.w3;
-    const float* b3 = A.gp + L.b3;
+    const gen_cfloat* w3 = gp + L.w3;
+    const gen_cfloat* b3 = gp + L.b3;
     float o[3] = {b3[0], b3[1], b3[2]};
 #pragma unroll
     for (int j = 0; j < HID; ++j) {
       const float hv = fmaxf(h[j], 0.f);
-      if (DUMP && valid) A.dump_h2[m * A.ldh + j] = hv;
+      if (DUMP && valid) dump_h2[m * A.ldh + j] = hv;
       o[0] = fmaf(w3[j], hv, o[0]); o[1] = fmaf(w3[HID + j], hv, o[1]); o[2] = fmaf(w3[2 * HID + j], hv, o[2]);
     }
     if (valid) {
-      float* op = A.out + m * 3;
+      float* op = outp + m * 3;
       op[0] = sigmoidf(o[0]); op[1] = sigmoidf(o[1]); op[2] = sigmoidf(o[2]);
     }
   }
@@ -382,58 +416,72 @@ struct GenScatterArgs {
   int32_t C, ldd;
 };
 
-__global__ void k_scatter_generic(GenScatterArgs A) {
+// sum over the 16 lanes of a row on the DPP path (every lane gets the total)
+__device__ __forceinline__ float gen_row_sum16(float v) {
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xb1, 0xf, 0xf, false));    // quad_perm [1,0,3,2]
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4e, 0xf, 0xf, false));    // quad_perm [2,3,0,1]
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xf, 0xf, false));   // row_half_mirror
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xf, 0xf, false));   // row_mirror
+  return v;
+}
+
+// A 16-lane group per (sample, plane), lane = channel (16 at a time): every gather and every atomic of a group is one 64-byte line, as in
+// the tuned k_vm_scatter (ego_train.inc) but without its run merging.  (Rounds 2-5 had a THREAD per (sample, plane): 64 lanes = 64 texels
+// = 64 lines per atomic instruction, 105 ms for the shipped tables at 8192 x 256 - 71 % of a training step of the other heads.)
+__global__ __launch_bounds__(256) void k_scatter_generic(GenScatterArgs A) {
 #pragma clang fp contract(fast)
-  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= A.M * 3) return;
-  const int64_t m = idx / 3;
-  const int i = (int)(idx % 3), C = A.C;
+  const int c16 = threadIdx.x & 15, C = A.C;
   const bool dens = A.ldd == 0;
-  float ds = 0.f;
-  if (dens) {
-    ds = A.d[m];
-    if (ds == 0.f) return;
-  }
-  const f32x4 cc = ((const f32x4*)A.coords)[m];
-  const int g = cc.w != 0.f;
-  const VMTaps t = vm_setup(cc.x, cc.y, cc.z, A.F.res);
-  const Lin1 X = t.ax[i == 2 ? 1 : 0], Y = t.ax[i == 0 ? 1 : 2], Ln = t.ax[2 - i];
-  const int W = A.F.res[i == 2 ? 1 : 0];
-  const float* P = g ? A.F.plane[1][i] : A.F.plane[0][i];
-  const float* Lp = g ? A.F.line[1][i] : A.F.line[0][i];
-  float* GP = g ? A.gplane[1][i] : A.gplane[0][i];
-  float* GL = g ? A.gline[1][i] : A.gline[0][i];
-  const int64_t o00 = ((int64_t)Y.i0 * W + X.i0) * C, o01 = ((int64_t)Y.i0 * W + X.i1) * C, o10 = ((int64_t)Y.i1 * W + X.i0) * C,
-                o11 = ((int64_t)Y.i1 * W + X.i1) * C, ol0 = (int64_t)Ln.i0 * C, ol1 = (int64_t)Ln.i1 * C;
-  const float w00 = __fmul_rn(Y.w0, X.w0), w01 = __fmul_rn(Y.w0, X.w1), w10 = __fmul_rn(Y.w1, X.w0), w11 = __fmul_rn(Y.w1, X.w1);
-  if (dens) {
-    float dot = 0.f;
-    for (int c4 = 0; c4 < C; c4 += 4) {
-      const f32x4 pv = *(const f32x4*)(P + o00 + c4) * w00 + *(const f32x4*)(P + o01 + c4) * w01 + *(const f32x4*)(P + o10 + c4) * w10 +
-                       *(const f32x4*)(P + o11 + c4) * w11;
-      const f32x4 lv = *(const f32x4*)(Lp + ol0 + c4) * Ln.w0 + *(const f32x4*)(Lp + ol1 + c4) * Ln.w1;
-      const f32x4 mm = pv * lv;
-      dot += (mm.x + mm.y) + (mm.z + mm.w);
+  const int64_t n_items = A.M * 3, n_groups = (int64_t)gridDim.x * 16;
+  for (int64_t item = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 4; item < n_items; item += n_groups) {
+    const int64_t m = item / 3;
+    const int i = (int)(item - m * 3);
+    float ds = 0.f;
+    if (dens) {
+      ds = A.d[m];
+      if (ds == 0.f) continue;
     }
-    if (!(dot > 0.f)) return;
-  }
-  for (int c4 = 0; c4 < C; c4 += 4) {
-    const f32x4 pv = *(const f32x4*)(P + o00 + c4) * w00 + *(const f32x4*)(P + o01 + c4) * w01 + *(const f32x4*)(P + o10 + c4) * w10 +
-                     *(const f32x4*)(P + o11 + c4) * w11;
-    const f32x4 lv = *(const f32x4*)(Lp + ol0 + c4) * Ln.w0 + *(const f32x4*)(Lp + ol1 + c4) * Ln.w1;
-    const f32x4 di = dens ? f32x4{ds, ds, ds, ds} : *(const f32x4*)(A.d + m * A.ldd + i * C + c4);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const float gp = di[e] * lv[e], gl = di[e] * pv[e];
+    const f32x4 cc = ((const f32x4*)A.coords)[m];
+    const int g = cc.w != 0.f;
+    const VMTaps t = vm_setup(cc.x, cc.y, cc.z, A.F.res);
+    const Lin1 X = t.ax[i == 2 ? 1 : 0], Y = t.ax[i == 0 ? 1 : 2], Ln = t.ax[2 - i];
+    const int W = A.F.res[i == 2 ? 1 : 0];
+    const float* P = g ? A.F.plane[1][i] : A.F.plane[0][i];
+    const float* Lp = g ? A.F.line[1][i] : A.F.line[0][i];
+    float* GP = g ? A.gplane[1][i] : A.gplane[0][i];
+    float* GL = g ? A.gline[1][i] : A.gline[0][i];
+    const int64_t o00 = ((int64_t)Y.i0 * W + X.i0) * C, o01 = ((int64_t)Y.i0 * W + X.i1) * C, o10 = ((int64_t)Y.i1 * W + X.i0) * C,
+                  o11 = ((int64_t)Y.i1 * W + X.i1) * C, ol0 = (int64_t)Ln.i0 * C, ol1 = (int64_t)Ln.i1 * C;
+    const float w00 = __fmul_rn(Y.w0, X.w0), w01 = __fmul_rn(Y.w0, X.w1), w10 = __fmul_rn(Y.w1, X.w0), w11 = __fmul_rn(Y.w1, X.w1);
+    if (dens) {   // relu per plane (EgoNeRF.py:340,346): the gradient passes where this plane's sum over channels is positive
+      float dot = 0.f;
+      for (int c0 = 0; c0 < C; c0 += 16) {
+        const int ch = c0 + c16;
+        if (ch < C) {
+          const float pv = P[o00 + ch] * w00 + P[o01 + ch] * w01 + P[o10 + ch] * w10 + P[o11 + ch] * w11;
+          const float lv = Lp[ol0 + ch] * Ln.w0 + Lp[ol1 + ch] * Ln.w1;
+          dot += pv * lv;
+        }
+      }
+      dot = gen_row_sum16(dot);
+      if (!(dot > 0.f)) continue;
+    }
+    for (int c0 = 0; c0 < C; c0 += 16) {
+      const int ch = c0 + c16;
+      if (ch >= C) continue;
+      const float pv = P[o00 + ch] * w00 + P[o01 + ch] * w01 + P[o10 + ch] * w10 + P[o11 + ch] * w11;
+      const float lv = Lp[ol0 + ch] * Ln.w0 + Lp[ol1 + ch] * Ln.w1;
+      const float di = dens ? ds : A.d[m * A.ldd + i * C + ch];
+      const float gp = di * lv, gl = di * pv;
       if (gp != 0.f) {
-        if (w00 != 0.f) unsafeAtomicAdd(GP + o00 + c4 + e, gp * w00);
-        if (w01 != 0.f) unsafeAtomicAdd(GP + o01 + c4 + e, gp * w01);
-        if (w10 != 0.f) unsafeAtomicAdd(GP + o10 + c4 + e, gp * w10);
-        if (w11 != 0.f) unsafeAtomicAdd(GP + o11 + c4 + e, gp * w11);
+        if (w00 != 0.f) unsafeAtomicAdd(GP + o00 + ch, gp * w00);
+        if (w01 != 0.f) unsafeAtomicAdd(GP + o01 + ch, gp * w01);
+        if (w10 != 0.f) unsafeAtomicAdd(GP + o10 + ch, gp * w10);
+        if (w11 != 0.f) unsafeAtomicAdd(GP + o11 + ch, gp * w11);
       }
       if (gl != 0.f) {
-        if (Ln.w0 != 0.f) unsafeAtomicAdd(GL + ol0 + c4 + e, gl * Ln.w0);
-        if (Ln.w1 != 0.f) unsafeAtomicAdd(GL + ol1 + c4 + e, gl * Ln.w1);
+        if (Ln.w0 != 0.f) unsafeAtomicAdd(GL + ol0 + ch, gl * Ln.w0);
+        if (Ln.w1 != 0.f) unsafeAtomicAdd(GL + ol1 + ch, gl * Ln.w1);
       }
     }
   }
@@ -727,8 +775,8 @@ int ego_scatter_generic(const ego_vm_field* field, const ego_vm_grad* grad, cons
       a.gplane[g][i] = grad->plane[g][i]; a.gline[g][i] = grad->line[g][i];
     }
   a.coords = coords; a.d = d; a.M = N * (int64_t)S; a.C = C; a.ldd = ldd;
-  const int64_t n = a.M * 3;
-  k_scatter_generic<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(a);
+  const int64_t n = a.M * 3, blocks = (n + 15) / 16;   // 16 groups of 16 lanes per workgroup
+  k_scatter_generic<<<(unsigned)(blocks < (1 << 20) ? (blocks > 0 ? blocks : 1) : (1 << 20)), 256, 0, (hipStream_t)stream>>>(a);
   return ego_launch_status("k_scatter_generic");
 }
 
