@@ -51,7 +51,7 @@ def new_scene() -> "Scene":
 class RenderArgs(C.Structure):
     _fields_ = [("n_coarse", C.c_int32), ("n_fine", C.c_int32), ("resampling", C.c_int32),
                 ("use_coarse_sample", C.c_int32), ("r_sched", C.c_void_p), ("jitter", C.c_void_p),
-                ("u", C.c_void_p), ("near_", C.c_float), ("reserved", C.c_int32), ("z_coarse", C.c_void_p)]
+                ("u", C.c_void_p), ("near_", C.c_float), ("reserved", C.c_int32), ("z_coarse", C.c_void_p), ("marched", C.c_void_p)]
 
 
 class VmGrad(C.Structure):
@@ -73,7 +73,7 @@ SP = C.POINTER(Scene)
 # The EGO_ABI_VERSION (include/egonerf_hip.h) the PROTOTYPES below were written against.  load() refuses a library that reports
 # another one: a stale libegonerf_hip.so can keep every struct size and still disagree on an argument list (ABI 5 -> 7 inserted
 # `normalize` before ego_erp_rays' output pointer), which ctypes would pass through as a wild pointer.
-EXPECTED_ABI_VERSION = 16
+EXPECTED_ABI_VERSION = 17
 
 # name -> (restype, argtypes); mirrors include/egonerf_hip.h one to one
 PROTOTYPES = {
@@ -86,6 +86,7 @@ PROTOTYPES = {
     "ego_packed_floats_scene": (I64, [SP]),
     "ego_sample_ray_exp": (C.c_int, [P, P, P, F32, I64, I32, P, P, P]),
     "ego_erp_rays": (C.c_int, [I32, I32, I32, I32, C.POINTER(C.c_float), I32, P, P]),
+    "ego_copy_out": (C.c_int, [I32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int64), I32, P]),
     "ego_from_cartesian": (C.c_int, [SP, P, I64, P, P]),
     "ego_normalize_coord": (C.c_int, [SP, P, I64, P, P]),
     "ego_density_feature": (C.c_int, [SP, P, I64, I32, P, P]),

@@ -1052,6 +1052,48 @@ int ego_erp_rays(int32_t H, int32_t W, int32_t row0, int32_t n_rows, const float
   return ego_launch_status("k_erp_rays");
 }
 
+// ---- device -> mapped host memory, by a kernel of a chosen (small) footprint --------------------------------------------------------
+struct CopyOutArgs {
+  const float* src[EGO_COPY_OUT_MAX];
+  float* dst[EGO_COPY_OUT_MAX];
+  int64_t n[EGO_COPY_OUT_MAX];   // floats
+  int32_t count;
+};
+
+__global__ __launch_bounds__(256) void k_copy_out(CopyOutArgs A) {
+  const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x, nth = (int64_t)gridDim.x * 256;
+  for (int t = 0; t < A.count; ++t) {
+    const float* __restrict__ s = A.src[t];
+    float* __restrict__ d = A.dst[t];
+    const int64_t n = A.n[t];
+    if ((((uintptr_t)s | (uintptr_t)d) & 15) == 0) {
+      const int64_t n4 = n >> 2;
+      for (int64_t i = tid; i < n4; i += nth) __builtin_nontemporal_store(((const f32x4*)s)[i], (f32x4*)d + i);
+      for (int64_t i = (n4 << 2) + tid; i < n; i += nth) d[i] = s[i];
+    } else {
+      for (int64_t i = tid; i < n; i += nth) d[i] = s[i];
+    }
+  }
+}
+
+int ego_copy_out(int32_t count, const float* const* src, float* const* dst, const int64_t* n_floats, int32_t workgroups, void* stream) {
+  EGO_TRACE("ego_copy_out");
+  EGO_REQUIRE(count >= 0 && count <= EGO_COPY_OUT_MAX && workgroups >= 1 && workgroups <= 65535, "copy_out: count / workgroups out of range");
+  if (count == 0) return EGO_OK;
+  EGO_REQUIRE(src && dst && n_floats, "copy_out: null argument");
+  CopyOutArgs a{};
+  int64_t total = 0;
+  for (int t = 0; t < count; ++t) {
+    EGO_REQUIRE(n_floats[t] >= 0 && (n_floats[t] == 0 || (src[t] && dst[t])), "copy_out: null buffer or negative size");
+    a.src[t] = src[t]; a.dst[t] = dst[t]; a.n[t] = n_floats[t];
+    total += n_floats[t];
+  }
+  a.count = count;
+  if (total == 0) return EGO_OK;
+  k_copy_out<<<workgroups, 256, 0, (hipStream_t)stream>>>(a);
+  return ego_launch_status("k_copy_out");
+}
+
 int ego_from_cartesian(const ego_scene* sc, const float* xyz, int64_t M, float* c7, void* stream) {
   EGO_TRACE("ego_from_cartesian");
   EGO_REQUIRE(M >= 0, "from_cartesian: M < 0");

@@ -76,6 +76,9 @@ int ego_render_forward(const ego_scene* sc, const ego_render_args* a, const floa
                                zc_in ? nullptr : ws + p.zc, alpha, astride, ws + p.w, ws + p.bg, ws + p.crd, nullptr, act, stream))) return e;
     z = zc_in ? zc_in : ws + p.zc;
   }
+  if (a->marched)
+    if (const hipError_t ee = hipEventRecord((hipEvent_t)a->marched, (hipStream_t)stream))
+      return ego_fail((int)ee, "render_forward: hipEventRecord(marched) failed: %s", hipGetErrorString(ee));
   // one launch for shading + compositing wherever it applies and its ray-granular deal of the work is balanced (ego_render_forward_folds):
   // since the folded kernel loads a plane's basis fragments ahead of the next plane's taps (it has the registers for that, the two-launch
   // kernel does not) it is 3.5 % faster than ego_shade, 2.8 % at step level (round 5; before that it lost by 0.25 %).  EGO_RENDER_FOLD=0

@@ -332,6 +332,7 @@ class YinYangAlphaGridMask(torch.nn.Module):
 
 class EgoNeRF(TensorBase):
     supports_need_alpha = True  # forward(..., need_alpha=False): see volume_renderer(keep_alpha=False)
+    supports_marched_event = True  # forward(..., marched_event=ev): see renderer._render_to_host
     def __init__(self, aabb, gridSize, device, coordinates, **kargs):
         super().__init__(aabb, gridSize, device, coordinates, **kargs)
         assert isinstance(coordinates, YinYangSphericalCoords), "EgoNeRF needs YinYangSphericalCoords (EgoNeRF.py:522)"
@@ -909,12 +910,24 @@ class EgoNeRF(TensorBase):
     @_lib.device_guard
     def forward(self, rays_chunk, white_bg=True, is_train=False, ndc_ray=False, n_coarse=-1, n_fine=0, exp_sampling=False,
                 pretrain_envmap=False, pivotal_sample_th=0.0, resampling=False, use_coarse_sample=True, interval_th=False,
-                jitter: Optional[torch.Tensor] = None, u: Optional[torch.Tensor] = None, need_alpha: bool = True):
+                jitter: Optional[torch.Tensor] = None, u: Optional[torch.Tensor] = None, need_alpha: bool = True,
+                marched_event: Optional["torch.cuda.Event"] = None):
+        out = self._forward(rays_chunk, is_train, ndc_ray, n_coarse, n_fine, exp_sampling, pretrain_envmap, resampling, use_coarse_sample,
+                            jitter, u, need_alpha, marched_event)
+        if marched_event is not None and not getattr(self, "_marched_recorded", False):
+            marched_event.record()   # a path without a march of its own (training, envmap pre-training, ...): "marched" = done
+        self._marched_recorded = False
+        return out
+
+    def _forward(self, rays_chunk, is_train, ndc_ray, n_coarse, n_fine, exp_sampling, pretrain_envmap, resampling, use_coarse_sample,
+                 jitter, u, need_alpha, marched_event):
         """EgoNeRF.forward (EgoNeRF.py:491-602) -> (rgb_map [N,3], depth_map [N], bg_map|None, env_map|None,
         alpha [N, S(+1)]).  `white_bg`, `pivotal_sample_th`, `interval_th` are accepted and unused, as in the
         reference.  `jitter` [N,n_coarse] / `u` [N,n_fine] pin the is_train noise.  `need_alpha=False` (eval only; what
         `volume_renderer(keep_alpha=False)` passes) returns None for the per-sample alpha, which also lets the ray march stop
-        evaluating a ray once its transmittance is exactly 0 (the remaining weights are exactly 0 either way)."""
+        evaluating a ray once its transmittance is exactly 0 (the remaining weights are exactly 0 either way).  `marched_event` (a created
+        torch.cuda.Event; volume_renderer's host hand-over passes it): recorded on the current stream behind the call's last march, ahead
+        of its shade kernel (ego_render_args.marched) - or at the end of a call that takes another path."""
         _require_cuda(rays_chunk, "EgoNeRF.forward")
         if rays_chunk.dim() != 2 or rays_chunk.shape[1] < 6:
             raise IndexError(f"EgoNeRF.forward: rays_chunk must be [N, >=6] (origin, direction), got {tuple(rays_chunk.shape)}")
@@ -968,6 +981,9 @@ class EgoNeRF(TensorBase):
             args.jitter = jitter.data_ptr()
         if u is not None:
             args.u = u.data_ptr()
+        if marched_event is not None and N:
+            args.marched = marched_event.cuda_event
+            self._marched_recorded = True
         S = (n_coarse + n_fine if use_coarse_sample else n_fine) if resampling else n_coarse
         lib = _lib.load()
         ws_bytes = lib.ego_render_workspace_bytes(N, C.byref(args))

@@ -72,30 +72,73 @@ def _render_to_host(rays, model, chunk, dev, keep_alpha, jitter, u, kw):
         hold = stage   # the pinned source must outlive the copy: referenced until the final synchronisation
     side = _copy_stream(dev)
     host: List[Optional[torch.Tensor]] = [None] * 5
-    shapes_known = False
-    for lo in range(0, max(n_all, 1), chunk):  # an empty ray list still makes one (empty) call, so the outputs keep their shapes
+    # The runtime copies device -> pinned host with a blit KERNEL (`__amd_rocclr_copyBuffer`: 170 us for the 8 MB alpha of a chunk), and next
+    # to it the following chunk's march - bound by the latency of its own gathers - took 260 us instead of 97 (tools/handover_timeline.sh;
+    # stream priorities changed nothing).  So chunk k's copies wait for chunk k + 1's MARCH (ego_render_args.marched) and run under its
+    # shade kernel, which is bound by instruction issue and has the memory system to spare.
+    mid = getattr(model, "supports_marched_event", False) and _DELAY_COPIES
+    events = []
+    if mid:
+        for _ in range(2):
+            ev = torch.cuda.Event()
+            ev.record(main)   # (creates the underlying event: the library records it by handle)
+            events.append(ev)
+
+    def copy_out(o, lo):
+        with torch.cuda.stream(side):
+            live = [(host[j][lo:lo + t.shape[0]], t.detach().contiguous()) for j, t in enumerate(o) if t is not None and t.shape[0]]
+            if _COPY_WORKGROUPS > 0 and live and all(t.dtype == torch.float32 for _h, t in live):
+                # ONE small kernel writes the chunk's outputs into the pinned arrays (mapped: the device sees them through the same
+                # pointer) - the runtime's copy is a kernel too, but one that fills the chip (see above)
+                import ctypes as C
+                from . import _lib
+                n = len(live)
+                src = (C.c_void_p * n)(*[t.data_ptr() for _h, t in live])
+                dst = (C.c_void_p * n)(*[h.data_ptr() for h, _t in live])
+                cnt = (C.c_int64 * n)(*[t.numel() for _h, t in live])
+                _lib.check(_lib.load().ego_copy_out(n, src, dst, cnt, _COPY_WORKGROUPS, _lib.stream_handle()), "ego_copy_out")
+            else:
+                for h, t in live:
+                    h.copy_(t, non_blocking=True)
+            for _h, t in live:
+                t.record_stream(side)   # the allocator must not hand the block out again before the copy has read it
+
+    pending = None
+    for k, lo in enumerate(range(0, max(n_all, 1), chunk)):  # an empty ray list still makes one (empty) call, so the outputs keep their shapes
         rays_chunk = rays[lo:lo + chunk].to(dev, non_blocking=True)
         extra = dict(jitter=None if jitter is None else jitter[lo:lo + chunk], u=None if u is None else u[lo:lo + chunk])
         if not keep_alpha and getattr(model, "supports_need_alpha", False):
             extra["need_alpha"] = False
+        if mid:
+            extra["marched_event"] = events[k & 1]
         o = model(rays_chunk, **kw, **extra)
         if not keep_alpha:
             o = o[:4] + (None,)
-        if not shapes_known:
+        if host[0] is None:
             for j, t in enumerate(o):
                 if t is not None:
                     host[j] = torch.empty((n_all,) + tuple(t.shape[1:]), dtype=t.dtype, pin_memory=True)
-            shapes_known = True
-        side.wait_stream(main)   # chunk k's copies start when its kernels are done; chunk k + 1's kernels are queued behind them on `main`
-        with torch.cuda.stream(side):
-            for j, t in enumerate(o):
-                if t is not None and t.shape[0]:
-                    t = t.detach()
-                    host[j][lo:lo + t.shape[0]].copy_(t, non_blocking=True)
-                    t.record_stream(side)   # the allocator must not hand the block out again before the copy has read it
+        if mid:
+            if pending is not None:   # the previous chunk is complete where this chunk's march is: its copies go under this chunk's shade
+                side.wait_event(events[k & 1])
+                copy_out(*pending)
+            pending = (o, lo)
+        else:
+            side.wait_stream(main)   # chunk k's copies start when its kernels are done; chunk k + 1's kernels are queued behind them on `main`
+            copy_out(o, lo)
+    if pending is not None:
+        side.wait_stream(main)
+        copy_out(*pending)
     side.synchronize()
     main.synchronize()
     return tuple(None if h is None else h.numpy() for h in host)
+
+
+# workgroups of ego_copy_out per chunk; 0: the runtime's hipMemcpyAsync.  M rays/s at 4096 x 512 with alpha copied back, one box: runtime copy
+# 5.1-5.3, 128 workgroups 6.2, 32: 6.3, 16: 6.5, 8: 6.7, 4: 7.26, 3: 7.1, 2: 6.7, 1: 5.5 (resident: 7.69) - alone, four workgroups move the
+# 8 MB in 172 us (49 GB/s); under the shade kernel in 540 us, just inside the chunk's 560
+_COPY_WORKGROUPS = int(__import__("os").environ.get("EGO_HANDOVER_WORKGROUPS", "4"))
+_DELAY_COPIES = __import__("os").environ.get("EGO_HANDOVER_DELAY", "1") != "0"   # 0: copies start as soon as their chunk is done (round 6's first form)
 
 
 _COPY_STREAMS: dict = {}

@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define EGO_ABI_VERSION 16
+#define EGO_ABI_VERSION 17
 
 enum { EGO_PREC_F16X3 = 0, EGO_PREC_F32 = 1, EGO_PREC_F16F8 = 2, EGO_PREC_F16F6 = 3 };
 /* ego_scene.head: the appearance head TensorBase.init_render_func selected (models/tensorBase.py:186-200) */
@@ -496,6 +496,14 @@ int ego_adam_step_graph(const ego_adam_tensor* tensors, int32_t count, float bet
 int ego_rgb_ssim(const float* img0, const float* img1, int32_t H, int32_t W, double max_val, int32_t filter_size, double filter_sigma,
                  double k1, double k2, double* sum, float* ssim_map, void* stream);
 
+/* v17: up to EGO_COPY_OUT_MAX float arrays device -> MAPPED host memory (hipHostMalloc / torch pinned memory: the device writes it through the
+ * same pointer) in ONE launch of `workgroups` x 256 threads.  For renderer.py:39-53's `.cpu().numpy()` of every chunk's outputs: the runtime's
+ * own device -> host copy is a kernel that fills the chip - next to it the following chunk's march took 260 us instead of 97, its shade 570
+ * instead of 450 (tools/handover_timeline.sh) - while 8 MB over the host link need no more than a few dozen workgroups.  Ordered on `stream`
+ * like any kernel; the host may read `dst` once the stream (or an event behind the call) has completed. */
+#define EGO_COPY_OUT_MAX 8
+int ego_copy_out(int32_t count, const float* const* src, float* const* dst, const int64_t* n_floats, int32_t workgroups, void* stream);
+
 typedef struct ego_render_args {
   int32_t n_coarse, n_fine;
   int32_t resampling, use_coarse_sample;
@@ -507,6 +515,10 @@ typedef struct ego_render_args {
   const float* z_coarse; /* dev [N][n_coarse] explicit distances of the first pass, or NULL.  Overrides r_sched / jitter: the
                           * exp_sampling=False path, TensorBase.sample_ray (tensorBase.py:308-327), whose per-ray schedule the
                           * host computes */
+  void* marched;         /* v17: hipEvent_t or NULL.  Recorded on `stream` behind the LAST march launch, ahead of the shade: lets a caller
+                          * start copies of the PREVIOUS call's outputs under this call's shade kernel (bound by instruction issue) instead
+                          * of under its march (bound by the latency of its gathers: next to the runtime's copy kernel it took 260 us
+                          * instead of 97, tools/handover_timeline.sh) */
 } ego_render_args;
 
 /* Whole EgoNeRF.forward for N rays.  S_out = n_coarse (no resampling) | n_coarse+n_fine | n_fine.

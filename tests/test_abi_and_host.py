@@ -24,7 +24,7 @@ def test_library_exports_every_header_symbol():
     for n in names:
         assert hasattr(lib, n), n
     assert set(names) == set(_lib.PROTOTYPES)  # the binding covers the whole header, nothing extra
-    assert lib.ego_abi_version() == _lib.EXPECTED_ABI_VERSION == 16
+    assert lib.ego_abi_version() == _lib.EXPECTED_ABI_VERSION == 17
     assert [lib.ego_sizeof(i) for i in range(3)] == [ctypes.sizeof(_lib.Scene), ctypes.sizeof(_lib.RenderArgs),
                                                      ctypes.sizeof(_lib.VmField)]
     assert lib.ego_packed_floats() == 2 * 46852 + 9216 + 2 * 36864  # fp32 layout + fp16-split layout + fp16-table basis fragments + f16f8 and f16f6 W1/W2

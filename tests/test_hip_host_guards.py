@@ -120,6 +120,60 @@ def test_activations_beyond_the_half_range_do_not_poison_a_pixel():
     assert all(bool(torch.isfinite(p.grad).all()) for p in model.parameters())
 
 
+def test_copy_out_moves_any_size_and_alignment_and_refuses_bad_arguments():
+    """ABI v17 ego_copy_out: up to EGO_COPY_OUT_MAX float arrays device -> mapped (pinned) host memory in one small launch: aligned and
+    misaligned pointers, sizes that are no multiple of four floats, empty arrays, one workgroup and many; bad arguments are refused."""
+    import ctypes as C
+    from egonerf_amd import _lib
+    lib, st = _lib.load(), _lib.stream_handle()
+    g = torch.Generator().manual_seed(3)
+    sizes = [0, 1, 3, 4, 5, 1023, 4096 * 3, 70001]
+    for wgs in (1, 4, 64):
+        big_d = torch.rand(sum(sizes) + 64, generator=g).cuda()
+        big_h = torch.full((sum(sizes) + 64,), -1.0).pin_memory()
+        src, dst, off = [], [], 0
+        for k, n in enumerate(sizes):
+            o = off + (k % 3)   # every third pair 16-byte aligned relative to the base, the others not
+            src.append(big_d[o:o + n]); dst.append(big_h[o:o + n]); off = o + n
+        n = len(sizes)
+        ps = (C.c_void_p * n)(*[t.data_ptr() if t.numel() else None for t in src])
+        pd = (C.c_void_p * n)(*[t.data_ptr() if t.numel() else None for t in dst])
+        cn = (C.c_int64 * n)(*sizes)
+        _lib.check(lib.ego_copy_out(n, ps, pd, cn, wgs, st), "ego_copy_out")
+        torch.cuda.synchronize()
+        want = torch.full_like(big_h, -1.0)
+        for s_, d_ in zip(src, dst):
+            want[d_.storage_offset():d_.storage_offset() + d_.numel()] = s_.cpu()
+        assert torch.equal(big_h, want), wgs   # every array arrived, nothing next to them was touched
+    one = (C.c_void_p * 1)(big_d.data_ptr()); oneh = (C.c_void_p * 1)(big_h.data_ptr()); c1 = (C.c_int64 * 1)(8)
+    assert lib.ego_copy_out(0, None, None, None, 4, st) == 0
+    assert lib.ego_copy_out(1, one, oneh, c1, 0, st) != 0          # no workgroup
+    assert lib.ego_copy_out(9, one, oneh, c1, 4, st) != 0          # more than EGO_COPY_OUT_MAX arrays
+    assert lib.ego_copy_out(1, one, (C.c_void_p * 1)(None), c1, 4, st) != 0
+    assert lib.ego_copy_out(1, one, oneh, (C.c_int64 * 1)(-1), 4, st) != 0
+
+
+@pytest.mark.parametrize("copy_form", ["kernel_delayed", "kernel", "runtime"])
+def test_host_hand_over_forms_agree(copy_form, monkeypatch):
+    """The three forms of the device -> host copies (ego_copy_out under the NEXT chunk's shade kernel = the default, ego_copy_out as soon
+    as the chunk is done, the runtime's hipMemcpyAsync) return the same bits; an odd chunk size puts the rows of the pinned arrays at
+    addresses that are no multiple of 16."""
+    from egonerf_amd import renderer
+    monkeypatch.setattr(renderer, "_COPY_WORKGROUPS", 0 if copy_form == "runtime" else 4)
+    monkeypatch.setattr(renderer, "_DELAY_COPIES", copy_form == "kernel_delayed")
+    cfg = synth.SceneConfig(n_voxel=24 ** 3)
+    model = make_model(cfg, synth.make_weights(cfg, seed=78), "cuda")
+    host = torch.from_numpy(synth.make_rays(1000, seed=10))
+    kw = dict(chunk=193, n_coarse=33, exp_sampling=True, device="cuda")
+    with torch.no_grad():
+        want = renderer.volume_renderer(host.cuda(), model, keep_alpha=True, **kw)
+        got = renderer.volume_renderer(host, model, keep_alpha=True, empty_gpu_cache=True, **kw)
+    for j, (w_, g_) in enumerate(zip(want, got)):
+        assert (w_ is None) == (g_ is None), j
+        if w_ is not None:
+            assert np.array_equal(g_, w_.cpu().numpy()), (copy_form, j)
+
+
 @pytest.mark.parametrize("where", ["pageable", "pinned", "device"])
 def test_volume_renderer_host_hand_over_equals_the_resident_path(where):
     """the reference's own call pattern - volume_renderer(..., empty_gpu_cache=True), every chunk's outputs (the
