@@ -383,7 +383,8 @@ int ego_scatter_app_sorted(const ego_scene* sc, const ego_vm_grad* gapp, const f
  * by a power of two per sample / per channel, fp16 hi + lo, three MFMA terms, fp32 accumulation), so ego_shade_backward
  * need not write dv at all (pass it dv = NULL: its dv_absmax then carries max |dfe|, which is what this call expects in that case - the
  * fixed-point unit comes from max |dfe| x the largest column sum of |basis|).  A sample's dv differs from ego_shade_backward's by the
- * rounding of that arithmetic (~2^-21 per product; the fp32 summation order over the 27 slots differs). */
+ * rounding of that arithmetic (~2^-21 per product; the fp32 summation order over the 27 slots differs).  The padding columns of dfe (slots
+ * 14, 15 of either half and feature 27) meet zero weights here and must be finite, as ego_shade_backward writes them (zeros). */
 /* v15: ONE pass over dfeat / dv.  The gradient of a plane and of the line it is multiplied with (the table of the axis that is not in the
  * plane) come out of the same walk over the plane's cells: a cell's samples share the four plane texels, so the line's contribution of a
  * sample is four multiply-adds away - but it lands in an arbitrary line texel.  Those sums are therefore taken in 64-bit FIXED POINT
