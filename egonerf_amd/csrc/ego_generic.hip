@@ -77,6 +77,14 @@ __global__ void k_generic_pack(const float* __restrict__ w1, const float* __rest
 }
 
 enum { G_SHADE = 0, G_APP = 1, G_MLP = 2 };
+#ifndef EGO_GENERIC_MFMA
+#define EGO_GENERIC_MFMA 1
+#endif
+__device__ __forceinline__ void wave_sync_g() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 typedef __attribute__((address_space(4))) float gen_cfloat;
 
 // torch.sin / torch.cos of the positional encodings (tensorBase.py:10-19), both from ONE argument reduction, branch-free: the reduction
@@ -127,6 +135,12 @@ __global__ __launch_bounds__(128) void k_shade_generic(GenShadeArgs A) {
 #pragma unroll
     for (int f = 0; f < 32; ++f) feat[f] = 0.f;
     float vd[3] = {0.f, 0.f, 0.f};
+#if EGO_GENERIC_MFMA
+    const int l31 = lane & 31, kk = lane >> 5;
+    const float* gw = A.gp;
+    // slab element (row, sample): the column is swizzled with the row so that the 32 lanes of a D tile (32 rows, one sample) hit 32 banks
+    auto SL = [&](int row, int col) -> float& { return sl[row][col ^ (row & 31)]; };
+#endif
     if (MODE == G_MLP) {
 #pragma unroll
       for (int f = 0; f < 32; ++f)
@@ -150,6 +164,19 @@ __global__ __launch_bounds__(128) void k_shade_generic(GenShadeArgs A) {
       }
       const VMTaps t = vm_setup(a[0], a[1], a[2], A.F.res);
       const int C = A.n_comp;
+#if EGO_GENERIC_MFMA
+      // features = basis_g (plane value x line value): the unit's [64 samples][3 C] products go through the slab a plane at a time and
+      // meet basisT [g][column][32 features] on the matrix pipe; a sample's row of A is zero for the grid it does not belong to, so both
+      // grids accumulate into the same tiles (the lane = sample form took 2 x 32 scalar weights and 32 selects per column and sample)
+      f32x16 accf[2];
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accf[mt][r] = 0.f;
+      const unsigned long long gmask = __ballot(g != 0);
+      const bool any_yin = ~gmask != 0ull, any_yang = gmask != 0ull;
+      const bool yang0 = (gmask >> l31) & 1ull, yang1 = (gmask >> (32 + l31)) & 1ull;   // grid of samples l31 and 32 + l31
+#endif
 #pragma unroll
       for (int i = 0; i < 3; ++i) {
         const Lin1 X = t.ax[vm_plane_x(i)], Y = t.ax[vm_plane_y(i)], Ln = t.ax[vm_line_ax(i)];
@@ -169,6 +196,10 @@ __global__ __launch_bounds__(128) void k_shade_generic(GenShadeArgs A) {
           const f32x4 lv = *(const f32x4*)(l0 + c4) * Ln.w0 + *(const f32x4*)(l1 + c4) * Ln.w1;
           const f32x4 pr = pv * lv;
           if (DUMP && valid) *(f32x4*)(dump_v + m * A.ldv + i * C + c4) = pr;
+#if EGO_GENERIC_MFMA
+#pragma unroll
+          for (int e = 0; e < 4; ++e) SL(c4 + e, lane) = pr[e];
+#else
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             // basisT [g][col][32]: uniform addresses -> scalar loads of both grids' rows, selected per lane
@@ -178,8 +209,42 @@ __global__ __launch_bounds__(128) void k_shade_generic(GenShadeArgs A) {
             for (int f = 0; f < 32; ++f)
               if (f < A.app_dim) feat[f] = fmaf(g ? b1[f] : b0[f], pr[e], feat[f]);
           }
+#endif
         }
+#if EGO_GENERIC_MFMA
+        wave_sync_g();
+        for (int t0 = 0; t0 < C; t0 += 2) {
+          const int tt = t0 + kk;
+          const bool ok = tt < C;
+          const int tc = ok ? tt : C - 1;
+          const float x0 = ok ? SL(tc, l31) : 0.f, x1 = ok ? SL(tc, 32 + l31) : 0.f;
+          const float* bw = gw + L.basis + (int64_t)(i * C + tc) * 32 + l31;
+          if (any_yin) {
+            const float b = bw[0];
+            accf[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(yang0 ? 0.f : x0, b, accf[0], 0, 0, 0);
+            accf[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(yang1 ? 0.f : x1, b, accf[1], 0, 0, 0);
+          }
+          if (any_yang) {
+            const float b = bw[(int64_t)3 * C * 32];
+            accf[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(yang0 ? x0 : 0.f, b, accf[0], 0, 0, 0);
+            accf[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(yang1 ? x1 : 0.f, b, accf[1], 0, 0, 0);
+          }
+        }
+        wave_sync_g();
+#endif
       }
+#if EGO_GENERIC_MFMA
+      // D register r of lane l = sample 32 mt + 8 (r / 4) + 4 (l / 32) + r % 4, feature l % 32: back to lane = sample through the slab
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) SL(l31, 32 * mt + 8 * (r >> 2) + 4 * kk + (r & 3)) = accf[mt][r];
+      wave_sync_g();
+#pragma unroll
+      for (int f = 0; f < 32; ++f)
+        if (f < A.app_dim) feat[f] = SL(f, lane);
+      wave_sync_g();
+#endif
     }
     if (MODE == G_APP) {
       if (valid) {
@@ -197,6 +262,124 @@ __global__ __launch_bounds__(128) void k_shade_generic(GenShadeArgs A) {
       continue;
     }
     // ---- row G: mlp_in = [features, viewdirs, PE(features), PE(viewdirs)] (tensorBase.py:68-75) -> Linear relu Linear relu Linear ----
+#if EGO_GENERIC_MFMA
+    // Both hidden layers on the matrix pipe in fp32 (v_mfma_f32_32x32x2_f32: products and sums in fp32, as the reference's): the unit's 64
+    // samples x HID hidden units are 2 x HID / 32 tiles of 16 accumulators; A = the staged inputs from the slab (lane = (sample l % 32,
+    // k = l / 32)), B = two rows of W^T by coalesced VECTOR loads (lane = (k, hidden unit l % 32)).  The lane = sample form it replaces
+    // fed every FMA an SGPR weight: 128 weights per input row through a 104-SGPR file, every row two or three dependent scalar-load ->
+    // FMA phases with one wave per SIMD to hide them (5-10 % of the fp32 rate; kept as -DEGO_GENERIC_MFMA=0).
+    constexpr int NT = HID / 32;
+    f32x16 acc[2][NT];
+    auto bias = [&](int64_t off) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const float bv = gw[off + 32 * nt + l31];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[mt][nt][r] = bv;
+      }
+    };
+    // n staged inputs (slab rows off .. off + n - 1) times rows wrow0 + t * stride of the [rows][HID] matrix at `wbase`
+    auto matmul = [&](int n, int off, int64_t wbase, int wrow0, int stride) {
+      wave_sync_g();   // the slab rows were written by lane = sample
+      for (int t0 = 0; t0 < n; t0 += 2) {
+        const int tt = t0 + kk;
+        const bool ok = tt < n;
+        const int tc = ok ? tt : n - 1;
+        float av[2], bv[NT];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) { const float x = SL(off + tc, 32 * mt + l31); av[mt] = ok ? x : 0.f; }
+        const float* w = gw + wbase + (int64_t)(wrow0 + tc * stride) * HID + l31;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) bv[nt] = w[32 * nt];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt], bv[nt], acc[mt][nt], 0, 0, 0);
+      }
+      wave_sync_g();   // ... and will be overwritten by the next chunk
+    };
+    // relu of the accumulators -> slab [hidden][sample] (+ the row-major dump: a register's 32 lanes are 32 consecutive hidden units of
+    // one sample - 128-byte stores); D register r of lane l = sample 32 mt + 8 (r / 4) + 4 (l / 32) + r % 4, hidden unit 32 nt + l % 32
+    auto relu_out = [&](float* dump) {
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int smp = 32 * mt + 8 * (r >> 2) + 4 * kk + (r & 3), hu = 32 * nt + l31;
+            const float hv = fmaxf(acc[mt][nt][r], 0.f);
+            SL(hu, smp) = hv;
+            if (DUMP) {
+              const int64_t ms = unit * 64 + smp;
+              if (ms < A.M) dump[ms * A.ldh + hu] = hv;
+            }
+          }
+    };
+    auto consume = [&](int n, int row0, int stride, int off = 0) {
+      if (DUMP && valid)
+        for (int tt = 0; tt < n; ++tt) dump_x[m * A.ldx + row0 + tt * stride] = SL(off + tt, lane);
+      matmul(n, off, L.w1t, row0, stride);
+    };
+    bias(L.b1);
+    const int D = A.app_dim;
+    // chunk 1: the raw features and the view direction (rows 0 .. D + 2)
+#pragma unroll
+    for (int f = 0; f < 32; ++f)
+      if (f < D) SL(f, lane) = feat[f];
+    SL(D, lane) = vd[0]; SL(D + 1, lane) = vd[1]; SL(D + 2, lane) = vd[2];
+    consume(D + 3, 0, 1);
+    // PE(features): element-major, frequency-minor; all sines (rows base + f * fea_pe + q), then all cosines
+    {
+      const int base_s = D + 3, base_c = base_s + D * A.fea_pe;
+      float fr = 1.f;
+      for (int q = 0; q < A.fea_pe; ++q, fr *= 2.f) {
+        // sine and cosine of one argument from ONE reduction (gen_sincos), the cosines parked in rows D .. 2 D - 1 of the slab (2 D <= 64 <= HID)
+#pragma unroll
+        for (int f = 0; f < 32; ++f)
+          if (f < D) {
+            float sv, cv;
+            gen_sincos(__fmul_rn(feat[f], fr), sv, cv);
+            SL(f, lane) = sv; SL(D + f, lane) = cv;
+          }
+        consume(D, base_s + q, A.fea_pe);
+        consume(D, base_c + q, A.fea_pe, D);
+      }
+      const int vbase_s = base_c + D * A.fea_pe, vbase_c = vbase_s + 3 * A.view_pe;
+      fr = 1.f;
+      for (int q = 0; q < A.view_pe; ++q, fr *= 2.f) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+          float sv, cv;
+          gen_sincos(__fmul_rn(vd[d], fr), sv, cv);
+          SL(d, lane) = sv; SL(3 + d, lane) = cv;
+        }
+        consume(3, vbase_s + q, A.view_pe);
+        consume(3, vbase_c + q, A.view_pe, 3);
+      }
+    }
+    relu_out(dump_h1);
+    bias(L.b2);
+    matmul(HID, 0, L.w2t, 0, 1);
+    relu_out(dump_h2);
+    wave_sync_g();
+    const gen_cfloat* w3 = gp + L.w3;
+    const gen_cfloat* b3 = gp + L.b3;
+    float o[3] = {b3[0], b3[1], b3[2]};
+    for (int j = 0; j < HID; ++j) {   // three outputs: lane = sample again, the weights as scalars
+      const float hv = SL(j, lane);
+      o[0] = fmaf(w3[j], hv, o[0]); o[1] = fmaf(w3[HID + j], hv, o[1]); o[2] = fmaf(w3[2 * HID + j], hv, o[2]);
+    }
+    if (valid) {
+      float* op = outp + m * 3;
+      op[0] = sigmoidf(o[0]); op[1] = sigmoidf(o[1]); op[2] = sigmoidf(o[2]);
+    }
+    wave_sync_g();   // the next unit stages into the slab
+  }
+}
+#else
     float h[HID];
     {
       const gen_cfloat* b1 = gp + L.b1;
@@ -282,6 +465,7 @@ __global__ __launch_bounds__(128) void k_shade_generic(GenShadeArgs A) {
     }
   }
 }
+#endif
 
 // ---- training of the other model shapes: backward of rows F, G and of the VM lookups, plain fp32, lane = sample --------------------
 // The data-gradient chain of one sample: do = dL/d(pre-sigmoid) -> dh2 = relu'(h2) W3^T do -> dh1 = relu'(h1) W2^T dh2 -> dx = W1^T dh1
