@@ -36,9 +36,9 @@ struct GenShadeArgs {
   int32_t ldx, ldh, ldv;
 };
 
-// packed layout (floats): W1T [in_c][HID] | b1 [HID] | W2T [HID][HID] | b2 [HID] | W3 [3][HID] | b3 [4] | basisT [2][3 C][32]
+// packed layout (floats): W1T [in_c][HID] | b1 [HID] | W2T [HID][HID] | b2 [HID] | W3 [3][HID] | b3 [4] | basisT [2][3 C][32] | W1 | W2 | basis [2][32][3 C]
 struct GenLayout {
-  int64_t w1t, b1, w2t, b2, w3, b3, basis, total;
+  int64_t w1t, b1, w2t, b2, w3, b3, basis, w1n, w2n, basisn, total;
 };
 __host__ __device__ inline GenLayout gen_layout(int in_c, int hid, int n_comp) {
   GenLayout L;
@@ -50,6 +50,11 @@ __host__ __device__ inline GenLayout gen_layout(int in_c, int hid, int n_comp) {
   L.w3 = o; o += 3 * hid;
   L.b3 = o; o += 4;
   L.basis = o; o += 2 * 3 * (int64_t)n_comp * 32;
+  // the same matrices the other way round, for the backward's products on the matrix pipe (B operands with the OUTPUT index contiguous):
+  // W1 [HID][in_c], W2 [HID][HID] (the reference's own layouts), basis [2][32][3 C] (rows >= app_dim zero)
+  L.w1n = o; o += (int64_t)hid * in_c;
+  L.w2n = o; o += (int64_t)hid * hid;
+  L.basisn = o; o += 2 * 32 * 3 * (int64_t)n_comp;
   L.total = o;
   return L;
 }
@@ -68,10 +73,17 @@ __global__ void k_generic_pack(const float* __restrict__ w1, const float* __rest
   else if (idx < L.w3) v = b2[idx - L.b2];
   else if (idx < L.b3) v = w3[idx - L.w3];
   else if (idx < L.basis) { const int c = (int)(idx - L.b3); v = (c < 3 && b3) ? b3[c] : 0.f; }   // b3 == null: EGO_HEAD_RGB (hid = in_c = 0)
-  else {
+  else if (idx < L.w1n) {
     const int64_t e = idx - L.basis;
     const int f = (int)(e & 31), col = (int)((e >> 5) % (3 * n_comp)), g = (int)((e >> 5) / (3 * n_comp));
     if (f < app_dim) v = (g ? basis_yang : basis_yin)[(int64_t)f * (3 * n_comp) + col];
+  }
+  else if (idx < L.w2n) v = w1[idx - L.w1n];
+  else if (idx < L.basisn) v = w2[idx - L.w2n];
+  else {
+    const int64_t e = idx - L.basisn;
+    const int ncol = 3 * n_comp, col = (int)(e % ncol), f = (int)((e / ncol) & 31), g = (int)(e / ((int64_t)32 * ncol));
+    if (f < app_dim) v = (g ? basis_yang : basis_yin)[(int64_t)f * ncol + col];
   }
   out[idx] = v;
 }
@@ -80,6 +92,31 @@ enum { G_SHADE = 0, G_APP = 1, G_MLP = 2 };
 #ifndef EGO_GENERIC_MFMA
 #define EGO_GENERIC_MFMA 1
 #endif
+
+// n iterations of body(it, b) with the NB values b = loadb(it) of iteration it + PF already in flight: one wave per SIMD has nobody else
+// to hide a global load behind (a loop that loads, waits and multiplies spent 3 000 clocks per 512 clocks of MFMA)
+template <int PF, int NB, class LB, class BD>
+__device__ __forceinline__ void gen_pipelined(int n, LB loadb, BD body) {
+  if (n <= 0) return;
+  float bq[PF][NB];
+#pragma unroll
+  for (int p = 0; p < PF; ++p) loadb(p < n ? p : n - 1, bq[p]);
+  for (int i0 = 0; i0 < n; i0 += PF) {
+#pragma unroll
+    for (int p = 0; p < PF; ++p) {
+      const int it = i0 + p;
+      if (it < n) {
+        float b[NB];
+#pragma unroll
+        for (int e = 0; e < NB; ++e) b[e] = bq[p][e];
+        const int nx = it + PF;
+        loadb(nx < n ? nx : n - 1, bq[p]);
+        body(it, b);
+      }
+    }
+  }
+}
+
 __device__ __forceinline__ void wave_sync_g() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -213,23 +250,27 @@ __global__ __launch_bounds__(128) void k_shade_generic(GenShadeArgs A) {
         }
 #if EGO_GENERIC_MFMA
         wave_sync_g();
-        for (int t0 = 0; t0 < C; t0 += 2) {
-          const int tt = t0 + kk;
-          const bool ok = tt < C;
-          const int tc = ok ? tt : C - 1;
-          const float x0 = ok ? SL(tc, l31) : 0.f, x1 = ok ? SL(tc, 32 + l31) : 0.f;
-          const float* bw = gw + L.basis + (int64_t)(i * C + tc) * 32 + l31;
-          if (any_yin) {
-            const float b = bw[0];
-            accf[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(yang0 ? 0.f : x0, b, accf[0], 0, 0, 0);
-            accf[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(yang1 ? 0.f : x1, b, accf[1], 0, 0, 0);
-          }
-          if (any_yang) {
-            const float b = bw[(int64_t)3 * C * 32];
-            accf[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(yang0 ? x0 : 0.f, b, accf[0], 0, 0, 0);
-            accf[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(yang1 ? x1 : 0.f, b, accf[1], 0, 0, 0);
-          }
-        }
+        gen_pipelined<4, 2>((C + 1) / 2,
+          [&](int it, float (&bq)[2]) {
+            const int tt = 2 * it + kk, tc = tt < C ? tt : C - 1;
+            const float* bw = gw + L.basis + (int64_t)(i * C + tc) * 32 + l31;
+            bq[0] = any_yin ? bw[0] : 0.f;
+            bq[1] = any_yang ? bw[(int64_t)3 * C * 32] : 0.f;
+          },
+          [&](int it, const float (&bq)[2]) {
+            const int tt = 2 * it + kk;
+            const bool ok = tt < C;
+            const int tc = ok ? tt : C - 1;
+            const float x0 = ok ? SL(tc, l31) : 0.f, x1 = ok ? SL(tc, 32 + l31) : 0.f;
+            if (any_yin) {
+              accf[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(yang0 ? 0.f : x0, bq[0], accf[0], 0, 0, 0);
+              accf[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(yang1 ? 0.f : x1, bq[0], accf[1], 0, 0, 0);
+            }
+            if (any_yang) {
+              accf[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(yang0 ? x0 : 0.f, bq[1], accf[0], 0, 0, 0);
+              accf[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(yang1 ? x1 : 0.f, bq[1], accf[1], 0, 0, 0);
+            }
+          });
         wave_sync_g();
 #endif
       }
@@ -283,25 +324,30 @@ __global__ __launch_bounds__(128) void k_shade_generic(GenShadeArgs A) {
     // n staged inputs (slab rows off .. off + n - 1) times rows wrow0 + t * stride of the [rows][HID] matrix at `wbase`
     auto matmul = [&](int n, int off, int64_t wbase, int wrow0, int stride) {
       wave_sync_g();   // the slab rows were written by lane = sample
-      for (int t0 = 0; t0 < n; t0 += 2) {
-        const int tt = t0 + kk;
-        const bool ok = tt < n;
-        const int tc = ok ? tt : n - 1;
-        float av[2], bv[NT];
+      gen_pipelined<2, NT>((n + 1) / 2,
+        [&](int it, float (&bq)[NT]) {
+          const int tt = 2 * it + kk, tc = tt < n ? tt : n - 1;
+          const float* w = gw + wbase + (int64_t)(wrow0 + tc * stride) * HID + l31;
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) { const float x = SL(off + tc, 32 * mt + l31); av[mt] = ok ? x : 0.f; }
-        const float* w = gw + wbase + (int64_t)(wrow0 + tc * stride) * HID + l31;
+          for (int nt = 0; nt < NT; ++nt) bq[nt] = w[32 * nt];
+        },
+        [&](int it, const float (&bq)[NT]) {
+          const int tt = 2 * it + kk;
+          const bool ok = tt < n;
+          const int tc = ok ? tt : n - 1;
+          float av[2];
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) bv[nt] = w[32 * nt];
+          for (int mt = 0; mt < 2; ++mt) { const float x = SL(off + tc, 32 * mt + l31); av[mt] = ok ? x : 0.f; }
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+          for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-          for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt], bv[nt], acc[mt][nt], 0, 0, 0);
-      }
+            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt], bq[nt], acc[mt][nt], 0, 0, 0);
+        });
       wave_sync_g();   // ... and will be overwritten by the next chunk
     };
     // relu of the accumulators -> slab [hidden][sample] (+ the row-major dump: a register's 32 lanes are 32 consecutive hidden units of
     // one sample - 128-byte stores); D register r of lane l = sample 32 mt + 8 (r / 4) + 4 (l / 32) + r % 4, hidden unit 32 nt + l % 32
+    const bool full = unit * 64 + 64 <= A.M;
     auto relu_out = [&](float* dump) {
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt)
@@ -314,7 +360,7 @@ __global__ __launch_bounds__(128) void k_shade_generic(GenShadeArgs A) {
             SL(hu, smp) = hv;
             if (DUMP) {
               const int64_t ms = unit * 64 + smp;
-              if (ms < A.M) dump[ms * A.ldh + hu] = hv;
+              if (full || ms < A.M) dump[ms * A.ldh + hu] = hv;   // (`full`, a scalar, spares 128 exec-mask branches: the stores then leave in one batch)
             }
           }
     };
@@ -488,6 +534,217 @@ struct GenBwdArgs {
   int32_t head;
 };
 
+#if EGO_GENERIC_MFMA
+// The data-gradient chain on the matrix pipe (fp32 MFMA, as the forward): one wave = 64 samples, one wave per workgroup, slab rows
+// [0, HID): the A operand of the running product ([k][sample]), [HID, HID + 32): one 32-column tile of dx, [HID + 32, HID + 64): the
+// feature gradients being summed.  B operands from the natural-order copies in the blob (output index contiguous: coalesced loads); the
+// relu masks read h2 / h1 and write dh2 / dh1 in the D layout, where a register's 32 lanes are 32 consecutive hidden units of one sample.
+template <int HID>
+__global__ __launch_bounds__(64) void k_shade_generic_bwd(GenBwdArgs A) {
+  __shared__ float slab[HID + 64][64];
+  const int lane = threadIdx.x & 63, l31 = lane & 31, kk = lane >> 5;
+  float (*sl)[64] = slab;
+  auto SL = [&](int row, int col) -> float& { return sl[row][col ^ (row & 31)]; };
+  const GenLayout L = gen_layout(A.in_c, A.head == EGO_HEAD_RGB ? 0 : HID, A.n_comp);
+  const int64_t n_units = (A.M + 63) >> 6;
+  const int D = A.app_dim;
+  const float* gw = A.gp;
+  constexpr int NT = HID / 32;
+  for (int64_t unit = blockIdx.x; unit < n_units; unit += gridDim.x) {
+    const int64_t m_raw = unit * 64 + lane;
+    const bool valid = m_raw < A.M;
+    const int64_t m = valid ? m_raw : A.M - 1;
+    const int g = ((const f32x4*)A.coords)[m].w != 0.f;
+    const int ncol = 3 * A.n_comp;
+    if (A.head == EGO_HEAD_RGB) {   // colour = features: dfe = dL/d rgb_sample, then dv = B_g^T dfe (basisT [g][col][32])
+      float dfe[3] = {A.dc[m * 3], A.dc[m * 3 + 1], A.dc[m * 3 + 2]};
+      if (valid) {
+#pragma unroll
+        for (int f = 0; f < 32; ++f) {
+          A.dfe[m * 64 + 32 * g + f] = f < 3 ? dfe[f] : 0.f;
+          A.dfe[m * 64 + 32 * (1 - g) + f] = 0.f;
+        }
+      }
+      for (int col = 0; col < ncol; ++col) {
+        const float* b0 = A.gp + L.basis + (int64_t)col * 32;
+        const float* b1 = b0 + (int64_t)ncol * 32;
+        float s = 0.f;
+#pragma unroll
+        for (int f = 0; f < 3; ++f) s = fmaf(g ? b1[f] : b0[f], dfe[f], s);
+        if (valid) A.dv[m * A.ldv + col] = s;
+      }
+      continue;
+    }
+    // acc[mt][nt] (+)= slab rows [off, off + n) x rows of the [..][ld] matrix at wbase, columns col0 + 32 nt + l % 32 (zero beyond ncols)
+    auto matmul = [&](f32x16 (&acc)[2][NT], int nts, int n, int off, int64_t wbase, int ld, int col0, int ncols) {
+      wave_sync_g();
+      gen_pipelined<2, NT>((n + 1) / 2,
+        [&](int it, float (&bq)[NT]) {
+          const int tt = 2 * it + kk, tc = tt < n ? tt : n - 1;
+          const float* w = gw + wbase + (int64_t)tc * ld;
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            const int c = col0 + 32 * nt + l31;
+            const float x = w[c < ncols ? c : ncols - 1];
+            bq[nt] = (nt < nts && c < ncols) ? x : 0.f;
+          }
+        },
+        [&](int it, const float (&bq)[NT]) {
+          const int tt = 2 * it + kk;
+          const bool ok = tt < n;
+          const int tc = ok ? tt : n - 1;
+          float av[2];
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt) { const float x = SL(off + tc, 32 * mt + l31); av[mt] = ok ? x : 0.f; }
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+              if (nt < nts) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt], bq[nt], acc[mt][nt], 0, 0, 0);
+        });
+      wave_sync_g();
+    };
+    const bool full = unit * 64 + 64 <= A.M;
+    auto zero = [&](f32x16 (&acc)[2][NT]) {
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+    };
+    // relu'(h) mask in the D layout, the masked gradient out (row-major [M][HID]) and into slab rows [0, HID) as the next A operand
+    auto mask_out = [&](f32x16 (&acc)[2][NT], const float* h, float* out) {
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          // a tile's 16 loads first, then its 16 stores: `out` may alias `h` as far as the compiler knows, and load, store, load, store
+          // in program order is one exposed round trip per element (6 of this kernel's 10 ms)
+          const int hu = 32 * nt + l31;
+          float hv[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int64_t ms = unit * 64 + 32 * mt + 8 * (r >> 2) + 4 * kk + (r & 3), mc = (full || ms < A.M) ? ms : A.M - 1;
+            hv[r] = h[mc * A.ldh + hu];
+          }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int smp = 32 * mt + 8 * (r >> 2) + 4 * kk + (r & 3);
+            const int64_t ms = unit * 64 + smp;
+            const float v = hv[r] > 0.f ? acc[mt][nt][r] : 0.f;      // threshold backward of torch.nn.ReLU
+            if (full || ms < A.M) out[ms * HID + hu] = v;
+            SL(hu, smp) = v;
+          }
+        }
+    };
+    float d_o[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float y = A.rgb[m * 3 + c];
+      d_o[c] = A.dc[m * 3 + c] * y * (1.f - y);       // sigmoid'
+    }
+    if (valid) { A.dc[m * 3] = d_o[0]; A.dc[m * 3 + 1] = d_o[1]; A.dc[m * 3 + 2] = d_o[2]; }
+    SL(0, lane) = d_o[0]; SL(1, lane) = d_o[1]; SL(2, lane) = d_o[2];
+    f32x16 acc[2][NT];
+    zero(acc);
+    matmul(acc, NT, 3, 0, L.w3, HID, 0, HID);                 // dh2 (before the mask) = d_o W3, W3 [3][HID]
+    mask_out(acc, A.h2, A.dh2);
+    zero(acc);
+    matmul(acc, NT, HID, 0, L.w2n, HID, 0, HID);              // dh1 (before the mask) = dh2 W2, W2 [j][k]
+    mask_out(acc, A.h1, A.dh1);
+    // dx = dh1 W1 a 32-column tile at a time, each tile folded into the feature gradients through the encodings' derivatives
+    // (d sin(f w) = w cos(f w) df, d cos(f w) = -w sin(f w) df, sines and cosines taken from the dumped x)
+#pragma unroll
+    for (int f = 0; f < 32; ++f) SL(HID + 32 + f, lane) = 0.f;
+    const int base_s = D + 3, base_c = base_s + D * A.fea_pe, vbase_s = base_c + D * A.fea_pe;
+    const float* xr = A.x + m * A.ldx;
+    for (int c0 = 0; c0 < vbase_s; c0 += 32 * NT) {           // (the view-direction encodings behind vbase_s carry no gradient)
+      zero(acc);
+      const int nts = (vbase_s - c0 + 31) / 32 < NT ? (vbase_s - c0 + 31) / 32 : NT;
+      matmul(acc, nts, HID, 0, L.w1n, A.in_c, c0, A.in_c);    // NT tiles per pass: two MFMAs per k-pair do not cover the loads' latency
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int b0 = c0 + 32 * nt;
+        if (b0 >= vbase_s) break;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) SL(HID + l31, 32 * mt + 8 * (r >> 2) + 4 * kk + (r & 3)) = acc[mt][nt][r];
+        wave_sync_g();
+        const int b1 = b0 + 32 < vbase_s ? b0 + 32 : vbase_s;
+        for (int t = b0; t < b1; ++t) {                        // lane = sample; t is uniform
+          int f;
+          float coef;
+          if (t < D) { f = t; coef = 1.f; }
+          else if (t < base_s) continue;                        // the view direction itself
+          else if (t < base_c) { const int e = t - base_s, q = e % A.fea_pe; f = e / A.fea_pe; coef = ldexpf(xr[t + D * A.fea_pe], q); }
+          else { const int e = t - base_c, q = e % A.fea_pe; f = e / A.fea_pe; coef = -ldexpf(xr[t - D * A.fea_pe], q); }
+          SL(HID + 32 + f, lane) += coef * SL(HID + (t - b0), lane);
+        }
+        wave_sync_g();
+      }
+    }
+    if (valid) {
+#pragma unroll
+      for (int f = 0; f < 32; ++f) {
+        A.dfe[m * 64 + 32 * g + f] = SL(HID + 32 + f, lane);
+        A.dfe[m * 64 + 32 * (1 - g) + f] = 0.f;
+      }
+    }
+    // dv = dfe basis_g, basis [g][32][3 C]: a sample's row of A is zero for the grid it does not belong to
+    const unsigned long long gmask = __ballot(g != 0);
+    const bool any_yin = ~gmask != 0ull, any_yang = gmask != 0ull;
+    const bool yang0 = (gmask >> l31) & 1ull, yang1 = (gmask >> (32 + l31)) & 1ull;
+    wave_sync_g();
+    for (int c0 = 0; c0 < ncol; c0 += 32 * NT) {
+      zero(acc);
+      gen_pipelined<2, 2 * NT>(16,
+        [&](int it, float (&bq)[2 * NT]) {
+          const float* bw = gw + L.basisn + (int64_t)(2 * it + kk) * ncol;
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            const int c = c0 + 32 * nt + l31;
+            const bool okc = c < ncol;
+            const int cc = okc ? c : ncol - 1;
+            const float y0 = any_yin ? bw[cc] : 0.f, y1 = any_yang ? bw[(int64_t)32 * ncol + cc] : 0.f;
+            bq[2 * nt] = okc ? y0 : 0.f; bq[2 * nt + 1] = okc ? y1 : 0.f;
+          }
+        },
+        [&](int it, const float (&bq)[2 * NT]) {
+          const int tt = 2 * it + kk;
+          const float x0 = SL(HID + 32 + tt, l31), x1 = SL(HID + 32 + tt, 32 + l31);
+          const float a00 = yang0 ? 0.f : x0, a01 = yang1 ? 0.f : x1, a10 = yang0 ? x0 : 0.f, a11 = yang1 ? x1 : 0.f;
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            if (c0 + 32 * nt >= ncol) break;
+            if (any_yin) {
+              acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a00, bq[2 * nt], acc[0][nt], 0, 0, 0);
+              acc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a01, bq[2 * nt], acc[1][nt], 0, 0, 0);
+            }
+            if (any_yang) {
+              acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a10, bq[2 * nt + 1], acc[0][nt], 0, 0, 0);
+              acc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a11, bq[2 * nt + 1], acc[1][nt], 0, 0, 0);
+            }
+          }
+        });
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int c = c0 + 32 * nt + l31;
+        if (c0 + 32 * nt >= ncol) break;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int64_t ms = unit * 64 + 32 * mt + 8 * (r >> 2) + 4 * kk + (r & 3);
+            if (c < ncol && (full || ms < A.M)) A.dv[ms * A.ldv + c] = acc[mt][nt][r];
+          }
+      }
+    }
+    wave_sync_g();   // the next unit stages into the slab
+  }
+}
+#else
 template <int HID>
 __global__ __launch_bounds__(128) void k_shade_generic_bwd(GenBwdArgs A) {
   __shared__ float slab[2][HID][64];
@@ -588,6 +845,7 @@ __global__ __launch_bounds__(128) void k_shade_generic_bwd(GenBwdArgs A) {
     }
   }
 }
+#endif
 
 // backward of the VM lookups for any component count (multiple of 4): thread = (sample, plane); float atomics per tap and channel
 struct GenScatterArgs {
@@ -936,9 +1194,15 @@ int ego_shade_backward_generic(const ego_scene* sc, const float* coords, float* 
   a.M = N * (int64_t)S; a.app_dim = sc->app_dim; a.n_comp = sc->app.n_comp; a.in_c = sc->mlp_in; a.view_pe = sc->view_pe; a.fea_pe = sc->fea_pe;
   a.ldx = ldx; a.ldh = ldh; a.ldv = ldv; a.head = sc->head;
   const int64_t units = (a.M + 63) >> 6;
+#if EGO_GENERIC_MFMA
+  const unsigned grid = (unsigned)(units < 4096 ? units : 4096);   // one wave per workgroup (its slab: 32 / 48 KB)
+  if (sc->mlp_hidden != 128) k_shade_generic_bwd<64><<<grid, 64, 0, (hipStream_t)stream>>>(a);
+  else k_shade_generic_bwd<128><<<grid, 64, 0, (hipStream_t)stream>>>(a);
+#else
   const unsigned grid = (unsigned)((units + 1) / 2 < 2048 ? (units + 1) / 2 : 2048);
   if (sc->mlp_hidden != 128) k_shade_generic_bwd<64><<<grid, 128, 0, (hipStream_t)stream>>>(a);
   else k_shade_generic_bwd<128><<<grid, 128, 0, (hipStream_t)stream>>>(a);
+#endif
   return ego_launch_status("k_shade_generic_bwd");
 }
 
