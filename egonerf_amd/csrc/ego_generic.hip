@@ -117,6 +117,12 @@ __device__ __forceinline__ void gen_pipelined(int n, LB loadb, BD body) {
   }
 }
 
+// dv element (sample ms, column c = plane * C + channel): row-major [M][ldv], or (ldv == 0; C == 48) the tuned scatters' blocked layout
+// [tile of 32 samples][plane * 3 + 16-channel line][sample][16] (include/egonerf_hip.h, ego_shade_backward)
+__device__ __forceinline__ int64_t gen_dv_index(int64_t ms, int c, int ldv) {
+  return ldv ? ms * ldv + c : (ms >> 5) * (32 * 144) + (int64_t)(c >> 4) * 512 + (ms & 31) * 16 + (c & 15);
+}
+
 __device__ __forceinline__ void wave_sync_g() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -571,7 +577,7 @@ __global__ __launch_bounds__(64) void k_shade_generic_bwd(GenBwdArgs A) {
         float s = 0.f;
 #pragma unroll
         for (int f = 0; f < 3; ++f) s = fmaf(g ? b1[f] : b0[f], dfe[f], s);
-        if (valid) A.dv[m * A.ldv + col] = s;
+        if (valid) A.dv[gen_dv_index(m, col, A.ldv)] = s;
       }
       continue;
     }
@@ -737,7 +743,7 @@ __global__ __launch_bounds__(64) void k_shade_generic_bwd(GenBwdArgs A) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int64_t ms = unit * 64 + 32 * mt + 8 * (r >> 2) + 4 * kk + (r & 3);
-            if (c < ncol && (full || ms < A.M)) A.dv[ms * A.ldv + c] = acc[mt][nt][r];
+            if (c < ncol && (full || ms < A.M)) A.dv[gen_dv_index(ms, c, A.ldv)] = acc[mt][nt][r];
           }
       }
     }
@@ -774,7 +780,7 @@ __global__ __launch_bounds__(128) void k_shade_generic_bwd(GenBwdArgs A) {
         float s = 0.f;
 #pragma unroll
         for (int f = 0; f < 3; ++f) s = fmaf(g ? b1[f] : b0[f], dfe[f], s);
-        if (valid) A.dv[m * A.ldv + col] = s;
+        if (valid) A.dv[gen_dv_index(m, col, A.ldv)] = s;
       }
       continue;
     }
@@ -841,7 +847,7 @@ __global__ __launch_bounds__(128) void k_shade_generic_bwd(GenBwdArgs A) {
       float s = 0.f;
 #pragma unroll
       for (int f = 0; f < 32; ++f) s = fmaf(g ? b1[f] : b0[f], dfe[f], s);
-      if (valid) A.dv[m * A.ldv + col] = s;
+      if (valid) A.dv[gen_dv_index(m, col, A.ldv)] = s;
     }
   }
 }
@@ -1188,7 +1194,8 @@ int ego_shade_backward_generic(const ego_scene* sc, const float* coords, float* 
   if (N == 0) return EGO_OK;
   if (int e = check_generic_shape(sc, "shade_backward_generic", false, true)) return e;
   EGO_REQUIRE(coords && dc && dfe64 && dv && (sc->head == EGO_HEAD_RGB || (rgb && x && h1 && h2 && dh2 && dh1)), "shade_backward_generic: null argument");
-  EGO_REQUIRE(ldx >= sc->mlp_in && ldh >= sc->mlp_hidden && ldv >= 3 * sc->app.n_comp, "shade_backward_generic: leading dimensions too small");
+  EGO_REQUIRE(ldx >= sc->mlp_in && ldh >= sc->mlp_hidden && (ldv >= 3 * sc->app.n_comp || (ldv == 0 && sc->app.n_comp == 48)),
+              "shade_backward_generic: leading dimensions too small (ldv == 0 = the blocked dv of the tuned scatters: 48 components only)");
   GenBwdArgs a{};
   a.gp = sc->packed; a.coords = coords; a.dc = dc; a.rgb = rgb; a.x = x; a.h1 = h1; a.h2 = h2; a.dh2 = dh2; a.dh1 = dh1; a.dfe = dfe64; a.dv = dv;
   a.M = N * (int64_t)S; a.app_dim = sc->app_dim; a.n_comp = sc->app.n_comp; a.in_c = sc->mlp_in; a.view_pe = sc->view_pe; a.fea_pe = sc->fea_pe;

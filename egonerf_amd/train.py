@@ -161,6 +161,13 @@ def head_is_tuned(model) -> bool:
     return model.head_is_tuned
 
 
+def _generic_head_sorted_app(model, sort_ws, M: int) -> bool:
+    """A head of another shape over 48-component appearance tables: ego_shade_backward_generic writes the blocked dv and the sorted walk
+    scatters it (the step's sort exists whenever the density field has its tuned shape)."""
+    return (sort_ws is not None and model.app_n_comp[0] == 48 and __import__("os").environ.get("EGO_SORTED_WALK", "1") != "0"
+            and (M + 31) // 32 * 32 * 144 < 2 ** 30)
+
+
 def differentiable_params(model) -> List[torch.nn.Parameter]:
     """Fixed order: 12 density tables, 12 appearance tables, basis yin/yang, mlp (w0,b0,w1,b1,w2,b2)."""
     head = [model.basis_mat_yin.weight, model.basis_mat_yang.weight]
@@ -310,7 +317,7 @@ class RenderFunction(torch.autograd.Function):
         dens, app = table_params(model, "density"), table_params(model, "app")
         # keeps the channel-last strides of the parameters; the sorted scatters store every texel, the atomic ones add into zeros
         sorted_dens = ctx.sort_ws is not None and model.density_n_comp[0] == 16
-        sorted_app = ctx.sort_ws is not None and ctx.head_tuned
+        sorted_app = ctx.sort_ws is not None and (ctx.head_tuned or _generic_head_sorted_app(model, ctx.sort_ws, N * S))
         g_dens, g_app = _zeros_like_many(dens, zero=not sorted_dens), _zeros_like_many(app, zero=not sorted_app)
         for p, g in zip(dens + app, g_dens + g_app):
             assert g.stride() == p.stride()
@@ -429,13 +436,22 @@ class RenderFunction(torch.autograd.Function):
         hid, in_c, ncol, D = model.head_hidden, model.head_in_mlpC, 3 * model.app_n_comp[0], model.app_dim
         rgb_head = model.shadingMode == "RGB"
         ldx = _G_LD if rgb_head else sv["x"].shape[1]
-        dh2, dh1, dfe, dv = (None if rgb_head else f(M, hid)), (None if rgb_head else f(M, hid)), f(M, 64), f(M, _G_LD)
+        # another head over the SHIPPED table shape: dv in the tuned scatters' blocked layout, and the sorted walk takes the table gradients
+        # (deterministic, 0.75 ms where the any-shape atomic scatter takes 9.8)
+        ws = ctx.sort_ws
+        app_sorted = _generic_head_sorted_app(model, ws, M)
+        dh2, dh1, dfe = (None if rgb_head else f(M, hid)), (None if rgb_head else f(M, hid)), f(M, 64)
+        dv = f((M + 31) // 32 * 32, 144) if app_sorted else f(M, _G_LD)
         _chk(lib.ego_shade_backward_generic(sc, sv["coords"].data_ptr(), dc.data_ptr(), sv["rgb"].data_ptr(), _lib.ptr(sv["x"]), ldx,
                                             _lib.ptr(sv["h1"]), _lib.ptr(sv["h2"]), _G_LD, _lib.ptr(dh2), _lib.ptr(dh1), dfe.data_ptr(),
-                                            dv.data_ptr(), _G_LD, N, S, st), "ego_shade_backward_generic")
+                                            dv.data_ptr(), 0 if app_sorted else _G_LD, N, S, st), "ego_shade_backward_generic")
         ga = _grad_struct(g_app)
-        on_side(lambda s_: _chk(lib.ego_scatter_generic(C.byref(sc.app), C.byref(ga), sv["coords"].data_ptr(), dv.data_ptr(), _G_LD, N, S, s_),
-                                "ego_scatter_generic(app)"))
+        if app_sorted:
+            on_side(lambda s_: _chk(lib.ego_scatter_app_sorted(sc, C.byref(ga), sv["coords"].data_ptr(), dv.data_ptr(), None, None, None, 0, N, S,
+                                                               ws.data_ptr(), ws.numel(), s_), "ego_scatter_app_sorted(generic head)"))
+        else:
+            on_side(lambda s_: _chk(lib.ego_scatter_generic(C.byref(sc.app), C.byref(ga), sv["coords"].data_ptr(), dv.data_ptr(), _G_LD, N, S, s_),
+                                    "ego_scatter_generic(app)"))
         hp = (hid + 31) // 32 * 32
         n_chunks = ldx // _G_LD
 

@@ -445,7 +445,9 @@ int ego_shade_train_generic(const ego_scene* sc, const float* rays, const float*
                             float* h1, float* h2, int32_t ldh, float* v, int32_t ldv, void* stream);
 /* dc [M][3] in = dL/d rgb_sample, out = dL/d(pre-sigmoid).  Writes dh2, dh1 [M][mlp_hidden], dfe64 [M][64] (the feature gradients of
  * the sample's own grid g in columns [32 g, 32 g + 32), zeros in the other half: dfe64^T v gives both basis gradients in one
- * product) and dv [M][ldv] = dL/d(plane x line products). */
+ * product) and dv [M][ldv] = dL/d(plane x line products).  ldv == 0 (48 appearance components only): dv in ego_shade_backward's blocked layout
+ * ([ceil(M / 32)][9][32][16] floats), so that the tuned scatters (ego_scatter_app_sorted / ego_scatter_app) serve a model whose HEAD has
+ * another shape but whose tables have the shipped one. */
 int ego_shade_backward_generic(const ego_scene* sc, const float* coords, float* dc, const float* rgb, const float* x, int32_t ldx, const float* h1,
                                const float* h2, int32_t ldh, float* dh2, float* dh1, float* dfe64, float* dv, int32_t ldv, int64_t N, int32_t S,
                                void* stream);
