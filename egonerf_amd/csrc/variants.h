@@ -30,3 +30,8 @@
 // waves into device counters, per wave the busy time, steps and iterations (ego_debug_walk_prof / ego_debug_walk_waves, read by
 // tools/sorted_probe.py with PROBE_PROF=1 on a tools/build_variant.sh build).  It is how round 6 found that the first walk's slowest
 // wave took 3.5 x the mean (chunks of cells dealt by count) and that the 48-channel walk is bound by VALU issue, not by its gathers.
+
+// EGO_GENERIC_MFMA (ego_generic.hip, default 1): 1 = the any-shape head (basis, both hidden layers, the backward chain) runs on the matrix
+// pipe in fp32 (v_mfma_f32_32x32x2_f32 over slab-staged inputs); 0 = the lane = sample form of rounds 2-5 (every FMA with an SGPR weight
+// operand, one wave per SIMD: 5-10 % of the fp32 rate) - kept as the plain restatement of the reference's op order to hold the MFMA form
+// against (NOTEBOOK 10.7: inference 18 -> 2.4 ms, training 50 -> 15.5 ms on the MLP-head shape).

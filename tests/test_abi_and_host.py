@@ -317,13 +317,13 @@ def test_isa_guard_sees_the_faulty_form(tmp_path):
     assert open(build.LIB + ".hash").read().strip() == build.source_hash()
 
 
-@pytest.mark.parametrize("flags", [["-DEGO_GATHER_TEAMS=0"], ["-DEGO_PAIRED_WEIGHTS"], ["-DEGO_WALK_PROF"]])
+@pytest.mark.parametrize("flags", [["-DEGO_GATHER_TEAMS=0"], ["-DEGO_PAIRED_WEIGHTS"], ["-DEGO_WALK_PROF"], ["-DEGO_GENERIC_MFMA=0"]])
 def test_kept_variants_compile(tmp_path, flags):
     """csrc/variants.h lists the compile-time variants kept on purpose (the section-5.1 reproducer forms); each must keep
     compiling for gfx950 next to the default build.  Everything else that was tried is recorded in DESIGN.md, not in #ifdefs."""
     import os, re, subprocess
     from egonerf_amd import build
-    name = "ego_scatter_sorted.hip" if "WALK" in flags[0] else "ego_shade.hip"
+    name = "ego_scatter_sorted.hip" if "WALK" in flags[0] else "ego_generic.hip" if "GENERIC" in flags[0] else "ego_shade.hip"
     src = os.path.join(build.CSRC, name)
     macros = set(re.findall(r"\bEGO_[A-Z_]+\b", open(os.path.join(build.CSRC, "variants.h")).read()))
     assert flags[0][2:].split("=")[0] in macros

@@ -51,7 +51,10 @@ def test_packed_size_follows_the_shape():
     assert lib.ego_packed_floats_scene(ctypes.byref(sc)) == lib.ego_packed_floats()
     sc.mlp_hidden, sc.app.n_comp = 64, 24
     in_c, hid, C = 150, 64, 24
-    assert lib.ego_packed_floats_scene(ctypes.byref(sc)) == in_c * hid + hid + hid * hid + hid + 3 * hid + 4 + 2 * 3 * C * 32
+    # W1T | b1 | W2T | b2 | W3 | b3 (4) | basisT [2][3 C][32], then (r06: the B operands of the backward's products on the matrix pipe) the
+    # same matrices in natural order: W1 | W2 | basis [2][32][3 C]
+    assert lib.ego_packed_floats_scene(ctypes.byref(sc)) == (in_c * hid + hid + hid * hid + hid + 3 * hid + 4 + 2 * 3 * C * 32
+                                                             + hid * in_c + hid * hid + 2 * 32 * 3 * C)
     assert lib.ego_packed_floats_scene(None) == -1
 
 
