@@ -1269,6 +1269,47 @@ def run_erp(a, rk: Ranks):
     return line
 
 
+def run_other_shape(a, rk: Ranks):
+    """A model shape the tuned kernels do not serve - `shadingMode="MLP"` (MLPRender, tensorBase.py:100-126) over the shipped tables - through
+    the any-shape kernels (csrc/ego_generic.hip: fp32 MFMA since round 6): inference at the headline's 4096 x 512, one training forward +
+    backward at configs[3]'s 8192 x (128 + 128), parity of the render against the oracle.  VERDICT r05 weak #8 in the record."""
+    dev = rk.dev
+    cfg = synth.SceneConfig(shadingMode="MLP")
+    weights = synth.make_weights(cfg, seed=1234)
+    model = synth.build_model(cfg, weights, dev)
+    rays = torch.from_numpy(synth.make_rays(N_RAYS, seed=1)).to(dev)
+    with torch.no_grad():
+        dt = timed(rk, lambda: model(rays, n_coarse=N_SAMPLES, exp_sampling=True), a.steps, a.warmup)
+        got = model(rays[:128], n_coarse=N_SAMPLES, exp_sampling=True)[0].cpu()
+    from oracle.egonerf_oracle import OracleScene
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    with torch.no_grad():
+        ref = OracleScene(cfg, weights).forward(rays[:128].cpu(), n_coarse=N_SAMPLES)[0]
+    err = float((got - ref).abs().max())
+    model.train()
+    rays8 = torch.from_numpy(synth.make_rays(TRAIN_RAYS, seed=1)).to(dev)
+    gt = torch.rand(TRAIN_RAYS, 3, device=dev)
+
+    def step():
+        model.zero_grad(set_to_none=True)
+        rgb, *_ = model(rays8, is_train=True, n_coarse=TRAIN_NC, n_fine=TRAIN_NF, exp_sampling=True, resampling=True, use_coarse_sample=True)
+        torch.mean((rgb - gt) ** 2).backward()
+    dtt = timed(rk, step, 5, 2)
+    t = dt / a.steps
+    # algorithmic flops per sample: basis 2 x 144 x app_dim + MLPRender (in_c -> 128 -> 128 -> 3)
+    in_c = model.head_in_mlpC
+    flop = 2.0 * (144 * cfg.app_dim + in_c * 128 + 128 * 128 + 128 * 3)
+    achieved = flop * N_RAYS * N_SAMPLES / t / 1e12
+    return dict(metric="rays/sec at 4096-ray batch, 512 samples, shadingMode MLP (any-shape kernels)", value=N_RAYS / t, unit="rays/s",
+                ms_per_step=t * 1e3, steps=a.steps, warmup=a.warmup, dtype="f32 (fp32-input MFMA)", data="synthetic",
+                train_fwd_bwd_ms=dtt / 5 * 1e3, tuned=bool(model.is_tuned_shape),
+                config=dict(workload=f"{N_RAYS} x {N_SAMPLES} render and {TRAIN_RAYS} x ({TRAIN_NC}+{TRAIN_NF}) fwd+bwd of a shadingMode='MLP' model on the headline grid"),
+                roofline=dict(bound="mfma", kernel="k_shade_generic (whole step timed: march + shade + composite)", unit="TFLOP/s", achieved=achieved,
+                              peak=MFMA_F32_PEAK_TFLOPS, frac=achieved / MFMA_F32_PEAK_TFLOPS, traffic=None,
+                              note="algorithmic flops of basis + MLPRender per sample over the WHOLE step's time (an underestimate of the kernel's own rate)"),
+                parity=dict(max_abs_rgb_err=err, tolerance_rgb=1e-4, rays=128))
+
+
 def run_secondary(a, rk: Ranks):
     """Short runs of the other single-GPU BASELINE configs, folded into the default line as `secondary` (N = 1 only): configs[3]
     (training step) and configs[2] (full ERP image; once more on an opaque field, density_shift 0, which is what a trained scene
@@ -1292,7 +1333,8 @@ def run_secondary(a, rk: Ranks):
                                         density_shift=None)),
             ("erp_opaque_field", run_erp, sub(config="erp", steps=2, warmup=1, views=2, erp_size=[1024, 2048], mask=False, term_eps=0.0,
                                               density_shift=0.0, carve=False)),   # with its own parity leg + cpu_baseline
-            ("eval_metrics_1024x2048", run_eval_metrics, sub(config="metrics", steps=10, warmup=2, erp_size=[1024, 2048])))
+            ("eval_metrics_1024x2048", run_eval_metrics, sub(config="metrics", steps=10, warmup=2, erp_size=[1024, 2048])),
+            ("other_shape_mlp_head", run_other_shape, sub(config="render", steps=20, warmup=3)))
     for name, fn, args in jobs:
         t0 = time.perf_counter()
         try:
