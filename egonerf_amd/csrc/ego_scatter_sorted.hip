@@ -1241,7 +1241,9 @@ __device__ __forceinline__ void sorted_walk(const FusedArgs& F, const int gb, co
   const float* __restrict__ L = g ? A.F.line[1][I] : A.F.line[0][I];
   const float* __restrict__ Dv = A.d;
   // (BYTE offsets: `base + zext(u32)` is what selects the scalar-base form of global_load; an element index would need a 64-bit shift)
-  auto at = [](const float* base, uint32_t byte_off) -> float { return *(const float*)((const char*)base + byte_off); };
+  // (`imm`: a constant added in 64 bits, behind the zero-extension - it lands in the instruction's offset field; added to the 32-bit offset it
+  // cost a VALU add per load, because that sum may wrap where the address must not)
+  auto at = [](const float* base, uint32_t byte_off, int imm = 0) -> float { return *(const float*)((const char*)base + byte_off + imm); };
   const int nmin1 = A.F.res[sort_minor(S_)] + 1;
   const double magic = F.fx->magic[I];
   const uint32_t magic_hi = (uint32_t)((unsigned long long)__double_as_longlong(magic) >> 32);
@@ -1376,7 +1378,7 @@ __device__ __forceinline__ void sorted_walk(const FusedArgs& F, const int gb, co
           tL0[u] = R.f[10][tt]; tL1[u] = R.f[11][tt];
           const uint32_t oL0 = R.f[5][tt] + (uint32_t)c16 * 4u, oL1 = R.f[6][tt] + (uint32_t)c16 * 4u;
 #pragma unroll
-          for (int i = 0; i < NL; ++i) { l0[u][i] = at(L, oL0 + 64u * i); l1[u][i] = at(L, oL1 + 64u * i); }
+          for (int i = 0; i < NL; ++i) { l0[u][i] = at(L, oL0, 64 * i); l1[u][i] = at(L, oL1, 64 * i); }
           if (DENS) {
             di[u][0] = __uint_as_float(R.f[9][tt]);
           } else {
@@ -1384,11 +1386,11 @@ __device__ __forceinline__ void sorted_walk(const FusedArgs& F, const int gb, co
             if constexpr (!RDV) {
               const uint32_t od = ((m >> 5) * (uint32_t)(32 * 3 * C) + (uint32_t)(I * NL) * 512u + (m & 31u) * 16u + (uint32_t)c16) * 4u;
 #pragma unroll
-              for (int i = 0; i < NL; ++i) di[u][i] = at(Dv, od + 2048u * i);
+              for (int i = 0; i < NL; ++i) di[u][i] = at(Dv, od, 2048 * i);
             }
             if constexpr (BAS) {
               const uint32_t of = (m * 32u + (uint32_t)c16) * 4u;
-              fa[0][u] = at(F.dfe, of); fa[1][u] = at(F.dfe, of + 64u);
+              fa[0][u] = at(F.dfe, of); fa[1][u] = at(F.dfe, of, 64);
             }
           }
         }
