@@ -3,7 +3,9 @@ import os, sys, torch, numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from egonerf_amd import synth
 dev="cuda"
-cfg = synth.SceneConfig(shadingMode="MLP")
+SHAPES = {"mlp": dict(shadingMode="MLP"), "small": dict(density_n_comp=(8, 8, 8), app_n_comp=(24, 24, 24), featureC=64),
+          "enc66": dict(view_pe=6, fea_pe=6, app_dim=12)}
+cfg = synth.SceneConfig(**SHAPES[os.environ.get("GEN_SHAPE", "mlp")])
 model = synth.build_model(cfg, synth.make_weights(cfg, seed=1234), dev)
 model.train()
 rays8 = torch.from_numpy(synth.make_rays(8192, seed=1)).to(dev); gt = torch.rand(8192, 3, device=dev)
