@@ -111,7 +111,9 @@ __device__ __forceinline__ void gen_pipelined(int n, LB loadb, BD body) {
         for (int e = 0; e < NB; ++e) b[e] = bq[p][e];
         const int nx = it + PF;
         loadb(nx < n ? nx : n - 1, bq[p]);
+        __builtin_amdgcn_sched_barrier(0);   // (the machine scheduler sinks the loads back to their uses otherwise: `s_waitcnt vmcnt(0)` at the loop's top)
         body(it, b);
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
   }
