@@ -1001,10 +1001,11 @@ def run_train(a, rk: Ranks):
     M = N * (TRAIN_NC + TRAIN_NF)
     # (bytes per fine sample as the kernels exchange them in round 6: h1 / h2 / dh1 / dh2 as halves, ReLU masks as bits, 27 feature slots
     # in 32 floats, dv fp32; the x dump is gone since r05, the scatter reads dv ONCE since r06)
-    # r06, late: v is not dumped any more - d(basis) rides along in the appearance scatter's walk, which reads dfe (128 B) once per sort
+    # r06, late: v is not dumped any more - d(basis) rides along in the appearance scatter's walk, which reads dfe (128 B) once per sort -
+    # and dv is not written any more either: the walk re-derives it from those 128 B
     design = dict(forward_dumps_written=(256 + 256 + 32 + 128) * M, shade_bwd_read=(128 + 32 + 16 + 12 + 12) * M,
-                  shade_bwd_written=(256 + 256 + 128 + 576 + 8) * M, wgrad_read=((256 + 256) + (256 + 128) + (12 + 256)) * M,
-                  scatter_read=(576 + 3 * 128 + 4 + 6 * (16 + 4)) * M + 3 * 2 * 16 * (M // 13), adam=24_721_123 * 28)
+                  shade_bwd_written=(256 + 256 + 128 + 8) * M, wgrad_read=((256 + 256) + (256 + 128) + (12 + 256)) * M,
+                  scatter_read=(3 * 128 + 4 + 6 * (16 + 4)) * M + 3 * 2 * 16 * (M // 13), adam=24_721_123 * 28)
     design_total = float(sum(design.values()))
     pmc, src, stale = load_pmc_section("train_step")
     traffic = None if pmc is None else pmc.get("traffic_bytes")
