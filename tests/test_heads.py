@@ -125,3 +125,51 @@ def test_training_gradients_of_the_other_heads_vs_reference_autograd(golden, nam
         assert float(np.abs(g - ref).max()) <= 2e-4 * max(float(np.abs(ref).max()), 1e-12), k
     from egonerf_amd.optim import FusedAdam
     FusedAdam(model.get_optparam_groups(0.02, 1e-3), betas=(0.9, 0.99)).step()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["mlp_head", "rgb_head"])
+def test_other_heads_over_the_shipped_tables_take_the_sorted_scatter(name, monkeypatch):
+    """Round 6: a head of another shape over 48-component appearance tables has ego_shade_backward_generic write `dv` in the tuned scatters'
+    blocked layout (ldv = 0) and ego_scatter_app_sorted walk it - deterministic, and 13 x faster than the any-shape atomics at 8192 x 256.
+    Same gradients as the row-major `dv` + ego_scatter_generic route (EGO_SORTED_WALK=0) up to the order of the float sums, the same bits
+    twice, and the table gradients of a model whose tables are NOT 48-wide still arrive (through the atomics)."""
+    from egonerf_amd import train
+    cfg = synth.SceneConfig(n_voxel=24 ** 3, **HEADS[name])
+    weights = synth.make_weights(cfg, seed=5)
+    rays = T(synth.make_rays(300, seed=6)).cuda()
+    g = torch.Generator().manual_seed(7)
+    jit, u, gt = torch.rand(300, 16, generator=g).cuda(), torch.rand(300, 16, generator=g).cuda(), torch.rand(300, 3, generator=g).cuda()
+
+    def grads():
+        model = make_model(cfg, weights, "cuda")
+        model.train()
+        rgb = model(rays, is_train=True, exp_sampling=True, use_coarse_sample=True, jitter=jit, u=u, **TRAIN_KW)[0]
+        torch.mean((rgb - gt) ** 2).backward()
+        return {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
+
+    assert train._generic_head_sorted_app(make_model(cfg, weights, "cuda"), object(), 300 * 32)
+    a, b = grads(), grads()
+    for k in a:
+        assert torch.equal(a[k], b[k]), ("sorted route, run to run", k)
+    monkeypatch.setenv("EGO_SORTED_WALK", "0")
+    assert not train._generic_head_sorted_app(make_model(cfg, weights, "cuda"), object(), 300 * 32)
+    c = grads()
+    assert sorted(a) == sorted(c)
+    for k in a:
+        scale = max(float(c[k].abs().max()), 1e-12)
+        assert float((a[k] - c[k]).abs().max()) <= 2e-5 * scale, (k, float((a[k] - c[k]).abs().max()) / scale)
+
+
+@pytest.mark.gpu
+def test_blocked_dv_is_refused_for_other_table_widths():
+    """ego_shade_backward_generic(ldv = 0) is the 48-component blocked layout: a 24-component model must be refused, not mis-indexed."""
+    import ctypes as C
+    from egonerf_amd import _lib
+    cfg = _cfg("mlp_head_small")
+    model = make_model(cfg, synth.make_weights(cfg, seed=5), "cuda")
+    sc = model.scene(training=True)
+    buf = torch.zeros(64 * 160, device="cuda")
+    p = buf.data_ptr()
+    rc = _lib.load().ego_shade_backward_generic(sc, p, p, p, p, 160, p, p, 160, p, p, p, p, 0, 2, 16, _lib.stream_handle())
+    assert rc != 0 and b"blocked" in _lib.load().ego_last_error()
