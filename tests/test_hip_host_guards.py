@@ -199,3 +199,35 @@ def test_volume_renderer_host_hand_over_equals_the_resident_path(where):
             assert (got[4] is None) == (not keep_alpha)
         empty = volume_renderer(rays[:0], model, empty_gpu_cache=True, **kw)
         assert empty[0].shape == (0, 3) and empty[1].shape == (0,)
+
+
+def test_marched_event_is_recorded_on_every_path():
+    """ABI v17 ego_render_args.marched / EgoNeRF.forward(marched_event=ev): the event is recorded behind the call's last march (render path)
+    or at the end of a call that has no march of its own (an empty batch, the envmap pre-training branch, a differentiable call) - a
+    stream that waits for it must never wait for a record that does not come - and passing it changes no output bit."""
+    cfg = synth.SceneConfig(n_voxel=24 ** 3, use_envmap=True, envmap_res_H=16)
+    model = make_model(cfg, synth.make_weights(cfg, seed=79), "cuda")
+    rays = torch.from_numpy(synth.make_rays(200, seed=11)).cuda()
+    kw = dict(n_coarse=32, n_fine=32, resampling=True, exp_sampling=True)
+    other = torch.cuda.Stream()
+    with torch.no_grad():
+        want = model(rays, **kw)
+        for r, extra in ((rays, {}), (rays[:0], {}), (rays, dict(pretrain_envmap=True))):
+            ev = torch.cuda.Event()
+            ev.record()   # (creates the underlying event: the library records it by handle)
+            torch.cuda.synchronize()
+            got = model(r, marched_event=ev, **kw, **extra)
+            other.wait_event(ev)
+            other.synchronize()   # returns: the wait found a record to wait for
+            assert ev.query()
+            if r.shape[0] and not extra:
+                for a_, b_ in zip(want, got):
+                    assert (a_ is None) == (b_ is None) and (a_ is None or torch.equal(a_, b_))
+    model.train()
+    ev = torch.cuda.Event()
+    ev.record()
+    rgb = model(rays, is_train=True, marched_event=ev, **kw)[0]
+    assert rgb.requires_grad
+    other.wait_event(ev)
+    other.synchronize()
+    assert ev.query()
